@@ -1,0 +1,360 @@
+// mzk_field.h -- prime-field arithmetic for the MyZKP prover hot path on gfx950.
+//
+// Replaces, on the device, the BigInt-backed FiniteFieldElement<M> of the reference
+// (myzkp/src/modules/algebra/field.rs:87-133 type, :157-207 Ring impl, :209-279 Field impl) for the
+// three moduli on the path: Fr = ModEIP197 (field.rs:428-431), Fq = BN128Modulus
+// (curve/bn128.rs:19-22), M128 (zkstark/fri.rs:408).
+//
+// Representation: unsaturated 29-bit limbs (L = 9 for the 254-bit fields, 5 for M128), Montgomery
+// radix R = 2^(29 L).  Why 29 bits: on gfx950 v_mad_u64_u32 (32x32+64 -> 64) issues at half rate and
+// takes its 64-bit addend for free, so a product-scanning column sum  col += a_i * b_j  costs exactly
+// one instruction and no carry handling as long as a column never exceeds 64 bits; 18 terms of
+// 29x29 bits do not.  Measured on MI355X (profiles/r01_ubench_instr_rates.txt, scratch/mm29.hip):
+// 154 G Montgomery mul/s in this form vs 93 G/s for saturated 8x32 CIOS (carry chains: 300 v_mov +
+// 138 v_lshl_add_u64 per product).
+//
+// The header is plain C++ so that the same code compiles with g++ for the bounds-checked host unit
+// tests (tests/hostcheck); the shipped library only instantiates it inside HIP kernels.
+//
+// Invariants (checked in host builds with -DMZK_CHECK_BOUNDS):
+//   normalised  : l[i] < 2^29 for i < L-1 (top limb free).
+//   fe_mul(a,b) : needs max_limb(a) * max_limb(b) * L + L * 2^58 < 2^64  (e.g. both < 2^30, or
+//                 2^30.6 x 2^29); returns a normalised value  < a*b/R + p.
+//   Values are only ever compared after fe_reduce() (canonical representative in [0,p)), which is
+//   the reference's own parity definition (sanitize(), field.rs:260-270; PartialEq field.rs:290-294).
+#pragma once
+#include <stdint.h>
+#include "mzk_constants.h"
+
+#if defined(__HIPCC__)
+#define MZK_HD __host__ __device__ __forceinline__
+#else
+#define MZK_HD inline
+#endif
+
+#if defined(MZK_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+#include <assert.h>
+#define MZK_ASSERT(x) assert(x)
+#else
+#define MZK_ASSERT(x) ((void)0)
+#endif
+
+namespace mzk {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+
+constexpr int W29 = 29;
+constexpr u32 MASK29 = (1u << 29) - 1u;
+
+template <class P> struct Fe { u32 l[P::L]; };
+
+template <class P> MZK_HD Fe<P> fe_zero() {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) r.l[i] = 0;
+  return r;
+}
+// Montgomery form of 1.
+template <class P> MZK_HD Fe<P> fe_one() {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) r.l[i] = P::ONE[i];
+  return r;
+}
+template <class P> MZK_HD Fe<P> fe_r2() {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) r.l[i] = P::R2[i];
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Montgomery product  a*b/R mod p  (finely integrated product scanning, one 64-bit column
+// accumulator).  Reference semantics: Ring::mul_ref, field.rs:176-179 (value * value % modulus).
+// ---------------------------------------------------------------------------------------------
+template <class P> MZK_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+  constexpr int L = P::L;
+  u32 m[L];
+  Fe<P> r;
+  u64 col = 0;
+#if defined(MZK_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+  {  // the widest column must fit 64 bits
+    unsigned __int128 worst = 0;
+    u64 ma = 0, mb = 0;
+    for (int i = 0; i < L; i++) { if (a.l[i] > ma) ma = a.l[i]; if (b.l[i] > mb) mb = b.l[i]; }
+    worst = (unsigned __int128)ma * mb * L + (unsigned __int128)L * ((u64)MASK29 * MASK29) + ((u64)1 << 36);
+    assert(worst < ((unsigned __int128)1 << 64));
+  }
+#endif
+#pragma unroll
+  for (int k = 0; k < L; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) col += (u64)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = 0; i < k; i++) col += (u64)m[i] * P::P[k - i];
+    m[k] = ((u32)col * P::N0) & MASK29;
+    col += (u64)m[k] * P::P[0];
+    col >>= W29;
+  }
+#pragma unroll
+  for (int k = L; k < 2 * L - 1; k++) {
+#pragma unroll
+    for (int i = k - L + 1; i < L; i++) col += (u64)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = k - L + 1; i < L; i++) col += (u64)m[i] * P::P[k - i];
+    r.l[k - L] = (u32)col & MASK29;
+    col >>= W29;
+  }
+  MZK_ASSERT(col < ((u64)1 << 32));
+  r.l[L - 1] = (u32)col;
+  return r;
+}
+
+// Montgomery square: cross products once, doubled (45 instead of 81 product terms for L = 9).
+template <class P> MZK_HD Fe<P> fe_sqr(const Fe<P>& a) {
+  constexpr int L = P::L;
+  u32 m[L], a2[L];
+  Fe<P> r;
+  u64 col = 0;
+#pragma unroll
+  for (int i = 0; i < L; i++) a2[i] = a.l[i] << 1;
+#if defined(MZK_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+  {
+    u64 ma = 0;
+    for (int i = 0; i < L; i++) { assert(a.l[i] < (1u << 31)); if (a.l[i] > ma) ma = a.l[i]; }
+    unsigned __int128 worst = (unsigned __int128)ma * ma * L + (unsigned __int128)L * ((u64)MASK29 * MASK29) + ((u64)1 << 36);
+    assert(worst < ((unsigned __int128)1 << 64));
+  }
+#endif
+#pragma unroll
+  for (int k = 0; k < L; k++) {
+#pragma unroll
+    for (int i = 0; 2 * i < k; i++) col += (u64)a2[i] * a.l[k - i];
+    if ((k & 1) == 0) col += (u64)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+    for (int i = 0; i < k; i++) col += (u64)m[i] * P::P[k - i];
+    m[k] = ((u32)col * P::N0) & MASK29;
+    col += (u64)m[k] * P::P[0];
+    col >>= W29;
+  }
+#pragma unroll
+  for (int k = L; k < 2 * L - 1; k++) {
+#pragma unroll
+    for (int i = k - L + 1; 2 * i < k; i++) col += (u64)a2[i] * a.l[k - i];
+    if ((k & 1) == 0) col += (u64)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+    for (int i = k - L + 1; i < L; i++) col += (u64)m[i] * P::P[k - i];
+    r.l[k - L] = (u32)col & MASK29;
+    col >>= W29;
+  }
+  MZK_ASSERT(col < ((u64)1 << 32));
+  r.l[L - 1] = (u32)col;
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lazy additive ops: limb-wise, no carry propagation, no modular reduction.
+// ---------------------------------------------------------------------------------------------
+template <class P> MZK_HD Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) {
+    MZK_ASSERT((u64)a.l[i] + b.l[i] < ((u64)1 << 32));
+    r.l[i] = a.l[i] + b.l[i];
+  }
+  return r;
+}
+// a - b + K p  (K in {2,4,8,16}); b must be normalised with value < (K/2) p.
+template <class P, int K> MZK_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) {
+    const u32 c = (K == 2) ? P::KP2[i] : (K == 4) ? P::KP4[i] : (K == 8) ? P::KP8[i] : P::KP16[i];
+    MZK_ASSERT(c >= b.l[i]);
+    MZK_ASSERT((u64)a.l[i] + (c - b.l[i]) < ((u64)1 << 32));
+    r.l[i] = a.l[i] + (c - b.l[i]);
+  }
+  return r;
+}
+template <class P> MZK_HD Fe<P> fe_dbl(const Fe<P>& a) {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) {
+    MZK_ASSERT(a.l[i] < (1u << 31));
+    r.l[i] = a.l[i] << 1;
+  }
+  return r;
+}
+// Carry propagation: any limbs -> normalised limbs, same value.
+template <class P> MZK_HD Fe<P> fe_carry(const Fe<P>& a) {
+  Fe<P> r;
+  u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < P::L - 1; i++) {
+    MZK_ASSERT((u64)a.l[i] + c < ((u64)1 << 32));
+    u32 v = a.l[i] + c;
+    r.l[i] = v & MASK29;
+    c = v >> W29;
+  }
+  MZK_ASSERT((u64)a.l[P::L - 1] + c < ((u64)1 << 32));
+  r.l[P::L - 1] = a.l[P::L - 1] + c;
+  return r;
+}
+
+// x - p if that is >= 0, else x.  x must be normalised.
+template <class P> MZK_HD Fe<P> fe_cond_sub_p(const Fe<P>& x) {
+  constexpr int L = P::L;
+  Fe<P> d;
+  i32 c = 0;
+#pragma unroll
+  for (int i = 0; i < L - 1; i++) {
+    i32 v = (i32)x.l[i] - (i32)P::P[i] + c;
+    d.l[i] = (u32)v & MASK29;
+    c = v >> W29;  // arithmetic: 0 or -1
+  }
+  i32 top = (i32)x.l[L - 1] - (i32)P::P[L - 1] + c;
+  d.l[L - 1] = (u32)top;
+  const bool neg = top < 0;
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < L; i++) r.l[i] = neg ? x.l[i] : d.l[i];
+  return r;
+}
+
+// Canonical representative in [0, p).  Accepts any limbs whose carried top limb stays below
+// P::TOPMAX (every value the kernels produce is far below that).  Mirrors Field::sanitize
+// (field.rs:260-270).  Quotient estimate q = floor(top * QM / 2^QS) <= floor(top / (Ptop+1))
+// <= floor(x / p), and q >= floor(x / p) - 2, so two conditional subtractions finish.
+template <class P> MZK_HD Fe<P> fe_reduce(const Fe<P>& a) {
+  constexpr int L = P::L;
+  Fe<P> x = fe_carry<P>(a);
+  MZK_ASSERT(x.l[L - 1] < P::TOPMAX);
+  const u32 q = (u32)(((u64)x.l[L - 1] * P::QM) >> P::QS);
+  // Q = q * p as normalised limbs, then x - Q with a signed borrow chain (x >= Q).
+  u64 acc = 0;
+  i32 c = 0;
+#pragma unroll
+  for (int i = 0; i < L - 1; i++) {
+    acc += (u64)q * P::P[i];
+    i32 v = (i32)x.l[i] - (i32)((u32)acc & MASK29) + c;
+    x.l[i] = (u32)v & MASK29;
+    c = v >> W29;
+    acc >>= W29;
+  }
+  acc += (u64)q * P::P[L - 1];
+  {
+    int64_t v = (int64_t)x.l[L - 1] - (int64_t)acc + c;
+    MZK_ASSERT(v >= 0 && v < ((int64_t)1 << 31));
+    x.l[L - 1] = (u32)v;
+  }
+  x = fe_cond_sub_p<P>(x);
+  x = fe_cond_sub_p<P>(x);
+  return x;
+}
+
+template <class P> MZK_HD bool fe_is_zero_canon(const Fe<P>& a) {
+  u32 acc = 0;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) acc |= a.l[i];
+  return acc == 0;
+}
+template <class P> MZK_HD bool fe_eq_canon(const Fe<P>& a, const Fe<P>& b) {
+  u32 acc = 0;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) acc |= a.l[i] ^ b.l[i];
+  return acc == 0;
+}
+// value == 0 (mod p) for a lazily reduced value
+template <class P> MZK_HD bool fe_is_zero(const Fe<P>& a) { return fe_is_zero_canon<P>(fe_reduce<P>(a)); }
+
+// -x mod p for canonical x (canonical result).  Ring Neg, field.rs:296-303.
+template <class P> MZK_HD Fe<P> fe_neg_canon(const Fe<P>& x) {
+  constexpr int L = P::L;
+  Fe<P> d;
+  i32 c = 0;
+  u32 nz = 0;
+#pragma unroll
+  for (int i = 0; i < L; i++) nz |= x.l[i];
+#pragma unroll
+  for (int i = 0; i < L - 1; i++) {
+    i32 v = (i32)P::P[i] - (i32)x.l[i] + c;
+    d.l[i] = (u32)v & MASK29;
+    c = v >> W29;
+  }
+  d.l[L - 1] = (u32)((i32)P::P[L - 1] - (i32)x.l[L - 1] + c);
+#pragma unroll
+  for (int i = 0; i < L; i++) d.l[i] = nz ? d.l[i] : 0u;
+  return d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ABI encoding <-> limbs.  The ABI carries canonical values as NW little-endian 32-bit words
+// (= 4 or 2 u64 limbs), the wire format of examples/sumcheck/src/utils.rs:51-72.
+// ---------------------------------------------------------------------------------------------
+template <class P> MZK_HD Fe<P> fe_unpack(const u32* w) {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) {
+    const int o = W29 * i, k = o >> 5, s = o & 31;
+    u32 lo = (k < P::NW) ? w[k] : 0u;
+    u32 hi = (k + 1 < P::NW) ? w[k + 1] : 0u;
+    u32 v = (s == 0) ? lo : ((lo >> s) | (hi << (32 - s)));
+    r.l[i] = (i < P::L - 1) ? (v & MASK29) : v;
+  }
+  // the top limb holds bits [29(L-1), 32 NW): already exact
+  return r;
+}
+// requires normalised limbs and value < 2^(32 NW)
+template <class P> MZK_HD void fe_pack(const Fe<P>& a, u32* w) {
+#pragma unroll
+  for (int k = 0; k < P::NW; k++) {
+    // word k holds bits [32k, 32k+32)
+    const int lo_l = (32 * k) / W29, lo_s = (32 * k) % W29;
+    u64 v = (u64)a.l[lo_l] >> lo_s;
+    int have = W29 - lo_s;
+    if (lo_l + 1 < P::L) v |= (u64)a.l[lo_l + 1] << have;
+    have += W29;
+    if (have < 32 && lo_l + 2 < P::L) v |= (u64)a.l[lo_l + 2] << have;
+    w[k] = (u32)v;
+  }
+}
+
+template <class P> MZK_HD Fe<P> fe_to_mont(const Fe<P>& plain) { return fe_mul<P>(plain, fe_r2<P>()); }
+template <class P> MZK_HD Fe<P> fe_from_mont(const Fe<P>& mont) {
+  Fe<P> one = fe_zero<P>();
+  one.l[0] = 1;
+  return fe_reduce<P>(fe_mul<P>(mont, one));
+}
+
+// a^e for a Montgomery-form a; e given as nw little-endian 32-bit words (MSB-first square-multiply).
+// Reference: Ring::pow -> utils.rs:108-137 (LSB-first; same value).
+template <class P> MZK_HD Fe<P> fe_pow_words(const Fe<P>& a, const u32* e, int nw) {
+  Fe<P> r = fe_one<P>();
+  bool started = false;
+  for (int k = nw - 1; k >= 0; k--) {
+    for (int bit = 31; bit >= 0; bit--) {
+      if (started) r = fe_sqr<P>(r);
+      if ((e[k] >> bit) & 1u) {
+        r = started ? fe_mul<P>(r, a) : a;
+        started = true;
+      }
+    }
+  }
+  return r;
+}
+template <class P> MZK_HD Fe<P> fe_pow_u64(const Fe<P>& a, u64 e) {
+  u32 w[2] = {(u32)e, (u32)(e >> 32)};
+  return fe_pow_words<P>(a, w, 2);
+}
+// Multiplicative inverse by Fermat (a^(p-2)); 0 -> 0.  The reference uses extended Euclid
+// (field.rs:210-237); the value is the same canonical residue.
+template <class P> MZK_HD Fe<P> fe_inv(const Fe<P>& a) {
+  u32 e[P::NW];
+#pragma unroll
+  for (int i = 0; i < P::NW; i++) e[i] = P::PM2[i];
+  return fe_pow_words<P>(a, e, P::NW);
+}
+
+}  // namespace mzk

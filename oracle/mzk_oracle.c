@@ -1,0 +1,990 @@
+/* mzk_oracle.c -- CPU restatement of the MyZKP prover hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle for the HIP kernels.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it; the product library (myzkp_amd/csrc) never links,
+ * includes or calls anything in oracle/.
+ *
+ * The reference (Koukyosyumei/MyZKP, Rust) cannot be built in this environment (no rustc/cargo,
+ * SURVEY.md F5), so this is a from-scratch C restatement of its algorithms, function by function,
+ * each citing the reference lines it follows.  Paths are relative to myzkp/src/modules/.
+ * Arithmetic is on 64-bit limbs with unsigned __int128 (radix-2^64 Montgomery internally); that is a
+ * deliberately different limb size and radix from the device code (29-bit limbs, R = 2^261), so an
+ * arithmetic slip on one side does not cancel on the other.
+ *
+ * Pinning status: pinned against every known-answer test the reference holds for this path
+ * (tests/test_oracle_kats.py: field.rs:491-504,544-550; curve.rs:494-495; bn128.rs:285-301;
+ * rescueprime.rs:606-620; fri.rs:436-438; ntt.rs:346-374; cuda/test_fr.cu:16-42;
+ * cuda/kernels/field.hpp:9-31) and against fixtures produced by an independent Python big-integer
+ * transcription (tests/golden/, generator tests/golden/make_golden.py).
+ *
+ * Two layers:
+ *   orc_*_ref  : literal restatements of the reference's algorithms (recursive NTT with one pow per
+ *                output, affine double-and-add MSM with one inversion per group operation, ...).
+ *   orc_*_fast : CPU implementations of the same functions with better algorithms (iterative NTT,
+ *                Pippenger), validated against the *_ref layer, used to check 2^20..2^24 GPU results
+ *                and as the multi-core "cpu_fast" figure in bench.py.
+ *
+ * Encoding at this API = the library ABI: canonical little-endian u64 limbs (4 for Fr/Fq, 2 for
+ * M128, 1 for the toy field); affine points are x||y, all-zero = point at infinity.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+#define MAXN 4
+
+/* ------------------------------------------------------------------------------------------- */
+/* Field descriptors                                                                            */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int n;          /* 64-bit limbs */
+  u64 p[MAXN];    /* modulus */
+  u64 n0;         /* -p^-1 mod 2^64 */
+  u64 one[MAXN];  /* R mod p */
+  u64 r2[MAXN];   /* R^2 mod p */
+} fld_t;
+
+enum { FID_FR = 0, FID_M128 = 1, FID_FQ = 2, FID_F631 = 3, FID_F17 = 4, FID_F31 = 5, FID_COUNT = 6 };
+static fld_t g_fld[FID_COUNT];
+static int g_init = 0;
+
+static int ge(const u64* a, const u64* b, int n) {
+  for (int i = n - 1; i >= 0; i--) {
+    if (a[i] != b[i]) return a[i] > b[i];
+  }
+  return 1;
+}
+static u64 sub_n(u64* r, const u64* a, const u64* b, int n) {
+  u64 br = 0;
+  for (int i = 0; i < n; i++) {
+    u128 d = (u128)a[i] - b[i] - br;
+    r[i] = (u64)d;
+    br = (u64)(d >> 64) & 1;
+  }
+  return br;
+}
+static u64 add_n(u64* r, const u64* a, const u64* b, int n) {
+  u64 c = 0;
+  for (int i = 0; i < n; i++) {
+    u128 s = (u128)a[i] + b[i] + c;
+    r[i] = (u64)s;
+    c = (u64)(s >> 64);
+  }
+  return c;
+}
+static int is_zero_n(const u64* a, int n) {
+  u64 acc = 0;
+  for (int i = 0; i < n; i++) acc |= a[i];
+  return acc == 0;
+}
+static int eq_n(const u64* a, const u64* b, int n) { return memcmp(a, b, 8 * n) == 0; }
+
+/* (a + b) mod p, inputs < p.  Ring::add_ref, algebra/field.rs:166-169. */
+static void f_add(const fld_t* f, u64* r, const u64* a, const u64* b) {
+  u64 t[MAXN];
+  u64 c = add_n(t, a, b, f->n);
+  if (c || ge(t, f->p, f->n)) sub_n(t, t, f->p, f->n);
+  memcpy(r, t, 8 * f->n);
+}
+/* (a - b) mod p.  Ring::sub_ref, field.rs:171-174 (canonical representative). */
+static void f_sub(const fld_t* f, u64* r, const u64* a, const u64* b) {
+  u64 t[MAXN];
+  if (sub_n(t, a, b, f->n)) add_n(t, t, f->p, f->n);
+  memcpy(r, t, 8 * f->n);
+}
+static void f_neg(const fld_t* f, u64* r, const u64* a) {
+  u64 z[MAXN] = {0};
+  f_sub(f, r, z, a);
+}
+/* Montgomery product a*b/R mod p (CIOS). */
+static void f_mmul(const fld_t* f, u64* r, const u64* a, const u64* b) {
+  const int n = f->n;
+  u64 t[MAXN + 2];
+  memset(t, 0, sizeof t);
+  for (int i = 0; i < n; i++) {
+    u64 c = 0;
+    for (int j = 0; j < n; j++) {
+      u128 s = (u128)a[j] * b[i] + t[j] + c;
+      t[j] = (u64)s;
+      c = (u64)(s >> 64);
+    }
+    u128 s = (u128)t[n] + c;
+    t[n] = (u64)s;
+    t[n + 1] = (u64)(s >> 64);
+    u64 m = t[0] * f->n0;
+    s = (u128)m * f->p[0] + t[0];
+    c = (u64)(s >> 64);
+    for (int j = 1; j < n; j++) {
+      s = (u128)m * f->p[j] + t[j] + c;
+      t[j - 1] = (u64)s;
+      c = (u64)(s >> 64);
+    }
+    s = (u128)t[n] + c;
+    t[n - 1] = (u64)s;
+    t[n] = t[n + 1] + (u64)(s >> 64);
+  }
+  if (t[n] || ge(t, f->p, n)) sub_n(t, t, f->p, n);
+  memcpy(r, t, 8 * n);
+}
+static void f_tomont(const fld_t* f, u64* r, const u64* a) { f_mmul(f, r, a, f->r2); }
+static void f_frommont(const fld_t* f, u64* r, const u64* a) {
+  u64 one[MAXN] = {1, 0, 0, 0};
+  f_mmul(f, r, a, one);
+}
+/* Montgomery-domain pow, exponent as n_e limbs.  LSB-first square-and-multiply exactly as
+ * mod_pow, algebra/utils.rs:108-137. */
+static void f_mpow(const fld_t* f, u64* r, const u64* a, const u64* e, int ne) {
+  u64 result[MAXN], base[MAXN];
+  memcpy(result, f->one, 8 * f->n);
+  memcpy(base, a, 8 * f->n);
+  int top = ne * 64 - 1;
+  while (top >= 0 && !((e[top / 64] >> (top % 64)) & 1)) top--;
+  for (int i = 0; i <= top; i++) {
+    if ((e[i / 64] >> (i % 64)) & 1) f_mmul(f, result, result, base);
+    f_mmul(f, base, base, base);
+  }
+  memcpy(r, result, 8 * f->n);
+}
+/* Montgomery-domain inverse.  The reference runs extended Euclid on BigInts (field.rs:210-237);
+ * Fermat's a^(p-2) returns the same canonical residue (0 -> 0, as extended Euclid's t = 0). */
+static void f_minv(const fld_t* f, u64* r, const u64* a) {
+  u64 e[MAXN], two[MAXN] = {2, 0, 0, 0};
+  sub_n(e, f->p, two, f->n);
+  f_mpow(f, r, a, e, f->n);
+}
+
+static void fld_setup(fld_t* f, int n, const u64* p) {
+  memset(f, 0, sizeof *f);
+  f->n = n;
+  memcpy(f->p, p, 8 * n);
+  u64 inv = 1; /* Newton: inv = p^-1 mod 2^64 */
+  for (int i = 0; i < 6; i++) inv *= 2 - p[0] * inv;
+  f->n0 = (u64)0 - inv;
+  /* one = 2^(64n) mod p, r2 = 2^(128n) mod p by doubling */
+  u64 t[MAXN] = {1, 0, 0, 0};
+  for (int i = 0; i < 128 * n; i++) {
+    f_add(f, t, t, t);
+    if (i == 64 * n - 1) memcpy(f->one, t, 8 * n);
+  }
+  memcpy(f->r2, t, 8 * n);
+}
+
+static void orc_init(void) {
+  if (g_init) return;
+  /* ModEIP197, field.rs:428-431 */
+  static const u64 FR[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+  /* BN128Modulus, curve/bn128.rs:19-22 */
+  static const u64 FQ[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+  /* M128 = 1 + 407 * 2^119, zkstark/fri.rs:408 */
+  static const u64 M128[2] = {1ULL, 407ULL << 55};
+  static const u64 F631[1] = {631}, F17[1] = {17}, F31[1] = {31};
+  fld_setup(&g_fld[FID_FR], 4, FR);
+  fld_setup(&g_fld[FID_FQ], 4, FQ);
+  fld_setup(&g_fld[FID_M128], 2, M128);
+  fld_setup(&g_fld[FID_F631], 1, F631);
+  fld_setup(&g_fld[FID_F17], 1, F17);
+  fld_setup(&g_fld[FID_F31], 1, F31);
+  g_init = 1;
+}
+static const fld_t* fld_of(int fid) {
+  orc_init();
+  if (fid < 0 || fid >= FID_COUNT) return NULL;
+  return &g_fld[fid];
+}
+
+int orc_field_limbs(int fid) { const fld_t* f = fld_of(fid); return f ? f->n : -1; }
+int orc_field_modulus(int fid, u64* out) {
+  const fld_t* f = fld_of(fid);
+  if (!f) return -1;
+  memcpy(out, f->p, 8 * f->n);
+  return 0;
+}
+
+/* ---- canonical-in / canonical-out scalar field API (FiniteFieldElement ops, field.rs:157-279) */
+/* FiniteFieldElement::new + sanitize (field.rs:102-110, 260-270): reduce an arbitrary n-limb value. */
+int orc_field_reduce(int fid, const u64* a, u64* out) {
+  const fld_t* f = fld_of(fid);
+  if (!f) return -1;
+  u64 t[MAXN];
+  memcpy(t, a, 8 * f->n);
+  /* value < 2^(64n) < 2^64 p for every field here except tiny ones; use Montgomery round trip */
+  u64 m[MAXN];
+  f_mmul(f, m, t, f->r2); /* t*R mod p (valid for any t < 2^(64n)) */
+  f_frommont(f, out, m);
+  return 0;
+}
+int orc_field_add(int fid, const u64* a, const u64* b, u64* out) {
+  const fld_t* f = fld_of(fid); if (!f) return -1;
+  f_add(f, out, a, b); return 0;
+}
+int orc_field_sub(int fid, const u64* a, const u64* b, u64* out) {
+  const fld_t* f = fld_of(fid); if (!f) return -1;
+  f_sub(f, out, a, b); return 0;
+}
+int orc_field_neg(int fid, const u64* a, u64* out) {
+  const fld_t* f = fld_of(fid); if (!f) return -1;
+  f_neg(f, out, a); return 0;
+}
+int orc_field_mul(int fid, const u64* a, const u64* b, u64* out) {
+  const fld_t* f = fld_of(fid); if (!f) return -1;
+  u64 am[MAXN];
+  f_tomont(f, am, a);
+  f_mmul(f, out, am, b); /* (aR)*b/R = ab */
+  return 0;
+}
+int orc_field_inv(int fid, const u64* a, u64* out) {
+  const fld_t* f = fld_of(fid); if (!f) return -1;
+  u64 am[MAXN];
+  f_tomont(f, am, a);
+  f_minv(f, am, am);
+  f_frommont(f, out, am);
+  return 0;
+}
+int orc_field_pow(int fid, const u64* a, const u64* e, int ne, u64* out) {
+  const fld_t* f = fld_of(fid); if (!f) return -1;
+  u64 am[MAXN];
+  f_tomont(f, am, a);
+  f_mpow(f, am, am, e, ne);
+  f_frommont(f, out, am);
+  return 0;
+}
+
+/* get_nth_root_of_m128, zkstark/fri.rs:423-447: square the order-2^119 generator down to order n. */
+int orc_m128_nth_root(int log2n, u64* out) {
+  const fld_t* f = fld_of(FID_M128);
+  if (log2n < 0 || log2n > 119) return -2; /* the reference asserts n <= 2^119, power of two */
+  /* 85408008396924667383611388730472331217, fri.rs:436-438 */
+  u64 root[2] = {0xb5038f9c18f6f7d1ULL, 0x4040fbed12ee470fULL};
+  /* limbs are checked against the decimal literal by tests/test_oracle_kats.py */
+  u64 rm[MAXN];
+  f_tomont(f, rm, root);
+  for (int order = 119; order > log2n; order--) f_mmul(f, rm, rm, rm);
+  f_frommont(f, out, rm);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Polynomials and NTT -- literal restatements                                                  */
+/* ------------------------------------------------------------------------------------------- */
+static void to_mont_vec(const fld_t* f, u64* dst, const u64* src, size_t cnt) {
+  for (size_t i = 0; i < cnt; i++) f_tomont(f, dst + i * f->n, src + i * f->n);
+}
+static void from_mont_vec(const fld_t* f, u64* dst, const u64* src, size_t cnt) {
+  for (size_t i = 0; i < cnt; i++) f_frommont(f, dst + i * f->n, src + i * f->n);
+}
+static void f_mpow_u64(const fld_t* f, u64* r, const u64* a, u64 e) { f_mpow(f, r, a, &e, 1); }
+
+/* ntt::ntt, algebra/ntt.rs:7-48, Montgomery-domain values.  Returns 0, or -3/-4 for the two root
+ * assertions (:15-22), -2 for the power-of-two assertion (:8-11). */
+static int ntt_ref_rec(const fld_t* f, const u64* root, const u64* v, u64* out, size_t n) {
+  const int L = f->n;
+  if (n & (n - 1)) return -2;
+  if (n <= 1) { if (n) memcpy(out, v, 8 * L); return 0; }
+  u64 t[MAXN];
+  f_mpow_u64(f, t, root, n);
+  if (!eq_n(t, f->one, L)) return -3;
+  f_mpow_u64(f, t, root, n / 2);
+  if (eq_n(t, f->one, L)) return -4;
+  size_t half = n / 2;
+  u64* odds_in = malloc(8 * L * half), *evens_in = malloc(8 * L * half);
+  u64* odds = malloc(8 * L * half), *evens = malloc(8 * L * half);
+  for (size_t i = 0; i < n; i++) memcpy(((i & 1) ? odds_in : evens_in) + (i / 2) * L, v + i * L, 8 * L);
+  u64 root2[MAXN];
+  f_mpow_u64(f, root2, root, 2);
+  int rc = ntt_ref_rec(f, root2, odds_in, odds, half);
+  if (!rc) rc = ntt_ref_rec(f, root2, evens_in, evens, half);
+  if (!rc) {
+    for (size_t i = 0; i < n; i++) { /* ntt.rs:45-47: evens[i % half] + root^i * odds[i % half] */
+      u64 w[MAXN];
+      f_mpow_u64(f, w, root, i);
+      f_mmul(f, w, w, odds + (i % half) * L);
+      f_add(f, out + i * L, evens + (i % half) * L, w);
+    }
+  }
+  free(odds_in); free(evens_in); free(odds); free(evens);
+  return rc;
+}
+int orc_ntt_ref(int fid, const u64* root, const u64* in, u64* out, size_t n) {
+  const fld_t* f = fld_of(fid); if (!f) return -1;
+  if (n == 0) return 0;
+  if (n & (n - 1)) return -2;
+  const int L = f->n;
+  u64* vin = malloc(8 * L * n), *vout = malloc(8 * L * n);
+  u64 rm[MAXN];
+  to_mont_vec(f, vin, in, n);
+  f_tomont(f, rm, root);
+  int rc = ntt_ref_rec(f, rm, vin, vout, n);
+  if (!rc) from_mont_vec(f, out, vout, n);
+  free(vin); free(vout);
+  return rc;
+}
+/* ntt::intt, algebra/ntt.rs:50-64: n^-1 * ntt(root^-1, values); len 1 returns the input. */
+int orc_intt_ref(int fid, const u64* root, const u64* in, u64* out, size_t n) {
+  const fld_t* f = fld_of(fid); if (!f) return -1;
+  const int L = f->n;
+  if (n == 0) return 0;
+  if (n == 1) { memcpy(out, in, 8 * L); return 0; }
+  if (n & (n - 1)) return -2;
+  u64* vin = malloc(8 * L * n), *vout = malloc(8 * L * n);
+  u64 rm[MAXN], rinv[MAXN], nn[MAXN] = {0}, ninv[MAXN];
+  to_mont_vec(f, vin, in, n);
+  f_tomont(f, rm, root);
+  f_minv(f, rinv, rm);
+  nn[0] = (u64)n;
+  f_tomont(f, ninv, nn);
+  f_minv(f, ninv, ninv);
+  int rc = ntt_ref_rec(f, rinv, vin, vout, n);
+  if (!rc) {
+    for (size_t i = 0; i < n; i++) f_mmul(f, vout + i * L, ninv, vout + i * L);
+    from_mont_vec(f, out, vout, n);
+  }
+  free(vin); free(vout);
+  return rc;
+}
+
+/* Polynomial::eval, algebra/polynomial.rs:120-128 (power-accumulate, not Horner). */
+int orc_poly_eval(int fid, const u64* coef, size_t n, const u64* x, u64* out) {
+  const fld_t* f = fld_of(fid); if (!f) return -1;
+  const int L = f->n;
+  u64 res[MAXN] = {0}, tp[MAXN], xm[MAXN], c[MAXN], t[MAXN];
+  memcpy(tp, f->one, 8 * L);
+  f_tomont(f, xm, x);
+  for (size_t i = 0; i < n; i++) {
+    f_tomont(f, c, coef + i * L);
+    f_mmul(f, t, tp, c);
+    f_add(f, res, res, t);
+    f_mmul(f, tp, tp, xm);
+  }
+  f_frommont(f, out, res);
+  return 0;
+}
+
+/* Polynomial::scale, polynomial.rs:167-174: coef[i] * factor^i (one pow per coefficient). */
+static void poly_scale_m(const fld_t* f, u64* dst, const u64* coef_m, size_t n, const u64* factor_m) {
+  for (size_t i = 0; i < n; i++) {
+    u64 w[MAXN];
+    f_mpow_u64(f, w, factor_m, i);
+    f_mmul(f, dst + i * f->n, w, coef_m + i * f->n);
+  }
+}
+/* ntt::fast_coset_evaluate, algebra/ntt.rs:254-269.  n_coef > order panics in the reference
+ * (usize underflow at :265) -> -5. */
+int orc_fast_coset_evaluate_ref(int fid, const u64* coef, size_t n_coef, const u64* offset,
+                                const u64* generator, u64* out, size_t order) {
+  const fld_t* f = fld_of(fid); if (!f) return -1;
+  const int L = f->n;
+  if (n_coef > order) return -5;
+  if (order == 0) return 0;
+  u64* v = calloc(order, 8 * L), *vo = malloc(8 * L * order), *cm = malloc(8 * L * (n_coef ? n_coef : 1));
+  u64 om[MAXN], gm[MAXN];
+  f_tomont(f, om, offset);
+  f_tomont(f, gm, generator);
+  to_mont_vec(f, cm, coef, n_coef);
+  poly_scale_m(f, v, cm, n_coef, om);
+  int rc = ntt_ref_rec(f, gm, v, vo, order);
+  if (!rc) from_mont_vec(f, out, vo, order);
+  free(v); free(vo); free(cm);
+  return rc;
+}
+
+static size_t trimmed_len(const fld_t* f, const u64* c, size_t n) {
+  while (n > 0 && is_zero_n(c + (n - 1) * f->n, f->n)) n--;
+  return n;
+}
+/* schoolbook product, Polynomial::mul_ref polynomial.rs:302-316; returns trimmed length */
+static size_t poly_mul_school_m(const fld_t* f, const u64* a, size_t la, const u64* b, size_t lb, u64* out) {
+  const int L = f->n;
+  la = trimmed_len(f, a, la); lb = trimmed_len(f, b, lb);
+  if (la == 0 || lb == 0) return 0;
+  size_t lo = la + lb - 1;
+  memset(out, 0, 8 * L * lo);
+  for (size_t i = 0; i < la; i++)
+    for (size_t j = 0; j < lb; j++) {
+      u64 t[MAXN];
+      f_mmul(f, t, a + i * L, b + j * L);
+      f_add(f, out + (i + j) * L, out + (i + j) * L, t);
+    }
+  return trimmed_len(f, out, lo);
+}
+/* ntt::fast_multiply, algebra/ntt.rs:66-116.  out must hold max(root_order, la+lb) elements;
+ * *out_len receives the reference's result length (untrimmed `order` on the NTT path, trimmed on the
+ * schoolbook path (degree < 8), 0 for a zero operand). */
+int orc_fast_multiply_ref(int fid, const u64* a, size_t la, const u64* b, size_t lb, const u64* root,
+                          size_t root_order, u64* out, size_t* out_len) {
+  const fld_t* f = fld_of(fid); if (!f) return -1;
+  const int L = f->n;
+  u64 rm[MAXN], t[MAXN];
+  f_tomont(f, rm, root);
+  f_mpow_u64(f, t, rm, root_order);
+  if (!eq_n(t, f->one, L)) return -3;
+  f_mpow_u64(f, t, rm, root_order / 2);
+  if (eq_n(t, f->one, L)) return -4;
+  u64* am = malloc(8 * L * (la ? la : 1)), *bm = malloc(8 * L * (lb ? lb : 1));
+  to_mont_vec(f, am, a, la); to_mont_vec(f, bm, b, lb);
+  size_t da = trimmed_len(f, am, la), db = trimmed_len(f, bm, lb);
+  int rc = 0;
+  if (da == 0 || db == 0) { *out_len = 0; goto done; }
+  {
+    size_t degree = (da - 1) + (db - 1);
+    if (degree < 8) {
+      u64* o = malloc(8 * L * (da + db));
+      size_t lo = poly_mul_school_m(f, am, la, bm, lb, o);
+      from_mont_vec(f, out, o, lo);
+      *out_len = lo;
+      free(o);
+      goto done;
+    }
+    size_t order = root_order;
+    while (degree < order / 2) { f_mmul(f, rm, rm, rm); order /= 2; }
+    /* the reference pushes zeros "while len < order" (:98-103): len > order cannot happen because
+       degree >= order/2 ... but la may exceed order when trailing zeros are present; ntt then
+       asserts on the length.  Mirror: operands longer than order -> -5. */
+    if (la > order || lb > order) { rc = -5; goto done; }
+    u64* x = calloc(order, 8 * L), *y = calloc(order, 8 * L), *X = malloc(8 * L * order), *Y = malloc(8 * L * order);
+    memcpy(x, am, 8 * L * la); memcpy(y, bm, 8 * L * lb);
+    rc = ntt_ref_rec(f, rm, x, X, order);
+    if (!rc) rc = ntt_ref_rec(f, rm, y, Y, order);
+    if (!rc) {
+      for (size_t i = 0; i < order; i++) f_mmul(f, X + i * L, X + i * L, Y + i * L);
+      u64 rinv[MAXN], nn[MAXN] = {0}, ninv[MAXN];
+      f_minv(f, rinv, rm);
+      nn[0] = order; f_tomont(f, ninv, nn); f_minv(f, ninv, ninv);
+      rc = ntt_ref_rec(f, rinv, X, Y, order);
+      if (!rc) {
+        for (size_t i = 0; i < order; i++) f_mmul(f, Y + i * L, ninv, Y + i * L);
+        from_mont_vec(f, out, Y, order);
+        *out_len = order;
+      }
+    }
+    free(x); free(y); free(X); free(Y);
+  }
+done:
+  free(am); free(bm);
+  return rc;
+}
+
+/* private Polynomial::fft, polynomial.rs:278-300: recursive DIT with a running twiddle; natural
+ * order in, natural order out; no checks on omega. */
+static void fft_ref_rec(const fld_t* f, u64* a, size_t n, const u64* omega) {
+  const int L = f->n;
+  if (n == 1) return;
+  size_t h = n / 2;
+  u64* even = malloc(8 * L * h), *odd = malloc(8 * L * h);
+  for (size_t i = 0; i < h; i++) {
+    memcpy(even + i * L, a + (2 * i) * L, 8 * L);
+    memcpy(odd + i * L, a + (2 * i + 1) * L, 8 * L);
+  }
+  u64 w2[MAXN];
+  f_mmul(f, w2, omega, omega);
+  fft_ref_rec(f, even, h, w2);
+  fft_ref_rec(f, odd, h, w2);
+  u64 wi[MAXN], t[MAXN];
+  memcpy(wi, f->one, 8 * L);
+  for (size_t i = 0; i < h; i++) {
+    f_mmul(f, t, wi, odd + i * L);
+    f_add(f, a + i * L, even + i * L, t);
+    f_sub(f, a + (i + h) * L, even + i * L, t);
+    f_mmul(f, wi, wi, omega);
+  }
+  free(even); free(odd);
+}
+/* Polynomial::fft_multiply, polynomial.rs:242-276.  out holds la+lb-1 elements; *out_len = trimmed
+ * length (the reference trims trailing zeros, :273-275).  la + lb - 1 underflows for two empty
+ * operands in the reference (usize) -> -5. */
+int orc_fft_multiply_ref(int fid, const u64* a, size_t la, const u64* b, size_t lb, const u64* omega,
+                         u64* out, size_t* out_len) {
+  const fld_t* f = fld_of(fid); if (!f) return -1;
+  const int L = f->n;
+  if (la + lb == 0) return -5;
+  size_t m = la + lb - 1, n = 1;
+  while (n < m) n <<= 1;
+  if (m == 0) n = 1; /* usize::next_power_of_two(0) == 1 */
+  u64* x = calloc(n, 8 * L), *y = calloc(n, 8 * L);
+  to_mont_vec(f, x, a, la); to_mont_vec(f, y, b, lb);
+  u64 wm[MAXN], winv[MAXN], nn[MAXN] = {0}, ninv[MAXN];
+  f_tomont(f, wm, omega);
+  fft_ref_rec(f, x, n, wm);
+  fft_ref_rec(f, y, n, wm);
+  for (size_t i = 0; i < n; i++) f_mmul(f, x + i * L, x + i * L, y + i * L);
+  f_minv(f, winv, wm);
+  fft_ref_rec(f, x, n, winv);
+  nn[0] = n; f_tomont(f, ninv, nn); f_minv(f, ninv, ninv);
+  for (size_t i = 0; i < n; i++) f_mmul(f, x + i * L, x + i * L, ninv);
+  size_t lo = trimmed_len(f, x, m);
+  from_mont_vec(f, out, x, lo);
+  *out_len = lo;
+  free(x); free(y);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Affine short-Weierstrass group law, algebra/curve/curve.rs:44-191                            */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct { u64 x[MAXN], y[MAXN]; int inf; } pt_t; /* Montgomery-domain coordinates */
+typedef struct { const fld_t* f; u64 a[MAXN]; } crv_t;   /* y^2 = x^3 + a x + b; b is not needed */
+
+static void pt_set_inf(pt_t* p) { memset(p, 0, sizeof *p); p->inf = 1; }
+
+/* line_slope, curve.rs:56-70 */
+static void pt_slope(const crv_t* c, u64* s, const pt_t* p, const pt_t* q) {
+  const fld_t* f = c->f;
+  u64 num[MAXN], den[MAXN], t[MAXN];
+  if (eq_n(p->x, q->x, f->n)) {
+    f_mmul(f, t, p->x, p->x);   /* x1^2 */
+    f_add(f, num, t, t);
+    f_add(f, num, num, t);      /* 3 x1^2 */
+    f_add(f, num, num, c->a);   /* + a */
+    f_add(f, den, p->y, p->y);  /* 2 y1 */
+  } else {
+    f_sub(f, num, q->y, p->y);
+    f_sub(f, den, q->x, p->x);
+  }
+  f_minv(f, den, den);
+  f_mmul(f, s, num, den);
+}
+/* double / inplace_double, curve.rs:72-101 */
+static void pt_double(const crv_t* c, pt_t* r, const pt_t* p) {
+  const fld_t* f = c->f;
+  if (p->inf) { *r = *p; return; }
+  u64 s[MAXN], nx[MAXN], ny[MAXN], t[MAXN];
+  pt_slope(c, s, p, p);
+  f_mmul(f, nx, s, s);
+  f_sub(f, nx, nx, p->x);
+  f_sub(f, nx, nx, p->x);          /* s^2 - x - x */
+  f_mmul(f, t, s, nx);
+  f_neg(f, ny, t);                 /* -s*new_x */
+  f_mmul(f, t, s, p->x);
+  f_add(f, ny, ny, t);             /* + s*x */
+  f_sub(f, ny, ny, p->y);          /* - y */
+  memcpy(r->x, nx, 8 * f->n); memcpy(r->y, ny, 8 * f->n); r->inf = 0;
+}
+/* add_ref / add_assign_ref, curve.rs:103-161, all four special cases */
+static void pt_add(const crv_t* c, pt_t* r, const pt_t* p, const pt_t* q) {
+  const fld_t* f = c->f;
+  if (p->inf) { *r = *q; return; }
+  if (q->inf) { *r = *p; return; }
+  if (eq_n(p->x, q->x, f->n)) {
+    if (eq_n(p->y, q->y, f->n)) { pt_double(c, r, p); return; }
+    pt_set_inf(r); return;
+  }
+  u64 s[MAXN], nx[MAXN], ny[MAXN], t[MAXN];
+  pt_slope(c, s, p, q);
+  f_mmul(f, nx, s, s);
+  f_sub(f, nx, nx, p->x);
+  f_sub(f, nx, nx, q->x);
+  f_mmul(f, t, s, nx);
+  f_neg(f, ny, t);                 /* (-s)*new_x */
+  f_mmul(f, t, s, p->x);
+  f_sub(f, t, t, p->y);            /* s*x1 - y1 */
+  f_add(f, ny, ny, t);
+  memcpy(r->x, nx, 8 * f->n); memcpy(r->y, ny, 8 * f->n); r->inf = 0;
+}
+/* mul_ref_bigint, curve.rs:168-191: LSB-first double-and-add; scalar 0 -> infinity.  (Negative
+ * scalars panic in the reference; this API only carries non-negative limbs.) */
+static void pt_mul(const crv_t* c, pt_t* r, const pt_t* p, const u64* k, int nk) {
+  pt_t result, cur = *p;
+  pt_set_inf(&result);
+  int top = nk * 64 - 1;
+  while (top >= 0 && !((k[top / 64] >> (top % 64)) & 1)) top--;
+  for (int i = 0; i <= top; i++) {
+    if ((k[i / 64] >> (i % 64)) & 1) pt_add(c, &result, &result, &cur);
+    pt_double(c, &cur, &cur);
+  }
+  *r = result;
+}
+static void pt_load(const fld_t* f, pt_t* p, const u64* xy) {
+  if (is_zero_n(xy, 2 * f->n)) { pt_set_inf(p); return; }
+  f_tomont(f, p->x, xy); f_tomont(f, p->y, xy + f->n); p->inf = 0;
+}
+static void pt_store(const fld_t* f, u64* xy, const pt_t* p) {
+  if (p->inf) { memset(xy, 0, 16 * f->n); return; }
+  f_frommont(f, xy, p->x); f_frommont(f, xy + f->n, p->y);
+}
+static void crv_setup(crv_t* c, int fid, u64 a_small) {
+  c->f = fld_of(fid);
+  u64 a[MAXN] = {a_small, 0, 0, 0};
+  f_tomont(c->f, c->a, a);
+}
+/* curve ids: 0 = BN128Curve a=0,b=3 over Fq (bn128.rs:23); 1 = y^2=x^3+30x+34 over F_631
+ * (curve.rs:429-497 test curve) */
+static int crv_of(int cid, crv_t* c) {
+  if (cid == 0) { crv_setup(c, FID_FQ, 0); return 0; }
+  if (cid == 1) { crv_setup(c, FID_F631, 30); return 0; }
+  return -1;
+}
+int orc_ec_add(int cid, const u64* p_xy, const u64* q_xy, u64* out_xy) {
+  crv_t c; if (crv_of(cid, &c)) return -1;
+  pt_t p, q, r;
+  pt_load(c.f, &p, p_xy); pt_load(c.f, &q, q_xy);
+  pt_add(&c, &r, &p, &q);
+  pt_store(c.f, out_xy, &r);
+  return 0;
+}
+int orc_ec_double(int cid, const u64* p_xy, u64* out_xy) {
+  crv_t c; if (crv_of(cid, &c)) return -1;
+  pt_t p, r;
+  pt_load(c.f, &p, p_xy);
+  pt_double(&c, &r, &p);
+  pt_store(c.f, out_xy, &r);
+  return 0;
+}
+int orc_ec_mul(int cid, const u64* p_xy, const u64* k, int nk, u64* out_xy) {
+  crv_t c; if (crv_of(cid, &c)) return -1;
+  pt_t p, r;
+  pt_load(c.f, &p, p_xy);
+  pt_mul(&c, &r, &p, k, nk);
+  pt_store(c.f, out_xy, &r);
+  return 0;
+}
+/* is the affine point on y^2 = x^3 + 3 (BN254 G1)?  bn128.rs:285-289 checks this for the generator */
+int orc_g1_on_curve(const u64* xy) {
+  const fld_t* f = fld_of(FID_FQ);
+  if (is_zero_n(xy, 8)) return 1;
+  u64 x[MAXN], y[MAXN], l[MAXN], r[MAXN], three[MAXN] = {3, 0, 0, 0};
+  if (ge(xy, f->p, 4) || ge(xy + 4, f->p, 4)) return 0;
+  f_tomont(f, x, xy); f_tomont(f, y, xy + 4);
+  f_mmul(f, l, y, y);
+  f_mmul(f, r, x, x); f_mmul(f, r, r, x);
+  f_tomont(f, three, three);
+  f_add(f, r, r, three);
+  return eq_n(l, r, 4);
+}
+
+/* Polynomial::eval_with_powers_on_curve, algebra/polynomial.rs:156-165 -- THE MSM, literally:
+ * result += powers[i].mul_ref(coef[i].sanitize()), in index order. */
+int orc_msm_ref(const u64* scalars, const u64* points_xy, size_t n, u64* out_xy) {
+  crv_t c; crv_of(0, &c);
+  const fld_t* fr = fld_of(FID_FR);
+  pt_t acc, p, t;
+  pt_set_inf(&acc);
+  for (size_t i = 0; i < n; i++) {
+    u64 k[4];
+    if (ge(scalars + 4 * i, fr->p, 4)) orc_field_reduce(FID_FR, scalars + 4 * i, k); /* sanitize */
+    else memcpy(k, scalars + 4 * i, 32);
+    pt_load(c.f, &p, points_xy + 8 * i);
+    pt_mul(&c, &t, &p, k, 4);
+    pt_add(&c, &acc, &acc, &t);
+  }
+  pt_store(c.f, out_xy, &acc);
+  return 0;
+}
+
+/* setup_kzg, algebra/kzg.rs:27-40, G1 part, with the trapdoor alpha supplied by the caller (the
+ * reference draws it from thread_rng): powers[i] = g1 * alpha^i, i = 0..=max_d. */
+int orc_kzg_setup_g1_ref(const u64* g1_xy, const u64* alpha, size_t max_d, u64* powers_xy) {
+  crv_t c; crv_of(0, &c);
+  const fld_t* fr = fld_of(FID_FR);
+  pt_t g, t;
+  pt_load(c.f, &g, g1_xy);
+  u64 ap[MAXN], am[MAXN], k[MAXN];
+  memcpy(ap, fr->one, 32);
+  f_tomont(fr, am, alpha);
+  for (size_t i = 0; i <= max_d; i++) {
+    f_frommont(fr, k, ap);
+    pt_mul(&c, &t, &g, k, 4);
+    pt_store(c.f, powers_xy + 8 * i, &t);
+    f_mmul(fr, ap, ap, am);
+  }
+  return 0;
+}
+/* commit_kzg, kzg.rs:57-59 */
+int orc_kzg_commit_ref(const u64* coef, size_t n, const u64* powers_xy, u64* out_xy) {
+  return orc_msm_ref(coef, powers_xy, n, out_xy);
+}
+/* open_kzg, kzg.rs:61-72: y = f(u); f_u = (f - y) / (X - u) by the reference's long division
+ * (div_rem_ref, polynomial.rs:371-405); w = MSM(f_u, powers). */
+int orc_kzg_open_ref(const u64* coef, size_t n, const u64* u, const u64* powers_xy, u64* y_out, u64* w_xy) {
+  const fld_t* f = fld_of(FID_FR);
+  const int L = 4;
+  orc_poly_eval(FID_FR, coef, n, u, y_out);
+  /* f - y (Sub trims trailing zeros, polynomial.rs:517-523) */
+  u64* rem = malloc(8 * L * (n ? n : 1));
+  to_mont_vec(f, rem, coef, n);
+  u64 ym[MAXN], um[MAXN];
+  f_tomont(f, ym, y_out); f_tomont(f, um, u);
+  size_t rl = n;
+  if (n == 0) { rem[0] = rem[1] = rem[2] = rem[3] = 0; f_neg(f, rem, ym); rl = 1; }
+  else f_sub(f, rem, rem, ym);
+  rl = trimmed_len(f, rem, rl);
+  /* divisor X - u = [-u, 1] (from_monomials, polynomial.rs:202-212) */
+  u64 d0[MAXN];
+  f_neg(f, d0, um);
+  size_t ql = rl >= 2 ? rl - 1 : 0;
+  u64* quo = calloc(ql ? ql : 1, 8 * L);
+  while (rl >= 2) { /* polynomial.rs:385-395, divisor_lead_inv = 1 */
+    u64 lead[MAXN], t[MAXN];
+    memcpy(lead, rem + (rl - 1) * L, 8 * L);
+    size_t dd = rl - 2;
+    memcpy(quo + dd * L, lead, 8 * L);
+    f_mmul(f, t, lead, d0);
+    f_sub(f, rem + dd * L, rem + dd * L, t);
+    f_sub(f, rem + (dd + 1) * L, rem + (dd + 1) * L, lead);
+    rl = trimmed_len(f, rem, rl);
+  }
+  ql = trimmed_len(f, quo, ql);
+  u64* qc = malloc(8 * L * (ql ? ql : 1));
+  from_mont_vec(f, qc, quo, ql);
+  int rc = orc_msm_ref(qc, powers_xy, ql, w_xy);
+  free(rem); free(quo); free(qc);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Fast CPU layer (validated against the *_ref layer by tests/test_oracle_fast.py)              */
+/* ------------------------------------------------------------------------------------------- */
+static size_t bitrev(size_t x, int bits) {
+  size_t r = 0;
+  for (int i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
+  return r;
+}
+/* Iterative radix-2 DIT; same map as orc_ntt_ref / orc_intt_ref (natural in, natural out). */
+int orc_ntt_fast(int fid, const u64* root, const u64* in, u64* out, size_t n, int inverse, int nthreads) {
+  const fld_t* f = fld_of(fid); if (!f) return -1;
+  const int L = f->n;
+  if (n == 0) return 0;
+  if (n & (n - 1)) return -2;
+  if (n == 1) { memcpy(out, in, 8 * L); return 0; }
+  int lg = 0; while (((size_t)1 << lg) < n) lg++;
+  u64 rm[MAXN], t[MAXN];
+  f_tomont(f, rm, root);
+  f_mpow_u64(f, t, rm, n);
+  if (!eq_n(t, f->one, L)) return -3;
+  f_mpow_u64(f, t, rm, n / 2);
+  if (eq_n(t, f->one, L)) return -4;
+  if (inverse) f_minv(f, rm, rm);
+  if (nthreads < 1) nthreads = 1;
+  u64* tw = malloc(8 * L * (n / 2));
+  memcpy(tw, f->one, 8 * L);
+  for (size_t i = 1; i < n / 2; i++) f_mmul(f, tw + i * L, tw + (i - 1) * L, rm);
+  /* Values stay in the plain domain: multiplying a plain x by a Montgomery-form twiddle wR gives wx. */
+  u64* a = malloc(8 * L * n);
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+  for (size_t i = 0; i < n; i++) memcpy(a + bitrev(i, lg) * L, in + i * L, 8 * L);
+  for (int s = 1; s <= lg; s++) {
+    size_t half = (size_t)1 << (s - 1), step = n >> s;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (size_t b = 0; b < n / 2; b++) {
+      size_t grp = b / half, j = b % half;
+      u64* lo = a + (grp * 2 * half + j) * L, *hi = lo + half * L;
+      u64 tt[MAXN], u[MAXN];
+      f_mmul(f, tt, tw + (j * step) * L, hi);
+      memcpy(u, lo, 8 * L);
+      f_add(f, lo, u, tt);
+      f_sub(f, hi, u, tt);
+    }
+  }
+  if (inverse) {
+    u64 nn[MAXN] = {0}, ninv[MAXN];
+    nn[0] = n; f_tomont(f, ninv, nn); f_minv(f, ninv, ninv);
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (size_t i = 0; i < n; i++) f_mmul(f, a + i * L, ninv, a + i * L);
+  }
+  memcpy(out, a, 8 * L * n);
+  free(a); free(tw);
+  return 0;
+}
+
+/* Jacobian arithmetic for the fast MSM (a = 0).  Z = 0 encodes infinity. */
+typedef struct { u64 X[4], Y[4], Z[4]; } jac_t;
+static void jac_set_inf(jac_t* p) { memset(p, 0, sizeof *p); }
+static void jac_double(const fld_t* f, jac_t* r, const jac_t* p) {
+  if (is_zero_n(p->Z, 4)) { *r = *p; return; }
+  u64 A[4], B[4], C[4], D[4], E[4], F[4], t[4], X3[4], Y3[4], Z3[4];
+  f_mmul(f, A, p->X, p->X);
+  f_mmul(f, B, p->Y, p->Y);
+  f_mmul(f, C, B, B);
+  f_add(f, t, p->X, B); f_mmul(f, t, t, t); f_sub(f, t, t, A); f_sub(f, t, t, C); f_add(f, D, t, t);
+  f_add(f, E, A, A); f_add(f, E, E, A);
+  f_mmul(f, F, E, E);
+  f_sub(f, X3, F, D); f_sub(f, X3, X3, D);
+  f_sub(f, t, D, X3); f_mmul(f, Y3, E, t);
+  f_add(f, t, C, C); f_add(f, t, t, t); f_add(f, t, t, t); f_sub(f, Y3, Y3, t);
+  f_mmul(f, Z3, p->Y, p->Z); f_add(f, Z3, Z3, Z3);
+  memcpy(r->X, X3, 32); memcpy(r->Y, Y3, 32); memcpy(r->Z, Z3, 32);
+}
+static void jac_add(const fld_t* f, jac_t* r, const jac_t* p, const jac_t* q) {
+  if (is_zero_n(p->Z, 4)) { *r = *q; return; }
+  if (is_zero_n(q->Z, 4)) { *r = *p; return; }
+  u64 Z1Z1[4], Z2Z2[4], U1[4], U2[4], S1[4], S2[4], H[4], I[4], J[4], rr[4], V[4], t[4], X3[4], Y3[4], Z3[4];
+  f_mmul(f, Z1Z1, p->Z, p->Z); f_mmul(f, Z2Z2, q->Z, q->Z);
+  f_mmul(f, U1, p->X, Z2Z2); f_mmul(f, U2, q->X, Z1Z1);
+  f_mmul(f, S1, p->Y, q->Z); f_mmul(f, S1, S1, Z2Z2);
+  f_mmul(f, S2, q->Y, p->Z); f_mmul(f, S2, S2, Z1Z1);
+  if (eq_n(U1, U2, 4)) {
+    if (eq_n(S1, S2, 4)) { jac_double(f, r, p); return; }
+    jac_set_inf(r); return;
+  }
+  f_sub(f, H, U2, U1);
+  f_add(f, I, H, H); f_mmul(f, I, I, I);
+  f_mmul(f, J, H, I);
+  f_sub(f, rr, S2, S1); f_add(f, rr, rr, rr);
+  f_mmul(f, V, U1, I);
+  f_mmul(f, X3, rr, rr); f_sub(f, X3, X3, J); f_sub(f, X3, X3, V); f_sub(f, X3, X3, V);
+  f_sub(f, t, V, X3); f_mmul(f, Y3, rr, t); f_mmul(f, t, S1, J); f_add(f, t, t, t); f_sub(f, Y3, Y3, t);
+  f_add(f, Z3, p->Z, q->Z); f_mmul(f, Z3, Z3, Z3); f_sub(f, Z3, Z3, Z1Z1); f_sub(f, Z3, Z3, Z2Z2); f_mmul(f, Z3, Z3, H);
+  memcpy(r->X, X3, 32); memcpy(r->Y, Y3, 32); memcpy(r->Z, Z3, 32);
+}
+static void jac_from_affine(const fld_t* f, jac_t* r, const u64* xm, const u64* ym) {
+  memcpy(r->X, xm, 32); memcpy(r->Y, ym, 32); memcpy(r->Z, f->one, 32);
+}
+static void jac_store_affine(const fld_t* f, u64* xy, const jac_t* p) {
+  if (is_zero_n(p->Z, 4)) { memset(xy, 0, 64); return; }
+  u64 zi[4], zi2[4], x[4], y[4];
+  f_minv(f, zi, p->Z);
+  f_mmul(f, zi2, zi, zi);
+  f_mmul(f, x, p->X, zi2);
+  f_mmul(f, zi2, zi2, zi);
+  f_mmul(f, y, p->Y, zi2);
+  f_frommont(f, xy, x); f_frommont(f, xy + 4, y);
+}
+/* Pippenger bucket MSM, unsigned c-bit windows, threads over windows.  Same function as
+ * orc_msm_ref. */
+int orc_msm_fast(const u64* scalars, const u64* points_xy, size_t n, u64* out_xy, int nthreads) {
+  const fld_t* f = fld_of(FID_FQ);
+  const fld_t* fr = fld_of(FID_FR);
+  if (nthreads < 1) nthreads = 1;
+  int c = 1; while (((size_t)1 << (c + 3)) < n && c < 16) c++;
+  if (c < 4) c = 4;
+  const int nwin = (254 + c - 1) / c;
+  const size_t nb = ((size_t)1 << c) - 1;
+  u64* pm = malloc(64 * (n ? n : 1));
+  u64* sc = malloc(32 * (n ? n : 1));
+  unsigned char* isinf = malloc(n ? n : 1);
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+  for (size_t i = 0; i < n; i++) {
+    isinf[i] = is_zero_n(points_xy + 8 * i, 8);
+    f_tomont(f, pm + 8 * i, points_xy + 8 * i);
+    f_tomont(f, pm + 8 * i + 4, points_xy + 8 * i + 4);
+    if (ge(scalars + 4 * i, fr->p, 4)) orc_field_reduce(FID_FR, scalars + 4 * i, sc + 4 * i);
+    else memcpy(sc + 4 * i, scalars + 4 * i, 32);
+  }
+  jac_t* wsum = malloc(sizeof(jac_t) * nwin);
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+  for (int w = 0; w < nwin; w++) {
+    jac_t* bk = malloc(sizeof(jac_t) * nb);
+    for (size_t b = 0; b < nb; b++) jac_set_inf(&bk[b]);
+    for (size_t i = 0; i < n; i++) {
+      if (isinf[i]) continue;
+      int bit = w * c;
+      u64 d = sc[4 * i + bit / 64] >> (bit % 64);
+      if (bit % 64 + c > 64 && bit / 64 + 1 < 4) d |= sc[4 * i + bit / 64 + 1] << (64 - bit % 64);
+      d &= ((u64)1 << c) - 1;
+      if (!d) continue;
+      jac_t q;
+      jac_from_affine(f, &q, pm + 8 * i, pm + 8 * i + 4);
+      jac_add(f, &bk[d - 1], &bk[d - 1], &q);
+    }
+    jac_t run, acc;
+    jac_set_inf(&run); jac_set_inf(&acc);
+    for (size_t b = nb; b-- > 0;) {
+      jac_add(f, &run, &run, &bk[b]);
+      jac_add(f, &acc, &acc, &run);
+    }
+    wsum[w] = acc;
+    free(bk);
+  }
+  jac_t tot;
+  jac_set_inf(&tot);
+  for (int w = nwin - 1; w >= 0; w--) {
+    for (int k = 0; k < c; k++) jac_double(f, &tot, &tot);
+    jac_add(f, &tot, &tot, &wsum[w]);
+  }
+  jac_store_affine(f, out_xy, &tot);
+  free(pm); free(sc); free(isinf); free(wsum);
+  return 0;
+}
+
+/* [k_i] G for a batch of scalars (fixed base, 8-bit windows; used to build big SRS fixtures and
+ * trapdoor checks quickly): out[i] = k[i] * base. */
+int orc_g1_fixed_base_mul_batch(const u64* base_xy, const u64* scalars, size_t n, u64* out_xy, int nthreads) {
+  const fld_t* f = fld_of(FID_FQ);
+  if (nthreads < 1) nthreads = 1;
+  /* table[w][d] = d * 2^(8w) * base, d = 1..255 */
+  jac_t (*tab)[255] = malloc(sizeof(jac_t) * 255 * 32);
+  jac_t b;
+  u64 bx[4], by[4];
+  if (is_zero_n(base_xy, 8)) { memset(out_xy, 0, 64 * n); free(tab); return 0; }
+  f_tomont(f, bx, base_xy); f_tomont(f, by, base_xy + 4);
+  jac_from_affine(f, &b, bx, by);
+  for (int w = 0; w < 32; w++) {
+    tab[w][0] = b;
+    for (int d = 1; d < 255; d++) jac_add(f, &tab[w][d], &tab[w][d - 1], &b);
+    jac_t nb2 = tab[w][254];
+    jac_add(f, &nb2, &nb2, &b); /* 256 * b */
+    b = nb2;
+  }
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+  for (size_t i = 0; i < n; i++) {
+    jac_t acc;
+    jac_set_inf(&acc);
+    for (int w = 0; w < 32; w++) {
+      unsigned d = (unsigned)(scalars[4 * i + w / 8] >> (8 * (w % 8))) & 255u;
+      if (d) jac_add(f, &acc, &acc, &tab[w][d - 1]);
+    }
+    jac_store_affine(f, out_xy + 8 * i, &acc);
+  }
+  free(tab);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Deterministic synthetic inputs shared by tests and bench: SplitMix64 stream,       */
+/* rejection-sampled below the modulus.  The GPU generator kernels reproduce these bit for bit.   */
+/* ------------------------------------------------------------------------------------------- */
+static u64 splitmix64(u64* s) {
+  u64 z = (*s += 0x9e3779b97f4a7c15ULL);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  return z ^ (z >> 31);
+}
+/* element i of stream `seed`: limbs from SplitMix64 seeded with seed ^ (i * GOLD) ^ try, masked to
+ * the modulus bit length, rejected until < p. */
+void orc_synth_element(int fid, u64 seed, u64 index, u64* out) {
+  const fld_t* f = fld_of(fid);
+  int bits = 0;
+  for (int b = f->n * 64 - 1; b >= 0; b--) if ((f->p[b / 64] >> (b % 64)) & 1) { bits = b + 1; break; }
+  for (u64 attempt = 0;; attempt++) {
+    u64 s = seed ^ (index * 0xd1342543de82ef95ULL) ^ (attempt * 0xa0761d6478bd642fULL);
+    for (int i = 0; i < f->n; i++) out[i] = splitmix64(&s);
+    int topbits = bits - 64 * (f->n - 1);
+    if (topbits < 64) out[f->n - 1] &= (((u64)1 << topbits) - 1);
+    if (!ge(out, f->p, f->n)) return;
+  }
+}
+void orc_synth_vector(int fid, u64 seed, size_t n, u64* out, int nthreads) {
+  const fld_t* f = fld_of(fid);
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+  for (size_t i = 0; i < n; i++) orc_synth_element(fid, seed, i, out + i * f->n);
+}
+/* Try-and-increment G1 points: x = synth(seed, i) + t, smallest t >= 0 with x^3 + 3 a
+ * square; y = (x^3+3)^((q+1)/4) (q = 3 mod 4), then the smaller of y, q - y ... no: y as computed. */
+void orc_synth_g1_points(u64 seed, size_t n, u64* out_xy, int nthreads) {
+  const fld_t* f = fld_of(FID_FQ);
+  if (nthreads < 1) nthreads = 1;
+  u64 e[4], one[4] = {1, 0, 0, 0}, three[4] = {3, 0, 0, 0}, b3[4];
+  add_n(e, f->p, one, 4); /* (q+1)/4 */
+  for (int i = 0; i < 3; i++) e[i] = (e[i] >> 2) | (e[i + 1] << 62);
+  e[3] >>= 2;
+  f_tomont(f, b3, three);
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+  for (size_t i = 0; i < n; i++) {
+    u64 x[4], xm[4], rhs[4], y[4], y2[4];
+    orc_synth_element(FID_FQ, seed, i, x);
+    for (;;) {
+      f_tomont(f, xm, x);
+      f_mmul(f, rhs, xm, xm); f_mmul(f, rhs, rhs, xm); f_add(f, rhs, rhs, b3);
+      f_mpow(f, y, rhs, e, 4);
+      f_mmul(f, y2, y, y);
+      if (eq_n(y2, rhs, 4) && !is_zero_n(rhs, 4)) break;
+      f_add(f, x, x, one); /* x + 1 mod q */
+    }
+    memcpy(out_xy + 8 * i, x, 32);
+    f_frommont(f, out_xy + 8 * i + 4, y);
+  }
+}
