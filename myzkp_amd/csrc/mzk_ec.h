@@ -1,0 +1,210 @@
+// mzk_ec.h -- BN254 G1 group law for the MSM kernels (y^2 = x^3 + 3 over Fq, a = 0).
+//
+// The reference adds points in affine coordinates with one field inversion per operation
+// (EllipticCurvePoint::add_ref / double, myzkp/src/modules/algebra/curve/curve.rs:72-161).  The
+// kernels use inversion-free XYZZ coordinates (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2) and convert once at
+// the end; the group element -- hence the canonical affine output -- is identical.  Every special
+// case the reference distinguishes is kept explicit (curve.rs:104-115): inf + Q, P + inf,
+// P + P -> double, P + (-P) -> inf, so adversarial inputs (repeated points, P next to -P) agree.
+//
+// Bounds bookkeeping (units of p; "N" = normalised limbs, see mzk_field.h): coordinates of a stored
+// accumulator are N and < 2.5; fe_mul/fe_sqr outputs are N and < 2; fe_weak_reduce outputs are N and
+// < 2.01.  With rho = p/R ~ 2^-7.4 a product of inputs (va, vb) is < va*vb*rho + 1.
+#pragma once
+#include "mzk_field.h"
+
+namespace mzk {
+
+typedef Fe<FqParams> Fq;
+
+struct Affine { Fq x, y; };            // Montgomery form, canonical; never infinity in registers
+struct Xyzz { Fq X, Y, ZZ, ZZZ; };     // infinity <=> ZZ limbs all zero (written explicitly)
+
+MZK_HD bool xyzz_is_inf(const Xyzz& p) { return fe_is_zero_canon<FqParams>(p.ZZ); }
+MZK_HD Xyzz xyzz_inf() {
+  Xyzz r;
+  r.X = fe_zero<FqParams>(); r.Y = fe_zero<FqParams>(); r.ZZ = fe_zero<FqParams>(); r.ZZZ = fe_zero<FqParams>();
+  return r;
+}
+MZK_HD Xyzz xyzz_from_affine(const Affine& a) {
+  Xyzz r;
+  r.X = a.x; r.Y = a.y; r.ZZ = fe_one<FqParams>(); r.ZZZ = fe_one<FqParams>();
+  return r;
+}
+// -(x, y) = (x, p - y); y canonical and non-zero on this curve (no 2-torsion: the group order r is odd)
+MZK_HD Affine affine_neg(const Affine& a) {
+  Affine r;
+  r.x = a.x;
+  r.y = fe_neg_canon<FqParams>(a.y);
+  return r;
+}
+
+// 2 * (affine) -> XYZZ   (mdbl-2008-s-1, a = 0): 4M + 3S
+MZK_HD Xyzz xyzz_dbl_affine(const Affine& a) {
+  typedef FqParams P;
+  Xyzz r;
+  Fq U = fe_dbl<P>(a.y);                         // < 2, limbs < 2^30
+  Fq V = fe_sqr<P>(U);                           // < 1.03
+  Fq W = fe_mul<P>(U, V);                        // < 1.02
+  Fq S = fe_mul<P>(a.x, V);                      // < 1.01
+  Fq X2 = fe_sqr<P>(a.x);                        // < 1.01
+  Fq M = fe_carry<P>(fe_add<P>(fe_dbl<P>(X2), X2));  // 3 x^2 < 3.03, N
+  Fq MM = fe_sqr<P>(M);                          // < 1.06
+  Fq X3 = fe_weak_reduce<P>(fe_sub<P, 4>(fe_sub<P, 4>(MM, S), S));  // MM - 2S (+8p) -> < 2.01
+  Fq Vd = fe_carry<P>(fe_sub<P, 8>(S, X3));      // S - X3 (+8p) < 9.01, N
+  Fq A = fe_mul<P>(M, Vd);                       // < 1.17
+  Fq B = fe_mul<P>(W, a.y);                      // < 1.01
+  r.X = X3;
+  r.Y = fe_weak_reduce<P>(fe_sub<P, 4>(A, B));   // < 2.01
+  r.ZZ = V;
+  r.ZZZ = W;
+  return r;
+}
+
+// 2 * (XYZZ) -> XYZZ   (dbl-2008-s-1, a = 0): 6M + 3S.  inf -> inf.
+MZK_HD Xyzz xyzz_dbl(const Xyzz& p) {
+  typedef FqParams P;
+  if (xyzz_is_inf(p)) return p;
+  Xyzz r;
+  Fq U = fe_dbl<P>(p.Y);                         // < 5, limbs < 2^30
+  Fq V = fe_sqr<P>(U);                           // < 1.15
+  Fq W = fe_mul<P>(U, V);                        // < 1.04
+  Fq S = fe_mul<P>(p.X, V);                      // < 1.02
+  Fq X2 = fe_sqr<P>(p.X);                        // < 1.04
+  Fq M = fe_carry<P>(fe_add<P>(fe_dbl<P>(X2), X2));  // < 3.12, N
+  Fq MM = fe_sqr<P>(M);                          // < 1.06
+  Fq X3 = fe_weak_reduce<P>(fe_sub<P, 4>(fe_sub<P, 4>(MM, S), S));
+  Fq Vd = fe_carry<P>(fe_sub<P, 8>(S, X3));      // < 9.02
+  Fq A = fe_mul<P>(M, Vd);                       // < 1.17
+  Fq B = fe_mul<P>(W, p.Y);                      // < 1.02
+  r.X = X3;
+  r.Y = fe_weak_reduce<P>(fe_sub<P, 4>(A, B));
+  r.ZZ = fe_mul<P>(V, p.ZZ);
+  r.ZZZ = fe_mul<P>(W, p.ZZZ);
+  return r;
+}
+
+// acc + (affine q) -> XYZZ   (madd-2008-s): 8M + 2S.  Exception-complete.
+MZK_HD Xyzz xyzz_madd(const Xyzz& a, const Affine& q) {
+  typedef FqParams P;
+  if (xyzz_is_inf(a)) return xyzz_from_affine(q);
+  Fq U2 = fe_mul<P>(q.x, a.ZZ);                  // < 1.02
+  Fq S2 = fe_mul<P>(q.y, a.ZZZ);                 // < 1.02
+  Fq Pd = fe_carry<P>(fe_sub<P, 8>(U2, a.X));    // U2 - X1 (+8p) < 9.02, N
+  Fq Rd = fe_carry<P>(fe_sub<P, 8>(S2, a.Y));    // < 9.02, N
+  if (fe_is_zero_mod<P, 10>(Pd)) {               // same x: q == +-a   (curve.rs:111-115)
+    if (fe_is_zero_mod<P, 10>(Rd)) return xyzz_dbl_affine(q);
+    return xyzz_inf();
+  }
+  Xyzz r;
+  Fq PP = fe_sqr<P>(Pd);                         // < 1.49
+  Fq PPP = fe_mul<P>(Pd, PP);                    // < 1.08
+  Fq Q = fe_mul<P>(a.X, PP);                     // < 1.03
+  Fq RR = fe_sqr<P>(Rd);                         // < 1.49
+  Fq X3 = fe_weak_reduce<P>(fe_sub<P, 4>(fe_sub<P, 4>(fe_sub<P, 4>(RR, PPP), Q), Q));  // (+12p) < 13.5 -> < 2.01
+  Fq Vd = fe_carry<P>(fe_sub<P, 8>(Q, X3));      // < 9.03
+  Fq A = fe_mul<P>(Rd, Vd);                      // < 1.49
+  Fq B = fe_mul<P>(a.Y, PPP);                    // < 1.02
+  r.X = X3;
+  r.Y = fe_weak_reduce<P>(fe_sub<P, 4>(A, B));   // < 2.01
+  r.ZZ = fe_mul<P>(a.ZZ, PP);
+  r.ZZZ = fe_mul<P>(a.ZZZ, PPP);
+  return r;
+}
+
+// a + b, both XYZZ   (add-2008-s): 12M + 2S.  Exception-complete.
+MZK_HD Xyzz xyzz_add(const Xyzz& a, const Xyzz& b) {
+  typedef FqParams P;
+  if (xyzz_is_inf(a)) return b;
+  if (xyzz_is_inf(b)) return a;
+  Fq U1 = fe_mul<P>(a.X, b.ZZ);                  // < 1.04
+  Fq U2 = fe_mul<P>(b.X, a.ZZ);
+  Fq S1 = fe_mul<P>(a.Y, b.ZZZ);
+  Fq S2 = fe_mul<P>(b.Y, a.ZZZ);
+  Fq Pd = fe_carry<P>(fe_sub<P, 4>(U2, U1));     // < 5.04, N
+  Fq Rd = fe_carry<P>(fe_sub<P, 4>(S2, S1));
+  if (fe_is_zero_mod<P, 6>(Pd)) {
+    if (fe_is_zero_mod<P, 6>(Rd)) return xyzz_dbl(a);
+    return xyzz_inf();
+  }
+  Xyzz r;
+  Fq PP = fe_sqr<P>(Pd);                         // < 1.15
+  Fq PPP = fe_mul<P>(Pd, PP);                    // < 1.04
+  Fq Q = fe_mul<P>(U1, PP);                      // < 1.01
+  Fq RR = fe_sqr<P>(Rd);                         // < 1.15
+  Fq X3 = fe_weak_reduce<P>(fe_sub<P, 4>(fe_sub<P, 4>(fe_sub<P, 4>(RR, PPP), Q), Q));
+  Fq Vd = fe_carry<P>(fe_sub<P, 8>(Q, X3));      // < 9.02
+  Fq A = fe_mul<P>(Rd, Vd);                      // < 1.27
+  Fq B = fe_mul<P>(S1, PPP);                     // < 1.01
+  r.X = X3;
+  r.Y = fe_weak_reduce<P>(fe_sub<P, 4>(A, B));
+  r.ZZ = fe_mul<P>(fe_mul<P>(a.ZZ, b.ZZ), PP);
+  r.ZZZ = fe_mul<P>(fe_mul<P>(a.ZZZ, b.ZZZ), PPP);
+  return r;
+}
+
+// XYZZ -> canonical affine (Montgomery form); returns false for infinity.
+MZK_HD bool xyzz_to_affine(const Xyzz& p, Affine* out) {
+  typedef FqParams P;
+  if (xyzz_is_inf(p)) return false;
+  Fq d = fe_mul<P>(p.ZZ, p.ZZZ);
+  Fq di = fe_inv<P>(d);                          // 1 / (ZZ ZZZ)
+  Fq izz = fe_mul<P>(di, p.ZZZ);                 // 1 / ZZ
+  Fq izzz = fe_mul<P>(di, p.ZZ);                 // 1 / ZZZ
+  out->x = fe_reduce<P>(fe_mul<P>(p.X, izz));
+  out->y = fe_reduce<P>(fe_mul<P>(p.Y, izzz));
+  return true;
+}
+
+// ---- ABI <-> registers ------------------------------------------------------------------------
+// Affine point at the ABI: 16 u32 words x||y canonical, all-zero = infinity.
+MZK_HD bool affine_words_is_inf(const u32* w) {
+  u32 acc = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc |= w[i];
+  return acc == 0;
+}
+// canonical plain words -> Montgomery registers
+MZK_HD Affine affine_load_plain(const u32* w) {
+  Affine a;
+  a.x = fe_reduce<FqParams>(fe_to_mont<FqParams>(fe_unpack<FqParams>(w)));
+  a.y = fe_reduce<FqParams>(fe_to_mont<FqParams>(fe_unpack<FqParams>(w + 8)));
+  return a;
+}
+// Montgomery (canonical) words, as written by the point-preparation kernel
+MZK_HD Affine affine_load_mont(const u32* w) {
+  Affine a;
+  a.x = fe_unpack<FqParams>(w);
+  a.y = fe_unpack<FqParams>(w + 8);
+  return a;
+}
+MZK_HD void affine_store_mont(const Affine& a, u32* w) {
+  fe_pack<FqParams>(a.x, w);
+  fe_pack<FqParams>(a.y, w + 8);
+}
+MZK_HD void affine_store_plain(const Affine& a, u32* w) {
+  fe_pack<FqParams>(fe_from_mont<FqParams>(a.x), w);
+  fe_pack<FqParams>(fe_from_mont<FqParams>(a.y), w + 8);
+}
+// XYZZ in global memory: 4 x 8 words, each coordinate fully reduced (fits 256 bits); inf = zeros.
+MZK_HD void xyzz_store(const Xyzz& p, u32* w) {
+  if (xyzz_is_inf(p)) {
+#pragma unroll
+    for (int i = 0; i < 32; i++) w[i] = 0;
+    return;
+  }
+  fe_pack<FqParams>(fe_reduce<FqParams>(p.X), w);
+  fe_pack<FqParams>(fe_reduce<FqParams>(p.Y), w + 8);
+  fe_pack<FqParams>(fe_reduce<FqParams>(p.ZZ), w + 16);
+  fe_pack<FqParams>(fe_reduce<FqParams>(p.ZZZ), w + 24);
+}
+MZK_HD Xyzz xyzz_load(const u32* w) {
+  Xyzz p;
+  p.X = fe_unpack<FqParams>(w);
+  p.Y = fe_unpack<FqParams>(w + 8);
+  p.ZZ = fe_unpack<FqParams>(w + 16);
+  p.ZZZ = fe_unpack<FqParams>(w + 24);
+  return p;
+}
+
+}  // namespace mzk

@@ -227,12 +227,21 @@ template <class P> MZK_HD Fe<P> fe_cond_sub_p(const Fe<P>& x) {
 // P::TOPMAX (every value the kernels produce is far below that).  Mirrors Field::sanitize
 // (field.rs:260-270).  Quotient estimate q = floor(top * QM / 2^QS) <= floor(top / (Ptop+1))
 // <= floor(x / p), and q >= floor(x / p) - 2, so two conditional subtractions finish.
+template <class P> MZK_HD Fe<P> fe_weak_reduce(const Fe<P>& a);
 template <class P> MZK_HD Fe<P> fe_reduce(const Fe<P>& a) {
+  Fe<P> x = fe_weak_reduce<P>(a);
+  x = fe_cond_sub_p<P>(x);
+  x = fe_cond_sub_p<P>(x);
+  return x;
+}
+
+// Weak reduction: normalised limbs, same residue, value < 2.01 p.  Input: any limbs whose carried
+// top limb is below P::TOPMAX.
+template <class P> MZK_HD Fe<P> fe_weak_reduce(const Fe<P>& a) {
   constexpr int L = P::L;
   Fe<P> x = fe_carry<P>(a);
   MZK_ASSERT(x.l[L - 1] < P::TOPMAX);
   const u32 q = (u32)(((u64)x.l[L - 1] * P::QM) >> P::QS);
-  // Q = q * p as normalised limbs, then x - Q with a signed borrow chain (x >= Q).
   u64 acc = 0;
   i32 c = 0;
 #pragma unroll
@@ -249,8 +258,6 @@ template <class P> MZK_HD Fe<P> fe_reduce(const Fe<P>& a) {
     MZK_ASSERT(v >= 0 && v < ((int64_t)1 << 31));
     x.l[L - 1] = (u32)v;
   }
-  x = fe_cond_sub_p<P>(x);
-  x = fe_cond_sub_p<P>(x);
   return x;
 }
 
@@ -268,6 +275,16 @@ template <class P> MZK_HD bool fe_eq_canon(const Fe<P>& a, const Fe<P>& b) {
 }
 // value == 0 (mod p) for a lazily reduced value
 template <class P> MZK_HD bool fe_is_zero(const Fe<P>& a) { return fe_is_zero_canon<P>(fe_reduce<P>(a)); }
+
+// value == 0 (mod p)?  x normalised with value <= KMAX * p.  Cheap filter on limb 0 (x = k p exactly
+// for some k <= KMAX), full reduction only on a hit.
+template <class P, int KMAX> MZK_HD bool fe_is_zero_mod(const Fe<P>& x) {
+  bool maybe = false;
+#pragma unroll
+  for (int k = 0; k <= KMAX; k++) maybe |= (x.l[0] == (((u32)k * P::P[0]) & MASK29));
+  if (!maybe) return false;
+  return fe_is_zero_canon<P>(fe_reduce<P>(x));
+}
 
 // -x mod p for canonical x (canonical result).  Ring Neg, field.rs:296-303.
 template <class P> MZK_HD Fe<P> fe_neg_canon(const Fe<P>& x) {

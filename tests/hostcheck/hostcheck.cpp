@@ -1,0 +1,109 @@
+// Host build of the device arithmetic headers with bounds assertions (-DMZK_CHECK_BOUNDS).
+// TEST INFRASTRUCTURE: lets the CPU test-suite check the exact limb code the HIP kernels run
+// (29-bit-limb Montgomery field ops, XYZZ group law) against the oracle.  Never shipped.
+#include <stdint.h>
+#include <string.h>
+#include "../../myzkp_amd/csrc/mzk_ec.h"
+using namespace mzk;
+
+template <class P> static void run_field(int op, const u32* a, const u32* b, u32* out) {
+  Fe<P> x = fe_to_mont<P>(fe_unpack<P>(a));
+  Fe<P> y = fe_to_mont<P>(fe_unpack<P>(b));
+  Fe<P> r;
+  switch (op) {
+    case 0: r = fe_mul<P>(x, y); break;
+    case 1: r = fe_sqr<P>(x); break;
+    case 2: r = fe_add<P>(x, y); break;
+    case 3: r = fe_sub<P, 4>(x, fe_reduce<P>(y)); break;
+    case 4: r = fe_inv<P>(x); break;
+    case 5: r = fe_neg_canon<P>(fe_reduce<P>(x)); break;
+    case 6: {  // lazy chain stressing fe_weak_reduce: ((x+y)+(x+y)) + 16p - y ... then squared
+      Fe<P> s = fe_add<P>(x, y);
+      s = fe_carry<P>(fe_add<P>(s, s));
+      s = fe_sub<P, 16>(s, fe_reduce<P>(y));
+      r = fe_sqr<P>(fe_weak_reduce<P>(s));
+      break;
+    }
+    case 7: {  // plain-domain product by a Montgomery constant (the NTT trick): unpack(a) * mont(b)
+      r = fe_mul<P>(fe_unpack<P>(a), y);
+      fe_pack<P>(fe_reduce<P>(r), out);
+      return;
+    }
+    default: r = fe_zero<P>();
+  }
+  fe_pack<P>(fe_from_mont<P>(r), out);
+}
+
+extern "C" {
+// fid: 0 = Fr, 1 = M128, 2 = Fq.  Words are the ABI encoding (8 or 4 u32, canonical).
+int hc_field_op(int fid, int op, const u32* a, const u32* b, u32* out) {
+  if (fid == 0) run_field<FrParams>(op, a, b, out);
+  else if (fid == 1) run_field<M128Params>(op, a, b, out);
+  else if (fid == 2) run_field<FqParams>(op, a, b, out);
+  else return -1;
+  return 0;
+}
+// pack(unpack(w)) round trip
+int hc_pack_roundtrip(int fid, const u32* a, u32* out) {
+  if (fid == 1) fe_pack<M128Params>(fe_unpack<M128Params>(a), out);
+  else fe_pack<FrParams>(fe_unpack<FrParams>(a), out);
+  return 0;
+}
+static Xyzz load_pt(const u32* w) {
+  if (affine_words_is_inf(w)) return xyzz_inf();
+  return xyzz_from_affine(affine_load_plain(w));
+}
+static void store_pt(const Xyzz& p, u32* w) {
+  Affine a;
+  if (!xyzz_to_affine(p, &a)) { memset(w, 0, 64); return; }
+  affine_store_plain(a, w);
+}
+// op 0: madd (p XYZZ-ified + affine q), 1: add, 2: dbl(p), 3: dbl_affine(p)
+int hc_g1_op(int op, const u32* p, const u32* q, u32* out) {
+  Xyzz P = load_pt(p), R;
+  // scramble P's representation so ZZ != 1: P = (2P' - P') style is overkill; scale by lambda = 3:
+  if (!xyzz_is_inf(P)) {
+    Fq l = fe_to_mont<FqParams>(fe_unpack<FqParams>((const u32[]){3, 0, 0, 0, 0, 0, 0, 0}));
+    Fq l2 = fe_sqr<FqParams>(l), l3 = fe_mul<FqParams>(l2, l);
+    P.X = fe_mul<FqParams>(P.X, l2); P.Y = fe_mul<FqParams>(P.Y, l3);
+    P.ZZ = fe_mul<FqParams>(P.ZZ, l2); P.ZZZ = fe_mul<FqParams>(P.ZZZ, l3);
+  }
+  switch (op) {
+    case 0:
+      if (affine_words_is_inf(q)) R = P; else R = xyzz_madd(P, affine_load_plain(q));
+      break;
+    case 1: R = xyzz_add(P, load_pt(q)); break;
+    case 2: R = xyzz_dbl(P); break;
+    case 3: R = affine_words_is_inf(p) ? xyzz_inf() : xyzz_dbl_affine(affine_load_plain(p)); break;
+    default: return -1;
+  }
+  store_pt(R, out);
+  return 0;
+}
+// k * P by MSB-first double-and-madd over the kernel's XYZZ formulas (k: 8 u32 words)
+int hc_g1_mul(const u32* p, const u32* k, u32* out) {
+  Xyzz acc = xyzz_inf();
+  if (!affine_words_is_inf(p)) {
+    Affine a = affine_load_plain(p);
+    for (int i = 255; i >= 0; i--) {
+      acc = xyzz_dbl(acc);
+      if ((k[i >> 5] >> (i & 31)) & 1) acc = xyzz_madd(acc, a);
+    }
+  }
+  store_pt(acc, out);
+  return 0;
+}
+// sum of n affine points through madd, storing/reloading the accumulator through the packed
+// global-memory format every step (xyzz_store / xyzz_load)
+int hc_g1_sum(const u32* pts, int n, u32* out) {
+  u32 buf[32];
+  xyzz_store(xyzz_inf(), buf);
+  for (int i = 0; i < n; i++) {
+    Xyzz acc = xyzz_load(buf);
+    if (!affine_words_is_inf(pts + 16 * i)) acc = xyzz_madd(acc, affine_load_plain(pts + 16 * i));
+    xyzz_store(acc, buf);
+  }
+  store_pt(xyzz_load(buf), out);
+  return 0;
+}
+}

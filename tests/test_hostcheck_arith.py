@@ -1,0 +1,115 @@
+"""The device arithmetic headers (myzkp_amd/csrc/mzk_field.h, mzk_ec.h), compiled for the host with
+bounds assertions, against the oracle.  This checks the exact limb code the HIP kernels execute
+(29-bit-limb Montgomery ops, XYZZ group law incl. every exceptional case) without a GPU.  CPU only."""
+import ctypes, os, random, subprocess
+import numpy as np
+import pytest
+import orc
+from orc import FR, FQ, M128, P_FR, P_FQ, P_M128
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def hc():
+    src = os.path.join(HERE, "hostcheck", "hostcheck.cpp")
+    so = os.path.join(HERE, "hostcheck", "libhostcheck.so")
+    hdrs = [os.path.join(orc.ROOT, "myzkp_amd", "csrc", h) for h in ("mzk_field.h", "mzk_ec.h", "mzk_constants.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-DMZK_CHECK_BOUNDS", "-fPIC", "-shared", "-o", so, src])
+    return ctypes.CDLL(so)
+
+
+def w32(v, nw):
+    return np.array([(int(v) >> (32 * i)) & 0xFFFFFFFF for i in range(nw)], dtype=np.uint32)
+
+
+def from_w32(a):
+    return sum(int(x) << (32 * i) for i, x in enumerate(a))
+
+
+def fop(hc, fid, op, a, b):
+    nw = 4 if fid == M128 else 8
+    out = np.zeros(nw, dtype=np.uint32)
+    aa, bb = w32(a, nw), w32(b, nw)
+    assert hc.hc_field_op(fid, op, orc.ptr(aa), orc.ptr(bb), orc.ptr(out)) == 0
+    return from_w32(out)
+
+
+def test_field_ops_against_python(hc):
+    rng = random.Random(7)
+    for fid, p in ((FR, P_FR), (FQ, P_FQ), (M128, P_M128)):
+        edge = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (1 << (p.bit_length() - 1)) - 1]
+        vals = edge + [rng.randrange(p) for _ in range(150)]
+        for i, a in enumerate(vals):
+            b = vals[(i * 7 + 3) % len(vals)]
+            assert fop(hc, fid, 0, a, b) == a * b % p
+            assert fop(hc, fid, 1, a, b) == a * a % p
+            assert fop(hc, fid, 2, a, b) == (a + b) % p
+            assert fop(hc, fid, 3, a, b) == (a - b) % p
+            assert fop(hc, fid, 5, a, b) == (-a) % p
+            assert fop(hc, fid, 6, a, b) == pow(2 * (a + b) - b, 2, p)
+            assert fop(hc, fid, 7, a, b) == a * b % p
+            if i < 12:
+                assert fop(hc, fid, 4, a, b) == (pow(a, -1, p) if a else 0)
+                assert fop(hc, fid, 0, a, b) == orc.field_op("mul", fid, a, b)
+
+
+def test_pack_roundtrip(hc):
+    rng = random.Random(8)
+    for fid, nw, bits in ((FR, 8, 256), (M128, 4, 128)):
+        for _ in range(50):
+            v = rng.getrandbits(bits)
+            a, out = w32(v, nw), np.zeros(nw, dtype=np.uint32)
+            hc.hc_pack_roundtrip(fid, orc.ptr(a), orc.ptr(out))
+            assert from_w32(out) == v
+
+
+def ptw(P):
+    return np.concatenate([w32(P[0], 8), w32(P[1], 8)])
+
+
+def g1op(hc, op, P, Q=(0, 0)):
+    out = np.zeros(16, dtype=np.uint32)
+    p, q = ptw(P), ptw(Q)
+    assert hc.hc_g1_op(op, orc.ptr(p), orc.ptr(q), orc.ptr(out)) == 0
+    return (from_w32(out[:8]), from_w32(out[8:]))
+
+
+def test_group_law_and_exceptions(hc):
+    pts = orc.arr_to_pts(orc.synth_points(11, 12))
+    INF = (0, 0)
+    neg = lambda P: (P[0], (P_FQ - P[1]) % P_FQ)
+    cases = [(pts[0], pts[1]), (pts[2], pts[2]), (pts[3], neg(pts[3])), (INF, pts[4]), (pts[5], INF), (INF, INF),
+             (pts[6], pts[7]), ((1, 2), (1, 2)), ((1, 2), (1, P_FQ - 2))]
+    for P, Q in cases:
+        want = orc.ec_add(0, P, Q)
+        assert g1op(hc, 0, P, Q) == want, ("madd", P, Q)
+        assert g1op(hc, 1, P, Q) == want, ("add", P, Q)
+    for P in pts[:6] + [(1, 2), INF]:
+        want = orc.ec_mul(0, P, 2)
+        assert g1op(hc, 2, P) == want
+        assert g1op(hc, 3, P) == want
+
+
+def test_scalar_mul_through_xyzz(hc):
+    rng = random.Random(9)
+    ks = [0, 1, 2, P_FR - 1, P_FR, rng.randrange(P_FR), rng.randrange(P_FR)]
+    P = orc.arr_to_pts(orc.synth_points(3, 1))[0]
+    for k in ks:
+        out = np.zeros(16, dtype=np.uint32)
+        p, kk = ptw(P), w32(k, 8)
+        hc.hc_g1_mul(orc.ptr(p), orc.ptr(kk), orc.ptr(out))
+        assert (from_w32(out[:8]), from_w32(out[8:])) == orc.ec_mul(0, P, k)
+
+
+def test_running_sum_through_packed_storage(hc):
+    pts = orc.arr_to_pts(orc.synth_points(21, 40))
+    seq = pts[:10] + [pts[3], pts[3], (0, 0), (pts[5][0], P_FQ - pts[5][1])] + pts[10:]
+    arr = np.concatenate([ptw(P) for P in seq])
+    out = np.zeros(16, dtype=np.uint32)
+    hc.hc_g1_sum(orc.ptr(arr), len(seq), orc.ptr(out))
+    want = (0, 0)
+    for P in seq:
+        want = orc.ec_add(0, want, P)
+    assert (from_w32(out[:8]), from_w32(out[8:])) == want
