@@ -1,0 +1,117 @@
+/* mzk.h -- C ABI of the MI355X-native MSM / NTT prover path for MyZKP.
+ *
+ * The reference has no FFI for this path; this header defines the seam.  Each entry
+ * point names the reference call site it stands behind (paths relative to myzkp/src/modules/).
+ * A Rust maintainer binds these with an `extern "C"` block (INTEGRATION.md shows the shim).
+ *
+ * Conventions (taken from the reference's only device boundary, examples/sumcheck):
+ *   - field elements cross the boundary in STANDARD form as little-endian u64 limbs, canonical in
+ *     [0, p): 4 limbs for BN254 Fr/Fq, 2 limbs for M128      (examples/sumcheck/src/utils.rs:51-72)
+ *   - an affine G1 point is x||y (8 limbs); the all-zero encoding is the point at infinity
+ *     ((0,0) is not on y^2 = x^3 + 3)
+ *   - every function returns MZK_OK (0) or a negative MZK_E_* code; mzk_last_error() has the text.
+ *     The Rust shim asserts the reference's own preconditions first so that panic messages stay
+ *     identical (ntt.rs:8-23, curve.rs:174-176), then `expect()`s the status.
+ *   - blocking, one in-flight call per process (the reference is single-threaded); one process per
+ *     GPU.  The *_dev variants take device pointers + a hipStream_t and only enqueue work.
+ */
+#ifndef MZK_H
+#define MZK_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MZK_FIELD_FR = 0,   /* ModEIP197 / FqOrder: algebra/field.rs:428-431, curve/bn128.rs:30 */
+       MZK_FIELD_M128 = 1, /* M128 = 1 + 407*2^119: zkstark/fri.rs:408 */
+       MZK_FIELD_FQ = 2    /* BN128Modulus: curve/bn128.rs:19-22 (point coordinates only) */ };
+
+enum { MZK_OK = 0,
+       MZK_E_ARG = -1,        /* null pointer / bad field id */
+       MZK_E_NOT_POW2 = -2,   /* ntt.rs:8-11 "cannot compute ntt of non-power-of-two sequence" */
+       MZK_E_ROOT_ORDER = -3, /* ntt.rs:15-18 "primitive root must be nth root of unity" */
+       MZK_E_ROOT_PRIM = -4,  /* ntt.rs:19-22 "primitive root is not primitive nth root of unity" */
+       MZK_E_LENGTH = -5,     /* slice-index / usize-underflow panics (ntt.rs:265, polynomial.rs:162) */
+       MZK_E_RANGE = -6,      /* operand not canonical (>= modulus) where the ABI requires it */
+       MZK_E_HIP = -7,        /* HIP runtime error */
+       MZK_E_NOGPU = -8       /* no gfx950 device visible: there is NO CPU fallback */ };
+
+/* Select the device for this process, create streams/workspace.  Idempotent. */
+int mzk_init(int device_ordinal);
+void mzk_shutdown(void);
+const char* mzk_last_error(void);
+/* ABI version: bump on any signature change. */
+int mzk_abi_version(void);
+
+/* ---- NTT family ------------------------------------------------------------------------------- */
+/* ntt::ntt (algebra/ntt.rs:7-48) when inverse == 0: out[k] = sum_j in[j] * root^(j k), natural order
+ * in and out, n a power of two, root a primitive n-th root.  n <= 1 copies the input.
+ * ntt::intt (ntt.rs:50-64) when inverse != 0: n^-1 * ntt(root^-1, in); n == 1 copies the input.
+ * `root` is the forward root in both cases, exactly as the reference's callers pass it. */
+int mzk_ntt(int field_id, const uint64_t* root, const uint64_t* in, uint64_t* out, size_t n, int inverse);
+
+/* ntt::fast_coset_evaluate (ntt.rs:254-269) incl. Polynomial::scale (polynomial.rs:167-174):
+ * evaluations of the polynomial on { offset * generator^i : i < order }.  n_coef > order is the
+ * reference's usize underflow -> MZK_E_LENGTH. */
+int mzk_coset_lde(int field_id, const uint64_t* coef, size_t n_coef, const uint64_t* offset,
+                  const uint64_t* generator, uint64_t* out, size_t order);
+
+/* Polynomial::fft_multiply (polynomial.rs:242-276): omega must have order next_pow2(la+lb-1) (the
+ * reference does not check it; neither do we).  out holds la+lb-1 elements; *out_len = length after
+ * the reference's trailing-zero trim. */
+int mzk_fft_multiply(int field_id, const uint64_t* a, size_t la, const uint64_t* b, size_t lb,
+                     const uint64_t* omega, uint64_t* out, size_t* out_len);
+
+/* ntt::fast_multiply (ntt.rs:66-116): root of order root_order; picks the sub-root itself; schoolbook
+ * below degree 8; result NOT trimmed on the NTT path (length = chosen order).  out must hold
+ * max(root_order, la+lb) elements. */
+int mzk_fast_multiply(int field_id, const uint64_t* a, size_t la, const uint64_t* b, size_t lb,
+                      const uint64_t* root, size_t root_order, uint64_t* out, size_t* out_len);
+
+/* get_nth_root_of_m128 (zkstark/fri.rs:423-447) and the Fr analogue the reference lacks
+ * (omega_2^28 = 5^((r-1)/2^28)).  Pure host parameter math. */
+int mzk_root_of_unity(int field_id, unsigned log2_n, uint64_t* out);
+
+/* ---- MSM / KZG -------------------------------------------------------------------------------- */
+/* Polynomial::eval_with_powers_on_curve (algebra/polynomial.rs:156-165) = commit_kzg
+ * (algebra/kzg.rs:57-59): sum_i scalars[i] * points[i].  Scalars need not be canonical (the
+ * reference sanitizes, polynomial.rs:162): any 256-bit value is reduced mod r.  n == 0 -> infinity. */
+int mzk_msm_g1_bn254(const uint64_t* scalars, const uint64_t* points_xy, size_t n, uint64_t out_xy[8]);
+
+/* setup_kzg (kzg.rs:27-40), G1 part, trapdoor supplied by the caller: powers[i] = alpha^i * g1,
+ * i = 0..=max_d  ((max_d+1) * 8 limbs out). */
+int mzk_kzg_setup_g1(const uint64_t alpha[4], const uint64_t g1_xy[8], size_t max_d, uint64_t* powers_xy);
+
+/* open_kzg (kzg.rs:61-72): y = f(u); w = MSM((f - y)/(X - u), powers). */
+int mzk_kzg_open(const uint64_t* coef, size_t n, const uint64_t u[4], const uint64_t* powers_xy,
+                 uint64_t y[4], uint64_t w_xy[8]);
+
+/* Device-resident SRS for repeated commits against one PublicKeyKZG.powers_1 (kzg.rs:8-11). */
+typedef struct mzk_srs mzk_srs;
+int mzk_srs_upload(const uint64_t* powers_xy, size_t n, mzk_srs** out);
+void mzk_srs_free(mzk_srs* srs);
+int mzk_kzg_commit_srs(const mzk_srs* srs, const uint64_t* coef, size_t n, uint64_t out_xy[8]);
+
+/* ---- device-resident variants (inputs already in HBM; `stream` is a hipStream_t) --------------- */
+int mzk_ntt_dev(int field_id, const uint64_t* root_host, const void* d_in, void* d_out, size_t n,
+                int inverse, void* stream);
+int mzk_coset_lde_dev(int field_id, const void* d_coef, size_t n_coef, const uint64_t* offset_host,
+                      const uint64_t* generator_host, void* d_out, size_t order, void* stream);
+/* d_out_xy: 8 limbs on the device */
+int mzk_msm_g1_bn254_dev(const void* d_scalars, const void* d_points_xy, size_t n, void* d_out_xy, void* stream);
+/* Multi-GPU sharding (one process per GPU): each rank reduces its shard to one XYZZ partial
+ * (16 limbs, internal Montgomery encoding, opaque), the partials are exchanged with an all-gather
+ * (RCCL has no elliptic-curve reduction operator), and every rank folds them. */
+int mzk_msm_g1_bn254_partial_dev(const void* d_scalars, const void* d_points_xy, size_t n,
+                                 void* d_partial16, void* stream);
+int mzk_g1_fold_partials_dev(const void* d_partials16, int count, void* d_out_xy, void* stream);
+
+/* Deterministic synthetic inputs (bench + tests): bit-identical to the oracle's orc_synth_*. */
+int mzk_synth_field_dev(int field_id, uint64_t seed, size_t n, void* d_out, void* stream);
+int mzk_synth_g1_points_dev(uint64_t seed, size_t n, void* d_out_xy, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MZK_H */

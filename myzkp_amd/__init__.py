@@ -1,0 +1,15 @@
+"""myzkp_amd -- MI355X-native MSM / NTT prover path for MyZKP (Python binding of the C ABI, include/mzk.h).
+
+The product is the HIP library myzkp_amd/libmzk_hip.so; this module only marshals numpy limb arrays
+into it (ctypes).  There is no CPU fallback: importing works without a GPU (so the ABI can be
+inspected), but every compute call raises MzkError(MZK_E_NOGPU) unless a gfx950 device is present.
+"""
+from ._lib import (MzkError, lib, FIELD_FR, FIELD_M128, FIELD_FQ, LIMBS, MODULUS, init, shutdown,
+                   ntt, intt, coset_lde, fft_multiply, fast_multiply, root_of_unity, msm_g1,
+                   kzg_setup_g1, kzg_commit, kzg_open, Srs, to_limbs, from_limbs, points_to_array,
+                   array_to_points, exported_symbols, DECLARED_SYMBOLS)
+
+__all__ = ["MzkError", "lib", "FIELD_FR", "FIELD_M128", "FIELD_FQ", "LIMBS", "MODULUS", "init", "shutdown",
+           "ntt", "intt", "coset_lde", "fft_multiply", "fast_multiply", "root_of_unity", "msm_g1",
+           "kzg_setup_g1", "kzg_commit", "kzg_open", "Srs", "to_limbs", "from_limbs", "points_to_array",
+           "array_to_points", "exported_symbols", "DECLARED_SYMBOLS"]

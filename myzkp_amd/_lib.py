@@ -1,0 +1,219 @@
+"""ctypes loader + thin wrappers for include/mzk.h.  Arrays are numpy uint64, shape (n, limbs)."""
+import ctypes, os, re
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SO = os.path.join(HERE, "libmzk_hip.so")
+
+FIELD_FR, FIELD_M128, FIELD_FQ = 0, 1, 2
+LIMBS = {FIELD_FR: 4, FIELD_M128: 2, FIELD_FQ: 4}
+MODULUS = {
+    FIELD_FR: 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+    FIELD_M128: 270497897142230380135924736767050121217,
+    FIELD_FQ: 21888242871839275222246405745257275088696311157297823662689037894645226208583,
+}
+ERRORS = {0: "MZK_OK", -1: "MZK_E_ARG", -2: "MZK_E_NOT_POW2", -3: "MZK_E_ROOT_ORDER", -4: "MZK_E_ROOT_PRIM",
+          -5: "MZK_E_LENGTH", -6: "MZK_E_RANGE", -7: "MZK_E_HIP", -8: "MZK_E_NOGPU"}
+
+
+class MzkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERRORS.get(code, "?"), code, msg))
+        self.code = code
+        self.message = msg
+
+
+_lib = None
+
+
+def _declared_symbols():
+    hdr = os.path.join(ROOT, "include", "mzk.h")
+    txt = open(hdr).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mzk_[a-z0-9_]+)\s*\(", txt)))
+
+
+DECLARED_SYMBOLS = _declared_symbols()
+
+
+def lib():
+    """Load the HIP library; fail loudly if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            raise ImportError("myzkp_amd/libmzk_hip.so is missing: run `python -m myzkp_amd.build` "
+                              "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        _lib = ctypes.CDLL(SO)
+        _lib.mzk_last_error.restype = ctypes.c_char_p
+    return _lib
+
+
+def exported_symbols():
+    l = lib()
+    return [s for s in DECLARED_SYMBOLS if hasattr(l, s)]
+
+
+def _check(rc):
+    if rc != 0:
+        raise MzkError(rc, lib().mzk_last_error().decode())
+
+
+def init(device=0):
+    _check(lib().mzk_init(int(device)))
+
+
+def shutdown():
+    lib().mzk_shutdown()
+
+
+def to_limbs(vals, nl):
+    a = np.zeros((len(vals), nl), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        v = int(v)
+        for j in range(nl):
+            a[i, j] = (v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+    return a
+
+
+def from_limbs(a):
+    a = np.asarray(a, dtype=np.uint64)
+    a = a.reshape(-1, a.shape[-1])
+    return [sum(int(a[i, j]) << (64 * j) for j in range(a.shape[1])) for i in range(a.shape[0])]
+
+
+def points_to_array(pts):
+    a = np.zeros((len(pts), 8), dtype=np.uint64)
+    for i, p in enumerate(pts):
+        a[i, :4] = to_limbs([p[0]], 4)[0]
+        a[i, 4:] = to_limbs([p[1]], 4)[0]
+    return a
+
+
+def array_to_points(a):
+    a = np.asarray(a, dtype=np.uint64).reshape(-1, 8)
+    return [(from_limbs(a[i:i + 1, :4])[0], from_limbs(a[i:i + 1, 4:])[0]) for i in range(a.shape[0])]
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _one(fid, v):
+    return to_limbs([v], LIMBS[fid])
+
+
+def _arr(fid, a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a.reshape(-1, LIMBS[fid])
+
+
+def ntt(fid, root, values, inverse=False):
+    """ntt::ntt / ntt::intt (algebra/ntt.rs:7-64)."""
+    v = _arr(fid, values)
+    out = np.empty_like(v)
+    r = _one(fid, root)
+    _check(lib().mzk_ntt(fid, _p(r), _p(v), _p(out), ctypes.c_size_t(v.shape[0]), int(bool(inverse))))
+    return out
+
+
+def intt(fid, root, values):
+    return ntt(fid, root, values, inverse=True)
+
+
+def coset_lde(fid, coef, offset, generator, order):
+    """ntt::fast_coset_evaluate (algebra/ntt.rs:254-269)."""
+    c = _arr(fid, coef)
+    out = np.empty((order, LIMBS[fid]), dtype=np.uint64)
+    o, g = _one(fid, offset), _one(fid, generator)
+    _check(lib().mzk_coset_lde(fid, _p(c), ctypes.c_size_t(c.shape[0]), _p(o), _p(g), _p(out), ctypes.c_size_t(order)))
+    return out
+
+
+def fft_multiply(fid, a, b, omega):
+    """Polynomial::fft_multiply (algebra/polynomial.rs:242-276)."""
+    a, b = _arr(fid, a), _arr(fid, b)
+    out = np.zeros((max(a.shape[0] + b.shape[0], 1), LIMBS[fid]), dtype=np.uint64)
+    n = ctypes.c_size_t(0)
+    w = _one(fid, omega)
+    _check(lib().mzk_fft_multiply(fid, _p(a), ctypes.c_size_t(a.shape[0]), _p(b), ctypes.c_size_t(b.shape[0]), _p(w), _p(out), ctypes.byref(n)))
+    return out[:n.value]
+
+
+def fast_multiply(fid, a, b, root, root_order):
+    """ntt::fast_multiply (algebra/ntt.rs:66-116)."""
+    a, b = _arr(fid, a), _arr(fid, b)
+    out = np.zeros((max(root_order, a.shape[0] + b.shape[0], 1), LIMBS[fid]), dtype=np.uint64)
+    n = ctypes.c_size_t(0)
+    w = _one(fid, root)
+    _check(lib().mzk_fast_multiply(fid, _p(a), ctypes.c_size_t(a.shape[0]), _p(b), ctypes.c_size_t(b.shape[0]), _p(w),
+                                   ctypes.c_size_t(root_order), _p(out), ctypes.byref(n)))
+    return out[:n.value]
+
+
+def root_of_unity(fid, log2n):
+    out = np.zeros((1, LIMBS[fid]), dtype=np.uint64)
+    _check(lib().mzk_root_of_unity(fid, int(log2n), _p(out)))
+    return from_limbs(out)[0]
+
+
+def msm_g1(scalars, points):
+    """Polynomial::eval_with_powers_on_curve (algebra/polynomial.rs:156-165) / commit_kzg (kzg.rs:57-59)."""
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    p = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+    if p.shape[0] < s.shape[0]:
+        raise MzkError(-5, "index out of bounds: the len is %d but the index is %d" % (p.shape[0], p.shape[0]))
+    out = np.zeros((1, 8), dtype=np.uint64)
+    _check(lib().mzk_msm_g1_bn254(_p(s), _p(p), ctypes.c_size_t(s.shape[0]), _p(out)))
+    return array_to_points(out)[0]
+
+
+kzg_commit = msm_g1
+
+
+def kzg_setup_g1(alpha, max_d, g1=(1, 2)):
+    """setup_kzg (algebra/kzg.rs:27-40), G1 powers for a caller-supplied trapdoor."""
+    out = np.zeros((max_d + 1, 8), dtype=np.uint64)
+    a, g = _one(FIELD_FR, alpha), points_to_array([g1])
+    _check(lib().mzk_kzg_setup_g1(_p(a), _p(g), ctypes.c_size_t(max_d), _p(out)))
+    return out
+
+
+def kzg_open(coef, u, powers):
+    """open_kzg (algebra/kzg.rs:61-72) -> (y, w)."""
+    c = np.ascontiguousarray(coef, dtype=np.uint64).reshape(-1, 4)
+    p = np.ascontiguousarray(powers, dtype=np.uint64).reshape(-1, 8)
+    if c.shape[0] > 1 and p.shape[0] < c.shape[0] - 1:
+        raise MzkError(-5, "index out of bounds: the len is %d but the index is %d" % (p.shape[0], p.shape[0]))
+    y = np.zeros((1, 4), dtype=np.uint64)
+    w = np.zeros((1, 8), dtype=np.uint64)
+    uu = _one(FIELD_FR, u)
+    _check(lib().mzk_kzg_open(_p(c), ctypes.c_size_t(c.shape[0]), _p(uu), _p(p), _p(y), _p(w)))
+    return from_limbs(y)[0], array_to_points(w)[0]
+
+
+class Srs:
+    """Device-resident PublicKeyKZG.powers_1 (algebra/kzg.rs:8-11) for repeated commits."""
+
+    def __init__(self, powers):
+        p = np.ascontiguousarray(powers, dtype=np.uint64).reshape(-1, 8)
+        self._h = ctypes.c_void_p()
+        self.n = p.shape[0]
+        _check(lib().mzk_srs_upload(_p(p), ctypes.c_size_t(self.n), ctypes.byref(self._h)))
+
+    def commit(self, coef):
+        c = np.ascontiguousarray(coef, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros((1, 8), dtype=np.uint64)
+        _check(lib().mzk_kzg_commit_srs(self._h, _p(c), ctypes.c_size_t(c.shape[0]), _p(out)))
+        return array_to_points(out)[0]
+
+    def close(self):
+        if self._h:
+            lib().mzk_srs_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,467 @@
+// mzk_api.hip -- process context, host-side parameter math, and the host-buffer entry points of
+// include/mzk.h (H2D copy -> device implementation -> D2H copy, as the reference's only device
+// boundary does: examples/sumcheck/src/prover.rs:149-170).
+#include <stdarg.h>
+#include <stdlib.h>
+#include "mzk_common.h"
+
+namespace mzk {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+  return MZK_E_HIP;
+}
+
+static Context g_ctx;
+Context& ctx() { return g_ctx; }
+
+struct WsBuf { void* p = nullptr; size_t cap = 0; };
+static WsBuf g_ws[WS_COUNT];
+
+int ws_get(WsSlot slot, size_t bytes, void** out) {
+  WsBuf& b = g_ws[slot];
+  if (bytes > b.cap) {
+    if (b.p) {
+      MZK_HIP(hipDeviceSynchronize());
+      MZK_HIP(hipFree(b.p));
+      b.p = nullptr; b.cap = 0;
+    }
+    size_t cap = bytes < 4096 ? 4096 : bytes;
+    MZK_HIP(hipMalloc(&b.p, cap));
+    b.cap = cap;
+  }
+  *out = b.p;
+  return MZK_OK;
+}
+void ws_release_all() {
+  for (auto& b : g_ws) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.cap = 0;
+  }
+}
+
+int ensure_init() {
+  if (g_ctx.ready) return MZK_OK;
+  return mzk_init(g_ctx.device >= 0 ? g_ctx.device : 0);
+}
+
+// ---- host parameter math --------------------------------------------------------------------------
+static const HostField HF_FR = {4, {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}};
+static const HostField HF_FQ = {4, {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}};
+static const HostField HF_M128 = {2, {1ULL, 407ULL << 55, 0, 0}};
+const HostField* host_field(int fid) {
+  switch (fid) {
+    case MZK_FIELD_FR: return &HF_FR;
+    case MZK_FIELD_M128: return &HF_M128;
+    case MZK_FIELD_FQ: return &HF_FQ;
+    default: return nullptr;
+  }
+}
+static int h_cmp(const uint64_t* a, const uint64_t* b, int n) {
+  for (int i = n - 1; i >= 0; i--) if (a[i] != b[i]) return a[i] > b[i] ? 1 : -1;
+  return 0;
+}
+bool h_is_canonical(const HostField* f, const uint64_t* a) { return h_cmp(a, f->p, f->nl) < 0; }
+bool h_is_one(const HostField* f, const uint64_t* a) {
+  if (a[0] != 1) return false;
+  for (int i = 1; i < f->nl; i++) if (a[i]) return false;
+  return true;
+}
+static void h_addmod(const HostField* f, uint64_t* r, const uint64_t* a, const uint64_t* b) {
+  uint64_t t[4] = {0, 0, 0, 0};
+  unsigned __int128 c = 0;
+  for (int i = 0; i < f->nl; i++) { c += (unsigned __int128)a[i] + b[i]; t[i] = (uint64_t)c; c >>= 64; }
+  if (c || h_cmp(t, f->p, f->nl) >= 0) {
+    unsigned __int128 br = 0;
+    for (int i = 0; i < f->nl; i++) {
+      unsigned __int128 d = (unsigned __int128)t[i] - f->p[i] - (uint64_t)br;
+      t[i] = (uint64_t)d; br = (d >> 64) & 1;
+    }
+  }
+  for (int i = 0; i < f->nl; i++) r[i] = t[i];
+}
+// double-and-add product: O(bits) modular additions; only ever used for O(log n) parameter values
+void h_mulmod(const HostField* f, uint64_t* r, const uint64_t* a, const uint64_t* b) {
+  uint64_t acc[4] = {0, 0, 0, 0}, aa[4] = {0, 0, 0, 0}, bb[4] = {0, 0, 0, 0};
+  for (int i = 0; i < f->nl; i++) { aa[i] = a[i]; bb[i] = b[i]; }
+  for (int bit = 64 * f->nl - 1; bit >= 0; bit--) {
+    h_addmod(f, acc, acc, acc);
+    if ((bb[bit / 64] >> (bit % 64)) & 1) h_addmod(f, acc, acc, aa);
+  }
+  for (int i = 0; i < f->nl; i++) r[i] = acc[i];
+}
+void h_powmod_u64(const HostField* f, uint64_t* r, const uint64_t* a, uint64_t e) {
+  uint64_t res[4] = {1, 0, 0, 0}, base[4] = {0, 0, 0, 0};
+  for (int i = 0; i < f->nl; i++) base[i] = a[i];
+  while (e) {
+    if (e & 1) h_mulmod(f, res, res, base);
+    h_mulmod(f, base, base, base);
+    e >>= 1;
+  }
+  for (int i = 0; i < f->nl; i++) r[i] = res[i];
+}
+// n = 2^k divides p - 1:  n * ((p-1)/n) = -1 (mod p)  =>  n^-1 = p - (p-1)/n
+void h_ninv_pow2(const HostField* f, unsigned k, uint64_t* out) {
+  uint64_t q[4] = {0, 0, 0, 0};
+  for (int i = 0; i < f->nl; i++) q[i] = f->p[i];
+  q[0] -= 1;  // p is odd
+  for (unsigned s = 0; s < k; s++) {
+    for (int i = 0; i < f->nl; i++) q[i] = (q[i] >> 1) | ((i + 1 < f->nl) ? (q[i + 1] << 63) : 0);
+  }
+  unsigned __int128 br = 0;
+  for (int i = 0; i < f->nl; i++) {
+    unsigned __int128 d = (unsigned __int128)f->p[i] - q[i] - (uint64_t)br;
+    out[i] = (uint64_t)d; br = (d >> 64) & 1;
+  }
+}
+
+}  // namespace mzk
+
+using namespace mzk;
+
+extern "C" {
+
+int mzk_abi_version(void) { return 1; }
+const char* mzk_last_error(void) { return g_err; }
+
+int mzk_init(int device_ordinal) {
+  if (g_ctx.ready && g_ctx.device == device_ordinal) return MZK_OK;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    set_error("no HIP device visible (hipGetDeviceCount: %s); this library has no CPU fallback",
+              e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    return MZK_E_NOGPU;
+  }
+  if (device_ordinal < 0 || device_ordinal >= count) { set_error("mzk_init: device %d out of range (%d visible)", device_ordinal, count); return MZK_E_ARG; }
+  MZK_HIP(hipSetDevice(device_ordinal));
+  hipDeviceProp_t prop;
+  MZK_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device_ordinal, prop.gcnArchName);
+    return MZK_E_NOGPU;
+  }
+  if (g_ctx.ready) mzk_shutdown();
+  g_ctx.device = device_ordinal;
+  g_ctx.num_cu = prop.multiProcessorCount;
+  MZK_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+  g_ctx.ready = true;
+  return MZK_OK;
+}
+
+void mzk_shutdown(void) {
+  if (!g_ctx.ready) return;
+  (void)hipDeviceSynchronize();
+  ntt_release_plans();
+  ws_release_all();
+  if (g_ctx.stream) (void)hipStreamDestroy(g_ctx.stream);
+  g_ctx.stream = nullptr;
+  g_ctx.ready = false;
+}
+
+int mzk_root_of_unity(int field_id, unsigned log2_n, uint64_t* out) {
+  if (!out) { set_error("root_of_unity: null pointer"); return MZK_E_ARG; }
+  const HostField* f = host_field(field_id);
+  if (field_id == MZK_FIELD_M128) {
+    // get_nth_root_of_m128, zkstark/fri.rs:423-447
+    if (log2_n > 119) { set_error("Field does not have nth root of unity where n > 2^119 or not power of two."); return MZK_E_ARG; }
+    uint64_t r[4] = {0xb5038f9c18f6f7d1ULL, 0x4040fbed12ee470fULL, 0, 0};  // 85408008396924667383611388730472331217
+    for (unsigned o = 119; o > log2_n; o--) h_mulmod(f, r, r, r);
+    out[0] = r[0]; out[1] = r[1];
+    return MZK_OK;
+  }
+  if (field_id == MZK_FIELD_FR) {
+    // omega_2^28 = 5^((r-1)/2^28); the reference ships no Fr root helper
+    if (log2_n > 28) { set_error("Fr has 2-adicity 28"); return MZK_E_ARG; }
+    uint64_t r[4] = {0x9bd61b6e725b19f0ULL, 0x402d111e41112ed4ULL, 0x00e0a7eb8ef62abcULL, 0x2a3c09f0a58a7e85ULL};
+    for (unsigned o = 28; o > log2_n; o--) h_mulmod(f, r, r, r);
+    for (int i = 0; i < 4; i++) out[i] = r[i];
+    return MZK_OK;
+  }
+  set_error("root_of_unity: bad field id %d", field_id);
+  return MZK_E_ARG;
+}
+
+// ---- host-buffer NTT family ---------------------------------------------------------------------------
+static int stage_in(WsSlot slot, const void* host, size_t bytes, void** dev, hipStream_t s) {
+  MZK_TRY(ws_get(slot, bytes ? bytes : 16, dev));
+  if (bytes) MZK_HIP(hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, s));
+  return MZK_OK;
+}
+
+int mzk_ntt(int field_id, const uint64_t* root, const uint64_t* in, uint64_t* out, size_t n, int inverse) {
+  MZK_TRY(ensure_init());
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("ntt: bad field id %d", field_id); return MZK_E_ARG; }
+  if (n == 0) return MZK_OK;
+  if (!in || !out) { set_error("ntt: null pointer"); return MZK_E_ARG; }
+  hipStream_t s = g_ctx.stream;
+  const size_t bytes = n * field_bytes(field_id);
+  void *d_in, *d_out;
+  MZK_TRY(stage_in(WS_NTT_IO_A, in, bytes, &d_in, s));
+  MZK_TRY(ws_get(WS_NTT_IO_B, bytes, &d_out));
+  MZK_TRY(ntt_dev_impl(field_id, root, d_in, d_out, n, inverse, nullptr, s));
+  MZK_HIP(hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  return MZK_OK;
+}
+
+int mzk_ntt_dev(int field_id, const uint64_t* root_host, const void* d_in, void* d_out, size_t n, int inverse, void* stream) {
+  MZK_TRY(ensure_init());
+  return ntt_dev_impl(field_id, root_host, d_in, d_out, n, inverse, nullptr, (hipStream_t)stream);
+}
+
+int mzk_coset_lde(int field_id, const uint64_t* coef, size_t n_coef, const uint64_t* offset, const uint64_t* generator,
+                  uint64_t* out, size_t order) {
+  MZK_TRY(ensure_init());
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("coset_lde: bad field id %d", field_id); return MZK_E_ARG; }
+  if (n_coef > order) { set_error("attempt to subtract with overflow (order - polynomial.coef.len())"); return MZK_E_LENGTH; }
+  if (order == 0) return MZK_OK;
+  if (!out || (!coef && n_coef)) { set_error("coset_lde: null pointer"); return MZK_E_ARG; }
+  hipStream_t s = g_ctx.stream;
+  const size_t esz = field_bytes(field_id);
+  void *d_coef, *d_out;
+  MZK_TRY(stage_in(WS_MISC_A, coef, n_coef * esz, &d_coef, s));
+  MZK_TRY(ws_get(WS_NTT_IO_B, order * esz, &d_out));
+  MZK_TRY(coset_lde_dev_impl(field_id, d_coef, n_coef, offset, generator, d_out, order, s));
+  MZK_HIP(hipMemcpyAsync(out, d_out, order * esz, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  return MZK_OK;
+}
+
+int mzk_coset_lde_dev(int field_id, const void* d_coef, size_t n_coef, const uint64_t* offset_host,
+                      const uint64_t* generator_host, void* d_out, size_t order, void* stream) {
+  MZK_TRY(ensure_init());
+  return coset_lde_dev_impl(field_id, d_coef, n_coef, offset_host, generator_host, d_out, order, (hipStream_t)stream);
+}
+
+static size_t trimmed_len(const uint64_t* c, size_t n, int nl) {
+  while (n > 0) {
+    uint64_t acc = 0;
+    for (int i = 0; i < nl; i++) acc |= c[(n - 1) * nl + i];
+    if (acc) break;
+    n--;
+  }
+  return n;
+}
+
+// zero-pad two host polynomials to `order` on the device, forward-transform both, Hadamard, inverse.
+static int conv_on_device(int fid, const uint64_t* a, size_t la, const uint64_t* b, size_t lb, const uint64_t* root,
+                          size_t order, void** d_result, hipStream_t s) {
+  const size_t esz = field_bytes(fid);
+  void *da, *db, *dc;
+  MZK_TRY(ws_get(WS_MISC_A, order * esz, &da));
+  MZK_TRY(ws_get(WS_MISC_B, order * esz, &db));
+  MZK_TRY(ws_get(WS_MISC_C, order * esz, &dc));
+  MZK_HIP(hipMemsetAsync(da, 0, order * esz, s));
+  MZK_HIP(hipMemsetAsync(db, 0, order * esz, s));
+  if (la) MZK_HIP(hipMemcpyAsync(da, a, la * esz, hipMemcpyHostToDevice, s));
+  if (lb) MZK_HIP(hipMemcpyAsync(db, b, lb * esz, hipMemcpyHostToDevice, s));
+  MZK_TRY(ntt_dev_impl(fid, root, da, da, order, 0, nullptr, s));
+  MZK_TRY(ntt_dev_impl(fid, root, db, db, order, 0, nullptr, s));
+  MZK_TRY(pointwise_mul_dev(fid, da, db, dc, order, s));
+  MZK_TRY(ntt_dev_impl(fid, root, dc, dc, order, 1, nullptr, s));
+  *d_result = dc;
+  return MZK_OK;
+}
+
+int mzk_fft_multiply(int field_id, const uint64_t* a, size_t la, const uint64_t* b, size_t lb, const uint64_t* omega,
+                     uint64_t* out, size_t* out_len) {
+  MZK_TRY(ensure_init());
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fft_multiply: bad field id %d", field_id); return MZK_E_ARG; }
+  if (!out_len || (!a && la) || (!b && lb)) { set_error("fft_multiply: null pointer"); return MZK_E_ARG; }
+  if (la + lb == 0) { set_error("attempt to subtract with overflow (self.coef.len() + other.coef.len() - 1)"); return MZK_E_LENGTH; }
+  const size_t m = la + lb - 1;
+  size_t n = 1;
+  while (n < m) n <<= 1;
+  const int nl = field_limbs64(field_id);
+  hipStream_t s = g_ctx.stream;
+  const size_t esz = field_bytes(field_id);
+  if (m == 0) { *out_len = 0; return MZK_OK; }
+  if (!out) { set_error("fft_multiply: null pointer"); return MZK_E_ARG; }
+  std::vector<uint64_t> res(n * nl);
+  if (n == 1) {
+    // 1x1 product: the reference's fft() of length 1 is the identity; c[0] = a[0] * b[0] * 1^-1
+    void *da, *db, *dc;
+    MZK_TRY(stage_in(WS_MISC_A, a, la * esz, &da, s));
+    MZK_TRY(stage_in(WS_MISC_B, b, lb * esz, &db, s));
+    MZK_TRY(ws_get(WS_MISC_C, esz, &dc));
+    if (la == 0 || lb == 0) { *out_len = 0; return MZK_OK; }
+    MZK_TRY(pointwise_mul_dev(field_id, da, db, dc, 1, s));
+    MZK_HIP(hipMemcpyAsync(res.data(), dc, esz, hipMemcpyDeviceToHost, s));
+    MZK_HIP(hipStreamSynchronize(s));
+  } else {
+    if (!omega) { set_error("fft_multiply: null omega"); return MZK_E_ARG; }
+    void* dc;
+    MZK_TRY(conv_on_device(field_id, a, la, b, lb, omega, n, &dc, s));
+    MZK_HIP(hipMemcpyAsync(res.data(), dc, n * esz, hipMemcpyDeviceToHost, s));
+    MZK_HIP(hipStreamSynchronize(s));
+  }
+  size_t lo = trimmed_len(res.data(), m, nl);  // truncate(m) then trim_trailing_zeros, polynomial.rs:271-275
+  memcpy(out, res.data(), lo * esz);
+  *out_len = lo;
+  return MZK_OK;
+}
+
+int mzk_fast_multiply(int field_id, const uint64_t* a, size_t la, const uint64_t* b, size_t lb, const uint64_t* root,
+                      size_t root_order, uint64_t* out, size_t* out_len) {
+  MZK_TRY(ensure_init());
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fast_multiply: bad field id %d", field_id); return MZK_E_ARG; }
+  if (!out_len || !root || (!a && la) || (!b && lb)) { set_error("fast_multiply: null pointer"); return MZK_E_ARG; }
+  const HostField* hf = host_field(field_id);
+  const int nl = hf->nl;
+  if (!h_is_canonical(hf, root)) { set_error("fast_multiply: root not canonical"); return MZK_E_RANGE; }
+  uint64_t t[4];
+  h_powmod_u64(hf, t, root, root_order);  // ntt.rs:75-76
+  if (!h_is_one(hf, t)) { set_error("assertion failed: primitive_root.pow(root_order).is_one()"); return MZK_E_ROOT_ORDER; }
+  h_powmod_u64(hf, t, root, root_order / 2);
+  if (h_is_one(hf, t)) { set_error("assertion failed: !primitive_root.pow(root_order / 2).is_one()"); return MZK_E_ROOT_PRIM; }
+  const size_t da = trimmed_len(a, la, nl), db = trimmed_len(b, lb, nl);
+  if (da == 0 || db == 0) { *out_len = 0; return MZK_OK; }  // ntt.rs:78-80
+  const size_t degree = (da - 1) + (db - 1);
+  hipStream_t s = g_ctx.stream;
+  const size_t esz = field_bytes(field_id);
+  if (!out) { set_error("fast_multiply: null pointer"); return MZK_E_ARG; }
+  uint64_t r[4] = {0, 0, 0, 0};
+  memcpy(r, root, 8 * nl);
+  size_t order;
+  bool trim;
+  if (degree < 8) {
+    // ntt.rs:86-88 `return lhs * rhs` (schoolbook, trimmed).  Same product through a 16-point cyclic
+    // convolution (degree < 8 < 16, so no wrap-around), then trimmed like Polynomial::mul_ref.
+    order = 16;
+    if (field_id == MZK_FIELD_M128) MZK_TRY(mzk_root_of_unity(field_id, 4, r)); else MZK_TRY(mzk_root_of_unity(field_id, 4, r));
+    trim = true;
+    la = da; lb = db;
+  } else {
+    order = root_order;
+    while (degree < order / 2) { h_mulmod(hf, r, r, r); order /= 2; }  // ntt.rs:90-93
+    if (la > order || lb > order) { set_error("fast_multiply: operand longer than the transform order"); return MZK_E_LENGTH; }
+    trim = false;
+  }
+  void* dc;
+  MZK_TRY(conv_on_device(field_id, a, la, b, lb, r, order, &dc, s));
+  std::vector<uint64_t> res(order * nl);
+  MZK_HIP(hipMemcpyAsync(res.data(), dc, order * esz, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  size_t lo = trim ? trimmed_len(res.data(), da + db - 1, nl) : order;
+  memcpy(out, res.data(), lo * esz);
+  *out_len = lo;
+  return MZK_OK;
+}
+
+// ---- MSM / KZG ---------------------------------------------------------------------------------------------
+struct mzk_srs {
+  void* d_points_mont;
+  size_t n;
+};
+
+int mzk_msm_g1_bn254(const uint64_t* scalars, const uint64_t* points_xy, size_t n, uint64_t out_xy[8]) {
+  MZK_TRY(ensure_init());
+  if (!out_xy || ((!scalars || !points_xy) && n)) { set_error("msm: null pointer"); return MZK_E_ARG; }
+  hipStream_t s = g_ctx.stream;
+  void *d_s, *d_p, *d_o;
+  MZK_TRY(stage_in(WS_MSM_SCALARS, scalars, n * 32, &d_s, s));
+  MZK_TRY(stage_in(WS_MISC_A, points_xy, n * 64, &d_p, s));
+  MZK_TRY(ws_get(WS_MISC_B, 256, &d_o));
+  MZK_TRY(msm_dev_impl(d_s, d_p, n, false, d_o, false, s));
+  MZK_HIP(hipMemcpyAsync(out_xy, d_o, 64, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  return MZK_OK;
+}
+int mzk_msm_g1_bn254_dev(const void* d_scalars, const void* d_points_xy, size_t n, void* d_out_xy, void* stream) {
+  MZK_TRY(ensure_init());
+  return msm_dev_impl(d_scalars, d_points_xy, n, false, d_out_xy, false, (hipStream_t)stream);
+}
+int mzk_msm_g1_bn254_partial_dev(const void* d_scalars, const void* d_points_xy, size_t n, void* d_partial16, void* stream) {
+  MZK_TRY(ensure_init());
+  return msm_dev_impl(d_scalars, d_points_xy, n, false, d_partial16, true, (hipStream_t)stream);
+}
+int mzk_g1_fold_partials_dev(const void* d_partials16, int count, void* d_out_xy, void* stream) {
+  MZK_TRY(ensure_init());
+  return msm_fold_partials_impl(d_partials16, count, d_out_xy, (hipStream_t)stream);
+}
+
+int mzk_srs_upload(const uint64_t* powers_xy, size_t n, mzk_srs** out) {
+  MZK_TRY(ensure_init());
+  if (!out || (!powers_xy && n)) { set_error("srs_upload: null pointer"); return MZK_E_ARG; }
+  hipStream_t s = g_ctx.stream;
+  mzk_srs* h = new mzk_srs{nullptr, n};
+  if (n) {
+    void* d_plain;
+    if (hipMalloc(&h->d_points_mont, n * 64) != hipSuccess) { delete h; set_error("srs_upload: hipMalloc failed"); return MZK_E_HIP; }
+    int rc = stage_in(WS_MISC_A, powers_xy, n * 64, &d_plain, s);
+    if (rc == MZK_OK) rc = msm_prepare_points(d_plain, n, h->d_points_mont, s);
+    if (rc == MZK_OK && hipStreamSynchronize(s) != hipSuccess) rc = MZK_E_HIP;
+    if (rc != MZK_OK) { (void)hipFree(h->d_points_mont); delete h; return rc; }
+  }
+  *out = h;
+  return MZK_OK;
+}
+void mzk_srs_free(mzk_srs* srs) {
+  if (!srs) return;
+  if (srs->d_points_mont) (void)hipFree(srs->d_points_mont);
+  delete srs;
+}
+int mzk_kzg_commit_srs(const mzk_srs* srs, const uint64_t* coef, size_t n, uint64_t out_xy[8]) {
+  MZK_TRY(ensure_init());
+  if (!srs || !out_xy || (!coef && n)) { set_error("commit_srs: null pointer"); return MZK_E_ARG; }
+  if (n > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }  // powers[i], polynomial.rs:162
+  hipStream_t s = g_ctx.stream;
+  void *d_s, *d_o;
+  MZK_TRY(stage_in(WS_MSM_SCALARS, coef, n * 32, &d_s, s));
+  MZK_TRY(ws_get(WS_MISC_B, 256, &d_o));
+  MZK_TRY(msm_dev_impl(d_s, srs->d_points_mont, n, true, d_o, false, s));
+  MZK_HIP(hipMemcpyAsync(out_xy, d_o, 64, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  return MZK_OK;
+}
+
+int mzk_kzg_setup_g1(const uint64_t alpha[4], const uint64_t g1_xy[8], size_t max_d, uint64_t* powers_xy) {
+  MZK_TRY(ensure_init());
+  if (!alpha || !g1_xy || !powers_xy) { set_error("kzg_setup: null pointer"); return MZK_E_ARG; }
+  hipStream_t s = g_ctx.stream;
+  const size_t count = max_d + 1;  // `for _ in 0..1 + max_d`, kzg.rs:32
+  void* d_p;
+  MZK_TRY(ws_get(WS_MSM_POINTS, count * 64, &d_p));
+  MZK_TRY(kzg_setup_g1_dev(alpha, g1_xy, count, d_p, s));
+  MZK_HIP(hipMemcpyAsync(powers_xy, d_p, count * 64, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  return MZK_OK;
+}
+
+int mzk_kzg_open(const uint64_t* coef, size_t n, const uint64_t u[4], const uint64_t* powers_xy, uint64_t y[4], uint64_t w_xy[8]) {
+  MZK_TRY(ensure_init());
+  if (!u || !y || !w_xy || (!coef && n) || (!powers_xy && n > 1)) { set_error("kzg_open: null pointer"); return MZK_E_ARG; }
+  hipStream_t s = g_ctx.stream;
+  void *d_c, *d_p, *d_o;
+  MZK_TRY(stage_in(WS_MSM_SCALARS, coef, n * 32, &d_c, s));
+  MZK_TRY(stage_in(WS_NTT_IO_A, powers_xy, (n > 1 ? n - 1 : 0) * 64, &d_p, s));
+  MZK_TRY(ws_get(WS_NTT_IO_B, 256, &d_o));
+  MZK_TRY(kzg_open_dev(d_c, n, u, d_p, false, d_o, (char*)d_o + 64, s));
+  uint64_t tmp[16];
+  MZK_HIP(hipMemcpyAsync(tmp, d_o, 128, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  memcpy(y, tmp, 32);
+  memcpy(w_xy, tmp + 8, 64);
+  return MZK_OK;
+}
+
+int mzk_synth_field_dev(int field_id, uint64_t seed, size_t n, void* d_out, void* stream) {
+  MZK_TRY(ensure_init());
+  if (!d_out && n) { set_error("synth: null pointer"); return MZK_E_ARG; }
+  return synth_field_impl(field_id, seed, n, d_out, (hipStream_t)stream);
+}
+int mzk_synth_g1_points_dev(uint64_t seed, size_t n, void* d_out_xy, void* stream) {
+  MZK_TRY(ensure_init());
+  if (!d_out_xy && n) { set_error("synth: null pointer"); return MZK_E_ARG; }
+  return synth_g1_impl(seed, n, d_out_xy, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+// mzk_common.h -- process context, error reporting, workspace and host-side parameter math shared by
+// the library's translation units.  One process drives one GPU (one rank per GPU under torch.distributed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/mzk.h"
+#include "mzk_field.h"
+
+namespace mzk {
+
+// ---- error plumbing ------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+#define MZK_HIP(x)                                                        \
+  do {                                                                    \
+    hipError_t _e = (x);                                                  \
+    if (_e != hipSuccess) return mzk::hip_fail(_e, #x, __FILE__, __LINE__); \
+  } while (0)
+#define MZK_TRY(x)        \
+  do {                    \
+    int _rc = (x);        \
+    if (_rc != MZK_OK) return _rc; \
+  } while (0)
+
+// ---- context ----------------------------------------------------------------------------------------
+struct Context {
+  bool ready = false;
+  int device = -1;
+  int num_cu = 256;
+  hipStream_t stream = nullptr;  // library-owned stream for the host-buffer entry points
+};
+Context& ctx();
+int ensure_init();
+
+// Grow-only device scratch buffers, keyed by slot, so steady-state calls never hipMalloc.
+enum WsSlot { WS_NTT_TMP = 0, WS_NTT_IO_A, WS_NTT_IO_B, WS_MSM_POINTS, WS_MSM_SCALARS, WS_MSM_COUNTS, WS_MSM_OFFSETS,
+              WS_MSM_CURSOR, WS_MSM_ENTRIES, WS_MSM_BUCKETS, WS_MSM_RED_A, WS_MSM_RED_B, WS_MSM_SCAN, WS_MSM_OUT,
+              WS_MISC_A, WS_MISC_B, WS_MISC_C, WS_MISC_D, WS_COUNT };
+int ws_get(WsSlot slot, size_t bytes, void** out);
+void ws_release_all();
+
+// ---- host parameter math (O(log n) scalar work: roots, n^-1, canonical checks; never on the data path)
+struct HostField {
+  int nl;            // u64 limbs
+  uint64_t p[4];
+};
+const HostField* host_field(int fid);
+bool h_is_canonical(const HostField* f, const uint64_t* a);
+void h_mulmod(const HostField* f, uint64_t* r, const uint64_t* a, const uint64_t* b);
+void h_powmod_u64(const HostField* f, uint64_t* r, const uint64_t* a, uint64_t e);
+void h_ninv_pow2(const HostField* f, unsigned log2n, uint64_t* out);  // (2^log2n)^-1 mod p, needs 2^log2n | p-1
+bool h_is_one(const HostField* f, const uint64_t* a);
+
+static inline int field_words(int fid) { return fid == MZK_FIELD_M128 ? 4 : 8; }   // u32 words per element
+static inline int field_limbs64(int fid) { return fid == MZK_FIELD_M128 ? 2 : 4; }
+static inline size_t field_bytes(int fid) { return fid == MZK_FIELD_M128 ? 16 : 32; }
+
+// ---- entry points implemented per translation unit ------------------------------------------------
+int ntt_dev_impl(int fid, const uint64_t* root_host, const void* d_in, void* d_out, size_t n, int inverse,
+                 const uint64_t* extra_scale_host, hipStream_t s);
+int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_t* offset_host,
+                       const uint64_t* generator_host, void* d_out, size_t order, hipStream_t s);
+int pointwise_mul_dev(int fid, const void* d_a, const void* d_b, void* d_out, size_t n, hipStream_t s);
+void ntt_release_plans();
+
+int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, bool points_are_mont, void* d_out,
+                 bool out_partial_xyzz, hipStream_t s);
+int msm_fold_partials_impl(const void* d_partials, int count, void* d_out_xy, hipStream_t s);
+int msm_prepare_points(const void* d_points_plain, size_t n, void* d_points_mont, hipStream_t s);
+int synth_field_impl(int fid, uint64_t seed, size_t n, void* d_out, hipStream_t s);
+int synth_g1_impl(uint64_t seed, size_t n, void* d_out, hipStream_t s);
+int kzg_setup_g1_dev(const uint64_t* alpha_host, const uint64_t* g1_host, size_t count, void* d_powers_xy, hipStream_t s);
+int kzg_open_dev(const void* d_coef, size_t n, const uint64_t* u_host, const void* d_points, bool points_are_mont,
+                 void* d_y, void* d_w_xy, hipStream_t s);
+
+}  // namespace mzk

@@ -1,0 +1,217 @@
+// mzk_kzg.hip -- the non-MSM parts of KZG setup / open on gfx950.
+//
+// setup_kzg (myzkp/src/modules/algebra/kzg.rs:27-40, G1 part): powers[i] = alpha^i * g1.  The reference
+// runs max_d + 1 independent double-and-add scalar multiplications; here a fixed-base table
+// T[w][d] = d * 2^(8 w) * g1 (w < 32, d < 256) turns each into 32 mixed additions.
+//
+// open_kzg (kzg.rs:61-72): y = f(u) (Polynomial::eval, polynomial.rs:120-128) and the quotient
+// (f - y) / (X - u) (div_rem_ref, polynomial.rs:371-405).  Dividing by a monic linear factor is
+// synthetic division: b_{n-1} = c_{n-1}, b_i = c_i + u b_{i+1}; then y = b_0 and q_j = b_{j+1}.  The
+// suffix recurrence is solved by recursive chunking (chunk value at u, then the same recurrence on
+// the chunk values with base u^K), so it is parallel at every level.  The witness MSM then runs in
+// mzk_msm.hip on q.
+#include "mzk_common.h"
+#include "mzk_ec.h"
+
+namespace mzk {
+
+struct Words8k { u32 w[8]; };
+struct Words16k { u32 w[16]; };
+
+__device__ __forceinline__ void ld8(const u32* __restrict__ g, u32* w) {
+  const uint4* p4 = reinterpret_cast<const uint4*>(g);
+  uint4 a = p4[0], b = p4[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+__device__ __forceinline__ void st8(u32* __restrict__ g, const u32* w) {
+  uint4* p4 = reinterpret_cast<uint4*>(g);
+  p4[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  p4[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+// ---- fixed-base table ---------------------------------------------------------------------------------
+// bases[w] = 2^(8 w) * g1, affine Montgomery (16 words); infinity base -> zeros
+__global__ void k_fb_bases(Words16k g1_plain, u32* __restrict__ bases) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= 32) return;
+  u32 o[16];
+  for (int i = 0; i < 16; i++) o[i] = 0;
+  if (!affine_words_is_inf(g1_plain.w)) {
+    Xyzz p = xyzz_from_affine(affine_load_plain(g1_plain.w));
+    for (int d = 0; d < 8 * w; d++) p = xyzz_dbl(p);
+    Affine a;
+    if (xyzz_to_affine(p, &a)) affine_store_mont(a, o);
+  }
+  st8(bases + 16 * w, o);
+  st8(bases + 16 * w + 8, o + 8);
+}
+// table[w][d] = d * bases[w], d = 0..255 (d = 0 and infinity -> zeros), affine Montgomery
+__global__ void k_fb_table(const u32* __restrict__ bases, u32* __restrict__ table) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 32 * 256) return;
+  const int w = t >> 8, d = t & 255;
+  u32 bw[16], o[16];
+  ld8(bases + 16 * w, bw);
+  ld8(bases + 16 * w + 8, bw + 8);
+  for (int i = 0; i < 16; i++) o[i] = 0;
+  if (d != 0 && !affine_words_is_inf(bw)) {
+    Affine b = affine_load_mont(bw);
+    Xyzz acc = xyzz_inf();
+    for (int bit = 7; bit >= 0; bit--) {
+      acc = xyzz_dbl(acc);
+      if ((d >> bit) & 1) acc = xyzz_madd(acc, b);
+    }
+    Affine a;
+    if (xyzz_to_affine(acc, &a)) affine_store_mont(a, o);
+  }
+  st8(table + 16 * t, o);
+  st8(table + 16 * t + 8, o + 8);
+}
+// powers[i] = alpha^i * g1, i < count; affine plain out.
+__global__ __launch_bounds__(128) void k_fb_powers(Words8k alpha_plain, const u32* __restrict__ table, size_t count, u32* __restrict__ out) {
+  typedef FrParams R;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  Fe<R> a = fe_to_mont<R>(fe_unpack<R>(alpha_plain.w));
+  Fe<R> k = fe_from_mont<R>(fe_pow_u64<R>(a, (u64)i));   // canonical alpha^i   (kzg.rs:33-36)
+  u32 kw[8];
+  fe_pack<R>(k, kw);
+  Xyzz acc = xyzz_inf();
+  for (int w = 0; w < 32; w++) {
+    const u32 d = (kw[w >> 2] >> (8 * (w & 3))) & 255u;
+    if (d == 0) continue;
+    u32 tw[16];
+    ld8(table + 16 * ((size_t)w * 256 + d), tw);
+    ld8(table + 16 * ((size_t)w * 256 + d) + 8, tw + 8);
+    if (affine_words_is_inf(tw)) continue;
+    acc = xyzz_madd(acc, affine_load_mont(tw));
+  }
+  u32 o[16];
+  Affine af;
+  if (xyzz_to_affine(acc, &af)) affine_store_plain(af, o);
+  else for (int j = 0; j < 16; j++) o[j] = 0;
+  st8(out + 16 * i, o);
+  st8(out + 16 * i + 8, o + 8);
+}
+
+int kzg_setup_g1_dev(const uint64_t* alpha_host, const uint64_t* g1_host, size_t count, void* d_powers_xy, hipStream_t s) {
+  if (!alpha_host || !g1_host || (!d_powers_xy && count)) { set_error("kzg_setup: null pointer"); return MZK_E_ARG; }
+  if (count == 0) return MZK_OK;
+  if (!h_is_canonical(host_field(MZK_FIELD_FR), alpha_host) || !h_is_canonical(host_field(MZK_FIELD_FQ), g1_host) ||
+      !h_is_canonical(host_field(MZK_FIELD_FQ), g1_host + 4)) { set_error("kzg_setup: operand not canonical"); return MZK_E_RANGE; }
+  Words8k aw;
+  Words16k gw;
+  for (int i = 0; i < 4; i++) { aw.w[2 * i] = (u32)alpha_host[i]; aw.w[2 * i + 1] = (u32)(alpha_host[i] >> 32); }
+  for (int i = 0; i < 8; i++) { gw.w[2 * i] = (u32)g1_host[i]; gw.w[2 * i + 1] = (u32)(g1_host[i] >> 32); }
+  u32 *bases, *table;
+  MZK_TRY(ws_get(WS_MISC_A, 32 * 64, (void**)&bases));
+  MZK_TRY(ws_get(WS_MISC_B, 32 * 256 * 64, (void**)&table));
+  hipLaunchKernelGGL(k_fb_bases, dim3(1), dim3(32), 0, s, gw, bases);
+  hipLaunchKernelGGL(k_fb_table, dim3(32), dim3(256), 0, s, (const u32*)bases, table);
+  hipLaunchKernelGGL(k_fb_powers, dim3((unsigned)((count + 127) / 128)), dim3(128), 0, s, aw, (const u32*)table, count, (u32*)d_powers_xy);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+
+// ---- open: suffix Horner b_i = c_i + u b_{i+1} -----------------------------------------------------------
+constexpr int OPEN_K_LOG = 8;
+constexpr size_t OPEN_K = (size_t)1 << OPEN_K_LOG;
+typedef Fe<FrParams> FrE;
+__device__ __forceinline__ FrE fr_gload(const u32* __restrict__ g, size_t i) {
+  u32 w[8];
+  ld8(g + 8 * i, w);
+  return fe_unpack<FrParams>(w);
+}
+__device__ __forceinline__ void fr_gstore(u32* __restrict__ g, size_t i, const FrE& v) {
+  u32 w[8];
+  fe_pack<FrParams>(v, w);
+  st8(g + 8 * i, w);
+}
+// h[m] = sum_{t in chunk m} c[t] u^(t - m K)
+__global__ __launch_bounds__(64) void k_open_chunk_eval(const u32* __restrict__ c, size_t n, Words8k u_mont, u32* __restrict__ h) {
+  const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lo = m << OPEN_K_LOG;
+  if (lo >= n) return;
+  const size_t hi = (lo + OPEN_K < n) ? lo + OPEN_K : n;
+  const FrE u = fe_unpack<FrParams>(u_mont.w);
+  FrE acc = fr_gload(c, hi - 1);
+  for (size_t t = hi - 1; t-- > lo;) acc = fe_add<FrParams>(fe_mul<FrParams>(acc, u), fr_gload(c, t));
+  fr_gstore(h, m, fe_reduce<FrParams>(acc));
+}
+// b[t] = c[t] + u b[t+1] inside chunk m, with b[(m+1) K] = carry[m+1] (0 past the end)
+__global__ __launch_bounds__(64) void k_open_chunk_fill(const u32* __restrict__ c, size_t n, Words8k u_mont, const u32* __restrict__ carry,
+                                                         size_t ncarry, u32* __restrict__ b) {
+  const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lo = m << OPEN_K_LOG;
+  if (lo >= n) return;
+  const size_t hi = (lo + OPEN_K < n) ? lo + OPEN_K : n;
+  const FrE u = fe_unpack<FrParams>(u_mont.w);
+  FrE acc = (carry != nullptr && m + 1 < ncarry) ? fr_gload(carry, m + 1) : fe_zero<FrParams>();
+  for (size_t t = hi; t-- > lo;) {
+    acc = fe_reduce<FrParams>(fe_add<FrParams>(fe_mul<FrParams>(acc, u), fr_gload(c, t)));
+    fr_gstore(b, t, acc);
+  }
+}
+
+// d_y: 8 words; d_w_xy: 16 words.
+int kzg_open_dev(const void* d_coef, size_t n, const uint64_t* u_host, const void* d_points, bool points_are_mont,
+                 void* d_y, void* d_w_xy, hipStream_t s) {
+  if (!u_host || !d_y || !d_w_xy || (!d_coef && n) || (!d_points && n > 1)) { set_error("kzg_open: null pointer"); return MZK_E_ARG; }
+  const HostField* fr = host_field(MZK_FIELD_FR);
+  if (!h_is_canonical(fr, u_host)) { set_error("kzg_open: u not canonical"); return MZK_E_RANGE; }
+  if (n == 0) {  // empty polynomial: y = 0, quotient empty -> infinity
+    MZK_HIP(hipMemsetAsync(d_y, 0, 32, s));
+    MZK_HIP(hipMemsetAsync(d_w_xy, 0, 64, s));
+    return MZK_OK;
+  }
+  // level arrays: L0 = coef (n), L1 = chunk values (ceil(n/K)), ...
+  size_t lens[8];
+  int nlev = 0;
+  lens[0] = n;
+  while (lens[nlev] > OPEN_K) { lens[nlev + 1] = (lens[nlev] + OPEN_K - 1) >> OPEN_K_LOG; nlev++; }
+  size_t total_up = 0;
+  for (int l = 1; l <= nlev; l++) total_up += lens[l];
+  u32 *bbuf, *hbuf, *bup;
+  MZK_TRY(ws_get(WS_MISC_A, n * 32, (void**)&bbuf));                  // b of level 0
+  MZK_TRY(ws_get(WS_MISC_B, (total_up + 1) * 32, (void**)&hbuf));     // h of levels 1..nlev
+  MZK_TRY(ws_get(WS_MISC_C, (total_up + 1) * 32, (void**)&bup));      // b of levels 1..nlev
+  // u^(K^l) in Montgomery form, on the host (parameter math)
+  Words8k um[8];
+  {
+    uint64_t ul[4] = {u_host[0], u_host[1], u_host[2], u_host[3]};
+    uint64_t two[4] = {2, 0, 0, 0}, rmod[4], t[4];
+    h_powmod_u64(fr, rmod, two, 261);
+    for (int l = 0; l <= nlev; l++) {
+      h_mulmod(fr, t, ul, rmod);
+      for (int i = 0; i < 4; i++) { um[l].w[2 * i] = (u32)t[i]; um[l].w[2 * i + 1] = (u32)(t[i] >> 32); }
+      h_powmod_u64(fr, ul, ul, OPEN_K);
+    }
+  }
+  const u32* level_in[8];
+  u32* level_b[8];
+  level_in[0] = (const u32*)d_coef;
+  level_b[0] = bbuf;
+  size_t off = 0;
+  for (int l = 1; l <= nlev; l++) {
+    level_in[l] = hbuf + off * 8;
+    level_b[l] = bup + off * 8;
+    off += lens[l];
+  }
+  for (int l = 0; l < nlev; l++) {
+    const size_t chunks = lens[l + 1];
+    hipLaunchKernelGGL(k_open_chunk_eval, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, s, level_in[l], lens[l], um[l],
+                       (u32*)level_in[l + 1]);
+  }
+  for (int l = nlev; l >= 0; l--) {
+    const size_t chunks = (lens[l] + OPEN_K - 1) >> OPEN_K_LOG;
+    const u32* carry = (l == nlev) ? nullptr : level_b[l + 1];
+    hipLaunchKernelGGL(k_open_chunk_fill, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, s, level_in[l], lens[l], um[l], carry,
+                       (l == nlev) ? (size_t)0 : lens[l + 1], level_b[l]);
+  }
+  MZK_HIP(hipGetLastError());
+  MZK_HIP(hipMemcpyAsync(d_y, bbuf, 32, hipMemcpyDeviceToDevice, s));   // y = b_0
+  // w = MSM(q, powers), q_j = b_{j+1}, j < n - 1     (kzg.rs:70)
+  return msm_dev_impl(bbuf + 8, d_points, n - 1, points_are_mont, d_w_xy, false, s);
+}
+
+}  // namespace mzk

@@ -1,0 +1,520 @@
+// mzk_msm.hip -- Pippenger bucket multi-scalar multiplication over BN254 G1 on gfx950.
+//
+// Stands behind Polynomial::eval_with_powers_on_curve (myzkp/src/modules/algebra/polynomial.rs:156-165)
+// = commit_kzg (algebra/kzg.rs:57-59) and the second MSM of open_kzg (kzg.rs:70).  The reference runs
+// n independent affine double-and-add scalar multiplications (curve/curve.rs:168-191); this computes
+// the same group element sum_i s_i P_i with the bucket method and returns the same canonical affine
+// point (or the all-zero infinity encoding).
+//
+// Pipeline, all on the device:
+//   0. k_prepare_points   affine canonical -> Montgomery words (once per point set; an SRS handle keeps it)
+//   1. k_digits_count     scalars -> signed c-bit digits (sanitize = reduce mod r first,
+//                         polynomial.rs:162), histogram of (window, |digit|) buckets
+//   2. scan               exclusive prefix sum of the histogram
+//   3. k_digits_scatter   counting-sort scatter of (point index, sign) into bucket order
+//   4. k_bucket_accumulate one lane per bucket, XYZZ += affine (madd-2008-s), exception-complete
+//   5. bucket reduction   sum_b (b+1) B_b per window by recursive chunked running sums
+//   6. k_window_combine   Horner over the windows, XYZZ -> affine (one Fq inversion)
+#include "mzk_common.h"
+#include "mzk_ec.h"
+
+namespace mzk {
+
+constexpr int SCALAR_BITS = 254;
+constexpr int MAX_WINDOWS = 32;
+constexpr int RED_CH_LOG = 4;           // bucket-reduction chunk = 16
+constexpr int RED_CH = 1 << RED_CH_LOG;
+constexpr int MAX_RED_LEVELS = 6;
+
+struct MsmShape {
+  int c;          // window bits
+  int nwin;       // windows
+  int lgB;        // log2 buckets per window = c - 1
+  size_t nbuckets;
+};
+
+static MsmShape choose_shape(size_t n) {
+  int lg = 0;
+  while (((size_t)1 << lg) < n) lg++;
+  int c = lg - 3;
+  if (c < 8) c = 8;
+  if (c > 16) c = 16;
+  MsmShape s;
+  s.c = c;
+  s.nwin = SCALAR_BITS / c + 1;
+  s.lgB = c - 1;
+  s.nbuckets = (size_t)s.nwin << s.lgB;
+  return s;
+}
+
+// ---- global loads of packed 256-bit values -----------------------------------------------------------
+__device__ __forceinline__ void load_words8(const u32* __restrict__ g, u32* w) {
+  const uint4* p4 = reinterpret_cast<const uint4*>(g);
+  uint4 a = p4[0], b = p4[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+__device__ __forceinline__ void store_words8(u32* __restrict__ g, const u32* w) {
+  uint4* p4 = reinterpret_cast<uint4*>(g);
+  p4[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  p4[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+__device__ __forceinline__ Xyzz xyzz_gload(const u32* __restrict__ g, size_t idx) {
+  u32 w[32];
+#pragma unroll
+  for (int q = 0; q < 4; q++) load_words8(g + idx * 32 + 8 * q, w + 8 * q);
+  return xyzz_load(w);
+}
+__device__ __forceinline__ void xyzz_gstore(u32* __restrict__ g, size_t idx, const Xyzz& p) {
+  u32 w[32];
+  xyzz_store(p, w);
+#pragma unroll
+  for (int q = 0; q < 4; q++) store_words8(g + idx * 32 + 8 * q, w + 8 * q);
+}
+
+// ---- 0. point preparation ------------------------------------------------------------------------------
+__global__ void k_prepare_points(const u32* __restrict__ in, u32* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 w[16];
+  load_words8(in + i * 16, w);
+  load_words8(in + i * 16 + 8, w + 8);
+  if (!affine_words_is_inf(w)) {
+    Affine a = affine_load_plain(w);
+    affine_store_mont(a, w);
+  }
+  store_words8(out + i * 16, w);
+  store_words8(out + i * 16 + 8, w + 8);
+}
+
+// ---- 1/3. signed-digit decomposition ----------------------------------------------------------------
+// Canonical scalar words (sanitize(): polynomial.rs:162 -> field.rs:260-270).
+__device__ __forceinline__ void load_scalar_canonical(const u32* __restrict__ scalars, size_t i, u32* w) {
+  load_words8(scalars + i * 8, w);
+  // fast path: top word below r's top word => already canonical
+  if (w[7] >= 0x30644e72u) {
+    Fe<FrParams> x = fe_reduce<FrParams>(fe_unpack<FrParams>(w));
+    fe_pack<FrParams>(x, w);
+  }
+}
+// digit of window `win` before carry handling: bits [c win, c win + c)
+__device__ __forceinline__ u32 raw_window(const u32* w, int win, int c) {
+  const int bit = win * c;
+  if (bit >= 256) return 0;
+  const int k = bit >> 5, s = bit & 31;
+  u64 v = w[k];
+  if (k + 1 < 8) v |= (u64)w[k + 1] << 32;
+  return (u32)(v >> s) & ((1u << c) - 1u);
+}
+
+template <bool SCATTER>
+__global__ void k_digits(const u32* __restrict__ scalars, size_t n, int c, int nwin, u32* __restrict__ counts_or_cursor,
+                         u32* __restrict__ entries) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 w[8];
+  load_scalar_canonical(scalars, i, w);
+  const u32 half = 1u << (c - 1);
+  u32 carry = 0;
+  for (int win = 0; win < nwin; win++) {
+    u32 raw = raw_window(w, win, c) + carry;
+    u32 neg = 0, mag = raw;
+    carry = 0;
+    if (raw > half) { mag = (1u << c) - raw; neg = 1; carry = 1; }
+    if (mag != 0) {
+      const size_t bucket = ((size_t)win << (c - 1)) + (mag - 1);
+      if (SCATTER) {
+        const u32 pos = atomicAdd(&counts_or_cursor[bucket], 1u);
+        entries[pos] = (u32)i | (neg << 31);
+      } else {
+        atomicAdd(&counts_or_cursor[bucket], 1u);
+      }
+    }
+  }
+}
+
+// ---- 2. exclusive scan (three small kernels) -----------------------------------------------------------
+constexpr int SCAN_ITEMS = 8;                      // per thread
+constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;       // 2048 per block
+__global__ __launch_bounds__(256) void k_scan_local(const u32* __restrict__ in, u32* __restrict__ out, u32* __restrict__ block_sums, size_t n) {
+  __shared__ u32 sh[256];
+  const size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_ITEMS;
+  u32 v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    v[k] = (base + k < n) ? in[base + k] : 0u;
+    sum += v[k];
+  }
+  sh[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    u32 t = (threadIdx.x >= (unsigned)off) ? sh[threadIdx.x - off] : 0u;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  u32 excl = sh[threadIdx.x] - sum;
+  if (threadIdx.x == 255) block_sums[blockIdx.x] = sh[255];
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    if (base + k < n) out[base + k] = excl;
+    excl += v[k];
+  }
+}
+__global__ __launch_bounds__(256) void k_scan_blocksums(u32* __restrict__ block_sums, size_t nblocks, u32* __restrict__ total_out) {
+  __shared__ u32 sh[256];
+  __shared__ u32 running;
+  if (threadIdx.x == 0) running = 0;
+  __syncthreads();
+  for (size_t base = 0; base < nblocks; base += 256) {
+    const size_t i = base + threadIdx.x;
+    const u32 v = (i < nblocks) ? block_sums[i] : 0u;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      u32 t = (threadIdx.x >= (unsigned)off) ? sh[threadIdx.x - off] : 0u;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nblocks) block_sums[i] = running + sh[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 255) running += sh[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_out = running;
+}
+// offsets[i] += block_sums[block(i)]; cursor = offsets; offsets[n] = total
+__global__ __launch_bounds__(256) void k_scan_finish(u32* __restrict__ offsets, u32* __restrict__ cursor, const u32* __restrict__ block_sums,
+                                                      const u32* __restrict__ total, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const u32 v = offsets[i] + block_sums[i / SCAN_BLOCK];
+    offsets[i] = v;
+    cursor[i] = v;
+  } else if (i == n) {
+    offsets[n] = *total;
+  }
+}
+
+// ---- 4. bucket accumulation -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bucket_accumulate(const u32* __restrict__ points_mont, const u32* __restrict__ offsets,
+                                                            const u32* __restrict__ entries, u32* __restrict__ buckets, size_t nbuckets) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nbuckets) return;
+  const u32 beg = offsets[g], end = offsets[g + 1];
+  Xyzz acc = xyzz_inf();
+  for (u32 e = beg; e < end; e++) {
+    const u32 ent = entries[e];
+    const size_t idx = ent & 0x7fffffffu;
+    u32 w[16];
+    load_words8(points_mont + idx * 16, w);
+    load_words8(points_mont + idx * 16 + 8, w + 8);
+    if (affine_words_is_inf(w)) continue;  // infinity contributes nothing (curve.rs:107-109)
+    Affine p = affine_load_mont(w);
+    if (ent >> 31) p = affine_neg(p);
+    acc = xyzz_madd(acc, p);
+  }
+  xyzz_gstore(buckets, g, acc);
+}
+
+// ---- 5. bucket reduction: W0(X) = sum_i i X_i and Sum(X), per window, by chunked running sums ----------
+// in: nwin windows x n points.  Thread (w, u) handles chunk u of CH points:
+//   S[w][u]  = sum_l X[u CH + l]            (next level's input)
+//   T[w][u]  = sum_l l * X[u CH + l]        (plain-summed over u afterwards)
+__global__ __launch_bounds__(64) void k_chunk_runsum(const u32* __restrict__ X, size_t n, int lgch, u32* __restrict__ S, u32* __restrict__ T,
+                                                      int nwin) {
+  const size_t nchunks = (n + ((size_t)1 << lgch) - 1) >> lgch;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nchunks * nwin) return;
+  const size_t w = t / nchunks, u = t % nchunks;
+  const size_t base = w * n + (u << lgch);
+  const size_t len = (n - (u << lgch)) < ((size_t)1 << lgch) ? (n - (u << lgch)) : ((size_t)1 << lgch);
+  Xyzz run = xyzz_inf(), acc = xyzz_inf();
+  for (size_t l = len; l-- > 1;) {
+    run = xyzz_add(run, xyzz_gload(X, base + l));
+    acc = xyzz_add(acc, run);
+  }
+  run = xyzz_add(run, xyzz_gload(X, base));
+  xyzz_gstore(S, w * nchunks + u, run);
+  xyzz_gstore(T, w * nchunks + u, acc);
+}
+// plain chunk sums: out[w][u] = sum_l X[w][u CH + l]
+__global__ __launch_bounds__(64) void k_chunk_sum(const u32* __restrict__ X, size_t n, int lgch, u32* __restrict__ out, int nwin) {
+  const size_t nchunks = (n + ((size_t)1 << lgch) - 1) >> lgch;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nchunks * nwin) return;
+  const size_t w = t / nchunks, u = t % nchunks;
+  const size_t base = w * n + (u << lgch);
+  const size_t len = (n - (u << lgch)) < ((size_t)1 << lgch) ? (n - (u << lgch)) : ((size_t)1 << lgch);
+  Xyzz acc = xyzz_inf();
+  for (size_t l = 0; l < len; l++) acc = xyzz_add(acc, xyzz_gload(X, base + l));
+  xyzz_gstore(out, w * nchunks + u, acc);
+}
+
+// ---- 6. window combine ----------------------------------------------------------------------------------
+// For window w:  A_w = Sum_w + sum_level CH^level * Tsum[level][w]   (levels deepest-first Horner),
+// total = sum_w 2^(c w) A_w  (Horner, c doublings per window), then affine or XYZZ out.
+struct CombineArgs {
+  const u32* sum;            // [nwin] XYZZ: Sum(X) per window
+  const u32* tsum[MAX_RED_LEVELS];  // [nwin] XYZZ each
+  int nlevels;
+  int nwin;
+  int c;
+  int lgch;
+  int out_xyzz;              // 1: write 32-word XYZZ (partial for multi-GPU); 0: write 16-word affine plain
+};
+__global__ void k_window_combine(CombineArgs a, u32* __restrict__ out) {
+  __shared__ u32 win_pts[MAX_WINDOWS * 32];
+  const int w = threadIdx.x;
+  if (w < a.nwin) {
+    Xyzz acc = xyzz_inf();
+    for (int lev = a.nlevels - 1; lev >= 0; lev--) {
+      for (int d = 0; d < a.lgch; d++) acc = xyzz_dbl(acc);
+      acc = xyzz_add(acc, xyzz_gload(a.tsum[lev], w));
+    }
+    acc = xyzz_add(acc, xyzz_gload(a.sum, w));
+    xyzz_store(acc, win_pts + 32 * w);
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  Xyzz tot = xyzz_inf();
+  for (int win = a.nwin - 1; win >= 0; win--) {
+    for (int d = 0; d < a.c; d++) tot = xyzz_dbl(tot);
+    tot = xyzz_add(tot, xyzz_load(win_pts + 32 * win));
+  }
+  if (a.out_xyzz) {
+    u32 wds[32];
+    xyzz_store(tot, wds);
+    for (int i = 0; i < 32; i++) out[i] = wds[i];
+  } else {
+    u32 wds[16];
+    Affine af;
+    if (xyzz_to_affine(tot, &af)) affine_store_plain(af, wds);
+    else for (int i = 0; i < 16; i++) wds[i] = 0;
+    for (int i = 0; i < 16; i++) out[i] = wds[i];
+  }
+}
+// fold `count` XYZZ partials (multi-GPU all-gather result) into one affine point
+__global__ void k_fold_partials(const u32* __restrict__ partials, int count, u32* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Xyzz tot = xyzz_inf();
+  for (int i = 0; i < count; i++) tot = xyzz_add(tot, xyzz_gload(partials, i));
+  u32 wds[16];
+  Affine af;
+  if (xyzz_to_affine(tot, &af)) affine_store_plain(af, wds);
+  else for (int i = 0; i < 16; i++) wds[i] = 0;
+  for (int i = 0; i < 16; i++) out[i] = wds[i];
+}
+
+// ---- host orchestration -----------------------------------------------------------------------------------
+int msm_prepare_points(const void* d_points_plain, size_t n, void* d_points_mont, hipStream_t s) {
+  if (n == 0) return MZK_OK;
+  hipLaunchKernelGGL(k_prepare_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const u32*)d_points_plain,
+                     (u32*)d_points_mont, n);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+
+int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, bool points_are_mont, void* d_out,
+                 bool out_partial_xyzz, hipStream_t s) {
+  if (!d_out || ((!d_scalars || !d_points) && n)) { set_error("msm: null pointer"); return MZK_E_ARG; }
+  if (n > ((size_t)1 << 31)) { set_error("msm: n > 2^31 not supported"); return MZK_E_ARG; }
+  if (n == 0) {  // empty polynomial -> point at infinity (polynomial.rs:160)
+    MZK_HIP(hipMemsetAsync(d_out, 0, out_partial_xyzz ? 128 : 64, s));
+    return MZK_OK;
+  }
+  const MsmShape sh = choose_shape(n);
+  const size_t NB = sh.nbuckets;
+  const u32* pts = (const u32*)d_points;
+  if (!points_are_mont) {
+    void* pm;
+    MZK_TRY(ws_get(WS_MSM_POINTS, n * 64, &pm));
+    MZK_TRY(msm_prepare_points(d_points, n, pm, s));
+    pts = (const u32*)pm;
+  }
+  u32 *counts, *offsets, *cursor, *entries, *scan_tmp, *buckets;
+  const size_t scan_blocks = (NB + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  MZK_TRY(ws_get(WS_MSM_COUNTS, NB * 4, (void**)&counts));
+  MZK_TRY(ws_get(WS_MSM_OFFSETS, (NB + 1) * 4, (void**)&offsets));
+  MZK_TRY(ws_get(WS_MSM_CURSOR, NB * 4, (void**)&cursor));
+  MZK_TRY(ws_get(WS_MSM_ENTRIES, n * (size_t)sh.nwin * 4, (void**)&entries));
+  MZK_TRY(ws_get(WS_MSM_SCAN, (scan_blocks + 1) * 4, (void**)&scan_tmp));
+  MZK_TRY(ws_get(WS_MSM_BUCKETS, NB * 128, (void**)&buckets));
+  MZK_HIP(hipMemsetAsync(counts, 0, NB * 4, s));
+  const unsigned nblk = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL((k_digits<false>), dim3(nblk), dim3(256), 0, s, (const u32*)d_scalars, n, sh.c, sh.nwin, counts, (u32*)nullptr);
+  hipLaunchKernelGGL(k_scan_local, dim3((unsigned)scan_blocks), dim3(256), 0, s, counts, offsets, scan_tmp, NB);
+  hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, scan_tmp, scan_blocks, scan_tmp + scan_blocks);
+  hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((NB + 1 + 255) / 256)), dim3(256), 0, s, offsets, cursor, scan_tmp,
+                     scan_tmp + scan_blocks, NB);
+  hipLaunchKernelGGL((k_digits<true>), dim3(nblk), dim3(256), 0, s, (const u32*)d_scalars, n, sh.c, sh.nwin, cursor, entries);
+  hipLaunchKernelGGL(k_bucket_accumulate, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, s, pts, offsets, entries, buckets, NB);
+
+  // bucket reduction: weights (b+1) = b + 1  =>  W0(X) + Sum(X)
+  const size_t B = (size_t)1 << sh.lgB;
+  size_t level_n[MAX_RED_LEVELS + 1];
+  level_n[0] = B;
+  int nlev = 0;
+  while (level_n[nlev] > 1) {
+    level_n[nlev + 1] = (level_n[nlev] + RED_CH - 1) >> RED_CH_LOG;
+    nlev++;
+    if (nlev > MAX_RED_LEVELS) { set_error("msm: reduction depth"); return MZK_E_ARG; }
+  }
+  // scratch: S arrays (ping-pong), T arrays per level, T-sum ping-pong
+  size_t s_elems = (size_t)sh.nwin * level_n[1 < nlev ? 1 : nlev];
+  u32 *redA, *redB, *tbuf, *tsums;
+  size_t chunk1 = (size_t)sh.nwin * level_n[nlev ? 1 : 0];
+  MZK_TRY(ws_get(WS_MSM_RED_A, (chunk1 + 16) * 128, (void**)&redA));   // S of the current level
+  MZK_TRY(ws_get(WS_MSM_RED_B, (chunk1 + 16) * 128 * 2, (void**)&redB)); // S of the next level + T tree scratch
+  MZK_TRY(ws_get(WS_MISC_D, (chunk1 + 16) * 128, (void**)&tbuf));       // T of the current level
+  MZK_TRY(ws_get(WS_MSM_OUT, (size_t)(MAX_RED_LEVELS + 2) * MAX_WINDOWS * 128, (void**)&tsums));
+  (void)s_elems;
+  CombineArgs ca;
+  memset(&ca, 0, sizeof ca);
+  ca.nwin = sh.nwin; ca.c = sh.c; ca.lgch = RED_CH_LOG; ca.out_xyzz = out_partial_xyzz ? 1 : 0;
+  const u32* X = buckets;
+  u32* Sping = redA;
+  u32* Spong = redB;
+  u32* tree = redB + (chunk1 + 16) * 32;  // second half of redB (u32 units: 32 words per point)
+  for (int lev = 0; lev < nlev; lev++) {
+    const size_t nin = level_n[lev], nout = level_n[lev + 1];
+    const size_t threads = nout * sh.nwin;
+    hipLaunchKernelGGL(k_chunk_runsum, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, s, X, nin, RED_CH_LOG, Sping, tbuf, sh.nwin);
+    // plain-sum T over the chunks -> tsums[lev][w]
+    const u32* tin = tbuf;
+    size_t tn = nout;
+    u32* tA = tree;
+    u32* tB = tree + ((nout + RED_CH - 1) / RED_CH + 1) * (size_t)sh.nwin * 32;
+    while (tn > 1) {
+      const size_t tout = (tn + RED_CH - 1) >> RED_CH_LOG;
+      u32* dst = (tout == 1) ? (tsums + (size_t)lev * MAX_WINDOWS * 32) : tA;
+      hipLaunchKernelGGL(k_chunk_sum, dim3((unsigned)((tout * sh.nwin + 63) / 64)), dim3(64), 0, s, tin, tn, RED_CH_LOG, dst, sh.nwin);
+      tin = dst;
+      tn = tout;
+      u32* sw = tA; tA = tB; tB = sw;
+    }
+    if (nout == 1) {
+      // single chunk: T is already the per-window value
+      MZK_HIP(hipMemcpyAsync(tsums + (size_t)lev * MAX_WINDOWS * 32, tbuf, (size_t)sh.nwin * 128, hipMemcpyDeviceToDevice, s));
+    }
+    ca.tsum[lev] = tsums + (size_t)lev * MAX_WINDOWS * 32;
+    X = Sping;
+    u32* sw = Sping; Sping = Spong; Spong = sw;
+  }
+  ca.nlevels = nlev;
+  ca.sum = (nlev == 0) ? buckets : X;  // after the last level X holds Sum per window (n = 1)
+  hipLaunchKernelGGL(k_window_combine, dim3(1), dim3(64), 0, s, ca, (u32*)d_out);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+
+int msm_fold_partials_impl(const void* d_partials, int count, void* d_out_xy, hipStream_t s) {
+  if (!d_partials || !d_out_xy || count < 0) { set_error("fold_partials: bad argument"); return MZK_E_ARG; }
+  hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, s, (const u32*)d_partials, count, (u32*)d_out_xy);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+
+}  // namespace mzk
+
+// ---- deterministic synthetic inputs (bit-identical to oracle/mzk_oracle.c orc_synth_*) -------------------
+namespace mzk {
+__device__ __forceinline__ u64 splitmix64(u64& s) {
+  u64 z = (s += 0x9e3779b97f4a7c15ULL);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  return z ^ (z >> 31);
+}
+// canonical element `index` of stream `seed` as NW words
+template <class P> __device__ void synth_words(u64 seed, u64 index, u32* w) {
+  constexpr int NL = P::NW / 2;
+  // modulus as 32-bit words, from the 29-bit limbs
+  u32 pw[P::NW];
+  {
+    Fe<P> pm;
+    for (int i = 0; i < P::L; i++) pm.l[i] = P::P[i];
+    fe_pack<P>(pm, pw);
+  }
+  for (u64 attempt = 0;; attempt++) {
+    u64 s = seed ^ (index * 0xd1342543de82ef95ULL) ^ (attempt * 0xa0761d6478bd642fULL);
+    for (int i = 0; i < NL; i++) {
+      u64 v = splitmix64(s);
+      w[2 * i] = (u32)v;
+      w[2 * i + 1] = (u32)(v >> 32);
+    }
+    constexpr int topbits = P::BITS - 64 * (NL - 1);
+    if (topbits < 64) {
+      const u64 mask = (((u64)1 << topbits) - 1);
+      w[P::NW - 2] &= (u32)mask;
+      w[P::NW - 1] &= (u32)(mask >> 32);
+    }
+    bool lt = false, decided = false;
+    for (int i = P::NW - 1; i >= 0 && !decided; i--) {
+      if (w[i] != pw[i]) { lt = w[i] < pw[i]; decided = true; }
+    }
+    if (decided && lt) return;
+  }
+}
+template <class P> __global__ void k_synth_field(u64 seed, size_t n, u32* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 w[P::NW];
+  synth_words<P>(seed, i, w);
+  for (int k = 0; k < P::NW; k++) out[i * P::NW + k] = w[k];
+}
+// try-and-increment G1 points: x = synth(Fq, seed, i) (+1 until x^3+3 is a non-zero square),
+// y = (x^3+3)^((q+1)/4)
+__global__ void k_synth_g1(u64 seed, size_t n, u32* __restrict__ out) {
+  typedef FqParams P;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 w[8];
+  synth_words<P>(seed, i, w);
+  // exponent (q+1)/4 as words: q = 3 mod 4, so (q+1)/4 = (q >> 2) + 1
+  u32 e[8];
+  {
+    Fe<P> pm;
+    for (int k = 0; k < P::L; k++) pm.l[k] = P::P[k];
+    u32 qw[8];
+    fe_pack<P>(pm, qw);
+    for (int k = 0; k < 8; k++) e[k] = (qw[k] >> 2) | ((k + 1 < 8) ? (qw[k + 1] << 30) : 0u);
+    u32 c = 1;
+    for (int k = 0; k < 8 && c; k++) { e[k] += c; c = (e[k] == 0) ? 1u : 0u; }
+  }
+  Fe<P> b3;
+  for (int k = 0; k < P::L; k++) b3.l[k] = FQ_B_MONT[k];
+  Fe<P> x = fe_reduce<P>(fe_to_mont<P>(fe_unpack<P>(w)));
+  Fe<P> one = fe_one<P>();
+  for (;;) {
+    Fe<P> rhs = fe_reduce<P>(fe_add<P>(fe_mul<P>(fe_sqr<P>(x), x), b3));
+    Fe<P> y = fe_pow_words<P>(rhs, e, 8);
+    Fe<P> y2 = fe_reduce<P>(fe_sqr<P>(y));
+    if (fe_eq_canon<P>(y2, rhs) && !fe_is_zero_canon<P>(rhs)) {
+      Affine a;
+      a.x = x;
+      a.y = fe_reduce<P>(y);
+      u32 o[16];
+      affine_store_plain(a, o);
+      for (int k = 0; k < 16; k++) out[i * 16 + k] = o[k];
+      return;
+    }
+    x = fe_reduce<P>(fe_add<P>(x, one));
+  }
+}
+int synth_field_impl(int fid, u64 seed, size_t n, void* d_out, hipStream_t s) {
+  if (n == 0) return MZK_OK;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  if (fid == MZK_FIELD_FR) hipLaunchKernelGGL((k_synth_field<FrParams>), dim3(blocks), dim3(256), 0, s, seed, n, (u32*)d_out);
+  else if (fid == MZK_FIELD_FQ) hipLaunchKernelGGL((k_synth_field<FqParams>), dim3(blocks), dim3(256), 0, s, seed, n, (u32*)d_out);
+  else if (fid == MZK_FIELD_M128) hipLaunchKernelGGL((k_synth_field<M128Params>), dim3(blocks), dim3(256), 0, s, seed, n, (u32*)d_out);
+  else { set_error("synth: bad field id %d", fid); return MZK_E_ARG; }
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+int synth_g1_impl(u64 seed, size_t n, void* d_out, hipStream_t s) {
+  if (n == 0) return MZK_OK;
+  hipLaunchKernelGGL(k_synth_g1, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, seed, n, (u32*)d_out);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+}  // namespace mzk

@@ -1,0 +1,481 @@
+// mzk_ntt.hip -- radix-2 NTT / iNTT / coset LDE on gfx950.
+//
+// Stands behind ntt::ntt / ntt::intt (myzkp/src/modules/algebra/ntt.rs:7-64), the transform inside
+// Polynomial::fft_multiply (polynomial.rs:242-300) and ntt::fast_multiply (ntt.rs:66-116), and
+// ntt::fast_coset_evaluate (ntt.rs:254-269).  Same map as the reference: natural order in, natural
+// order out, out[k] = sum_j in[j] root^(j k).
+//
+// Algorithm: n = n_1 n_2 ... n_K (K <= 4, n_t <= 2^8, chosen so that every
+// workgroup tile is 1024 elements).  Input index j = (j_1, ..., j_K) row-major, output index
+// k = k_1 + n_1 (k_2 + n_2 (...)).  Pass t < K transforms along j_t in place on strided columns
+// (tile = n_t x C contiguous columns, C * 32 B runs), and multiplies element (k_t, j') of each block by
+// the inter-pass twiddle w_t^(j' k_t) read COALESCED from a table laid out like the data.  The last
+// pass transforms contiguous rows of n_K and scatters them transposed so that R = 1024 / n_K
+// consecutive outputs are written together.  No bit-reversal pass over HBM: the permutation happens
+// inside LDS.
+//
+// Arithmetic trick: values stay in the plain (non-Montgomery) domain.  Every multiplication in an
+// NTT is by a constant (twiddle, n^-1, offset^i); with the constant in Montgomery form w R,
+// fe_mul(x, wR) = x w exactly, so no element is ever converted into or out of Montgomery form.
+//
+// LDS layout: structure-of-arrays, limb-major (lds[limb][position]) so every access is a
+// conflict-light ds_read_b32 / ds_write_b32; positions are XOR-swizzled (pos ^ (pos >> 5 & 31)) so the
+// bit-reversed scatter of the load phase does not serialise on one bank.
+#include "mzk_common.h"
+
+namespace mzk {
+
+constexpr int TILE_LOG = 10;
+constexpr int TILE = 1 << TILE_LOG;
+constexpr int NTHREADS = 256;
+constexpr int MAX_LEVEL_LOG = 8;
+
+struct Words8 { u32 w[8]; };
+
+struct LevelInfo {
+  int nlev;
+  int lg[4];
+};
+
+// ---- global memory <-> limbs ----------------------------------------------------------------------
+template <class P> __device__ __forceinline__ Fe<P> gload(const u32* __restrict__ g, size_t idx) {
+  u32 w[P::NW];
+  const uint4* p4 = reinterpret_cast<const uint4*>(g + idx * P::NW);
+#pragma unroll
+  for (int q = 0; q < P::NW / 4; q++) {
+    uint4 v = p4[q];
+    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+  }
+  return fe_unpack<P>(w);
+}
+template <class P> __device__ __forceinline__ void gstore(u32* __restrict__ g, size_t idx, const Fe<P>& v) {
+  u32 w[P::NW];
+  fe_pack<P>(v, w);
+  uint4* p4 = reinterpret_cast<uint4*>(g + idx * P::NW);
+#pragma unroll
+  for (int q = 0; q < P::NW / 4; q++) p4[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+// value < 2p, normalised -> something fe_pack can hold (value < 2^(32 NW)).
+template <class P> __device__ __forceinline__ Fe<P> fe_fit(const Fe<P>& v) {
+  if constexpr (P::BITS + 1 > 32 * P::NW) return fe_cond_sub_p<P>(v);
+  else return v;
+}
+
+__device__ __forceinline__ int lds_phys(int pos) { return pos ^ ((pos >> 5) & 31); }
+template <class P> __device__ __forceinline__ Fe<P> lds_load(const u32* lds, int pos) {
+  Fe<P> r;
+  const int ph = lds_phys(pos);
+#pragma unroll
+  for (int i = 0; i < P::L; i++) r.l[i] = lds[i * TILE + ph];
+  return r;
+}
+template <class P> __device__ __forceinline__ void lds_store(u32* lds, int pos, const Fe<P>& v) {
+  const int ph = lds_phys(pos);
+#pragma unroll
+  for (int i = 0; i < P::L; i++) lds[i * TILE + ph] = v.l[i];
+}
+
+// In-LDS radix-2 DIT over the k-dimension of a [2^lgn][2^lgc] tile whose rows were stored
+// bit-reversed; leaves natural order.  tw: w_n^j, j < n/2, Montgomery, packed.
+template <class P>
+__device__ __forceinline__ void tile_stages(u32* lds, const u32* __restrict__ tw, int lgn, int lgc) {
+  const int tid = threadIdx.x;
+  const int nbf = 1 << (lgn + lgc - 1);  // butterflies per stage
+  const int cmask = (1 << lgc) - 1;
+  for (int s = 1; s <= lgn; s++) {
+    const int half = 1 << (s - 1);
+    for (int b = tid; b < nbf; b += NTHREADS) {
+      const int c = b & cmask, kb = b >> lgc;
+      const int j = kb & (half - 1);
+      const int klo = ((kb >> (s - 1)) << s) | j;
+      const int plo = (klo << lgc) | c, phi = plo + (half << lgc);
+      Fe<P> a = lds_load<P>(lds, plo);
+      Fe<P> t = lds_load<P>(lds, phi);
+      if (s > 1) {  // stage 1 has the trivial twiddle only
+        Fe<P> w = gload<P>(tw, (size_t)j << (lgn - s));
+        t = fe_mul<P>(t, w);
+      }
+      // t is normalised and < 2^(32 NW) (raw input, stage 1) or < 2 p (product): below the 4 p that
+      // fe_sub<8> tolerates in its subtrahend for every field here
+      lds_store<P>(lds, plo, fe_carry<P>(fe_add<P>(a, t)));
+      lds_store<P>(lds, phi, fe_carry<P>(fe_sub<P, 8>(a, t)));
+    }
+    __syncthreads();
+  }
+}
+
+// Pass t < K: in-place strided columns + inter-pass twiddle.
+template <class P>
+__global__ __launch_bounds__(NTHREADS) void k_ntt_strided(const u32* __restrict__ in, u32* __restrict__ out,
+                                                           const u32* __restrict__ tw_tile,
+                                                           const u32* __restrict__ tw_inter, int lgn, int lgM, int lgc) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  const int tid = threadIdx.x;
+  const int lg_tiles = lgM - lgc;
+  const size_t o = (size_t)blockIdx.x >> lg_tiles;
+  const size_t ct = (size_t)blockIdx.x & (((size_t)1 << lg_tiles) - 1);
+  const size_t base = (o << (lgn + lgM)) + (ct << lgc);
+  const int cmask = (1 << lgc) - 1;
+  const int tile_elems = 1 << (lgn + lgc);
+  for (int e = tid; e < tile_elems; e += NTHREADS) {
+    const int j1 = e >> lgc, c = e & cmask;
+    Fe<P> v = gload<P>(in, base + ((size_t)j1 << lgM) + c);
+    const int k = (int)(__brev((unsigned)j1) >> (32 - lgn));
+    lds_store<P>(lds, (k << lgc) | c, v);
+  }
+  __syncthreads();
+  tile_stages<P>(lds, tw_tile, lgn, lgc);
+  for (int e = tid; e < tile_elems; e += NTHREADS) {
+    const int k = e >> lgc, c = e & cmask;
+    const size_t off = ((size_t)k << lgM) + (ct << lgc) + c;
+    Fe<P> v = lds_load<P>(lds, (k << lgc) | c);
+    Fe<P> w = gload<P>(tw_inter, off);
+    gstore<P>(out, (o << (lgn + lgM)) + off, fe_fit<P>(fe_mul<P>(v, w)));
+  }
+}
+
+// Last pass: contiguous rows of 2^lgn, transposed scatter; optional final scale (n^-1 for a
+// single-pass inverse), canonical output.
+template <class P>
+__global__ __launch_bounds__(NTHREADS) void k_ntt_last(const u32* __restrict__ in, u32* __restrict__ out,
+                                                        const u32* __restrict__ tw_tile, LevelInfo li, int lgn, int lgr,
+                                                        int lg_rows, Words8 scale, int has_scale) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  const int tid = threadIdx.x;
+  const size_t p0 = (size_t)blockIdx.x << lgr;
+  const int rmask = (1 << lgr) - 1, nmask = (1 << lgn) - 1;
+  const int tile_elems = 1 << (lgn + lgr);
+  for (int e = tid; e < tile_elems; e += NTHREADS) {
+    const int rr = e >> lgn, j = e & nmask;
+    size_t rem = p0 + rr, row = 0;
+    for (int i = 0; i < li.nlev - 1; i++) {
+      row = (row << li.lg[i]) | (rem & (((size_t)1 << li.lg[i]) - 1));
+      rem >>= li.lg[i];
+    }
+    Fe<P> v = gload<P>(in, (row << lgn) + j);
+    const int k = (lgn == 0) ? 0 : (int)(__brev((unsigned)j) >> (32 - lgn));
+    lds_store<P>(lds, (k << lgr) | rr, v);
+  }
+  __syncthreads();
+  tile_stages<P>(lds, tw_tile, lgn, lgr);
+  Fe<P> sc;
+  if (has_scale) sc = fe_unpack<P>(scale.w);
+  for (int e = tid; e < tile_elems; e += NTHREADS) {
+    const int rr = e & rmask, k = e >> lgr;
+    Fe<P> v = lds_load<P>(lds, (k << lgr) | rr);
+    if (has_scale) v = fe_mul<P>(v, sc);
+    gstore<P>(out, p0 + rr + ((size_t)k << lg_rows), fe_reduce<P>(v));
+  }
+}
+
+// ---- table generation ------------------------------------------------------------------------------
+constexpr int GEN_CHUNK = 16;
+// out[j] = g^j (Montgomery, canonical), j < count, g = root^emul
+template <class P>
+__global__ void k_gen_pow_table(Words8 root_plain, uint64_t emul, size_t count, u32* __restrict__ out) {
+  const size_t chunk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t j0 = chunk * GEN_CHUNK;
+  if (j0 >= count) return;
+  Fe<P> g = fe_pow_u64<P>(fe_to_mont<P>(fe_unpack<P>(root_plain.w)), emul);
+  Fe<P> cur = fe_pow_u64<P>(g, j0);
+  for (int i = 0; i < GEN_CHUNK && j0 + i < count; i++) {
+    gstore<P>(out, j0 + i, fe_reduce<P>(cur));
+    cur = fe_mul<P>(cur, g);
+  }
+}
+// out[k * M + j'] = scale * g^(j' k), g = root^emul a primitive (n_t M)-th root; k < 2^lgn, j' < 2^lgM
+template <class P>
+__global__ void k_gen_inter_table(Words8 root_plain, uint64_t emul, int lgn, int lgM, Words8 scale_plain,
+                                  u32* __restrict__ out) {
+  const size_t chunk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t M = (size_t)1 << lgM;
+  const size_t clen = M < GEN_CHUNK ? M : GEN_CHUNK;
+  const size_t chunks_per_row = M / clen;
+  const size_t k = chunk / chunks_per_row, j0 = (chunk % chunks_per_row) * clen;
+  if (k >= ((size_t)1 << lgn)) return;
+  Fe<P> g = fe_pow_u64<P>(fe_to_mont<P>(fe_unpack<P>(root_plain.w)), emul);
+  Fe<P> gk = fe_pow_u64<P>(g, k);
+  Fe<P> cur = fe_mul<P>(fe_pow_u64<P>(gk, j0), fe_to_mont<P>(fe_unpack<P>(scale_plain.w)));
+  for (size_t i = 0; i < clen; i++) {
+    gstore<P>(out, k * M + j0 + i, fe_reduce<P>(cur));
+    cur = fe_mul<P>(cur, gk);
+  }
+}
+// Polynomial::scale (polynomial.rs:167-174) + zero padding (ntt.rs:264-267): out[i] = coef[i] * offset^i
+// for i < n_coef, 0 for n_coef <= i < order.
+template <class P>
+__global__ void k_coset_scale_pad(const u32* __restrict__ coef, size_t n_coef, Words8 offset_plain,
+                                  u32* __restrict__ out, size_t order) {
+  const size_t chunk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t j0 = chunk * GEN_CHUNK;
+  if (j0 >= order) return;
+  if (j0 >= n_coef) {
+    for (int i = 0; i < GEN_CHUNK && j0 + i < order; i++) gstore<P>(out, j0 + i, fe_zero<P>());
+    return;
+  }
+  Fe<P> g = fe_to_mont<P>(fe_unpack<P>(offset_plain.w));
+  Fe<P> cur = fe_pow_u64<P>(g, j0);
+  for (int i = 0; i < GEN_CHUNK && j0 + i < order; i++) {
+    if (j0 + i < n_coef) {
+      Fe<P> c = gload<P>(coef, j0 + i);
+      gstore<P>(out, j0 + i, fe_reduce<P>(fe_mul<P>(c, cur)));
+      cur = fe_mul<P>(cur, g);
+    } else {
+      gstore<P>(out, j0 + i, fe_zero<P>());
+    }
+  }
+}
+// out[i] = a[i] * b[i] (plain domain in and out; Hadamard step of the polynomial products)
+template <class P>
+__global__ void k_pointwise_mul(const u32* __restrict__ a, const u32* __restrict__ b, u32* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fe<P> x = gload<P>(a, i), y = gload<P>(b, i);
+  Fe<P> t = fe_mul<P>(fe_mul<P>(x, y), fe_r2<P>());
+  gstore<P>(out, i, fe_reduce<P>(t));
+}
+
+// ---- plans -------------------------------------------------------------------------------------------
+struct NttPlan {
+  int fid = -1;
+  unsigned logn = 0;
+  bool inverse = false;
+  uint64_t root[4] = {0, 0, 0, 0};     // forward root as passed by the caller
+  uint64_t scale[4] = {0, 0, 0, 0};    // extra plain scale folded into the tables (1 if none)
+  LevelInfo li{};
+  u32* tw_tile[4] = {nullptr, nullptr, nullptr, nullptr};
+  u32* tw_inter[3] = {nullptr, nullptr, nullptr};
+  Words8 last_scale{};                 // single-pass inverse: n^-1 (* scale), Montgomery
+  int has_last_scale = 0;
+  uint64_t stamp = 0;
+};
+static std::vector<NttPlan*> g_plans;
+static uint64_t g_stamp = 0;
+constexpr size_t MAX_PLANS = 12;
+
+static void free_plan(NttPlan* p) {
+  for (auto& t : p->tw_tile) if (t) (void)hipFree(t);
+  for (auto& t : p->tw_inter) if (t) (void)hipFree(t);
+  delete p;
+}
+void ntt_release_plans() {
+  for (auto* p : g_plans) free_plan(p);
+  g_plans.clear();
+}
+
+static LevelInfo choose_levels(unsigned logn) {
+  LevelInfo li{};
+  if (logn <= TILE_LOG) {
+    li.nlev = 1;
+    li.lg[0] = (int)logn;
+    return li;
+  }
+  int k = (int)((logn + MAX_LEVEL_LOG - 1) / MAX_LEVEL_LOG);
+  li.nlev = k;
+  int base = (int)logn / k, extra = (int)logn % k;
+  for (int i = 0; i < k; i++) li.lg[i] = base + (i < extra ? 1 : 0);
+  return li;
+}
+
+static void to_words(const uint64_t* limbs, int nl, Words8* w) {
+  memset(w, 0, sizeof *w);
+  for (int i = 0; i < nl; i++) {
+    w->w[2 * i] = (u32)limbs[i];
+    w->w[2 * i + 1] = (u32)(limbs[i] >> 32);
+  }
+}
+
+template <class P>
+static int build_tables(NttPlan* pl, const uint64_t* eff_root, const uint64_t* fold_scale, hipStream_t s) {
+  const HostField* hf = host_field(pl->fid);
+  Words8 rootw, scalew;
+  to_words(eff_root, hf->nl, &rootw);
+  to_words(fold_scale, hf->nl, &scalew);
+  uint64_t one[4] = {1, 0, 0, 0};
+  Words8 onew;
+  to_words(one, hf->nl, &onew);
+  const LevelInfo& li = pl->li;
+  const size_t esz = sizeof(u32) * P::NW;
+  int lg_after = (int)pl->logn;  // log of (n_t * M_t) while walking levels
+  for (int t = 0; t < li.nlev; t++) {
+    const int lgn = li.lg[t];
+    const int lgM = lg_after - lgn;
+    // in-tile twiddles: w_{n_t}^j = root^(j * n / n_t), j < n_t / 2
+    if (lgn >= 2) {
+      size_t cnt = (size_t)1 << (lgn - 1);
+      MZK_HIP(hipMalloc((void**)&pl->tw_tile[t], cnt * esz));
+      unsigned blocks = (unsigned)((cnt + GEN_CHUNK * 64 - 1) / (GEN_CHUNK * 64));
+      hipLaunchKernelGGL((k_gen_pow_table<P>), dim3(blocks), dim3(64), 0, s, rootw, (uint64_t)1 << (pl->logn - lgn), cnt,
+                         pl->tw_tile[t]);
+    }
+    if (t < li.nlev - 1) {
+      // inter-pass twiddles for the block of size n_t * M_t: primitive root = root^(n / (n_t M_t))
+      size_t cnt = (size_t)1 << lg_after;
+      MZK_HIP(hipMalloc((void**)&pl->tw_inter[t], cnt * esz));
+      size_t clen = ((size_t)1 << lgM) < (size_t)GEN_CHUNK ? ((size_t)1 << lgM) : (size_t)GEN_CHUNK;
+      size_t chunks = cnt / clen;
+      unsigned blocks = (unsigned)((chunks + 255) / 256);
+      hipLaunchKernelGGL((k_gen_inter_table<P>), dim3(blocks), dim3(256), 0, s, rootw,
+                         (uint64_t)1 << (pl->logn - lg_after), lgn, lgM, (t == 0) ? scalew : onew, pl->tw_inter[t]);
+    }
+    lg_after = lgM;
+  }
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+
+static int get_plan(int fid, unsigned logn, bool inverse, const uint64_t* root, const uint64_t* extra_scale,
+                    hipStream_t s, NttPlan** out) {
+  const HostField* hf = host_field(fid);
+  uint64_t one[4] = {1, 0, 0, 0};
+  const uint64_t* sc = extra_scale ? extra_scale : one;
+  for (auto* p : g_plans) {
+    if (p->fid == fid && p->logn == logn && p->inverse == inverse && !memcmp(p->root, root, 8 * hf->nl) &&
+        !memcmp(p->scale, sc, 8 * hf->nl)) {
+      p->stamp = ++g_stamp;
+      *out = p;
+      return MZK_OK;
+    }
+  }
+  // reference assertions, ntt.rs:15-22
+  const uint64_t n = (uint64_t)1 << logn;
+  uint64_t t[4];
+  h_powmod_u64(hf, t, root, n);
+  if (!h_is_one(hf, t)) { set_error("primitive root must be nth root of unity, where n is len(values)"); return MZK_E_ROOT_ORDER; }
+  h_powmod_u64(hf, t, root, n / 2);
+  if (h_is_one(hf, t)) { set_error("primitive root is not primitive nth root of unity, where n is len(values)"); return MZK_E_ROOT_PRIM; }
+
+  NttPlan* pl = new NttPlan();
+  pl->fid = fid; pl->logn = logn; pl->inverse = inverse;
+  memcpy(pl->root, root, 8 * hf->nl);
+  memcpy(pl->scale, sc, 8 * hf->nl);
+  pl->li = choose_levels(logn);
+  pl->stamp = ++g_stamp;
+  uint64_t eff_root[4] = {0, 0, 0, 0}, fold[4] = {0, 0, 0, 0};
+  memcpy(fold, sc, 8 * hf->nl);
+  if (inverse) {
+    h_powmod_u64(hf, eff_root, root, n - 1);  // root^-1 = root^(n-1)          (ntt.rs:59)
+    uint64_t ninv[4];
+    h_ninv_pow2(hf, logn, ninv);              // F::from_value(n).inverse()    (ntt.rs:58)
+    h_mulmod(hf, fold, fold, ninv);
+  } else {
+    memcpy(eff_root, root, 8 * hf->nl);
+  }
+  bool fold_is_one = h_is_one(hf, fold);
+  if (pl->li.nlev == 1 && !fold_is_one) {
+    // single pass: no inter-pass table to fold into -> explicit scale in the last pass (Montgomery form
+    // computed on the host: fold * R mod p via mulmod with R mod p)
+    uint64_t r_mod_p[4] = {0, 0, 0, 0}, two[4] = {2, 0, 0, 0};
+    // R = 2^(29 L): square-and-multiply on the host
+    h_powmod_u64(hf, r_mod_p, two, (uint64_t)(29 * (fid == MZK_FIELD_M128 ? 5 : 9)));
+    uint64_t m[4];
+    h_mulmod(hf, m, fold, r_mod_p);
+    to_words(m, hf->nl, &pl->last_scale);
+    pl->has_last_scale = 1;
+  }
+  int rc = (fid == MZK_FIELD_M128) ? build_tables<M128Params>(pl, eff_root, fold, s)
+                                   : build_tables<FrParams>(pl, eff_root, fold, s);
+  if (rc != MZK_OK) { free_plan(pl); return rc; }
+  if (g_plans.size() >= MAX_PLANS) {
+    size_t victim = 0;
+    for (size_t i = 1; i < g_plans.size(); i++) if (g_plans[i]->stamp < g_plans[victim]->stamp) victim = i;
+    MZK_HIP(hipStreamSynchronize(s));
+    free_plan(g_plans[victim]);
+    g_plans.erase(g_plans.begin() + victim);
+  }
+  g_plans.push_back(pl);
+  *out = pl;
+  return MZK_OK;
+}
+
+template <class P>
+static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t s) {
+  const LevelInfo& li = pl->li;
+  const unsigned logn = pl->logn;
+  const size_t lds_bytes = sizeof(u32) * P::L * TILE;
+  const u32* src = d_in;
+  u32* tmp = nullptr;
+  if (li.nlev > 1) MZK_TRY(ws_get(WS_NTT_TMP, ((size_t)1 << logn) * sizeof(u32) * P::NW, (void**)&tmp));
+  int lg_after = (int)logn;
+  for (int t = 0; t < li.nlev - 1; t++) {
+    const int lgn = li.lg[t], lgM = lg_after - lgn;
+    const int lgc = TILE_LOG - lgn;
+    const unsigned blocks = (unsigned)((size_t)1 << (logn - TILE_LOG));
+    hipLaunchKernelGGL((k_ntt_strided<P>), dim3(blocks), dim3(NTHREADS), lds_bytes, s, src, tmp, pl->tw_tile[t],
+                       pl->tw_inter[t], lgn, lgM, lgc);
+    src = tmp;
+    lg_after = lgM;
+  }
+  {
+    const int lgn = li.lg[li.nlev - 1];
+    const int lg_rows = (int)logn - lgn;
+    int lgr = TILE_LOG - lgn;
+    if (lgr > lg_rows) lgr = lg_rows;
+    const unsigned blocks = (unsigned)((size_t)1 << (lg_rows - lgr));
+    hipLaunchKernelGGL((k_ntt_last<P>), dim3(blocks), dim3(NTHREADS), lds_bytes, s, src, d_out,
+                       pl->tw_tile[li.nlev - 1], li, lgn, lgr, lg_rows, pl->last_scale, pl->has_last_scale);
+  }
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+
+static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+static unsigned ilog2(size_t n) { unsigned l = 0; while (((size_t)1 << l) < n) l++; return l; }
+
+// extra_scale_host: optional plain constant multiplied into every output (used by the polynomial
+// products to fold constants); nullptr = 1.
+int ntt_dev_impl(int fid, const uint64_t* root_host, const void* d_in, void* d_out, size_t n, int inverse,
+                 const uint64_t* extra_scale_host, hipStream_t s) {
+  if (fid != MZK_FIELD_FR && fid != MZK_FIELD_M128) { set_error("ntt: field id %d has no NTT on this path", fid); return MZK_E_ARG; }
+  if (n == 0) return MZK_OK;  // empty Vec in, empty Vec out (ntt.rs:12-14 `len <= 1`; len-1 underflow aside)
+  if (!is_pow2(n)) { set_error("cannot compute ntt of non-power-of-two sequence"); return MZK_E_NOT_POW2; }
+  if (!d_in || !d_out || (!root_host && n > 1)) { set_error("ntt: null pointer"); return MZK_E_ARG; }
+  const size_t esz = field_bytes(fid);
+  if (n == 1) {  // ntt.rs:12-14 / :54-56: returned unchanged
+    if (d_in != d_out) MZK_HIP(hipMemcpyAsync(d_out, d_in, esz, hipMemcpyDeviceToDevice, s));
+    return MZK_OK;
+  }
+  const HostField* hf = host_field(fid);
+  if (!h_is_canonical(hf, root_host)) { set_error("ntt: root not canonical"); return MZK_E_RANGE; }
+  if (ilog2(n) > 32) { set_error("ntt: n too large"); return MZK_E_ARG; }
+  NttPlan* pl = nullptr;
+  MZK_TRY(get_plan(fid, ilog2(n), inverse != 0, root_host, extra_scale_host, s, &pl));
+  if (fid == MZK_FIELD_M128) return run_plan<M128Params>(pl, (const u32*)d_in, (u32*)d_out, s);
+  return run_plan<FrParams>(pl, (const u32*)d_in, (u32*)d_out, s);
+}
+
+int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_t* offset_host,
+                       const uint64_t* generator_host, void* d_out, size_t order, hipStream_t s) {
+  if (fid != MZK_FIELD_FR && fid != MZK_FIELD_M128) { set_error("coset_lde: bad field id %d", fid); return MZK_E_ARG; }
+  if (n_coef > order) { set_error("attempt to subtract with overflow (order - polynomial.coef.len())"); return MZK_E_LENGTH; }
+  if (order == 0) return MZK_OK;
+  if (!is_pow2(order)) { set_error("cannot compute ntt of non-power-of-two sequence"); return MZK_E_NOT_POW2; }
+  if (!d_out || (!d_coef && n_coef) || !offset_host || !generator_host) { set_error("coset_lde: null pointer"); return MZK_E_ARG; }
+  const HostField* hf = host_field(fid);
+  if (!h_is_canonical(hf, offset_host) || !h_is_canonical(hf, generator_host)) { set_error("coset_lde: parameter not canonical"); return MZK_E_RANGE; }
+  Words8 offw;
+  to_words(offset_host, hf->nl, &offw);
+  void* scaled = nullptr;
+  MZK_TRY(ws_get(WS_NTT_IO_A, order * field_bytes(fid), &scaled));
+  const size_t chunks = (order + GEN_CHUNK - 1) / GEN_CHUNK;
+  const unsigned blocks = (unsigned)((chunks + 255) / 256);
+  if (fid == MZK_FIELD_M128)
+    hipLaunchKernelGGL((k_coset_scale_pad<M128Params>), dim3(blocks), dim3(256), 0, s, (const u32*)d_coef, n_coef, offw, (u32*)scaled, order);
+  else
+    hipLaunchKernelGGL((k_coset_scale_pad<FrParams>), dim3(blocks), dim3(256), 0, s, (const u32*)d_coef, n_coef, offw, (u32*)scaled, order);
+  MZK_HIP(hipGetLastError());
+  return ntt_dev_impl(fid, generator_host, scaled, d_out, order, 0, nullptr, s);
+}
+
+int pointwise_mul_dev(int fid, const void* d_a, const void* d_b, void* d_out, size_t n, hipStream_t s) {
+  if (n == 0) return MZK_OK;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  if (fid == MZK_FIELD_M128)
+    hipLaunchKernelGGL((k_pointwise_mul<M128Params>), dim3(blocks), dim3(256), 0, s, (const u32*)d_a, (const u32*)d_b, (u32*)d_out, n);
+  else
+    hipLaunchKernelGGL((k_pointwise_mul<FrParams>), dim3(blocks), dim3(256), 0, s, (const u32*)d_a, (const u32*)d_b, (u32*)d_out, n);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+
+}  // namespace mzk

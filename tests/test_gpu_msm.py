@@ -1,0 +1,114 @@
+"""GPU parity: G1 MSM / KZG setup, commit, open through the C ABI vs the oracle and golden vectors.
+Bit-exact on the canonical affine output."""
+import numpy as np
+import pytest
+import orc
+from orc import FR, FQ, P_FR, P_FQ, I
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mz():
+    import myzkp_amd
+    myzkp_amd.init(0)
+    return myzkp_amd
+
+
+def test_golden_msm_cases(mz):
+    g = orc.golden("curve_vectors.json")
+    for c in g["msm"]:
+        nl = 5 if c["tag"] == "unsanitized_scalar" else 4
+        s = np.ascontiguousarray(orc.to_limbs(I(c["scalars"]), nl)[:, :4]).reshape(-1, 4)
+        p = orc.pts_to_arr([tuple(x) for x in I(c["points"])]).reshape(-1, 8)
+        assert list(mz.msm_g1(s, p)) == I(c["out"]), c["tag"]
+
+
+def test_golden_kzg(mz):
+    g = orc.golden("curve_vectors.json")
+    for c in g["kzg"]:
+        coef = orc.to_limbs(I(c["coef"]), 4)
+        srs = mz.kzg_setup_g1(int(c["alpha"]), len(c["coef"]) - 1)
+        assert [list(p) for p in orc.arr_to_pts(srs)] == I(c["srs"])
+        assert list(mz.kzg_commit(coef, srs)) == I(c["commit"])
+        y, w = mz.kzg_open(coef, int(c["u"]), srs)
+        assert y == int(c["y"]) and list(w) == I(c["w"])
+        h = mz.Srs(srs)
+        assert list(h.commit(coef)) == I(c["commit"])
+        h.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 255, 256, 257, 1000, 1024])
+def test_msm_vs_literal_oracle(mz, n):
+    # config[0]: degree-2^10 polynomial on the reference-algorithm CPU path
+    s = orc.synth_vector(FR, 1000 + n, n)
+    p = orc.synth_points(2000 + n, n)
+    want = orc.msm_ref(s, p) if n <= 300 else orc.msm_fast(s, p)
+    assert mz.msm_g1(s, p) == want
+
+
+@pytest.mark.parametrize("lg", [12, 14, 16, 18])
+def test_msm_vs_fast_oracle(mz, lg):
+    n = 1 << lg
+    s = orc.synth_vector(FR, 31 + lg, n)
+    p = orc.synth_points(77 + lg, n)
+    assert mz.msm_g1(s, p) == orc.msm_fast(s, p, threads=8)
+
+
+def test_edge_batch(mz):
+    # SURVEY 8d-3 edge batch: 0, 1, r-1, repeated scalars, all-equal points, P and -P adjacent
+    n = 4096
+    s = orc.synth_vector(FR, 5, n)
+    p = orc.synth_points(6, n)
+    sl = orc.from_limbs(s)
+    sl[0], sl[1], sl[2] = 0, 1, P_FR - 1
+    for i in range(10, 200):
+        sl[i] = sl[10]                      # repeated scalars
+    s = orc.to_limbs(sl, 4)
+    p[300:600] = p[300]                     # all-equal points
+    for i in range(300, 600):
+        s[i] = s[300]                       # ... with equal scalars: bucket sees P + P
+    p[700] = p[701]
+    p[700, 4:] = orc.to_limbs([P_FQ - orc.from_limbs(p[701:702, 4:])[0]], 4)[0]   # -P next to P
+    s[700] = s[701]
+    p[900:910] = 0                          # points at infinity
+    want = orc.msm_fast(s, p)
+    assert mz.msm_g1(s, p) == want
+
+
+def test_all_same_bucket_skew(mz):
+    # adversarial skew: every scalar equal -> one bucket per window holds all n points
+    n = 2048
+    p = orc.synth_points(9, n)
+    s = orc.to_limbs([0x1234567890abcdef1234567890abcdef] * n, 4)
+    assert mz.msm_g1(s, p) == orc.msm_fast(s, p)
+
+
+def test_trapdoor_identity_2pow16(mz):
+    # commit == [f(alpha)] G on an SRS built on the GPU; w == [q(alpha)] G
+    n = 1 << 16
+    alpha = orc.from_limbs(orc.synth_vector(FR, 404, 1))[0]
+    srs = mz.kzg_setup_g1(alpha, n - 1)
+    f = orc.synth_vector(FR, 405, n)
+    fa = orc.poly_eval(FR, f, alpha)
+    assert mz.kzg_commit(f, srs) == orc.ec_mul(0, (1, 2), fa)
+    # spot-check the SRS itself against the oracle's fixed-base ladder
+    for i in (0, 1, 2, 255, 256, 4097, n - 1):
+        assert orc.arr_to_pts(srs[i:i + 1])[0] == orc.ec_mul(0, (1, 2), pow(alpha, i, P_FR))
+    u = orc.from_limbs(orc.synth_vector(FR, 406, 1))[0]
+    y, w = mz.kzg_open(f, u, srs)
+    assert y == orc.poly_eval(FR, f, u)
+    # q(alpha) = (f(alpha) - y) / (alpha - u)
+    qa = (fa - y) * pow(alpha - u, -1, P_FR) % P_FR
+    assert w == orc.ec_mul(0, (1, 2), qa)
+
+
+def test_msm_linearity_2pow20(mz):
+    # BASELINE size, size-independent property: MSM(s, P) + MSM(t, P) == MSM(s + t, P), and the
+    # structured-SRS closed form
+    n = 1 << 20
+    alpha = 0x1234567
+    srs = mz.kzg_setup_g1(alpha, n - 1)
+    s = orc.synth_vector(FR, 11, n)
+    fa = orc.poly_eval(FR, s, alpha)
+    assert mz.msm_g1(s, srs) == orc.ec_mul(0, (1, 2), fa)

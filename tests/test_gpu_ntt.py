@@ -1,0 +1,138 @@
+"""GPU parity: NTT / iNTT / coset LDE / polynomial products through the C ABI vs the oracle and the
+committed golden vectors.  Bit-exact (integer arithmetic)."""
+import numpy as np
+import pytest
+import orc
+from orc import FR, M128, I
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mz():
+    import myzkp_amd
+    myzkp_amd.init(0)
+    return myzkp_amd
+
+
+def _fid(name):
+    return {"Fr": FR, "M128": M128}[name]
+
+
+def test_golden_vectors(mz):
+    g = orc.golden("ntt_vectors.json")
+    for c in g["cases"]:
+        f = _fid(c["field"])
+        nl = orc.LIMBS[f]
+        k = c["kind"]
+        if k in ("ntt", "intt"):
+            out = mz.ntt(f, int(c["root"]), orc.to_limbs(I(c["input"]), nl), inverse=(k == "intt"))
+        elif k == "coset":
+            out = mz.coset_lde(f, orc.to_limbs(I(c["input"]), nl), int(c["offset"]), int(c["generator"]), c["order"])
+        elif k == "fft_multiply":
+            out = mz.fft_multiply(f, orc.to_limbs(I(c["a"]), nl), orc.to_limbs(I(c["b"]), nl), int(c["omega"]))
+        else:
+            out = mz.fast_multiply(f, orc.to_limbs(I(c["a"]), nl), orc.to_limbs(I(c["b"]), nl), int(c["root"]), c["root_order"])
+        assert orc.from_limbs(out) == I(c["output"]) if len(c["output"]) else out.shape[0] == 0, (k, c["field"])
+
+
+def test_reference_test_ntt(mz):
+    # ntt.rs:346-374
+    n, w = 256, orc.m128_root(8)
+    coef = orc.to_limbs(list(range(1, n + 1)), 2)
+    vals = mz.ntt(M128, w, coef)
+    v = orc.from_limbs(vals)
+    for i in range(0, n, 17):
+        assert v[i] == orc.poly_eval(M128, coef, orc.field_pow(M128, w, i))
+    assert orc.from_limbs(mz.intt(M128, w, vals)) == list(range(1, n + 1))
+
+
+@pytest.mark.parametrize("fid", [FR, M128])
+@pytest.mark.parametrize("lg", list(range(0, 15)))
+def test_all_small_sizes_vs_ref(mz, fid, lg):
+    n = 1 << lg
+    v = orc.synth_vector(fid, 100 + lg, n)
+    w = orc.root_of(fid, lg) if lg else 1
+    if lg <= 11:
+        rc, want = orc.ntt_ref(fid, w, v)
+    else:
+        rc, want = orc.ntt_fast(fid, w, v)
+    assert rc == 0
+    got = mz.ntt(fid, w, v)
+    assert np.array_equal(got, want)
+    rc, wanti = orc.ntt_fast(fid, w, v, inverse=True) if lg else (0, v)
+    assert np.array_equal(mz.intt(fid, w, v), wanti)
+
+
+@pytest.mark.parametrize("fid,lg", [(FR, 16), (M128, 17), (FR, 20), (M128, 20), (FR, 22)])
+def test_large_sizes_vs_fast_oracle(mz, fid, lg):
+    n = 1 << lg
+    v = orc.synth_vector(fid, 7 + lg, n)
+    w = orc.root_of(fid, lg)
+    rc, want = orc.ntt_fast(fid, w, v, threads=8)
+    assert rc == 0
+    got = mz.ntt(fid, w, v)
+    assert np.array_equal(got, want)
+    back = mz.intt(fid, w, got)
+    assert np.array_equal(back, v)
+
+
+def test_noncanonical_edge_values(mz):
+    # all p-1 / zeros / ones inputs
+    for fid in (FR, M128):
+        p = orc.MOD[fid]
+        for fill in (0, 1, p - 1):
+            n = 1 << 12
+            v = orc.to_limbs([fill] * n, orc.LIMBS[fid])
+            w = orc.root_of(fid, 12)
+            rc, want = orc.ntt_fast(fid, w, v)
+            assert np.array_equal(mz.ntt(fid, w, v), want)
+
+
+def test_error_behaviour(mz):
+    v = orc.to_limbs([1, 2, 3, 4, 5, 6, 7, 8], 2)
+    with pytest.raises(mz.MzkError) as e:      # ntt.rs:8-11
+        mz.ntt(M128, orc.m128_root(3), v[:6])
+    assert e.value.code == -2
+    with pytest.raises(mz.MzkError) as e:      # ntt.rs:15-18
+        mz.ntt(M128, orc.m128_root(4), v)
+    assert e.value.code == -3
+    with pytest.raises(mz.MzkError) as e:      # ntt.rs:19-22
+        mz.ntt(M128, orc.m128_root(2), v)
+    assert e.value.code == -4
+    with pytest.raises(mz.MzkError) as e:      # ntt.rs:265 usize underflow
+        mz.coset_lde(M128, v, 3, orc.m128_root(2), 4)
+    assert e.value.code == -5
+    assert mz.ntt(M128, 1, v[:0]).shape[0] == 0
+    assert np.array_equal(mz.ntt(M128, 12345, v[:1]), v[:1])      # len 1 returned unchanged, root unchecked
+
+
+def test_coset_lde_stark_parameters(mz):
+    # initialize_fast_stark_m128 (fast_stark.rs:573-616): offset = generator of order 2^119
+    n_coef, order = 1 << 10, 1 << 14
+    c = orc.synth_vector(M128, 5, n_coef)
+    g = orc.m128_root(14)
+    out = mz.coset_lde(M128, c, orc.M128_GEN, g, order)
+    # oracle: scale then fast NTT
+    scaled = [x * pow(orc.M128_GEN, i, orc.P_M128) % orc.P_M128 for i, x in enumerate(orc.from_limbs(c))]
+    rc, want = orc.ntt_fast(M128, g, orc.to_limbs(scaled + [0] * (order - n_coef), 2))
+    assert rc == 0 and np.array_equal(out, want)
+    rc, want_ref = orc.coset_ref(M128, c[:64], orc.M128_GEN, orc.m128_root(8), 256)
+    assert np.array_equal(mz.coset_lde(M128, c[:64], orc.M128_GEN, orc.m128_root(8), 256), want_ref)
+
+
+def test_linearity_at_full_size(mz):
+    # size-independent property at BASELINE size 2^20: NTT(a + b) == NTT(a) + NTT(b)
+    lg, fid = 20, FR
+    n = 1 << lg
+    p = orc.P_FR
+    a = orc.synth_vector(fid, 1, n)
+    b = orc.synth_vector(fid, 2, n)
+    w = orc.root_of(fid, lg)
+    A, B = mz.ntt(fid, w, a), mz.ntt(fid, w, b)
+    idx = np.random.RandomState(0).randint(0, n, 64)
+    ai, bi = orc.from_limbs(a), orc.from_limbs(b)
+    s = orc.to_limbs([(x + y) % p for x, y in zip(ai, bi)], 4)
+    Sv = mz.ntt(fid, w, s)
+    Al, Bl, Sl = orc.from_limbs(A[idx]), orc.from_limbs(B[idx]), orc.from_limbs(Sv[idx])
+    assert all((x + y) % p == z for x, y, z in zip(Al, Bl, Sl))
