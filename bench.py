@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MyZKP MSM / NTT prover path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log2n 20] [--skip-cpu]
+
+One JSON line on stdout (rank 0).  A "step" is one pass of the hot path over one batch of synthetic
+input already resident in HBM:
+  * primary (`value`): one BN254 G1 MSM of 2^log2n (scalar, point) pairs PER GPU (BASELINE.json
+    configs[2]; weak scaling: the N-GPU job is one MSM of N * 2^log2n pairs, contiguous shards, one
+    all-gather of N 128-byte partials over RCCL, local fold -- configs[3] shape);
+  * `ntt`: one forward radix-2 NTT of 2^log2n BN254-Fr elements per GPU (configs[1]; the transform
+    does not shard without an all-to-all, so N GPUs run N independent transforms -- "replicas").
+Both are checked bit-for-bit against the CPU oracle before timing.  `roofline` prices the dominant
+kernel against HBM bandwidth as BASELINE.md section 4 defines it (MSM: 96 B per pair, NTT: 2*32 B per
+element); `alu` adds the integer-multiply roofline that actually binds.
+"""
+import argparse, ctypes, json, os, sys, time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 0x4D595A4B50  # "MYZKP"
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MAD_PEAK_PER_S = 256 * 64 * 2.4e9   # v_mad_u64_u32 is half rate: 64 lanes/clk/CU (profiles/r01_ubench_instr_rates.txt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2n", type=int, default=20)
+    ap.add_argument("--skip-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--extra-sizes", type=str, default="24", help="comma list of extra log2 sizes timed once each (rank 0 view)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import myzkp_amd as mz
+    from myzkp_amd import sharded
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    dev = torch.device("cuda", local_rank)
+    mz.init(local_rank)
+    L = mz.lib()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def check(rc):
+        if rc != 0:
+            raise RuntimeError(L.mzk_last_error().decode())
+
+    def dptr(t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    def barrier_sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    n = 1 << args.log2n
+    # ------------------------------------------------------------------ synthetic inputs, resident in HBM
+    # global problem = world * n pairs; rank g owns indices [g n, (g+1) n) of the global streams
+    def synth_shard(nn, r):
+        sc = torch.empty(nn * 4, dtype=torch.int64, device=dev)
+        pt = torch.empty(nn * 8, dtype=torch.int64, device=dev)
+        # distinct streams per rank: seed offset keeps shards independent and reproducible
+        check(L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(SEED + 1000003 * r), ctypes.c_size_t(nn), dptr(sc), stream))
+        check(L.mzk_synth_g1_points_dev(ctypes.c_uint64(SEED + 7 + 1000003 * r), ctypes.c_size_t(nn), dptr(pt), stream))
+        return sc, pt
+
+    scalars, points = synth_shard(n, rank)
+    ntt_in = torch.empty(n * 4, dtype=torch.int64, device=dev)
+    ntt_out = torch.empty(n * 4, dtype=torch.int64, device=dev)
+    check(L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(SEED + 99 + rank), ctypes.c_size_t(n), dptr(ntt_in), stream))
+    root = mz.to_limbs([mz.root_of_unity(mz.FIELD_FR, args.log2n)], 4)
+    partial = torch.zeros(16, dtype=torch.int64, device=dev)
+    result = torch.zeros(8, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+
+    def msm_step():
+        check(L.mzk_msm_g1_bn254_partial_dev(dptr(scalars), dptr(points), ctypes.c_size_t(n), dptr(partial), stream))
+        recs = sharded.all_gather_partials(partial)
+        check(L.mzk_g1_fold_partials_dev(dptr(recs), ctypes.c_int(recs.shape[0]), dptr(result), stream))
+
+    def ntt_step():
+        check(L.mzk_ntt_dev(mz.FIELD_FR, root.ctypes.data_as(ctypes.c_void_p), dptr(ntt_in), dptr(ntt_out), ctypes.c_size_t(n), 0, stream))
+
+    # ------------------------------------------------------------------ parity before timing (bit-exact vs CPU oracle)
+    parity = {}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    msm_step()
+    torch.cuda.synchronize()
+    if rank == 0:
+        threads = os.cpu_count() or 1
+        # same streams on the CPU for every rank's shard
+        want = (0, 0)
+        for r in range(world):
+            s_cpu = orc.synth_vector(orc.FR, SEED + 1000003 * r, n, threads)
+            p_cpu = orc.synth_points(SEED + 7 + 1000003 * r, n, threads)
+            if r == 0:
+                assert np.array_equal(s_cpu.view(np.int64).reshape(-1), scalars.cpu().numpy()), "GPU synth scalars != oracle"
+                assert np.array_equal(p_cpu.view(np.int64).reshape(-1), points.cpu().numpy()), "GPU synth points != oracle"
+            want = orc.ec_add(0, want, orc.msm_fast(s_cpu, p_cpu, threads))
+        got = mz.array_to_points(result.cpu().numpy().view(np.uint64))[0]
+        parity["msm_bit_exact_vs_cpu"] = bool(got == want)
+        assert got == want, "MSM mismatch vs CPU oracle"
+    ntt_step()
+    torch.cuda.synchronize()
+    if rank == 0:
+        v_cpu = orc.synth_vector(orc.FR, SEED + 99, n, os.cpu_count() or 1)
+        rc, want = orc.ntt_fast(orc.FR, mz.from_limbs(root)[0], v_cpu, threads=os.cpu_count() or 1)
+        ok = rc == 0 and np.array_equal(want.view(np.int64).reshape(-1), ntt_out.cpu().numpy())
+        parity["ntt_bit_exact_vs_cpu"] = bool(ok)
+        assert ok, "NTT mismatch vs CPU oracle"
+
+    # ------------------------------------------------------------------ timed regions
+    def timed(step, K, W):
+        for _ in range(W):
+            step()
+        L.mzk_prof_reset()
+        L.mzk_prof_enable(1)
+        barrier_sync()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            step()
+        barrier_sync()
+        dt = time.perf_counter() - t0
+        L.mzk_prof_enable(0)
+        phases = {}
+        for ph in range(10):
+            ms, cnt = ctypes.c_double(0), ctypes.c_uint64(0)
+            check(L.mzk_prof_read(ph, ctypes.byref(ms), ctypes.byref(cnt)))
+            if cnt.value:
+                phases[L.mzk_prof_name(ph).decode() if isinstance(L.mzk_prof_name(ph), bytes) else str(ph)] = {
+                    "avg_ms": ms.value / cnt.value, "launches": cnt.value}
+        return max_over_ranks(dt), phases
+
+    L.mzk_prof_name.restype = ctypes.c_char_p
+    K, W = args.steps, args.warmup
+    msm_dt, msm_ph = timed(msm_step, K, W)
+    ntt_dt, ntt_ph = timed(ntt_step, K, W)
+
+    msm_ms = msm_dt / K * 1e3
+    ntt_ms = ntt_dt / K * 1e3
+    msm_rate = world * n / (msm_dt / K)
+    ntt_rate = world * n / (ntt_dt / K)
+
+    def hbm_roofline(alg_bytes, ms):
+        ach = alg_bytes / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None}
+
+    acc_ms = msm_ph.get("msm_bucket_accumulate", {}).get("avg_ms", float("nan"))
+    roof = hbm_roofline(96.0 * n, acc_ms)
+    roof["kernel"] = "k_bucket_accumulate"
+    roof["algorithmic_bytes_per_launch"] = 96 * n
+    ntt_total_ms = sum(v["avg_ms"] for k, v in ntt_ph.items() if k.startswith("ntt_pass"))
+    ntt_roof = hbm_roofline(64.0 * n, ntt_total_ms)
+    ntt_roof["kernel"] = "k_ntt_strided + k_ntt_last (whole transform, %d passes)" % sum(1 for k in ntt_ph if k.startswith("ntt_pass"))
+    ntt_roof["algorithmic_bytes_per_launch"] = 64 * n
+    # integer-multiply roofline (the binding one): v_mad_u64_u32 per Montgomery product = 171
+    nwin, c = 254 // 16 + 1, 16
+    msm_mads = n * nwin * (8 * 171 + 2 * 135)           # madd = 8M + 2S per (pair, window)
+    ntt_mads = (n // 2) * args.log2n * 171
+    alu = {"unit": "v_mad_u64_u32/s", "peak": MAD_PEAK_PER_S,
+           "msm_accumulate_frac": msm_mads / (acc_ms * 1e-3) / MAD_PEAK_PER_S if acc_ms == acc_ms else None,
+           "ntt_frac": ntt_mads / (ntt_total_ms * 1e-3) / MAD_PEAK_PER_S if ntt_total_ms else None}
+
+    out = {
+        "metric": "G1 MSM pairs/sec + NTT elems/sec at 2^20 and 2^24; bit-exact vs CPU",
+        "value": msm_rate, "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": msm_ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 254-bit Montgomery)",
+        "data": "synthetic",
+        "config": {"workload": "BN254 G1 Pippenger MSM, 2^%d pairs per GPU, 16-bit signed windows (BASELINE configs[2]; N GPUs = one MSM of N*2^%d pairs, configs[3] shape)" % (args.log2n, args.log2n),
+                   "pairs_per_gpu": n, "seed": SEED, "sharding": "contiguous shards + all_gather of 128 B partials (RCCL) + local fold"},
+        "roofline": roof,
+        "ntt": {"metric": "NTT elems/sec", "value": ntt_rate, "unit": "elems/s", "ms_per_step": ntt_ms, "field": "BN254 Fr",
+                "log2n": args.log2n, "multi_gpu": "replicas only (one independent transform per GPU)", "roofline": ntt_roof,
+                "phases": ntt_ph},
+        "alu_roofline": alu,
+        "phases": msm_ph,
+        "parity": parity,
+    }
+
+    # ------------------------------------------------------------------ extra sizes (single GPU view, rank 0 only, once each)
+    extras = {}
+    if rank == 0:
+        for lg in [int(x) for x in args.extra_sizes.split(",") if x]:
+            if lg == args.log2n:
+                continue
+            try:
+                nn = 1 << lg
+                sc, pt = synth_shard(nn, 0)
+                vin = torch.empty(nn * 4, dtype=torch.int64, device=dev)
+                vout = torch.empty(nn * 4, dtype=torch.int64, device=dev)
+                check(L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(SEED + 99), ctypes.c_size_t(nn), dptr(vin), stream))
+                rt = mz.to_limbs([mz.root_of_unity(mz.FIELD_FR, lg)], 4)
+                res = torch.zeros(8, dtype=torch.int64, device=dev)
+                def m():
+                    check(L.mzk_msm_g1_bn254_dev(dptr(sc), dptr(pt), ctypes.c_size_t(nn), dptr(res), stream))
+                def t():
+                    check(L.mzk_ntt_dev(mz.FIELD_FR, rt.ctypes.data_as(ctypes.c_void_p), dptr(vin), dptr(vout), ctypes.c_size_t(nn), 0, stream))
+                e = {}
+                for name, fn, reps in (("msm", m, 2), ("ntt", t, 3)):
+                    fn(); torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        fn()
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) / reps
+                    e[name] = {"ms": dt * 1e3, "rate": nn / dt, "hbm_frac": (96.0 if name == "msm" else 64.0) * nn / dt / 1e9 / HBM_PEAK_GBPS}
+                # round trip property at this size: intt(ntt(x)) == x
+                check(L.mzk_ntt_dev(mz.FIELD_FR, rt.ctypes.data_as(ctypes.c_void_p), dptr(vout), dptr(vout), ctypes.c_size_t(nn), 1, stream))
+                torch.cuda.synchronize()
+                e["ntt_roundtrip_ok"] = bool(torch.equal(vin, vout))
+                extras["2^%d" % lg] = e
+                del sc, pt, vin, vout
+                torch.cuda.empty_cache()
+            except Exception as ex:  # an extra must never sink the headline line
+                extras["2^%d" % lg] = {"error": str(ex)[:200]}
+    out["extra_sizes_1gpu"] = extras
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only, bounded sample)
+    if rank == 0 and world == 1 and not args.skip_cpu:
+        cores = os.cpu_count() or 1
+        sample = 1 << 11
+        s_cpu = orc.synth_vector(orc.FR, SEED, sample, cores)
+        p_cpu = orc.synth_points(SEED + 7, sample, cores)
+        t0 = time.perf_counter()
+        orc.msm_ref(s_cpu, p_cpu)
+        dt = time.perf_counter() - t0
+        cb = {"value": sample / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+              "sample": "first 2^11 pairs of the same stream through oracle orc_msm_ref (literal restatement of "
+                        "polynomial.rs:156-165: affine double-and-add, one inversion per group op); MSM cost is linear in n"}
+        nn = min(n, 1 << 18)
+        s2 = orc.synth_vector(orc.FR, SEED, nn, cores)
+        p2 = orc.synth_points(SEED + 7, nn, cores)
+        t0 = time.perf_counter()
+        orc.msm_fast(s2, p2, cores)
+        dt2 = time.perf_counter() - t0
+        cb["cpu_fast"] = {"value": nn / dt2, "unit": "pairs/s", "cores": cores, "what": "oracle Pippenger (orc_msm_fast), 2^%d pairs" % (nn.bit_length() - 1)}
+        lgs = 14
+        v = orc.synth_vector(orc.FR, SEED + 99, 1 << lgs, cores)
+        t0 = time.perf_counter()
+        orc.ntt_ref(orc.FR, orc.fr_root(lgs), v)
+        dt3 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        vv = orc.synth_vector(orc.FR, SEED + 99, n, cores)
+        orc.ntt_fast(orc.FR, orc.fr_root(args.log2n), vv, threads=cores)
+        dt4 = time.perf_counter() - t0
+        cb["ntt"] = {"value": (1 << lgs) / dt3, "unit": "elems/s", "cores": 1, "kind": "port",
+                     "sample": "2^14-point oracle orc_ntt_ref (literal ntt.rs:7-48, one pow per output per level; O(n log^2 n), so larger n is slower per element)",
+                     "cpu_fast": {"value": n / dt4, "unit": "elems/s", "cores": cores, "what": "oracle iterative NTT incl. input generation, 2^%d" % args.log2n}}
+        out["cpu_baseline"] = cb
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -111,6 +111,16 @@ int mzk_g1_fold_partials_dev(const void* d_partials16, int count, void* d_out_xy
 int mzk_synth_field_dev(int field_id, uint64_t seed, size_t n, void* d_out, void* stream);
 int mzk_synth_g1_points_dev(uint64_t seed, size_t n, void* d_out_xy, void* stream);
 
+/* ---- per-phase device timing (HIP events recorded on the launch stream around each kernel group) ---- */
+enum { MZK_PH_MSM_PREPARE = 0, MZK_PH_MSM_SORT = 1, MZK_PH_MSM_ACCUMULATE = 2, MZK_PH_MSM_REDUCE = 3,
+       MZK_PH_MSM_COMBINE = 4, MZK_PH_NTT_PASS0 = 5, MZK_PH_NTT_PASS1 = 6, MZK_PH_NTT_PASS2 = 7,
+       MZK_PH_NTT_PASS3 = 8, MZK_PH_NTT_PRESCALE = 9, MZK_PH_COUNT = 10 };
+int mzk_prof_enable(int on);
+int mzk_prof_reset(void);
+/* Synchronises the device, folds all pending event pairs, returns accumulated ms and launch count. */
+int mzk_prof_read(int phase, double* total_ms, uint64_t* launches);
+const char* mzk_prof_name(int phase);
+
 #ifdef __cplusplus
 }
 #endif

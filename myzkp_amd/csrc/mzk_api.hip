@@ -47,6 +47,44 @@ void ws_release_all() {
   }
 }
 
+// ---- profiling --------------------------------------------------------------------------------------
+static bool g_prof_on = false;
+struct ProfPair { hipEvent_t a, b; int phase; };
+static std::vector<ProfPair> g_prof_pending;
+static std::vector<hipEvent_t> g_prof_pool;
+static hipEvent_t g_prof_open[MZK_PH_COUNT];
+static double g_prof_ms[MZK_PH_COUNT];
+static uint64_t g_prof_cnt[MZK_PH_COUNT];
+static hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void prof_begin(hipStream_t s, int phase) {
+  if (!g_prof_on) return;
+  hipEvent_t e = prof_event();
+  (void)hipEventRecord(e, s);
+  g_prof_open[phase] = e;
+}
+void prof_end(hipStream_t s, int phase) {
+  if (!g_prof_on || !g_prof_open[phase]) return;
+  hipEvent_t e = prof_event();
+  (void)hipEventRecord(e, s);
+  g_prof_pending.push_back({g_prof_open[phase], e, phase});
+  g_prof_open[phase] = nullptr;
+}
+static void prof_drain() {
+  (void)hipDeviceSynchronize();
+  for (auto& pr : g_prof_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) { g_prof_ms[pr.phase] += ms; g_prof_cnt[pr.phase]++; }
+    g_prof_pool.push_back(pr.a);
+    g_prof_pool.push_back(pr.b);
+  }
+  g_prof_pending.clear();
+}
+
 int ensure_init() {
   if (g_ctx.ready) return MZK_OK;
   return mzk_init(g_ctx.device >= 0 ? g_ctx.device : 0);
@@ -164,6 +202,25 @@ void mzk_shutdown(void) {
   if (g_ctx.stream) (void)hipStreamDestroy(g_ctx.stream);
   g_ctx.stream = nullptr;
   g_ctx.ready = false;
+}
+
+int mzk_prof_enable(int on) { g_prof_on = on != 0; return MZK_OK; }
+int mzk_prof_reset(void) {
+  prof_drain();
+  for (int i = 0; i < MZK_PH_COUNT; i++) { g_prof_ms[i] = 0; g_prof_cnt[i] = 0; }
+  return MZK_OK;
+}
+int mzk_prof_read(int phase, double* total_ms, uint64_t* launches) {
+  if (phase < 0 || phase >= MZK_PH_COUNT || !total_ms || !launches) { set_error("prof_read: bad argument"); return MZK_E_ARG; }
+  prof_drain();
+  *total_ms = g_prof_ms[phase];
+  *launches = g_prof_cnt[phase];
+  return MZK_OK;
+}
+const char* mzk_prof_name(int phase) {
+  static const char* names[MZK_PH_COUNT] = {"msm_prepare_points", "msm_digit_sort", "msm_bucket_accumulate", "msm_bucket_reduce",
+                                            "msm_window_combine", "ntt_pass0", "ntt_pass1", "ntt_pass2", "ntt_pass3", "ntt_coset_prescale"};
+  return (phase >= 0 && phase < MZK_PH_COUNT) ? names[phase] : "?";
 }
 
 int mzk_root_of_unity(int field_id, unsigned log2_n, uint64_t* out) {

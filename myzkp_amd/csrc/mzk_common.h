@@ -44,6 +44,15 @@ enum WsSlot { WS_NTT_TMP = 0, WS_NTT_IO_A, WS_NTT_IO_B, WS_MSM_POINTS, WS_MSM_SC
 int ws_get(WsSlot slot, size_t bytes, void** out);
 void ws_release_all();
 
+// ---- per-phase timing (no-ops unless mzk_prof_enable(1)) ---------------------------------------------
+void prof_begin(hipStream_t s, int phase);
+void prof_end(hipStream_t s, int phase);
+struct ProfScope {
+  hipStream_t s; int ph;
+  ProfScope(hipStream_t s_, int ph_) : s(s_), ph(ph_) { prof_begin(s, ph); }
+  ~ProfScope() { prof_end(s, ph); }
+};
+
 // ---- host parameter math (O(log n) scalar work: roots, n^-1, canonical checks; never on the data path)
 struct HostField {
   int nl;            // u64 limbs

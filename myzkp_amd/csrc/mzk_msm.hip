@@ -329,7 +329,9 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, bool poi
   if (!points_are_mont) {
     void* pm;
     MZK_TRY(ws_get(WS_MSM_POINTS, n * 64, &pm));
+    prof_begin(s, MZK_PH_MSM_PREPARE);
     MZK_TRY(msm_prepare_points(d_points, n, pm, s));
+    prof_end(s, MZK_PH_MSM_PREPARE);
     pts = (const u32*)pm;
   }
   u32 *counts, *offsets, *cursor, *entries, *scan_tmp, *buckets;
@@ -340,6 +342,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, bool poi
   MZK_TRY(ws_get(WS_MSM_ENTRIES, n * (size_t)sh.nwin * 4, (void**)&entries));
   MZK_TRY(ws_get(WS_MSM_SCAN, (scan_blocks + 1) * 4, (void**)&scan_tmp));
   MZK_TRY(ws_get(WS_MSM_BUCKETS, NB * 128, (void**)&buckets));
+  prof_begin(s, MZK_PH_MSM_SORT);
   MZK_HIP(hipMemsetAsync(counts, 0, NB * 4, s));
   const unsigned nblk = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL((k_digits<false>), dim3(nblk), dim3(256), 0, s, (const u32*)d_scalars, n, sh.c, sh.nwin, counts, (u32*)nullptr);
@@ -348,7 +351,11 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, bool poi
   hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((NB + 1 + 255) / 256)), dim3(256), 0, s, offsets, cursor, scan_tmp,
                      scan_tmp + scan_blocks, NB);
   hipLaunchKernelGGL((k_digits<true>), dim3(nblk), dim3(256), 0, s, (const u32*)d_scalars, n, sh.c, sh.nwin, cursor, entries);
+  prof_end(s, MZK_PH_MSM_SORT);
+  prof_begin(s, MZK_PH_MSM_ACCUMULATE);
   hipLaunchKernelGGL(k_bucket_accumulate, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, s, pts, offsets, entries, buckets, NB);
+  prof_end(s, MZK_PH_MSM_ACCUMULATE);
+  prof_begin(s, MZK_PH_MSM_REDUCE);
 
   // bucket reduction: weights (b+1) = b + 1  =>  W0(X) + Sum(X)
   const size_t B = (size_t)1 << sh.lgB;
@@ -403,7 +410,10 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, bool poi
   }
   ca.nlevels = nlev;
   ca.sum = (nlev == 0) ? buckets : X;  // after the last level X holds Sum per window (n = 1)
+  prof_end(s, MZK_PH_MSM_REDUCE);
+  prof_begin(s, MZK_PH_MSM_COMBINE);
   hipLaunchKernelGGL(k_window_combine, dim3(1), dim3(64), 0, s, ca, (u32*)d_out);
+  prof_end(s, MZK_PH_MSM_COMBINE);
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }

@@ -401,8 +401,11 @@ static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t 
     const int lgn = li.lg[t], lgM = lg_after - lgn;
     const int lgc = TILE_LOG - lgn;
     const unsigned blocks = (unsigned)((size_t)1 << (logn - TILE_LOG));
-    hipLaunchKernelGGL((k_ntt_strided<P>), dim3(blocks), dim3(NTHREADS), lds_bytes, s, src, tmp, pl->tw_tile[t],
-                       pl->tw_inter[t], lgn, lgM, lgc);
+    {
+      ProfScope ps(s, MZK_PH_NTT_PASS0 + t);
+      hipLaunchKernelGGL((k_ntt_strided<P>), dim3(blocks), dim3(NTHREADS), lds_bytes, s, src, tmp, pl->tw_tile[t],
+                         pl->tw_inter[t], lgn, lgM, lgc);
+    }
     src = tmp;
     lg_after = lgM;
   }
@@ -412,6 +415,7 @@ static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t 
     int lgr = TILE_LOG - lgn;
     if (lgr > lg_rows) lgr = lg_rows;
     const unsigned blocks = (unsigned)((size_t)1 << (lg_rows - lgr));
+    ProfScope ps(s, MZK_PH_NTT_PASS0 + li.nlev - 1);
     hipLaunchKernelGGL((k_ntt_last<P>), dim3(blocks), dim3(NTHREADS), lds_bytes, s, src, d_out,
                        pl->tw_tile[li.nlev - 1], li, lgn, lgr, lg_rows, pl->last_scale, pl->has_last_scale);
   }
@@ -459,11 +463,13 @@ int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_
   MZK_TRY(ws_get(WS_NTT_IO_A, order * field_bytes(fid), &scaled));
   const size_t chunks = (order + GEN_CHUNK - 1) / GEN_CHUNK;
   const unsigned blocks = (unsigned)((chunks + 255) / 256);
+  prof_begin(s, MZK_PH_NTT_PRESCALE);
   if (fid == MZK_FIELD_M128)
     hipLaunchKernelGGL((k_coset_scale_pad<M128Params>), dim3(blocks), dim3(256), 0, s, (const u32*)d_coef, n_coef, offw, (u32*)scaled, order);
   else
     hipLaunchKernelGGL((k_coset_scale_pad<FrParams>), dim3(blocks), dim3(256), 0, s, (const u32*)d_coef, n_coef, offw, (u32*)scaled, order);
   MZK_HIP(hipGetLastError());
+  prof_end(s, MZK_PH_NTT_PRESCALE);
   return ntt_dev_impl(fid, generator_host, scaled, d_out, order, 0, nullptr, s);
 }
 
