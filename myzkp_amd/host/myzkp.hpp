@@ -1,0 +1,214 @@
+// myzkp.hpp -- host-side mirror of MyZKP's Rust surface for the MSM / NTT path, over the C ABI.
+//
+// The reference is Rust and rustc is not available in this environment, so the host side above
+// include/mzk.h is written in C++ with the SAME names, argument meaning and error behaviour as the
+// Rust items it mirrors (paths relative to myzkp/src/modules/):
+//
+//   FiniteFieldElement<M>, ModulusValue      algebra/field.rs:87-133, :94-96
+//   EllipticCurvePoint (BN254 G1 only)       algebra/curve/curve.rs:17-46, curve/bn128.rs:31
+//   Polynomial<F>                            algebra/polynomial.rs:69-74
+//     ::eval_with_powers_on_curve            polynomial.rs:156-165      -> mzk_msm_g1_bn254
+//     ::fft_multiply                         polynomial.rs:242-276      -> mzk_fft_multiply
+//   ntt / intt / fast_multiply / fast_coset_evaluate   algebra/ntt.rs:7-116, :254-269
+//   PublicKeyKZG, ProofKZG, setup_kzg_with_alpha / commit_kzg / open_kzg   algebra/kzg.rs:8-72
+//   get_nth_root_of_m128                     zkstark/fri.rs:423-447
+//
+// Values are held canonical (u64 limbs) -- the ABI wire format; arithmetic on single elements that the
+// reference does on the host (a handful of scalar ops in tests) is not offered here: this header only
+// marshals the bulk operations to the GPU.  Rust panics become C++ exceptions carrying the same text.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/mzk.h"
+
+namespace myzkp {
+
+struct Panic : std::runtime_error {
+  int code;
+  Panic(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+inline void expect(int rc) {
+  if (rc != MZK_OK) throw Panic(rc, mzk_last_error());
+}
+
+// ---- ModulusValue phantom types (field.rs:94-96, :408-431; bn128.rs:19-30; fri.rs:408) -------------
+struct ModEIP197 { static constexpr int FIELD_ID = MZK_FIELD_FR; static constexpr int LIMBS = 4; };
+struct BN128Modulus { static constexpr int FIELD_ID = MZK_FIELD_FQ; static constexpr int LIMBS = 4; };
+struct M128 { static constexpr int FIELD_ID = MZK_FIELD_M128; static constexpr int LIMBS = 2; };
+
+template <class M> struct FiniteFieldElement {
+  std::array<uint64_t, M::LIMBS> value{};  // canonical little-endian limbs (sanitize()d, field.rs:260-270)
+  FiniteFieldElement() = default;
+  static FiniteFieldElement from_value(uint64_t v) {  // Ring::from_value for small values
+    FiniteFieldElement e;
+    e.value[0] = v;
+    return e;
+  }
+  static FiniteFieldElement from_limbs(const uint64_t* l) {
+    FiniteFieldElement e;
+    std::memcpy(e.value.data(), l, 8 * M::LIMBS);
+    return e;
+  }
+  static FiniteFieldElement zero() { return FiniteFieldElement(); }
+  static FiniteFieldElement one() { return from_value(1); }
+  bool is_zero() const {
+    for (auto x : value) if (x) return false;
+    return true;
+  }
+  bool operator==(const FiniteFieldElement& o) const { return value == o.value; }
+  bool operator!=(const FiniteFieldElement& o) const { return !(*this == o); }
+};
+using FqOrder = FiniteFieldElement<ModEIP197>;  // bn128.rs:30
+using Fq = FiniteFieldElement<BN128Modulus>;    // bn128.rs:29
+
+// ---- EllipticCurvePoint<Fq, BN128Curve> = G1Point (curve.rs:17-46; bn128.rs:31) ------------------------
+struct G1Point {
+  bool infinity = true;  // x, y = None in the reference
+  Fq x, y;
+  static G1Point point_at_infinity() { return G1Point(); }
+  static G1Point new_point(const Fq& x, const Fq& y) {
+    G1Point p;
+    p.infinity = false; p.x = x; p.y = y;
+    return p;
+  }
+  bool is_point_at_infinity() const { return infinity; }
+  bool operator==(const G1Point& o) const { return infinity == o.infinity && (infinity || (x == o.x && y == o.y)); }
+  void to_wire(uint64_t* w) const {  // all-zero = infinity
+    if (infinity) { std::memset(w, 0, 64); return; }
+    std::memcpy(w, x.value.data(), 32);
+    std::memcpy(w + 4, y.value.data(), 32);
+  }
+  static G1Point from_wire(const uint64_t* w) {
+    bool z = true;
+    for (int i = 0; i < 8; i++) z = z && w[i] == 0;
+    if (z) return point_at_infinity();
+    return new_point(Fq::from_limbs(w), Fq::from_limbs(w + 4));
+  }
+};
+struct BN128 {  // bn128.rs:183-216
+  static G1Point generator_g1() { return G1Point::new_point(Fq::from_value(1), Fq::from_value(2)); }
+};
+
+template <class F> static std::vector<uint64_t> to_wire(const std::vector<F>& v) {
+  std::vector<uint64_t> w(v.size() * F().value.size());
+  for (size_t i = 0; i < v.size(); i++) std::memcpy(&w[i * v[i].value.size()], v[i].value.data(), 8 * v[i].value.size());
+  return w;
+}
+template <class F> static std::vector<F> from_wire(const std::vector<uint64_t>& w, size_t n) {
+  std::vector<F> v(n);
+  for (size_t i = 0; i < n; i++) std::memcpy(v[i].value.data(), &w[i * v[i].value.size()], 8 * v[i].value.size());
+  return v;
+}
+static inline std::vector<uint64_t> points_to_wire(const std::vector<G1Point>& p) {
+  std::vector<uint64_t> w(p.size() * 8);
+  for (size_t i = 0; i < p.size(); i++) p[i].to_wire(&w[8 * i]);
+  return w;
+}
+
+// ---- Polynomial<F> (polynomial.rs:69-74), coefficients in ascending degree ---------------------------
+template <class F> struct Polynomial {
+  std::vector<F> coef;
+
+  // polynomial.rs:156-165.  `powers.len() < coef.len()` is the reference's slice-index panic.
+  G1Point eval_with_powers_on_curve(const std::vector<G1Point>& powers) const {
+    static_assert(std::is_same<F, FqOrder>::value, "MSM scalars live in FqOrder");
+    if (powers.size() < coef.size())
+      throw Panic(MZK_E_LENGTH, "index out of bounds: the len is " + std::to_string(powers.size()) + " but the index is " + std::to_string(powers.size()));
+    auto s = to_wire(coef);
+    std::vector<uint64_t> p(coef.size() * 8);
+    for (size_t i = 0; i < coef.size(); i++) powers[i].to_wire(&p[8 * i]);
+    uint64_t out[8];
+    expect(mzk_msm_g1_bn254(s.data(), p.data(), coef.size(), out));
+    return G1Point::from_wire(out);
+  }
+
+  // polynomial.rs:242-276
+  Polynomial fft_multiply(const Polynomial& other, const F& omega) const {
+    auto a = to_wire(coef), b = to_wire(other.coef);
+    std::vector<uint64_t> out((coef.size() + other.coef.size() + 1) * F().value.size());
+    size_t n = 0;
+    expect(mzk_fft_multiply(field_id(), a.data(), coef.size(), b.data(), other.coef.size(), omega.value.data(), out.data(), &n));
+    return Polynomial{from_wire<F>(out, n)};
+  }
+  static int field_id() { return F().value.size() == 2 ? MZK_FIELD_M128 : MZK_FIELD_FR; }
+};
+
+// ---- algebra/ntt.rs ---------------------------------------------------------------------------------------
+template <class F> std::vector<F> ntt(const F& primitive_root, const std::vector<F>& values) {  // ntt.rs:7-48
+  auto in = to_wire(values);
+  std::vector<uint64_t> out(in.size());
+  expect(mzk_ntt(Polynomial<F>::field_id(), primitive_root.value.data(), in.data(), out.data(), values.size(), 0));
+  return from_wire<F>(out, values.size());
+}
+template <class F> std::vector<F> intt(const F& primitive_root, const std::vector<F>& values) {  // ntt.rs:50-64
+  auto in = to_wire(values);
+  std::vector<uint64_t> out(in.size());
+  expect(mzk_ntt(Polynomial<F>::field_id(), primitive_root.value.data(), in.data(), out.data(), values.size(), 1));
+  return from_wire<F>(out, values.size());
+}
+template <class F>
+Polynomial<F> fast_multiply(const Polynomial<F>& lhs, const Polynomial<F>& rhs, const F& primitive_root, size_t root_order) {  // ntt.rs:66-116
+  auto a = to_wire(lhs.coef), b = to_wire(rhs.coef);
+  const size_t cap = std::max(root_order, lhs.coef.size() + rhs.coef.size()) + 1;
+  std::vector<uint64_t> out(cap * F().value.size());
+  size_t n = 0;
+  expect(mzk_fast_multiply(Polynomial<F>::field_id(), a.data(), lhs.coef.size(), b.data(), rhs.coef.size(),
+                           primitive_root.value.data(), root_order, out.data(), &n));
+  return Polynomial<F>{from_wire<F>(out, n)};
+}
+template <class F>
+std::vector<F> fast_coset_evaluate(const Polynomial<F>& polynomial, const F& offset, const F& generator, size_t order) {  // ntt.rs:254-269
+  auto c = to_wire(polynomial.coef);
+  std::vector<uint64_t> out(order * F().value.size());
+  expect(mzk_coset_lde(Polynomial<F>::field_id(), c.data(), polynomial.coef.size(), offset.value.data(), generator.value.data(),
+                       out.data(), order));
+  return from_wire<F>(out, order);
+}
+// zkstark/fri.rs:423-447 (n given as log2)
+inline FiniteFieldElement<M128> get_nth_root_of_m128(unsigned log2_n) {
+  FiniteFieldElement<M128> r;
+  expect(mzk_root_of_unity(MZK_FIELD_M128, log2_n, r.value.data()));
+  return r;
+}
+inline FqOrder get_nth_root_of_fr(unsigned log2_n) {  // the reference ships none
+  FqOrder r;
+  expect(mzk_root_of_unity(MZK_FIELD_FR, log2_n, r.value.data()));
+  return r;
+}
+
+// ---- algebra/kzg.rs ---------------------------------------------------------------------------------------
+struct PublicKeyKZG { std::vector<G1Point> powers_1; };  // kzg.rs:8-11 (powers_2 lives in G2: out of scope)
+using CommitmentKZG = G1Point;                            // kzg.rs:13
+struct ProofKZG { FqOrder y; G1Point w; };                // kzg.rs:15-18
+
+// setup_kzg (kzg.rs:27-40) with the trapdoor supplied (the reference draws it from thread_rng)
+inline PublicKeyKZG setup_kzg_with_alpha(const G1Point& g1, const FqOrder& alpha, size_t max_d) {
+  uint64_t g[8];
+  g1.to_wire(g);
+  std::vector<uint64_t> out((max_d + 1) * 8);
+  expect(mzk_kzg_setup_g1(alpha.value.data(), g, max_d, out.data()));
+  PublicKeyKZG pk;
+  pk.powers_1.resize(max_d + 1);
+  for (size_t i = 0; i <= max_d; i++) pk.powers_1[i] = G1Point::from_wire(&out[8 * i]);
+  return pk;
+}
+inline CommitmentKZG commit_kzg(const Polynomial<FqOrder>& f, const PublicKeyKZG& pk) {  // kzg.rs:57-59
+  return f.eval_with_powers_on_curve(pk.powers_1);
+}
+inline ProofKZG open_kzg(const Polynomial<FqOrder>& f, const FqOrder& u, const PublicKeyKZG& pk) {  // kzg.rs:61-72
+  if (f.coef.size() > 1 && pk.powers_1.size() < f.coef.size() - 1)
+    throw Panic(MZK_E_LENGTH, "index out of bounds: the len is " + std::to_string(pk.powers_1.size()) + " but the index is " + std::to_string(pk.powers_1.size()));
+  auto c = to_wire(f.coef);
+  auto p = points_to_wire(pk.powers_1);
+  ProofKZG pr;
+  uint64_t w[8];
+  expect(mzk_kzg_open(c.data(), f.coef.size(), u.value.data(), p.data(), pr.y.value.data(), w));
+  pr.w = G1Point::from_wire(w);
+  return pr;
+}
+
+}  // namespace myzkp

@@ -22,9 +22,10 @@ def all_gather_partials(partial):
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return partial.reshape(1, -1)
     world = dist.get_world_size()
-    out = torch.empty((world, partial.numel()), dtype=partial.dtype, device=partial.device)
-    dist.all_gather_into_tensor(out, partial.contiguous())
-    return out
+    flat = partial.contiguous().reshape(-1)
+    out = torch.empty(world * flat.numel(), dtype=partial.dtype, device=partial.device)
+    dist.all_gather_into_tensor(out, flat)
+    return out.reshape(world, flat.numel())
 
 
 def sharded_msm(local_partial_fn, fold_fn):

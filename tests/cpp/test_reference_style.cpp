@@ -1,0 +1,138 @@
+// GPU tests that read like the reference's own #[test]s, written against the C++ mirror of the Rust
+// surface (myzkp_amd/host/myzkp.hpp) and checked with the oracle (test infrastructure).
+//   test_ntt            <- algebra/ntt.rs:346-374
+//   test_kzg            <- algebra/kzg.rs:152-172 (pairing check replaced by the trapdoor identity)
+//   test_g1             <- algebra/curve/bn128.rs:285-301 (relations, through the MSM)
+//   test_fast_multiply  <- algebra/ntt.rs:66-116 vs Polynomial::fft_multiply
+//   test_panics         <- ntt.rs:8-23, polynomial.rs:162 index panic
+#include <cstdio>
+#include <cstdlib>
+#include "../../myzkp_amd/host/myzkp.hpp"
+using namespace myzkp;
+
+extern "C" {  // oracle (checker only)
+int orc_poly_eval(int fid, const uint64_t* coef, size_t n, const uint64_t* x, uint64_t* out);
+int orc_field_pow(int fid, const uint64_t* a, const uint64_t* e, int ne, uint64_t* out);
+int orc_field_mul(int fid, const uint64_t* a, const uint64_t* b, uint64_t* out);
+int orc_ec_mul(int cid, const uint64_t* p_xy, const uint64_t* k, int nk, uint64_t* out_xy);
+}
+static int failures = 0;
+#define CHECK(c) do { if (!(c)) { printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); failures++; } } while (0)
+
+static void test_ntt() {
+  const unsigned logn = 8;
+  const size_t n = 1u << logn;
+  auto primitive_root = get_nth_root_of_m128(logn);
+  std::vector<FiniteFieldElement<M128>> coef;
+  for (size_t i = 0; i < n; i++) coef.push_back(FiniteFieldElement<M128>::from_value(i + 1));
+  Polynomial<FiniteFieldElement<M128>> poly{coef};
+  auto values = ntt(primitive_root, coef);
+  CHECK(values.size() == n);
+  auto cw = to_wire(poly.coef);
+  for (size_t i = 0; i < n; i++) {  // values_again = poly.eval_domain(root^i)
+    uint64_t e = i, x[2], y[2];
+    orc_field_pow(MZK_FIELD_M128, primitive_root.value.data(), &e, 1, x);
+    orc_poly_eval(MZK_FIELD_M128, cw.data(), n, x, y);
+    CHECK(values[i] == FiniteFieldElement<M128>::from_limbs(y));
+  }
+  auto coef_again = intt(primitive_root, values);
+  CHECK(coef_again.size() == coef.size());
+  for (size_t i = 0; i < n; i++) CHECK(coef[i] == coef_again[i]);
+}
+
+static void test_kzg() {
+  auto g1 = BN128::generator_g1();
+  // (x+1)(x+2)(x+3) = 6 + 11x + 6x^2 + x^3, kzg.rs:157-161
+  Polynomial<FqOrder> f{{FqOrder::from_value(6), FqOrder::from_value(11), FqOrder::from_value(6), FqOrder::from_value(1)}};
+  auto alpha = FqOrder::from_value(7);
+  auto pk = setup_kzg_with_alpha(g1, alpha, 3);
+  CHECK(pk.powers_1.size() == 4);
+  auto c = commit_kzg(f, pk);
+  // [f(7)] G, f(7) = 8*9*10 = 720
+  uint64_t g[8], k[4] = {720, 0, 0, 0}, want[8];
+  g1.to_wire(g);
+  orc_ec_mul(0, g, k, 4, want);
+  CHECK(c == G1Point::from_wire(want));
+  auto u = FqOrder::from_value(5);
+  auto proof = open_kzg(f, u, pk);
+  CHECK(proof.y == FqOrder::from_value(6 * 7 * 8));
+  // q(X) = (f(X) - f(5)) / (X - 5); q(7) = (720 - 336) / 2 = 192
+  uint64_t kq[4] = {192, 0, 0, 0};
+  orc_ec_mul(0, g, kq, 4, want);
+  CHECK(proof.w == G1Point::from_wire(want));
+  // tampered polynomial does not open to the same witness (kzg.rs:202-204 analogue)
+  Polynomial<FqOrder> f2 = f;
+  f2.coef[0] = FqOrder::from_value(7);
+  CHECK(!(commit_kzg(f2, pk) == c));
+}
+
+static void test_g1() {
+  auto g = BN128::generator_g1();
+  auto mul = [&](uint64_t k) { return Polynomial<FqOrder>{{FqOrder::from_value(k)}}.eval_with_powers_on_curve({g}); };
+  auto g2 = mul(2);
+  // 2G + G + G == (2G) * 2
+  auto lhs = Polynomial<FqOrder>{{FqOrder::one(), FqOrder::one(), FqOrder::one()}}.eval_with_powers_on_curve({g2, g, g});
+  auto rhs = Polynomial<FqOrder>{{FqOrder::from_value(2)}}.eval_with_powers_on_curve({g2});
+  CHECK(lhs == rhs);
+  // 9G + 5G == 12G + 2G
+  auto a = Polynomial<FqOrder>{{FqOrder::from_value(9), FqOrder::from_value(5)}}.eval_with_powers_on_curve({g, g});
+  auto b = Polynomial<FqOrder>{{FqOrder::from_value(12), FqOrder::from_value(2)}}.eval_with_powers_on_curve({g, g});
+  CHECK(a == b);
+  // r * G == infinity, as (r-1) G + G
+  uint64_t rm1[4] = {0x43e1f593f0000000ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+  auto z = Polynomial<FqOrder>{{FqOrder::from_limbs(rm1), FqOrder::one()}}.eval_with_powers_on_curve({g, g});
+  CHECK(z.is_point_at_infinity());
+  CHECK(Polynomial<FqOrder>{}.eval_with_powers_on_curve({}).is_point_at_infinity());
+}
+
+static void test_fast_multiply() {
+  Polynomial<FqOrder> a, b;
+  for (uint64_t i = 0; i < 40; i++) a.coef.push_back(FqOrder::from_value(3 * i + 1));
+  for (uint64_t i = 0; i < 25; i++) b.coef.push_back(FqOrder::from_value(i * i + 2));
+  auto p1 = a.fft_multiply(b, get_nth_root_of_fr(6));   // 64 >= 40 + 25 - 1
+  auto p2 = fast_multiply(a, b, get_nth_root_of_fr(10), 1024);
+  CHECK(p1.coef.size() == 64);
+  CHECK(p2.coef.size() == 128);  // untrimmed order (ntt.rs:113-115): degree 63 -> order 128
+  for (size_t i = 0; i < p1.coef.size(); i++) CHECK(p1.coef[i] == p2.coef[i]);
+  for (size_t i = p1.coef.size(); i < p2.coef.size(); i++) CHECK(p2.coef[i].is_zero());
+  // spot check coefficient 1: a0 b1 + a1 b0 = 1*3 + 4*2
+  CHECK(p1.coef[1] == FqOrder::from_value(11));
+}
+
+static void test_panics() {
+  std::vector<FiniteFieldElement<M128>> v(6, FiniteFieldElement<M128>::one());
+  bool caught = false;
+  try { ntt(get_nth_root_of_m128(3), v); } catch (const Panic& p) {
+    caught = std::string(p.what()) == "cannot compute ntt of non-power-of-two sequence";
+  }
+  CHECK(caught);
+  v.resize(8, FiniteFieldElement<M128>::one());
+  caught = false;
+  try { ntt(get_nth_root_of_m128(4), v); } catch (const Panic& p) {
+    caught = std::string(p.what()) == "primitive root must be nth root of unity, where n is len(values)";
+  }
+  CHECK(caught);
+  caught = false;
+  try { ntt(get_nth_root_of_m128(2), v); } catch (const Panic& p) {
+    caught = std::string(p.what()) == "primitive root is not primitive nth root of unity, where n is len(values)";
+  }
+  CHECK(caught);
+  caught = false;
+  try {
+    Polynomial<FqOrder>{{FqOrder::one(), FqOrder::one()}}.eval_with_powers_on_curve({BN128::generator_g1()});
+  } catch (const Panic& p) { caught = p.code == MZK_E_LENGTH; }
+  CHECK(caught);
+}
+
+int main() {
+  expect(mzk_init(0));
+  test_ntt();
+  test_kzg();
+  test_g1();
+  test_fast_multiply();
+  test_panics();
+  mzk_shutdown();
+  if (failures) { printf("%d check(s) failed\n", failures); return 1; }
+  printf("all reference-style tests passed\n");
+  return 0;
+}
