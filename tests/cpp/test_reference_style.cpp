@@ -92,7 +92,7 @@ static void test_fast_multiply() {
   auto p1 = a.fft_multiply(b, get_nth_root_of_fr(6));   // 64 >= 40 + 25 - 1
   auto p2 = fast_multiply(a, b, get_nth_root_of_fr(10), 1024);
   CHECK(p1.coef.size() == 64);
-  CHECK(p2.coef.size() == 128);  // untrimmed order (ntt.rs:113-115): degree 63 -> order 128
+  CHECK(p2.coef.size() == 64);   // untrimmed order (ntt.rs:90-93,113-115): degree 63 -> order 64
   for (size_t i = 0; i < p1.coef.size(); i++) CHECK(p1.coef[i] == p2.coef[i]);
   for (size_t i = p1.coef.size(); i < p2.coef.size(); i++) CHECK(p2.coef[i].is_zero());
   // spot check coefficient 1: a0 b1 + a1 b0 = 1*3 + 4*2
