@@ -106,6 +106,10 @@ int mzk_msm_g1_bn254_dev(const void* d_scalars, const void* d_points_xy, size_t 
 int mzk_msm_g1_bn254_partial_dev(const void* d_scalars, const void* d_points_xy, size_t n,
                                  void* d_partial16, void* stream);
 int mzk_g1_fold_partials_dev(const void* d_partials16, int count, void* d_out_xy, void* stream);
+/* commit against a device-resident SRS with device-resident coefficients; out_partial != 0 writes the
+ * 16-limb XYZZ partial (multi-GPU shard) instead of the 8-limb affine point. */
+int mzk_kzg_commit_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, void* d_out, int out_partial,
+                           void* stream);
 
 /* Deterministic synthetic inputs (bench + tests): bit-identical to the oracle's orc_synth_*. */
 int mzk_synth_field_dev(int field_id, uint64_t seed, size_t n, void* d_out, void* stream);

@@ -415,9 +415,12 @@ int mzk_fast_multiply(int field_id, const uint64_t* a, size_t la, const uint64_t
 
 // ---- MSM / KZG ---------------------------------------------------------------------------------------------
 struct mzk_srs {
-  void* d_points_mont;
+  void* d_points_mont;   // MSM_SRS_WINDOWS x n window tables when has_tables, else n prepared points
   size_t n;
+  bool has_tables;
 };
+// Below this size the per-call bucket overhead of 16-bit windows dominates: keep plain prepared points.
+static const size_t SRS_TABLE_MIN_N = (size_t)1 << 14;
 
 int mzk_msm_g1_bn254(const uint64_t* scalars, const uint64_t* points_xy, size_t n, uint64_t out_xy[8]) {
   MZK_TRY(ensure_init());
@@ -427,18 +430,18 @@ int mzk_msm_g1_bn254(const uint64_t* scalars, const uint64_t* points_xy, size_t 
   MZK_TRY(stage_in(WS_MSM_SCALARS, scalars, n * 32, &d_s, s));
   MZK_TRY(stage_in(WS_MISC_A, points_xy, n * 64, &d_p, s));
   MZK_TRY(ws_get(WS_MISC_B, 256, &d_o));
-  MZK_TRY(msm_dev_impl(d_s, d_p, n, false, d_o, false, s));
+  MZK_TRY(msm_dev_impl(d_s, d_p, n, MSM_PTS_PLAIN, 0, d_o, false, s));
   MZK_HIP(hipMemcpyAsync(out_xy, d_o, 64, hipMemcpyDeviceToHost, s));
   MZK_HIP(hipStreamSynchronize(s));
   return MZK_OK;
 }
 int mzk_msm_g1_bn254_dev(const void* d_scalars, const void* d_points_xy, size_t n, void* d_out_xy, void* stream) {
   MZK_TRY(ensure_init());
-  return msm_dev_impl(d_scalars, d_points_xy, n, false, d_out_xy, false, (hipStream_t)stream);
+  return msm_dev_impl(d_scalars, d_points_xy, n, MSM_PTS_PLAIN, 0, d_out_xy, false, (hipStream_t)stream);
 }
 int mzk_msm_g1_bn254_partial_dev(const void* d_scalars, const void* d_points_xy, size_t n, void* d_partial16, void* stream) {
   MZK_TRY(ensure_init());
-  return msm_dev_impl(d_scalars, d_points_xy, n, false, d_partial16, true, (hipStream_t)stream);
+  return msm_dev_impl(d_scalars, d_points_xy, n, MSM_PTS_PLAIN, 0, d_partial16, true, (hipStream_t)stream);
 }
 int mzk_g1_fold_partials_dev(const void* d_partials16, int count, void* d_out_xy, void* stream) {
   MZK_TRY(ensure_init());
@@ -449,12 +452,19 @@ int mzk_srs_upload(const uint64_t* powers_xy, size_t n, mzk_srs** out) {
   MZK_TRY(ensure_init());
   if (!out || (!powers_xy && n)) { set_error("srs_upload: null pointer"); return MZK_E_ARG; }
   hipStream_t s = g_ctx.stream;
-  mzk_srs* h = new mzk_srs{nullptr, n};
+  mzk_srs* h = new mzk_srs{nullptr, n, n >= SRS_TABLE_MIN_N};
   if (n) {
-    void* d_plain;
-    if (hipMalloc(&h->d_points_mont, n * 64) != hipSuccess) { delete h; set_error("srs_upload: hipMalloc failed"); return MZK_E_HIP; }
+    void *d_plain, *d_mont;
+    const size_t copies = h->has_tables ? (size_t)MSM_SRS_WINDOWS : 1;
+    if (hipMalloc(&h->d_points_mont, n * 64 * copies) != hipSuccess) { delete h; set_error("srs_upload: hipMalloc failed"); return MZK_E_HIP; }
     int rc = stage_in(WS_MISC_A, powers_xy, n * 64, &d_plain, s);
-    if (rc == MZK_OK) rc = msm_prepare_points(d_plain, n, h->d_points_mont, s);
+    if (rc == MZK_OK && h->has_tables) {
+      rc = ws_get(WS_MSM_POINTS, n * 64, &d_mont);
+      if (rc == MZK_OK) rc = msm_prepare_points(d_plain, n, d_mont, s);
+      if (rc == MZK_OK) rc = msm_build_tables(d_mont, n, h->d_points_mont, s);
+    } else if (rc == MZK_OK) {
+      rc = msm_prepare_points(d_plain, n, h->d_points_mont, s);
+    }
     if (rc == MZK_OK && hipStreamSynchronize(s) != hipSuccess) rc = MZK_E_HIP;
     if (rc != MZK_OK) { (void)hipFree(h->d_points_mont); delete h; return rc; }
   }
@@ -474,10 +484,18 @@ int mzk_kzg_commit_srs(const mzk_srs* srs, const uint64_t* coef, size_t n, uint6
   void *d_s, *d_o;
   MZK_TRY(stage_in(WS_MSM_SCALARS, coef, n * 32, &d_s, s));
   MZK_TRY(ws_get(WS_MISC_B, 256, &d_o));
-  MZK_TRY(msm_dev_impl(d_s, srs->d_points_mont, n, true, d_o, false, s));
+  MZK_TRY(msm_dev_impl(d_s, srs->d_points_mont, n, srs->has_tables ? MSM_PTS_TABLES : MSM_PTS_MONT, srs->n, d_o, false, s));
   MZK_HIP(hipMemcpyAsync(out_xy, d_o, 64, hipMemcpyDeviceToHost, s));
   MZK_HIP(hipStreamSynchronize(s));
   return MZK_OK;
+}
+
+int mzk_kzg_commit_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, void* d_out, int out_partial, void* stream) {
+  MZK_TRY(ensure_init());
+  if (!srs || !d_out || (!d_coef && n)) { set_error("commit_srs_dev: null pointer"); return MZK_E_ARG; }
+  if (n > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }
+  return msm_dev_impl(d_coef, srs->d_points_mont, n, srs->has_tables ? MSM_PTS_TABLES : MSM_PTS_MONT, srs->n, d_out, out_partial != 0,
+                      (hipStream_t)stream);
 }
 
 int mzk_kzg_setup_g1(const uint64_t alpha[4], const uint64_t g1_xy[8], size_t max_d, uint64_t* powers_xy) {
@@ -501,7 +519,7 @@ int mzk_kzg_open(const uint64_t* coef, size_t n, const uint64_t u[4], const uint
   MZK_TRY(stage_in(WS_MSM_SCALARS, coef, n * 32, &d_c, s));
   MZK_TRY(stage_in(WS_NTT_IO_A, powers_xy, (n > 1 ? n - 1 : 0) * 64, &d_p, s));
   MZK_TRY(ws_get(WS_NTT_IO_B, 256, &d_o));
-  MZK_TRY(kzg_open_dev(d_c, n, u, d_p, false, d_o, (char*)d_o + 64, s));
+  MZK_TRY(kzg_open_dev(d_c, n, u, d_p, MSM_PTS_PLAIN, 0, d_o, (char*)d_o + 64, s));
   uint64_t tmp[16];
   MZK_HIP(hipMemcpyAsync(tmp, d_o, 128, hipMemcpyDeviceToHost, s));
   MZK_HIP(hipStreamSynchronize(s));

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) void k_open_chunk_fill(const u32* __restrict__ 
 }
 
 // d_y: 8 words; d_w_xy: 16 words.
-int kzg_open_dev(const void* d_coef, size_t n, const uint64_t* u_host, const void* d_points, bool points_are_mont,
+int kzg_open_dev(const void* d_coef, size_t n, const uint64_t* u_host, const void* d_points, int point_kind, size_t table_stride,
                  void* d_y, void* d_w_xy, hipStream_t s) {
   if (!u_host || !d_y || !d_w_xy || (!d_coef && n) || (!d_points && n > 1)) { set_error("kzg_open: null pointer"); return MZK_E_ARG; }
   const HostField* fr = host_field(MZK_FIELD_FR);
@@ -211,7 +211,7 @@ int kzg_open_dev(const void* d_coef, size_t n, const uint64_t* u_host, const voi
   MZK_HIP(hipGetLastError());
   MZK_HIP(hipMemcpyAsync(d_y, bbuf, 32, hipMemcpyDeviceToDevice, s));   // y = b_0
   // w = MSM(q, powers), q_j = b_{j+1}, j < n - 1     (kzg.rs:70)
-  return msm_dev_impl(bbuf + 8, d_points, n - 1, points_are_mont, d_w_xy, false, s);
+  return msm_dev_impl(bbuf + 8, d_points, n - 1, point_kind, table_stride, d_w_xy, false, s);
 }
 
 }  // namespace mzk

@@ -25,6 +25,8 @@ constexpr int MAX_WINDOWS = 32;
 constexpr int RED_CH_LOG = 4;           // bucket-reduction chunk = 16
 constexpr int RED_CH = 1 << RED_CH_LOG;
 constexpr int MAX_RED_LEVELS = 6;
+constexpr int SRS_WINDOW_BITS = 16;     // fixed-base tables: 16 windows of 16 bits
+constexpr int SRS_WINDOWS = SCALAR_BITS / SRS_WINDOW_BITS + 1;
 
 struct MsmShape {
   int c;          // window bits
@@ -105,29 +107,59 @@ __device__ __forceinline__ u32 raw_window(const u32* w, int win, int c) {
   if (k + 1 < 8) v |= (u64)w[k + 1] << 32;
   return (u32)(v >> s) & ((1u << c) - 1u);
 }
+// Bucket layout.  Generic MSM: bucket = window * 2^(c-1) + |digit| - 1, entry = point index.
+// Fixed-base MSM over precomputed tables T[w][i] = 2^(c w) P_i: every window shares ONE bucket set,
+// bucket = |digit| - 1, entry = w * table_stride + i.
+struct DigitLayout {
+  int c, nwin, merged;
+  size_t table_stride;
+};
+constexpr u32 NO_RANK = 0xffffffffu;
 
-template <bool SCATTER>
-__global__ void k_digits(const u32* __restrict__ scalars, size_t n, int c, int nwin, u32* __restrict__ counts_or_cursor,
-                         u32* __restrict__ entries) {
+// Pass 1: histogram; the value returned by the atomic is this entry's rank inside its bucket, kept
+// (coalesced, [window][i]) so that the scatter pass needs no atomics.
+__global__ __launch_bounds__(256) void k_digits_count(const u32* __restrict__ scalars, size_t n, DigitLayout L, u32* __restrict__ counts,
+                                                       u32* __restrict__ ranks) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 w[8];
   load_scalar_canonical(scalars, i, w);
+  const int c = L.c;
   const u32 half = 1u << (c - 1);
   u32 carry = 0;
-  for (int win = 0; win < nwin; win++) {
+  for (int win = 0; win < L.nwin; win++) {
+    u32 raw = raw_window(w, win, c) + carry;
+    u32 mag = raw;
+    carry = 0;
+    if (raw > half) { mag = (1u << c) - raw; carry = 1; }
+    u32 rank = NO_RANK;
+    if (mag != 0) {
+      const size_t bucket = (L.merged ? (size_t)0 : ((size_t)win << (c - 1))) + (mag - 1);
+      rank = atomicAdd(&counts[bucket], 1u);
+    }
+    ranks[(size_t)win * n + i] = rank;
+  }
+}
+// Pass 2: entries[offsets[bucket] + rank] = reference | sign << 31
+__global__ __launch_bounds__(256) void k_digits_scatter(const u32* __restrict__ scalars, size_t n, DigitLayout L, const u32* __restrict__ offsets,
+                                                         const u32* __restrict__ ranks, u32* __restrict__ entries) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 w[8];
+  load_scalar_canonical(scalars, i, w);
+  const int c = L.c;
+  const u32 half = 1u << (c - 1);
+  u32 carry = 0;
+  for (int win = 0; win < L.nwin; win++) {
     u32 raw = raw_window(w, win, c) + carry;
     u32 neg = 0, mag = raw;
     carry = 0;
     if (raw > half) { mag = (1u << c) - raw; neg = 1; carry = 1; }
     if (mag != 0) {
-      const size_t bucket = ((size_t)win << (c - 1)) + (mag - 1);
-      if (SCATTER) {
-        const u32 pos = atomicAdd(&counts_or_cursor[bucket], 1u);
-        entries[pos] = (u32)i | (neg << 31);
-      } else {
-        atomicAdd(&counts_or_cursor[bucket], 1u);
-      }
+      const size_t bucket = (L.merged ? (size_t)0 : ((size_t)win << (c - 1))) + (mag - 1);
+      const u32 rank = ranks[(size_t)win * n + i];
+      const u32 ref = L.merged ? (u32)((size_t)win * L.table_stride + i) : (u32)i;
+      entries[offsets[bucket] + rank] = ref | (neg << 31);
     }
   }
 }
@@ -183,27 +215,48 @@ __global__ __launch_bounds__(256) void k_scan_blocksums(u32* __restrict__ block_
   }
   if (threadIdx.x == 0) *total_out = running;
 }
-// offsets[i] += block_sums[block(i)]; cursor = offsets; offsets[n] = total
-__global__ __launch_bounds__(256) void k_scan_finish(u32* __restrict__ offsets, u32* __restrict__ cursor, const u32* __restrict__ block_sums,
+// offsets[i] += block_sums[block(i)]; offsets[n] = total
+__global__ __launch_bounds__(256) void k_scan_finish(u32* __restrict__ offsets, const u32* __restrict__ block_sums,
                                                       const u32* __restrict__ total, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
-    const u32 v = offsets[i] + block_sums[i / SCAN_BLOCK];
-    offsets[i] = v;
-    cursor[i] = v;
+    offsets[i] = offsets[i] + block_sums[i / SCAN_BLOCK];
   } else if (i == n) {
     offsets[n] = *total;
   }
 }
 
-// ---- 4. bucket accumulation -----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bucket_accumulate(const u32* __restrict__ points_mont, const u32* __restrict__ offsets,
-                                                            const u32* __restrict__ entries, u32* __restrict__ buckets, size_t nbuckets) {
-  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= nbuckets) return;
-  const u32 beg = offsets[g], end = offsets[g + 1];
+// ---- 4. bucket accumulation, segmented ------------------------------------------------------------------
+// The sorted entry array is cut into fixed segments of SEG entries, one lane per segment, so the work
+// per lane is equal whatever the scalar distribution (no Poisson tail, no skew cliff).  A lane walks
+// its segment, keeps one XYZZ accumulator, and flushes it whenever the bucket changes.  The partial
+// of (segment t, bucket b) goes to slot t + b: (t, b) pairs met in order strictly increase t + b, so
+// slots are unique, and all partials of bucket b sit in the contiguous slot range
+// [offsets[b] / SEG + b, offsets[b+1] / SEG + b + 1) -- pass 2 sums that range (unused slots are the
+// all-zero infinity encoding and cost nothing).
+__global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ points_mont, const u32* __restrict__ offsets,
+                                                         const u32* __restrict__ entries, u32* __restrict__ slots, size_t nbuckets,
+                                                         int lgseg) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 total_entries = offsets[nbuckets];
+  const u32 e0 = (u32)(t << lgseg);
+  if (e0 >= total_entries) return;
+  const u32 e1 = (e0 + (1u << lgseg) < total_entries) ? e0 + (1u << lgseg) : total_entries;
+  // bucket of entry e0: last b with offsets[b] <= e0
+  size_t lo = 0, hi = nbuckets;  // invariant: offsets[lo] <= e0 < offsets[hi] (offsets[nbuckets] = total)
+  while (hi - lo > 1) {
+    const size_t mid = (lo + hi) >> 1;
+    if (offsets[mid] <= e0) lo = mid; else hi = mid;
+  }
+  size_t b = lo;
+  u32 bend = offsets[b + 1];
   Xyzz acc = xyzz_inf();
-  for (u32 e = beg; e < end; e++) {
+  for (u32 e = e0; e < e1; e++) {
+    if (e >= bend) {
+      xyzz_gstore(slots, t + b, acc);
+      acc = xyzz_inf();
+      do { b++; bend = offsets[b + 1]; } while (e >= bend);
+    }
     const u32 ent = entries[e];
     const size_t idx = ent & 0x7fffffffu;
     u32 w[16];
@@ -214,7 +267,21 @@ __global__ __launch_bounds__(256) void k_bucket_accumulate(const u32* __restrict
     if (ent >> 31) p = affine_neg(p);
     acc = xyzz_madd(acc, p);
   }
-  xyzz_gstore(buckets, g, acc);
+  xyzz_gstore(slots, t + b, acc);
+}
+// pass 2: buckets[b] = sum of slots [offsets[b] >> lgseg + b, offsets[b+1] >> lgseg + b]   (inclusive end:
+// the last entry of bucket b is offsets[b+1]-1, whose segment is <= offsets[b+1] >> lgseg)
+__global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slots, const u32* __restrict__ offsets, u32* __restrict__ buckets,
+                                                      size_t nbuckets, int lgseg) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbuckets) return;
+  const u32 o0 = offsets[b], o1 = offsets[b + 1];
+  Xyzz acc = xyzz_inf();
+  if (o1 > o0) {
+    const size_t s0 = (size_t)(o0 >> lgseg) + b, s1 = (size_t)((o1 - 1) >> lgseg) + b;
+    for (size_t sl = s0; sl <= s1; sl++) acc = xyzz_add(acc, xyzz_gload(slots, sl));
+  }
+  xyzz_gstore(buckets, b, acc);
 }
 
 // ---- 5. bucket reduction: W0(X) = sum_i i X_i and Sum(X), per window, by chunked running sums ----------
@@ -315,18 +382,65 @@ int msm_prepare_points(const void* d_points_plain, size_t n, void* d_points_mont
   return MZK_OK;
 }
 
-int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, bool points_are_mont, void* d_out,
+// SRS window tables: T[w][i] = 2^(c w) * P_i, affine Montgomery, w < nwin (w = 0 is the point itself).
+// One lane per point: c doublings in XYZZ, then back to affine (one inversion per entry; one-time cost
+// per SRS).
+__global__ __launch_bounds__(128) void k_srs_tables(const u32* __restrict__ pts_mont, size_t n, int c, int nwin, u32* __restrict__ tables) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 w[16];
+  load_words8(pts_mont + i * 16, w);
+  load_words8(pts_mont + i * 16 + 8, w + 8);
+  store_words8(tables + i * 16, w);
+  store_words8(tables + i * 16 + 8, w + 8);
+  if (affine_words_is_inf(w)) {
+    for (int win = 1; win < nwin; win++) {
+      store_words8(tables + ((size_t)win * n + i) * 16, w);
+      store_words8(tables + ((size_t)win * n + i) * 16 + 8, w + 8);
+    }
+    return;
+  }
+  Affine a = affine_load_mont(w);
+  for (int win = 1; win < nwin; win++) {
+    Xyzz p = xyzz_dbl_affine(a);
+    for (int d = 1; d < c; d++) p = xyzz_dbl(p);
+    xyzz_to_affine(p, &a);  // never infinity: the group has odd prime order
+    affine_store_mont(a, w);
+    store_words8(tables + ((size_t)win * n + i) * 16, w);
+    store_words8(tables + ((size_t)win * n + i) * 16 + 8, w + 8);
+  }
+}
+int msm_build_tables(const void* d_points_mont, size_t n, void* d_tables, hipStream_t s) {
+  if (n == 0) return MZK_OK;
+  hipLaunchKernelGGL(k_srs_tables, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, (const u32*)d_points_mont, n, SRS_WINDOW_BITS,
+                     SRS_WINDOWS, (u32*)d_tables);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+
+// point_kind: 0 = affine canonical (ABI form), 1 = affine Montgomery (prepared), 2 = SRS window tables
+// (SRS_WINDOWS x table_stride affine Montgomery points: all windows share one bucket set, no Horner).
+int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int point_kind, size_t table_stride, void* d_out,
                  bool out_partial_xyzz, hipStream_t s) {
   if (!d_out || ((!d_scalars || !d_points) && n)) { set_error("msm: null pointer"); return MZK_E_ARG; }
-  if (n > ((size_t)1 << 31)) { set_error("msm: n > 2^31 not supported"); return MZK_E_ARG; }
+  if (n > ((size_t)1 << 27)) { set_error("msm: n > 2^27 not supported"); return MZK_E_ARG; }
   if (n == 0) {  // empty polynomial -> point at infinity (polynomial.rs:160)
     MZK_HIP(hipMemsetAsync(d_out, 0, out_partial_xyzz ? 128 : 64, s));
     return MZK_OK;
   }
-  const MsmShape sh = choose_shape(n);
+  MsmShape sh = choose_shape(n);
+  DigitLayout L;
+  L.merged = (point_kind == 2) ? 1 : 0;
+  L.table_stride = table_stride;
+  if (L.merged) {
+    sh.c = SRS_WINDOW_BITS; sh.nwin = SRS_WINDOWS; sh.lgB = sh.c - 1; sh.nbuckets = (size_t)1 << sh.lgB;
+  }
+  L.c = sh.c; L.nwin = sh.nwin;
   const size_t NB = sh.nbuckets;
+  const int red_windows = L.merged ? 1 : sh.nwin;   // bucket sets to reduce
+  const int horner_c = L.merged ? 0 : sh.c;
   const u32* pts = (const u32*)d_points;
-  if (!points_are_mont) {
+  if (point_kind == 0) {
     void* pm;
     MZK_TRY(ws_get(WS_MSM_POINTS, n * 64, &pm));
     prof_begin(s, MZK_PH_MSM_PREPARE);
@@ -334,30 +448,38 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, bool poi
     prof_end(s, MZK_PH_MSM_PREPARE);
     pts = (const u32*)pm;
   }
-  u32 *counts, *offsets, *cursor, *entries, *scan_tmp, *buckets;
+  const size_t E_max = n * (size_t)sh.nwin;
+  int lgseg = 4;
+  while ((E_max >> lgseg) > ((size_t)1 << 18) && lgseg < 16) lgseg++;
+  const size_t T = (E_max + ((size_t)1 << lgseg) - 1) >> lgseg;
+  const size_t nslots = T + NB + 1;
+  u32 *counts, *offsets, *ranks, *entries, *scan_tmp, *buckets, *slots;
   const size_t scan_blocks = (NB + SCAN_BLOCK - 1) / SCAN_BLOCK;
   MZK_TRY(ws_get(WS_MSM_COUNTS, NB * 4, (void**)&counts));
   MZK_TRY(ws_get(WS_MSM_OFFSETS, (NB + 1) * 4, (void**)&offsets));
-  MZK_TRY(ws_get(WS_MSM_CURSOR, NB * 4, (void**)&cursor));
-  MZK_TRY(ws_get(WS_MSM_ENTRIES, n * (size_t)sh.nwin * 4, (void**)&entries));
+  MZK_TRY(ws_get(WS_MSM_CURSOR, E_max * 4, (void**)&ranks));
+  MZK_TRY(ws_get(WS_MSM_ENTRIES, E_max * 4, (void**)&entries));
   MZK_TRY(ws_get(WS_MSM_SCAN, (scan_blocks + 1) * 4, (void**)&scan_tmp));
   MZK_TRY(ws_get(WS_MSM_BUCKETS, NB * 128, (void**)&buckets));
+  MZK_TRY(ws_get(WS_MSM_SLOTS, nslots * 128, (void**)&slots));
   prof_begin(s, MZK_PH_MSM_SORT);
   MZK_HIP(hipMemsetAsync(counts, 0, NB * 4, s));
+  MZK_HIP(hipMemsetAsync(slots, 0, nslots * 128, s));
   const unsigned nblk = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL((k_digits<false>), dim3(nblk), dim3(256), 0, s, (const u32*)d_scalars, n, sh.c, sh.nwin, counts, (u32*)nullptr);
+  hipLaunchKernelGGL(k_digits_count, dim3(nblk), dim3(256), 0, s, (const u32*)d_scalars, n, L, counts, ranks);
   hipLaunchKernelGGL(k_scan_local, dim3((unsigned)scan_blocks), dim3(256), 0, s, counts, offsets, scan_tmp, NB);
   hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, scan_tmp, scan_blocks, scan_tmp + scan_blocks);
-  hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((NB + 1 + 255) / 256)), dim3(256), 0, s, offsets, cursor, scan_tmp,
-                     scan_tmp + scan_blocks, NB);
-  hipLaunchKernelGGL((k_digits<true>), dim3(nblk), dim3(256), 0, s, (const u32*)d_scalars, n, sh.c, sh.nwin, cursor, entries);
+  hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((NB + 1 + 255) / 256)), dim3(256), 0, s, offsets, scan_tmp, scan_tmp + scan_blocks, NB);
+  hipLaunchKernelGGL(k_digits_scatter, dim3(nblk), dim3(256), 0, s, (const u32*)d_scalars, n, L, offsets, ranks, entries);
   prof_end(s, MZK_PH_MSM_SORT);
   prof_begin(s, MZK_PH_MSM_ACCUMULATE);
-  hipLaunchKernelGGL(k_bucket_accumulate, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, s, pts, offsets, entries, buckets, NB);
+  // the true entry count lives in offsets[NB] on the device; lanes past it exit (E_max bounds it)
+  hipLaunchKernelGGL(k_seg_accumulate, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, pts, offsets, entries, slots, NB, lgseg);
+  hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, lgseg);
   prof_end(s, MZK_PH_MSM_ACCUMULATE);
   prof_begin(s, MZK_PH_MSM_REDUCE);
 
-  // bucket reduction: weights (b+1) = b + 1  =>  W0(X) + Sum(X)
+  // bucket reduction: weights (b+1) = b + 1  =>  W0(X) + Sum(X), per bucket set
   const size_t B = (size_t)1 << sh.lgB;
   size_t level_n[MAX_RED_LEVELS + 1];
   level_n[0] = B;
@@ -367,49 +489,44 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, bool poi
     nlev++;
     if (nlev > MAX_RED_LEVELS) { set_error("msm: reduction depth"); return MZK_E_ARG; }
   }
-  // scratch: S arrays (ping-pong), T arrays per level, T-sum ping-pong
-  size_t s_elems = (size_t)sh.nwin * level_n[1 < nlev ? 1 : nlev];
   u32 *redA, *redB, *tbuf, *tsums;
-  size_t chunk1 = (size_t)sh.nwin * level_n[nlev ? 1 : 0];
-  MZK_TRY(ws_get(WS_MSM_RED_A, (chunk1 + 16) * 128, (void**)&redA));   // S of the current level
+  const size_t chunk1 = (size_t)red_windows * level_n[nlev ? 1 : 0];
+  MZK_TRY(ws_get(WS_MSM_RED_A, (chunk1 + 16) * 128, (void**)&redA));     // S of the current level
   MZK_TRY(ws_get(WS_MSM_RED_B, (chunk1 + 16) * 128 * 2, (void**)&redB)); // S of the next level + T tree scratch
-  MZK_TRY(ws_get(WS_MISC_D, (chunk1 + 16) * 128, (void**)&tbuf));       // T of the current level
+  MZK_TRY(ws_get(WS_MISC_D, (chunk1 + 16) * 128, (void**)&tbuf));         // T of the current level
   MZK_TRY(ws_get(WS_MSM_OUT, (size_t)(MAX_RED_LEVELS + 2) * MAX_WINDOWS * 128, (void**)&tsums));
-  (void)s_elems;
   CombineArgs ca;
   memset(&ca, 0, sizeof ca);
-  ca.nwin = sh.nwin; ca.c = sh.c; ca.lgch = RED_CH_LOG; ca.out_xyzz = out_partial_xyzz ? 1 : 0;
+  ca.nwin = red_windows; ca.c = horner_c; ca.lgch = RED_CH_LOG; ca.out_xyzz = out_partial_xyzz ? 1 : 0;
   const u32* X = buckets;
   u32* Sping = redA;
   u32* Spong = redB;
   u32* tree = redB + (chunk1 + 16) * 32;  // second half of redB (u32 units: 32 words per point)
   for (int lev = 0; lev < nlev; lev++) {
     const size_t nin = level_n[lev], nout = level_n[lev + 1];
-    const size_t threads = nout * sh.nwin;
-    hipLaunchKernelGGL(k_chunk_runsum, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, s, X, nin, RED_CH_LOG, Sping, tbuf, sh.nwin);
-    // plain-sum T over the chunks -> tsums[lev][w]
+    const size_t threads = nout * red_windows;
+    hipLaunchKernelGGL(k_chunk_runsum, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, s, X, nin, RED_CH_LOG, Sping, tbuf, red_windows);
     const u32* tin = tbuf;
     size_t tn = nout;
     u32* tA = tree;
-    u32* tB = tree + ((nout + RED_CH - 1) / RED_CH + 1) * (size_t)sh.nwin * 32;
+    u32* tB = tree + ((nout + RED_CH - 1) / RED_CH + 1) * (size_t)red_windows * 32;
     while (tn > 1) {
       const size_t tout = (tn + RED_CH - 1) >> RED_CH_LOG;
       u32* dst = (tout == 1) ? (tsums + (size_t)lev * MAX_WINDOWS * 32) : tA;
-      hipLaunchKernelGGL(k_chunk_sum, dim3((unsigned)((tout * sh.nwin + 63) / 64)), dim3(64), 0, s, tin, tn, RED_CH_LOG, dst, sh.nwin);
+      hipLaunchKernelGGL(k_chunk_sum, dim3((unsigned)((tout * red_windows + 63) / 64)), dim3(64), 0, s, tin, tn, RED_CH_LOG, dst, red_windows);
       tin = dst;
       tn = tout;
       u32* sw = tA; tA = tB; tB = sw;
     }
     if (nout == 1) {
-      // single chunk: T is already the per-window value
-      MZK_HIP(hipMemcpyAsync(tsums + (size_t)lev * MAX_WINDOWS * 32, tbuf, (size_t)sh.nwin * 128, hipMemcpyDeviceToDevice, s));
+      MZK_HIP(hipMemcpyAsync(tsums + (size_t)lev * MAX_WINDOWS * 32, tbuf, (size_t)red_windows * 128, hipMemcpyDeviceToDevice, s));
     }
     ca.tsum[lev] = tsums + (size_t)lev * MAX_WINDOWS * 32;
     X = Sping;
     u32* sw = Sping; Sping = Spong; Spong = sw;
   }
   ca.nlevels = nlev;
-  ca.sum = (nlev == 0) ? buckets : X;  // after the last level X holds Sum per window (n = 1)
+  ca.sum = (nlev == 0) ? buckets : X;
   prof_end(s, MZK_PH_MSM_REDUCE);
   prof_begin(s, MZK_PH_MSM_COMBINE);
   hipLaunchKernelGGL(k_window_combine, dim3(1), dim3(64), 0, s, ca, (u32*)d_out);

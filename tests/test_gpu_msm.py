@@ -112,3 +112,23 @@ def test_msm_linearity_2pow20(mz):
     s = orc.synth_vector(FR, 11, n)
     fa = orc.poly_eval(FR, s, alpha)
     assert mz.msm_g1(s, srs) == orc.ec_mul(0, (1, 2), fa)
+
+
+def test_srs_window_tables_path(mz):
+    # device-resident SRS with precomputed window tables T[w][i] = 2^(16 w) P_i (n >= 2^14): all windows
+    # share one bucket set; result must equal the plain MSM
+    n = 1 << 14
+    p = orc.synth_points(321, n)
+    p[100:104] = 0                                  # infinity entries in the SRS
+    h = mz.Srs(p)
+    for seed, m in ((1, n), (2, n - 5), (3, 1000), (4, 1)):
+        s = orc.synth_vector(FR, 500 + seed, m)
+        assert h.commit(s) == orc.msm_fast(s, p[:m])
+    # edge scalars through the merged-bucket path
+    sl = [0, 1, P_FR - 1, (1 << 15), (1 << 15) + 1, (1 << 16) - 1, P_FR - (1 << 15)] + [0x7fff8000_7fff8000] * 9
+    s = orc.to_limbs(sl, 4)
+    assert h.commit(s) == orc.msm_fast(s, p[:len(sl)])
+    with pytest.raises(mz.MzkError) as e:
+        h.commit(orc.synth_vector(FR, 9, n + 1))
+    assert e.value.code == -5
+    h.close()
