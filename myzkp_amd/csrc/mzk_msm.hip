@@ -13,7 +13,7 @@
 //   2. scan               exclusive prefix sum of the histogram
 //   3. k_digits_scatter   counting-sort scatter of (point index, sign) into bucket order
 //   4. k_bucket_accumulate one lane per bucket, XYZZ += affine (madd-2008-s), exception-complete
-//   5. bucket reduction   sum_b (b+1) B_b per window by recursive chunked running sums
+//   5. bucket reduction   sum_b (b+1) B_b per bucket set by in-place halving (lgB dependent steps)
 //   6. k_window_combine   Horner over the windows, XYZZ -> affine (one Fq inversion)
 #include "mzk_common.h"
 #include "mzk_ec.h"
@@ -22,9 +22,6 @@ namespace mzk {
 
 constexpr int SCALAR_BITS = 254;
 constexpr int MAX_WINDOWS = 32;
-constexpr int RED_CH_LOG = 4;           // bucket-reduction chunk = 16
-constexpr int RED_CH = 1 << RED_CH_LOG;
-constexpr int MAX_RED_LEVELS = 6;
 constexpr int SRS_WINDOW_BITS = 16;     // fixed-base tables: 16 windows of 16 bits
 constexpr int SRS_WINDOWS = SCALAR_BITS / SRS_WINDOW_BITS + 1;
 
@@ -164,6 +161,82 @@ __global__ __launch_bounds__(256) void k_digits_scatter(const u32* __restrict__ 
   }
 }
 
+// Merged (fixed-base) layout: one bucket set of 2^(c-1) = 32768 counters = 128 KiB fits the 160 KiB LDS of
+// a CU, so the histogram runs on LDS atomics (the returned value is the entry's rank inside this
+// workgroup's share of the bucket) and no global atomic is issued at all.  Workgroup g owns scalars
+// [g * per_wg, (g+1) * per_wg); wg_hist[g][b] receives its counts.
+constexpr int LDS_SORT_THREADS = 1024;
+__global__ __launch_bounds__(LDS_SORT_THREADS) void k_digits_count_lds(const u32* __restrict__ scalars, size_t n, size_t per_wg, DigitLayout L,
+                                                                      u32* __restrict__ wg_hist, u32* __restrict__ ranks) {
+  extern __shared__ u32 hist[];
+  const int NBK = 1 << (L.c - 1);
+  for (int b = threadIdx.x; b < NBK; b += LDS_SORT_THREADS) hist[b] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)blockIdx.x * per_wg;
+  const size_t hi = (lo + per_wg < n) ? lo + per_wg : n;
+  const int c = L.c;
+  const u32 half = 1u << (c - 1);
+  for (size_t i = lo + threadIdx.x; i < hi; i += LDS_SORT_THREADS) {
+    u32 w[8];
+    load_scalar_canonical(scalars, i, w);
+    u32 carry = 0;
+    for (int win = 0; win < L.nwin; win++) {
+      u32 raw = raw_window(w, win, c) + carry;
+      u32 mag = raw;
+      carry = 0;
+      if (raw > half) { mag = (1u << c) - raw; carry = 1; }
+      u32 rank = NO_RANK;
+      if (mag != 0) rank = atomicAdd(&hist[mag - 1], 1u);
+      ranks[(size_t)win * n + i] = rank;
+    }
+  }
+  __syncthreads();
+  u32* row = wg_hist + (size_t)blockIdx.x * NBK;
+  for (int b = threadIdx.x; b < NBK; b += LDS_SORT_THREADS) row[b] = hist[b];
+}
+// counts[b] = sum_g wg_hist[g][b]; wg_hist[g][b] <- exclusive prefix over g (this workgroup's base inside
+// bucket b)
+__global__ __launch_bounds__(256) void k_wg_hist_prefix(u32* __restrict__ wg_hist, int nwg, int nbk, u32* __restrict__ counts) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbk) return;
+  u32 run = 0;
+  for (int g = 0; g < nwg; g++) {
+    const u32 v = wg_hist[(size_t)g * nbk + b];
+    wg_hist[(size_t)g * nbk + b] = run;
+    run += v;
+  }
+  counts[b] = run;
+}
+__global__ __launch_bounds__(LDS_SORT_THREADS) void k_digits_scatter_lds(const u32* __restrict__ scalars, size_t n, size_t per_wg, DigitLayout L,
+                                                                        const u32* __restrict__ offsets, const u32* __restrict__ wg_hist,
+                                                                        const u32* __restrict__ ranks, u32* __restrict__ entries) {
+  extern __shared__ u32 base[];   // offsets[b] + this workgroup's prefix inside bucket b
+  const int NBK = 1 << (L.c - 1);
+  const u32* row = wg_hist + (size_t)blockIdx.x * NBK;
+  for (int b = threadIdx.x; b < NBK; b += LDS_SORT_THREADS) base[b] = offsets[b] + row[b];
+  __syncthreads();
+  const size_t lo = (size_t)blockIdx.x * per_wg;
+  const size_t hi = (lo + per_wg < n) ? lo + per_wg : n;
+  const int c = L.c;
+  const u32 half = 1u << (c - 1);
+  for (size_t i = lo + threadIdx.x; i < hi; i += LDS_SORT_THREADS) {
+    u32 w[8];
+    load_scalar_canonical(scalars, i, w);
+    u32 carry = 0;
+    for (int win = 0; win < L.nwin; win++) {
+      u32 raw = raw_window(w, win, c) + carry;
+      u32 neg = 0, mag = raw;
+      carry = 0;
+      if (raw > half) { mag = (1u << c) - raw; neg = 1; carry = 1; }
+      if (mag != 0) {
+        const u32 rank = ranks[(size_t)win * n + i];
+        const u32 ref = (u32)((size_t)win * L.table_stride + i);
+        entries[base[mag - 1] + rank] = ref | (neg << 31);
+      }
+    }
+  }
+}
+
 // ---- 2. exclusive scan (three small kernels) -----------------------------------------------------------
 constexpr int SCAN_ITEMS = 8;                      // per thread
 constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;       // 2048 per block
@@ -284,72 +357,72 @@ __global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slo
   xyzz_gstore(buckets, b, acc);
 }
 
-// ---- 5. bucket reduction: W0(X) = sum_i i X_i and Sum(X), per window, by chunked running sums ----------
-// in: nwin windows x n points.  Thread (w, u) handles chunk u of CH points:
-//   S[w][u]  = sum_l X[u CH + l]            (next level's input)
-//   T[w][u]  = sum_l l * X[u CH + l]        (plain-summed over u afterwards)
-__global__ __launch_bounds__(64) void k_chunk_runsum(const u32* __restrict__ X, size_t n, int lgch, u32* __restrict__ S, u32* __restrict__ T,
-                                                      int nwin) {
-  const size_t nchunks = (n + ((size_t)1 << lgch) - 1) >> lgch;
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nchunks * nwin) return;
-  const size_t w = t / nchunks, u = t % nchunks;
-  const size_t base = w * n + (u << lgch);
-  const size_t len = (n - (u << lgch)) < ((size_t)1 << lgch) ? (n - (u << lgch)) : ((size_t)1 << lgch);
-  Xyzz run = xyzz_inf(), acc = xyzz_inf();
-  for (size_t l = len; l-- > 1;) {
-    run = xyzz_add(run, xyzz_gload(X, base + l));
-    acc = xyzz_add(acc, run);
-  }
-  run = xyzz_add(run, xyzz_gload(X, base));
-  xyzz_gstore(S, w * nchunks + u, run);
-  xyzz_gstore(T, w * nchunks + u, acc);
+// ---- 5. bucket reduction: sum_b (b+1) B_b per bucket set, by in-place halving ---------------------------
+// Write b in binary.  Step t adds the upper half of every live block onto its lower half:
+//   main block  M (size B / 2^t at offset 0):      M[j] += M[j + h]      -> still "all buckets, folded"
+//   the upper half it just consumed stays in place and becomes a new live block U_t (the buckets whose
+//   bit (lgB-1-t) is set), which later steps keep folding onto its own lower half.
+// After lgB steps  buf[0] = sum_b B_b  and  buf[2^j] = sum_{b : bit j of b set} B_b, hence
+//   sum_b (b + 1) B_b = buf[0] + sum_j 2^j buf[2^j].
+// 2 B additions in total (the same as the serial running-sum trick) but only lgB dependent steps.
+__device__ __forceinline__ void halve_op(u32* __restrict__ buf, int lgB, int t, size_t id) {
+  const int lgh = lgB - t - 1;                    // log2(half)
+  const size_t a = id >> lgh, j = id & (((size_t)1 << lgh) - 1);
+  const size_t base = (a == 0) ? 0 : ((size_t)1 << (lgB - a));
+  const size_t idx = base + j;
+  Xyzz x = xyzz_gload(buf, idx), y = xyzz_gload(buf, idx + ((size_t)1 << lgh));
+  xyzz_gstore(buf, idx, xyzz_add(x, y));
 }
-// plain chunk sums: out[w][u] = sum_l X[w][u CH + l]
-__global__ __launch_bounds__(64) void k_chunk_sum(const u32* __restrict__ X, size_t n, int lgch, u32* __restrict__ out, int nwin) {
-  const size_t nchunks = (n + ((size_t)1 << lgch) - 1) >> lgch;
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nchunks * nwin) return;
-  const size_t w = t / nchunks, u = t % nchunks;
-  const size_t base = w * n + (u << lgch);
-  const size_t len = (n - (u << lgch)) < ((size_t)1 << lgch) ? (n - (u << lgch)) : ((size_t)1 << lgch);
-  Xyzz acc = xyzz_inf();
-  for (size_t l = 0; l < len; l++) acc = xyzz_add(acc, xyzz_gload(X, base + l));
-  xyzz_gstore(out, w * nchunks + u, acc);
+__global__ __launch_bounds__(128) void k_halve_step(u32* __restrict__ buckets, int lgB, int t) {
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)(t + 1) << (lgB - t - 1);
+  if (id >= total) return;
+  halve_op(buckets + ((size_t)blockIdx.y << lgB) * 32, lgB, t, id);
+}
+// Remaining steps t_start..lgB-1 inside one workgroup per bucket set, then the weighted sum
+// buf[0] + sum_j 2^j buf[2^j] (lane j doubles j times, LDS tree sum).  out[w] = XYZZ result of set w.
+constexpr int TAIL_THREADS = 256;
+__global__ __launch_bounds__(TAIL_THREADS) void k_reduce_tail(u32* __restrict__ buckets, int lgB, int t_start, u32* __restrict__ out) {
+  __shared__ u32 sh[32 * 32];
+  u32* buf = buckets + ((size_t)blockIdx.x << lgB) * 32;
+  for (int t = t_start; t < lgB; t++) {
+    const size_t total = (size_t)(t + 1) << (lgB - t - 1);
+    for (size_t id = threadIdx.x; id < total; id += TAIL_THREADS) halve_op(buf, lgB, t, id);
+    __syncthreads();
+  }
+  const int lane = threadIdx.x;
+  if (lane < 32) {
+    Xyzz v = xyzz_inf();
+    if (lane < lgB) {
+      v = xyzz_gload(buf, (size_t)1 << lane);
+      for (int d = 0; d < lane; d++) v = xyzz_dbl(v);
+    } else if (lane == lgB) {
+      v = xyzz_gload(buf, 0);
+    }
+    xyzz_store(v, sh + 32 * lane);
+  }
+  __syncthreads();
+  for (int off = 16; off >= 1; off >>= 1) {
+    if (lane < off) {
+      Xyzz a = xyzz_load(sh + 32 * lane), b = xyzz_load(sh + 32 * (lane + off));
+      xyzz_store(xyzz_add(a, b), sh + 32 * lane);
+    }
+    __syncthreads();
+  }
+  if (lane < 32) out[(size_t)blockIdx.x * 32 + lane] = sh[lane];
 }
 
 // ---- 6. window combine ----------------------------------------------------------------------------------
-// For window w:  A_w = Sum_w + sum_level CH^level * Tsum[level][w]   (levels deepest-first Horner),
-// total = sum_w 2^(c w) A_w  (Horner, c doublings per window), then affine or XYZZ out.
-struct CombineArgs {
-  const u32* sum;            // [nwin] XYZZ: Sum(X) per window
-  const u32* tsum[MAX_RED_LEVELS];  // [nwin] XYZZ each
-  int nlevels;
-  int nwin;
-  int c;
-  int lgch;
-  int out_xyzz;              // 1: write 32-word XYZZ (partial for multi-GPU); 0: write 16-word affine plain
-};
-__global__ void k_window_combine(CombineArgs a, u32* __restrict__ out) {
-  __shared__ u32 win_pts[MAX_WINDOWS * 32];
-  const int w = threadIdx.x;
-  if (w < a.nwin) {
-    Xyzz acc = xyzz_inf();
-    for (int lev = a.nlevels - 1; lev >= 0; lev--) {
-      for (int d = 0; d < a.lgch; d++) acc = xyzz_dbl(acc);
-      acc = xyzz_add(acc, xyzz_gload(a.tsum[lev], w));
-    }
-    acc = xyzz_add(acc, xyzz_gload(a.sum, w));
-    xyzz_store(acc, win_pts + 32 * w);
+// total = sum_w 2^(c w) R_w  (Horner, c doublings per window; a single bucket set skips it), then affine
+// (one Fq inversion) or the XYZZ partial record.
+__global__ void k_window_combine(const u32* __restrict__ wsum, int nwin, int c, int out_xyzz, u32* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Xyzz tot = xyzz_gload(wsum, nwin - 1);
+  for (int win = nwin - 2; win >= 0; win--) {
+    for (int d = 0; d < c; d++) tot = xyzz_dbl(tot);
+    tot = xyzz_add(tot, xyzz_gload(wsum, win));
   }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  Xyzz tot = xyzz_inf();
-  for (int win = a.nwin - 1; win >= 0; win--) {
-    for (int d = 0; d < a.c; d++) tot = xyzz_dbl(tot);
-    tot = xyzz_add(tot, xyzz_load(win_pts + 32 * win));
-  }
-  if (a.out_xyzz) {
+  if (out_xyzz) {
     u32 wds[32];
     xyzz_store(tot, wds);
     for (int i = 0; i < 32; i++) out[i] = wds[i];
@@ -463,14 +536,38 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   MZK_TRY(ws_get(WS_MSM_BUCKETS, NB * 128, (void**)&buckets));
   MZK_TRY(ws_get(WS_MSM_SLOTS, nslots * 128, (void**)&slots));
   prof_begin(s, MZK_PH_MSM_SORT);
-  MZK_HIP(hipMemsetAsync(counts, 0, NB * 4, s));
   MZK_HIP(hipMemsetAsync(slots, 0, nslots * 128, s));
   const unsigned nblk = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_digits_count, dim3(nblk), dim3(256), 0, s, (const u32*)d_scalars, n, L, counts, ranks);
-  hipLaunchKernelGGL(k_scan_local, dim3((unsigned)scan_blocks), dim3(256), 0, s, counts, offsets, scan_tmp, NB);
-  hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, scan_tmp, scan_blocks, scan_tmp + scan_blocks);
-  hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((NB + 1 + 255) / 256)), dim3(256), 0, s, offsets, scan_tmp, scan_tmp + scan_blocks, NB);
-  hipLaunchKernelGGL(k_digits_scatter, dim3(nblk), dim3(256), 0, s, (const u32*)d_scalars, n, L, offsets, ranks, entries);
+  if (L.merged) {
+    // LDS histogram path (no global atomics)
+    int nwg = (int)((n + 4095) / 4096);
+    if (nwg > ctx().num_cu) nwg = ctx().num_cu;
+    if (nwg < 1) nwg = 1;
+    const size_t per_wg = (n + nwg - 1) / nwg;
+    u32* wg_hist;
+    MZK_TRY(ws_get(WS_MSM_WGHIST, (size_t)nwg * NB * 4, (void**)&wg_hist));
+    const size_t lds = NB * 4;
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {
+      MZK_HIP(hipFuncSetAttribute((const void*)k_digits_count_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      MZK_HIP(hipFuncSetAttribute((const void*)k_digits_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      lds_attr_set = true;
+    }
+    hipLaunchKernelGGL(k_digits_count_lds, dim3(nwg), dim3(LDS_SORT_THREADS), lds, s, (const u32*)d_scalars, n, per_wg, L, wg_hist, ranks);
+    hipLaunchKernelGGL(k_wg_hist_prefix, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, s, wg_hist, nwg, (int)NB, counts);
+    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)scan_blocks), dim3(256), 0, s, counts, offsets, scan_tmp, NB);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, scan_tmp, scan_blocks, scan_tmp + scan_blocks);
+    hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((NB + 1 + 255) / 256)), dim3(256), 0, s, offsets, scan_tmp, scan_tmp + scan_blocks, NB);
+    hipLaunchKernelGGL(k_digits_scatter_lds, dim3(nwg), dim3(LDS_SORT_THREADS), lds, s, (const u32*)d_scalars, n, per_wg, L, (const u32*)offsets,
+                       (const u32*)wg_hist, (const u32*)ranks, entries);
+  } else {
+    MZK_HIP(hipMemsetAsync(counts, 0, NB * 4, s));
+    hipLaunchKernelGGL(k_digits_count, dim3(nblk), dim3(256), 0, s, (const u32*)d_scalars, n, L, counts, ranks);
+    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)scan_blocks), dim3(256), 0, s, counts, offsets, scan_tmp, NB);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, scan_tmp, scan_blocks, scan_tmp + scan_blocks);
+    hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((NB + 1 + 255) / 256)), dim3(256), 0, s, offsets, scan_tmp, scan_tmp + scan_blocks, NB);
+    hipLaunchKernelGGL(k_digits_scatter, dim3(nblk), dim3(256), 0, s, (const u32*)d_scalars, n, L, offsets, ranks, entries);
+  }
   prof_end(s, MZK_PH_MSM_SORT);
   prof_begin(s, MZK_PH_MSM_ACCUMULATE);
   // the true entry count lives in offsets[NB] on the device; lanes past it exit (E_max bounds it)
@@ -479,57 +576,19 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   prof_end(s, MZK_PH_MSM_ACCUMULATE);
   prof_begin(s, MZK_PH_MSM_REDUCE);
 
-  // bucket reduction: weights (b+1) = b + 1  =>  W0(X) + Sum(X), per bucket set
-  const size_t B = (size_t)1 << sh.lgB;
-  size_t level_n[MAX_RED_LEVELS + 1];
-  level_n[0] = B;
-  int nlev = 0;
-  while (level_n[nlev] > 1) {
-    level_n[nlev + 1] = (level_n[nlev] + RED_CH - 1) >> RED_CH_LOG;
-    nlev++;
-    if (nlev > MAX_RED_LEVELS) { set_error("msm: reduction depth"); return MZK_E_ARG; }
+  // bucket reduction: sum_b (b+1) B_b per bucket set (in-place halving), then the window Horner
+  u32* wsum;
+  MZK_TRY(ws_get(WS_MSM_OUT, (size_t)MAX_WINDOWS * 128, (void**)&wsum));
+  int t_start = 0;
+  while (t_start < sh.lgB && ((size_t)(t_start + 1) << (sh.lgB - t_start - 1)) > (size_t)2 * TAIL_THREADS) t_start++;
+  for (int t = 0; t < t_start; t++) {
+    const size_t total = (size_t)(t + 1) << (sh.lgB - t - 1);
+    hipLaunchKernelGGL(k_halve_step, dim3((unsigned)((total + 127) / 128), (unsigned)red_windows), dim3(128), 0, s, buckets, sh.lgB, t);
   }
-  u32 *redA, *redB, *tbuf, *tsums;
-  const size_t chunk1 = (size_t)red_windows * level_n[nlev ? 1 : 0];
-  MZK_TRY(ws_get(WS_MSM_RED_A, (chunk1 + 16) * 128, (void**)&redA));     // S of the current level
-  MZK_TRY(ws_get(WS_MSM_RED_B, (chunk1 + 16) * 128 * 2, (void**)&redB)); // S of the next level + T tree scratch
-  MZK_TRY(ws_get(WS_MISC_D, (chunk1 + 16) * 128, (void**)&tbuf));         // T of the current level
-  MZK_TRY(ws_get(WS_MSM_OUT, (size_t)(MAX_RED_LEVELS + 2) * MAX_WINDOWS * 128, (void**)&tsums));
-  CombineArgs ca;
-  memset(&ca, 0, sizeof ca);
-  ca.nwin = red_windows; ca.c = horner_c; ca.lgch = RED_CH_LOG; ca.out_xyzz = out_partial_xyzz ? 1 : 0;
-  const u32* X = buckets;
-  u32* Sping = redA;
-  u32* Spong = redB;
-  u32* tree = redB + (chunk1 + 16) * 32;  // second half of redB (u32 units: 32 words per point)
-  for (int lev = 0; lev < nlev; lev++) {
-    const size_t nin = level_n[lev], nout = level_n[lev + 1];
-    const size_t threads = nout * red_windows;
-    hipLaunchKernelGGL(k_chunk_runsum, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, s, X, nin, RED_CH_LOG, Sping, tbuf, red_windows);
-    const u32* tin = tbuf;
-    size_t tn = nout;
-    u32* tA = tree;
-    u32* tB = tree + ((nout + RED_CH - 1) / RED_CH + 1) * (size_t)red_windows * 32;
-    while (tn > 1) {
-      const size_t tout = (tn + RED_CH - 1) >> RED_CH_LOG;
-      u32* dst = (tout == 1) ? (tsums + (size_t)lev * MAX_WINDOWS * 32) : tA;
-      hipLaunchKernelGGL(k_chunk_sum, dim3((unsigned)((tout * red_windows + 63) / 64)), dim3(64), 0, s, tin, tn, RED_CH_LOG, dst, red_windows);
-      tin = dst;
-      tn = tout;
-      u32* sw = tA; tA = tB; tB = sw;
-    }
-    if (nout == 1) {
-      MZK_HIP(hipMemcpyAsync(tsums + (size_t)lev * MAX_WINDOWS * 32, tbuf, (size_t)red_windows * 128, hipMemcpyDeviceToDevice, s));
-    }
-    ca.tsum[lev] = tsums + (size_t)lev * MAX_WINDOWS * 32;
-    X = Sping;
-    u32* sw = Sping; Sping = Spong; Spong = sw;
-  }
-  ca.nlevels = nlev;
-  ca.sum = (nlev == 0) ? buckets : X;
+  hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)red_windows), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, t_start, wsum);
   prof_end(s, MZK_PH_MSM_REDUCE);
   prof_begin(s, MZK_PH_MSM_COMBINE);
-  hipLaunchKernelGGL(k_window_combine, dim3(1), dim3(64), 0, s, ca, (u32*)d_out);
+  hipLaunchKernelGGL(k_window_combine, dim3(1), dim3(64), 0, s, (const u32*)wsum, red_windows, horner_c, out_partial_xyzz ? 1 : 0, (u32*)d_out);
   prof_end(s, MZK_PH_MSM_COMBINE);
   MZK_HIP(hipGetLastError());
   return MZK_OK;
