@@ -97,6 +97,9 @@ def main():
     torch.cuda.synchronize()
 
     def msm_step():
+        if world == 1:   # nothing to exchange: the kernel chain ends in the affine point
+            check(L.mzk_msm_g1_bn254_dev(dptr(scalars), dptr(points), ctypes.c_size_t(n), dptr(result), stream))
+            return
         check(L.mzk_msm_g1_bn254_partial_dev(dptr(scalars), dptr(points), ctypes.c_size_t(n), dptr(partial), stream))
         recs = sharded.all_gather_partials(partial)
         check(L.mzk_g1_fold_partials_dev(dptr(recs), ctypes.c_int(recs.shape[0]), dptr(result), stream))
@@ -106,6 +109,9 @@ def main():
     result_srs = torch.zeros(8, dtype=torch.int64, device=dev)
 
     def srs_step():
+        if world == 1:
+            check(L.mzk_kzg_commit_srs_dev(srs._h, dptr(scalars), ctypes.c_size_t(n), dptr(result_srs), ctypes.c_int(0), stream))
+            return
         check(L.mzk_kzg_commit_srs_dev(srs._h, dptr(scalars), ctypes.c_size_t(n), dptr(partial), ctypes.c_int(1), stream))
         recs = sharded.all_gather_partials(partial)
         check(L.mzk_g1_fold_partials_dev(dptr(recs), ctypes.c_int(recs.shape[0]), dptr(result_srs), stream))
@@ -114,39 +120,46 @@ def main():
         check(L.mzk_ntt_dev(mz.FIELD_FR, root.ctypes.data_as(ctypes.c_void_p), dptr(ntt_in), dptr(ntt_out), ctypes.c_size_t(n), 0, stream))
 
     # ------------------------------------------------------------------ parity before timing (bit-exact vs CPU oracle)
+    # Every rank checks ITS OWN shard on its share of the host cores (GPU shard result == oracle Pippenger on the
+    # same synthetic streams), then rank 0 checks that the folded N-GPU result == the CPU sum of the N shard points.
     parity = {}
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
-    msm_step()
+    threads = max(1, (os.cpu_count() or 1) // world)
+    s_cpu = orc.synth_vector(orc.FR, SEED + 1000003 * rank, n, threads)
+    p_cpu = orc.synth_points(SEED + 7 + 1000003 * rank, n, threads)
+    ok_inputs = bool(np.array_equal(s_cpu.view(np.int64).reshape(-1), scalars.cpu().numpy()) and
+                     np.array_equal(p_cpu.view(np.int64).reshape(-1), points.cpu().numpy()))
+    assert ok_inputs, "GPU synthetic inputs != oracle streams"
+    shard_want = orc.msm_fast(s_cpu, p_cpu, threads)
+    shard_out = torch.zeros(8, dtype=torch.int64, device=dev)
+    check(L.mzk_msm_g1_bn254_dev(dptr(scalars), dptr(points), ctypes.c_size_t(n), dptr(shard_out), stream))
+    torch.cuda.synchronize()
+    shard_got = mz.array_to_points(shard_out.cpu().numpy().view(np.uint64))[0]
+    assert shard_got == shard_want, "rank %d: MSM shard mismatch vs CPU oracle" % rank
+    check(L.mzk_kzg_commit_srs_dev(srs._h, dptr(scalars), ctypes.c_size_t(n), dptr(shard_out), ctypes.c_int(0), stream))
+    torch.cuda.synchronize()
+    assert mz.array_to_points(shard_out.cpu().numpy().view(np.uint64))[0] == shard_want, "rank %d: SRS commit mismatch" % rank
+    shard_pts = sharded.all_gather_partials(shard_out)          # (world, 8) affine shard results
+    msm_step(); srs_step()
     torch.cuda.synchronize()
     if rank == 0:
-        threads = os.cpu_count() or 1
-        # same streams on the CPU for every rank's shard
         want = (0, 0)
         for r in range(world):
-            s_cpu = orc.synth_vector(orc.FR, SEED + 1000003 * r, n, threads)
-            p_cpu = orc.synth_points(SEED + 7 + 1000003 * r, n, threads)
-            if r == 0:
-                assert np.array_equal(s_cpu.view(np.int64).reshape(-1), scalars.cpu().numpy()), "GPU synth scalars != oracle"
-                assert np.array_equal(p_cpu.view(np.int64).reshape(-1), points.cpu().numpy()), "GPU synth points != oracle"
-            want = orc.ec_add(0, want, orc.msm_fast(s_cpu, p_cpu, threads))
+            want = orc.ec_add(0, want, mz.array_to_points(shard_pts[r].cpu().numpy().view(np.uint64))[0])
         got = mz.array_to_points(result.cpu().numpy().view(np.uint64))[0]
-        parity["msm_bit_exact_vs_cpu"] = bool(got == want)
-        assert got == want, "MSM mismatch vs CPU oracle"
-    srs_step()
-    torch.cuda.synchronize()
-    if rank == 0:
         got2 = mz.array_to_points(result_srs.cpu().numpy().view(np.uint64))[0]
+        parity["msm_bit_exact_vs_cpu"] = bool(got == want)
         parity["kzg_commit_srs_bit_exact_vs_cpu"] = bool(got2 == want)
-        assert got2 == want, "SRS-table commit mismatch vs CPU oracle"
+        assert got == want and got2 == want, "folded N-GPU MSM mismatch vs CPU"
     ntt_step()
     torch.cuda.synchronize()
-    if rank == 0:
-        v_cpu = orc.synth_vector(orc.FR, SEED + 99, n, os.cpu_count() or 1)
-        rc, want = orc.ntt_fast(orc.FR, mz.from_limbs(root)[0], v_cpu, threads=os.cpu_count() or 1)
-        ok = rc == 0 and np.array_equal(want.view(np.int64).reshape(-1), ntt_out.cpu().numpy())
-        parity["ntt_bit_exact_vs_cpu"] = bool(ok)
-        assert ok, "NTT mismatch vs CPU oracle"
+    v_cpu = orc.synth_vector(orc.FR, SEED + 99 + rank, n, threads)
+    rc, want_ntt = orc.ntt_fast(orc.FR, mz.from_limbs(root)[0], v_cpu, threads=threads)
+    ok = rc == 0 and np.array_equal(want_ntt.view(np.int64).reshape(-1), ntt_out.cpu().numpy())
+    assert ok, "rank %d: NTT mismatch vs CPU oracle" % rank
+    parity["ntt_bit_exact_vs_cpu"] = bool(ok)
+    del s_cpu, p_cpu, v_cpu, want_ntt
 
     # ------------------------------------------------------------------ timed regions
     def timed(step, K, W):
@@ -204,22 +217,31 @@ def main():
            "msm_accumulate_frac": msm_mads / (acc_ms * 1e-3) / MAD_PEAK_PER_S if acc_ms == acc_ms else None,
            "ntt_frac": ntt_mads / (ntt_total_ms * 1e-3) / MAD_PEAK_PER_S if ntt_total_ms else None}
 
+    srs_ms = srs_dt / K * 1e3
+    srs_rate = world * n / (srs_dt / K)
+    srs_acc_ms = srs_ph.get("msm_bucket_accumulate", {}).get("avg_ms", float("nan"))
+    srs_roof = hbm_roofline(96.0 * n, srs_acc_ms)
+    srs_roof["kernel"] = "k_seg_accumulate (+ k_seg_combine)"
+    srs_roof["algorithmic_bytes_per_launch"] = 96 * n
+    alu["kzg_commit_accumulate_frac"] = msm_mads / (srs_acc_ms * 1e-3) / MAD_PEAK_PER_S if srs_acc_ms == srs_acc_ms else None
     out = {
         "metric": "G1 MSM pairs/sec + NTT elems/sec at 2^20 and 2^24; bit-exact vs CPU",
-        "value": msm_rate, "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": msm_ms,
+        "value": srs_rate, "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": srs_ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 254-bit Montgomery)",
         "data": "synthetic",
-        "config": {"workload": "BN254 G1 Pippenger MSM, 2^%d pairs per GPU, 16-bit signed windows (BASELINE configs[2]; N GPUs = one MSM of N*2^%d pairs, configs[3] shape)" % (args.log2n, args.log2n),
+        "config": {"workload": "KZG commit = BN254 G1 Pippenger MSM of 2^%d (scalar, point) pairs per GPU against a device-resident SRS "
+                               "(commit_kzg, kzg.rs:57-59; 16-bit signed windows; the SRS handle holds 16 window tables 2^(16w)*P_i built "
+                               "once at upload like an FFT plan, so all windows share one bucket set); N GPUs = one MSM of N*2^%d pairs "
+                               "(BASELINE configs[2]/[3])" % (args.log2n, args.log2n),
                    "pairs_per_gpu": n, "seed": SEED, "sharding": "contiguous shards + all_gather of 128 B partials (RCCL) + local fold"},
-        "roofline": roof,
+        "roofline": srs_roof,
+        "phases": srs_ph,
+        "msm_generic": {"metric": "G1 MSM pairs/sec, arbitrary points every call (no per-point-set precomputation; 16 bucket sets + window Horner)",
+                        "value": msm_rate, "unit": "pairs/s", "ms_per_step": msm_ms, "phases": msm_ph, "roofline": roof},
         "ntt": {"metric": "NTT elems/sec", "value": ntt_rate, "unit": "elems/s", "ms_per_step": ntt_ms, "field": "BN254 Fr",
                 "log2n": args.log2n, "multi_gpu": "replicas only (one independent transform per GPU)", "roofline": ntt_roof,
                 "phases": ntt_ph},
-        "kzg_commit_srs": {"metric": "G1 MSM pairs/sec, fixed base (device-resident SRS with 16 precomputed window tables, built once at upload)",
-                           "value": world * n / (srs_dt / K), "unit": "pairs/s", "ms_per_step": srs_dt / K * 1e3, "phases": srs_ph,
-                           "roofline": dict(hbm_roofline(96.0 * n, srs_ph.get("msm_bucket_accumulate", {}).get("avg_ms", float("nan"))), kernel="k_seg_accumulate + k_seg_combine")},
         "alu_roofline": alu,
-        "phases": msm_ph,
         "parity": parity,
     }
 
@@ -242,19 +264,23 @@ def main():
                 def t():
                     check(L.mzk_ntt_dev(mz.FIELD_FR, rt.ctypes.data_as(ctypes.c_void_p), dptr(vin), dptr(vout), ctypes.c_size_t(nn), 0, stream))
                 e = {}
-                for name, fn, reps in (("msm", m, 2), ("ntt", t, 3)):
+                srs_x = mz.Srs(pt.cpu().numpy().view(np.uint64).reshape(-1, 8))
+                def c():
+                    check(L.mzk_kzg_commit_srs_dev(srs_x._h, dptr(sc), ctypes.c_size_t(nn), dptr(res), ctypes.c_int(0), stream))
+                for name, fn, reps in (("kzg_commit_srs", c, 3), ("msm_generic", m, 2), ("ntt", t, 3)):
                     fn(); torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     for _ in range(reps):
                         fn()
                     torch.cuda.synchronize()
                     dt = (time.perf_counter() - t0) / reps
-                    e[name] = {"ms": dt * 1e3, "rate": nn / dt, "hbm_frac": (96.0 if name == "msm" else 64.0) * nn / dt / 1e9 / HBM_PEAK_GBPS}
+                    e[name] = {"ms": dt * 1e3, "rate": nn / dt, "hbm_frac": (64.0 if name == "ntt" else 96.0) * nn / dt / 1e9 / HBM_PEAK_GBPS}
                 # round trip property at this size: intt(ntt(x)) == x
                 check(L.mzk_ntt_dev(mz.FIELD_FR, rt.ctypes.data_as(ctypes.c_void_p), dptr(vout), dptr(vout), ctypes.c_size_t(nn), 1, stream))
                 torch.cuda.synchronize()
                 e["ntt_roundtrip_ok"] = bool(torch.equal(vin, vout))
                 extras["2^%d" % lg] = e
+                srs_x.close()
                 del sc, pt, vin, vout
                 torch.cuda.empty_cache()
             except Exception as ex:  # an extra must never sink the headline line
