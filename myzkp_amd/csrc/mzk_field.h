@@ -203,6 +203,36 @@ template <class P> MZK_HD Fe<P> fe_carry(const Fe<P>& a) {
   return r;
 }
 
+// Fused (a + b) and (a - b + K p) with carry propagation: normalised result, one pass over the limbs.
+template <class P> MZK_HD Fe<P> fe_add_carry(const Fe<P>& a, const Fe<P>& b) {
+  Fe<P> r;
+  u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < P::L - 1; i++) {
+    MZK_ASSERT((u64)a.l[i] + b.l[i] + c < ((u64)1 << 32));
+    const u32 v = a.l[i] + b.l[i] + c;
+    r.l[i] = v & MASK29;
+    c = v >> W29;
+  }
+  MZK_ASSERT((u64)a.l[P::L - 1] + b.l[P::L - 1] + c < ((u64)1 << 32));
+  r.l[P::L - 1] = a.l[P::L - 1] + b.l[P::L - 1] + c;
+  return r;
+}
+template <class P, int K> MZK_HD Fe<P> fe_sub_carry(const Fe<P>& a, const Fe<P>& b) {
+  Fe<P> r;
+  u32 c = 0;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) {
+    const u32 kp = (K == 2) ? P::KP2[i] : (K == 4) ? P::KP4[i] : (K == 8) ? P::KP8[i] : P::KP16[i];
+    MZK_ASSERT(kp >= b.l[i]);
+    MZK_ASSERT((u64)a.l[i] + (kp - b.l[i]) + c < ((u64)1 << 32));
+    const u32 v = a.l[i] + (kp - b.l[i]) + c;
+    if (i < P::L - 1) { r.l[i] = v & MASK29; c = v >> W29; }
+    else r.l[i] = v;
+  }
+  return r;
+}
+
 // x - p if that is >= 0, else x.  x must be normalised.
 template <class P> MZK_HD Fe<P> fe_cond_sub_p(const Fe<P>& x) {
   constexpr int L = P::L;

@@ -79,30 +79,52 @@ template <class P> __device__ __forceinline__ void lds_store(u32* lds, int pos, 
   for (int i = 0; i < P::L; i++) lds[i * TILE + ph] = v.l[i];
 }
 
-// In-LDS radix-2 DIT over the k-dimension of a [2^lgn][2^lgc] tile whose rows were stored
-// bit-reversed; leaves natural order.  tw: w_n^j, j < n/2, Montgomery, packed.
+// In-tile twiddles w_n^j (j < n/2) staged in LDS in limb form, limb-major, so a butterfly fetches its
+// twiddle with L ds_read_b32 and no unpacking.
 template <class P>
-__device__ __forceinline__ void tile_stages(u32* lds, const u32* __restrict__ tw, int lgn, int lgc) {
+__device__ __forceinline__ void stage_twiddles(u32* twl, const u32* __restrict__ tw, int lgn) {
+  const int cnt = (lgn >= 2) ? (1 << (lgn - 1)) : 0;
+  for (int j = threadIdx.x; j < cnt; j += NTHREADS) {
+    Fe<P> w = gload<P>(tw, j);
+#pragma unroll
+    for (int i = 0; i < P::L; i++) twl[i * cnt + j] = w.l[i];
+  }
+}
+// In-LDS radix-2 DIT over the k-dimension of a [2^lgn][2^lgc] tile whose rows were stored
+// bit-reversed; leaves natural order.  Butterflies are enumerated twiddle-major (all butterflies with
+// twiddle index j = 0 first), so whole waves skip the multiplication by w^0 = 1: stage s has a
+// fraction 2^-(s-1) of trivial butterflies, about one stage's worth of products per level.
+template <class P>
+__device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, int lgc) {
   const int tid = threadIdx.x;
-  const int nbf = 1 << (lgn + lgc - 1);  // butterflies per stage
+  const int lgbf = lgn + lgc - 1;
+  const int nbf = 1 << lgbf;  // butterflies per stage
   const int cmask = (1 << lgc) - 1;
+  const int tws = (lgn >= 2) ? (1 << (lgn - 1)) : 1;   // twiddle table stride (entries per limb row)
   for (int s = 1; s <= lgn; s++) {
-    const int half = 1 << (s - 1);
+    const int lgh = s - 1;
+    const int lgrest = lgbf - lgh;
     for (int b = tid; b < nbf; b += NTHREADS) {
-      const int c = b & cmask, kb = b >> lgc;
-      const int j = kb & (half - 1);
-      const int klo = ((kb >> (s - 1)) << s) | j;
-      const int plo = (klo << lgc) | c, phi = plo + (half << lgc);
+      const int j = b >> lgrest;
+      const int rest = b & ((1 << lgrest) - 1);
+      const int c = rest & cmask, grp = rest >> lgc;
+      const int klo = (grp << s) | j;
+      const int plo = (klo << lgc) | c, phi = plo + (1 << (lgh + lgc));
       Fe<P> a = lds_load<P>(lds, plo);
       Fe<P> t = lds_load<P>(lds, phi);
-      if (s > 1) {  // stage 1 has the trivial twiddle only
-        Fe<P> w = gload<P>(tw, (size_t)j << (lgn - s));
+      if (j != 0) {
+        Fe<P> w;
+        const int ti = j << (lgn - s);
+#pragma unroll
+        for (int i = 0; i < P::L; i++) w.l[i] = twl[i * tws + ti];
         t = fe_mul<P>(t, w);
+      } else if (s > 1) {
+        t = fe_weak_reduce<P>(t);   // w = 1: no product, but t has grown by up to 8 p per earlier stage
       }
-      // t is normalised and < 2^(32 NW) (raw input, stage 1) or < 2 p (product): below the 4 p that
-      // fe_sub<8> tolerates in its subtrahend for every field here
-      lds_store<P>(lds, plo, fe_carry<P>(fe_add<P>(a, t)));
-      lds_store<P>(lds, phi, fe_carry<P>(fe_sub<P, 8>(a, t)));
+      // t is normalised and < 2^(32 NW) (raw input, stage 1) or < 2.01 p: below the 4 p that the K = 8
+      // subtraction tolerates in its subtrahend for every field here
+      lds_store<P>(lds, plo, fe_add_carry<P>(a, t));
+      lds_store<P>(lds, phi, fe_sub_carry<P, 8>(a, t));
     }
     __syncthreads();
   }
@@ -121,6 +143,8 @@ __global__ __launch_bounds__(NTHREADS) void k_ntt_strided(const u32* __restrict_
   const size_t base = (o << (lgn + lgM)) + (ct << lgc);
   const int cmask = (1 << lgc) - 1;
   const int tile_elems = 1 << (lgn + lgc);
+  u32* twl = lds + P::L * TILE;
+  stage_twiddles<P>(twl, tw_tile, lgn);
   for (int e = tid; e < tile_elems; e += NTHREADS) {
     const int j1 = e >> lgc, c = e & cmask;
     Fe<P> v = gload<P>(in, base + ((size_t)j1 << lgM) + c);
@@ -128,7 +152,7 @@ __global__ __launch_bounds__(NTHREADS) void k_ntt_strided(const u32* __restrict_
     lds_store<P>(lds, (k << lgc) | c, v);
   }
   __syncthreads();
-  tile_stages<P>(lds, tw_tile, lgn, lgc);
+  tile_stages<P>(lds, twl, lgn, lgc);
   for (int e = tid; e < tile_elems; e += NTHREADS) {
     const int k = e >> lgc, c = e & cmask;
     const size_t off = ((size_t)k << lgM) + (ct << lgc) + c;
@@ -149,6 +173,8 @@ __global__ __launch_bounds__(NTHREADS) void k_ntt_last(const u32* __restrict__ i
   const size_t p0 = (size_t)blockIdx.x << lgr;
   const int rmask = (1 << lgr) - 1, nmask = (1 << lgn) - 1;
   const int tile_elems = 1 << (lgn + lgr);
+  u32* twl = lds + P::L * TILE;
+  stage_twiddles<P>(twl, tw_tile, lgn);
   for (int e = tid; e < tile_elems; e += NTHREADS) {
     const int rr = e >> lgn, j = e & nmask;
     size_t rem = p0 + rr, row = 0;
@@ -161,7 +187,7 @@ __global__ __launch_bounds__(NTHREADS) void k_ntt_last(const u32* __restrict__ i
     lds_store<P>(lds, (k << lgr) | rr, v);
   }
   __syncthreads();
-  tile_stages<P>(lds, tw_tile, lgn, lgr);
+  tile_stages<P>(lds, twl, lgn, lgr);
   Fe<P> sc;
   if (has_scale) sc = fe_unpack<P>(scale.w);
   for (int e = tid; e < tile_elems; e += NTHREADS) {
@@ -652,7 +678,7 @@ static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t 
       default: return run_plan_rb<P, 12>(pl, d_in, d_out, s);
     }
   }
-  const size_t lds_bytes = sizeof(u32) * P::L * TILE;
+  auto lds_for = [](int lgn) { return sizeof(u32) * P::L * ((size_t)TILE + (lgn >= 2 ? ((size_t)1 << (lgn - 1)) : 1)); };  // tile + in-tile twiddles
   const u32* src = d_in;
   u32* tmp = nullptr;
   if (li.nlev > 1) MZK_TRY(ws_get(WS_NTT_TMP, ((size_t)1 << logn) * sizeof(u32) * P::NW, (void**)&tmp));
@@ -663,7 +689,7 @@ static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t 
     const unsigned blocks = (unsigned)((size_t)1 << (logn - TILE_LOG));
     {
       ProfScope ps(s, MZK_PH_NTT_PASS0 + t);
-      hipLaunchKernelGGL((k_ntt_strided<P>), dim3(blocks), dim3(NTHREADS), lds_bytes, s, src, tmp, pl->tw_tile[t],
+      hipLaunchKernelGGL((k_ntt_strided<P>), dim3(blocks), dim3(NTHREADS), lds_for(lgn), s, src, tmp, pl->tw_tile[t],
                          pl->tw_inter[t], lgn, lgM, lgc);
     }
     src = tmp;
@@ -676,7 +702,7 @@ static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t 
     if (lgr > lg_rows) lgr = lg_rows;
     const unsigned blocks = (unsigned)((size_t)1 << (lg_rows - lgr));
     ProfScope ps(s, MZK_PH_NTT_PASS0 + li.nlev - 1);
-    hipLaunchKernelGGL((k_ntt_last<P>), dim3(blocks), dim3(NTHREADS), lds_bytes, s, src, d_out,
+    hipLaunchKernelGGL((k_ntt_last<P>), dim3(blocks), dim3(NTHREADS), lds_for(lgn), s, src, d_out,
                        pl->tw_tile[li.nlev - 1], li, lgn, lgr, lg_rows, pl->last_scale, pl->has_last_scale);
   }
   MZK_HIP(hipGetLastError());
