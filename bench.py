@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--skip-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--e2e-log2n", type=int, default=22, help="degree of the end-to-end KZG run (0 = skip)")
     ap.add_argument("--extra-sizes", type=str, default="24", help="comma list of extra log2 sizes timed once each (rank 0 view)")
     args = ap.parse_args()
 
@@ -286,6 +287,51 @@ def main():
             except Exception as ex:  # an extra must never sink the headline line
                 extras["2^%d" % lg] = {"error": str(ex)[:200]}
     out["extra_sizes_1gpu"] = extras
+
+    # ------------------------------------------------------------------ BASELINE configs[4]: end-to-end KZG at degree 2^e2e (rank 0)
+    if rank == 0 and args.e2e_log2n > 0:
+        try:
+            lg = args.e2e_log2n
+            nn = 1 << lg
+            ev = torch.empty(nn * 4, dtype=torch.int64, device=dev)
+            cf = torch.empty(nn * 4, dtype=torch.int64, device=dev)
+            sp = torch.empty(nn * 8, dtype=torch.int64, device=dev)
+            o = torch.zeros(20, dtype=torch.int64, device=dev)
+            check(L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(SEED + 555), ctypes.c_size_t(nn), dptr(ev), stream))
+            rt = mz.to_limbs([mz.root_of_unity(mz.FIELD_FR, lg)], 4)
+            alpha = orc.from_limbs(orc.synth_vector(orc.FR, SEED + 556, 1))[0]
+            uu = orc.from_limbs(orc.synth_vector(orc.FR, SEED + 557, 1))[0]
+            a_l, u_l, g_l = mz.to_limbs([alpha], 4), mz.to_limbs([uu], 4), mz.points_to_array([(1, 2)])
+            hh = ctypes.c_void_p()
+            stages = {}
+            def stage(name, fn):
+                torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize()
+                stages[name] = (time.perf_counter() - t0) * 1e3
+            # untimed warm pass for plans / workspaces, then timed
+            for timed_pass in (False, True):
+                if hh:
+                    L.mzk_srs_free(hh); hh = ctypes.c_void_p()
+                stage("intt", lambda: check(L.mzk_ntt_dev(mz.FIELD_FR, rt.ctypes.data_as(ctypes.c_void_p), dptr(ev), dptr(cf), ctypes.c_size_t(nn), 1, stream)))
+                stage("setup_srs_powers", lambda: check(L.mzk_kzg_setup_g1_dev(a_l.ctypes.data_as(ctypes.c_void_p), g_l.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(nn - 1), dptr(sp), stream)))
+                stage("srs_window_tables", lambda: check(L.mzk_srs_from_device(dptr(sp), ctypes.c_size_t(nn), ctypes.byref(hh), stream)))
+                stage("commit", lambda: check(L.mzk_kzg_commit_srs_dev(hh, dptr(cf), ctypes.c_size_t(nn), dptr(o), 0, stream)))
+                stage("open", lambda: check(L.mzk_kzg_open_srs_dev(hh, dptr(cf), ctypes.c_size_t(nn), u_l.ctypes.data_as(ctypes.c_void_p),
+                                                                    ctypes.c_void_p(o.data_ptr() + 64), ctypes.c_void_p(o.data_ptr() + 96), stream)))
+            oc = o.cpu().numpy().view(np.uint64)
+            cf_cpu = cf.cpu().numpy().view(np.uint64).reshape(-1, 4)
+            fa = orc.poly_eval(orc.FR, cf_cpu, alpha)
+            yy = mz.from_limbs(oc[8:12].reshape(1, 4))[0]
+            qa = (fa - yy) * pow(alpha - uu, -1, orc.P_FR) % orc.P_FR
+            okc = mz.array_to_points(oc[:8])[0] == orc.ec_mul(0, (1, 2), fa)
+            oky = yy == orc.poly_eval(orc.FR, cf_cpu, uu)
+            okw = mz.array_to_points(oc[12:20])[0] == orc.ec_mul(0, (1, 2), qa)
+            out["e2e_kzg"] = {"log2_degree": lg, "stages_ms": stages, "trapdoor_identities_hold": bool(okc and oky and okw),
+                              "what": "evaluations -> iNTT -> setup(alpha) -> commit -> open(u), device-resident (BASELINE configs[4])"}
+            L.mzk_srs_free(hh)
+            del ev, cf, sp
+            torch.cuda.empty_cache()
+        except Exception as ex:
+            out["e2e_kzg"] = {"error": str(ex)[:300]}
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only, bounded sample)
     if rank == 0 and world == 1 and not args.skip_cpu:

@@ -111,6 +111,15 @@ int mzk_g1_fold_partials_dev(const void* d_partials16, int count, void* d_out_xy
 int mzk_kzg_commit_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, void* d_out, int out_partial,
                            void* stream);
 
+/* open_kzg / setup_kzg with everything device-resident (end-to-end pipelines: iNTT -> commit -> open).
+ * d_y: 4 limbs, d_w_xy: 8 limbs on the device; u / alpha / g1 are host parameters. */
+int mzk_kzg_open_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, const uint64_t u_host[4], void* d_y,
+                         void* d_w_xy, void* stream);
+int mzk_kzg_setup_g1_dev(const uint64_t alpha_host[4], const uint64_t g1_xy_host[8], size_t max_d, void* d_powers_xy,
+                         void* stream);
+/* Build an SRS handle from points already in HBM (affine canonical, n * 8 limbs). */
+int mzk_srs_from_device(const void* d_powers_xy, size_t n, mzk_srs** out, void* stream);
+
 /* Deterministic synthetic inputs (bench + tests): bit-identical to the oracle's orc_synth_*. */
 int mzk_synth_field_dev(int field_id, uint64_t seed, size_t n, void* d_out, void* stream);
 int mzk_synth_g1_points_dev(uint64_t seed, size_t n, void* d_out_xy, void* stream);

@@ -498,6 +498,40 @@ int mzk_kzg_commit_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, voi
                       (hipStream_t)stream);
 }
 
+int mzk_kzg_open_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, const uint64_t u_host[4], void* d_y, void* d_w_xy, void* stream) {
+  MZK_TRY(ensure_init());
+  if (!srs) { set_error("open_srs_dev: null srs"); return MZK_E_ARG; }
+  if (n > 1 && n - 1 > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }
+  return kzg_open_dev(d_coef, n, u_host, srs->d_points_mont, srs->has_tables ? MSM_PTS_TABLES : MSM_PTS_MONT, srs->n, d_y, d_w_xy, (hipStream_t)stream);
+}
+int mzk_kzg_setup_g1_dev(const uint64_t alpha_host[4], const uint64_t g1_xy_host[8], size_t max_d, void* d_powers_xy, void* stream) {
+  MZK_TRY(ensure_init());
+  return kzg_setup_g1_dev(alpha_host, g1_xy_host, max_d + 1, d_powers_xy, (hipStream_t)stream);
+}
+int mzk_srs_from_device(const void* d_powers_xy, size_t n, mzk_srs** out, void* stream) {
+  MZK_TRY(ensure_init());
+  if (!out || (!d_powers_xy && n)) { set_error("srs_from_device: null pointer"); return MZK_E_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  mzk_srs* h = new mzk_srs{nullptr, n, n >= SRS_TABLE_MIN_N};
+  if (n) {
+    void* d_mont;
+    const size_t copies = h->has_tables ? (size_t)MSM_SRS_WINDOWS : 1;
+    if (hipMalloc(&h->d_points_mont, n * 64 * copies) != hipSuccess) { delete h; set_error("srs_from_device: hipMalloc failed"); return MZK_E_HIP; }
+    int rc = MZK_OK;
+    if (h->has_tables) {
+      rc = ws_get(WS_MSM_POINTS, n * 64, &d_mont);
+      if (rc == MZK_OK) rc = msm_prepare_points(d_powers_xy, n, d_mont, s);
+      if (rc == MZK_OK) rc = msm_build_tables(d_mont, n, h->d_points_mont, s);
+    } else {
+      rc = msm_prepare_points(d_powers_xy, n, h->d_points_mont, s);
+    }
+    if (rc == MZK_OK && hipStreamSynchronize(s) != hipSuccess) rc = MZK_E_HIP;
+    if (rc != MZK_OK) { (void)hipFree(h->d_points_mont); delete h; return rc; }
+  }
+  *out = h;
+  return MZK_OK;
+}
+
 int mzk_kzg_setup_g1(const uint64_t alpha[4], const uint64_t g1_xy[8], size_t max_d, uint64_t* powers_xy) {
   MZK_TRY(ensure_init());
   if (!alpha || !g1_xy || !powers_xy) { set_error("kzg_setup: null pointer"); return MZK_E_ARG; }

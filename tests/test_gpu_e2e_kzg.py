@@ -1,0 +1,63 @@
+"""BASELINE configs[4]: end-to-end KZG on the device -- evaluations -> iNTT -> coefficients -> setup(alpha)
+-> commit -> open(u), everything resident in HBM, verified with the trapdoor identities:
+commit == [f(alpha)] G,  y == f(u),  w == [(f(alpha) - y) / (alpha - u)] G."""
+import ctypes
+import numpy as np
+import pytest
+import orc
+from orc import FR, P_FR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("lg", [10, 16, 18])
+def test_end_to_end_device_resident(lg):
+    import torch
+    import myzkp_amd as mz
+    mz.init(0)
+    L = mz.lib()
+    dev = torch.device("cuda", 0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    n = 1 << lg
+
+    def ok(rc):
+        assert rc == 0, L.mzk_last_error().decode()
+
+    def dp(t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    evals = torch.empty(n * 4, dtype=torch.int64, device=dev)
+    coef = torch.empty(n * 4, dtype=torch.int64, device=dev)
+    srs_pts = torch.empty(n * 8, dtype=torch.int64, device=dev)
+    out = torch.zeros(8 + 4 + 8, dtype=torch.int64, device=dev)
+    ok(L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(77 + lg), ctypes.c_size_t(n), dp(evals), st))
+    root = mz.to_limbs([mz.root_of_unity(mz.FIELD_FR, lg)], 4)
+    ok(L.mzk_ntt_dev(mz.FIELD_FR, root.ctypes.data_as(ctypes.c_void_p), dp(evals), dp(coef), ctypes.c_size_t(n), 1, st))
+    alpha = orc.from_limbs(orc.synth_vector(FR, 900 + lg, 1))[0]
+    u = orc.from_limbs(orc.synth_vector(FR, 901 + lg, 1))[0]
+    a_l, u_l, g_l = mz.to_limbs([alpha], 4), mz.to_limbs([u], 4), mz.points_to_array([(1, 2)])
+    ok(L.mzk_kzg_setup_g1_dev(a_l.ctypes.data_as(ctypes.c_void_p), g_l.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n - 1), dp(srs_pts), st))
+    h = ctypes.c_void_p()
+    ok(L.mzk_srs_from_device(dp(srs_pts), ctypes.c_size_t(n), ctypes.byref(h), st))
+    ok(L.mzk_kzg_commit_srs_dev(h, dp(coef), ctypes.c_size_t(n), dp(out), 0, st))
+    ok(L.mzk_kzg_open_srs_dev(h, dp(coef), ctypes.c_size_t(n), u_l.ctypes.data_as(ctypes.c_void_p),
+                              ctypes.c_void_p(out.data_ptr() + 64), ctypes.c_void_p(out.data_ptr() + 96), st))
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().view(np.uint64)
+    commit = mz.array_to_points(o[:8])[0]
+    y = mz.from_limbs(o[8:12].reshape(1, 4))[0]
+    w = mz.array_to_points(o[12:20])[0]
+    # CPU side: coefficients via the oracle's iNTT, then the trapdoor identities
+    ev_cpu = orc.synth_vector(FR, 77 + lg, n)
+    rc, coef_cpu = orc.ntt_fast(FR, mz.from_limbs(root)[0], ev_cpu, inverse=True)
+    assert rc == 0 and np.array_equal(coef_cpu.view(np.int64).reshape(-1), coef.cpu().numpy())
+    fa = orc.poly_eval(FR, coef_cpu, alpha)
+    assert commit == orc.ec_mul(0, (1, 2), fa)
+    assert y == orc.poly_eval(FR, coef_cpu, u)
+    qa = (fa - y) * pow(alpha - u, -1, P_FR) % P_FR
+    assert w == orc.ec_mul(0, (1, 2), qa)
+    # and the SRS itself at a few indices
+    pts = srs_pts.cpu().numpy().view(np.uint64).reshape(-1, 8)
+    for i in (0, 1, n // 2, n - 1):
+        assert orc.arr_to_pts(pts[i:i + 1])[0] == orc.ec_mul(0, (1, 2), pow(alpha, i, P_FR))
+    L.mzk_srs_free(h)
