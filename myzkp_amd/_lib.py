@@ -44,6 +44,13 @@ def lib():
         if not os.path.exists(SO):
             raise ImportError("myzkp_amd/libmzk_hip.so is missing: run `python -m myzkp_amd.build` "
                               "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  Two HIP runtimes in one process
+        # cannot both own the GPU, and whichever is loaded first wins the SONAME: load torch's first (when torch
+        # is installed) so that this library binds to the same runtime and device tensors can be shared.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         _lib = ctypes.CDLL(SO)
         _lib.mzk_last_error.restype = ctypes.c_char_p
     return _lib

@@ -429,7 +429,7 @@ __global__ void k_window_combine(const u32* __restrict__ wsum, int nwin, int c, 
   } else {
     u32 wds[16];
     Affine af;
-    if (xyzz_to_affine(tot, &af)) affine_store_plain(af, wds);
+    if (xyzz_to_affine<true>(tot, &af)) affine_store_plain(af, wds);
     else for (int i = 0; i < 16; i++) wds[i] = 0;
     for (int i = 0; i < 16; i++) out[i] = wds[i];
   }
@@ -441,7 +441,7 @@ __global__ void k_fold_partials(const u32* __restrict__ partials, int count, u32
   for (int i = 0; i < count; i++) tot = xyzz_add(tot, xyzz_gload(partials, i));
   u32 wds[16];
   Affine af;
-  if (xyzz_to_affine(tot, &af)) affine_store_plain(af, wds);
+  if (xyzz_to_affine<true>(tot, &af)) affine_store_plain(af, wds);
   else for (int i = 0; i < 16; i++) wds[i] = 0;
   for (int i = 0; i < 16; i++) out[i] = wds[i];
 }

@@ -50,8 +50,11 @@ def test_field_ops_against_python(hc):
             assert fop(hc, fid, 5, a, b) == (-a) % p
             assert fop(hc, fid, 6, a, b) == pow(2 * (a + b) - b, 2, p)
             assert fop(hc, fid, 7, a, b) == a * b % p
+            if i < 40:
+                assert fop(hc, fid, 4, a, b) == (pow(a, -1, p) if a else 0)          # binary extended Euclid
+                assert fop(hc, fid, 9, a, b) == (pow(2 * a, -1, p) if a else 0)      # ... of a lazily reduced input
             if i < 12:
-                assert fop(hc, fid, 4, a, b) == (pow(a, -1, p) if a else 0)
+                assert fop(hc, fid, 8, a, b) == (pow(a, -1, p) if a else 0)          # Fermat ladder
                 assert fop(hc, fid, 0, a, b) == orc.field_op("mul", fid, a, b)
 
 
