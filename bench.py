@@ -117,6 +117,21 @@ def main():
         recs = sharded.all_gather_partials(partial)
         check(L.mzk_g1_fold_partials_dev(dptr(recs), ctypes.c_int(recs.shape[0]), dptr(result_srs), stream))
 
+    # M128 (the STARK field): forward NTT of 2^log2n elements, and the low-degree extension
+    # fast_coset_evaluate of a degree-2^(log2n-2) polynomial onto a 2^log2n coset (blow-up 4)
+    m_in = torch.empty(n * 2, dtype=torch.int64, device=dev)
+    m_out = torch.empty(n * 2, dtype=torch.int64, device=dev)
+    check(L.mzk_synth_field_dev(mz.FIELD_M128, ctypes.c_uint64(SEED + 199 + rank), ctypes.c_size_t(n), dptr(m_in), stream))
+    m_root = mz.to_limbs([mz.root_of_unity(mz.FIELD_M128, args.log2n)], 2)
+    m_off = mz.to_limbs([85408008396924667383611388730472331217], 2)   # fast_stark.rs:573-616: offset = generator
+
+    def ntt_m128_step():
+        check(L.mzk_ntt_dev(mz.FIELD_M128, m_root.ctypes.data_as(ctypes.c_void_p), dptr(m_in), dptr(m_out), ctypes.c_size_t(n), 0, stream))
+
+    def lde_m128_step():
+        check(L.mzk_coset_lde_dev(mz.FIELD_M128, dptr(m_in), ctypes.c_size_t(n // 4), m_off.ctypes.data_as(ctypes.c_void_p),
+                                  m_root.ctypes.data_as(ctypes.c_void_p), dptr(m_out), ctypes.c_size_t(n), stream))
+
     def ntt_step():
         check(L.mzk_ntt_dev(mz.FIELD_FR, root.ctypes.data_as(ctypes.c_void_p), dptr(ntt_in), dptr(ntt_out), ctypes.c_size_t(n), 0, stream))
 
@@ -160,7 +175,26 @@ def main():
     ok = rc == 0 and np.array_equal(want_ntt.view(np.int64).reshape(-1), ntt_out.cpu().numpy())
     assert ok, "rank %d: NTT mismatch vs CPU oracle" % rank
     parity["ntt_bit_exact_vs_cpu"] = bool(ok)
-    del s_cpu, p_cpu, v_cpu, want_ntt
+    lde_m128_step()
+    torch.cuda.synchronize()
+    c_cpu = orc.synth_vector(orc.M128, SEED + 199 + rank, n // 4, threads)
+    off = 85408008396924667383611388730472331217
+    acc, scaled = 1, []
+    for x in orc.from_limbs(c_cpu[:4096]):
+        scaled.append(x * acc % orc.P_M128); acc = acc * off % orc.P_M128
+    # full-size check: scale on the CPU with a running power, then the oracle's iterative NTT
+    sc_all = np.zeros((n, 2), dtype=np.uint64)
+    vals = orc.from_limbs(c_cpu)
+    acc = 1
+    for i, x in enumerate(vals):
+        vals[i] = x * acc % orc.P_M128
+        acc = acc * off % orc.P_M128
+    sc_all[: n // 4] = orc.to_limbs(vals, 2)
+    rc, want_lde = orc.ntt_fast(orc.M128, mz.from_limbs(m_root)[0], sc_all, threads=threads)
+    ok_lde = rc == 0 and np.array_equal(want_lde.view(np.int64).reshape(-1), m_out.cpu().numpy())
+    assert ok_lde, "rank %d: M128 coset LDE mismatch vs CPU oracle" % rank
+    parity["m128_coset_lde_bit_exact_vs_cpu"] = bool(ok_lde)
+    del s_cpu, p_cpu, v_cpu, want_ntt, c_cpu, sc_all, want_lde, vals
 
     # ------------------------------------------------------------------ timed regions
     def timed(step, K, W):
@@ -192,6 +226,8 @@ def main():
     msm_dt, msm_ph = timed(msm_step, K, W)
     srs_dt, srs_ph = timed(srs_step, K, W)
     ntt_dt, ntt_ph = timed(ntt_step, K, W)
+    nttm_dt, nttm_ph = timed(ntt_m128_step, K, W)
+    lde_dt, lde_ph = timed(lde_m128_step, K, W)
 
     msm_ms = msm_dt / K * 1e3
     ntt_ms = ntt_dt / K * 1e3
@@ -242,6 +278,11 @@ def main():
         "ntt": {"metric": "NTT elems/sec", "value": ntt_rate, "unit": "elems/s", "ms_per_step": ntt_ms, "field": "BN254 Fr",
                 "log2n": args.log2n, "multi_gpu": "replicas only (one independent transform per GPU)", "roofline": ntt_roof,
                 "phases": ntt_ph},
+        "ntt_m128": {"metric": "NTT elems/sec", "value": world * n / (nttm_dt / K), "unit": "elems/s", "ms_per_step": nttm_dt / K * 1e3,
+                     "field": "M128 = 1 + 407*2^119 (fri.rs:408)", "log2n": args.log2n, "phases": nttm_ph,
+                     "roofline": dict(hbm_roofline(32.0 * n, sum(v["avg_ms"] for k, v in nttm_ph.items() if k.startswith("ntt_pass"))), kernel="k_ntt_strided + k_ntt_last (whole transform)", algorithmic_bytes_per_launch=32 * n)},
+        "coset_lde_m128": {"metric": "LDE output elems/sec (fast_coset_evaluate, ntt.rs:254-269; blow-up 4)", "value": world * n / (lde_dt / K), "unit": "elems/s",
+                           "ms_per_step": lde_dt / K * 1e3, "n_coef": n // 4, "order": n, "phases": lde_ph},
         "alu_roofline": alu,
         "parity": parity,
     }
