@@ -87,6 +87,24 @@ int mzk_kzg_setup_g1(const uint64_t alpha[4], const uint64_t g1_xy[8], size_t ma
 int mzk_kzg_open(const uint64_t* coef, size_t n, const uint64_t u[4], const uint64_t* powers_xy,
                  uint64_t y[4], uint64_t w_xy[8]);
 
+/* ---- "next" rows of the path -------------------------------------------------------- */
+/* batch_open_kzg (kzg.rs:74-88): ys[i] = f(us[i]); w = MSM((f - I)/prod(X - us[i]), powers) where I
+ * interpolates (us, ys).  The us must be distinct (the reference's interpolate divides by their
+ * differences).  ys: k*4 limbs out. */
+int mzk_kzg_batch_open(const uint64_t* coef, size_t n, const uint64_t* us, size_t k, const uint64_t* powers_xy,
+                       uint64_t* ys, uint64_t w_xy[8]);
+/* prove_degree_bound (kzg.rs:121-134): MSM(f * X^(max_d - d), powers), max_d = n_powers - 1.
+ * d > max_d (usize underflow) or a product longer than the SRS (index panic) -> MZK_E_LENGTH. */
+int mzk_kzg_prove_degree_bound(const uint64_t* coef, size_t n, const uint64_t* powers_xy, size_t n_powers,
+                               size_t d, uint64_t out_xy[8]);
+/* FRI commit-loop split-and-fold (zkstark/fri.rs:182-193):
+ * out[i] = 2^-1 ((1 + alpha/(offset omega^i)) c[i] + (1 - alpha/(offset omega^i)) c[n/2 + i]), i < n/2,
+ * sanitized.  offset must be non-zero and omega a root of order n (as FRI::commit maintains). */
+int mzk_fri_fold(int field_id, const uint64_t* codeword, size_t n, const uint64_t* alpha, const uint64_t* offset,
+                 const uint64_t* omega, uint64_t* out);
+int mzk_fri_fold_dev(int field_id, const void* d_codeword, size_t n, const uint64_t* alpha_host,
+                     const uint64_t* offset_host, const uint64_t* omega_host, void* d_out, void* stream);
+
 /* Device-resident SRS for repeated commits against one PublicKeyKZG.powers_1 (kzg.rs:8-11). */
 typedef struct mzk_srs mzk_srs;
 int mzk_srs_upload(const uint64_t* powers_xy, size_t n, mzk_srs** out);

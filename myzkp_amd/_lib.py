@@ -199,6 +199,39 @@ def kzg_open(coef, u, powers):
     return from_limbs(y)[0], array_to_points(w)[0]
 
 
+def kzg_batch_open(coef, us, powers):
+    """batch_open_kzg (algebra/kzg.rs:74-88) -> (ys, w)."""
+    c = np.ascontiguousarray(coef, dtype=np.uint64).reshape(-1, 4)
+    p = np.ascontiguousarray(powers, dtype=np.uint64).reshape(-1, 8)
+    u = to_limbs(list(us), 4)
+    k = u.shape[0]
+    nq = max(c.shape[0] - k, 0)
+    if p.shape[0] < nq:
+        raise MzkError(-5, "index out of bounds: the len is %d but the index is %d" % (p.shape[0], p.shape[0]))
+    ys = np.zeros((max(k, 1), 4), dtype=np.uint64)
+    w = np.zeros((1, 8), dtype=np.uint64)
+    _check(lib().mzk_kzg_batch_open(_p(c), ctypes.c_size_t(c.shape[0]), _p(u), ctypes.c_size_t(k), _p(p), _p(ys), _p(w)))
+    return from_limbs(ys[:k]), array_to_points(w)[0]
+
+
+def kzg_prove_degree_bound(coef, powers, d):
+    """prove_degree_bound (algebra/kzg.rs:121-134)."""
+    c = np.ascontiguousarray(coef, dtype=np.uint64).reshape(-1, 4)
+    p = np.ascontiguousarray(powers, dtype=np.uint64).reshape(-1, 8)
+    out = np.zeros((1, 8), dtype=np.uint64)
+    _check(lib().mzk_kzg_prove_degree_bound(_p(c), ctypes.c_size_t(c.shape[0]), _p(p), ctypes.c_size_t(p.shape[0]), ctypes.c_size_t(d), _p(out)))
+    return array_to_points(out)[0]
+
+
+def fri_fold(fid, codeword, alpha, offset, omega):
+    """FRI split-and-fold (zkstark/fri.rs:182-193)."""
+    c = _arr(fid, codeword)
+    out = np.zeros((max(c.shape[0] // 2, 1), LIMBS[fid]), dtype=np.uint64)
+    a, o, w = _one(fid, alpha), _one(fid, offset), _one(fid, omega)
+    _check(lib().mzk_fri_fold(fid, _p(c), ctypes.c_size_t(c.shape[0]), _p(a), _p(o), _p(w), _p(out)))
+    return out[:c.shape[0] // 2]
+
+
 class Srs:
     """Device-resident PublicKeyKZG.powers_1 (algebra/kzg.rs:8-11) for repeated commits."""
 

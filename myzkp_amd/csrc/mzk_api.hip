@@ -145,6 +145,23 @@ void h_powmod_u64(const HostField* f, uint64_t* r, const uint64_t* a, uint64_t e
   }
   for (int i = 0; i < f->nl; i++) r[i] = res[i];
 }
+void h_invmod(const HostField* f, uint64_t* r, const uint64_t* a) {
+  uint64_t e[4] = {0, 0, 0, 0}, res[4] = {1, 0, 0, 0}, base[4] = {0, 0, 0, 0};
+  for (int i = 0; i < f->nl; i++) { e[i] = f->p[i]; base[i] = a[i]; }
+  {  // e = p - 2 with borrow propagation (M128's low limb is 1)
+    uint64_t borrow = 2;
+    for (int i = 0; i < f->nl && borrow; i++) {
+      const uint64_t old = e[i];
+      e[i] = old - borrow;
+      borrow = (old < borrow) ? 1 : 0;
+    }
+  }
+  for (int bit = 0; bit < 64 * f->nl; bit++) {
+    if ((e[bit / 64] >> (bit % 64)) & 1) h_mulmod(f, res, res, base);
+    h_mulmod(f, base, base, base);
+  }
+  for (int i = 0; i < f->nl; i++) r[i] = res[i];
+}
 // n = 2^k divides p - 1:  n * ((p-1)/n) = -1 (mod p)  =>  n^-1 = p - (p-1)/n
 void h_ninv_pow2(const HostField* f, unsigned k, uint64_t* out) {
   uint64_t q[4] = {0, 0, 0, 0};
@@ -530,6 +547,59 @@ int mzk_srs_from_device(const void* d_powers_xy, size_t n, mzk_srs** out, void* 
   }
   *out = h;
   return MZK_OK;
+}
+
+int mzk_fri_fold_dev(int field_id, const void* d_codeword, size_t n, const uint64_t* alpha_host, const uint64_t* offset_host,
+                     const uint64_t* omega_host, void* d_out, void* stream) {
+  MZK_TRY(ensure_init());
+  return fri_fold_dev_impl(field_id, d_codeword, n, alpha_host, offset_host, omega_host, d_out, (hipStream_t)stream);
+}
+int mzk_fri_fold(int field_id, const uint64_t* codeword, size_t n, const uint64_t* alpha, const uint64_t* offset,
+                 const uint64_t* omega, uint64_t* out) {
+  MZK_TRY(ensure_init());
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fri_fold: bad field id %d", field_id); return MZK_E_ARG; }
+  if (n / 2 == 0) return MZK_OK;
+  if (!codeword || !out) { set_error("fri_fold: null pointer"); return MZK_E_ARG; }
+  hipStream_t s = g_ctx.stream;
+  const size_t esz = field_bytes(field_id);
+  void *d_in, *d_out;
+  MZK_TRY(stage_in(WS_NTT_IO_A, codeword, n * esz, &d_in, s));
+  MZK_TRY(ws_get(WS_NTT_IO_B, (n / 2) * esz, &d_out));
+  MZK_TRY(fri_fold_dev_impl(field_id, d_in, n, alpha, offset, omega, d_out, s));
+  MZK_HIP(hipMemcpyAsync(out, d_out, (n / 2) * esz, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  return MZK_OK;
+}
+
+int mzk_kzg_batch_open(const uint64_t* coef, size_t n, const uint64_t* us, size_t k, const uint64_t* powers_xy, uint64_t* ys,
+                       uint64_t w_xy[8]) {
+  MZK_TRY(ensure_init());
+  if (!w_xy || (!coef && n) || ((!us || !ys) && k) || (!powers_xy && n > k)) { set_error("batch_open: null pointer"); return MZK_E_ARG; }
+  hipStream_t s = g_ctx.stream;
+  const size_t nq = n > k ? n - k : 0;
+  void *d_c, *d_p, *d_o;
+  MZK_TRY(stage_in(WS_MSM_SCALARS, coef, n * 32, &d_c, s));
+  MZK_TRY(stage_in(WS_NTT_IO_A, powers_xy, nq * 64, &d_p, s));
+  MZK_TRY(ws_get(WS_NTT_IO_B, 64 + k * 32 + 64, &d_o));
+  MZK_TRY(kzg_batch_open_dev(d_c, n, us, k, d_p, MSM_PTS_PLAIN, 0, (char*)d_o + 64, d_o, s));
+  std::vector<uint64_t> tmp(8 + 4 * k + 8);
+  MZK_HIP(hipMemcpyAsync(tmp.data(), d_o, 64 + k * 32, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  memcpy(w_xy, tmp.data(), 64);
+  if (k) memcpy(ys, tmp.data() + 8, k * 32);
+  return MZK_OK;
+}
+
+int mzk_kzg_prove_degree_bound(const uint64_t* coef, size_t n, const uint64_t* powers_xy, size_t n_powers, size_t d, uint64_t out_xy[8]) {
+  MZK_TRY(ensure_init());
+  if (!out_xy || (!coef && n) || (!powers_xy && n_powers)) { set_error("degree_bound: null pointer"); return MZK_E_ARG; }
+  if (n_powers == 0 || d > n_powers - 1) { set_error("attempt to subtract with overflow (max_d - d)"); return MZK_E_LENGTH; }
+  const size_t shift = n_powers - 1 - d;
+  const size_t tl = trimmed_len(coef, n, 4);   // f * q is trimmed (polynomial.rs:313-315)
+  if (tl == 0) { memset(out_xy, 0, 64); return MZK_OK; }
+  if (shift + tl > n_powers) { set_error("index out of bounds: the len is %zu but the index is %zu", n_powers, n_powers); return MZK_E_LENGTH; }
+  // MSM(f * X^shift, powers) = MSM(f, powers[shift..])
+  return mzk_msm_g1_bn254(coef, powers_xy + 8 * shift, tl, out_xy);
 }
 
 int mzk_kzg_setup_g1(const uint64_t alpha[4], const uint64_t g1_xy[8], size_t max_d, uint64_t* powers_xy) {

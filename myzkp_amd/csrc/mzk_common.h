@@ -62,6 +62,7 @@ const HostField* host_field(int fid);
 bool h_is_canonical(const HostField* f, const uint64_t* a);
 void h_mulmod(const HostField* f, uint64_t* r, const uint64_t* a, const uint64_t* b);
 void h_powmod_u64(const HostField* f, uint64_t* r, const uint64_t* a, uint64_t e);
+void h_invmod(const HostField* f, uint64_t* r, const uint64_t* a);   // a^(p-2) on the host (parameters only)
 void h_ninv_pow2(const HostField* f, unsigned log2n, uint64_t* out);  // (2^log2n)^-1 mod p, needs 2^log2n | p-1
 bool h_is_one(const HostField* f, const uint64_t* a);
 
@@ -76,6 +77,10 @@ int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_
                        const uint64_t* generator_host, void* d_out, size_t order, hipStream_t s);
 int pointwise_mul_dev(int fid, const void* d_a, const void* d_b, void* d_out, size_t n, hipStream_t s);
 void ntt_release_plans();
+int fri_fold_dev_impl(int fid, const void* d_cw, size_t n, const uint64_t* alpha, const uint64_t* offset, const uint64_t* omega,
+                      void* d_out, hipStream_t s);
+int kzg_batch_open_dev(const void* d_coef, size_t n, const uint64_t* us_host, size_t k, const void* d_points, int point_kind,
+                       size_t table_stride, void* d_ys, void* d_w_xy, hipStream_t s);
 
 enum { MSM_PTS_PLAIN = 0, MSM_PTS_MONT = 1, MSM_PTS_TABLES = 2 };
 constexpr int MSM_SRS_WINDOWS = 16;   // 254 / 16 + 1

@@ -153,6 +153,88 @@ __global__ __launch_bounds__(64) void k_open_chunk_fill(const u32* __restrict__ 
   }
 }
 
+// One synthetic division of the level-0 array `c` (n elements) by (X - u): fills b (n elements) with
+// b_i = c_i + u b_{i+1}.  Scratch: hbuf / bup hold the upper levels.
+static int suffix_horner(const u32* c, size_t n, const uint64_t* u_host, u32* b, u32* hbuf, u32* bup, hipStream_t s) {
+  const HostField* fr = host_field(MZK_FIELD_FR);
+  size_t lens[8];
+  int nlev = 0;
+  lens[0] = n;
+  while (lens[nlev] > OPEN_K) { lens[nlev + 1] = (lens[nlev] + OPEN_K - 1) >> OPEN_K_LOG; nlev++; }
+  Words8k um[8];
+  {
+    uint64_t ul[4] = {u_host[0], u_host[1], u_host[2], u_host[3]};
+    uint64_t two[4] = {2, 0, 0, 0}, rmod[4], t[4];
+    h_powmod_u64(fr, rmod, two, 261);
+    for (int l = 0; l <= nlev; l++) {
+      h_mulmod(fr, t, ul, rmod);
+      for (int i = 0; i < 4; i++) { um[l].w[2 * i] = (u32)t[i]; um[l].w[2 * i + 1] = (u32)(t[i] >> 32); }
+      h_powmod_u64(fr, ul, ul, OPEN_K);
+    }
+  }
+  const u32* level_in[8];
+  u32* level_b[8];
+  level_in[0] = c;
+  level_b[0] = b;
+  size_t off = 0;
+  for (int l = 1; l <= nlev; l++) {
+    level_in[l] = hbuf + off * 8;
+    level_b[l] = bup + off * 8;
+    off += lens[l];
+  }
+  for (int l = 0; l < nlev; l++) {
+    const size_t chunks = lens[l + 1];
+    hipLaunchKernelGGL(k_open_chunk_eval, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, s, level_in[l], lens[l], um[l], (u32*)level_in[l + 1]);
+  }
+  for (int l = nlev; l >= 0; l--) {
+    const size_t chunks = (lens[l] + OPEN_K - 1) >> OPEN_K_LOG;
+    const u32* carry = (l == nlev) ? nullptr : level_b[l + 1];
+    hipLaunchKernelGGL(k_open_chunk_fill, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, s, level_in[l], lens[l], um[l], carry,
+                       (l == nlev) ? (size_t)0 : lens[l + 1], level_b[l]);
+  }
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+
+// batch_open_kzg (kzg.rs:74-88).  y_i = f(u_i) is b_0 of the synthetic division of f by (X - u_i).  The
+// quotient of f by prod (X - u_i) -- which equals (f - I)/Z because I = f mod Z -- is k successive synthetic
+// divisions (each drops the remainder b_0).  d_ys: k * 8 words, d_w_xy: 16 words.
+int kzg_batch_open_dev(const void* d_coef, size_t n, const uint64_t* us_host, size_t k, const void* d_points, int point_kind,
+                       size_t table_stride, void* d_ys, void* d_w_xy, hipStream_t s) {
+  if (!d_w_xy || (!d_coef && n) || ((!us_host || !d_ys) && k)) { set_error("batch_open: null pointer"); return MZK_E_ARG; }
+  const HostField* fr = host_field(MZK_FIELD_FR);
+  for (size_t i = 0; i < k; i++) if (!h_is_canonical(fr, us_host + 4 * i)) { set_error("batch_open: u not canonical"); return MZK_E_RANGE; }
+  if (n == 0) {  // zero polynomial: every y = 0, quotient empty
+    if (k) MZK_HIP(hipMemsetAsync(d_ys, 0, k * 32, s));
+    MZK_HIP(hipMemsetAsync(d_w_xy, 0, 64, s));
+    return MZK_OK;
+  }
+  size_t total_up = 0;
+  for (size_t l = (n + OPEN_K - 1) >> OPEN_K_LOG; ; l = (l + OPEN_K - 1) >> OPEN_K_LOG) { total_up += l; if (l <= 1) break; }
+  u32 *bA, *bB, *hbuf, *bup;
+  MZK_TRY(ws_get(WS_MISC_A, n * 32, (void**)&bA));
+  MZK_TRY(ws_get(WS_MISC_D, n * 32, (void**)&bB));
+  MZK_TRY(ws_get(WS_MISC_B, (total_up + 2) * 32, (void**)&hbuf));
+  MZK_TRY(ws_get(WS_MISC_C, (total_up + 2) * 32, (void**)&bup));
+  // evaluations of the ORIGINAL f
+  for (size_t i = 0; i < k; i++) {
+    MZK_TRY(suffix_horner((const u32*)d_coef, n, us_host + 4 * i, bA, hbuf, bup, s));
+    MZK_HIP(hipMemcpyAsync((char*)d_ys + 32 * i, bA, 32, hipMemcpyDeviceToDevice, s));
+  }
+  // successive quotients
+  const u32* cur = (const u32*)d_coef;
+  size_t len = n;
+  u32* dst = bA;
+  for (size_t i = 0; i < k && len > 0; i++) {
+    MZK_TRY(suffix_horner(cur, len, us_host + 4 * i, dst, hbuf, bup, s));
+    cur = dst + 8;          // q_j = b_{j+1}
+    len -= 1;
+    dst = (dst == bA) ? bB : bA;
+  }
+  if (k > n) len = 0;
+  return msm_dev_impl(cur, d_points, len, point_kind, table_stride, d_w_xy, false, s);
+}
+
 // d_y: 8 words; d_w_xy: 16 words.
 int kzg_open_dev(const void* d_coef, size_t n, const uint64_t* u_host, const void* d_points, int point_kind, size_t table_stride,
                  void* d_y, void* d_w_xy, hipStream_t s) {

@@ -759,6 +759,55 @@ int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_
   return ntt_dev_impl(fid, generator_host, scaled, d_out, order, 0, nullptr, s);
 }
 
+// FRI split-and-fold (zkstark/fri.rs:182-193).  With q_i = alpha / (offset omega^i):
+//   out[i] = 2^-1 ((1 + q_i) a + (1 - q_i) b) = 2^-1 (a + b) + r_i (a - b),   r_i = 2^-1 alpha offset^-1 omega^-i.
+// r_0 and omega^-1 are host parameters (Montgomery form); each lane walks 16 consecutive i.
+template <class P>
+__global__ void k_fri_fold(const u32* __restrict__ cw, size_t h, Words8 r0_mont, Words8 winv_mont, Words8 half_mont,
+                           u32* __restrict__ out) {
+  const size_t chunk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i0 = chunk * GEN_CHUNK;
+  if (i0 >= h) return;
+  const Fe<P> winv = fe_unpack<P>(winv_mont.w), half = fe_unpack<P>(half_mont.w);
+  Fe<P> r = fe_mul<P>(fe_unpack<P>(r0_mont.w), fe_pow_u64<P>(winv, i0));   // r_{i0}, Montgomery form
+  for (int t = 0; t < GEN_CHUNK && i0 + t < h; t++) {
+    const Fe<P> a = gload<P>(cw, i0 + t), b = gload<P>(cw, h + i0 + t);     // canonical, plain domain
+    const Fe<P> sum = fe_add<P>(a, b);                                       // < 2p, limbs < 2^30
+    const Fe<P> dif = fe_carry<P>(fe_sub<P, 4>(a, b));                       // a - b + 4p
+    const Fe<P> o = fe_add<P>(fe_mul<P>(sum, half), fe_mul<P>(dif, r));      // plain * Montgomery constant = plain
+    gstore<P>(out, i0 + t, fe_reduce<P>(o));                                 // .sanitize()
+    r = fe_mul<P>(r, winv);
+  }
+}
+int fri_fold_dev_impl(int fid, const void* d_cw, size_t n, const uint64_t* alpha, const uint64_t* offset, const uint64_t* omega,
+                      void* d_out, hipStream_t s) {
+  if (fid != MZK_FIELD_FR && fid != MZK_FIELD_M128) { set_error("fri_fold: bad field id %d", fid); return MZK_E_ARG; }
+  const size_t h = n / 2;
+  if (h == 0) return MZK_OK;
+  if (!d_cw || !d_out || !alpha || !offset || !omega) { set_error("fri_fold: null pointer"); return MZK_E_ARG; }
+  const HostField* hf = host_field(fid);
+  if (!h_is_canonical(hf, alpha) || !h_is_canonical(hf, offset) || !h_is_canonical(hf, omega)) { set_error("fri_fold: parameter not canonical"); return MZK_E_RANGE; }
+  // host parameter math: 2^-1, offset^-1, omega^-1, all to Montgomery form (x * R mod p)
+  uint64_t two[4] = {2, 0, 0, 0}, halfv[4], oinv[4], winv[4], r0[4], rmod[4];
+  h_invmod(hf, halfv, two);
+  h_invmod(hf, oinv, offset);
+  h_invmod(hf, winv, omega);
+  h_mulmod(hf, r0, halfv, alpha);
+  h_mulmod(hf, r0, r0, oinv);
+  h_powmod_u64(hf, rmod, two, (uint64_t)(29 * (fid == MZK_FIELD_M128 ? 5 : 9)));
+  h_mulmod(hf, r0, r0, rmod); h_mulmod(hf, winv, winv, rmod); h_mulmod(hf, halfv, halfv, rmod);
+  Words8 r0w, winvw, halfw;
+  to_words(r0, hf->nl, &r0w); to_words(winv, hf->nl, &winvw); to_words(halfv, hf->nl, &halfw);
+  const size_t chunks = (h + GEN_CHUNK - 1) / GEN_CHUNK;
+  const unsigned blocks = (unsigned)((chunks + 127) / 128);
+  if (fid == MZK_FIELD_M128)
+    hipLaunchKernelGGL((k_fri_fold<M128Params>), dim3(blocks), dim3(128), 0, s, (const u32*)d_cw, h, r0w, winvw, halfw, (u32*)d_out);
+  else
+    hipLaunchKernelGGL((k_fri_fold<FrParams>), dim3(blocks), dim3(128), 0, s, (const u32*)d_cw, h, r0w, winvw, halfw, (u32*)d_out);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+
 int pointwise_mul_dev(int fid, const void* d_a, const void* d_b, void* d_out, size_t n, hipStream_t s) {
   if (n == 0) return MZK_OK;
   const unsigned blocks = (unsigned)((n + 255) / 256);

@@ -988,3 +988,149 @@ void orc_synth_g1_points(u64 seed, size_t n, u64* out_xy, int nthreads) {
     f_frommont(f, out_xy + 8 * i + 4, y);
   }
 }
+
+/* ------------------------------------------------------------------------------------------- */
+/* "Next" rows: FRI split-and-fold, batch_open_kzg, prove_degree_bound              */
+/* ------------------------------------------------------------------------------------------- */
+/* FRI commit-loop fold, zkstark/fri.rs:182-193, literally (one pow and one inversion-by-division per
+ * element, twice):  out[i] = 2^-1 * ((1 + alpha/(offset*omega^i)) * c[i] + (1 - alpha/(offset*omega^i)) * c[n/2 + i]),
+ * sanitized.  out holds n/2 elements. */
+int orc_fri_fold_ref(int fid, const u64* codeword, size_t n, const u64* alpha, const u64* offset,
+                     const u64* omega, u64* out) {
+  const fld_t* f = fld_of(fid); if (!f) return -1;
+  const int L = f->n;
+  u64 am[MAXN], om[MAXN], wm[MAXN], two[MAXN] = {2, 0, 0, 0}, twoinv[MAXN];
+  f_tomont(f, am, alpha); f_tomont(f, om, offset); f_tomont(f, wm, omega);
+  f_tomont(f, twoinv, two); f_minv(f, twoinv, twoinv);
+  const size_t h = n / 2;
+  for (size_t i = 0; i < h; i++) {
+    u64 wi[MAXN], d[MAXN], q[MAXN], lhs[MAXN], rhs[MAXN], a[MAXN], b[MAXN], t[MAXN];
+    f_mpow_u64(f, wi, wm, i);
+    f_mmul(f, d, om, wi);               /* offset * omega^i */
+    f_minv(f, d, d);
+    f_mmul(f, q, am, d);                /* alpha / (offset * omega^i) */
+    f_add(f, lhs, f->one, q);
+    f_sub(f, rhs, f->one, q);
+    f_tomont(f, a, codeword + i * L);
+    f_tomont(f, b, codeword + (h + i) * L);
+    f_mmul(f, lhs, lhs, a);
+    f_mmul(f, rhs, rhs, b);
+    f_add(f, t, lhs, rhs);
+    f_mmul(f, t, twoinv, t);
+    f_frommont(f, out + i * L, t);
+  }
+  return 0;
+}
+
+/* general long division, Polynomial::div_rem_ref polynomial.rs:371-405 (Montgomery-domain arrays).
+ * quo must hold max(la - lb + 1, 1) elements; returns trimmed quotient length; rem (la elements) is
+ * overwritten with the remainder, *rem_len its trimmed length. */
+static size_t poly_divrem_m(const fld_t* f, u64* rem, size_t la, const u64* b, size_t lb, u64* quo, size_t* rem_len) {
+  const int L = f->n;
+  la = trimmed_len(f, rem, la); lb = trimmed_len(f, b, lb);
+  if (lb == 0 || la < lb) { *rem_len = la; return 0; }
+  u64 leadinv[MAXN];
+  f_minv(f, leadinv, b + (lb - 1) * L);
+  size_t ql = la - lb + 1;
+  memset(quo, 0, 8 * L * ql);
+  size_t rl = la;
+  while (rl >= lb) {
+    u64 lead[MAXN], t[MAXN];
+    f_mmul(f, lead, rem + (rl - 1) * L, leadinv);
+    size_t dd = rl - lb;
+    memcpy(quo + dd * L, lead, 8 * L);
+    for (size_t i = 0; i < lb; i++) {
+      f_mmul(f, t, lead, b + i * L);
+      f_sub(f, rem + (dd + i) * L, rem + (dd + i) * L, t);
+    }
+    rl = trimmed_len(f, rem, rl);
+  }
+  *rem_len = rl;
+  return trimmed_len(f, quo, ql);
+}
+/* from_monomials, polynomial.rs:202-212: prod (X - x_i); out holds k+1 elements */
+static void poly_from_monomials_m(const fld_t* f, const u64* xs, size_t k, u64* out) {
+  const int L = f->n;
+  memset(out, 0, 8 * L * (k + 1));
+  memcpy(out, f->one, 8 * L);
+  size_t len = 1;
+  for (size_t i = 0; i < k; i++) {
+    /* out <- out * (X - x_i):  new[j] = old[j-1] - x_i * old[j], from the top down */
+    for (size_t j = len + 1; j-- > 0;) {
+      u64 t[MAXN], lo[MAXN];
+      memset(lo, 0, sizeof lo);
+      if (j > 0) memcpy(lo, out + (j - 1) * L, 8 * L);
+      if (j < len) { f_mmul(f, t, out + j * L, xs + i * L); f_sub(f, lo, lo, t); }
+      memcpy(out + j * L, lo, 8 * L);
+    }
+    len++;
+  }
+}
+/* batch_open_kzg, algebra/kzg.rs:74-88: ys[i] = f(us[i]); ip = Lagrange interpolant (polynomial.rs:177-200);
+ * f_u = (f - ip) / prod (X - us[i]) by long division; w = MSM(f_u, powers).  Distinct us required (as in
+ * the reference, whose interpolate divides by prod (x_j - x_i)). */
+int orc_kzg_batch_open_ref(const u64* coef, size_t n, const u64* us, size_t k, const u64* powers_xy,
+                           u64* ys_out, u64* w_xy) {
+  const fld_t* f = fld_of(FID_FR);
+  const int L = 4;
+  for (size_t i = 0; i < k; i++) orc_poly_eval(FID_FR, coef, n, us + i * L, ys_out + i * L);
+  u64* usm = malloc(8 * L * (k ? k : 1)), *ysm = malloc(8 * L * (k ? k : 1));
+  to_mont_vec(f, usm, us, k); to_mont_vec(f, ysm, ys_out, k);
+  /* numerators = from_monomials(us) */
+  u64* z = malloc(8 * L * (k + 1));
+  poly_from_monomials_m(f, usm, k, z);
+  /* ip = sum_j y_j * numerators / ((X - u_j) * prod_{i != j} (u_j - u_i)) */
+  size_t ipcap = k + 1;
+  u64* ip = calloc(ipcap, 8 * L);
+  for (size_t j = 0; j < k; j++) {
+    u64 den[MAXN];
+    memcpy(den, f->one, 8 * L);
+    for (size_t i = 0; i < k; i++) {
+      if (i == j) continue;
+      u64 t[MAXN];
+      f_sub(f, t, usm + j * L, usm + i * L);
+      f_mmul(f, den, den, t);
+    }
+    /* divisor = (X - u_j) * den = [-u_j * den, den] */
+    u64 dv[2 * MAXN];
+    f_mmul(f, dv, usm + j * L, den); f_neg(f, dv, dv);
+    memcpy(dv + L, den, 8 * L);
+    u64* num = malloc(8 * L * (k + 1)), *q = calloc(k + 1, 8 * L);
+    memcpy(num, z, 8 * L * (k + 1));
+    size_t rl, ql = poly_divrem_m(f, num, k + 1, dv, 2, q, &rl);
+    for (size_t i = 0; i < ql; i++) {
+      u64 t[MAXN];
+      f_mmul(f, t, q + i * L, ysm + j * L);
+      f_add(f, ip + i * L, ip + i * L, t);
+    }
+    free(num); free(q);
+  }
+  /* f - ip */
+  size_t fl = n > ipcap ? n : ipcap;
+  u64* fm = calloc(fl ? fl : 1, 8 * L);
+  to_mont_vec(f, fm, coef, n);
+  for (size_t i = 0; i < ipcap; i++) f_sub(f, fm + i * L, fm + i * L, ip + i * L);
+  u64* quo = calloc(fl ? fl : 1, 8 * L);
+  size_t rl, ql = poly_divrem_m(f, fm, fl, z, k + 1, quo, &rl);
+  u64* qc = malloc(8 * L * (ql ? ql : 1));
+  from_mont_vec(f, qc, quo, ql);
+  int rc = orc_msm_ref(qc, powers_xy, ql, w_xy);
+  free(usm); free(ysm); free(z); free(ip); free(fm); free(quo); free(qc);
+  return rc;
+}
+/* prove_degree_bound, kzg.rs:121-134: r = f * X^(max_d - d); MSM(r, powers).  n_powers = max_d + 1.
+ * d > max_d is the reference's usize underflow -> -5; result longer than the SRS -> index panic -> -5. */
+int orc_kzg_prove_degree_bound_ref(const u64* coef, size_t n, const u64* powers_xy, size_t n_powers, size_t d, u64* out_xy) {
+  const fld_t* f = fld_of(FID_FR);
+  if (n_powers == 0 || d > n_powers - 1) return -5;
+  const size_t shift = n_powers - 1 - d;
+  size_t tl = 0;
+  { u64* cm = malloc(32 * (n ? n : 1)); to_mont_vec(f, cm, coef, n); tl = trimmed_len(f, cm, n); free(cm); }
+  if (tl == 0) { memset(out_xy, 0, 64); return 0; }   /* zero polynomial: product is zero */
+  if (shift + tl > n_powers) return -5;
+  u64* r = calloc(shift + tl, 32);
+  memcpy(r + 4 * shift, coef, 32 * tl);
+  int rc = orc_msm_ref(r, powers_xy, shift + tl, out_xy);
+  free(r);
+  return rc;
+}

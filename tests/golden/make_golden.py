@@ -189,6 +189,64 @@ def kzg_open(coef, u, powers):  # kzg.rs:61-72 with div_rem_ref (polynomial.rs:3
     quo = trim(quo)
     return y, msm(quo, powers)
 
+def poly_divrem(a, b, p):  # polynomial.rs:371-405
+    a, b = trim(a), trim(b)
+    if not b or len(a) < len(b):
+        return [], a
+    inv = pow(b[-1], -1, p)
+    quo = [0] * (len(a) - len(b) + 1)
+    rem = list(a)
+    while len(rem) >= len(b):
+        lead = rem[-1] * inv % p
+        dd = len(rem) - len(b)
+        quo[dd] = lead
+        for i in range(len(b)):
+            rem[dd + i] = (rem[dd + i] - lead * b[i]) % p
+        rem = trim(rem)
+    return trim(quo), rem
+
+def from_monomials(xs, p):  # polynomial.rs:202-212
+    out = [1]
+    for x in xs:
+        out = poly_mul(out, [(-x) % p, 1], p)
+    return out
+
+def interpolate(xs, ys, p):  # polynomial.rs:177-200
+    num = from_monomials(xs, p)
+    res = []
+    for j in range(len(xs)):
+        den = 1
+        for i in range(len(xs)):
+            if i != j:
+                den = den * (xs[j] - xs[i]) % p
+        q, _ = poly_divrem(num, [(-xs[j]) * den % p, den], p)
+        term = [c * ys[j] % p for c in q]
+        res = [((res[i] if i < len(res) else 0) + (term[i] if i < len(term) else 0)) % p for i in range(max(len(res), len(term)))]
+    return trim(res)
+
+def kzg_batch_open(coef, us, powers):  # kzg.rs:74-88
+    ys = [poly_eval(coef, u, FR) for u in us]
+    ip = interpolate(us, ys, FR)
+    z = from_monomials(us, FR)
+    diff = [((coef[i] if i < len(coef) else 0) - (ip[i] if i < len(ip) else 0)) % FR for i in range(max(len(coef), len(ip)))]
+    q, rem = poly_divrem(diff, z, FR)
+    assert not rem
+    return ys, msm(q, powers)
+
+def kzg_degree_bound(coef, powers, d):  # kzg.rs:121-134
+    max_d = len(powers) - 1
+    r = [0] * (max_d - d) + list(coef)
+    return msm(trim(r), powers)
+
+def fri_fold(cw, alpha, offset, omega, p):  # fri.rs:182-193
+    h = len(cw) // 2
+    two_inv = pow(2, -1, p)
+    out = []
+    for i in range(h):
+        q = alpha * pow(offset * pow(omega, i, p) % p, -1, p) % p
+        out.append(two_inv * ((1 + q) * cw[i] + (1 - q) * cw[h + i]) % p)
+    return out
+
 def pt(P):
     return [0, 0] if P is INF else [P[0], P[1]]
 
@@ -360,7 +418,25 @@ def main():
     assert msm(f2, srs2) == g1_mul(G1, poly_eval(f2, alpha, FR))
     kz.append(dict(alpha=S(alpha), coef=S(f2), srs=S([pt(P) for P in srs2]), commit=S(pt(msm(f2, srs2))), u=S(u2), y=S(y2), w=S(pt(w2))))
     ec["kzg"] = kz
+    # "next" rows: batch_open_kzg and prove_degree_bound on the second SRS
+    us3 = [rng.randrange(FR) for _ in range(3)]
+    ys3, w3 = kzg_batch_open(f2, us3, srs2)
+    ys1, w1 = kzg_batch_open(f, [5, 9], srs)
+    ec["kzg_batch_open"] = [dict(coef=S(f2), srs=S([pt(P) for P in srs2]), us=S(us3), ys=S(ys3), w=S(pt(w3))),
+                            dict(coef=S(f), srs=S([pt(P) for P in srs]), us=S([5, 9]), ys=S(ys1), w=S(pt(w1)))]
+    ec["kzg_degree_bound"] = [dict(coef=S(f2[:9]), srs=S([pt(P) for P in srs2]), d=8, out=S(pt(kzg_degree_bound(f2[:9], srs2, 8)))),
+                              dict(coef=S(f2[:5]), srs=S([pt(P) for P in srs2]), d=10, out=S(pt(kzg_degree_bound(f2[:5], srs2, 10))))]
     dump("curve_vectors.json", ec)
+    # FRI split-and-fold with the STARK parameters: offset = M128 generator
+    fr_cases = []
+    for name, p, rootf, off in (("M128", M128, m128_root, M128_GEN), ("Fr", FR, fr_root, 5)):
+        for lg in (1, 3, 6, 9):
+            n = 1 << lg
+            cw = [rng.randrange(p) for _ in range(n)]
+            al = rng.randrange(p)
+            om = rootf(n)
+            fr_cases.append(dict(field=name, alpha=S(al), offset=S(off), omega=S(om), input=S(cw), output=S(fri_fold(cw, al, off, om, p))))
+    dump("fri_vectors.json", {"cases": fr_cases})
 
     # ---------------- Rescue-Prime KAT (reference-held) ----------------
     rp_src = "/root/reference/myzkp/src/modules/zkstark/rescueprime.rs"

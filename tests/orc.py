@@ -190,6 +190,28 @@ def kzg_open_ref(coef_arr, u, srs_arr):
     return from_limbs(y)[0], arr_to_pts(w)[0]
 
 
+def kzg_batch_open_ref(coef_arr, us, srs_arr):
+    k = len(us)
+    ys = np.zeros((max(k, 1), 4), dtype=np.uint64)
+    w = np.zeros((1, 8), dtype=np.uint64)
+    ua = to_limbs(list(us), 4)
+    assert lib().orc_kzg_batch_open_ref(ptr(coef_arr), ctypes.c_size_t(coef_arr.shape[0]), ptr(ua), ctypes.c_size_t(k), ptr(srs_arr), ptr(ys), ptr(w)) == 0
+    return from_limbs(ys[:k]), arr_to_pts(w)[0]
+
+
+def kzg_degree_bound_ref(coef_arr, srs_arr, d):
+    out = np.zeros((1, 8), dtype=np.uint64)
+    rc = lib().orc_kzg_prove_degree_bound_ref(ptr(coef_arr), ctypes.c_size_t(coef_arr.shape[0]), ptr(srs_arr), ctypes.c_size_t(srs_arr.shape[0]), ctypes.c_size_t(d), ptr(out))
+    return rc, arr_to_pts(out)[0]
+
+
+def fri_fold_ref(fid, cw_arr, alpha, offset, omega):
+    out = np.zeros((max(cw_arr.shape[0] // 2, 1), LIMBS[fid]), dtype=np.uint64)
+    a, o, w = one(fid, alpha), one(fid, offset), one(fid, omega)
+    assert lib().orc_fri_fold_ref(fid, ptr(cw_arr), ctypes.c_size_t(cw_arr.shape[0]), ptr(a), ptr(o), ptr(w), ptr(out)) == 0
+    return out[:cw_arr.shape[0] // 2]
+
+
 def fixed_base_batch(base, scal_arr, threads=8):
     out = np.zeros((scal_arr.shape[0], 8), dtype=np.uint64)
     b = pts_to_arr([base])
