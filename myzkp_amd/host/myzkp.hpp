@@ -211,4 +211,36 @@ inline ProofKZG open_kzg(const Polynomial<FqOrder>& f, const FqOrder& u, const P
   return pr;
 }
 
+struct BatchProofKZG { std::vector<FqOrder> ys; G1Point w; };  // kzg.rs:20-23
+using ProofDegreeBound = G1Point;                              // kzg.rs:25
+inline BatchProofKZG batch_open_kzg(const Polynomial<FqOrder>& f, const std::vector<FqOrder>& us, const PublicKeyKZG& pk) {  // kzg.rs:74-88
+  const size_t nq = f.coef.size() > us.size() ? f.coef.size() - us.size() : 0;
+  if (pk.powers_1.size() < nq)
+    throw Panic(MZK_E_LENGTH, "index out of bounds: the len is " + std::to_string(pk.powers_1.size()) + " but the index is " + std::to_string(pk.powers_1.size()));
+  auto c = to_wire(f.coef), u = to_wire(us);
+  auto p = points_to_wire(pk.powers_1);
+  std::vector<uint64_t> ys(us.size() * 4 + 4);
+  uint64_t w[8];
+  expect(mzk_kzg_batch_open(c.data(), f.coef.size(), u.data(), us.size(), p.data(), ys.data(), w));
+  BatchProofKZG pr;
+  pr.ys = from_wire<FqOrder>(ys, us.size());
+  pr.w = G1Point::from_wire(w);
+  return pr;
+}
+inline ProofDegreeBound prove_degree_bound(const Polynomial<FqOrder>& f, const PublicKeyKZG& pk, size_t d) {  // kzg.rs:121-134
+  auto c = to_wire(f.coef);
+  auto p = points_to_wire(pk.powers_1);
+  uint64_t w[8];
+  expect(mzk_kzg_prove_degree_bound(c.data(), f.coef.size(), p.data(), pk.powers_1.size(), d, w));
+  return G1Point::from_wire(w);
+}
+// one round of the split-and-fold in FRI::commit (zkstark/fri.rs:182-193)
+template <class F>
+std::vector<F> fri_split_and_fold(const std::vector<F>& codeword, const F& alpha, const F& offset, const F& omega) {
+  auto c = to_wire(codeword);
+  std::vector<uint64_t> out((codeword.size() / 2 + 1) * F().value.size());
+  expect(mzk_fri_fold(Polynomial<F>::field_id(), c.data(), codeword.size(), alpha.value.data(), offset.value.data(), omega.value.data(), out.data()));
+  return from_wire<F>(out, codeword.size() / 2);
+}
+
 }  // namespace myzkp

@@ -66,6 +66,27 @@ static void test_kzg() {
   CHECK(!(commit_kzg(f2, pk) == c));
 }
 
+static void test_batch_kzg() {   // kzg.rs:174-204 test_batch_kzg, pairing check replaced by the quotient identity
+  auto g1 = BN128::generator_g1();
+  Polynomial<FqOrder> f{{FqOrder::from_value(6), FqOrder::from_value(11), FqOrder::from_value(6), FqOrder::from_value(1)}};
+  auto pk = setup_kzg_with_alpha(g1, FqOrder::from_value(7), 3);
+  std::vector<FqOrder> us{FqOrder::from_value(5), FqOrder::from_value(9)};
+  auto proof = batch_open_kzg(f, us, pk);
+  CHECK(proof.ys.size() == 2);
+  CHECK(proof.ys[0] == FqOrder::from_value(6 * 7 * 8));
+  CHECK(proof.ys[1] == FqOrder::from_value(10 * 11 * 12));
+  // f = (X-5)(X-9)(X+20) + I(X)  =>  quotient q(X) = X + 20, q(7) = 27
+  uint64_t g[8], k[4] = {27, 0, 0, 0}, want[8];
+  g1.to_wire(g);
+  orc_ec_mul(0, g, k, 4, want);
+  CHECK(proof.w == G1Point::from_wire(want));
+  // degree bound: f has degree 3 <= 3 -> MSM(f * X^0); bound 2 does not fit the SRS
+  CHECK(prove_degree_bound(f, pk, 3) == commit_kzg(f, pk));
+  bool caught = false;
+  try { prove_degree_bound(f, pk, 2); } catch (const Panic& p) { caught = p.code == MZK_E_LENGTH; }
+  CHECK(caught);
+}
+
 static void test_g1() {
   auto g = BN128::generator_g1();
   auto mul = [&](uint64_t k) { return Polynomial<FqOrder>{{FqOrder::from_value(k)}}.eval_with_powers_on_curve({g}); };
@@ -128,6 +149,7 @@ int main() {
   expect(mzk_init(0));
   test_ntt();
   test_kzg();
+  test_batch_kzg();
   test_g1();
   test_fast_multiply();
   test_panics();
