@@ -31,6 +31,15 @@
 #else
 #define MZK_HD inline
 #endif
+// MZK_COMPACT_CODE (set by the translation unit of the single-lane MSM tail kernels): the field product
+// and the group operations become real functions instead of being inlined everywhere.  Those kernels run
+// ONE wave, so nothing hides an instruction-cache miss; with ~2 KB per inlined product their
+// straight-line code (100+ KB) cost more in instruction fetch than in arithmetic.
+#if defined(MZK_COMPACT_CODE) && defined(__HIPCC__)
+#define MZK_HEAVY __device__ __noinline__
+#else
+#define MZK_HEAVY MZK_HD
+#endif
 
 #if defined(MZK_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
 #include <assert.h>
@@ -74,7 +83,7 @@ template <class P> MZK_HD Fe<P> fe_r2() {
 // Montgomery product  a*b/R mod p  (finely integrated product scanning, one 64-bit column
 // accumulator).  Reference semantics: Ring::mul_ref, field.rs:176-179 (value * value % modulus).
 // ---------------------------------------------------------------------------------------------
-template <class P> MZK_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+template <class P> MZK_HEAVY Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
   constexpr int L = P::L;
   u32 m[L];
   Fe<P> r;
@@ -113,7 +122,7 @@ template <class P> MZK_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
 }
 
 // Montgomery square: cross products once, doubled (45 instead of 81 product terms for L = 9).
-template <class P> MZK_HD Fe<P> fe_sqr(const Fe<P>& a) {
+template <class P> MZK_HEAVY Fe<P> fe_sqr(const Fe<P>& a) {
   constexpr int L = P::L;
   u32 m[L], a2[L];
   Fe<P> r;

@@ -379,9 +379,9 @@ __global__ __launch_bounds__(128) void k_halve_step(u32* __restrict__ buckets, i
   if (id >= total) return;
   halve_op(buckets + ((size_t)blockIdx.y << lgB) * 32, lgB, t, id);
 }
+constexpr int TAIL_THREADS = 256;
 // Remaining steps t_start..lgB-1 inside one workgroup per bucket set, then the weighted sum
 // buf[0] + sum_j 2^j buf[2^j] (lane j doubles j times, LDS tree sum).  out[w] = XYZZ result of set w.
-constexpr int TAIL_THREADS = 256;
 __global__ __launch_bounds__(TAIL_THREADS) void k_reduce_tail(u32* __restrict__ buckets, int lgB, int t_start, u32* __restrict__ out) {
   __shared__ u32 sh[32 * 32];
   u32* buf = buckets + ((size_t)blockIdx.x << lgB) * 32;
@@ -412,39 +412,9 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_reduce_tail(u32* __restrict__ 
   if (lane < 32) out[(size_t)blockIdx.x * 32 + lane] = sh[lane];
 }
 
-// ---- 6. window combine ----------------------------------------------------------------------------------
-// total = sum_w 2^(c w) R_w  (Horner, c doublings per window; a single bucket set skips it), then affine
-// (one Fq inversion) or the XYZZ partial record.
-__global__ void k_window_combine(const u32* __restrict__ wsum, int nwin, int c, int out_xyzz, u32* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  Xyzz tot = xyzz_gload(wsum, nwin - 1);
-  for (int win = nwin - 2; win >= 0; win--) {
-    for (int d = 0; d < c; d++) tot = xyzz_dbl(tot);
-    tot = xyzz_add(tot, xyzz_gload(wsum, win));
-  }
-  if (out_xyzz) {
-    u32 wds[32];
-    xyzz_store(tot, wds);
-    for (int i = 0; i < 32; i++) out[i] = wds[i];
-  } else {
-    u32 wds[16];
-    Affine af;
-    if (xyzz_to_affine<true>(tot, &af)) affine_store_plain(af, wds);
-    else for (int i = 0; i < 16; i++) wds[i] = 0;
-    for (int i = 0; i < 16; i++) out[i] = wds[i];
-  }
-}
-// fold `count` XYZZ partials (multi-GPU all-gather result) into one affine point
-__global__ void k_fold_partials(const u32* __restrict__ partials, int count, u32* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  Xyzz tot = xyzz_inf();
-  for (int i = 0; i < count; i++) tot = xyzz_add(tot, xyzz_gload(partials, i));
-  u32 wds[16];
-  Affine af;
-  if (xyzz_to_affine<true>(tot, &af)) affine_store_plain(af, wds);
-  else for (int i = 0; i < 16; i++) wds[i] = 0;
-  for (int i = 0; i < 16; i++) out[i] = wds[i];
-}
+// k_window_combine / k_fold_partials live in mzk_msm_tail.hip (compact-code build).
+int launch_window_combine(const u32* wsum, int nwin, int c, int out_xyzz, u32* out, hipStream_t s);
+int launch_fold_partials(const u32* partials, int count, u32* out, hipStream_t s);
 
 // ---- host orchestration -----------------------------------------------------------------------------------
 int msm_prepare_points(const void* d_points_plain, size_t n, void* d_points_mont, hipStream_t s) {
@@ -588,7 +558,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)red_windows), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, t_start, wsum);
   prof_end(s, MZK_PH_MSM_REDUCE);
   prof_begin(s, MZK_PH_MSM_COMBINE);
-  hipLaunchKernelGGL(k_window_combine, dim3(1), dim3(64), 0, s, (const u32*)wsum, red_windows, horner_c, out_partial_xyzz ? 1 : 0, (u32*)d_out);
+  MZK_TRY(launch_window_combine((const u32*)wsum, red_windows, horner_c, out_partial_xyzz ? 1 : 0, (u32*)d_out, s));
   prof_end(s, MZK_PH_MSM_COMBINE);
   MZK_HIP(hipGetLastError());
   return MZK_OK;
@@ -596,8 +566,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
 
 int msm_fold_partials_impl(const void* d_partials, int count, void* d_out_xy, hipStream_t s) {
   if (!d_partials || !d_out_xy || count < 0) { set_error("fold_partials: bad argument"); return MZK_E_ARG; }
-  hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, s, (const u32*)d_partials, count, (u32*)d_out_xy);
-  MZK_HIP(hipGetLastError());
+  MZK_TRY(launch_fold_partials((const u32*)d_partials, count, (u32*)d_out_xy, s));
   return MZK_OK;
 }
 
