@@ -198,165 +198,6 @@ __global__ __launch_bounds__(NTHREADS) void k_ntt_last(const u32* __restrict__ i
   }
 }
 
-// =====================================================================================================
-// Register-blocked passes (used whenever the transform fills whole tiles, i.e. n >= 8 * threads).
-// Each lane keeps 8 elements in registers and runs up to 3 butterfly stages per "round" without touching
-// LDS; elements move through LDS only between rounds (2 barriers per exchange instead of 1 per stage),
-// the first round loads straight from HBM and the last round multiplies by the inter-pass twiddle and
-// stores straight to HBM.  The in-tile twiddles w_n^j sit in LDS (packed, n/2 entries).
-//
-// Which tile position a (lane, element) pair owns changes per round (the round's 3 active k-bits come
-// from the element index).  The host picks, per round, where every thread bit lands (RoundPlan.src) so
-// that (a) the c-bits (contiguous HBM runs) are the lowest lane bits and (b) the 32 lanes of an LDS
-// access group hit 32 different banks under the pos ^ (pos >> 5) swizzle.
-// =====================================================================================================
-struct RoundPlan {
-  int s0, r;                 // stages s0+1 .. s0+r of this level
-  unsigned char src[12];     // per tile-position bit: 0..2 = element bit, 8+b = thread bit b
-};
-struct PassPlan {
-  int lgn, lgc, lgt, nrounds;
-  RoundPlan rd[4];
-};
-
-template <class P, int TLOG> __device__ __forceinline__ Fe<P> rb_lds_load(const u32* lds, int pos) {
-  Fe<P> r;
-  const int ph = lds_phys(pos);
-#pragma unroll
-  for (int i = 0; i < P::L; i++) r.l[i] = lds[(i << TLOG) + ph];
-  return r;
-}
-template <class P, int TLOG> __device__ __forceinline__ void rb_lds_store(u32* lds, int pos, const Fe<P>& v) {
-  const int ph = lds_phys(pos);
-#pragma unroll
-  for (int i = 0; i < P::L; i++) lds[(i << TLOG) + ph] = v.l[i];
-}
-template <class P> __device__ __forceinline__ Fe<P> tw_lds_load(const u32* twl, int idx) {
-  u32 w[P::NW];
-  const uint4* p4 = reinterpret_cast<const uint4*>(twl + idx * P::NW);
-#pragma unroll
-  for (int q = 0; q < P::NW / 4; q++) {
-    uint4 v = p4[q];
-    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
-  }
-  return fe_unpack<P>(w);
-}
-// stages s0+1..s0+R on the 8 register elements; pos[e] = tile position of element e
-template <class P, int R>
-__device__ __forceinline__ void rb_round(Fe<P> (&x)[8], const int (&pos)[8], int s0, int lgn, int lgc, const u32* twl) {
-#pragma unroll
-  for (int i = 1; i <= R; i++) {
-    const int bit = 1 << (i - 1);
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-      if (e & bit) continue;
-      const int lo = e, hi = e | bit;
-      Fe<P> t = x[hi];
-      if (s0 + i > 1) {  // stage 1 of a level has the trivial twiddle only
-        const int k = pos[lo] >> lgc;
-        const int j = k & ((1 << (s0 + i - 1)) - 1);
-        t = fe_mul<P>(t, tw_lds_load<P>(twl, j << (lgn - s0 - i)));
-      }
-      x[hi] = fe_carry<P>(fe_sub<P, 8>(x[lo], t));
-      x[lo] = fe_carry<P>(fe_add<P>(x[lo], t));
-    }
-  }
-}
-template <int TLOG> __device__ __forceinline__ void rb_positions(const RoundPlan& rp, int tid, int (&pos)[8]) {
-  int tpos = 0;
-  int ebit[3] = {0, 0, 0};
-#pragma unroll
-  for (int p = 0; p < TLOG; p++) {
-    const int sidx = rp.src[p];
-    if (sidx >= 8) tpos |= ((tid >> (sidx - 8)) & 1) << p;
-    else ebit[sidx] = 1 << p;
-  }
-#pragma unroll
-  for (int e = 0; e < 8; e++) pos[e] = tpos | ((e & 1) ? ebit[0] : 0) | ((e & 2) ? ebit[1] : 0) | ((e & 4) ? ebit[2] : 0);
-}
-
-// LAST = false: strided in-place pass + inter-pass twiddle; LAST = true: contiguous rows, transposed
-// scatter, canonical output (optionally scaled).
-template <class P, int TLOG, bool LAST>
-__global__ __launch_bounds__(1 << (TLOG - 3)) void k_ntt_rb(const u32* __restrict__ in, u32* __restrict__ out,
-                                                            const u32* __restrict__ tw_tile, const u32* __restrict__ tw_inter,
-                                                            PassPlan pp, int lgM, LevelInfo li, int lg_rows, Words8 scale, int has_scale) {
-  extern __shared__ __attribute__((aligned(16))) u32 lds[];
-  constexpr int NT = 1 << (TLOG - 3);
-  u32* twl = lds + (P::L << TLOG);
-  const int tid = threadIdx.x;
-  const int lgn = pp.lgn, lgc = pp.lgc;
-  const int cmask = (1 << lgc) - 1;
-  // in-tile twiddle table -> LDS
-  {
-    const int words = (lgn >= 2) ? ((1 << (lgn - 1)) * P::NW) : 0;
-    for (int i = tid * 4; i < words; i += NT * 4) *reinterpret_cast<uint4*>(twl + i) = *reinterpret_cast<const uint4*>(tw_tile + i);
-  }
-  size_t base = 0, ct = 0, p0 = 0;
-  if (!LAST) {
-    const int lg_tiles = lgM - lgc;
-    const size_t o = (size_t)blockIdx.x >> lg_tiles;
-    ct = (size_t)blockIdx.x & (((size_t)1 << lg_tiles) - 1);
-    base = (o << (lgn + lgM));
-  } else {
-    p0 = (size_t)blockIdx.x << lgc;   // lgc plays the role of lg(rows per tile)
-  }
-  Fe<P> x[8];
-  int pos[8];
-  rb_positions<TLOG>(pp.rd[0], tid, pos);
-  // ---- load straight from HBM (bit-reversed k) ----
-#pragma unroll
-  for (int e = 0; e < 8; e++) {
-    const int k = pos[e] >> lgc, c = pos[e] & cmask;
-    const size_t j1 = (size_t)(__brev((unsigned)k) >> (32 - lgn));
-    size_t gidx;
-    if (!LAST) {
-      gidx = base + (j1 << lgM) + (ct << lgc) + c;
-    } else {
-      size_t rem = p0 + c, row = 0;
-      for (int i = 0; i < li.nlev - 1; i++) {
-        row = (row << li.lg[i]) | (rem & (((size_t)1 << li.lg[i]) - 1));
-        rem >>= li.lg[i];
-      }
-      gidx = (row << lgn) + j1;
-    }
-    x[e] = gload<P>(in, gidx);
-  }
-  __syncthreads();  // twiddle table visible
-  for (int rd = 0; rd < pp.nrounds; rd++) {
-    const RoundPlan& rp = pp.rd[rd];
-    if (rd > 0) {
-      // exchange through LDS: write under the previous mapping (already in pos), read under this one
-#pragma unroll
-      for (int e = 0; e < 8; e++) rb_lds_store<P, TLOG>(lds, pos[e], x[e]);
-      __syncthreads();
-      rb_positions<TLOG>(rp, tid, pos);
-#pragma unroll
-      for (int e = 0; e < 8; e++) x[e] = rb_lds_load<P, TLOG>(lds, pos[e]);
-      __syncthreads();
-    }
-    if (rp.r == 3) rb_round<P, 3>(x, pos, rp.s0, lgn, lgc, twl);
-    else if (rp.r == 2) rb_round<P, 2>(x, pos, rp.s0, lgn, lgc, twl);
-    else rb_round<P, 1>(x, pos, rp.s0, lgn, lgc, twl);
-  }
-  // ---- store straight to HBM ----
-  Fe<P> sc;
-  if (LAST && has_scale) sc = fe_unpack<P>(scale.w);
-#pragma unroll
-  for (int e = 0; e < 8; e++) {
-    const int k = pos[e] >> lgc, c = pos[e] & cmask;
-    if (!LAST) {
-      const size_t off = ((size_t)k << lgM) + (ct << lgc) + c;
-      Fe<P> w = gload<P>(tw_inter, off);
-      gstore<P>(out, base + off, fe_fit<P>(fe_mul<P>(x[e], w)));
-    } else {
-      Fe<P> v = x[e];
-      if (has_scale) v = fe_mul<P>(v, sc);
-      gstore<P>(out, p0 + c + ((size_t)k << lg_rows), fe_reduce<P>(v));
-    }
-  }
-}
-
 // ---- table generation ------------------------------------------------------------------------------
 constexpr int GEN_CHUNK = 16;
 // out[j] = g^j (Montgomery, canonical), j < count, g = root^emul
@@ -452,32 +293,8 @@ void ntt_release_plans() {
   g_plans.clear();
 }
 
-// Register-blocked tile size (log2 elements per workgroup): 10 -> 128 threads, 11 -> 256, 12 -> 512.
-static int rb_tile_log() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MZK_NTT_TLOG");
-    v = e ? atoi(e) : 12;
-    if (v < 10 || v > 12) v = 12;
-  }
-  return v;
-}
-static bool use_rb(unsigned logn) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("MZK_NTT_RB"); on = e ? atoi(e) : 0; }   // measured slower than the per-stage LDS kernels on MI355X: off by default
-  return on && (int)logn >= rb_tile_log();
-}
-
 static LevelInfo choose_levels(unsigned logn) {
   LevelInfo li{};
-  if (use_rb(logn)) {
-    const int maxl = rb_tile_log() - 2;   // >= 4 contiguous columns per tile
-    int k = ((int)logn + maxl - 1) / maxl;
-    li.nlev = k;
-    int base = (int)logn / k, extra = (int)logn % k;
-    for (int i = 0; i < k; i++) li.lg[i] = base + (i < extra ? 1 : 0);
-    return li;
-  }
   if (logn <= TILE_LOG) {
     li.nlev = 1;
     li.lg[0] = (int)logn;
@@ -601,83 +418,11 @@ static int get_plan(int fid, unsigned logn, bool inverse, const uint64_t* root, 
   return MZK_OK;
 }
 
-static void make_round_plan(RoundPlan* rp, int s0, int r, int lgc, int lgt) {
-  int src[12];
-  for (int p = 0; p < 12; p++) src[p] = -1;
-  for (int i = 0; i < r; i++) src[lgc + s0 + i] = i;   // active k-bits come from element bits 0..r-1
-  const int lgnt = lgt - 3;
-  int next_t = 0, next_e = r;
-  const int low = lgt < 5 ? lgt : 5;
-  for (int p = 0; p < low; p++) if (src[p] < 0 && next_t < lgnt) src[p] = 8 + next_t++;   // bank bits <- lane bits
-  for (int p = 0; p < low; p++)                                                           // element bits inside the bank
-    if (src[p] >= 0 && src[p] < 8 && p + 5 < lgt && src[p + 5] < 0 && next_t < lgnt) src[p + 5] = 8 + next_t++;  // bits: swizzle partner
-  for (int p = 0; p < lgt; p++) {
-    if (src[p] >= 0) continue;
-    if (next_t < lgnt) src[p] = 8 + next_t++; else src[p] = next_e++;
-  }
-  rp->s0 = s0; rp->r = r;
-  for (int p = 0; p < 12; p++) rp->src[p] = (unsigned char)(src[p] < 0 ? 0 : src[p]);
-}
-static PassPlan make_pass_plan(int lgn, int lgt) {
-  PassPlan pp{};
-  pp.lgn = lgn; pp.lgc = lgt - lgn; pp.lgt = lgt;
-  int sizes[4], nr = 0;
-  if (lgn % 3) sizes[nr++] = lgn % 3;
-  for (int i = 0; i < lgn / 3; i++) sizes[nr++] = 3;
-  pp.nrounds = nr;
-  int s0 = 0;
-  for (int i = 0; i < nr; i++) { make_round_plan(&pp.rd[i], s0, sizes[i], pp.lgc, lgt); s0 += sizes[i]; }
-  return pp;
-}
-
-template <class P, int TLOG>
-static int run_plan_rb(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t s) {
-  const LevelInfo& li = pl->li;
-  const unsigned logn = pl->logn;
-  constexpr int NT = 1 << (TLOG - 3);
-  static bool attr_set = false;
-  if (!attr_set) {
-    MZK_HIP(hipFuncSetAttribute((const void*)k_ntt_rb<P, TLOG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MZK_HIP(hipFuncSetAttribute((const void*)k_ntt_rb<P, TLOG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
-  const u32* src = d_in;
-  u32* tmp = nullptr;
-  if (li.nlev > 1) MZK_TRY(ws_get(WS_NTT_TMP, ((size_t)1 << logn) * sizeof(u32) * P::NW, (void**)&tmp));
-  int lg_after = (int)logn;
-  const unsigned blocks = (unsigned)((size_t)1 << (logn - TLOG));
-  Words8 noscale{};
-  for (int t = 0; t < li.nlev; t++) {
-    const int lgn = li.lg[t], lgM = lg_after - lgn;
-    const bool last = (t == li.nlev - 1);
-    const PassPlan pp = make_pass_plan(lgn, TLOG);
-    const size_t lds_bytes = sizeof(u32) * ((size_t)P::L << TLOG) + (lgn >= 2 ? ((size_t)1 << (lgn - 1)) * P::NW * sizeof(u32) : 0);
-    ProfScope ps(s, MZK_PH_NTT_PASS0 + t);
-    if (!last) {
-      hipLaunchKernelGGL((k_ntt_rb<P, TLOG, false>), dim3(blocks), dim3(NT), lds_bytes, s, src, tmp, pl->tw_tile[t], pl->tw_inter[t], pp,
-                         lgM, li, 0, noscale, 0);
-      src = tmp;
-    } else {
-      hipLaunchKernelGGL((k_ntt_rb<P, TLOG, true>), dim3(blocks), dim3(NT), lds_bytes, s, src, d_out, pl->tw_tile[t], (const u32*)nullptr, pp,
-                         0, li, (int)logn - lgn, pl->last_scale, pl->has_last_scale);
-    }
-    lg_after = lgM;
-  }
-  MZK_HIP(hipGetLastError());
-  return MZK_OK;
-}
-
 template <class P>
 static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t s) {
   const LevelInfo& li = pl->li;
   const unsigned logn = pl->logn;
-  if (use_rb(logn)) {
-    switch (rb_tile_log()) {
-      case 10: return run_plan_rb<P, 10>(pl, d_in, d_out, s);
-      case 11: return run_plan_rb<P, 11>(pl, d_in, d_out, s);
-      default: return run_plan_rb<P, 12>(pl, d_in, d_out, s);
-    }
-  }
+
   auto lds_for = [](int lgn) { return sizeof(u32) * P::L * ((size_t)TILE + (lgn >= 2 ? ((size_t)1 << (lgn - 1)) : 1)); };  // tile + in-tile twiddles
   const u32* src = d_in;
   u32* tmp = nullptr;
