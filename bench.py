@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--skip-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--settle-s", type=float, default=0.5, help="untimed settle time per leg before the W warm-up steps")
     ap.add_argument("--e2e-log2n", type=int, default=22, help="degree of the end-to-end KZG run (0 = skip)")
     ap.add_argument("--extra-sizes", type=str, default="24", help="comma list of extra log2 sizes timed once each (rank 0 view)")
     args = ap.parse_args()
@@ -198,9 +199,15 @@ def main():
 
     # ------------------------------------------------------------------ timed regions
     def timed(step, K, W):
-        for _ in range(2):   # settle: workspace growth / plan building, never counted (W warm-up steps follow)
+        # settle: workspace growth / plan building, and the DVFS ramp -- on MI355X the same kernel runs ~25 %
+        # slower during the first few hundred ms after idle (scratch/mulv.hip: 136 -> 174 G mul/s).  Never
+        # counted; the W warm-up steps follow.
+        t_settle = time.perf_counter()
+        while True:
             step()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            if time.perf_counter() - t_settle > args.settle_s:
+                break
         for _ in range(W):
             step()
         L.mzk_prof_reset()
