@@ -52,10 +52,8 @@ MZK_HD Xyzz xyzz_dbl_affine(const Affine& a) {
   Fq MM = fe_sqr<P>(M);                          // < 1.06
   Fq X3 = fe_weak_reduce<P>(fe_sub<P, 4>(fe_sub<P, 4>(MM, S), S));  // MM - 2S (+8p) -> < 2.01
   Fq Vd = fe_carry<P>(fe_sub<P, 8>(S, X3));      // S - X3 (+8p) < 9.01, N
-  Fq A = fe_mul<P>(M, Vd);                       // < 1.17
-  Fq B = fe_mul<P>(W, a.y);                      // < 1.01
   r.X = X3;
-  r.Y = fe_weak_reduce<P>(fe_sub<P, 4>(A, B));   // < 2.01
+  r.Y = fe_mul_add2<P>(M, Vd, fe_neg_lazy<P, 4>(a.y), W);      // < 1.2
   r.ZZ = V;
   r.ZZZ = W;
   return r;
@@ -75,10 +73,8 @@ MZK_HEAVY Xyzz xyzz_dbl(const Xyzz& p) {
   Fq MM = fe_sqr<P>(M);                          // < 1.06
   Fq X3 = fe_weak_reduce<P>(fe_sub<P, 4>(fe_sub<P, 4>(MM, S), S));
   Fq Vd = fe_carry<P>(fe_sub<P, 8>(S, X3));      // < 9.02
-  Fq A = fe_mul<P>(M, Vd);                       // < 1.17
-  Fq B = fe_mul<P>(W, p.Y);                      // < 1.02
   r.X = X3;
-  r.Y = fe_weak_reduce<P>(fe_sub<P, 4>(A, B));
+  r.Y = fe_mul_add2<P>(M, Vd, fe_neg_lazy<P, 8>(p.Y), W);      // M (S - X3) - Y1 W: < 1.22
   r.ZZ = fe_mul<P>(V, p.ZZ);
   r.ZZZ = fe_mul<P>(W, p.ZZZ);
   return r;
@@ -103,10 +99,9 @@ MZK_HD Xyzz xyzz_madd(const Xyzz& a, const Affine& q) {
   Fq RR = fe_sqr<P>(Rd);                         // < 1.49
   Fq X3 = fe_weak_reduce<P>(fe_sub<P, 4>(fe_sub<P, 4>(fe_sub<P, 4>(RR, PPP), Q), Q));  // (+12p) < 13.5 -> < 2.01
   Fq Vd = fe_carry<P>(fe_sub<P, 8>(Q, X3));      // < 9.03
-  Fq A = fe_mul<P>(Rd, Vd);                      // < 1.49
-  Fq B = fe_mul<P>(a.Y, PPP);                    // < 1.02
   r.X = X3;
-  r.Y = fe_weak_reduce<P>(fe_sub<P, 4>(A, B));   // < 2.01
+  // Y3 = Rd (Q - X3) - Y1 PPP as one fused product pair: Rd Vd + (8p - Y1) PPP, single reduction
+  r.Y = fe_mul_add2<P>(Rd, Vd, fe_neg_lazy<P, 8>(a.Y), PPP);   // < (9.02*9.03 + 8*1.08) rho + 1 < 1.54
   r.ZZ = fe_mul<P>(a.ZZ, PP);
   r.ZZZ = fe_mul<P>(a.ZZZ, PPP);
   return r;
@@ -134,10 +129,8 @@ MZK_HEAVY Xyzz xyzz_add(const Xyzz& a, const Xyzz& b) {
   Fq RR = fe_sqr<P>(Rd);                         // < 1.15
   Fq X3 = fe_weak_reduce<P>(fe_sub<P, 4>(fe_sub<P, 4>(fe_sub<P, 4>(RR, PPP), Q), Q));
   Fq Vd = fe_carry<P>(fe_sub<P, 8>(Q, X3));      // < 9.02
-  Fq A = fe_mul<P>(Rd, Vd);                      // < 1.27
-  Fq B = fe_mul<P>(S1, PPP);                     // < 1.01
   r.X = X3;
-  r.Y = fe_weak_reduce<P>(fe_sub<P, 4>(A, B));
+  r.Y = fe_mul_add2<P>(Rd, Vd, fe_neg_lazy<P, 4>(S1), PPP);    // Rd Vd + (4p - S1) PPP: < 1.3
   r.ZZ = fe_mul<P>(fe_mul<P>(a.ZZ, b.ZZ), PP);
   r.ZZZ = fe_mul<P>(fe_mul<P>(a.ZZZ, b.ZZZ), PPP);
   return r;
