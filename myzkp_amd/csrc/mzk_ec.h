@@ -60,7 +60,7 @@ MZK_HD Xyzz xyzz_dbl_affine(const Affine& a) {
 }
 
 // 2 * (XYZZ) -> XYZZ   (dbl-2008-s-1, a = 0): 6M + 3S.  inf -> inf.
-MZK_HEAVY Xyzz xyzz_dbl(const Xyzz& p) {
+MZK_HD Xyzz xyzz_dbl(const Xyzz& p) {
   typedef FqParams P;
   if (xyzz_is_inf(p)) return p;
   Xyzz r;
@@ -108,7 +108,7 @@ MZK_HD Xyzz xyzz_madd(const Xyzz& a, const Affine& q) {
 }
 
 // a + b, both XYZZ   (add-2008-s): 12M + 2S.  Exception-complete.
-MZK_HEAVY Xyzz xyzz_add(const Xyzz& a, const Xyzz& b) {
+MZK_HD Xyzz xyzz_add(const Xyzz& a, const Xyzz& b) {
   typedef FqParams P;
   if (xyzz_is_inf(a)) return b;
   if (xyzz_is_inf(b)) return a;

@@ -31,15 +31,6 @@
 #else
 #define MZK_HD inline
 #endif
-// MZK_COMPACT_CODE (set by the translation unit of the single-lane MSM tail kernels): the field product
-// and the group operations become real functions instead of being inlined everywhere.  Those kernels run
-// ONE wave, so nothing hides an instruction-cache miss; with ~2 KB per inlined product their
-// straight-line code (100+ KB) cost more in instruction fetch than in arithmetic.
-#if defined(MZK_COMPACT_CODE) && defined(__HIPCC__)
-#define MZK_HEAVY __device__ __noinline__
-#else
-#define MZK_HEAVY MZK_HD
-#endif
 
 #if defined(MZK_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
 #include <assert.h>
@@ -83,7 +74,7 @@ template <class P> MZK_HD Fe<P> fe_r2() {
 // Montgomery product  a*b/R mod p  (finely integrated product scanning, one 64-bit column
 // accumulator).  Reference semantics: Ring::mul_ref, field.rs:176-179 (value * value % modulus).
 // ---------------------------------------------------------------------------------------------
-template <class P> MZK_HEAVY Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+template <class P> MZK_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
   constexpr int L = P::L;
   u32 m[L];
   Fe<P> r;
@@ -125,7 +116,7 @@ template <class P> MZK_HEAVY Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
 // (a b + c d)/R mod p, normalised, < (a b + c d)/R + p.  Saves a whole reduction (81 MADs + 9 v_mul_lo)
 // wherever a formula adds or subtracts two products.  Needs
 //   L (max_limb(a) max_limb(b) + max_limb(c) max_limb(d)) + L 2^58 < 2^64.
-template <class P> MZK_HEAVY Fe<P> fe_mul_add2(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) {
+template <class P> MZK_HD Fe<P> fe_mul_add2(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) {
   constexpr int L = P::L;
   u32 m[L];
   Fe<P> r;
@@ -183,7 +174,7 @@ template <class P, int K> MZK_HD Fe<P> fe_neg_lazy(const Fe<P>& b) {
 }
 
 // Montgomery square: cross products once, doubled (45 instead of 81 product terms for L = 9).
-template <class P> MZK_HEAVY Fe<P> fe_sqr(const Fe<P>& a) {
+template <class P> MZK_HD Fe<P> fe_sqr(const Fe<P>& a) {
   constexpr int L = P::L;
   u32 m[L], a2[L];
   Fe<P> r;

@@ -1,10 +1,6 @@
-// mzk_msm_tail.hip -- the single-LANE tail of the MSM: Horner over the bucket sets, the final Fq inversion,
-// and the multi-GPU fold of XYZZ partials.
-// Built with MZK_COMPACT_CODE: fe_mul / fe_sqr / xyzz_add / xyzz_dbl are real functions here (see
-// mzk_field.h), which shrinks these kernels ~10x; one lane cannot hide instruction-cache misses (window
-// Horner 2.8 -> 2.1 ms).  The multi-wave k_reduce_tail stays inlined in mzk_msm.hip: there the calls cost
-// more than the fetches (0.32 -> 0.41 ms measured).
-#define MZK_COMPACT_CODE 1
+// mzk_msm_tail.hip -- the single-wave tail of the MSM: Horner over the bucket sets (4-lane cooperative
+// doubling), the final Fq inversion, and the multi-GPU fold of XYZZ partials.  A separate translation
+// unit only to keep compile times of mzk_msm.hip down.
 #include "mzk_common.h"
 #include "mzk_ec.h"
 
@@ -39,13 +35,62 @@ __device__ __forceinline__ void xyzz_gstore(u32* __restrict__ g, size_t idx, con
 // ---- 6. window combine ----------------------------------------------------------------------------------
 // total = sum_w 2^(c w) R_w  (Horner, c doublings per window; a single bucket set skips it), then affine
 // (one Fq inversion) or the XYZZ partial record.
-__global__ void k_window_combine(const u32* __restrict__ wsum, int nwin, int c, int out_xyzz, u32* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+//
+// The 240 doublings are inherently serial, so the lever is the latency of ONE doubling: its 9 field
+// products form only 3 dependency levels (V, X^2 | W, S, M^2 | M(S-X3), W Y, V ZZ, W ZZZ).  Four lanes
+// hold the same point; at each level every lane computes a different product (same instruction stream,
+// lane-selected operands) and the results are broadcast back with v_readlane.  3 product latencies per
+// doubling instead of 9.
+__device__ __forceinline__ Fq bcast_lane(const Fq& v, int src) {
+  Fq r;
+#pragma unroll
+  for (int i = 0; i < FqParams::L; i++) r.l[i] = (u32)__builtin_amdgcn_readlane((int)v.l[i], src);
+  return r;
+}
+__device__ __forceinline__ Fq sel4(int lane, const Fq& a0, const Fq& a1, const Fq& a2, const Fq& a3) {
+  Fq r;
+#pragma unroll
+  for (int i = 0; i < FqParams::L; i++) r.l[i] = (lane == 0) ? a0.l[i] : (lane == 1) ? a1.l[i] : (lane == 2) ? a2.l[i] : a3.l[i];
+  return r;
+}
+// p is replicated in lanes 0..3 (lane = index within the group of four); result replicated again.
+// Straight-line on purpose: the cross-lane reads must not sit behind a branch the compiler cannot prove
+// uniform (an early `return` for infinity miscompiled when this was inlined into the Horner loop).
+// Infinity needs no special case: all-zero coordinates give ZZ3 = V * 0 = 0 exactly, and the final
+// select restores the canonical all-zero encoding.
+__device__ __forceinline__ void xyzz_dbl_coop4(Xyzz& p, int lane) {
+  typedef FqParams P;
+  const bool was_inf = xyzz_is_inf(p);
+  const Fq U = fe_dbl<P>(p.Y);                                  // < 5, limbs < 2^30
+  Fq r = fe_sqr<P>(sel4(lane, U, p.X, U, p.X));                 // lane 0: V = U^2, lane 1: X^2
+  const Fq V = bcast_lane(r, 0), X2 = bcast_lane(r, 1);
+  const Fq M = fe_carry<P>(fe_add<P>(fe_dbl<P>(X2), X2));       // 3 X^2 < 3.12, N
+  r = fe_mul<P>(sel4(lane, U, p.X, M, M), sel4(lane, V, V, M, M));   // W = U V | S = X V | M^2
+  const Fq W = bcast_lane(r, 0), S = bcast_lane(r, 1), MM = bcast_lane(r, 2);
+  const Fq X3 = fe_weak_reduce<P>(fe_sub<P, 4>(fe_sub<P, 4>(MM, S), S));
+  const Fq Vd = fe_carry<P>(fe_sub<P, 8>(S, X3));               // < 9.02
+  r = fe_mul<P>(sel4(lane, M, W, V, W), sel4(lane, Vd, p.Y, p.ZZ, p.ZZZ));   // A | B | ZZ3 | ZZZ3
+  const Fq A = bcast_lane(r, 0), B = bcast_lane(r, 1);
+  p.ZZ = bcast_lane(r, 2);
+  p.ZZZ = bcast_lane(r, 3);
+  p.X = X3;
+  p.Y = fe_weak_reduce<P>(fe_sub<P, 4>(A, B));                  // A < 1.17, B < 1.02
+#pragma unroll
+  for (int i = 0; i < P::L; i++) {
+    p.X.l[i] = was_inf ? 0u : p.X.l[i];
+    p.Y.l[i] = was_inf ? 0u : p.Y.l[i];
+    p.ZZ.l[i] = was_inf ? 0u : p.ZZ.l[i];
+    p.ZZZ.l[i] = was_inf ? 0u : p.ZZZ.l[i];
+  }
+}
+__global__ __launch_bounds__(64) void k_window_combine(const u32* __restrict__ wsum, int nwin, int c, int out_xyzz, u32* __restrict__ out) {
+  const int lane = threadIdx.x & 3;     // every group of four lanes replicates the same computation
   Xyzz tot = xyzz_gload(wsum, nwin - 1);
   for (int win = nwin - 2; win >= 0; win--) {
-    for (int d = 0; d < c; d++) tot = xyzz_dbl(tot);
+    for (int d = 0; d < c; d++) xyzz_dbl_coop4(tot, lane);
     tot = xyzz_add(tot, xyzz_gload(wsum, win));
   }
+  if (threadIdx.x != 0) return;
   if (out_xyzz) {
     u32 wds[32];
     xyzz_store(tot, wds);
