@@ -1,0 +1,111 @@
+"""Device-resident entry points (*_dev) and the multi-GPU data path exercised on ONE GPU: every shard's
+XYZZ partial is produced by the same calls bench.py makes per rank, the records are stacked the way
+all_gather_into_tensor stacks them, and mzk_g1_fold_partials_dev folds them."""
+import ctypes
+import numpy as np
+import pytest
+import orc
+from orc import FR, M128
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import myzkp_amd as mz
+    mz.init(0)
+    L = mz.lib()
+    dev = torch.device("cuda", 0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return torch, mz, L, dev, st
+
+
+def _ok(L, rc):
+    assert rc == 0, L.mzk_last_error().decode()
+
+
+def _dp(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _to_dev(torch, dev, arr):
+    return torch.from_numpy(np.ascontiguousarray(arr).view(np.int64).reshape(-1).copy()).to(dev)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_sharded_partials_fold_equals_full_msm(env, world):
+    torch, mz, L, dev, st = env
+    from myzkp_amd import sharded
+    n = 5000
+    s = orc.synth_vector(FR, 60 + world, n)
+    p = orc.synth_points(61 + world, n)
+    p[17] = 0
+    want = orc.msm_fast(s, p)
+    recs = torch.zeros((world, 16), dtype=torch.int64, device=dev)
+    recs_srs = torch.zeros((world, 16), dtype=torch.int64, device=dev)
+    for r in range(world):
+        lo, hi = sharded.shard_range(n, r, world)
+        ds, dpnt = _to_dev(torch, dev, s[lo:hi]), _to_dev(torch, dev, p[lo:hi])
+        _ok(L, L.mzk_msm_g1_bn254_partial_dev(_dp(ds), _dp(dpnt), ctypes.c_size_t(hi - lo), ctypes.c_void_p(recs[r].data_ptr()), st))
+        h = ctypes.c_void_p()
+        _ok(L, L.mzk_srs_from_device(_dp(dpnt), ctypes.c_size_t(hi - lo), ctypes.byref(h), st))
+        _ok(L, L.mzk_kzg_commit_srs_dev(h, _dp(ds), ctypes.c_size_t(hi - lo), ctypes.c_void_p(recs_srs[r].data_ptr()), 1, st))
+        torch.cuda.synchronize()
+        L.mzk_srs_free(h)
+    out = torch.zeros(8, dtype=torch.int64, device=dev)
+    for rr in (recs, recs_srs):
+        _ok(L, L.mzk_g1_fold_partials_dev(_dp(rr), ctypes.c_int(world), _dp(out), st))
+        torch.cuda.synchronize()
+        assert mz.array_to_points(out.cpu().numpy().view(np.uint64))[0] == want
+
+
+def test_partial_of_empty_and_cancelling_shards(env):
+    torch, mz, L, dev, st = env
+    p = orc.synth_points(5, 4)
+    neg = p.copy()
+    neg[:, 4:] = orc.to_limbs([orc.P_FQ - y for y in orc.from_limbs(p[:, 4:])], 4)
+    s = orc.to_limbs([7, 8, 9, 10], 4)
+    recs = torch.zeros((3, 16), dtype=torch.int64, device=dev)
+    ds, dp1, dp2 = _to_dev(torch, dev, s), _to_dev(torch, dev, p), _to_dev(torch, dev, neg)
+    _ok(L, L.mzk_msm_g1_bn254_partial_dev(_dp(ds), _dp(dp1), ctypes.c_size_t(4), ctypes.c_void_p(recs[0].data_ptr()), st))
+    _ok(L, L.mzk_msm_g1_bn254_partial_dev(_dp(ds), _dp(dp2), ctypes.c_size_t(4), ctypes.c_void_p(recs[1].data_ptr()), st))
+    _ok(L, L.mzk_msm_g1_bn254_partial_dev(_dp(ds), _dp(dp1), ctypes.c_size_t(0), ctypes.c_void_p(recs[2].data_ptr()), st))   # empty shard
+    out = torch.ones(8, dtype=torch.int64, device=dev)
+    _ok(L, L.mzk_g1_fold_partials_dev(_dp(recs), ctypes.c_int(3), _dp(out), st))
+    torch.cuda.synchronize()
+    assert mz.array_to_points(out.cpu().numpy().view(np.uint64))[0] == (0, 0)     # P + (-P) + inf = inf
+
+
+def test_ntt_dev_in_place_and_lde_and_fold_dev(env):
+    torch, mz, L, dev, st = env
+    lg = 13
+    n = 1 << lg
+    for fid, nl in ((FR, 4), (M128, 2)):
+        v = orc.synth_vector(fid, 80, n)
+        w = orc.root_of(fid, lg)
+        root = mz.to_limbs([w], nl)
+        d = _to_dev(torch, dev, v)
+        _ok(L, L.mzk_ntt_dev(fid, root.ctypes.data_as(ctypes.c_void_p), _dp(d), _dp(d), ctypes.c_size_t(n), 0, st))   # in place
+        torch.cuda.synchronize()
+        rc, want = orc.ntt_fast(fid, w, v)
+        assert np.array_equal(d.cpu().numpy().view(np.uint64).reshape(-1, nl), want)
+        _ok(L, L.mzk_ntt_dev(fid, root.ctypes.data_as(ctypes.c_void_p), _dp(d), _dp(d), ctypes.c_size_t(n), 1, st))
+        torch.cuda.synchronize()
+        assert np.array_equal(d.cpu().numpy().view(np.uint64).reshape(-1, nl), v)
+    # coset LDE and FRI fold, device-resident, M128
+    coef = orc.synth_vector(M128, 81, n // 4)
+    g = orc.m128_root(lg)
+    d_c = _to_dev(torch, dev, coef)
+    d_o = torch.zeros(n * 2, dtype=torch.int64, device=dev)
+    off, gen = mz.to_limbs([orc.M128_GEN], 2), mz.to_limbs([g], 2)
+    _ok(L, L.mzk_coset_lde_dev(M128, _dp(d_c), ctypes.c_size_t(n // 4), off.ctypes.data_as(ctypes.c_void_p), gen.ctypes.data_as(ctypes.c_void_p), _dp(d_o), ctypes.c_size_t(n), st))
+    torch.cuda.synchronize()
+    lde = d_o.cpu().numpy().view(np.uint64).reshape(-1, 2)
+    assert np.array_equal(lde, mz.coset_lde(M128, coef, orc.M128_GEN, g, n))
+    alpha = orc.from_limbs(orc.synth_vector(M128, 82, 1))[0]
+    al = mz.to_limbs([alpha], 2)
+    d_f = torch.zeros(n, dtype=torch.int64, device=dev)
+    _ok(L, L.mzk_fri_fold_dev(M128, _dp(d_o), ctypes.c_size_t(n), al.ctypes.data_as(ctypes.c_void_p), off.ctypes.data_as(ctypes.c_void_p), gen.ctypes.data_as(ctypes.c_void_p), _dp(d_f), st))
+    torch.cuda.synchronize()
+    assert np.array_equal(d_f.cpu().numpy().view(np.uint64).reshape(-1, 2), orc.fri_fold_ref(M128, lde, alpha, orc.M128_GEN, g))
