@@ -324,17 +324,31 @@ __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ 
   size_t b = lo;
   u32 bend = offsets[b + 1];
   Xyzz acc = xyzz_inf();
+  // software pipeline: the point of entry e+1 is requested before the ~3000-instruction madd of entry e,
+  // so the dependent entries[] -> points[] gather is in flight behind arithmetic instead of in front of it
+  u32 ent_next = entries[e0];
+  u32 wn[16];
+  {
+    const size_t idx = ent_next & 0x7fffffffu;
+    load_words8(points_mont + idx * 16, wn);
+    load_words8(points_mont + idx * 16 + 8, wn + 8);
+  }
   for (u32 e = e0; e < e1; e++) {
+    const u32 ent = ent_next;
+    u32 w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = wn[k];
+    if (e + 1 < e1) {
+      ent_next = entries[e + 1];
+      const size_t idx = ent_next & 0x7fffffffu;
+      load_words8(points_mont + idx * 16, wn);
+      load_words8(points_mont + idx * 16 + 8, wn + 8);
+    }
     if (e >= bend) {
       xyzz_gstore(slots, t + b, acc);
       acc = xyzz_inf();
       do { b++; bend = offsets[b + 1]; } while (e >= bend);
     }
-    const u32 ent = entries[e];
-    const size_t idx = ent & 0x7fffffffu;
-    u32 w[16];
-    load_words8(points_mont + idx * 16, w);
-    load_words8(points_mont + idx * 16 + 8, w + 8);
     if (affine_words_is_inf(w)) continue;  // infinity contributes nothing (curve.rs:107-109)
     Affine p = affine_load_mont(w);
     if (ent >> 31) p = affine_neg(p);
