@@ -90,41 +90,72 @@ __device__ __forceinline__ void stage_twiddles(u32* twl, const u32* __restrict__
     for (int i = 0; i < P::L; i++) twl[i * cnt + j] = w.l[i];
   }
 }
-// In-LDS radix-2 DIT over the k-dimension of a [2^lgn][2^lgc] tile whose rows were stored
-// bit-reversed; leaves natural order.  Butterflies are enumerated twiddle-major (all butterflies with
-// twiddle index j = 0 first), so whole waves skip the multiplication by w^0 = 1: stage s has a
-// fraction 2^-(s-1) of trivial butterflies, about one stage's worth of products per level.
+// One DIT butterfly in registers: (lo, hi) <- (lo + w hi, lo - w hi).  `trivial` (w = 1) skips the product;
+// then hi must still be brought below the 4 p the K = 8 subtraction tolerates, unless it is a raw input
+// (stage 1: < 2^(32 NW)).
+template <class P>
+__device__ __forceinline__ void bfly(Fe<P>& lo, Fe<P>& hi, const u32* twl, int tws, int ti, bool trivial, bool raw) {
+  Fe<P> t = hi;
+  if (!trivial) {
+    Fe<P> w;
+#pragma unroll
+    for (int i = 0; i < P::L; i++) w.l[i] = twl[i * tws + ti];
+    t = fe_mul<P>(t, w);
+  } else if (!raw) {
+    t = fe_weak_reduce<P>(t);
+  }
+  hi = fe_sub_carry<P, 8>(lo, t);
+  lo = fe_add_carry<P>(lo, t);
+}
+// In-LDS radix-2/radix-4 DIT over the k-dimension of a [2^lgn][2^lgc] tile whose rows were stored
+// bit-reversed; leaves natural order.  Stages run in pairs: a lane loads the four elements of a radix-4
+// group once, does two butterfly stages in registers and stores them (half the LDS traffic, address
+// arithmetic and barriers of one-stage-at-a-time); an odd lgn starts with one radix-2 stage.  Groups are
+// enumerated twiddle-major (all groups with twiddle index 0 first), so whole waves skip the products by
+// w^0 = 1: about one stage's worth of products per level.
 template <class P>
 __device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, int lgc) {
   const int tid = threadIdx.x;
-  const int lgbf = lgn + lgc - 1;
-  const int nbf = 1 << lgbf;  // butterflies per stage
   const int cmask = (1 << lgc) - 1;
   const int tws = (lgn >= 2) ? (1 << (lgn - 1)) : 1;   // twiddle table stride (entries per limb row)
-  for (int s = 1; s <= lgn; s++) {
-    const int lgh = s - 1;
-    const int lgrest = lgbf - lgh;
+  int s = 1;
+  if (lgn & 1) {  // stage 1 alone: every twiddle is 1
+    const int nbf = 1 << (lgn + lgc - 1);
     for (int b = tid; b < nbf; b += NTHREADS) {
-      const int j = b >> lgrest;
-      const int rest = b & ((1 << lgrest) - 1);
+      const int c = b & cmask, grp = b >> lgc;
+      const int plo = ((grp << 1) << lgc) | c, phi = plo + (1 << lgc);
+      Fe<P> x0 = lds_load<P>(lds, plo), x1 = lds_load<P>(lds, phi);
+      bfly<P>(x0, x1, twl, tws, 0, true, true);
+      lds_store<P>(lds, plo, x0);
+      lds_store<P>(lds, phi, x1);
+    }
+    __syncthreads();
+    s = 2;
+  }
+  const int lgg = lgn + lgc - 2;   // log2(radix-4 groups per stage pair)
+  for (; s + 1 <= lgn; s += 2) {
+    const int lgh = s - 1;                 // log2 of the first stage's half-distance (in k)
+    const int lgrest = lgg - lgh;
+    for (int g = tid; g < (1 << lgg); g += NTHREADS) {
+      const int j1 = g >> lgrest;
+      const int rest = g & ((1 << lgrest) - 1);
       const int c = rest & cmask, grp = rest >> lgc;
-      const int klo = (grp << s) | j;
-      const int plo = (klo << lgc) | c, phi = plo + (1 << (lgh + lgc));
-      Fe<P> a = lds_load<P>(lds, plo);
-      Fe<P> t = lds_load<P>(lds, phi);
-      if (j != 0) {
-        Fe<P> w;
-        const int ti = j << (lgn - s);
-#pragma unroll
-        for (int i = 0; i < P::L; i++) w.l[i] = twl[i * tws + ti];
-        t = fe_mul<P>(t, w);
-      } else if (s > 1) {
-        t = fe_weak_reduce<P>(t);   // w = 1: no product, but t has grown by up to 8 p per earlier stage
-      }
-      // t is normalised and < 2^(32 NW) (raw input, stage 1) or < 2.01 p: below the 4 p that the K = 8
-      // subtraction tolerates in its subtrahend for every field here
-      lds_store<P>(lds, plo, fe_add_carry<P>(a, t));
-      lds_store<P>(lds, phi, fe_sub_carry<P, 8>(a, t));
+      const int k0 = (grp << (s + 1)) | j1;
+      const int p0 = (k0 << lgc) | c;
+      const int d1 = 1 << (lgh + lgc), d2 = d1 << 1;
+      Fe<P> x0 = lds_load<P>(lds, p0), x1 = lds_load<P>(lds, p0 + d1);
+      Fe<P> x2 = lds_load<P>(lds, p0 + d2), x3 = lds_load<P>(lds, p0 + d2 + d1);
+      const bool triv = (j1 == 0);
+      const bool raw = (s == 1);
+      const int t1 = j1 << (lgn - s);
+      bfly<P>(x0, x1, twl, tws, t1, triv, raw);
+      bfly<P>(x2, x3, twl, tws, t1, triv, raw);
+      bfly<P>(x0, x2, twl, tws, j1 << (lgn - s - 1), triv, false);
+      bfly<P>(x1, x3, twl, tws, (j1 + (1 << lgh)) << (lgn - s - 1), false, false);
+      lds_store<P>(lds, p0, x0);
+      lds_store<P>(lds, p0 + d1, x1);
+      lds_store<P>(lds, p0 + d2, x2);
+      lds_store<P>(lds, p0 + d2 + d1, x3);
     }
     __syncthreads();
   }
