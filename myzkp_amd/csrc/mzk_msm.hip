@@ -7,14 +7,17 @@
 // point (or the all-zero infinity encoding).
 //
 // Pipeline, all on the device:
-//   0. k_prepare_points   affine canonical -> Montgomery words (once per point set; an SRS handle keeps it)
-//   1. k_digits_count     scalars -> signed c-bit digits (sanitize = reduce mod r first,
-//                         polynomial.rs:162), histogram of (window, |digit|) buckets
-//   2. scan               exclusive prefix sum of the histogram
-//   3. k_digits_scatter   counting-sort scatter of (point index, sign) into bucket order
-//   4. k_bucket_accumulate one lane per bucket, XYZZ += affine (madd-2008-s), exception-complete
-//   5. bucket reduction   sum_b (b+1) B_b per bucket set by in-place halving (lgB dependent steps)
-//   6. k_window_combine   Horner over the windows, XYZZ -> affine (one Fq inversion)
+//   0. k_prepare_points    affine canonical -> Montgomery words (generic path; an SRS handle holds
+//                          Montgomery-form window tables T[w][i] = 2^(16 w) P_i instead: k_srs_tables)
+//   1. k_digits_count[_lds] scalars -> signed c-bit digits (sanitize = reduce mod r first,
+//                          polynomial.rs:162), histogram of buckets; the atomic's return value is the
+//                          entry's rank (LDS atomics when the whole bucket set fits the 160 KiB LDS)
+//   2. scan                exclusive prefix sum of the histogram
+//   3. k_digits_scatter[_lds] counting-sort placement of (point reference, sign), no atomics
+//   4. k_seg_accumulate    one lane per fixed-size segment of the sorted entries, XYZZ += affine
+//                          (madd-2008-s), exception-complete; k_seg_combine sums a bucket's partials
+//   5. k_halve_step / k_reduce_tail   sum_b (b+1) B_b per bucket set by in-place halving
+//   6. k_window_combine (mzk_msm_tail.hip)  Horner over the bucket sets, XYZZ -> affine (one inversion)
 #include "mzk_common.h"
 #include "mzk_ec.h"
 
