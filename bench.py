@@ -241,6 +241,18 @@ def main():
     msm_rate = world * n / (msm_dt / K)
     ntt_rate = world * n / (ntt_dt / K)
 
+    # achievable HBM copy bandwidth on THIS box (SURVEY 8d asks for it next to the nominal 8 TB/s)
+    cp_a = torch.empty(1 << 28, dtype=torch.int32, device=dev)   # 1 GiB
+    cp_b = torch.empty_like(cp_a)
+    cp_b.copy_(cp_a); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        cp_b.copy_(cp_a)
+    torch.cuda.synchronize()
+    copy_gbps = 5 * 2 * cp_a.numel() * 4 / (time.perf_counter() - t0) / 1e9
+    del cp_a, cp_b
+    torch.cuda.empty_cache()
+
     def hbm_roofline(alg_bytes, ms):
         ach = alg_bytes / (ms * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None}
@@ -298,6 +310,7 @@ def main():
         "coset_lde_m128": {"metric": "LDE output elems/sec (fast_coset_evaluate, ntt.rs:254-269; blow-up 4)", "value": world * n / (lde_dt / K), "unit": "elems/s",
                            "ms_per_step": lde_dt / K * 1e3, "n_coef": n // 4, "order": n, "phases": lde_ph},
         "alu_roofline": alu,
+        "hbm_copy_GBps_measured": copy_gbps,
         "parity": parity,
     }
 
