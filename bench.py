@@ -356,50 +356,89 @@ def main():
                 extras["2^%d" % lg] = {"error": str(ex)[:200]}
     out["extra_sizes_1gpu"] = extras
 
-    # ------------------------------------------------------------------ BASELINE configs[4]: end-to-end KZG at degree 2^e2e (rank 0)
-    if rank == 0 and args.e2e_log2n > 0:
+    # ------------------------------------------------------------------ BASELINE configs[4]: end-to-end KZG at degree 2^e2e, 1 vs N GPUs
+    # evaluations -> iNTT -> setup(alpha) -> commit -> open(u).  Strong scaling over the N ranks of this job: the
+    # (cheap) iNTT and the synthetic-division quotient are replicated, rank g builds SRS powers [lo, hi) and runs the
+    # MSMs of its slice of the coefficient / quotient vectors, partials are all-gathered (2 x N x 128 B) and folded.
+    if args.e2e_log2n > 0:
+        lg = args.e2e_log2n
+        nn = 1 << lg
+        lo, hi = sharded.shard_range(nn, rank, world)
+        stages, err = {}, None
+        rec_c = torch.zeros(16, dtype=torch.int64, device=dev)
+        rec_w = torch.zeros(16, dtype=torch.int64, device=dev)
+        hh = ctypes.c_void_p()
         try:
-            lg = args.e2e_log2n
-            nn = 1 << lg
             ev = torch.empty(nn * 4, dtype=torch.int64, device=dev)
             cf = torch.empty(nn * 4, dtype=torch.int64, device=dev)
-            sp = torch.empty(nn * 8, dtype=torch.int64, device=dev)
-            o = torch.zeros(20, dtype=torch.int64, device=dev)
+            qq = torch.zeros(nn * 4, dtype=torch.int64, device=dev)
+            sp = torch.empty((hi - lo) * 8, dtype=torch.int64, device=dev)
+            yv = torch.zeros(4, dtype=torch.int64, device=dev)
             check(L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(SEED + 555), ctypes.c_size_t(nn), dptr(ev), stream))
             rt = mz.to_limbs([mz.root_of_unity(mz.FIELD_FR, lg)], 4)
             alpha = orc.from_limbs(orc.synth_vector(orc.FR, SEED + 556, 1))[0]
             uu = orc.from_limbs(orc.synth_vector(orc.FR, SEED + 557, 1))[0]
             a_l, u_l, g_l = mz.to_limbs([alpha], 4), mz.to_limbs([uu], 4), mz.points_to_array([(1, 2)])
-            hh = ctypes.c_void_p()
-            stages = {}
-            def stage(name, fn):
-                torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize()
-                stages[name] = (time.perf_counter() - t0) * 1e3
-            # untimed warm pass for plans / workspaces, then timed
-            for timed_pass in (False, True):
+
+            def stage(name, fn, record):
+                barrier_sync()
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                if record:
+                    stages[name] = (time.perf_counter() - t0) * 1e3
+
+            def off(t, elems, limbs):
+                return ctypes.c_void_p(t.data_ptr() + elems * limbs * 8)
+
+            for record in (False, True):     # first pass builds plans / workspaces
                 if hh:
                     L.mzk_srs_free(hh); hh = ctypes.c_void_p()
-                stage("intt", lambda: check(L.mzk_ntt_dev(mz.FIELD_FR, rt.ctypes.data_as(ctypes.c_void_p), dptr(ev), dptr(cf), ctypes.c_size_t(nn), 1, stream)))
-                stage("setup_srs_powers", lambda: check(L.mzk_kzg_setup_g1_dev(a_l.ctypes.data_as(ctypes.c_void_p), g_l.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(nn - 1), dptr(sp), stream)))
-                stage("srs_window_tables", lambda: check(L.mzk_srs_from_device(dptr(sp), ctypes.c_size_t(nn), ctypes.byref(hh), stream)))
-                stage("commit", lambda: check(L.mzk_kzg_commit_srs_dev(hh, dptr(cf), ctypes.c_size_t(nn), dptr(o), 0, stream)))
-                stage("open", lambda: check(L.mzk_kzg_open_srs_dev(hh, dptr(cf), ctypes.c_size_t(nn), u_l.ctypes.data_as(ctypes.c_void_p),
-                                                                    ctypes.c_void_p(o.data_ptr() + 64), ctypes.c_void_p(o.data_ptr() + 96), stream)))
-            oc = o.cpu().numpy().view(np.uint64)
-            cf_cpu = cf.cpu().numpy().view(np.uint64).reshape(-1, 4)
-            fa = orc.poly_eval(orc.FR, cf_cpu, alpha)
-            yy = mz.from_limbs(oc[8:12].reshape(1, 4))[0]
-            qa = (fa - yy) * pow(alpha - uu, -1, orc.P_FR) % orc.P_FR
-            okc = mz.array_to_points(oc[:8])[0] == orc.ec_mul(0, (1, 2), fa)
-            oky = yy == orc.poly_eval(orc.FR, cf_cpu, uu)
-            okw = mz.array_to_points(oc[12:20])[0] == orc.ec_mul(0, (1, 2), qa)
-            out["e2e_kzg"] = {"log2_degree": lg, "stages_ms": stages, "trapdoor_identities_hold": bool(okc and oky and okw),
-                              "what": "evaluations -> iNTT -> setup(alpha) -> commit -> open(u), device-resident (BASELINE configs[4])"}
-            L.mzk_srs_free(hh)
-            del ev, cf, sp
-            torch.cuda.empty_cache()
+                stage("intt", lambda: check(L.mzk_ntt_dev(mz.FIELD_FR, rt.ctypes.data_as(ctypes.c_void_p), dptr(ev), dptr(cf), ctypes.c_size_t(nn), 1, stream)), record)
+                stage("setup_srs_powers", lambda: check(L.mzk_kzg_setup_g1_range_dev(a_l.ctypes.data_as(ctypes.c_void_p), g_l.ctypes.data_as(ctypes.c_void_p),
+                                                                                   ctypes.c_size_t(lo), ctypes.c_size_t(hi - lo), dptr(sp), stream)), record)
+                # one commit + one open per SRS: keep plain prepared points (no window tables: 173 ms at 2^22 only pays
+                # off after ~20 commits)
+                stage("srs_prepare", lambda: check(L.mzk_srs_from_device_ex(dptr(sp), ctypes.c_size_t(hi - lo), ctypes.c_int(0), ctypes.byref(hh), stream)), record)
+                stage("commit_local", lambda: check(L.mzk_kzg_commit_srs_dev(hh, off(cf, lo, 4), ctypes.c_size_t(hi - lo), dptr(rec_c), ctypes.c_int(1), stream)), record)
+                def open_local():
+                    check(L.mzk_kzg_open_quotient_dev(dptr(cf), ctypes.c_size_t(nn), u_l.ctypes.data_as(ctypes.c_void_p), dptr(yv), dptr(qq), stream))
+                    qhi = min(hi, nn - 1)
+                    check(L.mzk_kzg_commit_srs_dev(hh, off(qq, lo, 4), ctypes.c_size_t(max(qhi - lo, 0)), dptr(rec_w), ctypes.c_int(1), stream))
+                stage("open_local", open_local, record)
         except Exception as ex:
-            out["e2e_kzg"] = {"error": str(ex)[:300]}
+            err = str(ex)[:300]
+        # every rank reaches this point; only fold if all local stages succeeded everywhere
+        all_ok = max_over_ranks(0.0 if err is None else 1.0) == 0.0
+        e2e = {"log2_degree": lg, "n_gpus": world,
+               "what": "evaluations -> iNTT -> setup(alpha) -> commit -> open(u), device-resident, MSMs and SRS sharded over the ranks (BASELINE configs[4])"}
+        if all_ok:
+            barrier_sync()
+            t0 = time.perf_counter()
+            fin = torch.zeros(16, dtype=torch.int64, device=dev)
+            rc_all = sharded.all_gather_partials(rec_c)
+            rw_all = sharded.all_gather_partials(rec_w)
+            check(L.mzk_g1_fold_partials_dev(dptr(rc_all), ctypes.c_int(rc_all.shape[0]), dptr(fin), stream))
+            check(L.mzk_g1_fold_partials_dev(dptr(rw_all), ctypes.c_int(rw_all.shape[0]), ctypes.c_void_p(fin.data_ptr() + 64), stream))
+            torch.cuda.synchronize()
+            stages["gather_and_fold"] = (time.perf_counter() - t0) * 1e3
+            stages = {k: max_over_ranks(v) for k, v in stages.items()}
+            if rank == 0:
+                oc = fin.cpu().numpy().view(np.uint64)
+                cf_cpu = cf.cpu().numpy().view(np.uint64).reshape(-1, 4)
+                fa = orc.poly_eval(orc.FR, cf_cpu, alpha)
+                yy = mz.from_limbs(yv.cpu().numpy().view(np.uint64).reshape(1, 4))[0]
+                qa = (fa - yy) * pow(alpha - uu, -1, orc.P_FR) % orc.P_FR
+                okc = mz.array_to_points(oc[:8])[0] == orc.ec_mul(0, (1, 2), fa)
+                oky = yy == orc.poly_eval(orc.FR, cf_cpu, uu)
+                okw = mz.array_to_points(oc[8:16])[0] == orc.ec_mul(0, (1, 2), qa)
+                e2e.update({"stages_ms": stages, "total_ms": sum(stages.values()), "trapdoor_identities_hold": bool(okc and oky and okw)})
+        else:
+            e2e["error"] = err or "a rank failed"
+        out["e2e_kzg"] = e2e
+        if hh:
+            L.mzk_srs_free(hh)
+        torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only, bounded sample)
     if rank == 0 and world == 1 and not args.skip_cpu:

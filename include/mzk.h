@@ -135,8 +135,17 @@ int mzk_kzg_open_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, const
                          void* d_w_xy, void* stream);
 int mzk_kzg_setup_g1_dev(const uint64_t alpha_host[4], const uint64_t g1_xy_host[8], size_t max_d, void* d_powers_xy,
                          void* stream);
-/* Build an SRS handle from points already in HBM (affine canonical, n * 8 limbs). */
+/* Sharded variants (one process per GPU): rank g builds powers [first, first+count) of the SRS and MSMs its own
+ * slice of the coefficient / quotient vectors; mzk_kzg_open_quotient_dev exposes y = f(u) (4 limbs) and the
+ * quotient (f - y)/(X - u) (n-1 elements) so that every rank can commit its slice of it. */
+int mzk_kzg_setup_g1_range_dev(const uint64_t alpha_host[4], const uint64_t g1_xy_host[8], size_t first, size_t count,
+                               void* d_powers_xy, void* stream);
+int mzk_kzg_open_quotient_dev(const void* d_coef, size_t n, const uint64_t u_host[4], void* d_y, void* d_q, void* stream);
+/* Build an SRS handle from points already in HBM (affine canonical, n * 8 limbs).  The _ex form chooses
+ * whether the 16 window tables are built (worth it from ~20 commits per SRS on; a one-shot pipeline keeps
+ * the plain prepared points and pays the window Horner instead). */
 int mzk_srs_from_device(const void* d_powers_xy, size_t n, mzk_srs** out, void* stream);
+int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, mzk_srs** out, void* stream);
 
 /* Deterministic synthetic inputs (bench + tests): bit-identical to the oracle's orc_synth_*. */
 int mzk_synth_field_dev(int field_id, uint64_t seed, size_t n, void* d_out, void* stream);

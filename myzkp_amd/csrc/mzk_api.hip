@@ -519,17 +519,31 @@ int mzk_kzg_open_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, const
   MZK_TRY(ensure_init());
   if (!srs) { set_error("open_srs_dev: null srs"); return MZK_E_ARG; }
   if (n > 1 && n - 1 > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }
-  return kzg_open_dev(d_coef, n, u_host, srs->d_points_mont, srs->has_tables ? MSM_PTS_TABLES : MSM_PTS_MONT, srs->n, d_y, d_w_xy, (hipStream_t)stream);
+  return kzg_open_dev(d_coef, n, u_host, srs->d_points_mont, srs->has_tables ? MSM_PTS_TABLES : MSM_PTS_MONT, srs->n, d_y, d_w_xy, nullptr, (hipStream_t)stream);
 }
 int mzk_kzg_setup_g1_dev(const uint64_t alpha_host[4], const uint64_t g1_xy_host[8], size_t max_d, void* d_powers_xy, void* stream) {
   MZK_TRY(ensure_init());
-  return kzg_setup_g1_dev(alpha_host, g1_xy_host, max_d + 1, d_powers_xy, (hipStream_t)stream);
+  return kzg_setup_g1_dev(alpha_host, g1_xy_host, 0, max_d + 1, d_powers_xy, (hipStream_t)stream);
+}
+int mzk_kzg_setup_g1_range_dev(const uint64_t alpha_host[4], const uint64_t g1_xy_host[8], size_t first, size_t count, void* d_powers_xy,
+                               void* stream) {
+  MZK_TRY(ensure_init());
+  return kzg_setup_g1_dev(alpha_host, g1_xy_host, first, count, d_powers_xy, (hipStream_t)stream);
+}
+int mzk_kzg_open_quotient_dev(const void* d_coef, size_t n, const uint64_t u_host[4], void* d_y, void* d_q, void* stream) {
+  MZK_TRY(ensure_init());
+  if (!d_q && n > 1) { set_error("open_quotient: null pointer"); return MZK_E_ARG; }
+  int dummy;
+  return kzg_open_dev(d_coef, n, u_host, nullptr, MSM_PTS_PLAIN, 0, d_y, nullptr, d_q ? d_q : (void*)&dummy, (hipStream_t)stream);
 }
 int mzk_srs_from_device(const void* d_powers_xy, size_t n, mzk_srs** out, void* stream) {
+  return mzk_srs_from_device_ex(d_powers_xy, n, 1, out, stream);
+}
+int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, mzk_srs** out, void* stream) {
   MZK_TRY(ensure_init());
   if (!out || (!d_powers_xy && n)) { set_error("srs_from_device: null pointer"); return MZK_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
-  mzk_srs* h = new mzk_srs{nullptr, n, n >= SRS_TABLE_MIN_N};
+  mzk_srs* h = new mzk_srs{nullptr, n, with_tables && n >= SRS_TABLE_MIN_N};
   if (n) {
     void* d_mont;
     const size_t copies = h->has_tables ? (size_t)MSM_SRS_WINDOWS : 1;
@@ -609,7 +623,7 @@ int mzk_kzg_setup_g1(const uint64_t alpha[4], const uint64_t g1_xy[8], size_t ma
   const size_t count = max_d + 1;  // `for _ in 0..1 + max_d`, kzg.rs:32
   void* d_p;
   MZK_TRY(ws_get(WS_MSM_POINTS, count * 64, &d_p));
-  MZK_TRY(kzg_setup_g1_dev(alpha, g1_xy, count, d_p, s));
+  MZK_TRY(kzg_setup_g1_dev(alpha, g1_xy, 0, count, d_p, s));
   MZK_HIP(hipMemcpyAsync(powers_xy, d_p, count * 64, hipMemcpyDeviceToHost, s));
   MZK_HIP(hipStreamSynchronize(s));
   return MZK_OK;
@@ -623,7 +637,7 @@ int mzk_kzg_open(const uint64_t* coef, size_t n, const uint64_t u[4], const uint
   MZK_TRY(stage_in(WS_MSM_SCALARS, coef, n * 32, &d_c, s));
   MZK_TRY(stage_in(WS_NTT_IO_A, powers_xy, (n > 1 ? n - 1 : 0) * 64, &d_p, s));
   MZK_TRY(ws_get(WS_NTT_IO_B, 256, &d_o));
-  MZK_TRY(kzg_open_dev(d_c, n, u, d_p, MSM_PTS_PLAIN, 0, d_o, (char*)d_o + 64, s));
+  MZK_TRY(kzg_open_dev(d_c, n, u, d_p, MSM_PTS_PLAIN, 0, d_o, (char*)d_o + 64, nullptr, s));
   uint64_t tmp[16];
   MZK_HIP(hipMemcpyAsync(tmp, d_o, 128, hipMemcpyDeviceToHost, s));
   MZK_HIP(hipStreamSynchronize(s));

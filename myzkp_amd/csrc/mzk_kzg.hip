@@ -68,12 +68,13 @@ __global__ void k_fb_table(const u32* __restrict__ bases, u32* __restrict__ tabl
   st8(table + 16 * t + 8, o + 8);
 }
 // powers[i] = alpha^i * g1, i < count; affine plain out.
-__global__ __launch_bounds__(128) void k_fb_powers(Words8k alpha_plain, const u32* __restrict__ table, size_t count, u32* __restrict__ out) {
+__global__ __launch_bounds__(128) void k_fb_powers(Words8k alpha_plain, const u32* __restrict__ table, size_t first, size_t count,
+                                                   u32* __restrict__ out) {
   typedef FrParams R;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   Fe<R> a = fe_to_mont<R>(fe_unpack<R>(alpha_plain.w));
-  Fe<R> k = fe_from_mont<R>(fe_pow_u64<R>(a, (u64)i));   // canonical alpha^i   (kzg.rs:33-36)
+  Fe<R> k = fe_from_mont<R>(fe_pow_u64<R>(a, (u64)(first + i)));   // canonical alpha^(first+i)   (kzg.rs:33-36)
   u32 kw[8];
   fe_pack<R>(k, kw);
   Xyzz acc = xyzz_inf();
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(128) void k_fb_powers(Words8k alpha_plain, const u3
   st8(out + 16 * i + 8, o + 8);
 }
 
-int kzg_setup_g1_dev(const uint64_t* alpha_host, const uint64_t* g1_host, size_t count, void* d_powers_xy, hipStream_t s) {
+int kzg_setup_g1_dev(const uint64_t* alpha_host, const uint64_t* g1_host, size_t first, size_t count, void* d_powers_xy, hipStream_t s) {
   if (!alpha_host || !g1_host || (!d_powers_xy && count)) { set_error("kzg_setup: null pointer"); return MZK_E_ARG; }
   if (count == 0) return MZK_OK;
   if (!h_is_canonical(host_field(MZK_FIELD_FR), alpha_host) || !h_is_canonical(host_field(MZK_FIELD_FQ), g1_host) ||
@@ -108,7 +109,7 @@ int kzg_setup_g1_dev(const uint64_t* alpha_host, const uint64_t* g1_host, size_t
   MZK_TRY(ws_get(WS_MISC_B, 32 * 256 * 64, (void**)&table));
   hipLaunchKernelGGL(k_fb_bases, dim3(1), dim3(32), 0, s, gw, bases);
   hipLaunchKernelGGL(k_fb_table, dim3(32), dim3(256), 0, s, (const u32*)bases, table);
-  hipLaunchKernelGGL(k_fb_powers, dim3((unsigned)((count + 127) / 128)), dim3(128), 0, s, aw, (const u32*)table, count, (u32*)d_powers_xy);
+  hipLaunchKernelGGL(k_fb_powers, dim3((unsigned)((count + 127) / 128)), dim3(128), 0, s, aw, (const u32*)table, first, count, (u32*)d_powers_xy);
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }
@@ -237,13 +238,13 @@ int kzg_batch_open_dev(const void* d_coef, size_t n, const uint64_t* us_host, si
 
 // d_y: 8 words; d_w_xy: 16 words.
 int kzg_open_dev(const void* d_coef, size_t n, const uint64_t* u_host, const void* d_points, int point_kind, size_t table_stride,
-                 void* d_y, void* d_w_xy, hipStream_t s) {
-  if (!u_host || !d_y || !d_w_xy || (!d_coef && n) || (!d_points && n > 1)) { set_error("kzg_open: null pointer"); return MZK_E_ARG; }
+                 void* d_y, void* d_w_xy, void* d_q_out, hipStream_t s) {
+  if (!u_host || !d_y || (!d_w_xy && !d_q_out) || (!d_coef && n) || (!d_points && n > 1 && !d_q_out)) { set_error("kzg_open: null pointer"); return MZK_E_ARG; }
   const HostField* fr = host_field(MZK_FIELD_FR);
   if (!h_is_canonical(fr, u_host)) { set_error("kzg_open: u not canonical"); return MZK_E_RANGE; }
   if (n == 0) {  // empty polynomial: y = 0, quotient empty -> infinity
     MZK_HIP(hipMemsetAsync(d_y, 0, 32, s));
-    MZK_HIP(hipMemsetAsync(d_w_xy, 0, 64, s));
+    if (d_w_xy) MZK_HIP(hipMemsetAsync(d_w_xy, 0, 64, s));
     return MZK_OK;
   }
   // level arrays: L0 = coef (n), L1 = chunk values (ceil(n/K)), ...
@@ -292,6 +293,10 @@ int kzg_open_dev(const void* d_coef, size_t n, const uint64_t* u_host, const voi
   }
   MZK_HIP(hipGetLastError());
   MZK_HIP(hipMemcpyAsync(d_y, bbuf, 32, hipMemcpyDeviceToDevice, s));   // y = b_0
+  if (d_q_out) {   // quotient only (sharded opening: every rank MSMs its own slice of q)
+    if (n > 1) MZK_HIP(hipMemcpyAsync(d_q_out, bbuf + 8, (n - 1) * 32, hipMemcpyDeviceToDevice, s));
+    return MZK_OK;
+  }
   // w = MSM(q, powers), q_j = b_{j+1}, j < n - 1     (kzg.rs:70)
   return msm_dev_impl(bbuf + 8, d_points, n - 1, point_kind, table_stride, d_w_xy, false, s);
 }

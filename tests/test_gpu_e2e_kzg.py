@@ -61,3 +61,63 @@ def test_end_to_end_device_resident(lg):
     for i in (0, 1, n // 2, n - 1):
         assert orc.arr_to_pts(pts[i:i + 1])[0] == orc.ec_mul(0, (1, 2), pow(alpha, i, P_FR))
     L.mzk_srs_free(h)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_end_to_end_on_one_gpu(world):
+    """The N-GPU form of configs[4], every rank's calls replayed on one GPU: replicated iNTT and quotient,
+    rank g builds SRS powers [lo, hi) and MSMs its slice of the coefficients / of the quotient; the XYZZ
+    partials are folded as after an all-gather."""
+    import torch
+    import myzkp_amd as mz
+    from myzkp_amd import sharded
+    mz.init(0)
+    L = mz.lib()
+    dev = torch.device("cuda", 0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lg = 15
+    n = 1 << lg
+
+    def ok(rc):
+        assert rc == 0, L.mzk_last_error().decode()
+
+    def dp(t, off_bytes=0):
+        return ctypes.c_void_p(t.data_ptr() + off_bytes)
+
+    evals = torch.empty(n * 4, dtype=torch.int64, device=dev)
+    coef = torch.empty(n * 4, dtype=torch.int64, device=dev)
+    quo = torch.zeros(n * 4, dtype=torch.int64, device=dev)
+    yv = torch.zeros(4, dtype=torch.int64, device=dev)
+    ok(L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(4242), ctypes.c_size_t(n), dp(evals), st))
+    root = mz.to_limbs([mz.root_of_unity(mz.FIELD_FR, lg)], 4)
+    ok(L.mzk_ntt_dev(mz.FIELD_FR, root.ctypes.data_as(ctypes.c_void_p), dp(evals), dp(coef), ctypes.c_size_t(n), 1, st))
+    alpha = orc.from_limbs(orc.synth_vector(FR, 4243, 1))[0]
+    u = orc.from_limbs(orc.synth_vector(FR, 4244, 1))[0]
+    a_l, u_l, g_l = mz.to_limbs([alpha], 4), mz.to_limbs([u], 4), mz.points_to_array([(1, 2)])
+    ok(L.mzk_kzg_open_quotient_dev(dp(coef), ctypes.c_size_t(n), u_l.ctypes.data_as(ctypes.c_void_p), dp(yv), dp(quo), st))
+    rec_c = torch.zeros((world, 16), dtype=torch.int64, device=dev)
+    rec_w = torch.zeros((world, 16), dtype=torch.int64, device=dev)
+    for r in range(world):
+        lo, hi = sharded.shard_range(n, r, world)
+        pts = torch.empty((hi - lo) * 8, dtype=torch.int64, device=dev)
+        ok(L.mzk_kzg_setup_g1_range_dev(a_l.ctypes.data_as(ctypes.c_void_p), g_l.ctypes.data_as(ctypes.c_void_p),
+                                         ctypes.c_size_t(lo), ctypes.c_size_t(hi - lo), dp(pts), st))
+        h = ctypes.c_void_p()
+        ok(L.mzk_srs_from_device(dp(pts), ctypes.c_size_t(hi - lo), ctypes.byref(h), st))
+        ok(L.mzk_kzg_commit_srs_dev(h, dp(coef, lo * 32), ctypes.c_size_t(hi - lo), ctypes.c_void_p(rec_c[r].data_ptr()), 1, st))
+        qhi = min(hi, n - 1)                      # the quotient has n - 1 coefficients
+        ok(L.mzk_kzg_commit_srs_dev(h, dp(quo, lo * 32), ctypes.c_size_t(max(qhi - lo, 0)), ctypes.c_void_p(rec_w[r].data_ptr()), 1, st))
+        torch.cuda.synchronize()
+        L.mzk_srs_free(h)
+    out = torch.zeros(16, dtype=torch.int64, device=dev)
+    ok(L.mzk_g1_fold_partials_dev(dp(rec_c), ctypes.c_int(world), dp(out), st))
+    ok(L.mzk_g1_fold_partials_dev(dp(rec_w), ctypes.c_int(world), dp(out, 64), st))
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().view(np.uint64)
+    commit, w = mz.array_to_points(o[:8])[0], mz.array_to_points(o[8:16])[0]
+    y = mz.from_limbs(yv.cpu().numpy().view(np.uint64).reshape(1, 4))[0]
+    coef_cpu = coef.cpu().numpy().view(np.uint64).reshape(-1, 4)
+    fa = orc.poly_eval(FR, coef_cpu, alpha)
+    assert commit == orc.ec_mul(0, (1, 2), fa)
+    assert y == orc.poly_eval(FR, coef_cpu, u)
+    assert w == orc.ec_mul(0, (1, 2), (fa - y) * pow(alpha - u, -1, P_FR) % P_FR)
