@@ -39,7 +39,7 @@ int ensure_init();
 
 // Grow-only device scratch buffers, keyed by slot, so steady-state calls never hipMalloc.
 enum WsSlot { WS_NTT_TMP = 0, WS_NTT_IO_A, WS_NTT_IO_B, WS_MSM_POINTS, WS_MSM_SCALARS, WS_MSM_COUNTS, WS_MSM_OFFSETS,
-              WS_MSM_CURSOR, WS_MSM_ENTRIES, WS_MSM_BUCKETS, WS_MSM_RED_A, WS_MSM_RED_B, WS_MSM_SCAN, WS_MSM_OUT, WS_MSM_SLOTS, WS_MSM_WGHIST,
+              WS_MSM_CURSOR, WS_MSM_ENTRIES, WS_MSM_BUCKETS, WS_MSM_RED_A, WS_MSM_RED_B, WS_MSM_SCAN, WS_MSM_OUT, WS_MSM_SLOTS, WS_MSM_WGHIST, WS_BATCHINV, WS_XYZZ_TMP,
               WS_MISC_A, WS_MISC_B, WS_MISC_C, WS_MISC_D, WS_COUNT };
 int ws_get(WsSlot slot, size_t bytes, void** out);
 void ws_release_all();
@@ -86,6 +86,7 @@ enum { MSM_PTS_PLAIN = 0, MSM_PTS_MONT = 1, MSM_PTS_TABLES = 2 };
 constexpr int MSM_SRS_WINDOWS = 16;   // 254 / 16 + 1
 int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int point_kind, size_t table_stride, void* d_out,
                  bool out_partial_xyzz, hipStream_t s);
+int xyzz_batch_to_affine(const void* d_xyzz, size_t count, void* d_out, bool out_mont, hipStream_t s);
 int msm_build_tables(const void* d_points_mont, size_t n, void* d_tables, hipStream_t s);
 int msm_fold_partials_impl(const void* d_partials, int count, void* d_out_xy, hipStream_t s);
 int msm_prepare_points(const void* d_points_plain, size_t n, void* d_points_mont, hipStream_t s);

@@ -67,14 +67,39 @@ __global__ void k_fb_table(const u32* __restrict__ bases, u32* __restrict__ tabl
   st8(table + 16 * t, o);
   st8(table + 16 * t + 8, o + 8);
 }
-// powers[i] = alpha^i * g1, i < count; affine plain out.
-__global__ __launch_bounds__(128) void k_fb_powers(Words8k alpha_plain, const u32* __restrict__ table, size_t first, size_t count,
-                                                   u32* __restrict__ out) {
+// atab[l][j] = alpha^(j * 2^(11 l)), l < 3, j < 2048, canonical Montgomery: alpha^e for e < 2^33 is then two
+// products instead of a ~96-product square-and-multiply per SRS power.
+constexpr int ATAB_BITS = 11;
+__global__ void k_alpha_table(Words8k alpha_plain, u32* __restrict__ atab) {
+  typedef FrParams R;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 3 << ATAB_BITS) return;
+  const int l = t >> ATAB_BITS, j = t & ((1 << ATAB_BITS) - 1);
+  Fe<R> a = fe_to_mont<R>(fe_unpack<R>(alpha_plain.w));
+  Fe<R> v = fe_reduce<R>(fe_pow_u64<R>(a, (u64)j << (ATAB_BITS * l)));
+  u32 o[8];
+  fe_pack<R>(v, o);
+  st8(atab + 8 * t, o);
+}
+// acc[i] = alpha^(first+i) * g1 as XYZZ (32 words); the affine conversion is batched afterwards.
+__global__ __launch_bounds__(128) void k_fb_powers(Words8k alpha_plain, const u32* __restrict__ atab, const u32* __restrict__ table,
+                                                   size_t first, size_t count, u32* __restrict__ out_xyzz) {
   typedef FrParams R;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
-  Fe<R> a = fe_to_mont<R>(fe_unpack<R>(alpha_plain.w));
-  Fe<R> k = fe_from_mont<R>(fe_pow_u64<R>(a, (u64)(first + i)));   // canonical alpha^(first+i)   (kzg.rs:33-36)
+  const u64 e = (u64)(first + i);
+  Fe<R> km;
+  if (e >> (3 * ATAB_BITS)) {
+    km = fe_pow_u64<R>(fe_to_mont<R>(fe_unpack<R>(alpha_plain.w)), e);
+  } else {
+    const u32 m = (1u << ATAB_BITS) - 1;
+    u32 w0[8], w1[8], w2[8];
+    ld8(atab + 8 * (size_t)(e & m), w0);
+    ld8(atab + 8 * (size_t)((1u << ATAB_BITS) + ((e >> ATAB_BITS) & m)), w1);
+    ld8(atab + 8 * (size_t)((2u << ATAB_BITS) + ((e >> (2 * ATAB_BITS)) & m)), w2);
+    km = fe_mul<R>(fe_mul<R>(fe_unpack<R>(w0), fe_unpack<R>(w1)), fe_unpack<R>(w2));
+  }
+  Fe<R> k = fe_from_mont<R>(km);   // canonical alpha^(first+i)   (kzg.rs:33-36)
   u32 kw[8];
   fe_pack<R>(k, kw);
   Xyzz acc = xyzz_inf();
@@ -87,12 +112,74 @@ __global__ __launch_bounds__(128) void k_fb_powers(Words8k alpha_plain, const u3
     if (affine_words_is_inf(tw)) continue;
     acc = xyzz_madd(acc, affine_load_mont(tw));
   }
-  u32 o[16];
-  Affine af;
-  if (xyzz_to_affine(acc, &af)) affine_store_plain(af, o);
-  else for (int j = 0; j < 16; j++) o[j] = 0;
-  st8(out + 16 * i, o);
-  st8(out + 16 * i + 8, o + 8);
+  u32 o[32];
+  xyzz_store(acc, o);
+#pragma unroll
+  for (int q = 0; q < 4; q++) st8(out_xyzz + 32 * i + 8 * q, o + 8 * q);
+}
+
+// XYZZ -> affine for a whole array with Montgomery's batch-inversion trick: one lane owns BATCH consecutive
+// points, multiplies their denominators ZZ*ZZZ into running prefix products (parked in `scratch`, 9 words
+// each), inverts the total ONCE (Fermat: all lanes in lockstep) and unwinds.  ~33 products per point instead
+// of ~390.  Infinity (all-zero record) contributes the factor 1 and comes out as the all-zero encoding.
+constexpr int BATCH_INV = 16;
+__global__ __launch_bounds__(128) void k_xyzz_batch_to_affine(const u32* __restrict__ xyzz, size_t count, u32* __restrict__ scratch,
+                                                              u32* __restrict__ out, int out_mont) {
+  typedef FqParams P;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i0 = t * BATCH_INV;
+  if (i0 >= count) return;
+  const int len = (int)((count - i0 < (size_t)BATCH_INV) ? (count - i0) : (size_t)BATCH_INV);
+  Fq run = fe_one<P>();
+  for (int j = 0; j < len; j++) {
+    u32 w[16];
+    ld8(xyzz + 32 * (i0 + j) + 16, w);       // ZZ
+    ld8(xyzz + 32 * (i0 + j) + 24, w + 8);   // ZZZ
+    const bool inf = affine_words_is_inf(w);
+    Fq d = fe_mul<P>(fe_unpack<P>(w), fe_unpack<P>(w + 8));
+    if (inf) d = fe_one<P>();
+    // prefix BEFORE including element j
+#pragma unroll
+    for (int k = 0; k < P::L; k++) scratch[(i0 + j) * P::L + k] = run.l[k];
+    run = fe_mul<P>(run, d);
+  }
+  Fq inv = fe_inv<P>(run);
+  for (int j = len - 1; j >= 0; j--) {
+    u32 w[32];
+#pragma unroll
+    for (int q = 0; q < 4; q++) ld8(xyzz + 32 * (i0 + j) + 8 * q, w + 8 * q);
+    const bool inf = affine_words_is_inf(w + 16);
+    const Fq X = fe_unpack<P>(w), Y = fe_unpack<P>(w + 8), ZZ = fe_unpack<P>(w + 16), ZZZ = fe_unpack<P>(w + 24);
+    Fq pre;
+#pragma unroll
+    for (int k = 0; k < P::L; k++) pre.l[k] = scratch[(i0 + j) * P::L + k];
+    const Fq dinv = fe_mul<P>(inv, pre);                       // 1 / (ZZ ZZZ) of element j
+    Fq d = fe_mul<P>(ZZ, ZZZ);
+    if (inf) d = fe_one<P>();
+    inv = fe_mul<P>(inv, d);                                   // drop element j from the running inverse
+    u32 o[16];
+    if (inf) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) o[k] = 0;
+    } else {
+      Affine a;
+      a.x = fe_reduce<P>(fe_mul<P>(X, fe_mul<P>(dinv, ZZZ)));   // X / ZZ
+      a.y = fe_reduce<P>(fe_mul<P>(Y, fe_mul<P>(dinv, ZZ)));    // Y / ZZZ
+      if (out_mont) affine_store_mont(a, o); else affine_store_plain(a, o);
+    }
+    st8(out + 16 * (i0 + j), o);
+    st8(out + 16 * (i0 + j) + 8, o + 8);
+  }
+}
+int xyzz_batch_to_affine(const void* d_xyzz, size_t count, void* d_out, bool out_mont, hipStream_t s) {
+  if (count == 0) return MZK_OK;
+  u32* scratch;
+  MZK_TRY(ws_get(WS_BATCHINV, count * FqParams::L * sizeof(u32), (void**)&scratch));
+  const size_t threads = (count + BATCH_INV - 1) / BATCH_INV;
+  hipLaunchKernelGGL(k_xyzz_batch_to_affine, dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, s, (const u32*)d_xyzz, count, scratch,
+                     (u32*)d_out, out_mont ? 1 : 0);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
 }
 
 int kzg_setup_g1_dev(const uint64_t* alpha_host, const uint64_t* g1_host, size_t first, size_t count, void* d_powers_xy, hipStream_t s) {
@@ -104,14 +191,18 @@ int kzg_setup_g1_dev(const uint64_t* alpha_host, const uint64_t* g1_host, size_t
   Words16k gw;
   for (int i = 0; i < 4; i++) { aw.w[2 * i] = (u32)alpha_host[i]; aw.w[2 * i + 1] = (u32)(alpha_host[i] >> 32); }
   for (int i = 0; i < 8; i++) { gw.w[2 * i] = (u32)g1_host[i]; gw.w[2 * i + 1] = (u32)(g1_host[i] >> 32); }
-  u32 *bases, *table;
+  u32 *bases, *table, *acc, *atab;
+  MZK_TRY(ws_get(WS_MISC_C, (size_t)(3 << ATAB_BITS) * 32, (void**)&atab));
   MZK_TRY(ws_get(WS_MISC_A, 32 * 64, (void**)&bases));
   MZK_TRY(ws_get(WS_MISC_B, 32 * 256 * 64, (void**)&table));
+  MZK_TRY(ws_get(WS_XYZZ_TMP, count * 128, (void**)&acc));
   hipLaunchKernelGGL(k_fb_bases, dim3(1), dim3(32), 0, s, gw, bases);
   hipLaunchKernelGGL(k_fb_table, dim3(32), dim3(256), 0, s, (const u32*)bases, table);
-  hipLaunchKernelGGL(k_fb_powers, dim3((unsigned)((count + 127) / 128)), dim3(128), 0, s, aw, (const u32*)table, first, count, (u32*)d_powers_xy);
+  hipLaunchKernelGGL(k_alpha_table, dim3((3 << ATAB_BITS) / 256), dim3(256), 0, s, aw, atab);
+  hipLaunchKernelGGL(k_fb_powers, dim3((unsigned)((count + 127) / 128)), dim3(128), 0, s, aw, (const u32*)atab, (const u32*)table, first,
+                     count, acc);
   MZK_HIP(hipGetLastError());
-  return MZK_OK;
+  return xyzz_batch_to_affine(acc, count, d_powers_xy, false, s);
 }
 
 // ---- open: suffix Horner b_i = c_i + u b_{i+1} -----------------------------------------------------------

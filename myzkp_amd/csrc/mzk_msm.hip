@@ -443,37 +443,35 @@ int msm_prepare_points(const void* d_points_plain, size_t n, void* d_points_mont
 }
 
 // SRS window tables: T[w][i] = 2^(c w) * P_i, affine Montgomery, w < nwin (w = 0 is the point itself).
-// One lane per point: c doublings in XYZZ, then back to affine (one inversion per entry; one-time cost
-// per SRS).
-__global__ __launch_bounds__(128) void k_srs_tables(const u32* __restrict__ pts_mont, size_t n, int c, int nwin, u32* __restrict__ tables) {
+// A per-point XYZZ state is doubled c times per window (k_srs_window_step) and converted to affine with the
+// batched inversion of mzk_kzg.hip (one inversion per 16 points instead of one per table entry).
+__global__ __launch_bounds__(128) void k_srs_state_init(const u32* __restrict__ pts_mont, size_t n, u32* __restrict__ state) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 w[16];
   load_words8(pts_mont + i * 16, w);
   load_words8(pts_mont + i * 16 + 8, w + 8);
-  store_words8(tables + i * 16, w);
-  store_words8(tables + i * 16 + 8, w + 8);
-  if (affine_words_is_inf(w)) {
-    for (int win = 1; win < nwin; win++) {
-      store_words8(tables + ((size_t)win * n + i) * 16, w);
-      store_words8(tables + ((size_t)win * n + i) * 16 + 8, w + 8);
-    }
-    return;
-  }
-  Affine a = affine_load_mont(w);
-  for (int win = 1; win < nwin; win++) {
-    Xyzz p = xyzz_dbl_affine(a);
-    for (int d = 1; d < c; d++) p = xyzz_dbl(p);
-    xyzz_to_affine(p, &a);  // never infinity: the group has odd prime order
-    affine_store_mont(a, w);
-    store_words8(tables + ((size_t)win * n + i) * 16, w);
-    store_words8(tables + ((size_t)win * n + i) * 16 + 8, w + 8);
-  }
+  Xyzz p = affine_words_is_inf(w) ? xyzz_inf() : xyzz_from_affine(affine_load_mont(w));
+  xyzz_gstore(state, i, p);
+}
+__global__ __launch_bounds__(128) void k_srs_window_step(u32* __restrict__ state, size_t n, int c) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Xyzz p = xyzz_gload(state, i);
+  for (int d = 0; d < c; d++) p = xyzz_dbl(p);
+  xyzz_gstore(state, i, p);
 }
 int msm_build_tables(const void* d_points_mont, size_t n, void* d_tables, hipStream_t s) {
   if (n == 0) return MZK_OK;
-  hipLaunchKernelGGL(k_srs_tables, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, (const u32*)d_points_mont, n, SRS_WINDOW_BITS,
-                     SRS_WINDOWS, (u32*)d_tables);
+  u32* state;
+  MZK_TRY(ws_get(WS_XYZZ_TMP, n * 128, (void**)&state));
+  const unsigned blocks = (unsigned)((n + 127) / 128);
+  MZK_HIP(hipMemcpyAsync(d_tables, d_points_mont, n * 64, hipMemcpyDeviceToDevice, s));   // window 0
+  hipLaunchKernelGGL(k_srs_state_init, dim3(blocks), dim3(128), 0, s, (const u32*)d_points_mont, n, state);
+  for (int win = 1; win < SRS_WINDOWS; win++) {
+    hipLaunchKernelGGL(k_srs_window_step, dim3(blocks), dim3(128), 0, s, state, n, SRS_WINDOW_BITS);
+    MZK_TRY(xyzz_batch_to_affine(state, n, (u32*)d_tables + (size_t)win * n * 16, true, s));
+  }
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }

@@ -109,3 +109,32 @@ def test_ntt_dev_in_place_and_lde_and_fold_dev(env):
     _ok(L, L.mzk_fri_fold_dev(M128, _dp(d_o), ctypes.c_size_t(n), al.ctypes.data_as(ctypes.c_void_p), off.ctypes.data_as(ctypes.c_void_p), gen.ctypes.data_as(ctypes.c_void_p), _dp(d_f), st))
     torch.cuda.synchronize()
     assert np.array_equal(d_f.cpu().numpy().view(np.uint64).reshape(-1, 2), orc.fri_fold_ref(M128, lde, alpha, orc.M128_GEN, g))
+
+
+@pytest.mark.parametrize("first,count", [(0, 1), (0, 37), (2047, 3), ((1 << 22) - 5, 40), ((1 << 33) - 7, 21), ((1 << 40) + 3, 17)])
+def test_setup_range_any_offset_matches_fixed_base_oracle(env, first, count):
+    """powers[i] = alpha^(first+i) * g1 (kzg.rs:33-36) for shard offsets on both sides of the alpha-table limit
+    and counts that leave a ragged batch-inversion tail."""
+    torch, mz, L, dev, st = env
+    alpha = 0x1234567890abcdef1234567890abcdef % orc.P_FR
+    g = (1, 2)
+    scal = orc.to_limbs([pow(alpha, first + i, orc.P_FR) for i in range(count)], 4)
+    want = orc.fixed_base_batch(g, scal)
+    a_l, g_l = orc.to_limbs([alpha], 4), orc.pts_to_arr([g])
+    out = torch.zeros((count, 8), dtype=torch.int64, device=dev)
+    _ok(L, L.mzk_kzg_setup_g1_range_dev(a_l.ctypes.data_as(ctypes.c_void_p), g_l.ctypes.data_as(ctypes.c_void_p),
+                                        ctypes.c_size_t(first), ctypes.c_size_t(count), _dp(out), st))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+
+
+def test_setup_alpha_zero_gives_g_then_infinity(env):
+    """alpha = 0: powers = [g, inf, inf, ...] -- the batched inversion must pass infinities through."""
+    torch, mz, L, dev, st = env
+    a_l, g_l = orc.to_limbs([0], 4), orc.pts_to_arr([(1, 2)])
+    out = torch.ones((20, 8), dtype=torch.int64, device=dev)
+    _ok(L, L.mzk_kzg_setup_g1_range_dev(a_l.ctypes.data_as(ctypes.c_void_p), g_l.ctypes.data_as(ctypes.c_void_p),
+                                        ctypes.c_size_t(0), ctypes.c_size_t(20), _dp(out), st))
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().view(np.uint64)
+    assert np.array_equal(o[0], g_l[0]) and not o[1:].any()
