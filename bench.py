@@ -133,6 +133,11 @@ def main():
         check(L.mzk_coset_lde_dev(mz.FIELD_M128, dptr(m_in), ctypes.c_size_t(n // 4), m_off.ctypes.data_as(ctypes.c_void_p),
                                   m_root.ctypes.data_as(ctypes.c_void_p), dptr(m_out), ctypes.c_size_t(n), stream))
 
+    def merkle_m128_step():
+        check(L.mzk_merkle_commit_field_dev(mz.FIELD_M128, dptr(m_out), ctypes.c_size_t(n), mk_root, ctypes.c_size_t(48), ctypes.byref(mk_len), stream))
+
+    mk_root, mk_len = (ctypes.c_uint8 * 48)(), ctypes.c_size_t()
+
     def ntt_step():
         check(L.mzk_ntt_dev(mz.FIELD_FR, root.ctypes.data_as(ctypes.c_void_p), dptr(ntt_in), dptr(ntt_out), ctypes.c_size_t(n), 0, stream))
 
@@ -195,6 +200,12 @@ def main():
     ok_lde = rc == 0 and np.array_equal(want_lde.view(np.int64).reshape(-1), m_out.cpu().numpy())
     assert ok_lde, "rank %d: M128 coset LDE mismatch vs CPU oracle" % rank
     parity["m128_coset_lde_bit_exact_vs_cpu"] = bool(ok_lde)
+    # Merkle root of that LDE codeword (fri.rs:160-166) vs the oracle's literal recursion over the same leaves
+    mroot, mlen = (ctypes.c_uint8 * 48)(), ctypes.c_size_t()
+    check(L.mzk_merkle_commit_field_dev(mz.FIELD_M128, dptr(m_out), ctypes.c_size_t(n), mroot, ctypes.c_size_t(48), ctypes.byref(mlen), stream))
+    ok_merkle = bytes(mroot[:mlen.value]) == orc.merkle_commit_field_ref(orc.M128, want_lde)
+    assert ok_merkle, "rank %d: Merkle root mismatch vs CPU oracle" % rank
+    parity["m128_codeword_merkle_root_bit_exact_vs_cpu"] = bool(ok_merkle)
     del s_cpu, p_cpu, v_cpu, want_ntt, c_cpu, sc_all, want_lde, vals
 
     # ------------------------------------------------------------------ timed regions
@@ -220,7 +231,7 @@ def main():
         dt = time.perf_counter() - t0
         L.mzk_prof_enable(0)
         phases = {}
-        for ph in range(10):
+        for ph in range(11):
             ms, cnt = ctypes.c_double(0), ctypes.c_uint64(0)
             check(L.mzk_prof_read(ph, ctypes.byref(ms), ctypes.byref(cnt)))
             if cnt.value:
@@ -235,6 +246,7 @@ def main():
     ntt_dt, ntt_ph = timed(ntt_step, K, W)
     nttm_dt, nttm_ph = timed(ntt_m128_step, K, W)
     lde_dt, lde_ph = timed(lde_m128_step, K, W)
+    mk_dt, mk_ph = timed(merkle_m128_step, K, W)
 
     msm_ms = msm_dt / K * 1e3
     ntt_ms = ntt_dt / K * 1e3
@@ -309,6 +321,9 @@ def main():
                      "roofline": dict(hbm_roofline(32.0 * n, sum(v["avg_ms"] for k, v in nttm_ph.items() if k.startswith("ntt_pass"))), kernel="k_ntt_strided + k_ntt_last (whole transform)", algorithmic_bytes_per_launch=32 * n)},
         "coset_lde_m128": {"metric": "LDE output elems/sec (fast_coset_evaluate, ntt.rs:254-269; blow-up 4)", "value": world * n / (lde_dt / K), "unit": "elems/s",
                            "ms_per_step": lde_dt / K * 1e3, "n_coef": n // 4, "order": n, "phases": lde_ph},
+        "merkle_m128": {"metric": "Merkle::commit of a codeword, SHA3-256 hashes/sec (merkle.rs:15-25 over bincode leaves, fri.rs:160-166; "
+                                  "root copied to the host every step as FRI::commit needs it for the transcript)",
+                        "value": world * (n - 1) / (mk_dt / K), "unit": "hashes/s", "ms_per_step": mk_dt / K * 1e3, "leaves": n, "phases": mk_ph},
         "alu_roofline": alu,
         "hbm_copy_GBps_measured": copy_gbps,
         "parity": parity,

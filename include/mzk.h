@@ -105,6 +105,37 @@ int mzk_fri_fold(int field_id, const uint64_t* codeword, size_t n, const uint64_
 int mzk_fri_fold_dev(int field_id, const void* d_codeword, size_t n, const uint64_t* alpha_host,
                      const uint64_t* offset_host, const uint64_t* omega_host, void* d_out, void* stream);
 
+/* ---- SHA3-256 Merkle trees over codewords (algebra/merkle.rs:15-46 as called from zkstark/fri.rs:160-166,
+ * 236-249 and fast_stark.rs:64-68, 237-241): leaves are bincode(FiniteFieldElement) of the canonical elements and
+ * are not hashed themselves; a one-leaf tree commits to the leaf bytes.  n must be a power of two (the provers
+ * only ever commit to codewords of such lengths); n = 0 is an error.  A handle keeps its own copy of the leaves
+ * and all node levels in HBM so that many paths can be opened against one codeword. */
+typedef struct mzk_merkle mzk_merkle;
+int mzk_merkle_build_field(int field_id, const uint64_t* elems, size_t n, mzk_merkle** out);
+int mzk_merkle_build_field_dev(int field_id, const void* d_elems, size_t n, mzk_merkle** out, void* stream);
+/* generic Merkle::commit input: leaf i = leaves[offsets[i] .. offsets[i+1]) (n + 1 offsets), any lengths */
+int mzk_merkle_build_bytes(const uint8_t* leaves, const uint64_t* offsets, size_t n, mzk_merkle** out);
+/* root: 32 bytes, or the leaf itself when n == 1 (merkle.rs:17-19); cap = capacity of `root` */
+int mzk_merkle_root(const mzk_merkle* tree, uint8_t* root, size_t cap, size_t* root_len);
+/* Merkle::open (merkle.rs:28-46): entry k of the bottom-up path goes to path + k * stride, its length to
+ * path_len[k] (entry 0 is the sibling leaf verbatim, the rest are 32-byte digests); *depth = log2 n entries. */
+int mzk_merkle_open(const mzk_merkle* tree, size_t index, uint8_t* path, size_t stride, uint64_t* path_len, size_t* depth);
+void mzk_merkle_free(mzk_merkle* tree);
+/* one-shot Merkle::commit(codeword.map(bincode::serialize)) */
+int mzk_merkle_commit_field(int field_id, const uint64_t* elems, size_t n, uint8_t* root, size_t cap, size_t* root_len);
+int mzk_merkle_commit_field_dev(int field_id, const void* d_elems, size_t n, uint8_t* root_host, size_t cap, size_t* root_len,
+                                void* stream);
+int mzk_merkle_commit_bytes(const uint8_t* leaves, const uint64_t* offsets, size_t n, uint8_t* root, size_t cap, size_t* root_len);
+
+/* FRI::commit (zkstark/fri.rs:144-209), codewords resident in HBM across all rounds.  Round r: the Merkle root of
+ * codeword_r is handed to `challenge` (which owns the proof stream: push the root, and unless `last` sample
+ * alpha = F::sample(prover_fiat_shamir(32)) into alpha_out, canonical limbs); then split-and-fold, omega and
+ * offset squared.  roots: num_rounds x 48 bytes (root_len[r] = 32, or the leaf length once a codeword has one
+ * element); codewords_out: the num_rounds codewords concatenated (n + n/2 + ... elements). */
+typedef void (*mzk_fri_challenge_fn)(void* user, int round, int last, const uint8_t* root, size_t root_len, uint64_t* alpha_out);
+int mzk_fri_commit(int field_id, const uint64_t* codeword, size_t n, const uint64_t* omega, const uint64_t* offset, int num_rounds,
+                   mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out);
+
 /* Device-resident SRS for repeated commits against one PublicKeyKZG.powers_1 (kzg.rs:8-11). */
 typedef struct mzk_srs mzk_srs;
 int mzk_srs_upload(const uint64_t* powers_xy, size_t n, mzk_srs** out);
@@ -154,7 +185,7 @@ int mzk_synth_g1_points_dev(uint64_t seed, size_t n, void* d_out_xy, void* strea
 /* ---- per-phase device timing (HIP events recorded on the launch stream around each kernel group) ---- */
 enum { MZK_PH_MSM_PREPARE = 0, MZK_PH_MSM_SORT = 1, MZK_PH_MSM_ACCUMULATE = 2, MZK_PH_MSM_REDUCE = 3,
        MZK_PH_MSM_COMBINE = 4, MZK_PH_NTT_PASS0 = 5, MZK_PH_NTT_PASS1 = 6, MZK_PH_NTT_PASS2 = 7,
-       MZK_PH_NTT_PASS3 = 8, MZK_PH_NTT_PRESCALE = 9, MZK_PH_COUNT = 10 };
+       MZK_PH_NTT_PASS3 = 8, MZK_PH_NTT_PRESCALE = 9, MZK_PH_MERKLE = 10, MZK_PH_COUNT = 11 };
 int mzk_prof_enable(int on);
 int mzk_prof_reset(void);
 /* Synchronises the device, folds all pending event pairs, returns accumulated ms and launch count. */

@@ -257,3 +257,92 @@ class Srs:
             self.close()
         except Exception:
             pass
+
+
+class MerkleTree:
+    """Merkle::commit / Merkle::open (algebra/merkle.rs:15-46) over a codeword, resident in HBM.
+
+    Leaves are bincode(FiniteFieldElement) of the elements (zkstark/fri.rs:160-166) or arbitrary byte strings."""
+
+    def __init__(self, fid=None, elems=None, leaves=None):
+        self._h = ctypes.c_void_p()
+        if leaves is not None:
+            blob = b"".join(leaves)
+            off = np.zeros(len(leaves) + 1, dtype=np.uint64)
+            off[1:] = np.cumsum([len(x) for x in leaves], dtype=np.uint64) if leaves else []
+            buf = (ctypes.c_uint8 * max(len(blob), 1)).from_buffer_copy(blob or b"\0")
+            self.n = len(leaves)
+            self.stride = max([32] + [len(x) for x in leaves])
+            _check(lib().mzk_merkle_build_bytes(buf, _p(off), ctypes.c_size_t(self.n), ctypes.byref(self._h)))
+        else:
+            e = _arr(fid, elems)
+            self.n = e.shape[0]
+            self.stride = 48
+            _check(lib().mzk_merkle_build_field(fid, _p(e), ctypes.c_size_t(self.n), ctypes.byref(self._h)))
+
+    def root(self):
+        buf = (ctypes.c_uint8 * max(self.stride, 48))()
+        ln = ctypes.c_size_t()
+        _check(lib().mzk_merkle_root(self._h, buf, ctypes.c_size_t(len(buf)), ctypes.byref(ln)))
+        return bytes(buf[:ln.value])
+
+    def open(self, index):
+        depth_cap = max(self.n.bit_length(), 1)
+        buf = (ctypes.c_uint8 * (self.stride * depth_cap))()
+        lens = (ctypes.c_uint64 * depth_cap)()
+        depth = ctypes.c_size_t()
+        _check(lib().mzk_merkle_open(self._h, ctypes.c_size_t(index), buf, ctypes.c_size_t(self.stride), lens, ctypes.byref(depth)))
+        raw = bytes(buf)
+        return [raw[k * self.stride:k * self.stride + lens[k]] for k in range(depth.value)]
+
+    def close(self):
+        if self._h:
+            lib().mzk_merkle_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def merkle_commit_field(fid, elems):
+    """Merkle::commit(&codeword.map(bincode::serialize)) (fri.rs:160-166)."""
+    e = _arr(fid, elems)
+    buf = (ctypes.c_uint8 * 48)()
+    ln = ctypes.c_size_t()
+    _check(lib().mzk_merkle_commit_field(fid, _p(e), ctypes.c_size_t(e.shape[0]), buf, ctypes.c_size_t(48), ctypes.byref(ln)))
+    return bytes(buf[:ln.value])
+
+
+_FRI_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t,
+                           ctypes.POINTER(ctypes.c_uint64))
+
+
+def fri_commit(fid, codeword, omega, offset, num_rounds, challenge):
+    """FRI::commit (zkstark/fri.rs:144-209), codewords resident in HBM.  challenge(round, last, root_bytes) -> alpha
+    (int; ignored when last).  Returns (codewords, roots)."""
+    c = _arr(fid, codeword)
+    n, nl = c.shape[0], LIMBS[fid]
+
+    def cb(user, rnd, last, root, root_len, alpha_out):
+        a = challenge(rnd, bool(last), bytes(root[:root_len]))
+        a = int(a or 0)
+        for j in range(nl):
+            alpha_out[j] = (a >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+
+    total = sum(n >> r for r in range(num_rounds))
+    roots = (ctypes.c_uint8 * (48 * max(num_rounds, 1)))()
+    lens = (ctypes.c_uint64 * max(num_rounds, 1))()
+    allcw = np.zeros((max(total, 1), nl), dtype=np.uint64)
+    w, o = _one(fid, omega), _one(fid, offset)
+    fn = _FRI_CB(cb)
+    _check(lib().mzk_fri_commit(fid, _p(c), ctypes.c_size_t(n), _p(w), _p(o), int(num_rounds), fn, None, roots, lens, _p(allcw)))
+    cws, rts, at = [], [], 0
+    raw = bytes(roots)
+    for r in range(num_rounds):
+        cws.append(allcw[at:at + (n >> r)].copy())
+        rts.append(raw[48 * r:48 * r + lens[r]])
+        at += n >> r
+    return cws, rts

@@ -236,7 +236,7 @@ int mzk_prof_read(int phase, double* total_ms, uint64_t* launches) {
 }
 const char* mzk_prof_name(int phase) {
   static const char* names[MZK_PH_COUNT] = {"msm_prepare_points", "msm_digit_sort", "msm_bucket_accumulate", "msm_bucket_reduce",
-                                            "msm_window_combine", "ntt_pass0", "ntt_pass1", "ntt_pass2", "ntt_pass3", "ntt_coset_prescale"};
+                                            "msm_window_combine", "ntt_pass0", "ntt_pass1", "ntt_pass2", "ntt_pass3", "ntt_coset_prescale", "merkle_sha3_levels"};
   return (phase >= 0 && phase < MZK_PH_COUNT) ? names[phase] : "?";
 }
 

@@ -1,0 +1,530 @@
+// mzk_merkle.hip -- SHA3-256 Merkle trees over FRI / STARK codewords, device-resident.
+//
+// Replaces Merkle::commit / Merkle::open (merkle.rs:15-46) as the provers call them: leaves are
+// bincode(FiniteFieldElement) of each codeword element (fri.rs:160-166, fast_stark.rs:64-68) and are NOT hashed
+// themselves -- a one-leaf tree commits to the leaf bytes (merkle.rs:17-19), so a level-1 node is
+// SHA3(leaf_2i || leaf_2i+1) and every node above is SHA3(left32 || right32).  The leaf bytes are produced on
+// the fly from the canonical element (layout: see oracle/mzk_oracle_merkle.c header; unpinned third-party format).
+//
+// Work shape: n/2 + n/4 + ... one-block Keccak-f[1600] permutations (each message fits the 136-byte rate), pure
+// 64-bit logic ops -- ALU-bound, ~5k VALU ops per hash; algorithmic HBM traffic is S*n bytes in, 32*(n-1) out.
+#include "mzk_common.h"
+
+namespace mzk {
+
+typedef uint64_t u64;
+typedef uint8_t u8;
+
+template <int R> __device__ __forceinline__ u64 rotl64(u64 x) {
+  if constexpr (R == 0) return x;
+  else return (x << R) | (x >> (64 - R));
+}
+__constant__ u64 KECCAK_RC[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+    0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+    0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+    0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+
+// Keccak-f[1600], FIPS 202 section 3.2/3.3: theta, rho+pi (fused with the theta xor), chi, iota; lane (x, y) = a[x + 5y].
+__device__ __forceinline__ void keccak_f(u64 (&a)[25]) {
+#pragma unroll 1
+  for (int rnd = 0; rnd < 24; rnd++) {
+    const u64 c0 = a[0] ^ a[5] ^ a[10] ^ a[15] ^ a[20];
+    const u64 c1 = a[1] ^ a[6] ^ a[11] ^ a[16] ^ a[21];
+    const u64 c2 = a[2] ^ a[7] ^ a[12] ^ a[17] ^ a[22];
+    const u64 c3 = a[3] ^ a[8] ^ a[13] ^ a[18] ^ a[23];
+    const u64 c4 = a[4] ^ a[9] ^ a[14] ^ a[19] ^ a[24];
+    const u64 d0 = c4 ^ rotl64<1>(c1);
+    const u64 d1 = c0 ^ rotl64<1>(c2);
+    const u64 d2 = c1 ^ rotl64<1>(c3);
+    const u64 d3 = c2 ^ rotl64<1>(c4);
+    const u64 d4 = c3 ^ rotl64<1>(c0);
+    const u64 b0 = rotl64<0>(a[0] ^ d0);
+    const u64 b16 = rotl64<36>(a[5] ^ d0);
+    const u64 b7 = rotl64<3>(a[10] ^ d0);
+    const u64 b23 = rotl64<41>(a[15] ^ d0);
+    const u64 b14 = rotl64<18>(a[20] ^ d0);
+    const u64 b10 = rotl64<1>(a[1] ^ d1);
+    const u64 b1 = rotl64<44>(a[6] ^ d1);
+    const u64 b17 = rotl64<10>(a[11] ^ d1);
+    const u64 b8 = rotl64<45>(a[16] ^ d1);
+    const u64 b24 = rotl64<2>(a[21] ^ d1);
+    const u64 b20 = rotl64<62>(a[2] ^ d2);
+    const u64 b11 = rotl64<6>(a[7] ^ d2);
+    const u64 b2 = rotl64<43>(a[12] ^ d2);
+    const u64 b18 = rotl64<15>(a[17] ^ d2);
+    const u64 b9 = rotl64<61>(a[22] ^ d2);
+    const u64 b5 = rotl64<28>(a[3] ^ d3);
+    const u64 b21 = rotl64<55>(a[8] ^ d3);
+    const u64 b12 = rotl64<25>(a[13] ^ d3);
+    const u64 b3 = rotl64<21>(a[18] ^ d3);
+    const u64 b19 = rotl64<56>(a[23] ^ d3);
+    const u64 b15 = rotl64<27>(a[4] ^ d4);
+    const u64 b6 = rotl64<20>(a[9] ^ d4);
+    const u64 b22 = rotl64<39>(a[14] ^ d4);
+    const u64 b13 = rotl64<8>(a[19] ^ d4);
+    const u64 b4 = rotl64<14>(a[24] ^ d4);
+    a[0] = b0 ^ (~b1 & b2);
+    a[1] = b1 ^ (~b2 & b3);
+    a[2] = b2 ^ (~b3 & b4);
+    a[3] = b3 ^ (~b4 & b0);
+    a[4] = b4 ^ (~b0 & b1);
+    a[5] = b5 ^ (~b6 & b7);
+    a[6] = b6 ^ (~b7 & b8);
+    a[7] = b7 ^ (~b8 & b9);
+    a[8] = b8 ^ (~b9 & b5);
+    a[9] = b9 ^ (~b5 & b6);
+    a[10] = b10 ^ (~b11 & b12);
+    a[11] = b11 ^ (~b12 & b13);
+    a[12] = b12 ^ (~b13 & b14);
+    a[13] = b13 ^ (~b14 & b10);
+    a[14] = b14 ^ (~b10 & b11);
+    a[15] = b15 ^ (~b16 & b17);
+    a[16] = b16 ^ (~b17 & b18);
+    a[17] = b17 ^ (~b18 & b19);
+    a[18] = b18 ^ (~b19 & b15);
+    a[19] = b19 ^ (~b15 & b16);
+    a[20] = b20 ^ (~b21 & b22);
+    a[21] = b21 ^ (~b22 & b23);
+    a[22] = b22 ^ (~b23 & b24);
+    a[23] = b23 ^ (~b24 & b20);
+    a[24] = b24 ^ (~b20 & b21);
+    a[0] ^= KECCAK_RC[rnd];
+  }
+}
+
+constexpr int SHA3_RATE = 136;
+
+// hash of one 64-byte message (two child digests): a[0..7] = data, pad 0x06 at byte 64, 0x80 at byte 135
+__device__ __forceinline__ void sha3_of_two_digests(const u64* __restrict__ children, u64* __restrict__ out) {
+  u64 a[25];
+  const ulonglong2* c2 = reinterpret_cast<const ulonglong2*>(children);
+#pragma unroll
+  for (int i = 0; i < 4; i++) { ulonglong2 v = c2[i]; a[2 * i] = v.x; a[2 * i + 1] = v.y; }
+  a[8] = 0x06ULL;
+#pragma unroll
+  for (int i = 9; i < 25; i++) a[i] = 0;
+  a[16] = 0x8000000000000000ULL;
+  keccak_f(a);
+  ulonglong2* o2 = reinterpret_cast<ulonglong2*>(out);
+  o2[0] = make_ulonglong2(a[0], a[1]);
+  o2[1] = make_ulonglong2(a[2], a[3]);
+}
+
+// ---- level 1 from field elements -----------------------------------------------------------------------
+// One lane per leaf pair.  The pair's message (<= 2 * (9 + 4 NW) <= 82 bytes) is serialised bytewise into a
+// word-major LDS block buffer, padded, and absorbed as 17 lanes.
+constexpr int LEAF_THREADS = 128;
+template <int NW>
+__global__ __launch_bounds__(LEAF_THREADS) void k_merkle_leaf_pairs(const u32* __restrict__ elems, size_t pairs, u64* __restrict__ nodes) {
+  __shared__ u32 blk[SHA3_RATE / 4][LEAF_THREADS];
+  const int tid = threadIdx.x;
+  const size_t i = (size_t)blockIdx.x * LEAF_THREADS + tid;
+  if (i >= pairs) return;
+#pragma unroll
+  for (int w = 0; w < SHA3_RATE / 4; w++) blk[w][tid] = 0;
+  auto put = [&](int pos, u32 byte) { reinterpret_cast<u8*>(&blk[pos >> 2][tid])[pos & 3] = (u8)byte; };
+  int pos = 0;
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    u32 w[NW];
+    const uint4* p4 = reinterpret_cast<const uint4*>(elems + (2 * i + e) * NW);
+#pragma unroll
+    for (int q = 0; q < NW / 4; q++) { uint4 v = p4[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+    int k = 0;                                    // significant u32 digits (BigUint keeps no leading zero digit)
+#pragma unroll
+    for (int j = 0; j < NW; j++) if (w[j]) k = j + 1;
+    put(pos, k ? 1u : 0u);                         // Sign::Plus / Sign::NoSign as i8
+    put(pos + 1, (u32)k);                          // sequence length as u64 LE (k <= 8: one non-zero byte)
+    pos += 9;
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+      if (j < k) {
+        put(pos, w[j] & 255u); put(pos + 1, (w[j] >> 8) & 255u); put(pos + 2, (w[j] >> 16) & 255u); put(pos + 3, w[j] >> 24);
+        pos += 4;
+      }
+    }
+  }
+  put(pos, 0x06u);
+  reinterpret_cast<u8*>(&blk[(SHA3_RATE - 1) >> 2][tid])[3] |= 0x80u;
+  u64 a[25];
+#pragma unroll
+  for (int l = 0; l < SHA3_RATE / 8; l++) a[l] = (u64)blk[2 * l][tid] | ((u64)blk[2 * l + 1][tid] << 32);
+#pragma unroll
+  for (int l = SHA3_RATE / 8; l < 25; l++) a[l] = 0;
+  keccak_f(a);
+  ulonglong2* o2 = reinterpret_cast<ulonglong2*>(nodes + 4 * i);
+  o2[0] = make_ulonglong2(a[0], a[1]);
+  o2[1] = make_ulonglong2(a[2], a[3]);
+}
+
+// ---- level 1 from arbitrary byte leaves: leaf 2i || leaf 2i+1 is the contiguous range off[2i] .. off[2i+2) ---
+__global__ __launch_bounds__(128) void k_merkle_leaf_pairs_bytes(const u8* __restrict__ leaves, const u64* __restrict__ off, size_t pairs,
+                                                                 u64* __restrict__ nodes) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pairs) return;
+  const u8* msg = leaves + off[2 * i];
+  const size_t len = (size_t)(off[2 * i + 2] - off[2 * i]);
+  u64 a[25];
+#pragma unroll
+  for (int l = 0; l < 25; l++) a[l] = 0;
+  size_t base = 0;
+  for (;;) {
+    const bool last = (len - base) < (size_t)SHA3_RATE;      // the padded final block
+#pragma unroll
+    for (int l = 0; l < SHA3_RATE / 8; l++) {
+      u64 wv = 0;
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        const size_t idx = base + 8 * l + t;
+        u64 b = idx < len ? (u64)msg[idx] : (idx == len ? 0x06ULL : 0ULL);
+        wv |= b << (8 * t);
+      }
+      a[l] ^= wv;
+    }
+    if (last) a[SHA3_RATE / 8 - 1] ^= 0x8000000000000000ULL;
+    keccak_f(a);
+    if (last) break;
+    base += SHA3_RATE;
+  }
+  ulonglong2* o2 = reinterpret_cast<ulonglong2*>(nodes + 4 * i);
+  o2[0] = make_ulonglong2(a[0], a[1]);
+  o2[1] = make_ulonglong2(a[2], a[3]);
+}
+
+// ---- inner levels -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_merkle_level(const u64* __restrict__ below, size_t count, u64* __restrict__ above) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  sha3_of_two_digests(below + 8 * i, above + 4 * i);
+}
+// the last levels (<= TAIL_NODES nodes each) in one workgroup: no launch per level
+constexpr int TAIL_NODES = 512;
+__global__ __launch_bounds__(TAIL_NODES) void k_merkle_tail(u64* __restrict__ level, size_t count) {
+  // `level` holds `count` nodes; the levels above follow contiguously (count/2, count/4, ... 1)
+  u64* below = level;
+  while (count > 1) {
+    const size_t up = count / 2;
+    u64* above = below + 4 * count;
+    if (threadIdx.x < up) sha3_of_two_digests(below + 8 * threadIdx.x, above + 4 * threadIdx.x);
+    __threadfence_block();
+    __syncthreads();
+    below = above;
+    count = up;
+  }
+}
+// authentication path: node (index >> l) ^ 1 of level l, l = 1 .. depth-1; level l starts at node n - n / 2^(l-1)
+__global__ void k_merkle_gather(const u64* __restrict__ nodes, size_t n, size_t index, int depth, u64* __restrict__ out) {
+  const int l = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= depth) return;
+  const size_t start = n - (n >> (l - 1));
+  const u64* src = nodes + 4 * (start + ((index >> l) ^ 1));
+#pragma unroll
+  for (int q = 0; q < 4; q++) out[4 * (l - 1) + q] = src[q];
+}
+
+}  // namespace mzk
+
+using namespace mzk;
+
+struct mzk_merkle {
+  int kind;              // 0 = field elements, 1 = byte leaves
+  int field;
+  size_t n;
+  int depth;             // log2 n
+  u64* d_nodes;          // n - 1 digests: level 1 (n/2), level 2 (n/4), ..., root
+  void* d_leaves;        // owned copy of the elements / the leaf bytes (needed by open and by n == 1)
+  std::vector<uint64_t> offsets;   // byte leaves only
+  hipStream_t stream;
+};
+
+namespace mzk {
+static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+
+// hashes level 1 .. root into d_nodes; d_leaves / d_off already on the device
+static int merkle_hash_levels(int kind, int fid, const void* d_leaves, const u64* d_off, size_t n, u64* d_nodes, hipStream_t s) {
+  if (n < 2) return MZK_OK;
+  ProfScope ps(s, MZK_PH_MERKLE);
+  const size_t pairs = n / 2;
+  const unsigned blocks = (unsigned)((pairs + 127) / 128);
+  if (kind == 1)
+    hipLaunchKernelGGL(k_merkle_leaf_pairs_bytes, dim3(blocks), dim3(128), 0, s, (const u8*)d_leaves, d_off, pairs, d_nodes);
+  else if (fid == MZK_FIELD_M128)
+    hipLaunchKernelGGL((k_merkle_leaf_pairs<4>), dim3(blocks), dim3(LEAF_THREADS), 0, s, (const u32*)d_leaves, pairs, d_nodes);
+  else
+    hipLaunchKernelGGL((k_merkle_leaf_pairs<8>), dim3(blocks), dim3(LEAF_THREADS), 0, s, (const u32*)d_leaves, pairs, d_nodes);
+  u64* below = d_nodes;
+  size_t count = pairs;
+  while (count > (size_t)TAIL_NODES) {
+    u64* above = below + 4 * count;
+    hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((count / 2 + 127) / 128)), dim3(128), 0, s, (const u64*)below, count / 2, above);
+    below = above;
+    count /= 2;
+  }
+  if (count > 1) hipLaunchKernelGGL(k_merkle_tail, dim3(1), dim3(TAIL_NODES), 0, s, below, count);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+
+// bincode(FiniteFieldElement) of ONE canonical element on the host: used for the n == 1 root and for the
+// sibling leaf of an authentication path (both are a copy of input bytes, not computation).
+static size_t host_bincode_field(const uint64_t* limbs, int nl, uint8_t* out) {
+  int k = 2 * nl;
+  while (k > 0 && (uint32_t)(limbs[(k - 1) / 2] >> (32 * ((k - 1) & 1))) == 0) k--;
+  out[0] = k ? 1 : 0;
+  uint64_t len = (uint64_t)k;
+  memcpy(out + 1, &len, 8);
+  for (int i = 0; i < k; i++) { uint32_t d = (uint32_t)(limbs[i / 2] >> (32 * (i & 1))); memcpy(out + 9 + 4 * i, &d, 4); }
+  return 9 + 4 * (size_t)k;
+}
+
+static int merkle_build(int kind, int fid, const void* src, bool src_on_device, size_t leaf_bytes, const uint64_t* offsets, size_t n,
+                        mzk_merkle** out, hipStream_t s) {
+  if (!out) { set_error("merkle: null output handle"); return MZK_E_ARG; }
+  *out = nullptr;
+  if (n == 0) { set_error("merkle: empty leaf set (Merkle::commit recurses forever on it, merkle.rs:20-22)"); return MZK_E_LENGTH; }
+  if (!is_pow2(n)) { set_error("merkle: leaf count must be a power of two"); return MZK_E_NOT_POW2; }
+  if (!src) { set_error("merkle: null pointer"); return MZK_E_ARG; }
+  mzk_merkle* t = new mzk_merkle();
+  t->kind = kind; t->field = fid; t->n = n; t->stream = s; t->d_nodes = nullptr; t->d_leaves = nullptr;
+  t->depth = 0;
+  while (((size_t)1 << t->depth) < n) t->depth++;
+  u64* d_off = nullptr;
+  int rc = MZK_OK;
+  do {
+    if (hipMalloc(&t->d_leaves, leaf_bytes ? leaf_bytes : 16) != hipSuccess) { set_error("merkle: hipMalloc failed"); rc = MZK_E_HIP; break; }
+    if (leaf_bytes && hipMemcpyAsync(t->d_leaves, src, leaf_bytes, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s) != hipSuccess) {
+      set_error("merkle: leaf copy failed"); rc = MZK_E_HIP; break;
+    }
+    if (n > 1 && hipMalloc((void**)&t->d_nodes, (n - 1) * 32) != hipSuccess) { set_error("merkle: hipMalloc failed"); rc = MZK_E_HIP; break; }
+    if (kind == 1) {
+      t->offsets.assign(offsets, offsets + n + 1);
+      if ((rc = ws_get(WS_MISC_D, (n + 1) * 8, (void**)&d_off)) != MZK_OK) break;
+      if (hipMemcpyAsync(d_off, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess) { set_error("merkle: offset copy failed"); rc = MZK_E_HIP; break; }
+    }
+    rc = merkle_hash_levels(kind, fid, t->d_leaves, d_off, n, t->d_nodes, s);
+    if (rc == MZK_OK && kind == 1 && hipStreamSynchronize(s) != hipSuccess) { set_error("merkle: sync failed"); rc = MZK_E_HIP; }
+  } while (0);
+  if (rc != MZK_OK) { if (t->d_leaves) (void)hipFree(t->d_leaves); if (t->d_nodes) (void)hipFree(t->d_nodes); delete t; return rc; }
+  *out = t;
+  return MZK_OK;
+}
+}  // namespace mzk
+
+extern "C" {
+
+int mzk_merkle_build_field_dev(int field_id, const void* d_elems, size_t n, mzk_merkle** out, void* stream) {
+  MZK_TRY(ensure_init());
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("merkle: bad field id %d", field_id); return MZK_E_ARG; }
+  return merkle_build(0, field_id, d_elems, true, n * field_bytes(field_id), nullptr, n, out, (hipStream_t)stream);
+}
+int mzk_merkle_build_field(int field_id, const uint64_t* elems, size_t n, mzk_merkle** out) {
+  MZK_TRY(ensure_init());
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("merkle: bad field id %d", field_id); return MZK_E_ARG; }
+  if (elems) {
+    const HostField* hf = host_field(field_id);
+    for (size_t i = 0; i < n; i++)
+      if (!h_is_canonical(hf, elems + (size_t)hf->nl * i)) { set_error("merkle: element %zu not canonical", i); return MZK_E_RANGE; }
+  }
+  MZK_TRY(merkle_build(0, field_id, elems, false, n * field_bytes(field_id), nullptr, n, out, ctx().stream));
+  MZK_HIP(hipStreamSynchronize(ctx().stream));
+  return MZK_OK;
+}
+int mzk_merkle_build_bytes(const uint8_t* leaves, const uint64_t* offsets, size_t n, mzk_merkle** out) {
+  MZK_TRY(ensure_init());
+  if (!offsets) { set_error("merkle: null offsets"); return MZK_E_ARG; }
+  for (size_t i = 0; i < n; i++)
+    if (offsets[i + 1] < offsets[i]) { set_error("merkle: offsets must be non-decreasing"); return MZK_E_ARG; }
+  const size_t total = n ? (size_t)(offsets[n] - offsets[0]) : 0;
+  uint8_t dummy = 0;
+  if (!leaves) { if (total) { set_error("merkle: null pointer"); return MZK_E_ARG; } leaves = &dummy; }
+  // offsets are rebased to the copied range
+  std::vector<uint64_t> off(n + 1);
+  for (size_t i = 0; i <= n; i++) off[i] = offsets[i] - offsets[0];
+  return merkle_build(1, -1, leaves + offsets[0], false, total, off.data(), n, out, ctx().stream);
+}
+
+int mzk_merkle_root(const mzk_merkle* t, uint8_t* root, size_t cap, size_t* root_len) {
+  if (!t || !root || !root_len) { set_error("merkle_root: null pointer"); return MZK_E_ARG; }
+  if (t->n == 1) {   // merkle.rs:17-19: the single leaf itself
+    uint8_t buf[48];
+    size_t len;
+    if (t->kind == 0) {
+      uint64_t limbs[4];
+      MZK_HIP(hipMemcpyAsync(limbs, t->d_leaves, field_bytes(t->field), hipMemcpyDeviceToHost, t->stream));
+      MZK_HIP(hipStreamSynchronize(t->stream));
+      len = host_bincode_field(limbs, field_limbs64(t->field), buf);
+      if (cap < len) { set_error("merkle_root: buffer too small (%zu < %zu)", cap, len); return MZK_E_LENGTH; }
+      memcpy(root, buf, len);
+    } else {
+      len = (size_t)(t->offsets[1] - t->offsets[0]);
+      if (cap < len) { set_error("merkle_root: buffer too small (%zu < %zu)", cap, len); return MZK_E_LENGTH; }
+      if (len) MZK_HIP(hipMemcpyAsync(root, t->d_leaves, len, hipMemcpyDeviceToHost, t->stream));
+      MZK_HIP(hipStreamSynchronize(t->stream));
+    }
+    *root_len = len;
+    return MZK_OK;
+  }
+  if (cap < 32) { set_error("merkle_root: buffer too small"); return MZK_E_LENGTH; }
+  MZK_HIP(hipMemcpyAsync(root, t->d_nodes + 4 * (t->n - 2), 32, hipMemcpyDeviceToHost, t->stream));
+  MZK_HIP(hipStreamSynchronize(t->stream));
+  *root_len = 32;
+  return MZK_OK;
+}
+
+int mzk_merkle_open(const mzk_merkle* t, size_t index, uint8_t* path, size_t stride, uint64_t* path_len, size_t* depth) {
+  if (!t || !path || !path_len || !depth) { set_error("merkle_open: null pointer"); return MZK_E_ARG; }
+  if (t->n < 2) { set_error("merkle_open: needs at least two leaves (merkle.rs:32)"); return MZK_E_LENGTH; }
+  if (index >= t->n) { set_error("merkle_open: index %zu out of range", index); return MZK_E_LENGTH; }
+  if (stride < 32) { set_error("merkle_open: stride < 32"); return MZK_E_LENGTH; }
+  hipStream_t s = t->stream;
+  const size_t sib = index ^ 1;
+  // entry 0: the sibling LEAF, verbatim
+  if (t->kind == 0) {
+    uint64_t limbs[4];
+    uint8_t buf[48];
+    MZK_HIP(hipMemcpyAsync(limbs, (const uint8_t*)t->d_leaves + sib * field_bytes(t->field), field_bytes(t->field), hipMemcpyDeviceToHost, s));
+    MZK_HIP(hipStreamSynchronize(s));
+    const size_t len = host_bincode_field(limbs, field_limbs64(t->field), buf);
+    if (stride < len) { set_error("merkle_open: stride %zu < leaf length %zu", stride, len); return MZK_E_LENGTH; }
+    memcpy(path, buf, len);
+    path_len[0] = len;
+  } else {
+    const size_t len = (size_t)(t->offsets[sib + 1] - t->offsets[sib]);
+    if (stride < len) { set_error("merkle_open: stride %zu < leaf length %zu", stride, len); return MZK_E_LENGTH; }
+    if (len) MZK_HIP(hipMemcpyAsync(path, (const uint8_t*)t->d_leaves + t->offsets[sib], len, hipMemcpyDeviceToHost, s));
+    path_len[0] = len;
+  }
+  if (t->depth > 1) {
+    u64* d_out;
+    MZK_TRY(ws_get(WS_MISC_C, (size_t)t->depth * 32, (void**)&d_out));
+    hipLaunchKernelGGL(k_merkle_gather, dim3(1), dim3(64), 0, s, (const u64*)t->d_nodes, t->n, index, t->depth, d_out);
+    MZK_HIP(hipGetLastError());
+    uint8_t tmp[64 * 32];
+    MZK_HIP(hipMemcpyAsync(tmp, d_out, (size_t)(t->depth - 1) * 32, hipMemcpyDeviceToHost, s));
+    MZK_HIP(hipStreamSynchronize(s));
+    for (int l = 1; l < t->depth; l++) { memcpy(path + (size_t)l * stride, tmp + 32 * (l - 1), 32); path_len[l] = 32; }
+  } else {
+    MZK_HIP(hipStreamSynchronize(s));
+  }
+  *depth = (size_t)t->depth;
+  return MZK_OK;
+}
+
+void mzk_merkle_free(mzk_merkle* t) {
+  if (!t) return;
+  if (t->d_leaves) (void)hipFree(t->d_leaves);
+  if (t->d_nodes) (void)hipFree(t->d_nodes);
+  delete t;
+}
+
+// One-shot commit of a device-resident codeword (the FRI round: root -> transcript -> alpha -> fold); nothing is
+// retained, the node levels live in workspace.  root: 32 bytes (n >= 2) or the leaf bytes (n == 1; cap >= 41).
+int mzk_merkle_commit_field_dev(int field_id, const void* d_elems, size_t n, uint8_t* root, size_t cap, size_t* root_len, void* stream) {
+  MZK_TRY(ensure_init());
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("merkle: bad field id %d", field_id); return MZK_E_ARG; }
+  if (n == 0) { set_error("merkle: empty leaf set (Merkle::commit recurses forever on it, merkle.rs:20-22)"); return MZK_E_LENGTH; }
+  if (!is_pow2(n)) { set_error("merkle: leaf count must be a power of two"); return MZK_E_NOT_POW2; }
+  if (!d_elems || !root || !root_len) { set_error("merkle: null pointer"); return MZK_E_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 1) {
+    uint64_t limbs[4];
+    uint8_t buf[48];
+    MZK_HIP(hipMemcpyAsync(limbs, d_elems, field_bytes(field_id), hipMemcpyDeviceToHost, s));
+    MZK_HIP(hipStreamSynchronize(s));
+    const size_t len = host_bincode_field(limbs, field_limbs64(field_id), buf);
+    if (cap < len) { set_error("merkle: root buffer too small"); return MZK_E_LENGTH; }
+    memcpy(root, buf, len);
+    *root_len = len;
+    return MZK_OK;
+  }
+  if (cap < 32) { set_error("merkle: root buffer too small"); return MZK_E_LENGTH; }
+  u64* d_nodes;
+  MZK_TRY(ws_get(WS_MERKLE_NODES, (n - 1) * 32, (void**)&d_nodes));
+  MZK_TRY(merkle_hash_levels(0, field_id, d_elems, nullptr, n, d_nodes, s));
+  MZK_HIP(hipMemcpyAsync(root, d_nodes + 4 * (n - 2), 32, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  *root_len = 32;
+  return MZK_OK;
+}
+int mzk_merkle_commit_field(int field_id, const uint64_t* elems, size_t n, uint8_t* root, size_t cap, size_t* root_len) {
+  mzk_merkle* t = nullptr;
+  MZK_TRY(mzk_merkle_build_field(field_id, elems, n, &t));
+  const int rc = mzk_merkle_root(t, root, cap, root_len);
+  mzk_merkle_free(t);
+  return rc;
+}
+int mzk_merkle_commit_bytes(const uint8_t* leaves, const uint64_t* offsets, size_t n, uint8_t* root, size_t cap, size_t* root_len) {
+  mzk_merkle* t = nullptr;
+  MZK_TRY(mzk_merkle_build_bytes(leaves, offsets, n, &t));
+  const int rc = mzk_merkle_root(t, root, cap, root_len);
+  mzk_merkle_free(t);
+  return rc;
+}
+
+// FRI::commit (zkstark/fri.rs:144-209) with the codewords resident in HBM for the whole loop.  Per round r:
+//   root_r = Merkle::commit(codeword_r as bincode leaves)              fri.rs:160-168
+//   challenge(user, r, last, root_r, len, alpha)  -- the host pushes the root to its proof stream and, unless
+//                                                    `last`, samples alpha from it                 fri.rs:168-176
+//   codeword_{r+1} = split-and-fold(codeword_r, alpha, offset, omega); omega, offset squared      fri.rs:182-195
+// Outputs: roots (num_rounds entries of 48 bytes, lengths in root_len: 32, or the leaf bytes once a codeword has
+// shrunk to one element) and all num_rounds codewords concatenated (n + n/2 + ... elements) -- the reference's
+// return value `(codewords, roots)`; sending the last codeword (fri.rs:198-206) is the caller's transcript work.
+int mzk_fri_commit(int field_id, const uint64_t* codeword, size_t n, const uint64_t* omega, const uint64_t* offset, int num_rounds,
+                   mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out) {
+  MZK_TRY(ensure_init());
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fri_commit: bad field id %d", field_id); return MZK_E_ARG; }
+  if (num_rounds <= 0) return MZK_OK;
+  if (!codeword || !omega || !offset || !challenge || !roots || !root_len || !codewords_out) { set_error("fri_commit: null pointer"); return MZK_E_ARG; }
+  if (n == 0) { set_error("fri_commit: empty codeword"); return MZK_E_LENGTH; }
+  if (!is_pow2(n)) { set_error("fri_commit: codeword length must be a power of two"); return MZK_E_NOT_POW2; }
+  if ((n >> (num_rounds - 1)) == 0) { set_error("fri_commit: %d rounds halve a length-%zu codeword away", num_rounds, n); return MZK_E_LENGTH; }
+  const HostField* hf = host_field(field_id);
+  if (!h_is_canonical(hf, omega) || !h_is_canonical(hf, offset)) { set_error("fri_commit: parameter not canonical"); return MZK_E_RANGE; }
+  hipStream_t s = ctx().stream;
+  const size_t esz = field_bytes(field_id);
+  const int nl = hf->nl;
+  size_t total = 0;
+  for (int r = 0; r < num_rounds; r++) total += n >> r;
+  uint8_t* d_all;
+  u64* d_nodes;
+  MZK_TRY(ws_get(WS_NTT_IO_A, total * esz, (void**)&d_all));
+  MZK_TRY(ws_get(WS_MERKLE_NODES, n * 32, (void**)&d_nodes));
+  MZK_HIP(hipMemcpyAsync(d_all, codeword, n * esz, hipMemcpyHostToDevice, s));
+  uint64_t om[4], of[4], alpha[4];
+  memcpy(om, omega, 8 * nl);
+  memcpy(of, offset, 8 * nl);
+  uint8_t* cur = d_all;
+  size_t len = n;
+  for (int r = 0; r < num_rounds; r++) {
+    uint8_t* root = roots + 48 * (size_t)r;
+    if (len == 1) {
+      uint64_t limbs[4];
+      MZK_HIP(hipMemcpyAsync(limbs, cur, esz, hipMemcpyDeviceToHost, s));
+      MZK_HIP(hipStreamSynchronize(s));
+      root_len[r] = host_bincode_field(limbs, nl, root);
+    } else {
+      MZK_TRY(merkle_hash_levels(0, field_id, cur, nullptr, len, d_nodes, s));
+      MZK_HIP(hipMemcpyAsync(root, d_nodes + 4 * (len - 2), 32, hipMemcpyDeviceToHost, s));
+      MZK_HIP(hipStreamSynchronize(s));
+      root_len[r] = 32;
+    }
+    const int last = (r == num_rounds - 1);
+    memset(alpha, 0, sizeof alpha);
+    challenge(user, r, last, root, (size_t)root_len[r], alpha);
+    if (last) break;
+    if (!h_is_canonical(hf, alpha)) { set_error("fri_commit: challenge of round %d not canonical", r); return MZK_E_RANGE; }
+    uint8_t* next = cur + len * esz;
+    MZK_TRY(fri_fold_dev_impl(field_id, cur, len, alpha, of, om, next, s));
+    h_mulmod(hf, om, om, om);
+    h_mulmod(hf, of, of, of);
+    cur = next;
+    len /= 2;
+  }
+  MZK_HIP(hipMemcpyAsync(codewords_out, d_all, total * esz, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  return MZK_OK;
+}
+
+}  // extern "C"

@@ -12,6 +12,8 @@
 //   ntt / intt / fast_multiply / fast_coset_evaluate   algebra/ntt.rs:7-116, :254-269
 //   PublicKeyKZG, ProofKZG, setup_kzg_with_alpha / commit_kzg / open_kzg   algebra/kzg.rs:8-72
 //   get_nth_root_of_m128                     zkstark/fri.rs:423-447
+//   Merkle::commit / open, commit_codeword   algebra/merkle.rs:15-46, zkstark/fri.rs:160-166
+//   fri_split_and_fold, fri_commit           zkstark/fri.rs:144-209
 //
 // Values are held canonical (u64 limbs) -- the ABI wire format; arithmetic on single elements that the
 // reference does on the host (a handful of scalar ops in tests) is not offered here: this header only
@@ -22,6 +24,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 #include "../../include/mzk.h"
 
@@ -241,6 +244,80 @@ std::vector<F> fri_split_and_fold(const std::vector<F>& codeword, const F& alpha
   std::vector<uint64_t> out((codeword.size() / 2 + 1) * F().value.size());
   expect(mzk_fri_fold(Polynomial<F>::field_id(), c.data(), codeword.size(), alpha.value.data(), offset.value.data(), omega.value.data(), out.data()));
   return from_wire<F>(out, codeword.size() / 2);
+}
+
+
+// ---- Merkle (algebra/merkle.rs) and the FRI commit phase (zkstark/fri.rs:144-209) ------------------------
+typedef std::vector<uint8_t> MerkleRoot;               // merkle.rs:4
+typedef std::vector<std::vector<uint8_t>> MerklePath;  // merkle.rs:5
+struct Merkle {
+  static void flatten(const std::vector<std::vector<uint8_t>>& leafs, std::vector<uint8_t>& blob, std::vector<uint64_t>& off, size_t& stride) {
+    off.assign(1, 0);
+    stride = 32;
+    for (auto& l : leafs) { blob.insert(blob.end(), l.begin(), l.end()); off.push_back(blob.size()); if (l.size() > stride) stride = l.size(); }
+  }
+  static MerkleRoot commit(const std::vector<std::vector<uint8_t>>& leafs) {   // merkle.rs:15-25
+    std::vector<uint8_t> blob; std::vector<uint64_t> off; size_t stride;
+    flatten(leafs, blob, off, stride);
+    MerkleRoot root(stride);
+    size_t len = 0;
+    expect(mzk_merkle_commit_bytes(blob.data(), off.data(), leafs.size(), root.data(), root.size(), &len));
+    root.resize(len);
+    return root;
+  }
+  static MerklePath open(size_t index, const std::vector<std::vector<uint8_t>>& leafs) {   // merkle.rs:28-46
+    std::vector<uint8_t> blob; std::vector<uint64_t> off; size_t stride;
+    flatten(leafs, blob, off, stride);
+    mzk_merkle* t = nullptr;
+    expect(mzk_merkle_build_bytes(blob.data(), off.data(), leafs.size(), &t));
+    std::vector<uint8_t> buf(stride * 64);
+    uint64_t lens[64];
+    size_t depth = 0;
+    const int rc = mzk_merkle_open(t, index, buf.data(), stride, lens, &depth);
+    mzk_merkle_free(t);
+    expect(rc);
+    MerklePath path;
+    for (size_t k = 0; k < depth; k++) path.emplace_back(buf.begin() + k * stride, buf.begin() + k * stride + lens[k]);
+    return path;
+  }
+};
+// Merkle::commit(&codeword.map(|c| bincode::serialize(&c))) as the provers write it (fri.rs:160-166)
+template <class F> MerkleRoot commit_codeword(const std::vector<F>& codeword) {
+  auto c = to_wire(codeword);
+  MerkleRoot root(48);
+  size_t len = 0;
+  expect(mzk_merkle_commit_field(Polynomial<F>::field_id(), c.data(), codeword.size(), root.data(), root.size(), &len));
+  root.resize(len);
+  return root;
+}
+// FRI::commit (fri.rs:144-209): `challenge(round, last, root) -> alpha` owns the proof stream (push the root;
+// sample alpha unless last).  Returns (codewords, roots) like the reference.
+template <class F> struct FriCommitment { std::vector<std::vector<F>> codewords; std::vector<MerkleRoot> roots; };
+template <class F, class Fn>
+FriCommitment<F> fri_commit(const std::vector<F>& initial_codeword, const F& omega, const F& offset, int num_rounds, Fn&& challenge) {
+  typedef typename std::remove_reference<Fn>::type Callee;
+  struct Ctx { Callee* fn; } cx{&challenge};
+  auto tramp = [](void* user, int round, int last, const uint8_t* root, size_t root_len, uint64_t* alpha_out) {
+    F a = (*static_cast<Ctx*>(user)->fn)(round, last != 0, MerkleRoot(root, root + root_len));
+    std::memcpy(alpha_out, a.value.data(), 8 * a.value.size());
+  };
+  const size_t n = initial_codeword.size(), nl = F().value.size();
+  size_t total = 0;
+  for (int r = 0; r < num_rounds; r++) total += n >> r;
+  auto c = to_wire(initial_codeword);
+  std::vector<uint8_t> roots(48 * (size_t)(num_rounds > 0 ? num_rounds : 0) + 1);
+  std::vector<uint64_t> lens(num_rounds > 0 ? num_rounds : 1), all((total + 1) * nl);
+  expect(mzk_fri_commit(Polynomial<F>::field_id(), c.data(), n, omega.value.data(), offset.value.data(), num_rounds, +tramp, &cx, roots.data(),
+                        lens.data(), all.data()));
+  FriCommitment<F> out;
+  size_t at = 0;
+  for (int r = 0; r < num_rounds; r++) {
+    std::vector<uint64_t> w(all.begin() + at * nl, all.begin() + (at + (n >> r)) * nl);
+    out.codewords.push_back(from_wire<F>(w, n >> r));
+    out.roots.emplace_back(roots.begin() + 48 * r, roots.begin() + 48 * r + lens[r]);
+    at += n >> r;
+  }
+  return out;
 }
 
 }  // namespace myzkp

@@ -5,6 +5,8 @@
 //   test_g1             <- algebra/curve/bn128.rs:285-301 (relations, through the MSM)
 //   test_fast_multiply  <- algebra/ntt.rs:66-116 vs Polynomial::fft_multiply
 //   test_panics         <- ntt.rs:8-23, polynomial.rs:162 index panic
+//   test_merkle         <- algebra/merkle.rs:76-93
+//   test_fri_commit     <- zkstark/fri.rs:144-209 (commit phase; transcript stood in for by a deterministic challenge)
 #include <cstdio>
 #include <cstdlib>
 #include "../../myzkp_amd/host/myzkp.hpp"
@@ -15,6 +17,13 @@ int orc_poly_eval(int fid, const uint64_t* coef, size_t n, const uint64_t* x, ui
 int orc_field_pow(int fid, const uint64_t* a, const uint64_t* e, int ne, uint64_t* out);
 int orc_field_mul(int fid, const uint64_t* a, const uint64_t* b, uint64_t* out);
 int orc_ec_mul(int cid, const uint64_t* p_xy, const uint64_t* k, int nk, uint64_t* out_xy);
+int orc_merkle_verify_ref(const uint8_t* root, size_t root_len, size_t index, const uint8_t* path, const uint64_t* path_len, size_t stride,
+                          size_t depth, const uint8_t* leaf, size_t leaf_len);
+int orc_merkle_commit_ref(const uint8_t* leaves, const uint64_t* offsets, size_t n, uint8_t* root, size_t* root_len);
+void orc_bincode_field_vector(const uint64_t* elems, int nl, size_t n, uint8_t* leaves, uint64_t* offsets);
+int orc_fri_fold_ref(int fid, const uint64_t* codeword, size_t n, const uint64_t* alpha, const uint64_t* offset, const uint64_t* omega,
+                     uint64_t* out);
+void orc_synth_vector(int fid, uint64_t seed, size_t n, uint64_t* out, int nthreads);
 }
 static int failures = 0;
 #define CHECK(c) do { if (!(c)) { printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); failures++; } } while (0)
@@ -145,6 +154,71 @@ static void test_panics() {
   CHECK(caught);
 }
 
+static bool oracle_verify(const MerkleRoot& root, size_t index, const MerklePath& path, const std::vector<uint8_t>& leaf) {
+  size_t stride = 32;
+  for (auto& e : path) if (e.size() > stride) stride = e.size();
+  std::vector<uint8_t> buf(stride * path.size());
+  std::vector<uint64_t> lens;
+  for (size_t k = 0; k < path.size(); k++) { std::copy(path[k].begin(), path[k].end(), buf.begin() + k * stride); lens.push_back(path[k].size()); }
+  return orc_merkle_verify_ref(root.data(), root.size(), index, buf.data(), lens.data(), stride, path.size(), leaf.data(), leaf.size()) != 0;
+}
+static std::vector<uint8_t> bytes_of(const char* s) { return std::vector<uint8_t>(s, s + strlen(s)); }
+
+static void test_merkle() {   // merkle.rs:76-93
+  std::vector<std::vector<uint8_t>> leafs = {bytes_of("leaf1"), bytes_of("leaf2"), bytes_of("leaf3"), bytes_of("leaf4")};
+  MerkleRoot root = Merkle::commit(leafs);
+  size_t index = 2;
+  MerklePath proof = Merkle::open(index, leafs);
+  CHECK(oracle_verify(root, index, proof, leafs[index]));
+  CHECK(!oracle_verify(root, index, proof, leafs[index + 1]));
+}
+
+static void test_fri_commit() {   // fri.rs:144-209
+  typedef FiniteFieldElement<M128> F;
+  const size_t n = 1 << 10;
+  const int rounds = 5;
+  std::vector<uint64_t> raw(2 * n);
+  orc_synth_vector(MZK_FIELD_M128, 4242, n, raw.data(), 1);
+  std::vector<F> cw;
+  for (size_t i = 0; i < n; i++) cw.push_back(F::from_limbs(&raw[2 * i]));
+  F omega = get_nth_root_of_m128(10);
+  F offset = F::from_value(3);
+  std::vector<MerkleRoot> seen;
+  auto challenge = [&](int round, bool last, const MerkleRoot& root) {
+    seen.push_back(root);
+    F a = F::from_value(0);
+    if (!last) { a.value[0] = 0x1234567ULL * (round + 1) + root[0]; a.value[1] = root[1]; }   // < 2^72: canonical
+    return a;
+  };
+  auto res = fri_commit(cw, omega, offset, rounds, challenge);
+  CHECK(res.codewords.size() == (size_t)rounds && res.roots.size() == (size_t)rounds && seen.size() == (size_t)rounds);
+  // oracle replay of the loop
+  std::vector<uint64_t> cur = raw, om(omega.value.begin(), omega.value.end()), of(offset.value.begin(), offset.value.end());
+  size_t len = n;
+  for (int r = 0; r < rounds; r++) {
+    std::vector<uint8_t> leaves(len * 25), root(48);
+    std::vector<uint64_t> off(len + 1);
+    orc_bincode_field_vector(cur.data(), 2, len, leaves.data(), off.data());
+    size_t rl = 0;
+    orc_merkle_commit_ref(leaves.data(), off.data(), len, root.data(), &rl);
+    root.resize(rl);
+    CHECK(res.roots[r] == root && seen[r] == root);
+    CHECK(res.codewords[r].size() == len);
+    bool same = true;
+    for (size_t i = 0; i < len; i++) same = same && res.codewords[r][i].value[0] == cur[2 * i] && res.codewords[r][i].value[1] == cur[2 * i + 1];
+    CHECK(same);
+    if (r == rounds - 1) break;
+    uint64_t alpha[2] = {0x1234567ULL * (r + 1) + root[0], root[1]};
+    std::vector<uint64_t> nxt(len);   // (len/2) elements x 2 limbs
+    orc_fri_fold_ref(MZK_FIELD_M128, cur.data(), len, alpha, of.data(), om.data(), nxt.data());
+    uint64_t t[2];
+    orc_field_mul(MZK_FIELD_M128, om.data(), om.data(), t); om.assign(t, t + 2);
+    orc_field_mul(MZK_FIELD_M128, of.data(), of.data(), t); of.assign(t, t + 2);
+    cur = nxt;
+    len /= 2;
+  }
+}
+
 int main() {
   expect(mzk_init(0));
   test_ntt();
@@ -153,6 +227,8 @@ int main() {
   test_g1();
   test_fast_multiply();
   test_panics();
+  test_merkle();
+  test_fri_commit();
   mzk_shutdown();
   if (failures) { printf("%d check(s) failed\n", failures); return 1; }
   printf("all reference-style tests passed\n");

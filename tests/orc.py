@@ -240,3 +240,87 @@ def I(x):
     if isinstance(x, list):
         return [I(v) for v in x]
     return int(x)
+
+
+# ---- Merkle / SHA3 / leaf bytes (oracle/mzk_oracle_merkle.c) ---------------------------------------------
+def sha3_256(data):
+    out = (ctypes.c_uint8 * 32)()
+    lib().orc_sha3_256(bytes(data), ctypes.c_size_t(len(data)), out)
+    return bytes(out)
+
+
+def bincode_field(v, nl):
+    a = to_limbs([v], nl)
+    out = (ctypes.c_uint8 * (9 + 8 * nl))()
+    lib().orc_bincode_field.restype = ctypes.c_size_t
+    ln = lib().orc_bincode_field(ptr(a), nl, out)
+    return bytes(out[:ln])
+
+
+def _leaf_blob(leaves):
+    blob = b"".join(leaves)
+    off = np.zeros(len(leaves) + 1, dtype=np.uint64)
+    if leaves:
+        off[1:] = np.cumsum([len(x) for x in leaves], dtype=np.uint64)
+    return (ctypes.c_uint8 * max(len(blob), 1)).from_buffer_copy(blob or b"\0"), off
+
+
+def merkle_commit_ref(leaves):
+    buf, off = _leaf_blob(leaves)
+    cap = max([32] + [len(x) for x in leaves])
+    root = (ctypes.c_uint8 * cap)()
+    ln = ctypes.c_size_t()
+    assert lib().orc_merkle_commit_ref(buf, ptr(off), ctypes.c_size_t(len(leaves)), root, ctypes.byref(ln)) == 0
+    return bytes(root[:ln.value])
+
+
+def merkle_open_ref(index, leaves):
+    buf, off = _leaf_blob(leaves)
+    stride = max([32] + [len(x) for x in leaves])
+    cap = max(len(leaves).bit_length(), 1)
+    path = (ctypes.c_uint8 * (stride * cap))()
+    lens = (ctypes.c_uint64 * cap)()
+    depth = ctypes.c_size_t()
+    assert lib().orc_merkle_open_ref(buf, ptr(off), ctypes.c_size_t(len(leaves)), ctypes.c_size_t(index), path, lens,
+                                     ctypes.c_size_t(stride), ctypes.byref(depth)) == 0
+    raw = bytes(path)
+    return [raw[k * stride:k * stride + lens[k]] for k in range(depth.value)]
+
+
+def merkle_verify_ref(root, index, path, leaf):
+    stride = max([32] + [len(x) for x in path])
+    buf = (ctypes.c_uint8 * (stride * len(path)))()
+    lens = (ctypes.c_uint64 * len(path))()
+    for k, e in enumerate(path):
+        buf[k * stride:k * stride + len(e)] = e
+        lens[k] = len(e)
+    return bool(lib().orc_merkle_verify_ref(bytes(root), ctypes.c_size_t(len(root)), ctypes.c_size_t(index), buf, lens,
+                                            ctypes.c_size_t(stride), ctypes.c_size_t(len(path)), bytes(leaf), ctypes.c_size_t(len(leaf))))
+
+
+def field_leaves(fid, arr):
+    nl = arr.shape[1]
+    return [bincode_field(v, nl) for v in from_limbs(arr)]
+
+
+def field_leaves_fast(fid, arr):
+    """same as field_leaves, serialised in C (for 2^20-element codewords)"""
+    nl = arr.shape[1]
+    n = arr.shape[0]
+    blob = (ctypes.c_uint8 * (n * (9 + 8 * nl)))()
+    off = np.zeros(n + 1, dtype=np.uint64)
+    lib().orc_bincode_field_vector(ptr(arr), nl, ctypes.c_size_t(n), blob, ptr(off))
+    raw = bytes(blob)
+    return [raw[int(off[i]):int(off[i + 1])] for i in range(n)]
+
+
+def merkle_commit_field_ref(fid, arr):
+    """Merkle::commit(&codeword.map(bincode::serialize)) entirely in the C oracle (no per-leaf Python objects)."""
+    nl, n = arr.shape[1], arr.shape[0]
+    blob = (ctypes.c_uint8 * (n * (9 + 8 * nl)))()
+    off = np.zeros(n + 1, dtype=np.uint64)
+    lib().orc_bincode_field_vector(ptr(arr), nl, ctypes.c_size_t(n), blob, ptr(off))
+    root = (ctypes.c_uint8 * 48)()
+    ln = ctypes.c_size_t()
+    assert lib().orc_merkle_commit_ref(blob, ptr(off), ctypes.c_size_t(n), root, ctypes.byref(ln)) == 0
+    return bytes(root[:ln.value])

@@ -1,0 +1,183 @@
+"""GPU parity for the Merkle commitments of FRI / STARK codewords (merkle.rs:15-46 as called
+from fri.rs:160-166 and fri.rs:236-249): roots and authentication paths bit-identical to the oracle."""
+import ctypes, hashlib, random
+import numpy as np
+import pytest
+import orc
+from orc import FR, M128
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mz():
+    import myzkp_amd
+    myzkp_amd.init(0)
+    return myzkp_amd
+
+
+def _edge_vector(fid, seed, n):
+    """uniform elements with short encodings mixed in: 0 (9-byte leaf), small values, exact digit boundaries"""
+    nl = orc.LIMBS[fid]
+    arr = orc.synth_vector(fid, seed, n)
+    specials = [0, 1, 255, (1 << 32) - 1, 1 << 32, (1 << 64) - 1, 1 << 64, 1 << 96, orc.MOD[fid] - 1, (1 << 120) + 5]
+    for i, v in enumerate(specials):
+        if 3 * i + 1 < n:
+            arr[3 * i + 1] = orc.to_limbs([v % orc.MOD[fid]], nl)[0]
+    return arr
+
+
+@pytest.mark.parametrize("fid", [M128, FR])
+@pytest.mark.parametrize("lg", [0, 1, 2, 3, 9, 10, 11, 13])
+def test_field_tree_root_matches_oracle(mz, fid, lg):
+    n = 1 << lg
+    arr = _edge_vector(fid, 300 + lg, n)
+    leaves = orc.field_leaves(fid, arr)
+    want = orc.merkle_commit_ref(leaves)
+    assert mz.merkle_commit_field(fid, arr) == want
+    t = mz.MerkleTree(fid, arr)
+    assert t.root() == want
+    t.close()
+
+
+@pytest.mark.parametrize("fid,lg", [(M128, 1), (M128, 2), (M128, 12), (FR, 5), (FR, 11)])
+def test_open_paths_match_oracle_and_verify(mz, fid, lg):
+    n = 1 << lg
+    arr = _edge_vector(fid, 400 + lg, n)
+    leaves = orc.field_leaves(fid, arr)
+    root = orc.merkle_commit_ref(leaves)
+    t = mz.MerkleTree(fid, arr)
+    rnd = random.Random(lg)
+    for idx in sorted({0, 1, n - 1, n // 2, 4 % n, 5 % n} | {rnd.randrange(n) for _ in range(6)}):
+        path = t.open(idx)
+        assert path == orc.merkle_open_ref(idx, leaves), idx
+        assert orc.merkle_verify_ref(root, idx, path, leaves[idx])
+        assert not orc.merkle_verify_ref(root, idx, path, leaves[idx ^ 1] + b"x")
+    t.close()
+
+
+def test_reference_merkle_test_on_gpu(mz):
+    """merkle.rs:76-93: leaf1..leaf4, open index 2"""
+    leaves = [b"leaf1", b"leaf2", b"leaf3", b"leaf4"]
+    t = mz.MerkleTree(leaves=leaves)
+    root = t.root()
+    assert root == orc.merkle_commit_ref(leaves)
+    proof = t.open(2)
+    assert proof == orc.merkle_open_ref(2, leaves)
+    assert orc.merkle_verify_ref(root, 2, proof, leaves[2]) and not orc.merkle_verify_ref(root, 2, proof, leaves[3])
+
+
+@pytest.mark.parametrize("n", [1, 2, 8, 1024, 2048])
+def test_byte_leaves_ragged_lengths_and_multi_block(mz, n):
+    rnd = random.Random(n)
+    leaves = [bytes(rnd.randrange(256) for _ in range(rnd.choice([0, 1, 9, 25, 41, 67, 68, 69, 135, 136, 137, 300]))) for _ in range(n)]
+    t = mz.MerkleTree(leaves=leaves)
+    assert t.root() == orc.merkle_commit_ref(leaves)
+    if n >= 2:
+        for idx in {0, n - 1, n // 3}:
+            assert t.open(idx) == orc.merkle_open_ref(idx, leaves)
+
+
+def test_contract_violations(mz):
+    with pytest.raises(mz.MzkError) as e:
+        mz.merkle_commit_field(M128, np.zeros((0, 2), dtype=np.uint64))
+    assert e.value.code == -5
+    with pytest.raises(mz.MzkError) as e:
+        mz.merkle_commit_field(M128, orc.synth_vector(M128, 1, 3))
+    assert e.value.code == -2
+    bad = orc.synth_vector(M128, 1, 4)
+    bad[2] = orc.to_limbs([orc.MOD[M128]], 2)[0]
+    with pytest.raises(mz.MzkError) as e:
+        mz.merkle_commit_field(M128, bad)
+    assert e.value.code == -6
+    t = mz.MerkleTree(M128, orc.synth_vector(M128, 1, 4))
+    with pytest.raises(mz.MzkError):
+        t.open(4)
+    one = mz.MerkleTree(M128, orc.synth_vector(M128, 1, 1))
+    with pytest.raises(mz.MzkError):
+        one.open(0)
+
+
+def test_device_resident_fri_commit_loop(mz):
+    """FRI::commit (fri.rs:144-209) with the codeword never leaving HBM: per round Merkle root -> (host transcript)
+    -> alpha -> split-and-fold; the transcript is stood in for by alpha = SHA3(root) mod p on both sides."""
+    import torch
+    L = mz.lib()
+    dev = torch.device("cuda", 0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lg = 14
+    n = 1 << lg
+    cw = orc.synth_vector(M128, 55, n)
+    omega, offset = orc.m128_root(lg), orc.M128_GEN
+    p = orc.MOD[M128]
+    d_cw = torch.from_numpy(cw.view(np.int64).reshape(-1).copy()).to(dev)
+    cpu = cw
+    for r in range(6):
+        root = (ctypes.c_uint8 * 48)()
+        ln = ctypes.c_size_t()
+        rc = L.mzk_merkle_commit_field_dev(M128, ctypes.c_void_p(d_cw.data_ptr()), ctypes.c_size_t(cpu.shape[0]), root, ctypes.c_size_t(48),
+                                           ctypes.byref(ln), st)
+        assert rc == 0, L.mzk_last_error().decode()
+        want_root = orc.merkle_commit_ref(orc.field_leaves(M128, cpu))
+        assert bytes(root[:ln.value]) == want_root
+        alpha = int.from_bytes(hashlib.sha3_256(want_root).digest(), "little") % p
+        a, o, w = (orc.to_limbs([v], 2) for v in (alpha, offset, omega))
+        d_next = torch.zeros(cpu.shape[0], dtype=torch.int64, device=dev)        # (n/2) * 2 limbs
+        rc = L.mzk_fri_fold_dev(M128, ctypes.c_void_p(d_cw.data_ptr()), ctypes.c_size_t(cpu.shape[0]), a.ctypes.data_as(ctypes.c_void_p),
+                                o.ctypes.data_as(ctypes.c_void_p), w.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_next.data_ptr()), st)
+        assert rc == 0, L.mzk_last_error().decode()
+        torch.cuda.synchronize()
+        cpu = orc.fri_fold_ref(M128, cpu, alpha, offset, omega)
+        assert np.array_equal(d_next.cpu().numpy().view(np.uint64).reshape(-1, 2), cpu)
+        d_cw = d_next
+        omega, offset = omega * omega % p, offset * offset % p
+
+
+def test_large_codeword_root(mz):
+    """2^20 M128 elements (BASELINE configs[2] size): root vs the oracle's literal recursion (~1 s of CPU)."""
+    arr = orc.synth_vector(M128, 1234, 1 << 20)
+    assert mz.merkle_commit_field(M128, arr) == orc.merkle_commit_ref(orc.field_leaves_fast(M128, arr))
+
+
+@pytest.mark.parametrize("fid,lg,rounds", [(M128, 12, 7), (FR, 9, 4), (M128, 3, 4), (M128, 0, 1)])
+def test_fri_commit_entry_point_matches_oracle_replay(mz, fid, lg, rounds):
+    """mzk_fri_commit (fri.rs:144-209): roots, every round's codeword, the challenge callback protocol (one call per
+    round, alpha ignored on the last) and the omega/offset squaring; (M128, 3, 4) ends on a one-element codeword whose
+    "root" is the leaf itself (merkle.rs:17-19)."""
+    n = 1 << lg
+    p = orc.MOD[fid]
+    nl = orc.LIMBS[fid]
+    cw = orc.synth_vector(fid, 900 + lg, n)
+    omega = orc.root_of(fid, lg) if lg else 1
+    offset = orc.M128_GEN if fid == M128 else 5
+    calls = []
+
+    def challenge(rnd, last, root):
+        calls.append((rnd, last, root))
+        return None if last else int.from_bytes(hashlib.sha3_256(root + bytes([rnd])).digest(), "little") % p
+
+    cws, roots = mz.fri_commit(fid, cw, omega, offset, rounds, challenge)
+    assert [c[0] for c in calls] == list(range(rounds)) and [c[1] for c in calls] == [False] * (rounds - 1) + [True]
+    cur, om, of = cw, omega, offset
+    for r in range(rounds):
+        want_root = orc.merkle_commit_ref(orc.field_leaves(fid, cur))
+        assert roots[r] == want_root == calls[r][2], r
+        assert np.array_equal(cws[r], cur), r
+        if r == rounds - 1:
+            break
+        alpha = int.from_bytes(hashlib.sha3_256(want_root + bytes([r])).digest(), "little") % p
+        cur = orc.fri_fold_ref(fid, cur, alpha, of, om)
+        om, of = om * om % p, of * of % p
+
+
+def test_fri_commit_contract_violations(mz):
+    cw = orc.synth_vector(M128, 1, 8)
+    with pytest.raises(mz.MzkError) as e:
+        mz.fri_commit(M128, cw, orc.root_of(M128, 3), 3, 5, lambda *a: 1)      # 5 rounds on 8 elements
+    assert e.value.code == -5
+    with pytest.raises(mz.MzkError) as e:
+        mz.fri_commit(M128, cw[:6], orc.root_of(M128, 3), 3, 2, lambda *a: 1)
+    assert e.value.code == -2
+    with pytest.raises(mz.MzkError) as e:
+        mz.fri_commit(M128, cw, orc.root_of(M128, 3), 3, 2, lambda *a: orc.MOD[M128])   # non-canonical challenge
+    assert e.value.code == -6
