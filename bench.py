@@ -25,6 +25,7 @@ MAD_PEAK_PER_S = 256 * 64 * 2.4e9   # v_mad_u64_u32 is half rate: 64 lanes/clk/C
 
 
 def main():
+    T_START = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -45,13 +46,31 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N>1 code path on a ONE-GPU box (the pool's boxes have one): all ranks share cuda:0 and the
+    # exchange goes over gloo through host memory.  Timings of such a run mean nothing and the line says so.
+    shared_gpu_test = world > 1 and os.environ.get("MZK_BENCH_SHARED_GPU_TEST") == "1"
+    if shared_gpu_test:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu_test:
+            dist.init_process_group("gloo")
+            _real_gather = sharded.all_gather_partials
+            sharded.all_gather_partials = lambda t: _real_gather(t.cpu()).to(t.device)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
+    import faulthandler
+    if os.environ.get("MZK_BENCH_WATCHDOG_S"):      # dump every thread's stack if the run is still going after that long
+        faulthandler.dump_traceback_later(float(os.environ["MZK_BENCH_WATCHDOG_S"]), repeat=True, file=sys.stderr)
+
+    def progress(msg):
+        if os.environ.get("MZK_BENCH_VERBOSE") == "1":
+            print("[bench rank %d +%.1fs] %s" % (rank, time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
     dev = torch.device("cuda", local_rank)
     mz.init(local_rank)
@@ -74,7 +93,7 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if shared_gpu_test else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -89,6 +108,7 @@ def main():
         check(L.mzk_synth_g1_points_dev(ctypes.c_uint64(SEED + 7 + 1000003 * r), ctypes.c_size_t(nn), dptr(pt), stream))
         return sc, pt
 
+    progress("process group up; generating inputs")
     scalars, points = synth_shard(n, rank)
     ntt_in = torch.empty(n * 4, dtype=torch.int64, device=dev)
     ntt_out = torch.empty(n * 4, dtype=torch.int64, device=dev)
@@ -107,7 +127,9 @@ def main():
         check(L.mzk_g1_fold_partials_dev(dptr(recs), ctypes.c_int(recs.shape[0]), dptr(result), stream))
 
     # device-resident SRS built from the same points (tables T[w][i] = 2^(16 w) P_i; one-time, untimed)
+    progress("building SRS handle")
     srs = mz.Srs(points.cpu().numpy().view(np.uint64).reshape(-1, 8))
+    progress("SRS handle built")
     result_srs = torch.zeros(8, dtype=torch.int64, device=dev)
 
     def srs_step():
@@ -162,7 +184,9 @@ def main():
     check(L.mzk_kzg_commit_srs_dev(srs._h, dptr(scalars), ctypes.c_size_t(n), dptr(shard_out), ctypes.c_int(0), stream))
     torch.cuda.synchronize()
     assert mz.array_to_points(shard_out.cpu().numpy().view(np.uint64))[0] == shard_want, "rank %d: SRS commit mismatch" % rank
+    progress("shard parity ok; exchanging shard points")
     shard_pts = sharded.all_gather_partials(shard_out)          # (world, 8) affine shard results
+    progress("exchange done")
     msm_step(); srs_step()
     torch.cuda.synchronize()
     if rank == 0:
@@ -174,6 +198,7 @@ def main():
         parity["msm_bit_exact_vs_cpu"] = bool(got == want)
         parity["kzg_commit_srs_bit_exact_vs_cpu"] = bool(got2 == want)
         assert got == want and got2 == want, "folded N-GPU MSM mismatch vs CPU"
+    progress("folded MSM parity ok")
     ntt_step()
     torch.cuda.synchronize()
     v_cpu = orc.synth_vector(orc.FR, SEED + 99 + rank, n, threads)
@@ -208,16 +233,19 @@ def main():
     parity["m128_codeword_merkle_root_bit_exact_vs_cpu"] = bool(ok_merkle)
     del s_cpu, p_cpu, v_cpu, want_ntt, c_cpu, sc_all, want_lde, vals
 
+    progress("parity done; timing")
     # ------------------------------------------------------------------ timed regions
     def timed(step, K, W):
         # settle: workspace growth / plan building, and the DVFS ramp -- on MI355X the same kernel runs ~25 %
         # slower during the first few hundred ms after idle (scratch/mulv.hip: 136 -> 174 G mul/s).  Never
         # counted; the W warm-up steps follow.
         t_settle = time.perf_counter()
+        # The exit decision is COLLECTIVE: a step may contain an all-gather, so every rank must run the same
+        # number of settle steps (a per-rank clock desynchronises the ranks and deadlocks the next collective).
         while True:
             step()
             torch.cuda.synchronize()
-            if time.perf_counter() - t_settle > args.settle_s:
+            if max_over_ranks(1.0 if time.perf_counter() - t_settle > args.settle_s else 0.0) > 0.0:
                 break
         for _ in range(W):
             step()
@@ -248,6 +276,7 @@ def main():
     lde_dt, lde_ph = timed(lde_m128_step, K, W)
     mk_dt, mk_ph = timed(merkle_m128_step, K, W)
 
+    progress("timed legs done")
     msm_ms = msm_dt / K * 1e3
     ntt_ms = ntt_dt / K * 1e3
     msm_rate = world * n / (msm_dt / K)
@@ -302,6 +331,7 @@ def main():
     out = {
         "metric": "G1 MSM pairs/sec + NTT elems/sec at 2^20 and 2^24; bit-exact vs CPU",
         "value": srs_rate, "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": srs_ms,
+        **({"REHEARSAL_NOT_A_MEASUREMENT": "ranks share one GPU, exchange over gloo via host (MZK_BENCH_SHARED_GPU_TEST=1)"} if shared_gpu_test else {}),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 254-bit Montgomery)",
         "data": "synthetic",
         "config": {"workload": "KZG commit = BN254 G1 Pippenger MSM of 2^%d (scalar, point) pairs per GPU against a device-resident SRS "
@@ -329,6 +359,7 @@ def main():
         "parity": parity,
     }
 
+    progress("line assembled; extra sizes")
     # ------------------------------------------------------------------ extra sizes (single GPU view, rank 0 only, once each)
     extras = {}
     if rank == 0:
