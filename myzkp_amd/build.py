@@ -10,7 +10,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmzk_hip.so")
 SOURCES = ["mzk_api.hip", "mzk_ntt.hip", "mzk_msm.hip", "mzk_msm_tail.hip", "mzk_kzg.hip", "mzk_merkle.hip"]
-HEADERS = ["mzk_common.h", "mzk_field.h", "mzk_ec.h", "mzk_constants.h", os.path.join(ROOT, "include", "mzk.h")]
+HEADERS = ["mzk_common.h", "mzk_field.h", "mzk_ec.h", "mzk_coop.h", "mzk_constants.h", os.path.join(ROOT, "include", "mzk.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
 
 

@@ -20,6 +20,7 @@
 //   6. k_window_combine (mzk_msm_tail.hip)  Horner over the bucket sets, XYZZ -> affine (one inversion)
 #include "mzk_common.h"
 #include "mzk_ec.h"
+#include "mzk_coop.h"
 
 namespace mzk {
 
@@ -382,51 +383,54 @@ __global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slo
 // After lgB steps  buf[0] = sum_b B_b  and  buf[2^j] = sum_{b : bit j of b set} B_b, hence
 //   sum_b (b + 1) B_b = buf[0] + sum_j 2^j buf[2^j].
 // 2 B additions in total (the same as the serial running-sum trick) but only lgB dependent steps.
-__device__ __forceinline__ void halve_op(u32* __restrict__ buf, int lgB, int t, size_t id) {
+// Every addition is done by a DPP quad (mzk_coop.h): these steps are latency chains, not throughput work.
+__device__ __forceinline__ void halve_op(u32* __restrict__ buf, int lgB, int t, size_t id, int lane) {
   const int lgh = lgB - t - 1;                    // log2(half)
   const size_t a = id >> lgh, j = id & (((size_t)1 << lgh) - 1);
   const size_t base = (a == 0) ? 0 : ((size_t)1 << (lgB - a));
   const size_t idx = base + j;
-  Xyzz x = xyzz_gload(buf, idx), y = xyzz_gload(buf, idx + ((size_t)1 << lgh));
-  xyzz_gstore(buf, idx, xyzz_add(x, y));
+  const Xyzz x = xyzz_gload_quad(buf, idx, lane), y = xyzz_gload_quad(buf, idx + ((size_t)1 << lgh), lane);
+  xyzz_gstore_quad(buf, idx, xyzz_add_quad(x, y, lane), lane);
 }
 __global__ __launch_bounds__(128) void k_halve_step(u32* __restrict__ buckets, int lgB, int t) {
-  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t id = tid >> 2;                     // one quad per addition
   const size_t total = (size_t)(t + 1) << (lgB - t - 1);
-  if (id >= total) return;
-  halve_op(buckets + ((size_t)blockIdx.y << lgB) * 32, lgB, t, id);
+  if (id >= total) return;                        // quad-uniform
+  halve_op(buckets + ((size_t)blockIdx.y << lgB) * 32, lgB, t, id, (int)(tid & 3));
 }
-constexpr int TAIL_THREADS = 256;
+constexpr int TAIL_THREADS = 512;
+constexpr int TAIL_QUADS = TAIL_THREADS / 4;
 // Remaining steps t_start..lgB-1 inside one workgroup per bucket set, then the weighted sum
-// buf[0] + sum_j 2^j buf[2^j] (lane j doubles j times, LDS tree sum).  out[w] = XYZZ result of set w.
+// buf[0] + sum_j 2^j buf[2^j] (quad j doubles j times, LDS tree sum).  out[w] = XYZZ result of set w.
 __global__ __launch_bounds__(TAIL_THREADS) void k_reduce_tail(u32* __restrict__ buckets, int lgB, int t_start, u32* __restrict__ out) {
-  __shared__ u32 sh[32 * 32];
+  __shared__ __attribute__((aligned(16))) u32 sh[32 * 32];
   u32* buf = buckets + ((size_t)blockIdx.x << lgB) * 32;
+  const int lane = threadIdx.x & 3, quad = threadIdx.x >> 2;
   for (int t = t_start; t < lgB; t++) {
     const size_t total = (size_t)(t + 1) << (lgB - t - 1);
-    for (size_t id = threadIdx.x; id < total; id += TAIL_THREADS) halve_op(buf, lgB, t, id);
+    for (size_t id = quad; id < total; id += TAIL_QUADS) halve_op(buf, lgB, t, id, lane);
     __syncthreads();
   }
-  const int lane = threadIdx.x;
-  if (lane < 32) {
+  if (quad < 32) {
     Xyzz v = xyzz_inf();
-    if (lane < lgB) {
-      v = xyzz_gload(buf, (size_t)1 << lane);
-      for (int d = 0; d < lane; d++) v = xyzz_dbl(v);
-    } else if (lane == lgB) {
-      v = xyzz_gload(buf, 0);
+    if (quad < lgB) {
+      v = xyzz_gload_quad(buf, (size_t)1 << quad, lane);
+      for (int d = 0; d < quad; d++) v = xyzz_dbl_quad(v, lane);
+    } else if (quad == lgB) {
+      v = xyzz_gload_quad(buf, 0, lane);
     }
-    xyzz_store(v, sh + 32 * lane);
+    xyzz_gstore_quad(sh, quad, v, lane);
   }
   __syncthreads();
   for (int off = 16; off >= 1; off >>= 1) {
-    if (lane < off) {
-      Xyzz a = xyzz_load(sh + 32 * lane), b = xyzz_load(sh + 32 * (lane + off));
-      xyzz_store(xyzz_add(a, b), sh + 32 * lane);
+    if (quad < off) {
+      const Xyzz a = xyzz_gload_quad(sh, quad, lane), b = xyzz_gload_quad(sh, quad + off, lane);
+      xyzz_gstore_quad(sh, quad, xyzz_add_quad(a, b, lane), lane);
     }
     __syncthreads();
   }
-  if (lane < 32) out[(size_t)blockIdx.x * 32 + lane] = sh[lane];
+  if (threadIdx.x < 32) out[(size_t)blockIdx.x * 32 + threadIdx.x] = sh[threadIdx.x];
 }
 
 // k_window_combine / k_fold_partials live in mzk_msm_tail.hip (compact-code build).
@@ -565,10 +569,10 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   u32* wsum;
   MZK_TRY(ws_get(WS_MSM_OUT, (size_t)MAX_WINDOWS * 128, (void**)&wsum));
   int t_start = 0;
-  while (t_start < sh.lgB && ((size_t)(t_start + 1) << (sh.lgB - t_start - 1)) > (size_t)2 * TAIL_THREADS) t_start++;
+  while (t_start < sh.lgB && ((size_t)(t_start + 1) << (sh.lgB - t_start - 1)) > (size_t)4 * TAIL_QUADS) t_start++;
   for (int t = 0; t < t_start; t++) {
     const size_t total = (size_t)(t + 1) << (sh.lgB - t - 1);
-    hipLaunchKernelGGL(k_halve_step, dim3((unsigned)((total + 127) / 128), (unsigned)red_windows), dim3(128), 0, s, buckets, sh.lgB, t);
+    hipLaunchKernelGGL(k_halve_step, dim3((unsigned)((4 * total + 127) / 128), (unsigned)red_windows), dim3(128), 0, s, buckets, sh.lgB, t);
   }
   hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)red_windows), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, t_start, wsum);
   prof_end(s, MZK_PH_MSM_REDUCE);

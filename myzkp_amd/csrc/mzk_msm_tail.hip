@@ -3,6 +3,7 @@
 // unit only to keep compile times of mzk_msm.hip down.
 #include "mzk_common.h"
 #include "mzk_ec.h"
+#include "mzk_coop.h"
 
 namespace mzk {
 
@@ -37,58 +38,14 @@ __device__ __forceinline__ void xyzz_gstore(u32* __restrict__ g, size_t idx, con
 // (one Fq inversion) or the XYZZ partial record.
 //
 // The 240 doublings are inherently serial, so the lever is the latency of ONE doubling: its 9 field
-// products form only 3 dependency levels (V, X^2 | W, S, M^2 | M(S-X3), W Y, V ZZ, W ZZZ).  Four lanes
-// hold the same point; at each level every lane computes a different product (same instruction stream,
-// lane-selected operands) and the results are broadcast back with v_readlane.  3 product latencies per
-// doubling instead of 9.
-__device__ __forceinline__ Fq bcast_lane(const Fq& v, int src) {
-  Fq r;
-#pragma unroll
-  for (int i = 0; i < FqParams::L; i++) r.l[i] = (u32)__builtin_amdgcn_readlane((int)v.l[i], src);
-  return r;
-}
-__device__ __forceinline__ Fq sel4(int lane, const Fq& a0, const Fq& a1, const Fq& a2, const Fq& a3) {
-  Fq r;
-#pragma unroll
-  for (int i = 0; i < FqParams::L; i++) r.l[i] = (lane == 0) ? a0.l[i] : (lane == 1) ? a1.l[i] : (lane == 2) ? a2.l[i] : a3.l[i];
-  return r;
-}
-// p is replicated in lanes 0..3 (lane = index within the group of four); result replicated again.
-// Straight-line on purpose: the cross-lane reads must not sit behind a branch the compiler cannot prove
-// uniform (an early `return` for infinity miscompiled when this was inlined into the Horner loop).
-// Infinity needs no special case: all-zero coordinates give ZZ3 = V * 0 = 0 exactly, and the final
-// select restores the canonical all-zero encoding.
-__device__ __forceinline__ void xyzz_dbl_coop4(Xyzz& p, int lane) {
-  typedef FqParams P;
-  const bool was_inf = xyzz_is_inf(p);
-  const Fq U = fe_dbl<P>(p.Y);                                  // < 5, limbs < 2^30
-  Fq r = fe_sqr<P>(sel4(lane, U, p.X, U, p.X));                 // lane 0: V = U^2, lane 1: X^2
-  const Fq V = bcast_lane(r, 0), X2 = bcast_lane(r, 1);
-  const Fq M = fe_carry<P>(fe_add<P>(fe_dbl<P>(X2), X2));       // 3 X^2 < 3.12, N
-  r = fe_mul<P>(sel4(lane, U, p.X, M, M), sel4(lane, V, V, M, M));   // W = U V | S = X V | M^2
-  const Fq W = bcast_lane(r, 0), S = bcast_lane(r, 1), MM = bcast_lane(r, 2);
-  const Fq X3 = fe_weak_reduce<P>(fe_sub<P, 4>(fe_sub<P, 4>(MM, S), S));
-  const Fq Vd = fe_carry<P>(fe_sub<P, 8>(S, X3));               // < 9.02
-  r = fe_mul<P>(sel4(lane, M, W, V, W), sel4(lane, Vd, p.Y, p.ZZ, p.ZZZ));   // A | B | ZZ3 | ZZZ3
-  const Fq A = bcast_lane(r, 0), B = bcast_lane(r, 1);
-  p.ZZ = bcast_lane(r, 2);
-  p.ZZZ = bcast_lane(r, 3);
-  p.X = X3;
-  p.Y = fe_weak_reduce<P>(fe_sub<P, 4>(A, B));                  // A < 1.17, B < 1.02
-#pragma unroll
-  for (int i = 0; i < P::L; i++) {
-    p.X.l[i] = was_inf ? 0u : p.X.l[i];
-    p.Y.l[i] = was_inf ? 0u : p.Y.l[i];
-    p.ZZ.l[i] = was_inf ? 0u : p.ZZ.l[i];
-    p.ZZZ.l[i] = was_inf ? 0u : p.ZZZ.l[i];
-  }
-}
-__global__ __launch_bounds__(64) void k_window_combine(const u32* __restrict__ wsum, int nwin, int c, int out_xyzz, u32* __restrict__ out) {
-  const int lane = threadIdx.x & 3;     // every group of four lanes replicates the same computation
-  Xyzz tot = xyzz_gload(wsum, nwin - 1);
+// products form only 3 dependency levels; a DPP quad holds the same point and splits each level
+// (xyzz_dbl_quad / xyzz_add_quad, mzk_coop.h).  One quad does the work.
+__global__ __launch_bounds__(4) void k_window_combine(const u32* __restrict__ wsum, int nwin, int c, int out_xyzz, u32* __restrict__ out) {
+  const int lane = threadIdx.x & 3;
+  Xyzz tot = xyzz_gload_quad(wsum, nwin - 1, lane);
   for (int win = nwin - 2; win >= 0; win--) {
-    for (int d = 0; d < c; d++) xyzz_dbl_coop4(tot, lane);
-    tot = xyzz_add(tot, xyzz_gload(wsum, win));
+    for (int d = 0; d < c; d++) tot = xyzz_dbl_quad(tot, lane);
+    tot = xyzz_add_quad(tot, xyzz_gload_quad(wsum, win, lane), lane);
   }
   if (threadIdx.x != 0) return;
   if (out_xyzz) {
@@ -117,7 +74,7 @@ __global__ void k_fold_partials(const u32* __restrict__ partials, int count, u32
 
 
 int launch_window_combine(const u32* wsum, int nwin, int c, int out_xyzz, u32* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_window_combine, dim3(1), dim3(64), 0, s, wsum, nwin, c, out_xyzz, out);
+  hipLaunchKernelGGL(k_window_combine, dim3(1), dim3(4), 0, s, wsum, nwin, c, out_xyzz, out);
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }
