@@ -142,7 +142,7 @@ template <bool SERIAL = false> MZK_HD bool xyzz_to_affine(const Xyzz& p, Affine*
   typedef FqParams P;
   if (xyzz_is_inf(p)) return false;
   Fq d = fe_mul<P>(p.ZZ, p.ZZZ);
-  Fq di = SERIAL ? fe_inv_serial<P>(d) : fe_inv<P>(d);   // 1 / (ZZ ZZZ)
+  Fq di = SERIAL ? fe_inv_safegcd<P>(d) : fe_inv<P>(d);   // 1 / (ZZ ZZZ)
   Fq izz = fe_mul<P>(di, p.ZZZ);                 // 1 / ZZ
   Fq izzz = fe_mul<P>(di, p.ZZ);                 // 1 / ZZZ
   out->x = fe_reduce<P>(fe_mul<P>(p.X, izz));

@@ -552,4 +552,166 @@ template <class P> MZK_HD Fe<P> fe_inv_serial(const Fe<P>& a) {
   return fe_mul<P>(fe_unpack<P>(r), r3);
 }
 
+// ---- inverse by safegcd (Bernstein-Yang divsteps), 62 divsteps per batch ---------------------------------
+// The single-lane tails (one inversion ends every MSM / fold) are pure latency, and both other inversions are
+// long dependent chains (Fermat: ~380 dependent products; binary Euclid: ~760 dependent multi-word steps).
+// Divsteps work on the LOW 64 bits of f, g for 62 steps, collect the steps in a 2x2 integer matrix and apply it
+// to the full-width f, g and to the cofactors d, e once per batch: ~10 batches for a 254-bit modulus.
+// Signed 62-bit limbs (5 of them hold up to 310 bits), variable time (ctz skips zero runs): single lane only.
+// Invariants: d x == f, e x == g (mod p) up to the common power of two that the batch update divides out
+// with the p^-1 mod 2^62 trick; d, e stay in (-2p, p).
+struct Sgn62 { int64_t v[5]; };
+struct DivMat { int64_t u, v, q, r; };
+typedef __int128 i128;
+MZK_HD int sg_ctz64(uint64_t x) { return __builtin_ctzll(x); }
+MZK_HD int64_t sg_divsteps_62(int64_t eta, uint64_t f0, uint64_t g0, DivMat* t) {
+  uint64_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0, m;
+  uint32_t w;
+  int i = 62;
+  for (;;) {
+    const int zeros = sg_ctz64(g | (~(uint64_t)0 << i));
+    g >>= zeros; u <<= zeros; v <<= zeros; eta -= zeros; i -= zeros;
+    if (i == 0) break;
+    // f and g odd here
+    if (eta < 0) {
+      uint64_t tmp;
+      eta = -eta;
+      tmp = f; f = g; g = (uint64_t)0 - tmp;
+      tmp = u; u = q; q = (uint64_t)0 - tmp;
+      tmp = v; v = r; r = (uint64_t)0 - tmp;
+      const int limit = ((int)eta + 1) > i ? i : ((int)eta + 1);     // up to 6 steps at once: w = -g / f mod 2^limit
+      m = (~(uint64_t)0 >> (64 - limit)) & 63u;
+      w = (uint32_t)((f * g * (f * f - 2)) & m);
+    } else {
+      const int limit = ((int)eta + 1) > i ? i : ((int)eta + 1);     // up to 4 steps at once
+      m = (~(uint64_t)0 >> (64 - limit)) & 15u;
+      w = (uint32_t)(f + (((f + 1) & 4) << 1));
+      w = (uint32_t)(((uint64_t)0 - (uint64_t)w) * g & m);
+    }
+    g += f * w; q += u * w; r += v * w;
+  }
+  t->u = (int64_t)u; t->v = (int64_t)v; t->q = (int64_t)q; t->r = (int64_t)r;
+  return eta;
+}
+// (f, g) <- t (f, g) / 2^62  (exact)
+MZK_HD void sg_update_fg(Sgn62* f, Sgn62* g, const DivMat* t) {
+  const uint64_t M62 = ~(uint64_t)0 >> 2;
+  const int64_t u = t->u, v = t->v, q = t->q, r = t->r;
+  i128 cf = (i128)u * f->v[0] + (i128)v * g->v[0];
+  i128 cg = (i128)q * f->v[0] + (i128)r * g->v[0];
+  cf >>= 62; cg >>= 62;
+#pragma unroll
+  for (int i = 1; i < 5; i++) {
+    cf += (i128)u * f->v[i] + (i128)v * g->v[i];
+    cg += (i128)q * f->v[i] + (i128)r * g->v[i];
+    f->v[i - 1] = (int64_t)((uint64_t)cf & M62); cf >>= 62;
+    g->v[i - 1] = (int64_t)((uint64_t)cg & M62); cg >>= 62;
+  }
+  f->v[4] = (int64_t)cf;
+  g->v[4] = (int64_t)cg;
+}
+// (d, e) <- t (d, e) / 2^62 mod p, result again in (-2p, p)
+MZK_HD void sg_update_de(Sgn62* d, Sgn62* e, const DivMat* t, const Sgn62* mod, uint64_t pinv62) {
+  const uint64_t M62 = ~(uint64_t)0 >> 2;
+  const int64_t u = t->u, v = t->v, q = t->q, r = t->r;
+  const int64_t sd = d->v[4] >> 63, se = e->v[4] >> 63;
+  int64_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
+  i128 cd = (i128)u * d->v[0] + (i128)v * e->v[0];
+  i128 ce = (i128)q * d->v[0] + (i128)r * e->v[0];
+  md -= (int64_t)((pinv62 * (uint64_t)cd + (uint64_t)md) & M62);
+  me -= (int64_t)((pinv62 * (uint64_t)ce + (uint64_t)me) & M62);
+  cd += (i128)mod->v[0] * md;
+  ce += (i128)mod->v[0] * me;
+  cd >>= 62; ce >>= 62;
+#pragma unroll
+  for (int i = 1; i < 5; i++) {
+    cd += (i128)u * d->v[i] + (i128)v * e->v[i] + (i128)mod->v[i] * md;
+    ce += (i128)q * d->v[i] + (i128)r * e->v[i] + (i128)mod->v[i] * me;
+    d->v[i - 1] = (int64_t)((uint64_t)cd & M62); cd >>= 62;
+    e->v[i - 1] = (int64_t)((uint64_t)ce & M62); ce >>= 62;
+  }
+  d->v[4] = (int64_t)cd;
+  e->v[4] = (int64_t)ce;
+}
+// r in (-2p, p), sign < 0 -> negate; result in [0, p)
+MZK_HD void sg_normalize(Sgn62* r, int64_t sign, const Sgn62* mod) {
+  const int64_t M62 = (int64_t)(~(uint64_t)0 >> 2);
+  int64_t c[5];
+  int64_t add = r->v[4] >> 63;
+#pragma unroll
+  for (int i = 0; i < 5; i++) c[i] = r->v[i] + (mod->v[i] & add);
+  const int64_t neg = sign >> 63;
+#pragma unroll
+  for (int i = 0; i < 5; i++) c[i] = (c[i] ^ neg) - neg;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { c[i + 1] += c[i] >> 62; c[i] &= M62; }
+  add = c[4] >> 63;
+#pragma unroll
+  for (int i = 0; i < 5; i++) c[i] += mod->v[i] & add;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { c[i + 1] += c[i] >> 62; c[i] &= M62; }
+#pragma unroll
+  for (int i = 0; i < 5; i++) r->v[i] = c[i];
+}
+template <int NW> MZK_HD void sg_from_words(const u32* w, Sgn62* o) {   // NW u32 words (<= 8) -> 62-bit limbs
+  uint64_t x[5] = {0, 0, 0, 0, 0};   // 64-bit words
+#pragma unroll
+  for (int i = 0; i < NW; i++) x[i >> 1] |= (uint64_t)w[i] << (32 * (i & 1));
+  const uint64_t M62 = ~(uint64_t)0 >> 2;
+  o->v[0] = (int64_t)(x[0] & M62);
+  o->v[1] = (int64_t)(((x[0] >> 62) | (x[1] << 2)) & M62);
+  o->v[2] = (int64_t)(((x[1] >> 60) | (x[2] << 4)) & M62);
+  o->v[3] = (int64_t)(((x[2] >> 58) | (x[3] << 6)) & M62);
+  o->v[4] = (int64_t)((x[3] >> 56) | (x[4] << 8));
+}
+template <int NW> MZK_HD void sg_to_words(const Sgn62* a, u32* w) {     // canonical value in [0, p) back to u32 words
+  const uint64_t a0 = (uint64_t)a->v[0], a1 = (uint64_t)a->v[1], a2 = (uint64_t)a->v[2], a3 = (uint64_t)a->v[3], a4 = (uint64_t)a->v[4];
+  uint64_t x[4];
+  x[0] = a0 | (a1 << 62);
+  x[1] = (a1 >> 2) | (a2 << 60);
+  x[2] = (a2 >> 4) | (a3 << 58);
+  x[3] = (a3 >> 6) | (a4 << 56);
+#pragma unroll
+  for (int i = 0; i < NW; i++) w[i] = (u32)(x[i >> 1] >> (32 * (i & 1)));
+}
+template <class P> MZK_HD Fe<P> fe_inv_safegcd(const Fe<P>& a) {
+  constexpr int NW = P::NW;
+  u32 xw[NW], pw[NW];
+  {
+    Fe<P> c = fe_reduce<P>(a);
+    if (fe_is_zero_canon<P>(c)) return fe_zero<P>();
+    fe_pack<P>(c, xw);
+  }
+#pragma unroll
+  for (int i = 0; i < NW; i++) pw[i] = P::PW[i];
+  Sgn62 mod, f, g, d, e;
+  sg_from_words<NW>(pw, &mod);
+  sg_from_words<NW>(xw, &g);
+  f = mod;
+#pragma unroll
+  for (int i = 0; i < 5; i++) { d.v[i] = 0; e.v[i] = 0; }
+  e.v[0] = 1;
+  // p^-1 mod 2^62 by Newton from p0 (p odd: p0 * p0 == 1 mod 8)
+  uint64_t pinv = (uint64_t)mod.v[0];
+#pragma unroll
+  for (int it = 0; it < 5; it++) pinv *= 2 - (uint64_t)mod.v[0] * pinv;
+  pinv &= ~(uint64_t)0 >> 2;
+  int64_t eta = -1;
+  for (int batch = 0; batch < 16; batch++) {       // 12 batches bound 254-bit inputs; g == 0 ends it (~9-10)
+    DivMat t;
+    eta = sg_divsteps_62(eta, (uint64_t)f.v[0], (uint64_t)g.v[0], &t);
+    sg_update_de(&d, &e, &t, &mod, pinv);
+    sg_update_fg(&f, &g, &t);
+    if ((g.v[0] | g.v[1] | g.v[2] | g.v[3] | g.v[4]) == 0) break;
+  }
+  sg_normalize(&d, f.v[4], &mod);                   // f = +-1, d = +-x^-1
+  u32 rw[NW];
+  sg_to_words<NW>(&d, rw);
+  // rw = (aR)^-1 = a^-1 R^-1 (plain words); Montgomery form of a^-1 is a^-1 R = mont(rw, R^3)
+  Fe<P> r3;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) r3.l[i] = P::R3[i];
+  return fe_mul<P>(fe_unpack<P>(rw), r3);
+}
+
 }  // namespace mzk

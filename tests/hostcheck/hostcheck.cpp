@@ -17,6 +17,8 @@ template <class P> static void run_field(int op, const u32* a, const u32* b, u32
     case 3: r = fe_sub<P, 4>(x, fe_reduce<P>(y)); break;
     case 4: r = fe_inv_serial<P>(x); break;
     case 8: r = fe_inv<P>(x); break;
+    case 10: r = fe_inv_safegcd<P>(x); break;
+    case 11: r = fe_inv_safegcd<P>(fe_add<P>(fe_add<P>(x, x), fe_sub<P, 4>(x, fe_reduce<P>(x)))); break;
     case 9: r = fe_inv_serial<P>(fe_add<P>(fe_add<P>(x, x), fe_sub<P, 4>(x, fe_reduce<P>(x)))); break;  // inverse of a lazy 2x (+4p)
     case 5: r = fe_neg_canon<P>(fe_reduce<P>(x)); break;
     case 6: {  // lazy chain stressing fe_weak_reduce: ((x+y)+(x+y)) + 16p - y ... then squared

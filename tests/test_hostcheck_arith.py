@@ -50,12 +50,29 @@ def test_field_ops_against_python(hc):
             assert fop(hc, fid, 5, a, b) == (-a) % p
             assert fop(hc, fid, 6, a, b) == pow(2 * (a + b) - b, 2, p)
             assert fop(hc, fid, 7, a, b) == a * b % p
+            assert fop(hc, fid, 10, a, b) == (pow(a, -1, p) if a else 0)             # safegcd (divsteps), every value
+            assert fop(hc, fid, 11, a, b) == (pow(2 * a, -1, p) if a else 0)         # ... of a lazily reduced input
             if i < 40:
                 assert fop(hc, fid, 4, a, b) == (pow(a, -1, p) if a else 0)          # binary extended Euclid
                 assert fop(hc, fid, 9, a, b) == (pow(2 * a, -1, p) if a else 0)      # ... of a lazily reduced input
             if i < 12:
                 assert fop(hc, fid, 8, a, b) == (pow(a, -1, p) if a else 0)          # Fermat ladder
                 assert fop(hc, fid, 0, a, b) == orc.field_op("mul", fid, a, b)
+
+
+def test_safegcd_inverse_many_values(hc):
+    """fe_inv_safegcd (62 divsteps per batch) on structured and random inputs: powers of two and their neighbours
+    (long zero runs in g), values next to p, small values, and 1500 random ones per field."""
+    rng = random.Random(99)
+    for fid, p in ((FQ, P_FQ), (FR, P_FR), (M128, P_M128)):
+        vals = [1, 2, 3, p - 1, p - 2, p - 3, (p + 1) // 2, (p - 1) // 2]
+        for k in range(1, p.bit_length()):
+            vals += [(1 << k) % p, ((1 << k) - 1) % p, ((1 << k) + 1) % p, (p - (1 << k)) % p]
+        vals += [rng.randrange(1, p) for _ in range(1500)]
+        vals += [rng.randrange(1, 1 << 64) for _ in range(100)]
+        for a in vals:
+            if a:
+                assert fop(hc, fid, 10, a, 0) == pow(a, -1, p), (fid, a)
 
 
 def test_pack_roundtrip(hc):
