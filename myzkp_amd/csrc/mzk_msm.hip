@@ -241,6 +241,138 @@ __global__ __launch_bounds__(LDS_SORT_THREADS) void k_digits_scatter_lds(const u
   }
 }
 
+// ---- 1b. two-level counting sort (large inputs) -----------------------------------------------------------
+// A one-pass counting sort scatters 4-byte entries over the whole entry array (64 MiB at 2^20 pairs): every
+// store dirties its own 32-byte sector, an 8x write amplification that bounded the single-pass kernels.  Two
+// levels keep every store stream local:
+//   coarse: 256 bins by the top 8 bits of the bucket key.  A workgroup owns 4096 scalars, counts its entries per
+//           bin in LDS (k_coarse_count), a scan over [bin][workgroup] gives each (bin, workgroup) a contiguous
+//           run, and k_coarse_scatter appends (payload, fine key) records to its runs through LDS cursors.
+//   fine:   bin b is now a contiguous slice of ~E/256 records covering NB/256 buckets.  (bin, sub) workgroups
+//           histogram their share in LDS (k_fine_count), a scan over [bucket][sub] yields the bucket offsets,
+//           and k_fine_scatter writes the final 4-byte entries -- all inside one bin's region (256 KiB at 2^20),
+//           which stays in L2 while it fills.
+// key = bucket index: |digit| - 1 (merged layout) or window * 2^(c-1) + |digit| - 1.
+constexpr int COARSE_BINS = 256;
+constexpr int COARSE_PER_WG = 4096;
+constexpr int SORT2_THREADS = 1024;
+// calls emit(key, payload) for every non-zero signed digit of scalar i
+template <class Emit>
+__device__ __forceinline__ void walk_digits(const u32* w, const DigitLayout& L, size_t i, Emit emit) {
+  const int c = L.c;
+  const u32 half = 1u << (c - 1);
+  u32 carry = 0;
+  for (int win = 0; win < L.nwin; win++) {
+    u32 raw = raw_window(w, win, c) + carry;
+    u32 neg = 0, mag = raw;
+    carry = 0;
+    if (raw > half) { mag = (1u << c) - raw; neg = 1; carry = 1; }
+    if (mag != 0) {
+      const u32 key = (L.merged ? 0u : ((u32)win << (c - 1))) + (mag - 1);
+      const u32 payload = (L.merged ? (u32)((size_t)win * L.table_stride + i) : (u32)i) | (neg << 31);
+      emit(key, payload);
+    }
+  }
+}
+__global__ __launch_bounds__(SORT2_THREADS) void k_coarse_count(const u32* __restrict__ scalars, size_t n, DigitLayout L, int key_shift,
+                                                                 u32* __restrict__ binhist, int nwg) {
+  __shared__ u32 hist[COARSE_BINS];
+  if (threadIdx.x < COARSE_BINS) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)blockIdx.x * COARSE_PER_WG;
+  const size_t hi = (lo + COARSE_PER_WG < n) ? lo + COARSE_PER_WG : n;
+  u32 w[COARSE_PER_WG / SORT2_THREADS][8];            // all of this lane's scalars in flight at once
+#pragma unroll
+  for (int k = 0; k < COARSE_PER_WG / SORT2_THREADS; k++) {
+    const size_t i = lo + threadIdx.x + (size_t)k * SORT2_THREADS;
+    if (i < hi) load_scalar_canonical(scalars, i, w[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < COARSE_PER_WG / SORT2_THREADS; k++) {
+    const size_t i = lo + threadIdx.x + (size_t)k * SORT2_THREADS;
+    if (i < hi) walk_digits(w[k], L, i, [&](u32 key, u32) { atomicAdd(&hist[key >> key_shift], 1u); });
+  }
+  __syncthreads();
+  if (threadIdx.x < COARSE_BINS) binhist[(size_t)threadIdx.x * nwg + blockIdx.x] = hist[threadIdx.x];
+}
+__global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter(const u32* __restrict__ scalars, size_t n, DigitLayout L, int key_shift,
+                                                                   u32 fine_mask, const u32* __restrict__ binbase, int nwg,
+                                                                   uint2* __restrict__ tmp) {
+  __shared__ u32 cursor[COARSE_BINS];
+  if (threadIdx.x < COARSE_BINS) cursor[threadIdx.x] = binbase[(size_t)threadIdx.x * nwg + blockIdx.x];
+  __syncthreads();
+  const size_t lo = (size_t)blockIdx.x * COARSE_PER_WG;
+  const size_t hi = (lo + COARSE_PER_WG < n) ? lo + COARSE_PER_WG : n;
+  u32 w[COARSE_PER_WG / SORT2_THREADS][8];
+#pragma unroll
+  for (int k = 0; k < COARSE_PER_WG / SORT2_THREADS; k++) {
+    const size_t i = lo + threadIdx.x + (size_t)k * SORT2_THREADS;
+    if (i < hi) load_scalar_canonical(scalars, i, w[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < COARSE_PER_WG / SORT2_THREADS; k++) {
+    const size_t i = lo + threadIdx.x + (size_t)k * SORT2_THREADS;
+    if (i < hi) walk_digits(w[k], L, i, [&](u32 key, u32 payload) {
+      const u32 pos = atomicAdd(&cursor[key >> key_shift], 1u);
+      tmp[pos] = make_uint2(payload, key & fine_mask);
+    });
+  }
+}
+// slice of bin b handled by sub-workgroup s of S: bins are the runs [binbase[b * nwg], binbase[(b+1) * nwg])
+__device__ __forceinline__ void fine_slice(const u32* __restrict__ binbase, int nwg, int b, int s, int S, u32* lo, u32* hi) {
+  const u32 start = binbase[(size_t)b * nwg], end = binbase[(size_t)(b + 1) * nwg];   // binbase has 256 * nwg + 1 entries
+  const u64 len = end - start;
+  *lo = start + (u32)(len * (u64)s / (u64)S);
+  *hi = start + (u32)(len * (u64)(s + 1) / (u64)S);
+}
+constexpr int FINE_UNROLL = 8;
+constexpr int FINE_MAX = 2048;     // buckets per bin: NB / 256 (128 merged, 2048 generic c = 16)
+__global__ __launch_bounds__(SORT2_THREADS) void k_fine_count(const uint2* __restrict__ tmp, const u32* __restrict__ binbase, int nwg, int F,
+                                                               int S, u32* __restrict__ finehist) {
+  __shared__ u32 hist[FINE_MAX];
+  for (int f = threadIdx.x; f < F; f += SORT2_THREADS) hist[f] = 0;
+  __syncthreads();
+  u32 lo, hi;
+  fine_slice(binbase, nwg, blockIdx.x, blockIdx.y, S, &lo, &hi);
+  // FINE_UNROLL independent loads in flight per lane: the loop is otherwise one global-load latency per entry
+  for (u32 base = lo + threadIdx.x; base < hi; base += FINE_UNROLL * SORT2_THREADS) {
+    u32 f[FINE_UNROLL];
+#pragma unroll
+    for (int k = 0; k < FINE_UNROLL; k++) {
+      const u32 e = base + k * SORT2_THREADS;
+      f[k] = (e < hi) ? tmp[e].y : 0xffffffffu;
+    }
+#pragma unroll
+    for (int k = 0; k < FINE_UNROLL; k++) if (f[k] != 0xffffffffu) atomicAdd(&hist[f[k]], 1u);
+  }
+  __syncthreads();
+  for (int f = threadIdx.x; f < F; f += SORT2_THREADS) finehist[((size_t)blockIdx.x * F + f) * S + blockIdx.y] = hist[f];
+}
+__global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter(const uint2* __restrict__ tmp, const u32* __restrict__ binbase, int nwg, int F,
+                                                                 int S, const u32* __restrict__ finebase, u32* __restrict__ offsets,
+                                                                 u32* __restrict__ entries, size_t nbuckets) {
+  __shared__ u32 cursor[FINE_MAX];
+  for (int f = threadIdx.x; f < F; f += SORT2_THREADS) {
+    const u32 base = finebase[((size_t)blockIdx.x * F + f) * S + blockIdx.y];
+    cursor[f] = base;
+    if (blockIdx.y == 0) offsets[(size_t)blockIdx.x * F + f] = base;      // start of bucket (bin, f)
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) offsets[nbuckets] = finebase[nbuckets * (size_t)S];   // total entries
+  __syncthreads();
+  u32 lo, hi;
+  fine_slice(binbase, nwg, blockIdx.x, blockIdx.y, S, &lo, &hi);
+  for (u32 base = lo + threadIdx.x; base < hi; base += FINE_UNROLL * SORT2_THREADS) {
+    uint2 r[FINE_UNROLL];
+#pragma unroll
+    for (int k = 0; k < FINE_UNROLL; k++) {
+      const u32 e = base + k * SORT2_THREADS;
+      r[k] = (e < hi) ? tmp[e] : make_uint2(0u, 0xffffffffu);
+    }
+#pragma unroll
+    for (int k = 0; k < FINE_UNROLL; k++) if (r[k].y != 0xffffffffu) entries[atomicAdd(&cursor[r[k].y], 1u)] = r[k].x;
+  }
+}
+
 // ---- 2. exclusive scan (three small kernels) -----------------------------------------------------------
 constexpr int SCAN_ITEMS = 8;                      // per thread
 constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;       // 2048 per block
@@ -362,8 +494,10 @@ __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ 
 }
 // pass 2: buckets[b] = sum of slots [offsets[b] >> lgseg + b, offsets[b+1] >> lgseg + b]   (inclusive end:
 // the last entry of bucket b is offsets[b+1]-1, whose segment is <= offsets[b+1] >> lgseg)
-__global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slots, const u32* __restrict__ offsets, u32* __restrict__ buckets,
-                                                      size_t nbuckets, int lgseg) {
+// one lane per bucket: with 2^19 buckets of one or two partials each (generic layout) the kernel is bound by
+// the record traffic, not by a dependent chain
+__global__ __launch_bounds__(128) void k_seg_combine_wide(const u32* __restrict__ slots, const u32* __restrict__ offsets,
+                                                           u32* __restrict__ buckets, size_t nbuckets, int lgseg) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbuckets) return;
   const u32 o0 = offsets[b], o1 = offsets[b + 1];
@@ -373,6 +507,23 @@ __global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slo
     for (size_t sl = s0; sl <= s1; sl++) acc = xyzz_add(acc, xyzz_gload(slots, sl));
   }
   xyzz_gstore(buckets, b, acc);
+}
+__global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slots, const u32* __restrict__ offsets, u32* __restrict__ buckets,
+                                                      size_t nbuckets, int lgseg) {
+  // one DPP quad per bucket: a bucket's partials form a serial chain of additions (about nine at 2^20 merged),
+  // so the quad-cooperative addition cuts the kernel's latency; the quad also splits the 128-byte records.
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t b = tid >> 2;
+  const int lane = (int)(tid & 3);
+  if (b >= nbuckets) return;
+  const u32 o0 = offsets[b], o1 = offsets[b + 1];
+  Xyzz acc = xyzz_inf();
+  if (o1 > o0) {
+    const size_t s0 = (size_t)(o0 >> lgseg) + b, s1 = (size_t)((o1 - 1) >> lgseg) + b;
+    acc = xyzz_gload_quad(slots, s0, lane);
+    for (size_t sl = s0 + 1; sl <= s1; sl++) acc = xyzz_add_quad(acc, xyzz_gload_quad(slots, sl, lane), lane);
+  }
+  xyzz_gstore_quad(buckets, b, acc, lane);
 }
 
 // ---- 5. bucket reduction: sum_b (b+1) B_b per bucket set, by in-place halving ---------------------------
@@ -391,6 +542,18 @@ __device__ __forceinline__ void halve_op(u32* __restrict__ buf, int lgB, int t, 
   const size_t idx = base + j;
   const Xyzz x = xyzz_gload_quad(buf, idx, lane), y = xyzz_gload_quad(buf, idx + ((size_t)1 << lgh), lane);
   xyzz_gstore_quad(buf, idx, xyzz_add_quad(x, y, lane), lane);
+}
+// one lane per addition: for the early steps of MANY bucket sets (generic layout: 16 sets x 16 Ki additions) the
+// work is throughput-bound and the plain addition issues fewer instructions than the quad form
+__global__ __launch_bounds__(128) void k_halve_step_wide(u32* __restrict__ buckets, int lgB, int t) {
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)(t + 1) << (lgB - t - 1);
+  if (id >= total) return;
+  u32* buf = buckets + ((size_t)blockIdx.y << lgB) * 32;
+  const int lgh = lgB - t - 1;
+  const size_t a = id >> lgh, j = id & (((size_t)1 << lgh) - 1);
+  const size_t idx = ((a == 0) ? 0 : ((size_t)1 << (lgB - a))) + j;
+  xyzz_gstore(buf, idx, xyzz_add(xyzz_gload(buf, idx), xyzz_gload(buf, idx + ((size_t)1 << lgh))));
 }
 __global__ __launch_bounds__(128) void k_halve_step(u32* __restrict__ buckets, int lgB, int t) {
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -519,7 +682,10 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   const size_t scan_blocks = (NB + SCAN_BLOCK - 1) / SCAN_BLOCK;
   MZK_TRY(ws_get(WS_MSM_COUNTS, NB * 4, (void**)&counts));
   MZK_TRY(ws_get(WS_MSM_OFFSETS, (NB + 1) * 4, (void**)&offsets));
-  MZK_TRY(ws_get(WS_MSM_CURSOR, E_max * 4, (void**)&ranks));
+  // two-level sort when the bucket space is a power of two >= 2^12 (merged layout always; generic at c = 16)
+  const size_t NBtot = NB;
+  const bool two_level = (NBtot & (NBtot - 1)) == 0 && NBtot >= 4096 && (NBtot / COARSE_BINS) <= (size_t)FINE_MAX && n >= 4096;
+  MZK_TRY(ws_get(WS_MSM_CURSOR, E_max * (two_level ? 8 : 4), (void**)&ranks));
   MZK_TRY(ws_get(WS_MSM_ENTRIES, E_max * 4, (void**)&entries));
   MZK_TRY(ws_get(WS_MSM_SCAN, (scan_blocks + 1) * 4, (void**)&scan_tmp));
   MZK_TRY(ws_get(WS_MSM_BUCKETS, NB * 128, (void**)&buckets));
@@ -527,7 +693,38 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   prof_begin(s, MZK_PH_MSM_SORT);
   MZK_HIP(hipMemsetAsync(slots, 0, nslots * 128, s));
   const unsigned nblk = (unsigned)((n + 255) / 256);
-  if (L.merged) {
+  if (two_level) {
+    int kb = 0;
+    while (((size_t)1 << kb) < NBtot) kb++;
+    const int key_shift = kb - 8;
+    const int F = (int)(NBtot / COARSE_BINS);
+    const u32 fine_mask = (u32)F - 1u;
+    const int nwg = (int)((n + COARSE_PER_WG - 1) / COARSE_PER_WG);
+    int S = (int)((E_max / COARSE_BINS + 32767) / 32768);     // <= 32 Ki records per fine workgroup, >= 2 workgroups per CU
+    if (S < 2) S = 2;
+    if (S > 64) S = 64;
+    const size_t n_coarse = (size_t)COARSE_BINS * nwg, n_fine = NBtot * (size_t)S;
+    u32 *binhist, *finehist;
+    uint2* tmp;
+    MZK_TRY(ws_get(WS_MSM_WGHIST, (n_coarse + 1 + n_fine + 1) * 4, (void**)&binhist));
+    finehist = binhist + n_coarse + 1;
+    tmp = (uint2*)ranks;
+    const size_t sb_c = (n_coarse + SCAN_BLOCK - 1) / SCAN_BLOCK, sb_f = (n_fine + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    u32* scan2;
+    MZK_TRY(ws_get(WS_MSM_SCAN, (sb_c + sb_f + 4) * 4, (void**)&scan2));
+    hipLaunchKernelGGL(k_coarse_count, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
+    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)sb_c), dim3(256), 0, s, (const u32*)binhist, binhist, scan2, n_coarse);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, scan2, sb_c, scan2 + sb_c);
+    hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((n_coarse + 1 + 255) / 256)), dim3(256), 0, s, binhist, (const u32*)scan2, (const u32*)(scan2 + sb_c), n_coarse);
+    hipLaunchKernelGGL(k_coarse_scatter, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, fine_mask, (const u32*)binhist, nwg, tmp);
+    hipLaunchKernelGGL(k_fine_count, dim3(COARSE_BINS, S), dim3(SORT2_THREADS), 0, s, (const uint2*)tmp, (const u32*)binhist, nwg, F, S, finehist);
+    u32* scan3 = scan2 + sb_c + 2;
+    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)sb_f), dim3(256), 0, s, (const u32*)finehist, finehist, scan3, n_fine);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, scan3, sb_f, scan3 + sb_f);
+    hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((n_fine + 1 + 255) / 256)), dim3(256), 0, s, finehist, (const u32*)scan3, (const u32*)(scan3 + sb_f), n_fine);
+    hipLaunchKernelGGL(k_fine_scatter, dim3(COARSE_BINS, S), dim3(SORT2_THREADS), 0, s, (const uint2*)tmp, (const u32*)binhist, nwg, F, S,
+                       (const u32*)finehist, offsets, entries, NBtot);
+  } else if (L.merged) {
     // LDS histogram path (no global atomics)
     int nwg = (int)((n + 4095) / 4096);
     if (nwg > ctx().num_cu) nwg = ctx().num_cu;
@@ -561,7 +758,10 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   prof_begin(s, MZK_PH_MSM_ACCUMULATE);
   // the true entry count lives in offsets[NB] on the device; lanes past it exit (E_max bounds it)
   hipLaunchKernelGGL(k_seg_accumulate, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, pts, offsets, entries, slots, NB, lgseg);
-  hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, lgseg);
+  if (NB >= ((size_t)1 << 17))
+    hipLaunchKernelGGL(k_seg_combine_wide, dim3((unsigned)((NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, lgseg);
+  else
+    hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, lgseg);
   prof_end(s, MZK_PH_MSM_ACCUMULATE);
   prof_begin(s, MZK_PH_MSM_REDUCE);
 
@@ -572,7 +772,10 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   while (t_start < sh.lgB && ((size_t)(t_start + 1) << (sh.lgB - t_start - 1)) > (size_t)4 * TAIL_QUADS) t_start++;
   for (int t = 0; t < t_start; t++) {
     const size_t total = (size_t)(t + 1) << (sh.lgB - t - 1);
-    hipLaunchKernelGGL(k_halve_step, dim3((unsigned)((4 * total + 127) / 128), (unsigned)red_windows), dim3(128), 0, s, buckets, sh.lgB, t);
+    if (total * (size_t)red_windows >= ((size_t)1 << 16))
+      hipLaunchKernelGGL(k_halve_step_wide, dim3((unsigned)((total + 127) / 128), (unsigned)red_windows), dim3(128), 0, s, buckets, sh.lgB, t);
+    else
+      hipLaunchKernelGGL(k_halve_step, dim3((unsigned)((4 * total + 127) / 128), (unsigned)red_windows), dim3(128), 0, s, buckets, sh.lgB, t);
   }
   hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)red_windows), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, t_start, wsum);
   prof_end(s, MZK_PH_MSM_REDUCE);
