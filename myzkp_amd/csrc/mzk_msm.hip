@@ -253,6 +253,27 @@ __global__ __launch_bounds__(LDS_SORT_THREADS) void k_digits_scatter_lds(const u
 //           and k_fine_scatter writes the final 4-byte entries -- all inside one bin's region (256 KiB at 2^20),
 //           which stays in L2 while it fills.
 // key = bucket index: |digit| - 1 (merged layout) or window * 2^(c-1) + |digit| - 1.
+// LDS counter increment that stays fast when most of a wave hits ONE counter (bit-vector or repeated scalars):
+// the lanes sharing the first active lane's key take a single atomic together.  Returns the lane's rank.
+__device__ __forceinline__ u32 lds_inc_agg(u32* __restrict__ ctr, u32 key) {
+  const u32 k0 = (u32)__builtin_amdgcn_readfirstlane((int)key);
+  const u64 same = __builtin_amdgcn_ballot_w64(key == k0);
+  if (__builtin_popcountll(same) >= 16) {
+    u32 r;
+    if (key == k0) {
+      const u32 lane_id = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      const u32 rank = (u32)__builtin_popcountll(same & (((u64)1 << lane_id) - 1));
+      u32 base = 0;
+      if (rank == 0) base = atomicAdd(&ctr[k0], (u32)__builtin_popcountll(same));
+      base = (u32)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(same));
+      r = base + rank;
+    } else {
+      r = atomicAdd(&ctr[key], 1u);
+    }
+    return r;
+  }
+  return atomicAdd(&ctr[key], 1u);
+}
 constexpr int COARSE_BINS = 256;
 constexpr int COARSE_PER_WG = 4096;
 constexpr int SORT2_THREADS = 1024;
@@ -290,7 +311,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_count(const u32* __res
 #pragma unroll
   for (int k = 0; k < COARSE_PER_WG / SORT2_THREADS; k++) {
     const size_t i = lo + threadIdx.x + (size_t)k * SORT2_THREADS;
-    if (i < hi) walk_digits(w[k], L, i, [&](u32 key, u32) { atomicAdd(&hist[key >> key_shift], 1u); });
+    if (i < hi) walk_digits(w[k], L, i, [&](u32 key, u32) { lds_inc_agg(hist, key >> key_shift); });
   }
   __syncthreads();
   if (threadIdx.x < COARSE_BINS) binhist[(size_t)threadIdx.x * nwg + blockIdx.x] = hist[threadIdx.x];
@@ -313,7 +334,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter(const u32* __r
   for (int k = 0; k < COARSE_PER_WG / SORT2_THREADS; k++) {
     const size_t i = lo + threadIdx.x + (size_t)k * SORT2_THREADS;
     if (i < hi) walk_digits(w[k], L, i, [&](u32 key, u32 payload) {
-      const u32 pos = atomicAdd(&cursor[key >> key_shift], 1u);
+      const u32 pos = lds_inc_agg(cursor, key >> key_shift);
       tmp[pos] = make_uint2(payload, key & fine_mask);
     });
   }
@@ -343,7 +364,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_fine_count(const uint2* __res
       f[k] = (e < hi) ? tmp[e].y : 0xffffffffu;
     }
 #pragma unroll
-    for (int k = 0; k < FINE_UNROLL; k++) if (f[k] != 0xffffffffu) atomicAdd(&hist[f[k]], 1u);
+    for (int k = 0; k < FINE_UNROLL; k++) if (f[k] != 0xffffffffu) lds_inc_agg(hist, f[k]);
   }
   __syncthreads();
   for (int f = threadIdx.x; f < F; f += SORT2_THREADS) finehist[((size_t)blockIdx.x * F + f) * S + blockIdx.y] = hist[f];
@@ -369,7 +390,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter(const uint2* __r
       r[k] = (e < hi) ? tmp[e] : make_uint2(0u, 0xffffffffu);
     }
 #pragma unroll
-    for (int k = 0; k < FINE_UNROLL; k++) if (r[k].y != 0xffffffffu) entries[atomicAdd(&cursor[r[k].y], 1u)] = r[k].x;
+    for (int k = 0; k < FINE_UNROLL; k++) if (r[k].y != 0xffffffffu) entries[lds_inc_agg(cursor, r[k].y)] = r[k].x;
   }
 }
 
@@ -494,22 +515,32 @@ __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ 
 }
 // pass 2: buckets[b] = sum of slots [offsets[b] >> lgseg + b, offsets[b+1] >> lgseg + b]   (inclusive end:
 // the last entry of bucket b is offsets[b+1]-1, whose segment is <= offsets[b+1] >> lgseg)
+// Buckets with more than HEAVY_SLOTS partials (skewed scalars: bit vectors, repeated values) would be one long
+// serial chain; they are queued in `heavy` (count at heavy[0], bucket ids from heavy[1]) and summed by a whole
+// workgroup each (k_seg_combine_heavy).
+constexpr u32 HEAVY_SLOTS = 32;
+__device__ __forceinline__ bool defer_heavy(size_t b, size_t s0, size_t s1, u32* __restrict__ heavy, bool leader) {
+  if (s1 - s0 + 1 <= HEAVY_SLOTS) return false;
+  if (leader) heavy[1 + atomicAdd(&heavy[0], 1u)] = (u32)b;
+  return true;
+}
 // one lane per bucket: with 2^19 buckets of one or two partials each (generic layout) the kernel is bound by
 // the record traffic, not by a dependent chain
 __global__ __launch_bounds__(128) void k_seg_combine_wide(const u32* __restrict__ slots, const u32* __restrict__ offsets,
-                                                           u32* __restrict__ buckets, size_t nbuckets, int lgseg) {
+                                                           u32* __restrict__ buckets, size_t nbuckets, int lgseg, u32* __restrict__ heavy) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbuckets) return;
   const u32 o0 = offsets[b], o1 = offsets[b + 1];
   Xyzz acc = xyzz_inf();
   if (o1 > o0) {
     const size_t s0 = (size_t)(o0 >> lgseg) + b, s1 = (size_t)((o1 - 1) >> lgseg) + b;
+    if (defer_heavy(b, s0, s1, heavy, true)) return;
     for (size_t sl = s0; sl <= s1; sl++) acc = xyzz_add(acc, xyzz_gload(slots, sl));
   }
   xyzz_gstore(buckets, b, acc);
 }
 __global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slots, const u32* __restrict__ offsets, u32* __restrict__ buckets,
-                                                      size_t nbuckets, int lgseg) {
+                                                      size_t nbuckets, int lgseg, u32* __restrict__ heavy) {
   // one DPP quad per bucket: a bucket's partials form a serial chain of additions (about nine at 2^20 merged),
   // so the quad-cooperative addition cuts the kernel's latency; the quad also splits the 128-byte records.
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -520,10 +551,37 @@ __global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slo
   Xyzz acc = xyzz_inf();
   if (o1 > o0) {
     const size_t s0 = (size_t)(o0 >> lgseg) + b, s1 = (size_t)((o1 - 1) >> lgseg) + b;
+    if (defer_heavy(b, s0, s1, heavy, lane == 0)) return;       // quad-uniform
     acc = xyzz_gload_quad(slots, s0, lane);
     for (size_t sl = s0 + 1; sl <= s1; sl++) acc = xyzz_add_quad(acc, xyzz_gload_quad(slots, sl, lane), lane);
   }
   xyzz_gstore_quad(buckets, b, acc, lane);
+}
+constexpr int HEAVY_THREADS = 256;
+constexpr int HEAVY_QUADS = HEAVY_THREADS / 4;
+__global__ __launch_bounds__(HEAVY_THREADS) void k_seg_combine_heavy(const u32* __restrict__ slots, const u32* __restrict__ offsets,
+                                                                      u32* __restrict__ buckets, int lgseg, const u32* __restrict__ heavy) {
+  __shared__ __attribute__((aligned(16))) u32 sh[HEAVY_QUADS * 32];
+  const u32 count = heavy[0];
+  const int lane = threadIdx.x & 3, quad = threadIdx.x >> 2;
+  for (u32 h = blockIdx.x; h < count; h += gridDim.x) {
+    const size_t b = heavy[1 + h];
+    const u32 o0 = offsets[b], o1 = offsets[b + 1];
+    const size_t s0 = (size_t)(o0 >> lgseg) + b, s1 = (size_t)((o1 - 1) >> lgseg) + b;
+    Xyzz acc = xyzz_inf();
+    for (size_t sl = s0 + quad; sl <= s1; sl += HEAVY_QUADS) acc = xyzz_add_quad(acc, xyzz_gload_quad(slots, sl, lane), lane);
+    xyzz_gstore_quad(sh, quad, acc, lane);
+    __syncthreads();
+    for (int off = HEAVY_QUADS / 2; off >= 1; off >>= 1) {
+      if (quad < off) {
+        const Xyzz x = xyzz_gload_quad(sh, quad, lane), y = xyzz_gload_quad(sh, quad + off, lane);
+        xyzz_gstore_quad(sh, quad, xyzz_add_quad(x, y, lane), lane);
+      }
+      __syncthreads();
+    }
+    if (quad == 0) xyzz_gstore_quad(buckets, b, xyzz_gload_quad(sh, 0, lane), lane);
+    __syncthreads();
+  }
 }
 
 // ---- 5. bucket reduction: sum_b (b+1) B_b per bucket set, by in-place halving ---------------------------
@@ -678,6 +736,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   while ((E_max >> lgseg) > ((size_t)1 << 18) && lgseg < 16) lgseg++;
   const size_t T = (E_max + ((size_t)1 << lgseg) - 1) >> lgseg;
   const size_t nslots = T + NB + 1;
+  const size_t heavy_words = 4 + (T + NB) / HEAVY_SLOTS;         // count + at most (T + NB) / 33 heavy buckets
   u32 *counts, *offsets, *ranks, *entries, *scan_tmp, *buckets, *slots;
   const size_t scan_blocks = (NB + SCAN_BLOCK - 1) / SCAN_BLOCK;
   MZK_TRY(ws_get(WS_MSM_COUNTS, NB * 4, (void**)&counts));
@@ -689,9 +748,10 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   MZK_TRY(ws_get(WS_MSM_ENTRIES, E_max * 4, (void**)&entries));
   MZK_TRY(ws_get(WS_MSM_SCAN, (scan_blocks + 1) * 4, (void**)&scan_tmp));
   MZK_TRY(ws_get(WS_MSM_BUCKETS, NB * 128, (void**)&buckets));
-  MZK_TRY(ws_get(WS_MSM_SLOTS, nslots * 128, (void**)&slots));
+  MZK_TRY(ws_get(WS_MSM_SLOTS, nslots * 128 + heavy_words * 4, (void**)&slots));
+  u32* heavy = slots + nslots * 32;                             // zeroed together with the slots
   prof_begin(s, MZK_PH_MSM_SORT);
-  MZK_HIP(hipMemsetAsync(slots, 0, nslots * 128, s));
+  MZK_HIP(hipMemsetAsync(slots, 0, nslots * 128 + 8, s));
   const unsigned nblk = (unsigned)((n + 255) / 256);
   if (two_level) {
     int kb = 0;
@@ -759,9 +819,10 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   // the true entry count lives in offsets[NB] on the device; lanes past it exit (E_max bounds it)
   hipLaunchKernelGGL(k_seg_accumulate, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, pts, offsets, entries, slots, NB, lgseg);
   if (NB >= ((size_t)1 << 17))
-    hipLaunchKernelGGL(k_seg_combine_wide, dim3((unsigned)((NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, lgseg);
+    hipLaunchKernelGGL(k_seg_combine_wide, dim3((unsigned)((NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, lgseg, heavy);
   else
-    hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, lgseg);
+    hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, lgseg, heavy);
+  hipLaunchKernelGGL(k_seg_combine_heavy, dim3(512), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)offsets, buckets, lgseg, (const u32*)heavy);
   prof_end(s, MZK_PH_MSM_ACCUMULATE);
   prof_begin(s, MZK_PH_MSM_REDUCE);
 

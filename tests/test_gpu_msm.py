@@ -132,3 +132,37 @@ def test_srs_window_tables_path(mz):
         h.commit(orc.synth_vector(FR, 9, n + 1))
     assert e.value.code == -5
     h.close()
+
+
+def _skewed_scalar_sets(n, seed):
+    """realistic skew: bit vectors and repeated values put most entries into a handful of buckets"""
+    rng = np.random.default_rng(seed)
+    uni = orc.synth_vector(FR, seed, n)
+    ones = np.zeros((n, 4), dtype=np.uint64); ones[:, 0] = 1
+    bits = np.zeros((n, 4), dtype=np.uint64); bits[:, 0] = rng.integers(0, 2, n, dtype=np.uint64)
+    equal = np.tile(uni[:1], (n, 1))
+    small = np.zeros((n, 4), dtype=np.uint64); small[:, 0] = uni[:, 0] & np.uint64(0xffff)
+    mixed = uni.copy(); mixed[: (3 * n) // 4] = ones[: (3 * n) // 4]        # 75 % ones, 25 % uniform
+    minus1 = np.tile(orc.to_limbs([P_FR - 1], 4), (n, 1))                     # every digit negative-carrying
+    return {"ones": ones, "bits": bits, "equal": equal, "small16": small, "mixed": mixed, "minus_one": minus1}
+
+
+def test_skewed_scalars_merged_two_level_sort(mz):
+    """SRS (merged-bucket) path at a size that takes the two-level sort, the aggregated LDS counters and the
+    heavy-bucket combine: result must equal the oracle for every skew pattern."""
+    n = 1 << 14
+    p = orc.synth_points(777, n)
+    h = mz.Srs(p)
+    for name, s in _skewed_scalar_sets(n, 31).items():
+        assert h.commit(s) == orc.msm_fast(s, p), name
+    h.close()
+
+
+def test_skewed_scalars_generic_two_level_sort(mz):
+    """generic layout takes the two-level sort from n = 2^19 (c = 16); heavy buckets there go through
+    k_seg_combine_wide's deferral"""
+    n = 1 << 19
+    p = orc.synth_points(778, n)
+    sets = _skewed_scalar_sets(n, 32)
+    for name in ("ones", "bits", "mixed", "equal"):
+        assert mz.msm_g1(sets[name], p) == orc.msm_fast(sets[name], p), name
