@@ -67,6 +67,26 @@ __global__ void k_fb_table(const u32* __restrict__ bases, u32* __restrict__ tabl
   st8(table + 16 * t, o);
   st8(table + 16 * t + 8, o + 8);
 }
+// table16[w][d] = d * 2^(16 w) * g1 for d < 65536 from the 8-bit table: T8[2w][d & 255] + T8[2w+1][d >> 8], written
+// as XYZZ records (converted to affine in one batched pass afterwards).  Halves the additions per SRS power.
+__global__ __launch_bounds__(128) void k_fb_table16(const u32* __restrict__ table8, u32* __restrict__ out_xyzz) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)16 << 16) return;
+  const int w = (int)(t >> 16);
+  const u32 d = (u32)t & 65535u, lo = d & 255u, hi = d >> 8;
+  u32 a[16], b[16];
+  ld8(table8 + 16 * ((size_t)(2 * w) * 256 + lo), a);
+  ld8(table8 + 16 * ((size_t)(2 * w) * 256 + lo) + 8, a + 8);
+  ld8(table8 + 16 * ((size_t)(2 * w + 1) * 256 + hi), b);
+  ld8(table8 + 16 * ((size_t)(2 * w + 1) * 256 + hi) + 8, b + 8);
+  Xyzz acc = xyzz_inf();
+  if (!affine_words_is_inf(a)) acc = xyzz_from_affine(affine_load_mont(a));
+  if (!affine_words_is_inf(b)) acc = xyzz_madd(acc, affine_load_mont(b));
+  u32 o[32];
+  xyzz_store(acc, o);
+#pragma unroll
+  for (int q = 0; q < 4; q++) st8(out_xyzz + 32 * t + 8 * q, o + 8 * q);
+}
 // atab[l][j] = alpha^(j * 2^(11 l)), l < 3, j < 2048, canonical Montgomery: alpha^e for e < 2^33 is then two
 // products instead of a ~96-product square-and-multiply per SRS power.
 constexpr int ATAB_BITS = 11;
@@ -82,6 +102,7 @@ __global__ void k_alpha_table(Words8k alpha_plain, u32* __restrict__ atab) {
   st8(atab + 8 * t, o);
 }
 // acc[i] = alpha^(first+i) * g1 as XYZZ (32 words); the affine conversion is batched afterwards.
+template <int WB>   // window bits of the fixed-base table: 8 (32 windows, 512 KiB) or 16 (16 windows, 64 MiB)
 __global__ __launch_bounds__(128) void k_fb_powers(Words8k alpha_plain, const u32* __restrict__ atab, const u32* __restrict__ table,
                                                    size_t first, size_t count, u32* __restrict__ out_xyzz) {
   typedef FrParams R;
@@ -103,12 +124,14 @@ __global__ __launch_bounds__(128) void k_fb_powers(Words8k alpha_plain, const u3
   u32 kw[8];
   fe_pack<R>(k, kw);
   Xyzz acc = xyzz_inf();
-  for (int w = 0; w < 32; w++) {
-    const u32 d = (kw[w >> 2] >> (8 * (w & 3))) & 255u;
+#pragma unroll 1
+  for (int w = 0; w < 256 / WB; w++) {
+    const u32 d = (WB == 8) ? ((kw[w >> 2] >> (8 * (w & 3))) & 255u) : ((kw[w >> 1] >> (16 * (w & 1))) & 65535u);
     if (d == 0) continue;
     u32 tw[16];
-    ld8(table + 16 * ((size_t)w * 256 + d), tw);
-    ld8(table + 16 * ((size_t)w * 256 + d) + 8, tw + 8);
+    const size_t idx = ((size_t)w << WB) + d;
+    ld8(table + 16 * idx, tw);
+    ld8(table + 16 * idx + 8, tw + 8);
     if (affine_words_is_inf(tw)) continue;
     acc = xyzz_madd(acc, affine_load_mont(tw));
   }
@@ -195,12 +218,23 @@ int kzg_setup_g1_dev(const uint64_t* alpha_host, const uint64_t* g1_host, size_t
   MZK_TRY(ws_get(WS_MISC_C, (size_t)(3 << ATAB_BITS) * 32, (void**)&atab));
   MZK_TRY(ws_get(WS_MISC_A, 32 * 64, (void**)&bases));
   MZK_TRY(ws_get(WS_MISC_B, 32 * 256 * 64, (void**)&table));
-  MZK_TRY(ws_get(WS_XYZZ_TMP, count * 128, (void**)&acc));
+  const bool wide = count >= ((size_t)1 << 16);      // the 64 MiB table pays for itself from ~2^16 powers on
+  const size_t t16 = (size_t)16 << 16;
+  MZK_TRY(ws_get(WS_XYZZ_TMP, (wide && t16 > count ? t16 : count) * 128, (void**)&acc));
+  u32* table16 = nullptr;
+  if (wide) MZK_TRY(ws_get(WS_FB_TABLE16, t16 * 64, (void**)&table16));
   hipLaunchKernelGGL(k_fb_bases, dim3(1), dim3(32), 0, s, gw, bases);
   hipLaunchKernelGGL(k_fb_table, dim3(32), dim3(256), 0, s, (const u32*)bases, table);
   hipLaunchKernelGGL(k_alpha_table, dim3((3 << ATAB_BITS) / 256), dim3(256), 0, s, aw, atab);
-  hipLaunchKernelGGL(k_fb_powers, dim3((unsigned)((count + 127) / 128)), dim3(128), 0, s, aw, (const u32*)atab, (const u32*)table, first,
-                     count, acc);
+  if (wide) {
+    hipLaunchKernelGGL(k_fb_table16, dim3((unsigned)(t16 / 128)), dim3(128), 0, s, (const u32*)table, acc);
+    MZK_TRY(xyzz_batch_to_affine(acc, t16, table16, true, s));
+    hipLaunchKernelGGL((k_fb_powers<16>), dim3((unsigned)((count + 127) / 128)), dim3(128), 0, s, aw, (const u32*)atab, (const u32*)table16,
+                       first, count, acc);
+  } else {
+    hipLaunchKernelGGL((k_fb_powers<8>), dim3((unsigned)((count + 127) / 128)), dim3(128), 0, s, aw, (const u32*)atab, (const u32*)table,
+                       first, count, acc);
+  }
   MZK_HIP(hipGetLastError());
   return xyzz_batch_to_affine(acc, count, d_powers_xy, false, s);
 }

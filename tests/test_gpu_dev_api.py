@@ -138,3 +138,22 @@ def test_setup_alpha_zero_gives_g_then_infinity(env):
     torch.cuda.synchronize()
     o = out.cpu().numpy().view(np.uint64)
     assert np.array_equal(o[0], g_l[0]) and not o[1:].any()
+
+
+def test_setup_wide_table_path_full_array_vs_oracle(env):
+    """count >= 2^16 switches to the 16-bit fixed-base table (k_fb_table16 + k_fb_powers<16>): every power of a
+    ragged, offset range over a non-standard base must equal the oracle's fixed-base ladder."""
+    torch, mz, L, dev, st = env
+    alpha = 0xfeedfacecafebeef0123456789abcdef0fedcba987654321 % orc.P_FR
+    g = orc.ec_mul(0, (1, 2), 5)
+    first, count = 12345, (1 << 16) + 37
+    acc, scal = pow(alpha, first, orc.P_FR), []
+    for _ in range(count):
+        scal.append(acc); acc = acc * alpha % orc.P_FR
+    want = orc.fixed_base_batch(g, orc.to_limbs(scal, 4))
+    a_l, g_l = orc.to_limbs([alpha], 4), orc.pts_to_arr([g])
+    out = torch.zeros((count, 8), dtype=torch.int64, device=dev)
+    _ok(L, L.mzk_kzg_setup_g1_range_dev(a_l.ctypes.data_as(ctypes.c_void_p), g_l.ctypes.data_as(ctypes.c_void_p),
+                                        ctypes.c_size_t(first), ctypes.c_size_t(count), _dp(out), st))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
