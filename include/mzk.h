@@ -97,6 +97,15 @@ int mzk_kzg_batch_open(const uint64_t* coef, size_t n, const uint64_t* us, size_
  * d > max_d (usize underflow) or a product longer than the SRS (index panic) -> MZK_E_LENGTH. */
 int mzk_kzg_prove_degree_bound(const uint64_t* coef, size_t n, const uint64_t* powers_xy, size_t n_powers,
                                size_t d, uint64_t out_xy[8]);
+/* ntt::fast_coset_divide (algebra/ntt.rs:271-330; FastStark::prove's quotients, zkstark/fast_stark.rs:265):
+ * both polynomials scaled onto the coset offset*<root>, forward transforms, pointwise el * r.inverse()
+ * (inverse(0) = 0, field.rs:209-232), inverse transform, first lhs.degree() - rhs.degree() + 1 coefficients scaled
+ * back by offset^-1.  degree < 8 returns lhs / rhs (true long division, trimmed).  The reference's assertions map to
+ * MZK_E_ROOT_ORDER / MZK_E_ROOT_PRIM (ntt.rs:282-283), MZK_E_ARG (rhs zero, :284), MZK_E_LENGTH (rhs.degree() >=
+ * lhs.degree(), :285 -- a zero lhs included).  out must hold ll coefficients; *out_len receives the count. */
+int mzk_fast_coset_divide(int field_id, const uint64_t* lhs, size_t ll, const uint64_t* rhs, size_t lr, const uint64_t* offset,
+                          const uint64_t* root, size_t root_order, uint64_t* out, size_t* out_len);
+
 /* FRI commit-loop split-and-fold (zkstark/fri.rs:182-193):
  * out[i] = 2^-1 ((1 + alpha/(offset omega^i)) c[i] + (1 - alpha/(offset omega^i)) c[n/2 + i]), i < n/2,
  * sanitized.  offset must be non-zero and omega a root of order n (as FRI::commit maintains). */

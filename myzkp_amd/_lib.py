@@ -346,3 +346,14 @@ def fri_commit(fid, codeword, omega, offset, num_rounds, challenge):
         rts.append(raw[48 * r:48 * r + lens[r]])
         at += n >> r
     return cws, rts
+
+
+def fast_coset_divide(fid, lhs, rhs, offset, root, root_order):
+    """ntt::fast_coset_divide (algebra/ntt.rs:271-330)."""
+    a, b = _arr(fid, lhs), _arr(fid, rhs)
+    out = np.zeros((max(a.shape[0], 1), LIMBS[fid]), dtype=np.uint64)
+    ln = ctypes.c_size_t()
+    o, r = _one(fid, offset), _one(fid, root)
+    _check(lib().mzk_fast_coset_divide(fid, _p(a), ctypes.c_size_t(a.shape[0]), _p(b), ctypes.c_size_t(b.shape[0]), _p(o), _p(r),
+                                       ctypes.c_size_t(root_order), _p(out), ctypes.byref(ln)))
+    return out[:ln.value]

@@ -430,6 +430,76 @@ int mzk_fast_multiply(int field_id, const uint64_t* a, size_t la, const uint64_t
   return MZK_OK;
 }
 
+// ntt::fast_coset_divide (ntt.rs:271-330): the quotient step of FastStark::prove (fast_stark.rs:265).
+int mzk_fast_coset_divide(int field_id, const uint64_t* lhs, size_t ll, const uint64_t* rhs, size_t lr, const uint64_t* offset,
+                          const uint64_t* root, size_t root_order, uint64_t* out, size_t* out_len) {
+  MZK_TRY(ensure_init());
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fast_coset_divide: bad field id %d", field_id); return MZK_E_ARG; }
+  if (!out || !out_len || !root || !offset || (!lhs && ll) || (!rhs && lr)) { set_error("fast_coset_divide: null pointer"); return MZK_E_ARG; }
+  const HostField* hf = host_field(field_id);
+  const int nl = hf->nl;
+  if (!h_is_canonical(hf, root) || !h_is_canonical(hf, offset)) { set_error("fast_coset_divide: parameter not canonical"); return MZK_E_RANGE; }
+  uint64_t t[4];
+  h_powmod_u64(hf, t, root, root_order);       // ntt.rs:282-283
+  if (!h_is_one(hf, t)) { set_error("assertion failed: primitive_root.pow(root_order).is_one()"); return MZK_E_ROOT_ORDER; }
+  h_powmod_u64(hf, t, root, root_order / 2);
+  if (h_is_one(hf, t)) { set_error("assertion failed: !primitive_root.pow(root_order / 2).is_one()"); return MZK_E_ROOT_PRIM; }
+  for (size_t i = 0; i < ll; i++) if (!h_is_canonical(hf, lhs + i * nl)) { set_error("fast_coset_divide: lhs[%zu] not canonical", i); return MZK_E_RANGE; }
+  for (size_t i = 0; i < lr; i++) if (!h_is_canonical(hf, rhs + i * nl)) { set_error("fast_coset_divide: rhs[%zu] not canonical", i); return MZK_E_RANGE; }
+  const size_t tl = trimmed_len(lhs, ll, nl), tr = trimmed_len(rhs, lr, nl);
+  if (tr == 0) { set_error("assertion failed: !rhs.is_zero()"); return MZK_E_ARG; }                           // ntt.rs:284
+  if (!(tr < tl)) { set_error("assertion failed: rhs.degree() < lhs.degree()"); return MZK_E_LENGTH; }      // ntt.rs:285 (a zero lhs has degree -1)
+  const size_t degree = tl - 1, ql = tl - tr + 1;
+  if (degree < 8) {
+    // ntt.rs:295-297 `return lhs / rhs`: true long division (polynomial.rs:371-405) of at most 8 coefficients --
+    // parameter-sized work, done with the host parameter arithmetic
+    uint64_t rem[8][4], quo[8][4], linv[4], lead[4], prod[4];
+    memset(rem, 0, sizeof rem); memset(quo, 0, sizeof quo);
+    for (size_t i = 0; i < tl; i++) memcpy(rem[i], lhs + i * nl, 8 * nl);
+    h_invmod(hf, linv, rhs + (tr - 1) * nl);
+    size_t rl = tl;
+    while (rl >= tr) {
+      h_mulmod(hf, lead, rem[rl - 1], linv);
+      const size_t dd = rl - tr;
+      memcpy(quo[dd], lead, 8 * nl);
+      for (size_t i = 0; i < tr; i++) {
+        h_mulmod(hf, prod, lead, rhs + i * nl);
+        // rem - prod mod p = rem + (p - prod)
+        uint64_t neg[4] = {0, 0, 0, 0};
+        bool z = true;
+        for (int k = 0; k < nl; k++) z = z && prod[k] == 0;
+        if (!z) { unsigned __int128 br = 0; for (int k = 0; k < nl; k++) { unsigned __int128 d = (unsigned __int128)hf->p[k] - prod[k] - br; neg[k] = (uint64_t)d; br = (d >> 64) & 1; } }
+        h_addmod(hf, rem[dd + i], rem[dd + i], neg);
+      }
+      while (rl > 0) { bool z = true; for (int k = 0; k < nl; k++) z = z && rem[rl - 1][k] == 0; if (!z) break; rl--; }
+    }
+    size_t qt = ql;
+    while (qt > 0) { bool z = true; for (int k = 0; k < nl; k++) z = z && quo[qt - 1][k] == 0; if (!z) break; qt--; }
+    for (size_t i = 0; i < qt; i++) memcpy(out + i * nl, quo[i], 8 * nl);
+    *out_len = qt;
+    return MZK_OK;
+  }
+  uint64_t r[4] = {0, 0, 0, 0};
+  memcpy(r, root, 8 * nl);
+  size_t order = root_order;
+  while (degree < order / 2) { h_mulmod(hf, r, r, r); order /= 2; }   // ntt.rs:299-302
+  if (tl > order) {   // the inner ntt call's own assertions (ntt.rs:8-18)
+    if (tl & (tl - 1)) { set_error("cannot compute ntt of non-power-of-two sequence"); return MZK_E_NOT_POW2; }
+    set_error("primitive root must be nth root of unity, where n is len(values)"); return MZK_E_ROOT_ORDER;
+  }
+  hipStream_t s = g_ctx.stream;
+  const size_t esz = field_bytes(field_id);
+  void *d_l, *d_r, *d_o;
+  MZK_TRY(stage_in(WS_MISC_C, lhs, tl * esz, &d_l, s));
+  MZK_TRY(stage_in(WS_MISC_D, rhs, tr * esz, &d_r, s));
+  MZK_TRY(ws_get(WS_NTT_IO_B, ql * esz, &d_o));
+  MZK_TRY(coset_divide_dev_impl(field_id, d_l, tl, d_r, tr, offset, r, order, d_o, s));
+  MZK_HIP(hipMemcpyAsync(out, d_o, ql * esz, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  *out_len = ql;
+  return MZK_OK;
+}
+
 // ---- MSM / KZG ---------------------------------------------------------------------------------------------
 struct mzk_srs {
   void* d_points_mont;   // MSM_SRS_WINDOWS x n window tables when has_tables, else n prepared points

@@ -584,6 +584,77 @@ int fri_fold_dev_impl(int fid, const void* d_cw, size_t n, const uint64_t* alpha
   return MZK_OK;
 }
 
+// out[i] = a[i] * b[i]^-1 with inverse(0) = 0 (field.rs:209-232: the extended Euclid returns t = 0 for 0), plain
+// domain in and out.  One lane owns DIV_BATCH consecutive elements and inverts them together (Montgomery's
+// trick: running products, ONE Fermat inversion, unwind): ~5 products per element + 1/DIV_BATCH of an inversion.
+constexpr int DIV_BATCH = 16;
+template <class P>
+__global__ __launch_bounds__(128) void k_pointwise_div(const u32* __restrict__ a, const u32* __restrict__ b, u32* __restrict__ out, size_t n) {
+  const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * DIV_BATCH;
+  if (i0 >= n) return;
+  const int len = (int)((n - i0 < (size_t)DIV_BATCH) ? (n - i0) : (size_t)DIV_BATCH);
+  Fe<P> pre[DIV_BATCH];                                      // lives in scratch (dynamically indexed): 36 B per element
+  Fe<P> run = fe_one<P>();
+  for (int j = 0; j < len; j++) {
+    {
+      const Fe<P> y = gload<P>(b, i0 + j);                   // canonical
+      pre[j] = run;                                          // product of the earlier non-zero denominators (Montgomery)
+      Fe<P> ym = fe_to_mont<P>(y);
+      if (fe_is_zero_canon<P>(y)) ym = fe_one<P>();
+      run = fe_mul<P>(run, ym);
+    }
+  }
+  Fe<P> inv = fe_inv<P>(run);
+  for (int j = len - 1; j >= 0; j--) {
+    {
+      const Fe<P> y = gload<P>(b, i0 + j);
+      const bool zero = fe_is_zero_canon<P>(y);
+      const Fe<P> yinv = fe_mul<P>(inv, pre[j]);             // Montgomery form of 1 / y_j
+      Fe<P> ym = fe_to_mont<P>(y);
+      if (zero) ym = fe_one<P>();
+      inv = fe_mul<P>(inv, ym);
+      const Fe<P> x = gload<P>(a, i0 + j);
+      const Fe<P> q = fe_reduce<P>(fe_mul<P>(x, yinv));       // plain * Montgomery = plain
+      gstore<P>(out, i0 + j, zero ? fe_zero<P>() : q);
+    }
+  }
+}
+
+// ntt::fast_coset_divide's transform part (ntt.rs:304-329): lhs (tl coefficients), rhs (tr) scaled by offset^i and
+// padded to `order`, forward transforms, pointwise quotient, inverse transform, the first tl - tr + 1 coefficients
+// scaled by offset^-i.  root has order exactly `order` (the caller squared it down, ntt.rs:299-302).
+int coset_divide_dev_impl(int fid, const void* d_lhs, size_t tl, const void* d_rhs, size_t tr, const uint64_t* offset_host,
+                          const uint64_t* root_host, size_t order, void* d_out, hipStream_t s) {
+  const HostField* hf = host_field(fid);
+  const size_t esz = field_bytes(fid);
+  void *ea, *eb;
+  MZK_TRY(ws_get(WS_MISC_A, order * esz, &ea));
+  MZK_TRY(ws_get(WS_MISC_B, order * esz, &eb));
+  MZK_TRY(coset_lde_dev_impl(fid, d_lhs, tl, offset_host, root_host, ea, order, s));
+  MZK_TRY(coset_lde_dev_impl(fid, d_rhs, tr, offset_host, root_host, eb, order, s));
+  const size_t lanes = (order + DIV_BATCH - 1) / DIV_BATCH;
+  const unsigned blocks = (unsigned)((lanes + 127) / 128);
+  if (fid == MZK_FIELD_M128)
+    hipLaunchKernelGGL((k_pointwise_div<M128Params>), dim3(blocks), dim3(128), 0, s, (const u32*)ea, (const u32*)eb, (u32*)ea, order);
+  else
+    hipLaunchKernelGGL((k_pointwise_div<FrParams>), dim3(blocks), dim3(128), 0, s, (const u32*)ea, (const u32*)eb, (u32*)ea, order);
+  MZK_HIP(hipGetLastError());
+  MZK_TRY(ntt_dev_impl(fid, root_host, ea, eb, order, 1, nullptr, s));
+  uint64_t oinv[4];
+  h_invmod(hf, oinv, offset_host);
+  Words8 ow;
+  to_words(oinv, hf->nl, &ow);
+  const size_t ql = tl - tr + 1;
+  const size_t chunks = (ql + GEN_CHUNK - 1) / GEN_CHUNK;
+  const unsigned sblocks = (unsigned)((chunks + 255) / 256);
+  if (fid == MZK_FIELD_M128)
+    hipLaunchKernelGGL((k_coset_scale_pad<M128Params>), dim3(sblocks), dim3(256), 0, s, (const u32*)eb, ql, ow, (u32*)d_out, ql);
+  else
+    hipLaunchKernelGGL((k_coset_scale_pad<FrParams>), dim3(sblocks), dim3(256), 0, s, (const u32*)eb, ql, ow, (u32*)d_out, ql);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+
 int pointwise_mul_dev(int fid, const void* d_a, const void* d_b, void* d_out, size_t n, hipStream_t s) {
   if (n == 0) return MZK_OK;
   const unsigned blocks = (unsigned)((n + 255) / 256);

@@ -237,6 +237,16 @@ inline ProofDegreeBound prove_degree_bound(const Polynomial<FqOrder>& f, const P
   expect(mzk_kzg_prove_degree_bound(c.data(), f.coef.size(), p.data(), pk.powers_1.size(), d, w));
   return G1Point::from_wire(w);
 }
+// ntt::fast_coset_divide (ntt.rs:271-330)
+template <class F>
+Polynomial<F> fast_coset_divide(const Polynomial<F>& lhs, const Polynomial<F>& rhs, const F& offset, const F& primitive_root, size_t root_order) {
+  auto a = to_wire(lhs.coef), b = to_wire(rhs.coef);
+  std::vector<uint64_t> out((lhs.coef.size() + 1) * F().value.size());
+  size_t len = 0;
+  expect(mzk_fast_coset_divide(Polynomial<F>::field_id(), a.data(), lhs.coef.size(), b.data(), rhs.coef.size(), offset.value.data(),
+                               primitive_root.value.data(), root_order, out.data(), &len));
+  return Polynomial<F>{from_wire<F>(out, len)};
+}
 // one round of the split-and-fold in FRI::commit (zkstark/fri.rs:182-193)
 template <class F>
 std::vector<F> fri_split_and_fold(const std::vector<F>& codeword, const F& alpha, const F& offset, const F& omega) {

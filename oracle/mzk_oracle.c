@@ -1134,3 +1134,73 @@ int orc_kzg_prove_degree_bound_ref(const u64* coef, size_t n, const u64* powers_
   free(r);
   return rc;
 }
+
+/* ntt::fast_coset_divide, algebra/ntt.rs:271-330 (the quotient step of FastStark::prove, fast_stark.rs:265).
+ * Returns: -3 / -4 root order assertions (ntt.rs:282-283), -1 rhs zero (:284), -5 rhs.degree() >= lhs.degree()
+ * (:285; a zero lhs has degree -1 and therefore lands here too, before the is_zero early return can be reached).
+ * out receives lhs.degree() - rhs.degree() + 1 coefficients (degree < 8: the trimmed quotient of lhs / rhs). */
+int orc_fast_coset_divide_ref(int fid, const u64* lhs, size_t ll, const u64* rhs, size_t lr, const u64* offset,
+                              const u64* root, size_t root_order, u64* out, size_t* out_len) {
+  const fld_t* f = fld_of(fid); if (!f) return -1;
+  const int L = f->n;
+  u64 rm[MAXN], t[MAXN], om[MAXN];
+  f_tomont(f, rm, root);
+  f_mpow_u64(f, t, rm, (u64)root_order);
+  if (memcmp(t, f->one, 8 * L) != 0) return -3;
+  f_mpow_u64(f, t, rm, (u64)(root_order / 2));
+  if (memcmp(t, f->one, 8 * L) == 0) return -4;
+  u64* lm = malloc(8 * L * (ll ? ll : 1)), *rhm = malloc(8 * L * (lr ? lr : 1));
+  to_mont_vec(f, lm, lhs, ll);
+  to_mont_vec(f, rhm, rhs, lr);
+  const size_t tl = trimmed_len(f, lm, ll), tr = trimmed_len(f, rhm, lr);
+  int rc = 0;
+  if (tr == 0) rc = -1;
+  else if (!((long)tr - 1 < (long)tl - 1)) rc = -5;
+  if (rc) { free(lm); free(rhm); return rc; }
+  const size_t degree = tl - 1;                       /* max(lhs.degree(), rhs.degree()) */
+  if (degree < 8) {                                   /* ntt.rs:295-297: lhs / rhs */
+    u64* rem = malloc(8 * L * tl), *quo = malloc(8 * L * tl);
+    memcpy(rem, lm, 8 * L * tl);
+    size_t rl, ql = poly_divrem_m(f, rem, tl, rhm, tr, quo, &rl);
+    from_mont_vec(f, out, quo, ql);
+    *out_len = ql;
+    free(rem); free(quo); free(lm); free(rhm);
+    return 0;
+  }
+  size_t order = root_order;
+  while (degree < order / 2) { f_mmul(f, rm, rm, rm); order /= 2; }      /* ntt.rs:299-302 */
+  if (tl > order) {   /* more coefficients than the root's order: the ntt call's own assertions fire (ntt.rs:8-18) */
+    free(lm); free(rhm);
+    return (tl & (tl - 1)) ? -2 : -3;
+  }
+  f_tomont(f, om, offset);
+  u64* a = calloc(order, 8 * L), *b = calloc(order, 8 * L), *ea = malloc(8 * L * order), *eb = malloc(8 * L * order);
+  poly_scale_m(f, a, lm, tl, om);                     /* scaled_lhs.coef[..=deg], zero-padded to order */
+  poly_scale_m(f, b, rhm, tr, om);
+  rc = ntt_ref_rec(f, rm, a, ea, order);
+  if (!rc) rc = ntt_ref_rec(f, rm, b, eb, order);
+  if (!rc) {
+    for (size_t i = 0; i < order; i++) {              /* el.div_ref(r): el * r.inverse(), inverse(0) = 0 */
+      u64 inv[MAXN];
+      f_minv(f, inv, eb + i * L);
+      f_mmul(f, ea + i * L, ea + i * L, inv);
+    }
+    /* intt (ntt.rs:50-64): n^-1 * ntt(root^-1, values) */
+    u64 rinv[MAXN], ninv[MAXN], nn[MAXN] = {0}, oinv[MAXN];
+    f_minv(f, rinv, rm);
+    nn[0] = (u64)order;
+    f_tomont(f, ninv, nn);
+    f_minv(f, ninv, ninv);
+    rc = ntt_ref_rec(f, rinv, ea, a, order);
+    if (!rc) {
+      const size_t ql = tl - tr + 1;
+      for (size_t i = 0; i < ql; i++) f_mmul(f, a + i * L, a + i * L, ninv);
+      f_minv(f, oinv, om);
+      poly_scale_m(f, b, a, ql, oinv);               /* scaled_quotient.scale(&offset.inverse()) */
+      from_mont_vec(f, out, b, ql);
+      *out_len = ql;
+    }
+  }
+  free(a); free(b); free(ea); free(eb); free(lm); free(rhm);
+  return rc;
+}

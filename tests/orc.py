@@ -324,3 +324,13 @@ def merkle_commit_field_ref(fid, arr):
     ln = ctypes.c_size_t()
     assert lib().orc_merkle_commit_ref(blob, ptr(off), ctypes.c_size_t(n), root, ctypes.byref(ln)) == 0
     return bytes(root[:ln.value])
+
+
+def fast_coset_divide_ref(fid, lhs, rhs, offset, root, root_order):
+    nl = LIMBS[fid]
+    out = np.zeros((max(lhs.shape[0], 1), nl), dtype=np.uint64)
+    ln = ctypes.c_size_t()
+    o, r = one(fid, offset), one(fid, root)
+    rc = lib().orc_fast_coset_divide_ref(fid, ptr(lhs), ctypes.c_size_t(lhs.shape[0]), ptr(rhs), ctypes.c_size_t(rhs.shape[0]), ptr(o), ptr(r),
+                                         ctypes.c_size_t(root_order), ptr(out), ctypes.byref(ln))
+    return rc, out[:ln.value]
