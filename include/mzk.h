@@ -145,6 +145,15 @@ typedef void (*mzk_fri_challenge_fn)(void* user, int round, int last, const uint
 int mzk_fri_commit(int field_id, const uint64_t* codeword, size_t n, const uint64_t* omega, const uint64_t* offset, int num_rounds,
                    mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out);
 
+/* ---- G2 (BN254 twist over Fq2 = Fq[u]/(u^2+1); bn128.rs:33-49) ------------------------------------------------
+ * A G2 point is 16 limbs: x.c0 | x.c1 | y.c0 | y.c1 (4 limbs each, canonical); all-zero = infinity.
+ * mzk_msm_g2_bn254: Polynomial::eval_with_powers_on_curve over pk.powers_2 (polynomial.rs:156-165 as called from
+ * batch_verify_kzg, kzg.rs:114).  mzk_kzg_setup_g2: powers_2 of setup_kzg_with_full_g2 (kzg.rs:42-55) for a
+ * caller-supplied alpha: [alpha^i] g2, i = 0..=max_d ((max_d + 1) x 16 limbs). */
+int mzk_msm_g2_bn254(const uint64_t* scalars, const uint64_t* points_xy, size_t n, uint64_t out_xy[16]);
+int mzk_msm_g2_bn254_dev(const void* d_scalars, const void* d_points_xy, size_t n, void* d_out_xy, void* stream);
+int mzk_kzg_setup_g2(const uint64_t alpha[4], const uint64_t g2_xy[16], size_t max_d, uint64_t* powers2_xy);
+
 /* Device-resident SRS for repeated commits against one PublicKeyKZG.powers_1 (kzg.rs:8-11). */
 typedef struct mzk_srs mzk_srs;
 int mzk_srs_upload(const uint64_t* powers_xy, size_t n, mzk_srs** out);

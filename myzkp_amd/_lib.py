@@ -357,3 +357,40 @@ def fast_coset_divide(fid, lhs, rhs, offset, root, root_order):
     _check(lib().mzk_fast_coset_divide(fid, _p(a), ctypes.c_size_t(a.shape[0]), _p(b), ctypes.c_size_t(b.shape[0]), _p(o), _p(r),
                                        ctypes.c_size_t(root_order), _p(out), ctypes.byref(ln)))
     return out[:ln.value]
+
+
+def g2_points_to_array(pts):
+    """[((x0, x1), (y0, y1)), ...] -> (n, 16) limbs; infinity = ((0, 0), (0, 0))."""
+    a = np.zeros((len(pts), 16), dtype=np.uint64)
+    for i, (x, y) in enumerate(pts):
+        a[i] = to_limbs([x[0], x[1], y[0], y[1]], 4).reshape(-1)
+    return a
+
+
+def array_to_g2_points(a):
+    a = np.asarray(a, dtype=np.uint64).reshape(-1, 16)
+    out = []
+    for row in a:
+        v = from_limbs(row.reshape(4, 4))
+        out.append(((v[0], v[1]), (v[2], v[3])))
+    return out
+
+
+def msm_g2(scalars, points):
+    """Polynomial::eval_with_powers_on_curve over G2 (kzg.rs:114)."""
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    p = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 16)
+    if p.shape[0] < s.shape[0]:
+        raise MzkError(-5, "index out of bounds: powers.len() < coef.len() (polynomial.rs:162)")
+    out = np.zeros(16, dtype=np.uint64)
+    _check(lib().mzk_msm_g2_bn254(_p(s), _p(p), ctypes.c_size_t(s.shape[0]), _p(out)))
+    return array_to_g2_points(out)[0]
+
+
+def kzg_setup_g2(alpha, max_d, g2):
+    """powers_2 of setup_kzg_with_full_g2 (kzg.rs:42-55) for a given alpha."""
+    a = to_limbs([alpha], 4)
+    g = g2_points_to_array([g2])
+    out = np.zeros((max_d + 1, 16), dtype=np.uint64)
+    _check(lib().mzk_kzg_setup_g2(_p(a), _p(g), ctypes.c_size_t(max_d), _p(out)))
+    return out

@@ -12,6 +12,8 @@
 //   ntt / intt / fast_multiply / fast_coset_evaluate   algebra/ntt.rs:7-116, :254-269
 //   PublicKeyKZG, ProofKZG, setup_kzg_with_alpha / commit_kzg / open_kzg   algebra/kzg.rs:8-72
 //   get_nth_root_of_m128                     zkstark/fri.rs:423-447
+//   fast_coset_divide                        algebra/ntt.rs:271-330
+//   G2Point, eval_with_powers_on_curve_g2, setup_kzg_powers_2_with_alpha   curve/bn128.rs:33-49, algebra/kzg.rs:42-55,114
 //   Merkle::commit / open, commit_codeword   algebra/merkle.rs:15-46, zkstark/fri.rs:160-166
 //   fri_split_and_fold, fri_commit           zkstark/fri.rs:144-209
 //
@@ -256,6 +258,50 @@ std::vector<F> fri_split_and_fold(const std::vector<F>& codeword, const F& alpha
   return from_wire<F>(out, codeword.size() / 2);
 }
 
+
+// ---- G2 (bn128.rs:33-49): Fq2 = Fq[u]/(u^2 + 1), G2Point = EllipticCurvePoint<Fq2, BN128Curve> ----------
+struct Fq2 {   // ExtendedFieldElement: poly.coef = [c0, c1]
+  Fq c0, c1;
+  bool operator==(const Fq2& o) const { return c0 == o.c0 && c1 == o.c1; }
+};
+struct G2Point {
+  bool infinity = true;
+  Fq2 x, y;
+  static G2Point point_at_infinity() { return G2Point(); }
+  static G2Point new_point(const Fq2& x, const Fq2& y) { G2Point p; p.infinity = false; p.x = x; p.y = y; return p; }
+  bool is_point_at_infinity() const { return infinity; }
+  bool operator==(const G2Point& o) const { return infinity == o.infinity && (infinity || (x == o.x && y == o.y)); }
+  void to_wire(uint64_t* w) const {
+    if (infinity) { std::memset(w, 0, 128); return; }
+    std::memcpy(w, x.c0.value.data(), 32); std::memcpy(w + 4, x.c1.value.data(), 32);
+    std::memcpy(w + 8, y.c0.value.data(), 32); std::memcpy(w + 12, y.c1.value.data(), 32);
+  }
+  static G2Point from_wire(const uint64_t* w) {
+    bool z = true;
+    for (int i = 0; i < 16; i++) z = z && w[i] == 0;
+    if (z) return point_at_infinity();
+    return new_point(Fq2{Fq::from_limbs(w), Fq::from_limbs(w + 4)}, Fq2{Fq::from_limbs(w + 8), Fq::from_limbs(w + 12)});
+  }
+};
+// Polynomial::eval_with_powers_on_curve over G2 (polynomial.rs:156-165 as called at kzg.rs:114)
+inline G2Point eval_with_powers_on_curve_g2(const Polynomial<FqOrder>& f, const std::vector<G2Point>& powers) {
+  if (powers.size() < f.coef.size()) throw Panic(MZK_E_LENGTH, "index out of bounds: powers.len() < coef.len() (polynomial.rs:162)");
+  auto s = to_wire(f.coef);
+  std::vector<uint64_t> p(16 * f.coef.size() + 16), out(16);
+  for (size_t i = 0; i < f.coef.size(); i++) powers[i].to_wire(&p[16 * i]);
+  expect(mzk_msm_g2_bn254(s.data(), p.data(), f.coef.size(), out.data()));
+  return G2Point::from_wire(out.data());
+}
+// powers_2 of setup_kzg_with_full_g2 (kzg.rs:42-55) for a caller-supplied alpha
+inline std::vector<G2Point> setup_kzg_powers_2_with_alpha(const G2Point& g2, const FqOrder& alpha, size_t max_d) {
+  uint64_t g[16];
+  g2.to_wire(g);
+  std::vector<uint64_t> w(16 * (max_d + 1));
+  expect(mzk_kzg_setup_g2(alpha.value.data(), g, max_d, w.data()));
+  std::vector<G2Point> out;
+  for (size_t i = 0; i <= max_d; i++) out.push_back(G2Point::from_wire(&w[16 * i]));
+  return out;
+}
 
 // ---- Merkle (algebra/merkle.rs) and the FRI commit phase (zkstark/fri.rs:144-209) ------------------------
 typedef std::vector<uint8_t> MerkleRoot;               // merkle.rs:4

@@ -1204,3 +1204,143 @@ int orc_fast_coset_divide_ref(int fid, const u64* lhs, size_t ll, const u64* rhs
   free(a); free(b); free(ea); free(eb); free(lm); free(rhm);
   return rc;
 }
+
+/* ------------------------------------------------------------------------------------------- */
+/* G2: the same affine group law over Fq2 = Fq[x]/(x^2 + 1)                    */
+/*   Fq2 / G2Point            bn128.rs:33-49;  generator bn128.rs:190-206;  b2 = 3/(9+u) :216-222 */
+/*   ExtendedFieldElement     efield.rs: mul = polynomial product mod x^2+1 (:351-353), inverse  */
+/*                            = extended Euclid over polynomials (:126-151; inverse(0) = 0) --    */
+/*                            restated through the norm, which yields the same field element     */
+/*   group law / scalar mul   curve.rs:56-191 (generic over the field)                            */
+/* Wire format: x = (c0, c1), y = (c0, c1), 4 limbs each, canonical; all-zero = infinity.         */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct { u64 c0[MAXN], c1[MAXN]; } fq2_t;            /* Montgomery-domain coefficients */
+typedef struct { fq2_t x, y; int inf; } pt2_t;
+static const fld_t* fq_fld(void) { return fld_of(FID_FQ); }
+static void q2_add(fq2_t* r, const fq2_t* a, const fq2_t* b) { const fld_t* f = fq_fld(); f_add(f, r->c0, a->c0, b->c0); f_add(f, r->c1, a->c1, b->c1); }
+static void q2_sub(fq2_t* r, const fq2_t* a, const fq2_t* b) { const fld_t* f = fq_fld(); f_sub(f, r->c0, a->c0, b->c0); f_sub(f, r->c1, a->c1, b->c1); }
+static void q2_neg(fq2_t* r, const fq2_t* a) { const fld_t* f = fq_fld(); f_neg(f, r->c0, a->c0); f_neg(f, r->c1, a->c1); }
+static void q2_mul(fq2_t* r, const fq2_t* a, const fq2_t* b) {   /* (a0 + a1 x)(b0 + b1 x) mod x^2 + 1 */
+  const fld_t* f = fq_fld();
+  u64 t0[MAXN], t1[MAXN], t2[MAXN], t3[MAXN];
+  f_mmul(f, t0, a->c0, b->c0); f_mmul(f, t1, a->c1, b->c1);
+  f_mmul(f, t2, a->c0, b->c1); f_mmul(f, t3, a->c1, b->c0);
+  f_sub(f, r->c0, t0, t1);
+  f_add(f, r->c1, t2, t3);
+}
+static void q2_inv(fq2_t* r, const fq2_t* a) {                    /* conj(a) / (a0^2 + a1^2); 0 -> 0 */
+  const fld_t* f = fq_fld();
+  u64 n[MAXN], t[MAXN];
+  f_mmul(f, n, a->c0, a->c0); f_mmul(f, t, a->c1, a->c1);
+  f_add(f, n, n, t);
+  f_minv(f, n, n);
+  f_mmul(f, r->c0, a->c0, n);
+  f_mmul(f, t, a->c1, n);
+  f_neg(f, r->c1, t);
+}
+static int q2_eq(const fq2_t* a, const fq2_t* b) { const fld_t* f = fq_fld(); return eq_n(a->c0, b->c0, f->n) && eq_n(a->c1, b->c1, f->n); }
+static void pt2_set_inf(pt2_t* p) { memset(p, 0, sizeof *p); p->inf = 1; }
+static void pt2_slope(fq2_t* s, const pt2_t* p, const pt2_t* q) {   /* curve.rs:56-70, a = 0 */
+  fq2_t num, den, t;
+  if (q2_eq(&p->x, &q->x)) {
+    q2_mul(&t, &p->x, &p->x);
+    q2_add(&num, &t, &t); q2_add(&num, &num, &t);
+    q2_add(&den, &p->y, &p->y);
+  } else {
+    q2_sub(&num, &q->y, &p->y);
+    q2_sub(&den, &q->x, &p->x);
+  }
+  q2_inv(&den, &den);
+  q2_mul(s, &num, &den);
+}
+static void pt2_double(pt2_t* r, const pt2_t* p) {                  /* curve.rs:72-101 */
+  if (p->inf) { *r = *p; return; }
+  fq2_t s, nx, ny, t;
+  pt2_slope(&s, p, p);
+  q2_mul(&nx, &s, &s); q2_sub(&nx, &nx, &p->x); q2_sub(&nx, &nx, &p->x);
+  q2_mul(&t, &s, &nx); q2_neg(&ny, &t);
+  q2_mul(&t, &s, &p->x); q2_sub(&t, &t, &p->y);
+  q2_add(&ny, &ny, &t);
+  r->x = nx; r->y = ny; r->inf = 0;
+}
+static void pt2_add(pt2_t* r, const pt2_t* p, const pt2_t* q) {      /* curve.rs:103-129 */
+  if (p->inf) { *r = *q; return; }
+  if (q->inf) { *r = *p; return; }
+  if (q2_eq(&p->x, &q->x)) {
+    if (q2_eq(&p->y, &q->y)) { pt2_double(r, p); return; }
+    pt2_set_inf(r); return;
+  }
+  fq2_t s, nx, ny, t;
+  pt2_slope(&s, p, q);
+  q2_mul(&nx, &s, &s); q2_sub(&nx, &nx, &p->x); q2_sub(&nx, &nx, &q->x);
+  q2_mul(&t, &s, &nx); q2_neg(&ny, &t);
+  q2_mul(&t, &s, &p->x); q2_sub(&t, &t, &p->y);
+  q2_add(&ny, &ny, &t);
+  r->x = nx; r->y = ny; r->inf = 0;
+}
+static void pt2_mul(pt2_t* r, const pt2_t* p, const u64* k, int nk) { /* curve.rs:168-191 */
+  pt2_t result, cur = *p;
+  pt2_set_inf(&result);
+  int top = nk * 64 - 1;
+  while (top >= 0 && !((k[top / 64] >> (top % 64)) & 1)) top--;
+  for (int i = 0; i <= top; i++) {
+    if ((k[i / 64] >> (i % 64)) & 1) pt2_add(&result, &result, &cur);
+    pt2_double(&cur, &cur);
+  }
+  *r = result;
+}
+static void pt2_load(pt2_t* p, const u64* w) {
+  const fld_t* f = fq_fld();
+  if (is_zero_n(w, 4 * f->n)) { pt2_set_inf(p); return; }
+  f_tomont(f, p->x.c0, w); f_tomont(f, p->x.c1, w + f->n); f_tomont(f, p->y.c0, w + 2 * f->n); f_tomont(f, p->y.c1, w + 3 * f->n);
+  p->inf = 0;
+}
+static void pt2_store(u64* w, const pt2_t* p) {
+  const fld_t* f = fq_fld();
+  if (p->inf) { memset(w, 0, 32 * f->n); return; }
+  f_frommont(f, w, p->x.c0); f_frommont(f, w + f->n, p->x.c1); f_frommont(f, w + 2 * f->n, p->y.c0); f_frommont(f, w + 3 * f->n, p->y.c1);
+}
+int orc_g2_add(const u64* p, const u64* q, u64* out) { pt2_t a, b, r; pt2_load(&a, p); pt2_load(&b, q); pt2_add(&r, &a, &b); pt2_store(out, &r); return 0; }
+int orc_g2_double(const u64* p, u64* out) { pt2_t a, r; pt2_load(&a, p); pt2_double(&r, &a); pt2_store(out, &r); return 0; }
+int orc_g2_mul(const u64* p, const u64* k, int nk, u64* out) { pt2_t a, r; pt2_load(&a, p); pt2_mul(&r, &a, k, nk); pt2_store(out, &r); return 0; }
+/* y^2 - x^3 == 3 / (9 + u)   (bn128.rs:216-222, test_g2 :309-314) */
+int orc_g2_on_curve(const u64* w) {
+  const fld_t* f = fq_fld();
+  pt2_t p; pt2_load(&p, w);
+  if (p.inf) return 1;
+  fq2_t y2, x3, lhs, three = {{0}, {0}}, nine_u = {{0}, {0}}, b2;
+  u64 t[MAXN] = {3, 0, 0, 0}; f_tomont(f, three.c0, t);
+  t[0] = 9; f_tomont(f, nine_u.c0, t); t[0] = 1; f_tomont(f, nine_u.c1, t);
+  q2_inv(&nine_u, &nine_u); q2_mul(&b2, &three, &nine_u);
+  q2_mul(&y2, &p.y, &p.y); q2_mul(&x3, &p.x, &p.x); q2_mul(&x3, &x3, &p.x);
+  q2_sub(&lhs, &y2, &x3);
+  return q2_eq(&lhs, &b2);
+}
+/* Polynomial::eval_with_powers_on_curve over G2 (polynomial.rs:156-165; kzg.rs:114), literal */
+int orc_g2_msm_ref(const u64* scalars, const u64* points, size_t n, u64* out) {
+  pt2_t acc; pt2_set_inf(&acc);
+  for (size_t i = 0; i < n; i++) {
+    pt2_t p, t;
+    pt2_load(&p, points + 16 * i);
+    pt2_mul(&t, &p, scalars + 4 * i, 4);
+    pt2_add(&acc, &acc, &t);
+  }
+  pt2_store(out, &acc);
+  return 0;
+}
+/* setup_kzg_with_full_g2's powers_2 (kzg.rs:42-55): [alpha^i] g2, i <= max_d, alpha_power a running product */
+int orc_kzg_setup_g2_ref(const u64* g2, const u64* alpha, size_t max_d, u64* powers) {
+  const fld_t* fr = fld_of(FID_FR);
+  pt2_t g; pt2_load(&g, g2);
+  u64 am[MAXN], cur[MAXN], plain[MAXN];
+  f_tomont(fr, am, alpha);
+  memcpy(cur, fr->one, 8 * fr->n);
+  for (size_t i = 0; i <= max_d; i++) {
+    pt2_t t;
+    f_frommont(fr, plain, cur);
+    pt2_mul(&t, &g, plain, 4);
+    pt2_store(powers + 16 * i, &t);
+    f_mmul(fr, cur, cur, am);
+  }
+  return 0;
+}

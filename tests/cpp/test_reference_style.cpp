@@ -6,6 +6,7 @@
 //   test_fast_multiply  <- algebra/ntt.rs:66-116 vs Polynomial::fft_multiply
 //   test_panics         <- ntt.rs:8-23, polynomial.rs:162 index panic
 //   test_merkle         <- algebra/merkle.rs:76-93
+//   test_g2             <- algebra/curve/bn128.rs:306-323 and algebra/kzg.rs:110-114
 //   test_fri_commit     <- zkstark/fri.rs:144-209 (commit phase; transcript stood in for by a deterministic challenge)
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +18,7 @@ int orc_poly_eval(int fid, const uint64_t* coef, size_t n, const uint64_t* x, ui
 int orc_field_pow(int fid, const uint64_t* a, const uint64_t* e, int ne, uint64_t* out);
 int orc_field_mul(int fid, const uint64_t* a, const uint64_t* b, uint64_t* out);
 int orc_ec_mul(int cid, const uint64_t* p_xy, const uint64_t* k, int nk, uint64_t* out_xy);
+int orc_g2_mul(const uint64_t* p, const uint64_t* k, int nk, uint64_t* out);
 int orc_merkle_verify_ref(const uint8_t* root, size_t root_len, size_t index, const uint8_t* path, const uint64_t* path_len, size_t stride,
                           size_t depth, const uint8_t* leaf, size_t leaf_len);
 int orc_merkle_commit_ref(const uint8_t* leaves, const uint64_t* offsets, size_t n, uint8_t* root, size_t* root_len);
@@ -219,6 +221,39 @@ static void test_fri_commit() {   // fri.rs:144-209
   }
 }
 
+static void test_g2() {   // bn128.rs:306-323 through the MSM, plus the G2 side of batch_verify_kzg (kzg.rs:110-114)
+  const uint64_t gen[16] = {   // BN128::generator_g2(), bn128.rs:190-206
+      0x46debd5cd992f6edULL, 0x674322d4f75edaddULL, 0x426a00665e5c4479ULL, 0x1800deef121f1e76ULL,
+      0x97e485b7aef312c2ULL, 0xf1aa493335a9e712ULL, 0x7260bfb731fb5d25ULL, 0x198e9393920d483aULL,
+      0x4ce6cc0166fa7daaULL, 0xe3d1e7690c43d37bULL, 0x4aab71808dcb408fULL, 0x12c85ea5db8c6debULL,
+      0x55acdadcd122975bULL, 0xbc4b313370b38ef3ULL, 0xec9e99ad690c3395ULL, 0x090689d0585ff075ULL};
+  G2Point g2 = G2Point::from_wire(gen);
+  auto msm = [&](std::vector<uint64_t> ks) {
+    Polynomial<FqOrder> f;
+    std::vector<G2Point> pw;
+    for (auto k : ks) { f.coef.push_back(FqOrder::from_value(k)); pw.push_back(g2); }
+    return eval_with_powers_on_curve_g2(f, pw);
+  };
+  CHECK(msm({2, 1, 1}) == msm({4}));
+  CHECK(msm({9, 5}) == msm({12, 2}));
+  uint64_t four[4] = {4, 0, 0, 0}, w[16];
+  orc_g2_mul(gen, four, 4, w);
+  CHECK(msm({4}) == G2Point::from_wire(w));
+  // powers_2 for alpha = 7: [1, 7, 49] g2; z = (X - 3)(X - 5) = 15 - 8X + X^2 -> z(7) g2 = 8 g2
+  auto p2 = setup_kzg_powers_2_with_alpha(g2, FqOrder::from_value(7), 2);
+  uint64_t k49[4] = {49, 0, 0, 0};
+  orc_g2_mul(gen, k49, 4, w);
+  CHECK(p2.size() == 3 && p2[0] == g2 && p2[2] == G2Point::from_wire(w));
+  Polynomial<FqOrder> z;
+  z.coef = {FqOrder::from_value(15), FqOrder::from_value(0), FqOrder::from_value(1)};
+  // -8 mod r
+  const uint64_t rm8[4] = {0x43e1f593f0000001ULL - 8, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+  z.coef[1] = FqOrder::from_limbs(rm8);
+  uint64_t k8[4] = {8, 0, 0, 0};
+  orc_g2_mul(gen, k8, 4, w);
+  CHECK(eval_with_powers_on_curve_g2(z, p2) == G2Point::from_wire(w));
+}
+
 int main() {
   expect(mzk_init(0));
   test_ntt();
@@ -229,6 +264,7 @@ int main() {
   test_panics();
   test_merkle();
   test_fri_commit();
+  test_g2();
   mzk_shutdown();
   if (failures) { printf("%d check(s) failed\n", failures); return 1; }
   printf("all reference-style tests passed\n");

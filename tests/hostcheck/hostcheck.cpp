@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <string.h>
 #include "../../myzkp_amd/csrc/mzk_ec.h"
+#include "../../myzkp_amd/csrc/mzk_g2.h"
 using namespace mzk;
 
 template <class P> static void run_field(int op, const u32* a, const u32* b, u32* out) {
@@ -108,6 +109,36 @@ int hc_g1_sum(const u32* pts, int n, u32* out) {
     xyzz_store(acc, buf);
   }
   store_pt(xyzz_load(buf), out);
+  return 0;
+}
+// ---- G2 (mzk_g2.h) with bounds assertions: op 0 add, 1 double, 2 scalar mul (k: 8 words), 3 Fq2 mul, 4 Fq2 inverse
+int hc_g2_op(int op, const u32* a, const u32* b, const u32* k, u32* out) {
+  if (op == 3 || op == 4) {
+    Fq2 x = f2_load_plain(a), y = f2_load_plain(b);
+    Fq2 r = (op == 3) ? f2_mul(x, y) : f2_inv(x);
+    f2_store_plain(r, out);
+    return 0;
+  }
+  Xyzz2 P = g2_words_is_inf(a) ? x2_inf() : x2_from_affine(g2_load_plain(a));
+  Xyzz2 r;
+  if (op == 0) {
+    Xyzz2 Q = g2_words_is_inf(b) ? x2_inf() : x2_from_affine(g2_load_plain(b));
+    // exercise both the mixed and the general addition
+    Xyzz2 r1 = g2_words_is_inf(b) ? P : x2_madd(P, g2_load_plain(b));
+    // general add on operands with non-trivial ZZ: (P + P) - P + Q style would change the value; instead re-randomise Z by doubling twice and halving is not available -> use x2_add directly
+    r = x2_add(P, Q);
+    u32 w1[32], w2[32];
+    g2_store_plain(r1, w1); g2_store_plain(r, w2);
+    for (int i = 0; i < 32; i++) if (w1[i] != w2[i]) return -7;
+  } else if (op == 1) {
+    r = x2_dbl(P);
+  } else if (op == 2) {
+    if (g2_words_is_inf(a)) r = x2_inf(); else r = x2_scalar_mul(g2_load_plain(a), k);
+  } else return -1;
+  // round trip through the XYZZ record as the kernels do
+  u32 rec[64];
+  x2_store(r, rec);
+  g2_store_plain(x2_load(rec), out);
   return 0;
 }
 }

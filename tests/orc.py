@@ -334,3 +334,57 @@ def fast_coset_divide_ref(fid, lhs, rhs, offset, root, root_order):
     rc = lib().orc_fast_coset_divide_ref(fid, ptr(lhs), ctypes.c_size_t(lhs.shape[0]), ptr(rhs), ctypes.c_size_t(rhs.shape[0]), ptr(o), ptr(r),
                                          ctypes.c_size_t(root_order), ptr(out), ctypes.byref(ln))
     return rc, out[:ln.value]
+
+
+# ---- G2 (Fq2) -----------------------------------------------------------------------------------------------
+G2_GEN = ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
+           11559732032986387107991004021392285783925812861821192530917403151452391805634),
+          (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+           4082367875863433681332203403145435568316851327593401208105741076214120093531))   # bn128.rs:190-206
+G2_INF = ((0, 0), (0, 0))
+
+
+def g2_to_arr(pts):
+    a = np.zeros((len(pts), 16), dtype=np.uint64)
+    for i, (x, y) in enumerate(pts):
+        a[i] = to_limbs([x[0], x[1], y[0], y[1]], 4).reshape(-1)
+    return a
+
+
+def arr_to_g2(a):
+    a = np.asarray(a, dtype=np.uint64).reshape(-1, 16)
+    out = []
+    for row in a:
+        v = from_limbs(row.reshape(4, 4))
+        out.append(((v[0], v[1]), (v[2], v[3])))
+    return out
+
+
+def g2_add(P, Q):
+    out = np.zeros(16, dtype=np.uint64)
+    assert lib().orc_g2_add(ptr(g2_to_arr([P])), ptr(g2_to_arr([Q])), ptr(out)) == 0
+    return arr_to_g2(out)[0]
+
+
+def g2_mul(P, k):
+    out = np.zeros(16, dtype=np.uint64)
+    kk = to_limbs([k], 4)
+    assert lib().orc_g2_mul(ptr(g2_to_arr([P])), ptr(kk), 4, ptr(out)) == 0
+    return arr_to_g2(out)[0]
+
+
+def g2_on_curve(P):
+    return bool(lib().orc_g2_on_curve(ptr(g2_to_arr([P]))))
+
+
+def g2_msm_ref(scal_arr, pts_arr):
+    out = np.zeros(16, dtype=np.uint64)
+    assert lib().orc_g2_msm_ref(ptr(scal_arr), ptr(pts_arr), ctypes.c_size_t(scal_arr.shape[0]), ptr(out)) == 0
+    return arr_to_g2(out)[0]
+
+
+def kzg_setup_g2_ref(alpha, max_d, g2=None):
+    out = np.zeros((max_d + 1, 16), dtype=np.uint64)
+    a = to_limbs([alpha], 4)
+    assert lib().orc_kzg_setup_g2_ref(ptr(g2_to_arr([g2 or G2_GEN])), ptr(a), ctypes.c_size_t(max_d), ptr(out)) == 0
+    return out

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def hc():
     src = os.path.join(HERE, "hostcheck", "hostcheck.cpp")
     so = os.path.join(HERE, "hostcheck", "libhostcheck.so")
-    hdrs = [os.path.join(orc.ROOT, "myzkp_amd", "csrc", h) for h in ("mzk_field.h", "mzk_ec.h", "mzk_constants.h")]
+    hdrs = [os.path.join(orc.ROOT, "myzkp_amd", "csrc", h) for h in ("mzk_field.h", "mzk_ec.h", "mzk_g2.h", "mzk_constants.h")]
     if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-DMZK_CHECK_BOUNDS", "-fPIC", "-shared", "-o", so, src])
     return ctypes.CDLL(so)
@@ -133,3 +133,37 @@ def test_running_sum_through_packed_storage(hc):
     for P in seq:
         want = orc.ec_add(0, want, P)
     assert (from_w32(out[:8]), from_w32(out[8:])) == want
+
+
+def _g2op(hc, op, A, B=None, k=0):
+    a = orc.g2_to_arr([A]).view(np.uint32).reshape(-1).copy()
+    b = orc.g2_to_arr([B if B is not None else orc.G2_INF]).view(np.uint32).reshape(-1).copy()
+    kw = w32(k, 8)
+    out = np.zeros(32, dtype=np.uint32)
+    rc = hc.hc_g2_op(op, orc.ptr(a), orc.ptr(b), orc.ptr(kw), orc.ptr(out))
+    assert rc == 0, rc
+    return orc.arr_to_g2(out.view(np.uint64))[0]
+
+
+def test_g2_fq2_arithmetic_and_group_law_with_bounds(hc):
+    """mzk_g2.h under -DMZK_CHECK_BOUNDS: Fq2 mul / inverse, XYZZ add (mixed and general), double, scalar mul over Fq2
+    against the oracle (which test_oracle_g2.py pins to the reference's test_g2)."""
+    rng = random.Random(21)
+    G = orc.G2_GEN
+    q = P_FQ
+    for _ in range(20):
+        x = (rng.randrange(q), rng.randrange(q)); y = (rng.randrange(q), rng.randrange(q))
+        got = _g2op(hc, 3, (x, (0, 0)), (y, (0, 0)))[0]
+        assert got == ((x[0] * y[0] - x[1] * y[1]) % q, (x[0] * y[1] + x[1] * y[0]) % q)
+        inv = _g2op(hc, 4, (x, (0, 0)))[0]
+        n = pow(x[0] * x[0] + x[1] * x[1], -1, q)
+        assert inv == (x[0] * n % q, -x[1] * n % q)
+    pts = [orc.g2_mul(G, rng.randrange(1, P_FR)) for _ in range(6)]
+    neg = lambda P: (P[0], ((-P[1][0]) % q, (-P[1][1]) % q))
+    for P, Q in [(pts[0], pts[1]), (pts[2], pts[2]), (pts[3], neg(pts[3])), (orc.G2_INF, pts[4]), (pts[5], orc.G2_INF),
+                 (orc.G2_INF, orc.G2_INF)]:
+        assert _g2op(hc, 0, P, Q) == orc.g2_add(P, Q)
+    for P in pts[:3] + [orc.G2_INF]:
+        assert _g2op(hc, 1, P) == orc.g2_add(P, P)
+    for k in [0, 1, 2, 3, P_FR - 1, P_FR, rng.randrange(P_FR), (1 << 200) + 5]:
+        assert _g2op(hc, 2, pts[0], k=k) == orc.g2_mul(pts[0], k), k
