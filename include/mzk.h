@@ -195,6 +195,8 @@ int mzk_kzg_open_quotient_dev(const void* d_coef, size_t n, const uint64_t u_hos
  * the plain prepared points and pays the window Horner instead). */
 int mzk_srs_from_device(const void* d_powers_xy, size_t n, mzk_srs** out, void* stream);
 int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, mzk_srs** out, void* stream);
+/* with_tables: 0 = plain prepared points, 1 = tables with the default 16-bit windows, 12..22 = that window width
+ * (tuning / tests; wider windows were measured and do not pay). */
 
 /* Deterministic synthetic inputs (bench + tests): bit-identical to the oracle's orc_synth_*. */
 int mzk_synth_field_dev(int field_id, uint64_t seed, size_t n, void* d_out, void* stream);

@@ -502,9 +502,11 @@ int mzk_fast_coset_divide(int field_id, const uint64_t* lhs, size_t ll, const ui
 
 // ---- MSM / KZG ---------------------------------------------------------------------------------------------
 struct mzk_srs {
-  void* d_points_mont;   // MSM_SRS_WINDOWS x n window tables when has_tables, else n prepared points
+  void* d_points_mont;   // msm_table_windows(window_bits) x n window tables when has_tables, else n prepared points
   size_t n;
   bool has_tables;
+  int window_bits;
+  int kind() const { return has_tables ? MSM_PTS_TABLES_C(window_bits) : MSM_PTS_MONT; }
 };
 // Below this size the per-call bucket overhead of 16-bit windows dominates: keep plain prepared points.
 static const size_t SRS_TABLE_MIN_N = (size_t)1 << 14;
@@ -539,16 +541,16 @@ int mzk_srs_upload(const uint64_t* powers_xy, size_t n, mzk_srs** out) {
   MZK_TRY(ensure_init());
   if (!out || (!powers_xy && n)) { set_error("srs_upload: null pointer"); return MZK_E_ARG; }
   hipStream_t s = g_ctx.stream;
-  mzk_srs* h = new mzk_srs{nullptr, n, n >= SRS_TABLE_MIN_N};
+  mzk_srs* h = new mzk_srs{nullptr, n, n >= SRS_TABLE_MIN_N, msm_srs_window_bits(n)};
   if (n) {
     void *d_plain, *d_mont;
-    const size_t copies = h->has_tables ? (size_t)MSM_SRS_WINDOWS : 1;
+    const size_t copies = h->has_tables ? (size_t)msm_table_windows(h->window_bits) : 1;
     if (hipMalloc(&h->d_points_mont, n * 64 * copies) != hipSuccess) { delete h; set_error("srs_upload: hipMalloc failed"); return MZK_E_HIP; }
     int rc = stage_in(WS_MISC_A, powers_xy, n * 64, &d_plain, s);
     if (rc == MZK_OK && h->has_tables) {
       rc = ws_get(WS_MSM_POINTS, n * 64, &d_mont);
       if (rc == MZK_OK) rc = msm_prepare_points(d_plain, n, d_mont, s);
-      if (rc == MZK_OK) rc = msm_build_tables(d_mont, n, h->d_points_mont, s);
+      if (rc == MZK_OK) rc = msm_build_tables(d_mont, n, h->d_points_mont, h->window_bits, s);
     } else if (rc == MZK_OK) {
       rc = msm_prepare_points(d_plain, n, h->d_points_mont, s);
     }
@@ -571,7 +573,7 @@ int mzk_kzg_commit_srs(const mzk_srs* srs, const uint64_t* coef, size_t n, uint6
   void *d_s, *d_o;
   MZK_TRY(stage_in(WS_MSM_SCALARS, coef, n * 32, &d_s, s));
   MZK_TRY(ws_get(WS_MISC_B, 256, &d_o));
-  MZK_TRY(msm_dev_impl(d_s, srs->d_points_mont, n, srs->has_tables ? MSM_PTS_TABLES : MSM_PTS_MONT, srs->n, d_o, false, s));
+  MZK_TRY(msm_dev_impl(d_s, srs->d_points_mont, n, srs->kind(), srs->n, d_o, false, s));
   MZK_HIP(hipMemcpyAsync(out_xy, d_o, 64, hipMemcpyDeviceToHost, s));
   MZK_HIP(hipStreamSynchronize(s));
   return MZK_OK;
@@ -581,7 +583,7 @@ int mzk_kzg_commit_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, voi
   MZK_TRY(ensure_init());
   if (!srs || !d_out || (!d_coef && n)) { set_error("commit_srs_dev: null pointer"); return MZK_E_ARG; }
   if (n > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }
-  return msm_dev_impl(d_coef, srs->d_points_mont, n, srs->has_tables ? MSM_PTS_TABLES : MSM_PTS_MONT, srs->n, d_out, out_partial != 0,
+  return msm_dev_impl(d_coef, srs->d_points_mont, n, srs->kind(), srs->n, d_out, out_partial != 0,
                       (hipStream_t)stream);
 }
 
@@ -589,7 +591,7 @@ int mzk_kzg_open_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, const
   MZK_TRY(ensure_init());
   if (!srs) { set_error("open_srs_dev: null srs"); return MZK_E_ARG; }
   if (n > 1 && n - 1 > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }
-  return kzg_open_dev(d_coef, n, u_host, srs->d_points_mont, srs->has_tables ? MSM_PTS_TABLES : MSM_PTS_MONT, srs->n, d_y, d_w_xy, nullptr, (hipStream_t)stream);
+  return kzg_open_dev(d_coef, n, u_host, srs->d_points_mont, srs->kind(), srs->n, d_y, d_w_xy, nullptr, (hipStream_t)stream);
 }
 int mzk_kzg_setup_g1_dev(const uint64_t alpha_host[4], const uint64_t g1_xy_host[8], size_t max_d, void* d_powers_xy, void* stream) {
   MZK_TRY(ensure_init());
@@ -613,16 +615,17 @@ int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, m
   MZK_TRY(ensure_init());
   if (!out || (!d_powers_xy && n)) { set_error("srs_from_device: null pointer"); return MZK_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
-  mzk_srs* h = new mzk_srs{nullptr, n, with_tables && n >= SRS_TABLE_MIN_N};
+  if (with_tables < 0 || (with_tables > 1 && (with_tables < 12 || with_tables > 22))) { set_error("srs_from_device: with_tables must be 0, 1 or a window width 12..22"); return MZK_E_ARG; }
+  mzk_srs* h = new mzk_srs{nullptr, n, with_tables > 1 || (with_tables && n >= SRS_TABLE_MIN_N), with_tables > 1 ? with_tables : msm_srs_window_bits(n)};
   if (n) {
     void* d_mont;
-    const size_t copies = h->has_tables ? (size_t)MSM_SRS_WINDOWS : 1;
+    const size_t copies = h->has_tables ? (size_t)msm_table_windows(h->window_bits) : 1;
     if (hipMalloc(&h->d_points_mont, n * 64 * copies) != hipSuccess) { delete h; set_error("srs_from_device: hipMalloc failed"); return MZK_E_HIP; }
     int rc = MZK_OK;
     if (h->has_tables) {
       rc = ws_get(WS_MSM_POINTS, n * 64, &d_mont);
       if (rc == MZK_OK) rc = msm_prepare_points(d_powers_xy, n, d_mont, s);
-      if (rc == MZK_OK) rc = msm_build_tables(d_mont, n, h->d_points_mont, s);
+      if (rc == MZK_OK) rc = msm_build_tables(d_mont, n, h->d_points_mont, h->window_bits, s);
     } else {
       rc = msm_prepare_points(d_powers_xy, n, h->d_points_mont, s);
     }

@@ -85,11 +85,18 @@ int kzg_batch_open_dev(const void* d_coef, size_t n, const uint64_t* us_host, si
                        size_t table_stride, void* d_ys, void* d_w_xy, hipStream_t s);
 
 enum { MSM_PTS_PLAIN = 0, MSM_PTS_MONT = 1, MSM_PTS_TABLES = 2 };
-constexpr int MSM_SRS_WINDOWS = 16;   // 254 / 16 + 1
+// Fixed-base window tables: c-bit signed windows, 254 / c + 1 of them.  point_kind carries c in bits 8..15
+// (MSM_PTS_TABLES alone = 16).  The default is 16 bits at every size: wider windows (fewer additions per pair, more
+// buckets) were measured and lose -- 2^24 pairs: c = 16 25.7 ms, 18 28.5, 20 28.2, 22 32.8 (scratch/window_sweep.py);
+// the sort grows with the bucket count and the accumulate kernel gains nothing (shorter bucket runs, more flushes).
+// Other widths stay selectable through mzk_srs_from_device_ex for tuning and tests.
+static inline int msm_table_windows(int c) { return 254 / c + 1; }
+static inline int msm_srs_window_bits(size_t) { return 16; }
+#define MSM_PTS_TABLES_C(c) (MSM_PTS_TABLES | ((c) << 8))
 int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int point_kind, size_t table_stride, void* d_out,
                  bool out_partial_xyzz, hipStream_t s);
 int xyzz_batch_to_affine(const void* d_xyzz, size_t count, void* d_out, bool out_mont, hipStream_t s);
-int msm_build_tables(const void* d_points_mont, size_t n, void* d_tables, hipStream_t s);
+int msm_build_tables(const void* d_points_mont, size_t n, void* d_tables, int window_bits, hipStream_t s);
 int msm_fold_partials_impl(const void* d_partials, int count, void* d_out_xy, hipStream_t s);
 int msm_prepare_points(const void* d_points_plain, size_t n, void* d_points_mont, hipStream_t s);
 int synth_field_impl(int fid, uint64_t seed, size_t n, void* d_out, hipStream_t s);

@@ -26,8 +26,6 @@ namespace mzk {
 
 constexpr int SCALAR_BITS = 254;
 constexpr int MAX_WINDOWS = 32;
-constexpr int SRS_WINDOW_BITS = 16;     // fixed-base tables: 16 windows of 16 bits
-constexpr int SRS_WINDOWS = SCALAR_BITS / SRS_WINDOW_BITS + 1;
 
 struct MsmShape {
   int c;          // window bits
@@ -347,7 +345,7 @@ __device__ __forceinline__ void fine_slice(const u32* __restrict__ binbase, int 
   *hi = start + (u32)(len * (u64)(s + 1) / (u64)S);
 }
 constexpr int FINE_UNROLL = 8;
-constexpr int FINE_MAX = 2048;     // buckets per bin: NB / 256 (128 merged, 2048 generic c = 16)
+constexpr int FINE_MAX = 8192;     // buckets per bin: NB / 256 (128 merged c = 16, 2048 generic c = 16, 8192 merged c = 22)
 __global__ __launch_bounds__(SORT2_THREADS) void k_fine_count(const uint2* __restrict__ tmp, const u32* __restrict__ binbase, int nwg, int F,
                                                                int S, u32* __restrict__ finehist) {
   __shared__ u32 hist[FINE_MAX];
@@ -686,15 +684,15 @@ __global__ __launch_bounds__(128) void k_srs_window_step(u32* __restrict__ state
   for (int d = 0; d < c; d++) p = xyzz_dbl(p);
   xyzz_gstore(state, i, p);
 }
-int msm_build_tables(const void* d_points_mont, size_t n, void* d_tables, hipStream_t s) {
+int msm_build_tables(const void* d_points_mont, size_t n, void* d_tables, int window_bits, hipStream_t s) {
   if (n == 0) return MZK_OK;
   u32* state;
   MZK_TRY(ws_get(WS_XYZZ_TMP, n * 128, (void**)&state));
   const unsigned blocks = (unsigned)((n + 127) / 128);
   MZK_HIP(hipMemcpyAsync(d_tables, d_points_mont, n * 64, hipMemcpyDeviceToDevice, s));   // window 0
   hipLaunchKernelGGL(k_srs_state_init, dim3(blocks), dim3(128), 0, s, (const u32*)d_points_mont, n, state);
-  for (int win = 1; win < SRS_WINDOWS; win++) {
-    hipLaunchKernelGGL(k_srs_window_step, dim3(blocks), dim3(128), 0, s, state, n, SRS_WINDOW_BITS);
+  for (int win = 1; win < msm_table_windows(window_bits); win++) {
+    hipLaunchKernelGGL(k_srs_window_step, dim3(blocks), dim3(128), 0, s, state, n, window_bits);
     MZK_TRY(xyzz_batch_to_affine(state, n, (u32*)d_tables + (size_t)win * n * 16, true, s));
   }
   MZK_HIP(hipGetLastError());
@@ -713,10 +711,12 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   }
   MsmShape sh = choose_shape(n);
   DigitLayout L;
+  const int table_c = (point_kind >> 8) ? (point_kind >> 8) : 16;
+  point_kind &= 0xff;
   L.merged = (point_kind == 2) ? 1 : 0;
   L.table_stride = table_stride;
   if (L.merged) {
-    sh.c = SRS_WINDOW_BITS; sh.nwin = SRS_WINDOWS; sh.lgB = sh.c - 1; sh.nbuckets = (size_t)1 << sh.lgB;
+    sh.c = table_c; sh.nwin = msm_table_windows(table_c); sh.lgB = sh.c - 1; sh.nbuckets = (size_t)1 << sh.lgB;
   }
   L.c = sh.c; L.nwin = sh.nwin;
   const size_t NB = sh.nbuckets;
@@ -743,7 +743,9 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   MZK_TRY(ws_get(WS_MSM_OFFSETS, (NB + 1) * 4, (void**)&offsets));
   // two-level sort when the bucket space is a power of two >= 2^12 (merged layout always; generic at c = 16)
   const size_t NBtot = NB;
-  const bool two_level = (NBtot & (NBtot - 1)) == 0 && NBtot >= 4096 && (NBtot / COARSE_BINS) <= (size_t)FINE_MAX && n >= 4096;
+  // (small inputs keep the one-pass kernels, except that the merged one-pass histogram must fit the LDS: 2^15 buckets)
+  const bool two_level = (NBtot & (NBtot - 1)) == 0 && NBtot >= 4096 && (NBtot / COARSE_BINS) <= (size_t)FINE_MAX &&
+                         (n >= 4096 || ((point_kind & 0xff) == 2 && NBtot > ((size_t)1 << 15)));
   MZK_TRY(ws_get(WS_MSM_CURSOR, E_max * (two_level ? 8 : 4), (void**)&ranks));
   MZK_TRY(ws_get(WS_MSM_ENTRIES, E_max * 4, (void**)&entries));
   MZK_TRY(ws_get(WS_MSM_SCAN, (scan_blocks + 1) * 4, (void**)&scan_tmp));
@@ -760,7 +762,10 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     const int F = (int)(NBtot / COARSE_BINS);
     const u32 fine_mask = (u32)F - 1u;
     const int nwg = (int)((n + COARSE_PER_WG - 1) / COARSE_PER_WG);
-    int S = (int)((E_max / COARSE_BINS + 32767) / 32768);     // <= 32 Ki records per fine workgroup, >= 2 workgroups per CU
+    // records per fine workgroup: 32 Ki (>= 2 workgroups per CU at 2^20), 128 Ki when a bin has thousands of buckets
+    // (the [bucket][sub] histogram that is scanned afterwards has NB * S entries)
+    const size_t per_fine = (NBtot / COARSE_BINS >= 4096) ? 131072 : 32768;
+    int S = (int)((E_max / COARSE_BINS + per_fine - 1) / per_fine);
     if (S < 2) S = 2;
     if (S > 64) S = 64;
     const size_t n_coarse = (size_t)COARSE_BINS * nwg, n_fine = NBtot * (size_t)S;
@@ -814,6 +819,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((NB + 1 + 255) / 256)), dim3(256), 0, s, offsets, scan_tmp, scan_tmp + scan_blocks, NB);
     hipLaunchKernelGGL(k_digits_scatter, dim3(nblk), dim3(256), 0, s, (const u32*)d_scalars, n, L, offsets, ranks, entries);
   }
+  MZK_HIP(hipGetLastError());
   prof_end(s, MZK_PH_MSM_SORT);
   prof_begin(s, MZK_PH_MSM_ACCUMULATE);
   // the true entry count lives in offsets[NB] on the device; lanes past it exit (E_max bounds it)
@@ -823,6 +829,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   else
     hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, lgseg, heavy);
   hipLaunchKernelGGL(k_seg_combine_heavy, dim3(512), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)offsets, buckets, lgseg, (const u32*)heavy);
+  MZK_HIP(hipGetLastError());
   prof_end(s, MZK_PH_MSM_ACCUMULATE);
   prof_begin(s, MZK_PH_MSM_REDUCE);
 
@@ -839,6 +846,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
       hipLaunchKernelGGL(k_halve_step, dim3((unsigned)((4 * total + 127) / 128), (unsigned)red_windows), dim3(128), 0, s, buckets, sh.lgB, t);
   }
   hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)red_windows), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, t_start, wsum);
+  MZK_HIP(hipGetLastError());
   prof_end(s, MZK_PH_MSM_REDUCE);
   prof_begin(s, MZK_PH_MSM_COMBINE);
   MZK_TRY(launch_window_combine((const u32*)wsum, red_windows, horner_c, out_partial_xyzz ? 1 : 0, (u32*)d_out, s));

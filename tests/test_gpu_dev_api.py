@@ -157,3 +157,28 @@ def test_setup_wide_table_path_full_array_vs_oracle(env):
                                         ctypes.c_size_t(first), ctypes.c_size_t(count), _dp(out), st))
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+
+
+@pytest.mark.parametrize("c", [12, 16, 20, 22])
+def test_srs_tables_with_explicit_window_width(env, c):
+    """the merged-bucket path at the window widths used for large SRS sizes (20 bits from 2^21+1 points, 22 from
+    2^23+1), forced here on a small SRS: 254 / c + 1 tables, 2^(c-1) buckets, two-level sort with up to 8192 buckets per bin"""
+    torch, mz, L, dev, st = env
+    n = 1 << 13
+    p = orc.synth_points(90 + c, n)
+    p[5] = 0
+    s = orc.synth_vector(FR, 91 + c, n)
+    s[7] = orc.to_limbs([orc.P_FR - 1], 4)[0]
+    s[8] = 0
+    s[9] = orc.to_limbs([(1 << (c - 1))], 4)[0]          # exactly half the window: the signed-digit boundary
+    s[10] = orc.to_limbs([(1 << c) - 1], 4)[0]
+    want = orc.msm_fast(s, p)
+    dp, ds = _to_dev(torch, dev, p), _to_dev(torch, dev, s)
+    h = ctypes.c_void_p()
+    _ok(L, L.mzk_srs_from_device_ex(_dp(dp), ctypes.c_size_t(n), ctypes.c_int(c), ctypes.byref(h), st))
+    out = torch.zeros(8, dtype=torch.int64, device=dev)
+    for m in (n, n - 3, 100):
+        _ok(L, L.mzk_kzg_commit_srs_dev(h, _dp(ds), ctypes.c_size_t(m), _dp(out), 0, st))
+        torch.cuda.synchronize()
+        assert mz.array_to_points(out.cpu().numpy().view(np.uint64))[0] == (want if m == n else orc.msm_fast(s[:m], p[:m])), (c, m)
+    L.mzk_srs_free(h)
