@@ -320,12 +320,12 @@ def main():
     srs_roof = hbm_roofline(96.0 * n, srs_acc_ms)
     srs_roof["kernel"] = "k_seg_accumulate (+ k_seg_combine)"
     if args.log2n == 20:
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r01c_hbm_traffic_pmc.txt: per launch of
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r01e_hbm_traffic_pmc.txt: per launch of
         # k_seg_accumulate at 2^20 pairs, raw counters (16-B gathers: the gfx950 x2 FETCH_SIZE correction for wide
         # coalesced streams is not applied).  The fixed-base method reads each of the 16 table points of a pair once
         # (16 x 64 B); the 128-B fetch granule doubles it.  Mostly served by L2 / Infinity Cache.
-        srs_roof["traffic"] = (2047254 + 65792) * 1024
-        srs_roof["traffic_source"] = "profiles/r01c_hbm_traffic_pmc.txt (recorded profile, not collected by this run)"
+        srs_roof["traffic"] = (2039663 + 63856) * 1024
+        srs_roof["traffic_source"] = "profiles/r01e_hbm_traffic_pmc.txt (recorded profile, not collected by this run)"
     srs_roof["algorithmic_bytes_per_launch"] = 96 * n
     alu["kzg_commit_accumulate_frac"] = msm_mads / (srs_acc_ms * 1e-3) / MAD_PEAK_PER_S if srs_acc_ms == srs_acc_ms else None
     out = {
