@@ -60,11 +60,12 @@ __global__ __launch_bounds__(4) void k_window_combine(const u32* __restrict__ ws
     for (int i = 0; i < 16; i++) out[i] = wds[i];
   }
 }
-// fold `count` XYZZ partials (multi-GPU all-gather result) into one affine point
-__global__ void k_fold_partials(const u32* __restrict__ partials, int count, u32* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// fold `count` XYZZ partials (multi-GPU all-gather result) into one affine point; one DPP quad does the chain
+__global__ __launch_bounds__(4) void k_fold_partials(const u32* __restrict__ partials, int count, u32* __restrict__ out) {
+  const int lane = threadIdx.x & 3;
   Xyzz tot = xyzz_inf();
-  for (int i = 0; i < count; i++) tot = xyzz_add(tot, xyzz_gload(partials, i));
+  for (int i = 0; i < count; i++) tot = xyzz_add_quad(tot, xyzz_gload_quad(partials, i, lane), lane);
+  if (threadIdx.x != 0) return;
   u32 wds[16];
   Affine af;
   if (xyzz_to_affine<true>(tot, &af)) affine_store_plain(af, wds);
@@ -79,7 +80,7 @@ int launch_window_combine(const u32* wsum, int nwin, int c, int out_xyzz, u32* o
   return MZK_OK;
 }
 int launch_fold_partials(const u32* partials, int count, u32* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, s, partials, count, out);
+  hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(4), 0, s, partials, count, out);
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }
