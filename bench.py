@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--settle-s", type=float, default=0.5, help="untimed settle time per leg before the W warm-up steps")
     ap.add_argument("--e2e-log2n", type=int, default=22, help="degree of the end-to-end KZG run (0 = skip)")
+    ap.add_argument("--strong-log2n", type=int, default=24,
+                    help="total size of the fixed-size MSM split over all ranks (BASELINE configs[3]; 0 = skip)")
     ap.add_argument("--extra-sizes", type=str, default="24", help="comma list of extra log2 sizes timed once each (rank 0 view)")
     args = ap.parse_args()
 
@@ -484,6 +486,60 @@ def main():
         out["e2e_kzg"] = e2e
         if hh:
             L.mzk_srs_free(hh)
+        torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ fixed-size MSM over all ranks (BASELINE configs[3])
+    # ONE KZG commit of 2^strong_log2n pairs: rank g builds SRS powers [lo_g, hi_g) on its GPU (tables included),
+    # commits its slice, the 128-byte partials are all-gathered and folded.  Strong-scaling view next to the weak-
+    # scaling headline: total pairs fixed, time should fall with N.  Verified by the trapdoor identity on rank 0.
+    progress("fixed-size (strong scaling) leg")
+    if args.strong_log2n > 0:
+        tot = 1 << args.strong_log2n
+        lo, hi = sharded.shard_range(tot, rank, world)
+        m = hi - lo
+        alpha = orc.from_limbs(orc.synth_vector(orc.FR, SEED + 901, 1))[0]
+        a_l, g_l = mz.to_limbs([alpha], 4), mz.points_to_array([(1, 2)])
+        err, hs, step_fn = None, ctypes.c_void_p(), None
+        try:
+            sc2 = torch.empty(m * 4, dtype=torch.int64, device=dev)
+            check(L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(SEED + 5000 + 1000003 * rank), ctypes.c_size_t(m), dptr(sc2), stream))
+            sp2 = torch.empty(m * 8, dtype=torch.int64, device=dev)
+            check(L.mzk_kzg_setup_g1_range_dev(a_l.ctypes.data_as(ctypes.c_void_p), g_l.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(lo),
+                                               ctypes.c_size_t(m), dptr(sp2), stream))
+            check(L.mzk_srs_from_device(dptr(sp2), ctypes.c_size_t(m), ctypes.byref(hs), stream))
+            torch.cuda.synchronize()
+            del sp2
+            part2 = torch.zeros(16, dtype=torch.int64, device=dev)
+            res2 = torch.zeros(8, dtype=torch.int64, device=dev)
+
+            def step_fn():
+                check(L.mzk_kzg_commit_srs_dev(hs, dptr(sc2), ctypes.c_size_t(m), dptr(part2), ctypes.c_int(1), stream))
+                recs = sharded.all_gather_partials(part2)
+                check(L.mzk_g1_fold_partials_dev(dptr(recs), ctypes.c_int(recs.shape[0]), dptr(res2), stream))
+        except Exception as ex:
+            err = str(ex)[:300]
+        strong = {"total_pairs": tot, "n_gpus": world, "pairs_per_gpu": m,
+                  "what": "one KZG commit of 2^%d pairs, SRS and scalars sharded contiguously over the ranks, all_gather of 128-byte "
+                          "partials + fold (BASELINE configs[3]); time should fall with the number of GPUs" % args.strong_log2n}
+        if max_over_ranks(0.0 if err is None else 1.0) == 0.0:
+            Ks = max(3, min(K, 5))
+            sdt, _ = timed(step_fn, Ks, 1)
+            strong.update({"ms_per_step": sdt / Ks * 1e3, "value": tot / (sdt / Ks), "unit": "pairs/s"})
+            # trapdoor identity: the commitment must be [f(alpha)] G for f = the concatenation of all ranks' scalars
+            got2 = mz.array_to_points(res2.cpu().numpy().view(np.uint64))[0]
+            if rank == 0:
+                cores = os.cpu_count() or 1
+                fa, apow = 0, 1
+                for r in range(world):
+                    rlo, rhi = sharded.shard_range(tot, r, world)
+                    sr = orc.synth_vector(orc.FR, SEED + 5000 + 1000003 * r, rhi - rlo, cores)
+                    fa = (fa + orc.poly_eval(orc.FR, sr, alpha) * pow(alpha, rlo, orc.P_FR)) % orc.P_FR
+                strong["trapdoor_identity_holds"] = bool(got2 == orc.ec_mul(0, (1, 2), fa))
+        else:
+            strong["error"] = err or "a rank failed"
+        out["strong_scaling_msm"] = strong
+        if hs:
+            L.mzk_srs_free(hs)
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only, bounded sample)
