@@ -460,8 +460,8 @@ __global__ __launch_bounds__(256) void k_scan_finish(u32* __restrict__ offsets, 
 // its segment, keeps one XYZZ accumulator, and flushes it whenever the bucket changes.  The partial
 // of (segment t, bucket b) goes to slot t + b: (t, b) pairs met in order strictly increase t + b, so
 // slots are unique, and all partials of bucket b sit in the contiguous slot range
-// [offsets[b] / SEG + b, offsets[b+1] / SEG + b + 1) -- pass 2 sums that range (unused slots are the
-// all-zero infinity encoding and cost nothing).
+// [offsets[b] / SEG + b, offsets[b+1] / SEG + b + 1) -- pass 2 sums that range (every slot of that range is
+// written: segment t overlaps bucket b exactly when slot t + b lies in it).
 __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ points_mont, const u32* __restrict__ offsets,
                                                          const u32* __restrict__ entries, u32* __restrict__ slots, size_t nbuckets,
                                                          int lgseg) {
@@ -751,9 +751,12 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   MZK_TRY(ws_get(WS_MSM_SCAN, (scan_blocks + 1) * 4, (void**)&scan_tmp));
   MZK_TRY(ws_get(WS_MSM_BUCKETS, NB * 128, (void**)&buckets));
   MZK_TRY(ws_get(WS_MSM_SLOTS, nslots * 128 + heavy_words * 4, (void**)&slots));
-  u32* heavy = slots + nslots * 32;                             // zeroed together with the slots
+  u32* heavy = slots + nslots * 32;
   prof_begin(s, MZK_PH_MSM_SORT);
-  MZK_HIP(hipMemsetAsync(slots, 0, nslots * 128 + 8, s));
+  // every slot k_seg_combine reads is written by k_seg_accumulate first (slot t + b exists exactly when segment t
+  // overlaps bucket b; checked by poisoning the array under the whole GPU suite), so only the heavy-bucket counter
+  // needs clearing
+  MZK_HIP(hipMemsetAsync(heavy, 0, 8, s));
   const unsigned nblk = (unsigned)((n + 255) / 256);
   if (two_level) {
     int kb = 0;
