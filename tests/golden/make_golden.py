@@ -296,6 +296,119 @@ def rescue_hash(par, x):
         state = [(state[i] + par["round_constants"][2 * r * m + m + i]) % p for i in range(m)]
     return state[0]
 
+# --- rows widened after the hot path: Merkle over bincode leaves, fast_coset_divide, G2 ---------------
+def bincode_field(v):   # bincode 1.3 of FiniteFieldElement{value: BigInt}: Sign as i8, u32 digits as a u64-length sequence
+    digits = []
+    while v:
+        digits.append(v & 0xffffffff)
+        v >>= 32
+    return bytes([1 if digits else 0]) + len(digits).to_bytes(8, "little") + b"".join(d.to_bytes(4, "little") for d in digits)
+
+def merkle_commit(leaves):   # merkle.rs:15-25
+    if len(leaves) == 1:
+        return leaves[0]
+    mid = len(leaves) // 2
+    return hashlib.sha3_256(merkle_commit(leaves[:mid]) + merkle_commit(leaves[mid:])).digest()
+
+def merkle_open(index, leaves):   # merkle.rs:28-46
+    if len(leaves) == 2:
+        return [leaves[1 - index]]
+    mid = len(leaves) // 2
+    if index < mid:
+        return merkle_open(index, leaves[:mid]) + [merkle_commit(leaves[mid:])]
+    return merkle_open(index - mid, leaves[mid:]) + [merkle_commit(leaves[:mid])]
+
+def fast_coset_divide(lhs, rhs, offset, root, order, p):   # ntt.rs:271-330
+    lhs, rhs = trim(list(lhs)), trim(list(rhs))
+    dl, dr = len(lhs) - 1, len(rhs) - 1
+    assert pow(root, order, p) == 1 and pow(root, order // 2, p) != 1 and rhs and dr < dl
+    if dl < 8:
+        return poly_divrem(lhs, rhs, p)[0]
+    while dl < order // 2:
+        root, order = root * root % p, order // 2
+    a = [c * pow(offset, i, p) % p for i, c in enumerate(lhs)] + [0] * (order - dl - 1)
+    b = [c * pow(offset, i, p) % p for i, c in enumerate(rhs)] + [0] * (order - dr - 1)
+    ea, eb = ntt(root, a, p), ntt(root, b, p)
+    q = [x * (pow(y, -1, p) if y else 0) % p for x, y in zip(ea, eb)]      # inverse(0) = 0 (field.rs:209-232)
+    sq = intt(root, q, p)[: dl - dr + 1]
+    oi = pow(offset, -1, p)
+    return [c * pow(oi, i, p) % p for i, c in enumerate(sq)]
+
+G2_GEN = ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
+           11559732032986387107991004021392285783925812861821192530917403151452391805634),
+          (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+           4082367875863433681332203403145435568316851327593401208105741076214120093531))   # bn128.rs:190-206
+def f2mul(a, b): return ((a[0] * b[0] - a[1] * b[1]) % FQ, (a[0] * b[1] + a[1] * b[0]) % FQ)   # efield.rs:351-353, mod x^2+1
+def f2sub(a, b): return ((a[0] - b[0]) % FQ, (a[1] - b[1]) % FQ)
+def f2add(a, b): return ((a[0] + b[0]) % FQ, (a[1] + b[1]) % FQ)
+def f2inv(a):
+    n = pow(a[0] * a[0] + a[1] * a[1], -1, FQ)
+    return (a[0] * n % FQ, -a[1] * n % FQ)
+G2_INF = None
+def g2_add(P, Q):   # curve.rs:56-129 over Fq2, a = 0
+    if P is None: return Q
+    if Q is None: return P
+    (x1, y1), (x2, y2) = P, Q
+    if x1 == x2:
+        if y1 != y2: return None
+        lam = f2mul(f2mul((3, 0), f2mul(x1, x1)), f2inv(f2add(y1, y1)))
+    else:
+        lam = f2mul(f2sub(y2, y1), f2inv(f2sub(x2, x1)))
+    x3 = f2sub(f2sub(f2mul(lam, lam), x1), x2)
+    return (x3, f2sub(f2mul(lam, f2sub(x1, x3)), y1))
+def g2_mul(P, k):   # curve.rs:168-191
+    acc, cur = None, P
+    while k:
+        if k & 1: acc = g2_add(acc, cur)
+        cur = g2_add(cur, cur)
+        k >>= 1
+    return acc
+def g2pt(P): return [[0, 0], [0, 0]] if P is None else [list(P[0]), list(P[1])]
+
+def next_rows():
+    rng = random.Random(0x6e657874)
+    out = {}
+    # Merkle roots / paths of field codewords (fri.rs:160-166) and of raw byte leaves (merkle.rs:76-93)
+    mk = []
+    for name, p in (("M128", M128), ("Fr", FR)):
+        for lg in (0, 1, 3, 6):
+            vals = [rng.randrange(p) for _ in range(1 << lg)]
+            if lg >= 3:
+                vals[1], vals[2], vals[5] = 0, 7, 1 << 64
+            leaves = [bincode_field(v) for v in vals]
+            case = dict(field=name, values=S(vals), root=merkle_commit(leaves).hex())
+            if lg >= 1:
+                idx = rng.randrange(1 << lg)
+                case["open_index"] = idx
+                case["path"] = [e.hex() for e in merkle_open(idx, leaves)]
+            mk.append(case)
+    leaves = [b"leaf1", b"leaf2", b"leaf3", b"leaf4"]
+    out["merkle_field"] = mk
+    out["merkle_bytes"] = dict(leaves=[l.hex() for l in leaves], root=merkle_commit(leaves).hex(), open_index=2,
+                               path=[e.hex() for e in merkle_open(2, leaves)])
+    # fast_coset_divide: exact and inexact, both branches (degree < 8 and transform)
+    cd = []
+    for name, p, rootf, off in (("M128", M128, m128_root, M128_GEN), ("Fr", FR, fr_root, 5)):
+        for dq, dr, exact in ((3, 2, True), (20, 9, True), (45, 17, False), (5, 1, False)):
+            q = [rng.randrange(p) for _ in range(dq)] + [rng.randrange(1, p)]
+            r = [rng.randrange(p) for _ in range(dr)] + [rng.randrange(1, p)]
+            lhs = poly_mul(q, r, p) if exact else [rng.randrange(p) for _ in range(dq + dr)] + [rng.randrange(1, p)]
+            order = 256
+            cd.append(dict(field=name, lhs=S(lhs), rhs=S(r), offset=S(off), root=S(rootf(order)), root_order=order,
+                           out=S(fast_coset_divide(lhs, r, off, rootf(order), order, p))))
+    out["fast_coset_divide"] = cd
+    # G2: multiples of the generator, an MSM, powers_2
+    ks = [1, 2, 3, 9, FR - 1, rng.randrange(FR)]
+    out["g2_mul"] = [dict(k=S(k), out=S(g2pt(g2_mul(G2_GEN, k)))) for k in ks] + [dict(k=S(FR), out=S(g2pt(g2_mul(G2_GEN, FR))))]
+    pts = [g2_mul(G2_GEN, rng.randrange(1, FR)) for _ in range(4)] + [None]
+    sc = [rng.randrange(FR) for _ in range(5)]
+    acc = None
+    for k, P in zip(sc, pts):
+        acc = g2_add(acc, g2_mul(P, k) if P is not None else None)
+    out["g2_msm"] = dict(scalars=S(sc), points=S([g2pt(P) for P in pts]), out=S(g2pt(acc)))
+    out["g2_powers"] = dict(alpha="7", max_d=3, powers=S([g2pt(g2_mul(G2_GEN, pow(7, i, FR))) for i in range(4)]))
+    dump("next_rows_vectors.json", out)
+
 def main():
     rng = random.Random(0x4d595a4b50)  # "MYZKP"
 
@@ -437,6 +550,8 @@ def main():
             om = rootf(n)
             fr_cases.append(dict(field=name, alpha=S(al), offset=S(off), omega=S(om), input=S(cw), output=S(fri_fold(cw, al, off, om, p))))
     dump("fri_vectors.json", {"cases": fr_cases})
+
+    next_rows()
 
     # ---------------- Rescue-Prime KAT (reference-held) ----------------
     rp_src = "/root/reference/myzkp/src/modules/zkstark/rescueprime.rs"
