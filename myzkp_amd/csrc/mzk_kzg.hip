@@ -240,7 +240,7 @@ int kzg_setup_g1_dev(const uint64_t* alpha_host, const uint64_t* g1_host, size_t
 }
 
 // ---- open: suffix Horner b_i = c_i + u b_{i+1} -----------------------------------------------------------
-constexpr int OPEN_K_LOG = 8;
+constexpr int OPEN_K_LOG = 5;   // chunk = 32: the per-lane recurrence is a serial chain, so short chunks (more levels, all tiny) win
 constexpr size_t OPEN_K = (size_t)1 << OPEN_K_LOG;
 typedef Fe<FrParams> FrE;
 __device__ __forceinline__ FrE fr_gload(const u32* __restrict__ g, size_t i) {
