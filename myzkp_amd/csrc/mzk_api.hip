@@ -40,7 +40,10 @@ int ws_get(WsSlot slot, size_t bytes, void** out) {
   *out = b.p;
   return MZK_OK;
 }
+static uint64_t g_ws_generation = 1;
+uint64_t ws_generation() { return g_ws_generation; }
 void ws_release_all() {
+  g_ws_generation++;
   for (auto& b : g_ws) {
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr; b.cap = 0;

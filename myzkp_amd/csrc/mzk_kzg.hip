@@ -216,19 +216,37 @@ int kzg_setup_g1_dev(const uint64_t* alpha_host, const uint64_t* g1_host, size_t
   for (int i = 0; i < 8; i++) { gw.w[2 * i] = (u32)g1_host[i]; gw.w[2 * i + 1] = (u32)(g1_host[i] >> 32); }
   u32 *bases, *table, *acc, *atab;
   MZK_TRY(ws_get(WS_MISC_C, (size_t)(3 << ATAB_BITS) * 32, (void**)&atab));
-  MZK_TRY(ws_get(WS_MISC_A, 32 * 64, (void**)&bases));
-  MZK_TRY(ws_get(WS_MISC_B, 32 * 256 * 64, (void**)&table));
+  MZK_TRY(ws_get(WS_FB_TABLE8, 32 * 64 + 32 * 256 * 64, (void**)&bases));
+  table = bases + 32 * 16;
   const bool wide = count >= ((size_t)1 << 16);      // the 64 MiB table pays for itself from ~2^16 powers on
   const size_t t16 = (size_t)16 << 16;
   MZK_TRY(ws_get(WS_XYZZ_TMP, (wide && t16 > count ? t16 : count) * 128, (void**)&acc));
   u32* table16 = nullptr;
   if (wide) MZK_TRY(ws_get(WS_FB_TABLE16, t16 * 64, (void**)&table16));
-  hipLaunchKernelGGL(k_fb_bases, dim3(1), dim3(32), 0, s, gw, bases);
-  hipLaunchKernelGGL(k_fb_table, dim3(32), dim3(256), 0, s, (const u32*)bases, table);
-  hipLaunchKernelGGL(k_alpha_table, dim3((3 << ATAB_BITS) / 256), dim3(256), 0, s, aw, atab);
-  if (wide) {
+  // The fixed-base tables depend only on g1 (in practice always BN128::generator_g1()) and their construction is a
+  // latency chain (248 serial doublings for the window bases + two inversions: ~1.4 ms, more than a whole 2^16-power
+  // setup), so they are kept across calls, keyed by g1 and by the workspace generation.
+  static struct { uint64_t g[8]; uint64_t gen; bool have8, have16; hipEvent_t ready; } cache = {{0}, 0, false, false, nullptr};
+  if (cache.gen != ws_generation() || memcmp(cache.g, g1_host, sizeof cache.g) != 0) {
+    cache.gen = ws_generation(); cache.have8 = cache.have16 = false;
+    memcpy(cache.g, g1_host, sizeof cache.g);
+  }
+  if (!cache.ready) MZK_HIP(hipEventCreateWithFlags(&cache.ready, hipEventDisableTiming));
+  bool built = false;
+  if (!cache.have8) {
+    hipLaunchKernelGGL(k_fb_bases, dim3(1), dim3(32), 0, s, gw, bases);
+    hipLaunchKernelGGL(k_fb_table, dim3(32), dim3(256), 0, s, (const u32*)bases, table);
+    cache.have8 = true; built = true;
+  }
+  if (wide && !cache.have16) {
     hipLaunchKernelGGL(k_fb_table16, dim3((unsigned)(t16 / 128)), dim3(128), 0, s, (const u32*)table, acc);
     MZK_TRY(xyzz_batch_to_affine(acc, t16, table16, true, s));
+    cache.have16 = true; built = true;
+  }
+  if (built) MZK_HIP(hipEventRecord(cache.ready, s));
+  else MZK_HIP(hipStreamWaitEvent(s, cache.ready, 0));     // tables may have been built on another stream
+  hipLaunchKernelGGL(k_alpha_table, dim3((3 << ATAB_BITS) / 256), dim3(256), 0, s, aw, atab);
+  if (wide) {
     hipLaunchKernelGGL((k_fb_powers<16>), dim3((unsigned)((count + 127) / 128)), dim3(128), 0, s, aw, (const u32*)atab, (const u32*)table16,
                        first, count, acc);
   } else {
