@@ -198,6 +198,11 @@ int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, m
 /* with_tables: 0 = plain prepared points, 1 = tables with the default 16-bit windows, 12..22 = that window width
  * (tuning / tests; wider windows were measured and do not pay). */
 
+/* Host-side parameter arithmetic of the library (roots, inverses, offsets: O(log n) scalar work per call, never on the
+ * data path), exposed for checking without a GPU: op 0 = a * b, 1 = a^-1 (0 -> 0), 2 = a^(b[0]), 3 = a * b by the
+ * bit-serial reference implementation.  field_id may also be MZK_FIELD_FQ. */
+int mzk_host_field_op(int field_id, int op, const uint64_t* a, const uint64_t* b, uint64_t* out);
+
 /* Deterministic synthetic inputs (bench + tests): bit-identical to the oracle's orc_synth_*. */
 int mzk_synth_field_dev(int field_id, uint64_t seed, size_t n, void* d_out, void* stream);
 int mzk_synth_g1_points_dev(uint64_t seed, size_t n, void* d_out_xy, void* stream);

@@ -128,8 +128,9 @@ static void h_addmod(const HostField* f, uint64_t* r, const uint64_t* a, const u
   }
   for (int i = 0; i < f->nl; i++) r[i] = t[i];
 }
-// double-and-add product: O(bits) modular additions; only ever used for O(log n) parameter values
-void h_mulmod(const HostField* f, uint64_t* r, const uint64_t* a, const uint64_t* b) {
+// double-and-add product: O(bits) modular additions.  Only used once per field, to derive the Montgomery constant
+// of the fast product below (and as its cross-check in tests through the same entry point).
+static void h_mulmod_slow(const HostField* f, uint64_t* r, const uint64_t* a, const uint64_t* b) {
   uint64_t acc[4] = {0, 0, 0, 0}, aa[4] = {0, 0, 0, 0}, bb[4] = {0, 0, 0, 0};
   for (int i = 0; i < f->nl; i++) { aa[i] = a[i]; bb[i] = b[i]; }
   for (int bit = 64 * f->nl - 1; bit >= 0; bit--) {
@@ -137,6 +138,50 @@ void h_mulmod(const HostField* f, uint64_t* r, const uint64_t* a, const uint64_t
     if ((bb[bit / 64] >> (bit % 64)) & 1) h_addmod(f, acc, acc, aa);
   }
   for (int i = 0; i < f->nl; i++) r[i] = acc[i];
+}
+// Montgomery constants per host field (64-bit limbs): n0 = -p^-1 mod 2^64, r2 = 2^(128 nl) mod p
+struct HostMont { bool ready; uint64_t n0; uint64_t r2[4]; };
+static HostMont g_hmont[3];
+static const HostMont* host_mont(const HostField* f) {
+  HostMont* m = &g_hmont[f == &HF_FR ? 0 : (f == &HF_FQ ? 1 : 2)];
+  if (!m->ready) {
+    uint64_t inv = f->p[0];                              // Newton: p0 * p0 == 1 mod 8
+    for (int i = 0; i < 6; i++) inv *= 2 - f->p[0] * inv;
+    m->n0 = (uint64_t)0 - inv;
+    uint64_t x[4] = {1, 0, 0, 0};                        // 2^(128 nl) mod p by 128 nl modular doublings
+    for (int i = 0; i < 128 * f->nl; i++) h_addmod(f, x, x, x);
+    for (int i = 0; i < 4; i++) m->r2[i] = x[i];
+    m->ready = true;
+  }
+  return m;
+}
+// a * b / 2^(64 nl) mod p (CIOS), inputs < p
+static void h_montmul(const HostField* f, const HostMont* m, uint64_t* r, const uint64_t* a, const uint64_t* b) {
+  const int n = f->nl;
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < n; i++) {
+    unsigned __int128 c = 0;
+    for (int j = 0; j < n; j++) { c += (unsigned __int128)a[j] * b[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+    c += t[n]; t[n] = (uint64_t)c; t[n + 1] = (uint64_t)(c >> 64);
+    const uint64_t q = t[0] * m->n0;
+    c = (unsigned __int128)q * f->p[0] + t[0];
+    c >>= 64;
+    for (int j = 1; j < n; j++) { c += (unsigned __int128)q * f->p[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+    c += t[n]; t[n - 1] = (uint64_t)c;
+    t[n] = t[n + 1] + (uint64_t)(c >> 64);
+  }
+  if (t[n] || h_cmp(t, f->p, n) >= 0) {
+    unsigned __int128 br = 0;
+    for (int i = 0; i < n; i++) { unsigned __int128 d = (unsigned __int128)t[i] - f->p[i] - (uint64_t)br; t[i] = (uint64_t)d; br = (d >> 64) & 1; }
+  }
+  for (int i = 0; i < n; i++) r[i] = t[i];
+}
+// a * b mod p for canonical a, b: mont(mont(a, b), R^2)
+void h_mulmod(const HostField* f, uint64_t* r, const uint64_t* a, const uint64_t* b) {
+  const HostMont* m = host_mont(f);
+  uint64_t t[4] = {0, 0, 0, 0};
+  h_montmul(f, m, t, a, b);
+  h_montmul(f, m, r, t, m->r2);
 }
 void h_powmod_u64(const HostField* f, uint64_t* r, const uint64_t* a, uint64_t e) {
   uint64_t res[4] = {1, 0, 0, 0}, base[4] = {0, 0, 0, 0};
@@ -241,6 +286,21 @@ const char* mzk_prof_name(int phase) {
   static const char* names[MZK_PH_COUNT] = {"msm_prepare_points", "msm_digit_sort", "msm_bucket_accumulate", "msm_bucket_reduce",
                                             "msm_window_combine", "ntt_pass0", "ntt_pass1", "ntt_pass2", "ntt_pass3", "ntt_coset_prescale", "merkle_sha3_levels"};
   return (phase >= 0 && phase < MZK_PH_COUNT) ? names[phase] : "?";
+}
+
+// Host parameter arithmetic, exposed so that it can be checked without a GPU (tests/test_abi_load.py): op 0 = a * b,
+// 1 = a^-1 (0 -> 0), 2 = a^b[0], 3 = a * b by the bit-serial reference implementation.
+int mzk_host_field_op(int field_id, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+  const HostField* f = host_field(field_id);
+  if (!f || !a || !out || (!b && op != 1)) { set_error("host_field_op: bad argument"); return MZK_E_ARG; }
+  if (!h_is_canonical(f, a) || ((op == 0 || op == 3) && !h_is_canonical(f, b))) { set_error("host_field_op: operand not canonical"); return MZK_E_RANGE; }
+  switch (op) {
+    case 0: h_mulmod(f, out, a, b); return MZK_OK;
+    case 1: h_invmod(f, out, a); return MZK_OK;
+    case 2: h_powmod_u64(f, out, a, b[0]); return MZK_OK;
+    case 3: h_mulmod_slow(f, out, a, b); return MZK_OK;
+    default: set_error("host_field_op: bad op %d", op); return MZK_E_ARG;
+  }
 }
 
 int mzk_root_of_unity(int field_id, unsigned log2_n, uint64_t* out) {

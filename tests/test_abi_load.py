@@ -45,3 +45,32 @@ def test_no_cpu_fallback(mz):
     with pytest.raises(mz.MzkError) as e:
         mz.msm_g1(np.zeros((1, 4), dtype=np.uint64), np.zeros((1, 8), dtype=np.uint64))
     assert e.value.code == -8
+
+
+def test_host_parameter_arithmetic_without_a_gpu(mz):
+    """the library's host-side field arithmetic (Montgomery on 64-bit limbs) against Python big ints and against its own
+    bit-serial reference, for all three fields"""
+    import ctypes, random
+    import numpy as np
+    import orc
+    L = mz.lib()
+    rnd = random.Random(44)
+
+    def op(fid, o, a, b=0):
+        nl = 2 if fid == mz.FIELD_M128 else 4
+        aa, bb = orc.to_limbs([a], nl), orc.to_limbs([b], nl)
+        out = np.zeros(4, dtype=np.uint64)
+        assert L.mzk_host_field_op(fid, o, orc.ptr(aa), orc.ptr(bb), orc.ptr(out)) == 0
+        return orc.from_limbs(out[:nl].reshape(1, nl))[0]
+
+    for fid in (mz.FIELD_FR, mz.FIELD_M128, mz.FIELD_FQ):
+        p = mz.MODULUS[fid]
+        vals = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, 1 << 64, (1 << 64) - 1] + [rnd.randrange(p) for _ in range(300)]
+        for i, a in enumerate(vals):
+            b = vals[(7 * i + 3) % len(vals)]
+            assert op(fid, 0, a, b) == a * b % p
+            if i < 30:
+                assert op(fid, 3, a, b) == a * b % p
+                assert op(fid, 1, a) == (pow(a, -1, p) if a else 0)
+                e = rnd.getrandbits(64)
+                assert op(fid, 2, a, e) == pow(a, e, p)
