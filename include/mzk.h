@@ -76,7 +76,9 @@ int mzk_root_of_unity(int field_id, unsigned log2_n, uint64_t* out);
 /* ---- MSM / KZG -------------------------------------------------------------------------------- */
 /* Polynomial::eval_with_powers_on_curve (algebra/polynomial.rs:156-165) = commit_kzg
  * (algebra/kzg.rs:57-59): sum_i scalars[i] * points[i].  Scalars need not be canonical (the
- * reference sanitizes, polynomial.rs:162): any 256-bit value is reduced mod r.  n == 0 -> infinity. */
+ * reference sanitizes, polynomial.rs:162): any 256-bit value is reduced mod r.  n == 0 -> infinity.
+ * Points must lie on y^2 = x^3 + 3 (every G1Point the reference produces does): the kernels use the curve's
+ * endomorphism (k P = k1 P + k2 phi(P), GLV), an identity of the prime-order group, not of arbitrary (x, y) pairs. */
 int mzk_msm_g1_bn254(const uint64_t* scalars, const uint64_t* points_xy, size_t n, uint64_t out_xy[8]);
 
 /* setup_kzg (kzg.rs:27-40), G1 part, trapdoor supplied by the caller: powers[i] = alpha^i * g1,

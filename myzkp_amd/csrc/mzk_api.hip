@@ -565,7 +565,7 @@ int mzk_fast_coset_divide(int field_id, const uint64_t* lhs, size_t ll, const ui
 
 // ---- MSM / KZG ---------------------------------------------------------------------------------------------
 struct mzk_srs {
-  void* d_points_mont;   // msm_table_windows(window_bits) x n window tables when has_tables, else n prepared points
+  void* d_points_mont;   // msm_table_windows(window_bits) x n window tables when has_tables, else n prepared points + their n phi images
   size_t n;
   bool has_tables;
   int window_bits;
@@ -607,15 +607,15 @@ int mzk_srs_upload(const uint64_t* powers_xy, size_t n, mzk_srs** out) {
   mzk_srs* h = new mzk_srs{nullptr, n, n >= SRS_TABLE_MIN_N, msm_srs_window_bits(n)};
   if (n) {
     void *d_plain, *d_mont;
-    const size_t copies = h->has_tables ? (size_t)msm_table_windows(h->window_bits) : 1;
+    const size_t copies = h->has_tables ? (size_t)msm_table_windows(h->window_bits) : 2;   // no tables: P_i, then phi(P_i) (GLV layout)
     if (hipMalloc(&h->d_points_mont, n * 64 * copies) != hipSuccess) { delete h; set_error("srs_upload: hipMalloc failed"); return MZK_E_HIP; }
     int rc = stage_in(WS_MISC_A, powers_xy, n * 64, &d_plain, s);
     if (rc == MZK_OK && h->has_tables) {
       rc = ws_get(WS_MSM_POINTS, n * 64, &d_mont);
-      if (rc == MZK_OK) rc = msm_prepare_points(d_plain, n, d_mont, s);
+      if (rc == MZK_OK) rc = msm_prepare_points(d_plain, n, d_mont, nullptr, s);
       if (rc == MZK_OK) rc = msm_build_tables(d_mont, n, h->d_points_mont, h->window_bits, s);
     } else if (rc == MZK_OK) {
-      rc = msm_prepare_points(d_plain, n, h->d_points_mont, s);
+      rc = msm_prepare_points(d_plain, n, h->d_points_mont, (uint8_t*)h->d_points_mont + n * 64, s);
     }
     if (rc == MZK_OK && hipStreamSynchronize(s) != hipSuccess) rc = MZK_E_HIP;
     if (rc != MZK_OK) { (void)hipFree(h->d_points_mont); delete h; return rc; }
@@ -682,15 +682,15 @@ int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, m
   mzk_srs* h = new mzk_srs{nullptr, n, with_tables > 1 || (with_tables && n >= SRS_TABLE_MIN_N), with_tables > 1 ? with_tables : msm_srs_window_bits(n)};
   if (n) {
     void* d_mont;
-    const size_t copies = h->has_tables ? (size_t)msm_table_windows(h->window_bits) : 1;
+    const size_t copies = h->has_tables ? (size_t)msm_table_windows(h->window_bits) : 2;   // no tables: P_i, then phi(P_i) (GLV layout)
     if (hipMalloc(&h->d_points_mont, n * 64 * copies) != hipSuccess) { delete h; set_error("srs_from_device: hipMalloc failed"); return MZK_E_HIP; }
     int rc = MZK_OK;
     if (h->has_tables) {
       rc = ws_get(WS_MSM_POINTS, n * 64, &d_mont);
-      if (rc == MZK_OK) rc = msm_prepare_points(d_powers_xy, n, d_mont, s);
+      if (rc == MZK_OK) rc = msm_prepare_points(d_powers_xy, n, d_mont, nullptr, s);
       if (rc == MZK_OK) rc = msm_build_tables(d_mont, n, h->d_points_mont, h->window_bits, s);
     } else {
-      rc = msm_prepare_points(d_powers_xy, n, h->d_points_mont, s);
+      rc = msm_prepare_points(d_powers_xy, n, h->d_points_mont, (uint8_t*)h->d_points_mont + n * 64, s);
     }
     if (rc == MZK_OK && hipStreamSynchronize(s) != hipSuccess) rc = MZK_E_HIP;
     if (rc != MZK_OK) { (void)hipFree(h->d_points_mont); delete h; return rc; }

@@ -99,7 +99,8 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
 int xyzz_batch_to_affine(const void* d_xyzz, size_t count, void* d_out, bool out_mont, hipStream_t s);
 int msm_build_tables(const void* d_points_mont, size_t n, void* d_tables, int window_bits, hipStream_t s);
 int msm_fold_partials_impl(const void* d_partials, int count, void* d_out_xy, hipStream_t s);
-int msm_prepare_points(const void* d_points_plain, size_t n, void* d_points_mont, hipStream_t s);
+int msm_prepare_points(const void* d_points_plain, size_t n, void* d_points_mont, void* d_phi, hipStream_t s);
+int msm_phi_points(const void* d_points_mont, size_t n, void* d_phi, hipStream_t s);
 int synth_field_impl(int fid, uint64_t seed, size_t n, void* d_out, hipStream_t s);
 int synth_g1_impl(uint64_t seed, size_t n, void* d_out, hipStream_t s);
 int kzg_setup_g1_dev(const uint64_t* alpha_host, const uint64_t* g1_host, size_t first, size_t count, void* d_powers_xy, hipStream_t s);

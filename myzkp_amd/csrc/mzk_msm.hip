@@ -21,6 +21,7 @@
 #include "mzk_common.h"
 #include "mzk_ec.h"
 #include "mzk_coop.h"
+#include "mzk_glv.h"
 
 namespace mzk {
 
@@ -43,6 +44,32 @@ static MsmShape choose_shape(size_t n) {
   MsmShape s;
   s.c = c;
   s.nwin = SCALAR_BITS / c + 1;
+  s.lgB = c - 1;
+  s.nbuckets = (size_t)s.nwin << s.lgB;
+  return s;
+}
+
+// Generic layout after the GLV split: 2n points with scalars below 2^126.  Windows must cover 127 bits plus the
+// signed-digit carry; at c = 16 that is exactly 8 windows (2^18 buckets: the two-level sort's power of two).
+constexpr int GLV_MAG_BITS = 126;      // |k1|, |k2| < 2^126 (mzk_glv.h)
+static MsmShape choose_shape_glv(size_t n) {
+  int lg = 0;
+  while (((size_t)1 << lg) < 2 * n) lg++;
+  int c = lg - 3;
+  if (c < 8) c = 8;
+  if (c > 16) c = 16;
+  if (c == 15) c = 16;     // 2^17 pairs: 8 full windows + the two-level sort beat 9 windows with a 6-bit top window
+  // nwin windows must cover the 126 magnitude bits plus the signed-digit carry.  The top window only holds
+  // 126 - c (nwin - 1) real bits; if that is (almost) nothing, every scalar whose carry runs into it lands in the
+  // same few buckets (c = 14: ONE bucket receives a third of all entries) -- step c down until the top window is
+  // reasonably populated.
+  for (; c > 8; c--) {
+    const int nw = GLV_MAG_BITS / c + 1;
+    if (GLV_MAG_BITS - c * (nw - 1) >= 5) break;
+  }
+  MsmShape s;
+  s.c = c;
+  s.nwin = GLV_MAG_BITS / c + 1;
   s.lgB = c - 1;
   s.nbuckets = (size_t)s.nwin << s.lgB;
   return s;
@@ -73,18 +100,49 @@ __device__ __forceinline__ void xyzz_gstore(u32* __restrict__ g, size_t idx, con
 }
 
 // ---- 0. point preparation ------------------------------------------------------------------------------
-__global__ void k_prepare_points(const u32* __restrict__ in, u32* __restrict__ out, size_t n) {
+__global__ void k_prepare_points(const u32* __restrict__ in, u32* __restrict__ out, size_t n, u32* __restrict__ phi_out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 w[16];
   load_words8(in + i * 16, w);
   load_words8(in + i * 16 + 8, w + 8);
-  if (!affine_words_is_inf(w)) {
-    Affine a = affine_load_plain(w);
+  Affine a;
+  const bool inf = affine_words_is_inf(w);
+  if (!inf) {
+    a = affine_load_plain(w);
     affine_store_mont(a, w);
   }
   store_words8(out + i * 16, w);
   store_words8(out + i * 16 + 8, w + 8);
+  if (phi_out) {        // phi(x, y) = (beta x, y); infinity stays the all-zero record
+    if (!inf) {
+      Fq beta;
+#pragma unroll
+      for (int k = 0; k < FqParams::L; k++) beta.l[k] = GlvParams::BETA_MONT[k];
+      a.x = fe_reduce<FqParams>(fe_mul<FqParams>(a.x, beta));
+      affine_store_mont(a, w);
+    }
+    store_words8(phi_out + i * 16, w);
+    store_words8(phi_out + i * 16 + 8, w + 8);
+  }
+}
+// phi images of already prepared (Montgomery) points
+__global__ void k_phi_points(const u32* __restrict__ in_mont, size_t n, u32* __restrict__ phi_out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 w[16];
+  load_words8(in_mont + i * 16, w);
+  load_words8(in_mont + i * 16 + 8, w + 8);
+  if (!affine_words_is_inf(w)) {
+    Affine a = affine_load_mont(w);
+    Fq beta;
+#pragma unroll
+    for (int k = 0; k < FqParams::L; k++) beta.l[k] = GlvParams::BETA_MONT[k];
+    a.x = fe_reduce<FqParams>(fe_mul<FqParams>(a.x, beta));
+    affine_store_mont(a, w);
+  }
+  store_words8(phi_out + i * 16, w);
+  store_words8(phi_out + i * 16 + 8, w + 8);
 }
 
 // ---- 1/3. signed-digit decomposition ----------------------------------------------------------------
@@ -112,32 +170,91 @@ __device__ __forceinline__ u32 raw_window(const u32* w, int win, int c) {
 struct DigitLayout {
   int c, nwin, merged;
   size_t table_stride;
+  int glv;               // generic layout only: scalars are GLV-split, the phi images of the points start at phi_offset
+  size_t phi_offset;
 };
+// Calls emit(slot, key, payload) for every non-zero signed digit of scalar i (canonical words w).  `slot` numbers
+// the (half, window) positions of a scalar: 0 .. slots_per_scalar-1.  key = bucket index; payload = point reference
+// with the sign in bit 31.
+//   merged : windows of the full scalar, key = |d| - 1, reference = window * table_stride + i
+//   generic: k = k1 + k2 lambda (mzk_glv.h); windows of |k1| address point i, windows of |k2| its phi image
+//            phi_offset + i; key = window * 2^(c-1) + |d| - 1; the sign of the part flips the digit's sign
+__device__ __forceinline__ int slots_per_scalar(const DigitLayout& L) { return L.glv ? 2 * L.nwin : L.nwin; }
+template <class Emit>
+__device__ __forceinline__ void walk_digits(const u32* w, const DigitLayout& L, size_t i, Emit emit) {
+  const int c = L.c;
+  const u32 half = 1u << (c - 1);
+  if (!L.glv) {
+    u32 carry = 0;
+    for (int win = 0; win < L.nwin; win++) {
+      u32 raw = raw_window(w, win, c) + carry;
+      u32 neg = 0, mag = raw;
+      carry = 0;
+      if (raw > half) { mag = (1u << c) - raw; neg = 1; carry = 1; }
+      if (mag != 0) {
+        const u32 key = (L.merged ? 0u : ((u32)win << (c - 1))) + (mag - 1);
+        const u32 payload = (L.merged ? (u32)((size_t)win * L.table_stride + i) : (u32)i) | (neg << 31);
+        emit(win, key, payload);
+      }
+    }
+    return;
+  }
+  u32 m[2][8], sg[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int j = 4; j < 8; j++) m[h][j] = 0;
+  glv_split(w, m[0], &sg[0], m[1], &sg[1]);
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    u32 carry = 0;
+    for (int win = 0; win < L.nwin; win++) {
+      u32 raw = raw_window(m[h], win, c) + carry;
+      u32 neg = 0, mag = raw;
+      carry = 0;
+      if (raw > half) { mag = (1u << c) - raw; neg = 1; carry = 1; }
+      if (mag != 0) {
+        const u32 key = ((u32)win << (c - 1)) + (mag - 1);
+        const u32 payload = (u32)(i + (h ? L.phi_offset : 0)) | ((neg ^ sg[h]) << 31);
+        emit(h * L.nwin + win, key, payload);
+      }
+    }
+  }
+}
+
+// Counter increment (LDS or global) that stays fast when most of a wave hits ONE counter (bit-vector or repeated
+// scalars, the sparsely populated top window of a GLV half):
+// the lanes sharing the first active lane's key take a single atomic together.  Returns the lane's rank.
+__device__ __forceinline__ u32 counter_inc_agg(u32* __restrict__ ctr, u32 key) {
+  const u32 k0 = (u32)__builtin_amdgcn_readfirstlane((int)key);
+  const u64 same = __builtin_amdgcn_ballot_w64(key == k0);
+  if (__builtin_popcountll(same) >= 16) {
+    u32 r;
+    if (key == k0) {
+      const u32 lane_id = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      const u32 rank = (u32)__builtin_popcountll(same & (((u64)1 << lane_id) - 1));
+      u32 base = 0;
+      if (rank == 0) base = atomicAdd(&ctr[k0], (u32)__builtin_popcountll(same));
+      base = (u32)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(same));
+      r = base + rank;
+    } else {
+      r = atomicAdd(&ctr[key], 1u);
+    }
+    return r;
+  }
+  return atomicAdd(&ctr[key], 1u);
+}
 constexpr u32 NO_RANK = 0xffffffffu;
 
 // Pass 1: histogram; the value returned by the atomic is this entry's rank inside its bucket, kept
-// (coalesced, [window][i]) so that the scatter pass needs no atomics.
+// (coalesced, [slot][i]) so that the scatter pass needs no atomics.
 __global__ __launch_bounds__(256) void k_digits_count(const u32* __restrict__ scalars, size_t n, DigitLayout L, u32* __restrict__ counts,
                                                        u32* __restrict__ ranks) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 w[8];
   load_scalar_canonical(scalars, i, w);
-  const int c = L.c;
-  const u32 half = 1u << (c - 1);
-  u32 carry = 0;
-  for (int win = 0; win < L.nwin; win++) {
-    u32 raw = raw_window(w, win, c) + carry;
-    u32 mag = raw;
-    carry = 0;
-    if (raw > half) { mag = (1u << c) - raw; carry = 1; }
-    u32 rank = NO_RANK;
-    if (mag != 0) {
-      const size_t bucket = (L.merged ? (size_t)0 : ((size_t)win << (c - 1))) + (mag - 1);
-      rank = atomicAdd(&counts[bucket], 1u);
-    }
-    ranks[(size_t)win * n + i] = rank;
-  }
+  walk_digits(w, L, i, [&](int slot, u32 key, u32) { ranks[(size_t)slot * n + i] = counter_inc_agg(counts, key); });
 }
 // Pass 2: entries[offsets[bucket] + rank] = reference | sign << 31
 __global__ __launch_bounds__(256) void k_digits_scatter(const u32* __restrict__ scalars, size_t n, DigitLayout L, const u32* __restrict__ offsets,
@@ -146,21 +263,7 @@ __global__ __launch_bounds__(256) void k_digits_scatter(const u32* __restrict__ 
   if (i >= n) return;
   u32 w[8];
   load_scalar_canonical(scalars, i, w);
-  const int c = L.c;
-  const u32 half = 1u << (c - 1);
-  u32 carry = 0;
-  for (int win = 0; win < L.nwin; win++) {
-    u32 raw = raw_window(w, win, c) + carry;
-    u32 neg = 0, mag = raw;
-    carry = 0;
-    if (raw > half) { mag = (1u << c) - raw; neg = 1; carry = 1; }
-    if (mag != 0) {
-      const size_t bucket = (L.merged ? (size_t)0 : ((size_t)win << (c - 1))) + (mag - 1);
-      const u32 rank = ranks[(size_t)win * n + i];
-      const u32 ref = L.merged ? (u32)((size_t)win * L.table_stride + i) : (u32)i;
-      entries[offsets[bucket] + rank] = ref | (neg << 31);
-    }
-  }
+  walk_digits(w, L, i, [&](int slot, u32 key, u32 payload) { entries[offsets[key] + ranks[(size_t)slot * n + i]] = payload; });
 }
 
 // Merged (fixed-base) layout: one bucket set of 2^(c-1) = 32768 counters = 128 KiB fits the 160 KiB LDS of
@@ -251,48 +354,9 @@ __global__ __launch_bounds__(LDS_SORT_THREADS) void k_digits_scatter_lds(const u
 //           and k_fine_scatter writes the final 4-byte entries -- all inside one bin's region (256 KiB at 2^20),
 //           which stays in L2 while it fills.
 // key = bucket index: |digit| - 1 (merged layout) or window * 2^(c-1) + |digit| - 1.
-// LDS counter increment that stays fast when most of a wave hits ONE counter (bit-vector or repeated scalars):
-// the lanes sharing the first active lane's key take a single atomic together.  Returns the lane's rank.
-__device__ __forceinline__ u32 lds_inc_agg(u32* __restrict__ ctr, u32 key) {
-  const u32 k0 = (u32)__builtin_amdgcn_readfirstlane((int)key);
-  const u64 same = __builtin_amdgcn_ballot_w64(key == k0);
-  if (__builtin_popcountll(same) >= 16) {
-    u32 r;
-    if (key == k0) {
-      const u32 lane_id = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-      const u32 rank = (u32)__builtin_popcountll(same & (((u64)1 << lane_id) - 1));
-      u32 base = 0;
-      if (rank == 0) base = atomicAdd(&ctr[k0], (u32)__builtin_popcountll(same));
-      base = (u32)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(same));
-      r = base + rank;
-    } else {
-      r = atomicAdd(&ctr[key], 1u);
-    }
-    return r;
-  }
-  return atomicAdd(&ctr[key], 1u);
-}
 constexpr int COARSE_BINS = 256;
 constexpr int COARSE_PER_WG = 4096;
 constexpr int SORT2_THREADS = 1024;
-// calls emit(key, payload) for every non-zero signed digit of scalar i
-template <class Emit>
-__device__ __forceinline__ void walk_digits(const u32* w, const DigitLayout& L, size_t i, Emit emit) {
-  const int c = L.c;
-  const u32 half = 1u << (c - 1);
-  u32 carry = 0;
-  for (int win = 0; win < L.nwin; win++) {
-    u32 raw = raw_window(w, win, c) + carry;
-    u32 neg = 0, mag = raw;
-    carry = 0;
-    if (raw > half) { mag = (1u << c) - raw; neg = 1; carry = 1; }
-    if (mag != 0) {
-      const u32 key = (L.merged ? 0u : ((u32)win << (c - 1))) + (mag - 1);
-      const u32 payload = (L.merged ? (u32)((size_t)win * L.table_stride + i) : (u32)i) | (neg << 31);
-      emit(key, payload);
-    }
-  }
-}
 __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_count(const u32* __restrict__ scalars, size_t n, DigitLayout L, int key_shift,
                                                                  u32* __restrict__ binhist, int nwg) {
   __shared__ u32 hist[COARSE_BINS];
@@ -309,7 +373,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_count(const u32* __res
 #pragma unroll
   for (int k = 0; k < COARSE_PER_WG / SORT2_THREADS; k++) {
     const size_t i = lo + threadIdx.x + (size_t)k * SORT2_THREADS;
-    if (i < hi) walk_digits(w[k], L, i, [&](u32 key, u32) { lds_inc_agg(hist, key >> key_shift); });
+    if (i < hi) walk_digits(w[k], L, i, [&](int, u32 key, u32) { counter_inc_agg(hist, key >> key_shift); });
   }
   __syncthreads();
   if (threadIdx.x < COARSE_BINS) binhist[(size_t)threadIdx.x * nwg + blockIdx.x] = hist[threadIdx.x];
@@ -331,8 +395,8 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter(const u32* __r
 #pragma unroll
   for (int k = 0; k < COARSE_PER_WG / SORT2_THREADS; k++) {
     const size_t i = lo + threadIdx.x + (size_t)k * SORT2_THREADS;
-    if (i < hi) walk_digits(w[k], L, i, [&](u32 key, u32 payload) {
-      const u32 pos = lds_inc_agg(cursor, key >> key_shift);
+    if (i < hi) walk_digits(w[k], L, i, [&](int, u32 key, u32 payload) {
+      const u32 pos = counter_inc_agg(cursor, key >> key_shift);
       tmp[pos] = make_uint2(payload, key & fine_mask);
     });
   }
@@ -362,7 +426,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_fine_count(const uint2* __res
       f[k] = (e < hi) ? tmp[e].y : 0xffffffffu;
     }
 #pragma unroll
-    for (int k = 0; k < FINE_UNROLL; k++) if (f[k] != 0xffffffffu) lds_inc_agg(hist, f[k]);
+    for (int k = 0; k < FINE_UNROLL; k++) if (f[k] != 0xffffffffu) counter_inc_agg(hist, f[k]);
   }
   __syncthreads();
   for (int f = threadIdx.x; f < F; f += SORT2_THREADS) finehist[((size_t)blockIdx.x * F + f) * S + blockIdx.y] = hist[f];
@@ -388,7 +452,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter(const uint2* __r
       r[k] = (e < hi) ? tmp[e] : make_uint2(0u, 0xffffffffu);
     }
 #pragma unroll
-    for (int k = 0; k < FINE_UNROLL; k++) if (r[k].y != 0xffffffffu) entries[lds_inc_agg(cursor, r[k].y)] = r[k].x;
+    for (int k = 0; k < FINE_UNROLL; k++) if (r[k].y != 0xffffffffu) entries[counter_inc_agg(cursor, r[k].y)] = r[k].x;
   }
 }
 
@@ -657,10 +721,18 @@ int launch_window_combine(const u32* wsum, int nwin, int c, int out_xyzz, u32* o
 int launch_fold_partials(const u32* partials, int count, u32* out, hipStream_t s);
 
 // ---- host orchestration -----------------------------------------------------------------------------------
-int msm_prepare_points(const void* d_points_plain, size_t n, void* d_points_mont, hipStream_t s) {
+// d_phi (optional): receives the endomorphism images (beta x, y) of the n points (the generic MSM layout reads them
+// at index phi_offset + i)
+int msm_prepare_points(const void* d_points_plain, size_t n, void* d_points_mont, void* d_phi, hipStream_t s) {
   if (n == 0) return MZK_OK;
   hipLaunchKernelGGL(k_prepare_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const u32*)d_points_plain,
-                     (u32*)d_points_mont, n);
+                     (u32*)d_points_mont, n, (u32*)d_phi);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+int msm_phi_points(const void* d_points_mont, size_t n, void* d_phi, hipStream_t s) {
+  if (n == 0) return MZK_OK;
+  hipLaunchKernelGGL(k_phi_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const u32*)d_points_mont, n, (u32*)d_phi);
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }
@@ -709,12 +781,15 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     MZK_HIP(hipMemsetAsync(d_out, 0, out_partial_xyzz ? 128 : 64, s));
     return MZK_OK;
   }
-  MsmShape sh = choose_shape(n);
   DigitLayout L;
   const int table_c = (point_kind >> 8) ? (point_kind >> 8) : 16;
   point_kind &= 0xff;
   L.merged = (point_kind == 2) ? 1 : 0;
   L.table_stride = table_stride;
+  // generic layout: GLV split (mzk_glv.h) -- 2n points (P_i and phi(P_i) at phi_offset + i), half-length scalars
+  L.glv = L.merged ? 0 : 1;
+  L.phi_offset = (point_kind == 0) ? n : table_stride;   // prepared below / laid out by the SRS handle
+  MsmShape sh = L.merged ? choose_shape(n) : choose_shape_glv(n);
   if (L.merged) {
     sh.c = table_c; sh.nwin = msm_table_windows(table_c); sh.lgB = sh.c - 1; sh.nbuckets = (size_t)1 << sh.lgB;
   }
@@ -725,13 +800,13 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   const u32* pts = (const u32*)d_points;
   if (point_kind == 0) {
     void* pm;
-    MZK_TRY(ws_get(WS_MSM_POINTS, n * 64, &pm));
+    MZK_TRY(ws_get(WS_MSM_POINTS, 2 * n * 64, &pm));
     prof_begin(s, MZK_PH_MSM_PREPARE);
-    MZK_TRY(msm_prepare_points(d_points, n, pm, s));
+    MZK_TRY(msm_prepare_points(d_points, n, pm, (u32*)pm + n * 16, s));
     prof_end(s, MZK_PH_MSM_PREPARE);
     pts = (const u32*)pm;
   }
-  const size_t E_max = n * (size_t)sh.nwin;
+  const size_t E_max = n * (size_t)(L.glv ? 2 * sh.nwin : sh.nwin);
   int lgseg = 4;
   while ((E_max >> lgseg) > ((size_t)1 << 18) && lgseg < 16) lgseg++;
   const size_t T = (E_max + ((size_t)1 << lgseg) - 1) >> lgseg;

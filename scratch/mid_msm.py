@@ -3,7 +3,7 @@ import numpy as np, torch, myzkp_amd as mz
 mz.init(0); L = mz.lib(); dev = torch.device("cuda", 0)
 L.mzk_prof_name.restype = ctypes.c_char_p
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-for lg in (8, 10, 12, 14, 16, 18, 19):
+for lg in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "8,10,12,14,16,18,19").split(",")]:
     n = 1 << lg
     pts = torch.empty(n * 8, dtype=torch.int64, device=dev); sc = torch.empty(n * 4, dtype=torch.int64, device=dev); out = torch.zeros(8, dtype=torch.int64, device=dev)
     assert L.mzk_synth_g1_points_dev(ctypes.c_uint64(7), ctypes.c_size_t(n), ctypes.c_void_p(pts.data_ptr()), st) == 0

@@ -5,6 +5,7 @@
 #include <string.h>
 #include "../../myzkp_amd/csrc/mzk_ec.h"
 #include "../../myzkp_amd/csrc/mzk_g2.h"
+#include "../../myzkp_amd/csrc/mzk_glv.h"
 using namespace mzk;
 
 template <class P> static void run_field(int op, const u32* a, const u32* b, u32* out) {
@@ -139,6 +140,11 @@ int hc_g2_op(int op, const u32* a, const u32* b, const u32* k, u32* out) {
   u32 rec[64];
   x2_store(r, rec);
   g2_store_plain(x2_load(rec), out);
+  return 0;
+}
+// GLV split (mzk_glv.h): out = m1 (4 words) | neg1 | m2 (4 words) | neg2
+int hc_glv_split(const u32* k, u32* out) {
+  glv_split(k, out, out + 4, out + 5, out + 9);
   return 0;
 }
 }

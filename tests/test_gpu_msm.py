@@ -166,3 +166,26 @@ def test_skewed_scalars_generic_two_level_sort(mz):
     sets = _skewed_scalar_sets(n, 32)
     for name in ("ones", "bits", "mixed", "equal"):
         assert mz.msm_g1(sets[name], p) == orc.msm_fast(sets[name], p), name
+
+
+def test_glv_edge_scalars_generic_path(mz):
+    """the generic MSM splits every scalar as k = k1 + k2 lambda (mzk_glv.h) and runs on (P, phi(P)): scalars at the
+    decomposition's corners (lambda itself, its negative, powers of two, values that make one half zero or negative)"""
+    lam = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
+    ks = [0, 1, 2, lam, lam - 1, lam + 1, P_FR - lam, (lam * lam) % P_FR, P_FR - 1, P_FR - 2, 1 << 126, 1 << 127, (1 << 128) - 1,
+          1 << 253, (P_FR - 1) // 2, (P_FR + 1) // 2, 9931322734385697763, 147946756881789319010696353538189108491,
+          147946756881789319000765030803803410728]
+    pts = orc.synth_points(4242, len(ks))
+    s = orc.to_limbs(ks, 4)
+    assert mz.msm_g1(s, pts) == orc.msm_fast(s, pts)
+    for i, k in enumerate(ks):                      # one at a time: each is a bare scalar multiplication
+        assert mz.msm_g1(s[i:i + 1], pts[i:i + 1]) == orc.ec_mul(0, orc.arr_to_pts(pts[i:i + 1])[0], k), hex(k)
+
+
+@pytest.mark.parametrize("lg", [13, 15, 16, 17])
+def test_generic_msm_window_shapes(mz, lg):
+    """sizes that select different GLV window shapes (c = 12 / 13 / 13 / 16) and both sort paths"""
+    n = 1 << lg
+    p = orc.synth_points(600 + lg, n)
+    s = orc.synth_vector(FR, 601 + lg, n)
+    assert mz.msm_g1(s, p) == orc.msm_fast(s, p)

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def hc():
     src = os.path.join(HERE, "hostcheck", "hostcheck.cpp")
     so = os.path.join(HERE, "hostcheck", "libhostcheck.so")
-    hdrs = [os.path.join(orc.ROOT, "myzkp_amd", "csrc", h) for h in ("mzk_field.h", "mzk_ec.h", "mzk_g2.h", "mzk_constants.h")]
+    hdrs = [os.path.join(orc.ROOT, "myzkp_amd", "csrc", h) for h in ("mzk_field.h", "mzk_ec.h", "mzk_g2.h", "mzk_glv.h", "mzk_constants.h")]
     if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-DMZK_CHECK_BOUNDS", "-fPIC", "-shared", "-o", so, src])
     return ctypes.CDLL(so)
@@ -167,3 +167,26 @@ def test_g2_fq2_arithmetic_and_group_law_with_bounds(hc):
         assert _g2op(hc, 1, P) == orc.g2_add(P, P)
     for k in [0, 1, 2, 3, P_FR - 1, P_FR, rng.randrange(P_FR), (1 << 200) + 5]:
         assert _g2op(hc, 2, pts[0], k=k) == orc.g2_mul(pts[0], k), k
+
+
+def test_glv_split_identity_and_bounds(hc):
+    """mzk_glv.h: k1 + k2 lambda == k (mod r), both parts below 2^126 (asserted inside the header too), and the
+    endomorphism itself: lambda P == (beta x, y) on curve points"""
+    lam = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
+    beta = 0x59e26bcea0d48bacd4f263f1acdb5c4f5763473177fffffe
+    rng = random.Random(77)
+    ks = [0, 1, 2, P_FR - 1, P_FR - 2, lam, lam + 1, P_FR - lam, (P_FR - 1) // 2, 1 << 127, (1 << 128) - 1, 1 << 253] + \
+         [rng.randrange(P_FR) for _ in range(3000)] + [rng.getrandbits(b) for b in range(1, 254, 3)]
+    worst = 0
+    for k in ks:
+        out = np.zeros(10, dtype=np.uint32)
+        assert hc.hc_glv_split(orc.ptr(w32(k, 8)), orc.ptr(out)) == 0
+        m1, n1, m2, n2 = from_w32(out[0:4]), int(out[4]), from_w32(out[5:9]), int(out[9])
+        k1, k2 = (-m1 if n1 else m1), (-m2 if n2 else m2)
+        assert (k1 + k2 * lam - k) % P_FR == 0, k
+        assert m1 < 1 << 126 and m2 < 1 << 126
+        worst = max(worst, m1, m2)
+    assert worst > 1 << 120                       # the parts really are half-length, not trivially small
+    for kk in (1, 5, 12345678901234567890):
+        P = orc.ec_mul(0, (1, 2), kk)
+        assert orc.ec_mul(0, P, lam) == (beta * P[0] % P_FQ, P[1])
