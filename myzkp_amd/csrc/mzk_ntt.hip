@@ -32,7 +32,10 @@ constexpr int TILE = 1 << TILE_LOG;
 #define MZK_NTT_THREADS 256
 #endif
 constexpr int NTHREADS = MZK_NTT_THREADS;
-constexpr int MAX_LEVEL_LOG = 8;
+#ifndef MZK_NTT_MAX_LEVEL_LOG
+#define MZK_NTT_MAX_LEVEL_LOG 8
+#endif
+constexpr int MAX_LEVEL_LOG = MZK_NTT_MAX_LEVEL_LOG;
 
 struct Words8 { u32 w[8]; };
 
