@@ -809,6 +809,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   const size_t E_max = n * (size_t)(L.glv ? 2 * sh.nwin : sh.nwin);
   int lgseg = 4;
   while ((E_max >> lgseg) > ((size_t)1 << 18) && lgseg < 16) lgseg++;
+  // (segment length swept at 2^20 pairs: 32 / 64 / 128 / 256 entries -> 1.35 / 1.31 / 1.38 / 1.52 ms)
   const size_t T = (E_max + ((size_t)1 << lgseg) - 1) >> lgseg;
   const size_t nslots = T + NB + 1;
   const size_t heavy_words = 4 + (T + NB) / HEAVY_SLOTS;         // count + at most (T + NB) / 33 heavy buckets
