@@ -431,7 +431,9 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_fine_count(const uint2* __res
   __syncthreads();
   for (int f = threadIdx.x; f < F; f += SORT2_THREADS) finehist[((size_t)blockIdx.x * F + f) * S + blockIdx.y] = hist[f];
 }
-__global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter(const uint2* __restrict__ tmp, const u32* __restrict__ binbase, int nwg, int F,
+// Direct form: every record is stored straight to its final position (isolated 4-byte stores).  Only used when a
+// bin has more buckets than the staged kernel below has LDS for.
+__global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter_direct(const uint2* __restrict__ tmp, const u32* __restrict__ binbase, int nwg, int F,
                                                                  int S, const u32* __restrict__ finebase, u32* __restrict__ offsets,
                                                                  u32* __restrict__ entries, size_t nbuckets) {
   __shared__ u32 cursor[FINE_MAX];
@@ -453,6 +455,80 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter(const uint2* __r
     }
 #pragma unroll
     for (int k = 0; k < FINE_UNROLL; k++) if (r[k].y != 0xffffffffu) entries[counter_inc_agg(cursor, r[k].y)] = r[k].x;
+  }
+}
+
+// Staged form: the workgroup sorts up to STAGE_CAP records of its slice by bucket INSIDE LDS (count, prefix, place),
+// then copies the staged run out with consecutive lanes writing consecutive entries -- bucket runs leave as
+// contiguous stores instead of one dirty sector per record (HBM write traffic of this kernel 3.5x -> ~1x payload).
+constexpr int STAGE_CAP = 16384;
+constexpr int STAGE_PER_LANE = STAGE_CAP / SORT2_THREADS;     // 16 records per lane per round
+constexpr int STAGE_F_MAX = 2048;
+__global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter(const uint2* __restrict__ tmp, const u32* __restrict__ binbase, int nwg, int F,
+                                                                 int S, const u32* __restrict__ finebase, u32* __restrict__ offsets,
+                                                                 u32* __restrict__ entries, size_t nbuckets) {
+  extern __shared__ u32 lds_fs[];
+  u32* gbase = lds_fs;                 // [F]   global position of the next entry of bucket f written by this workgroup
+  u32* cnt = gbase + F;                // [F]   records of bucket f in the current round
+  u32* lpre = cnt + F;                 // [F]   exclusive prefix of cnt
+  u32* scan = lpre + F;                // [SORT2_THREADS] block-scan scratch
+  u32* spay = scan + SORT2_THREADS;    // [STAGE_CAP] staged payloads, bucket-sorted
+  unsigned short* skey = reinterpret_cast<unsigned short*>(spay + STAGE_CAP);   // [STAGE_CAP] their buckets
+  const int tid = threadIdx.x;
+  for (int f = tid; f < F; f += SORT2_THREADS) {
+    const u32 base = finebase[((size_t)blockIdx.x * F + f) * S + blockIdx.y];
+    gbase[f] = base;
+    if (blockIdx.y == 0) offsets[(size_t)blockIdx.x * F + f] = base;      // start of bucket (bin, f)
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) offsets[nbuckets] = finebase[nbuckets * (size_t)S];   // total entries
+  u32 lo, hi;
+  fine_slice(binbase, nwg, blockIdx.x, blockIdx.y, S, &lo, &hi);
+  const int per = (F + SORT2_THREADS - 1) / SORT2_THREADS;     // counters per lane in the prefix (<= 2)
+  for (u32 chunk = lo; chunk < hi; chunk += STAGE_CAP) {
+    const u32 cend = (hi - chunk > (u32)STAGE_CAP) ? chunk + STAGE_CAP : hi;
+    for (int f = tid; f < F; f += SORT2_THREADS) cnt[f] = 0;
+    __syncthreads();
+    uint2 r[STAGE_PER_LANE];
+    u32 rk[STAGE_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < STAGE_PER_LANE; k++) {
+      const u32 e = chunk + tid + k * SORT2_THREADS;
+      r[k] = (e < cend) ? tmp[e] : make_uint2(0u, 0xffffffffu);
+    }
+#pragma unroll
+    for (int k = 0; k < STAGE_PER_LANE; k++) rk[k] = (r[k].y != 0xffffffffu) ? counter_inc_agg(cnt, r[k].y) : 0u;
+    __syncthreads();
+    // exclusive prefix of cnt[0..F): lane-local run of `per` counters, Hillis-Steele over the lane sums
+    u32 local = 0;
+    for (int q = 0; q < per; q++) { const int f = tid * per + q; if (f < F) local += cnt[f]; }
+    scan[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < SORT2_THREADS; off <<= 1) {
+      const u32 t = (tid >= off) ? scan[tid - off] : 0u;
+      __syncthreads();
+      scan[tid] += t;
+      __syncthreads();
+    }
+    u32 run = scan[tid] - local;
+    for (int q = 0; q < per; q++) { const int f = tid * per + q; if (f < F) { lpre[f] = run; run += cnt[f]; } }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < STAGE_PER_LANE; k++) {
+      if (r[k].y != 0xffffffffu) {
+        const u32 pos = lpre[r[k].y] + rk[k];
+        spay[pos] = r[k].x;
+        skey[pos] = (unsigned short)r[k].y;
+      }
+    }
+    __syncthreads();
+    const u32 m = cend - chunk;
+    for (u32 j = tid; j < m; j += SORT2_THREADS) {
+      const u32 f = skey[j];
+      entries[gbase[f] + (j - lpre[f])] = spay[j];
+    }
+    __syncthreads();
+    for (int f = tid; f < F; f += SORT2_THREADS) gbase[f] += cnt[f];
+    __syncthreads();
   }
 }
 
@@ -866,8 +942,19 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     hipLaunchKernelGGL(k_scan_local, dim3((unsigned)sb_f), dim3(256), 0, s, (const u32*)finehist, finehist, scan3, n_fine);
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, scan3, sb_f, scan3 + sb_f);
     hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((n_fine + 1 + 255) / 256)), dim3(256), 0, s, finehist, (const u32*)scan3, (const u32*)(scan3 + sb_f), n_fine);
-    hipLaunchKernelGGL(k_fine_scatter, dim3(COARSE_BINS, S), dim3(SORT2_THREADS), 0, s, (const uint2*)tmp, (const u32*)binhist, nwg, F, S,
-                       (const u32*)finehist, offsets, entries, NBtot);
+    if (F <= STAGE_F_MAX) {
+      const size_t lds = ((size_t)3 * F + SORT2_THREADS + STAGE_CAP) * 4 + (size_t)STAGE_CAP * 2;
+      static bool staged_attr = false;
+      if (!staged_attr) {
+        MZK_HIP(hipFuncSetAttribute((const void*)k_fine_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        staged_attr = true;
+      }
+      hipLaunchKernelGGL(k_fine_scatter, dim3(COARSE_BINS, S), dim3(SORT2_THREADS), lds, s, (const uint2*)tmp, (const u32*)binhist, nwg, F, S,
+                         (const u32*)finehist, offsets, entries, NBtot);
+    } else {
+      hipLaunchKernelGGL(k_fine_scatter_direct, dim3(COARSE_BINS, S), dim3(SORT2_THREADS), 0, s, (const uint2*)tmp, (const u32*)binhist, nwg, F, S,
+                         (const u32*)finehist, offsets, entries, NBtot);
+    }
   } else if (L.merged) {
     // LDS histogram path (no global atomics)
     int nwg = (int)((n + 4095) / 4096);
