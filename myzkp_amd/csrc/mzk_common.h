@@ -39,7 +39,7 @@ int ensure_init();
 
 // Grow-only device scratch buffers, keyed by slot, so steady-state calls never hipMalloc.
 enum WsSlot { WS_NTT_TMP = 0, WS_NTT_IO_A, WS_NTT_IO_B, WS_MSM_POINTS, WS_MSM_SCALARS, WS_MSM_COUNTS, WS_MSM_OFFSETS,
-              WS_MSM_CURSOR, WS_MSM_ENTRIES, WS_MSM_BUCKETS, WS_MSM_RED_A, WS_MSM_RED_B, WS_MSM_SCAN, WS_MSM_OUT, WS_MSM_SLOTS, WS_MSM_WGHIST, WS_BATCHINV, WS_XYZZ_TMP, WS_MERKLE_NODES, WS_FB_TABLE16, WS_FB_TABLE8,
+              WS_MSM_CURSOR, WS_MSM_ENTRIES, WS_MSM_BUCKETS, WS_MSM_RED_A, WS_MSM_RED_B, WS_MSM_SCAN, WS_MSM_OUT, WS_MSM_SLOTS, WS_MSM_WGHIST, WS_BATCHINV, WS_XYZZ_TMP, WS_MERKLE_NODES, WS_FB_TABLE16, WS_FB_TABLE8, WS_NTT_PRE, WS_NTT_PRE_M128,
               WS_MISC_A, WS_MISC_B, WS_MISC_C, WS_MISC_D, WS_COUNT };
 int ws_get(WsSlot slot, size_t bytes, void** out);
 void ws_release_all();

@@ -165,10 +165,15 @@ __device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, i
 }
 
 // Pass t < K: in-place strided columns + inter-pass twiddle.
-template <class P>
+// PRE (first pass of a coset LDE, ntt.rs:254-269): the input is the coefficient vector itself -- element idx is
+// coef[idx] * offset^idx for idx < n_coef and zero beyond -- so Polynomial::scale and the zero padding cost no pass
+// of their own.  offset^idx = offset^(j1 M) * offset^col comes from two small per-call tables (pre_row: 2^lgn
+// entries, pre_col: M entries, Montgomery form).
+struct PreArgs { const u32* coef; size_t n_coef; const u32* pre_row; const u32* pre_col; };
+template <class P, bool PRE>
 __global__ __launch_bounds__(NTHREADS) void k_ntt_strided(const u32* __restrict__ in, u32* __restrict__ out,
                                                            const u32* __restrict__ tw_tile,
-                                                           const u32* __restrict__ tw_inter, int lgn, int lgM, int lgc) {
+                                                           const u32* __restrict__ tw_inter, int lgn, int lgM, int lgc, PreArgs pre) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   const int tid = threadIdx.x;
   const int lg_tiles = lgM - lgc;
@@ -181,7 +186,19 @@ __global__ __launch_bounds__(NTHREADS) void k_ntt_strided(const u32* __restrict_
   stage_twiddles<P>(twl, tw_tile, lgn);
   for (int e = tid; e < tile_elems; e += NTHREADS) {
     const int j1 = e >> lgc, c = e & cmask;
-    Fe<P> v = gload<P>(in, base + ((size_t)j1 << lgM) + c);
+    Fe<P> v;
+    if constexpr (PRE) {
+      const size_t idx = base + ((size_t)j1 << lgM) + c;          // o == 0 in the first pass
+      if (idx < pre.n_coef) {
+        const Fe<P> x = gload<P>(pre.coef, idx);
+        const Fe<P> wc = gload<P>(pre.pre_col, (ct << lgc) + c), wr = gload<P>(pre.pre_row, (size_t)j1);
+        v = fe_fit<P>(fe_mul<P>(fe_mul<P>(x, wc), wr));            // plain * Montgomery * Montgomery = plain
+      } else {
+        v = fe_zero<P>();
+      }
+    } else {
+      v = gload<P>(in, base + ((size_t)j1 << lgM) + c);
+    }
     const int k = (int)(__brev((unsigned)j1) >> (32 - lgn));
     lds_store<P>(lds, (k << lgc) | c, v);
   }
@@ -453,7 +470,7 @@ static int get_plan(int fid, unsigned logn, bool inverse, const uint64_t* root, 
 }
 
 template <class P>
-static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t s) {
+static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t s, const PreArgs* pre = nullptr) {
   const LevelInfo& li = pl->li;
   const unsigned logn = pl->logn;
 
@@ -468,8 +485,12 @@ static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t 
     const unsigned blocks = (unsigned)((size_t)1 << (logn - TILE_LOG));
     {
       ProfScope ps(s, MZK_PH_NTT_PASS0 + t);
-      hipLaunchKernelGGL((k_ntt_strided<P>), dim3(blocks), dim3(NTHREADS), lds_for(lgn), s, src, tmp, pl->tw_tile[t],
-                         pl->tw_inter[t], lgn, lgM, lgc);
+      if (t == 0 && pre)
+        hipLaunchKernelGGL((k_ntt_strided<P, true>), dim3(blocks), dim3(NTHREADS), lds_for(lgn), s, src, tmp, pl->tw_tile[t],
+                           pl->tw_inter[t], lgn, lgM, lgc, *pre);
+      else
+        hipLaunchKernelGGL((k_ntt_strided<P, false>), dim3(blocks), dim3(NTHREADS), lds_for(lgn), s, src, tmp, pl->tw_tile[t],
+                           pl->tw_inter[t], lgn, lgM, lgc, PreArgs{nullptr, 0, nullptr, nullptr});
     }
     src = tmp;
     lg_after = lgM;
@@ -524,6 +545,49 @@ int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_
   if (!h_is_canonical(hf, offset_host) || !h_is_canonical(hf, generator_host)) { set_error("coset_lde: parameter not canonical"); return MZK_E_RANGE; }
   Words8 offw;
   to_words(offset_host, hf->nl, &offw);
+  const unsigned logn = ilog2(order);
+  if (order > 1 && choose_levels(logn).nlev > 1) {
+    // multi-pass transform: Polynomial::scale + padding fused into the first pass (PreArgs)
+    if (!h_is_canonical(hf, generator_host)) { set_error("coset_lde: parameter not canonical"); return MZK_E_RANGE; }
+    NttPlan* pl = nullptr;
+    MZK_TRY(get_plan(fid, logn, false, generator_host, nullptr, s, &pl));
+    const int lgn0 = pl->li.lg[0], lgM0 = (int)logn - lgn0;
+    const size_t nrow = (size_t)1 << lgn0, ncol = (size_t)1 << lgM0;
+    // offset^(j M) and offset^col tables: like the plan's twiddles they depend only on (field, offset, size) -- a STARK
+    // prover evaluates every polynomial on ONE coset -- so the last pair per field is kept (workspace generation and
+    // stream order checked like the fixed-base tables in mzk_kzg.hip).
+    static struct { uint64_t off[4]; unsigned logn; uint64_t gen; bool valid; hipEvent_t ready; } cache[2] = {};
+    auto& ce = cache[fid == MZK_FIELD_M128 ? 1 : 0];
+    void* tabs = nullptr;
+    MZK_TRY(ws_get(fid == MZK_FIELD_M128 ? WS_NTT_PRE_M128 : WS_NTT_PRE, (nrow + ncol) * field_bytes(fid), &tabs));
+    u32* pre_row = (u32*)tabs;
+    u32* pre_col = pre_row + nrow * field_words(fid);
+    if (!ce.ready) MZK_HIP(hipEventCreateWithFlags(&ce.ready, hipEventDisableTiming));
+    const bool hit = ce.valid && ce.gen == ws_generation() && ce.logn == logn && memcmp(ce.off, offset_host, 8 * hf->nl) == 0;
+    if (!hit) {
+      // a regrown slot or another size invalidates the pointers: wait for earlier users of the old contents
+      prof_begin(s, MZK_PH_NTT_PRESCALE);
+      const unsigned bc = (unsigned)((ncol + GEN_CHUNK * 64 - 1) / (GEN_CHUNK * 64)), br = (unsigned)((nrow + GEN_CHUNK * 64 - 1) / (GEN_CHUNK * 64));
+      if (fid == MZK_FIELD_M128) {
+        hipLaunchKernelGGL((k_gen_pow_table<M128Params>), dim3(bc), dim3(64), 0, s, offw, (uint64_t)1, ncol, pre_col);
+        hipLaunchKernelGGL((k_gen_pow_table<M128Params>), dim3(br), dim3(64), 0, s, offw, (uint64_t)ncol, nrow, pre_row);
+      } else {
+        hipLaunchKernelGGL((k_gen_pow_table<FrParams>), dim3(bc), dim3(64), 0, s, offw, (uint64_t)1, ncol, pre_col);
+        hipLaunchKernelGGL((k_gen_pow_table<FrParams>), dim3(br), dim3(64), 0, s, offw, (uint64_t)ncol, nrow, pre_row);
+      }
+      MZK_HIP(hipGetLastError());
+      prof_end(s, MZK_PH_NTT_PRESCALE);
+      memset(ce.off, 0, sizeof ce.off);
+      memcpy(ce.off, offset_host, 8 * hf->nl);
+      ce.logn = logn; ce.gen = ws_generation(); ce.valid = true;
+      MZK_HIP(hipEventRecord(ce.ready, s));
+    } else {
+      MZK_HIP(hipStreamWaitEvent(s, ce.ready, 0));
+    }
+    const PreArgs pre{(const u32*)d_coef, n_coef, pre_row, pre_col};
+    if (fid == MZK_FIELD_M128) return run_plan<M128Params>(pl, (const u32*)d_coef, (u32*)d_out, s, &pre);
+    return run_plan<FrParams>(pl, (const u32*)d_coef, (u32*)d_out, s, &pre);
+  }
   void* scaled = nullptr;
   MZK_TRY(ws_get(WS_NTT_IO_A, order * field_bytes(fid), &scaled));
   const size_t chunks = (order + GEN_CHUNK - 1) / GEN_CHUNK;

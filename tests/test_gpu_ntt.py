@@ -136,3 +136,28 @@ def test_linearity_at_full_size(mz):
     Sv = mz.ntt(fid, w, s)
     Al, Bl, Sl = orc.from_limbs(A[idx]), orc.from_limbs(B[idx]), orc.from_limbs(Sv[idx])
     assert all((x + y) % p == z for x, y, z in zip(Al, Bl, Sl))
+
+
+@pytest.mark.parametrize("fid", [M128, FR])
+def test_coset_lde_fused_prescale_and_table_cache(mz, fid):
+    """multi-pass sizes fuse Polynomial::scale + padding into the first pass and keep the offset-power tables between
+    calls: alternate offsets, sizes and coefficient counts so that hits, misses and regrown tables all occur"""
+    p = orc.MOD[fid]
+    offs = [orc.M128_GEN % p, 5, 7, 5]
+    for lg, ncoef in ((12, 1 << 10), (12, 1000), (13, 1 << 13), (12, 1 << 10), (11, 3), (14, 1 << 12)):
+        order = 1 << lg
+        gen = orc.root_of(fid, lg)
+        coef = orc.synth_vector(fid, 70 + lg + ncoef, ncoef)
+        for off in offs:
+            got = mz.coset_lde(fid, coef, off, gen, order)
+            want = orc.coset_ref(fid, coef, off, gen, order)[1] if lg <= 12 else None
+            if want is None:      # literal oracle is O(n log^2 n): above 2^12 use the fast oracle on the scaled, padded vector
+                vals = orc.from_limbs(coef)
+                acc, sc = 1, []
+                for x in vals:
+                    sc.append(x * acc % p); acc = acc * off % p
+                arr = np.zeros((order, orc.LIMBS[fid]), dtype=np.uint64)
+                arr[:ncoef] = orc.to_limbs(sc, orc.LIMBS[fid])
+                rc, want = orc.ntt_fast(fid, gen, arr)
+                assert rc == 0
+            assert np.array_equal(got, want), (lg, ncoef, off)
