@@ -189,3 +189,28 @@ def test_generic_msm_window_shapes(mz, lg):
     p = orc.synth_points(600 + lg, n)
     s = orc.synth_vector(FR, 601 + lg, n)
     assert mz.msm_g1(s, p) == orc.msm_fast(s, p)
+
+
+def test_randomised_differential_generic_and_srs(mz):
+    """25 seeded random cases: ragged sizes across every window shape, mixed scalar patterns (uniform, short, bit,
+    repeated, r-1, zero), infinity points sprinkled in, same result through the generic MSM and an SRS handle"""
+    import random
+    rnd = random.Random(20261001)
+    base = orc.synth_points(99, 6000)
+    for case in range(25):
+        n = rnd.choice([1, 2, 3, 7, 31, 100, 255, 256, 257, 1000, 2049, 4095, 4096, 4097, 5999])
+        p = base[:n].copy()
+        vals = []
+        for i in range(n):
+            kind = rnd.randrange(8)
+            vals.append([rnd.randrange(P_FR), rnd.getrandbits(16), rnd.getrandbits(1), 7, P_FR - 1, 0, rnd.getrandbits(128),
+                         P_FR - rnd.getrandbits(20) - 1][kind])
+        for i in rnd.sample(range(n), min(n, 3)):
+            if rnd.random() < 0.5:
+                p[i] = 0
+        s = orc.to_limbs(vals, 4)
+        want = orc.msm_fast(s, p)
+        assert mz.msm_g1(s, p) == want, (case, n)
+        h = mz.Srs(p)
+        assert h.commit(s) == want, (case, n)
+        h.close()
