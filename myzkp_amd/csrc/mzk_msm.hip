@@ -378,9 +378,25 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_count(const u32* __res
   __syncthreads();
   if (threadIdx.x < COARSE_BINS) binhist[(size_t)threadIdx.x * nwg + blockIdx.x] = hist[threadIdx.x];
 }
+// Intermediate records of the two-level sort: (payload, fine key).  The 8-byte form always works; when the point
+// reference, the fine key and the sign fit 32 bits together (up to 2^20 pairs in both layouts) the 4-byte form halves the
+// traffic of the coarse scatter and of both fine passes.
+struct Rec8 {
+  typedef uint2 T;
+  static __device__ __forceinline__ T make(u32 payload, u32 fine, int) { return make_uint2(payload, fine); }
+  static __device__ __forceinline__ u32 fine(const T& r, u32, int) { return r.y; }
+  static __device__ __forceinline__ u32 payload(const T& r, int) { return r.x; }
+};
+struct Rec4 {   // ref << (fb + 1) | fine << 1 | sign;  needs ref < 2^(31 - fb)
+  typedef u32 T;
+  static __device__ __forceinline__ T make(u32 payload, u32 fine, int fb) { return ((payload & 0x7fffffffu) << (fb + 1)) | (fine << 1) | (payload >> 31); }
+  static __device__ __forceinline__ u32 fine(const T& r, u32 fmask, int) { return (r >> 1) & fmask; }
+  static __device__ __forceinline__ u32 payload(const T& r, int fb) { return (r >> (fb + 1)) | ((r & 1u) << 31); }
+};
+template <class REC>
 __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter(const u32* __restrict__ scalars, size_t n, DigitLayout L, int key_shift,
-                                                                   u32 fine_mask, const u32* __restrict__ binbase, int nwg,
-                                                                   uint2* __restrict__ tmp) {
+                                                                   u32 fine_mask, int fb, const u32* __restrict__ binbase, int nwg,
+                                                                   typename REC::T* __restrict__ tmp) {
   __shared__ u32 cursor[COARSE_BINS];
   if (threadIdx.x < COARSE_BINS) cursor[threadIdx.x] = binbase[(size_t)threadIdx.x * nwg + blockIdx.x];
   __syncthreads();
@@ -397,7 +413,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter(const u32* __r
     const size_t i = lo + threadIdx.x + (size_t)k * SORT2_THREADS;
     if (i < hi) walk_digits(w[k], L, i, [&](int, u32 key, u32 payload) {
       const u32 pos = counter_inc_agg(cursor, key >> key_shift);
-      tmp[pos] = make_uint2(payload, key & fine_mask);
+      tmp[pos] = REC::make(payload, key & fine_mask, fb);
     });
   }
 }
@@ -410,8 +426,9 @@ __device__ __forceinline__ void fine_slice(const u32* __restrict__ binbase, int 
 }
 constexpr int FINE_UNROLL = 8;
 constexpr int FINE_MAX = 8192;     // buckets per bin: NB / 256 (128 merged c = 16, 2048 generic c = 16, 8192 merged c = 22)
-__global__ __launch_bounds__(SORT2_THREADS) void k_fine_count(const uint2* __restrict__ tmp, const u32* __restrict__ binbase, int nwg, int F,
-                                                               int S, u32* __restrict__ finehist) {
+template <class REC>
+__global__ __launch_bounds__(SORT2_THREADS) void k_fine_count(const typename REC::T* __restrict__ tmp, const u32* __restrict__ binbase, int nwg, int F,
+                                                               int S, int fb, u32* __restrict__ finehist) {
   __shared__ u32 hist[FINE_MAX];
   for (int f = threadIdx.x; f < F; f += SORT2_THREADS) hist[f] = 0;
   __syncthreads();
@@ -423,7 +440,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_fine_count(const uint2* __res
 #pragma unroll
     for (int k = 0; k < FINE_UNROLL; k++) {
       const u32 e = base + k * SORT2_THREADS;
-      f[k] = (e < hi) ? tmp[e].y : 0xffffffffu;
+      f[k] = (e < hi) ? REC::fine(tmp[e], (u32)F - 1u, fb) : 0xffffffffu;
     }
 #pragma unroll
     for (int k = 0; k < FINE_UNROLL; k++) if (f[k] != 0xffffffffu) counter_inc_agg(hist, f[k]);
@@ -433,8 +450,9 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_fine_count(const uint2* __res
 }
 // Direct form: every record is stored straight to its final position (isolated 4-byte stores).  Only used when a
 // bin has more buckets than the staged kernel below has LDS for.
-__global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter_direct(const uint2* __restrict__ tmp, const u32* __restrict__ binbase, int nwg, int F,
-                                                                 int S, const u32* __restrict__ finebase, u32* __restrict__ offsets,
+template <class REC>
+__global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter_direct(const typename REC::T* __restrict__ tmp, const u32* __restrict__ binbase, int nwg, int F,
+                                                                 int S, int fb, const u32* __restrict__ finebase, u32* __restrict__ offsets,
                                                                  u32* __restrict__ entries, size_t nbuckets) {
   __shared__ u32 cursor[FINE_MAX];
   for (int f = threadIdx.x; f < F; f += SORT2_THREADS) {
@@ -447,14 +465,15 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter_direct(const uin
   u32 lo, hi;
   fine_slice(binbase, nwg, blockIdx.x, blockIdx.y, S, &lo, &hi);
   for (u32 base = lo + threadIdx.x; base < hi; base += FINE_UNROLL * SORT2_THREADS) {
-    uint2 r[FINE_UNROLL];
+    typename REC::T r[FINE_UNROLL];
 #pragma unroll
     for (int k = 0; k < FINE_UNROLL; k++) {
       const u32 e = base + k * SORT2_THREADS;
-      r[k] = (e < hi) ? tmp[e] : make_uint2(0u, 0xffffffffu);
+      if (e < hi) r[k] = tmp[e];
     }
 #pragma unroll
-    for (int k = 0; k < FINE_UNROLL; k++) if (r[k].y != 0xffffffffu) entries[counter_inc_agg(cursor, r[k].y)] = r[k].x;
+    for (int k = 0; k < FINE_UNROLL; k++)
+      if (base + k * SORT2_THREADS < hi) entries[counter_inc_agg(cursor, REC::fine(r[k], (u32)F - 1u, fb))] = REC::payload(r[k], fb);
   }
 }
 
@@ -464,8 +483,9 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter_direct(const uin
 constexpr int STAGE_CAP = 16384;
 constexpr int STAGE_PER_LANE = STAGE_CAP / SORT2_THREADS;     // 16 records per lane per round
 constexpr int STAGE_F_MAX = 2048;
-__global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter(const uint2* __restrict__ tmp, const u32* __restrict__ binbase, int nwg, int F,
-                                                                 int S, const u32* __restrict__ finebase, u32* __restrict__ offsets,
+template <class REC>
+__global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter(const typename REC::T* __restrict__ tmp, const u32* __restrict__ binbase, int nwg, int F,
+                                                                 int S, int fb, const u32* __restrict__ finebase, u32* __restrict__ offsets,
                                                                  u32* __restrict__ entries, size_t nbuckets) {
   extern __shared__ u32 lds_fs[];
   u32* gbase = lds_fs;                 // [F]   global position of the next entry of bucket f written by this workgroup
@@ -488,15 +508,16 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter(const uint2* __r
     const u32 cend = (hi - chunk > (u32)STAGE_CAP) ? chunk + STAGE_CAP : hi;
     for (int f = tid; f < F; f += SORT2_THREADS) cnt[f] = 0;
     __syncthreads();
-    uint2 r[STAGE_PER_LANE];
+    typename REC::T r[STAGE_PER_LANE];
     u32 rk[STAGE_PER_LANE];
+    const u32 fmask = (u32)F - 1u;
 #pragma unroll
     for (int k = 0; k < STAGE_PER_LANE; k++) {
       const u32 e = chunk + tid + k * SORT2_THREADS;
-      r[k] = (e < cend) ? tmp[e] : make_uint2(0u, 0xffffffffu);
+      if (e < cend) r[k] = tmp[e];
     }
 #pragma unroll
-    for (int k = 0; k < STAGE_PER_LANE; k++) rk[k] = (r[k].y != 0xffffffffu) ? counter_inc_agg(cnt, r[k].y) : 0u;
+    for (int k = 0; k < STAGE_PER_LANE; k++) rk[k] = (chunk + tid + k * SORT2_THREADS < cend) ? counter_inc_agg(cnt, REC::fine(r[k], fmask, fb)) : 0u;
     __syncthreads();
     // exclusive prefix of cnt[0..F): lane-local run of `per` counters, Hillis-Steele over the lane sums
     u32 local = 0;
@@ -514,10 +535,11 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter(const uint2* __r
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < STAGE_PER_LANE; k++) {
-      if (r[k].y != 0xffffffffu) {
-        const u32 pos = lpre[r[k].y] + rk[k];
-        spay[pos] = r[k].x;
-        skey[pos] = (unsigned short)r[k].y;
+      if (chunk + tid + k * SORT2_THREADS < cend) {
+        const u32 fk = REC::fine(r[k], fmask, fb);
+        const u32 pos = lpre[fk] + rk[k];
+        spay[pos] = REC::payload(r[k], fb);
+        skey[pos] = (unsigned short)fk;
       }
     }
     __syncthreads();
@@ -847,6 +869,39 @@ int msm_build_tables(const void* d_points_mont, size_t n, void* d_tables, int wi
   return MZK_OK;
 }
 
+// record-format dependent half of the two-level sort (coarse scatter, fine count, scan, fine scatter)
+struct SortArgs {
+  const u32* scalars; size_t n; DigitLayout L; int key_shift; u32 fine_mask; int fb; u32* binhist; int nwg; void* tmp; int F; int S;
+  u32* finehist; u32* scan3; size_t sb_f; size_t n_fine; u32* offsets; u32* entries; size_t NBtot;
+};
+template <class REC>
+static int sort_records(const SortArgs& a, hipStream_t s) {
+  typedef typename REC::T R;
+  hipLaunchKernelGGL((k_coarse_scatter<REC>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb,
+                     (const u32*)a.binhist, a.nwg, (R*)a.tmp);
+  hipLaunchKernelGGL((k_fine_count<REC>), dim3(COARSE_BINS, a.S), dim3(SORT2_THREADS), 0, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg, a.F, a.S,
+                     a.fb, a.finehist);
+  hipLaunchKernelGGL(k_scan_local, dim3((unsigned)a.sb_f), dim3(256), 0, s, (const u32*)a.finehist, a.finehist, a.scan3, a.n_fine);
+  hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, a.scan3, a.sb_f, a.scan3 + a.sb_f);
+  hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((a.n_fine + 1 + 255) / 256)), dim3(256), 0, s, a.finehist, (const u32*)a.scan3,
+                     (const u32*)(a.scan3 + a.sb_f), a.n_fine);
+  if (a.F <= STAGE_F_MAX) {
+    const size_t lds = ((size_t)3 * a.F + SORT2_THREADS + STAGE_CAP) * 4 + (size_t)STAGE_CAP * 2;
+    static bool staged_attr = false;     // one flag per instantiation
+    if (!staged_attr) {
+      MZK_HIP(hipFuncSetAttribute((const void*)k_fine_scatter<REC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      staged_attr = true;
+    }
+    hipLaunchKernelGGL((k_fine_scatter<REC>), dim3(COARSE_BINS, a.S), dim3(SORT2_THREADS), lds, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg, a.F,
+                       a.S, a.fb, (const u32*)a.finehist, a.offsets, a.entries, a.NBtot);
+  } else {
+    hipLaunchKernelGGL((k_fine_scatter_direct<REC>), dim3(COARSE_BINS, a.S), dim3(SORT2_THREADS), 0, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg,
+                       a.F, a.S, a.fb, (const u32*)a.finehist, a.offsets, a.entries, a.NBtot);
+  }
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+
 // point_kind: 0 = affine canonical (ABI form), 1 = affine Montgomery (prepared), 2 = SRS window tables
 // (SRS_WINDOWS x table_stride affine Montgomery points: all windows share one bucket set, no Horner).
 int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int point_kind, size_t table_stride, void* d_out,
@@ -925,10 +980,8 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     if (S > 64) S = 64;
     const size_t n_coarse = (size_t)COARSE_BINS * nwg, n_fine = NBtot * (size_t)S;
     u32 *binhist, *finehist;
-    uint2* tmp;
     MZK_TRY(ws_get(WS_MSM_WGHIST, (n_coarse + 1 + n_fine + 1) * 4, (void**)&binhist));
     finehist = binhist + n_coarse + 1;
-    tmp = (uint2*)ranks;
     const size_t sb_c = (n_coarse + SCAN_BLOCK - 1) / SCAN_BLOCK, sb_f = (n_fine + SCAN_BLOCK - 1) / SCAN_BLOCK;
     u32* scan2;
     MZK_TRY(ws_get(WS_MSM_SCAN, (sb_c + sb_f + 4) * 4, (void**)&scan2));
@@ -936,25 +989,14 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     hipLaunchKernelGGL(k_scan_local, dim3((unsigned)sb_c), dim3(256), 0, s, (const u32*)binhist, binhist, scan2, n_coarse);
     hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, scan2, sb_c, scan2 + sb_c);
     hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((n_coarse + 1 + 255) / 256)), dim3(256), 0, s, binhist, (const u32*)scan2, (const u32*)(scan2 + sb_c), n_coarse);
-    hipLaunchKernelGGL(k_coarse_scatter, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, fine_mask, (const u32*)binhist, nwg, tmp);
-    hipLaunchKernelGGL(k_fine_count, dim3(COARSE_BINS, S), dim3(SORT2_THREADS), 0, s, (const uint2*)tmp, (const u32*)binhist, nwg, F, S, finehist);
-    u32* scan3 = scan2 + sb_c + 2;
-    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)sb_f), dim3(256), 0, s, (const u32*)finehist, finehist, scan3, n_fine);
-    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, scan3, sb_f, scan3 + sb_f);
-    hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((n_fine + 1 + 255) / 256)), dim3(256), 0, s, finehist, (const u32*)scan3, (const u32*)(scan3 + sb_f), n_fine);
-    if (F <= STAGE_F_MAX) {
-      const size_t lds = ((size_t)3 * F + SORT2_THREADS + STAGE_CAP) * 4 + (size_t)STAGE_CAP * 2;
-      static bool staged_attr = false;
-      if (!staged_attr) {
-        MZK_HIP(hipFuncSetAttribute((const void*)k_fine_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        staged_attr = true;
-      }
-      hipLaunchKernelGGL(k_fine_scatter, dim3(COARSE_BINS, S), dim3(SORT2_THREADS), lds, s, (const uint2*)tmp, (const u32*)binhist, nwg, F, S,
-                         (const u32*)finehist, offsets, entries, NBtot);
-    } else {
-      hipLaunchKernelGGL(k_fine_scatter_direct, dim3(COARSE_BINS, S), dim3(SORT2_THREADS), 0, s, (const uint2*)tmp, (const u32*)binhist, nwg, F, S,
-                         (const u32*)finehist, offsets, entries, NBtot);
-    }
+    int fb = 0;
+    while ((1 << fb) < F) fb++;
+    // largest point reference: merged nwin * stride, generic phi_offset + n
+    const size_t ref_max = L.merged ? (size_t)sh.nwin * table_stride : L.phi_offset + n;
+    const bool compact = ref_max <= ((size_t)1 << (31 - fb));      // references are < ref_max
+    SortArgs sa{(const u32*)d_scalars, n, L, key_shift, fine_mask, fb, binhist, nwg, (void*)ranks, F, S, finehist, scan2 + sb_c + 2, sb_f, n_fine,
+                offsets, entries, NBtot};
+    MZK_TRY(compact ? sort_records<Rec4>(sa, s) : sort_records<Rec8>(sa, s));
   } else if (L.merged) {
     // LDS histogram path (no global atomics)
     int nwg = (int)((n + 4095) / 4096);

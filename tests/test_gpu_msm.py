@@ -214,3 +214,17 @@ def test_randomised_differential_generic_and_srs(mz):
         h = mz.Srs(p)
         assert h.commit(s) == want, (case, n)
         h.close()
+
+
+def test_wide_sort_records_above_2pow20(mz):
+    """just above 2^20 pairs the two-level sort switches from 4-byte to 8-byte intermediate records (point reference + fine
+    key + sign no longer fit 32 bits): trapdoor identity through the generic MSM and through an SRS handle with tables"""
+    n = (1 << 20) + 4096
+    alpha = 0xabcdef123
+    srs = mz.kzg_setup_g1(alpha, n - 1)
+    s = orc.synth_vector(FR, 2020, n)
+    want = orc.ec_mul(0, (1, 2), orc.poly_eval(FR, s, alpha))
+    assert mz.msm_g1(s, srs) == want
+    h = mz.Srs(srs)
+    assert h.commit(s) == want
+    h.close()
