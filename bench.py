@@ -239,7 +239,7 @@ def main():
     # ------------------------------------------------------------------ timed regions
     def timed(step, K, W):
         # settle: workspace growth / plan building, and the DVFS ramp -- on MI355X the same kernel runs ~25 %
-        # slower during the first few hundred ms after idle (scratch/mulv.hip: 136 -> 174 G mul/s).  Never
+        # slower during the first few hundred ms after idle (tools/microbench/mulv.hip: 136 -> 174 G mul/s).  Never
         # counted; the W warm-up steps follow.
         t_settle = time.perf_counter()
         # The exit decision is COLLECTIVE: a step may contain an all-gather, so every rank must run the same

@@ -14,6 +14,10 @@
  *     identical (ntt.rs:8-23, curve.rs:174-176), then `expect()`s the status.
  *   - blocking, one in-flight call per process (the reference is single-threaded); one process per
  *     GPU.  The *_dev variants take device pointers + a hipStream_t and only enqueue work.
+ *   - all entry points of a context share one grow-only workspace.  Calls on DIFFERENT streams are ordered by the
+ *     library (each entry point waits on the previous one's completion event before touching the workspace and
+ *     records its own), so results are correct on any stream; work on one context never overlaps.  Calls must
+ *     still come from one host thread at a time.
  */
 #ifndef MZK_H
 #define MZK_H
@@ -35,10 +39,20 @@ enum { MZK_OK = 0,
        MZK_E_LENGTH = -5,     /* slice-index / usize-underflow panics (ntt.rs:265, polynomial.rs:162) */
        MZK_E_RANGE = -6,      /* operand not canonical (>= modulus) where the ABI requires it */
        MZK_E_HIP = -7,        /* HIP runtime error */
-       MZK_E_NOGPU = -8       /* no gfx950 device visible: there is NO CPU fallback */ };
+       MZK_E_NOGPU = -8,      /* no gfx950 device visible: there is NO CPU fallback */
+       MZK_E_CALLBACK = -9,   /* a caller-supplied callback reported failure (mzk_fri_commit's challenge) */
+       MZK_E_IO = -10         /* file could not be opened / read / written, or is not a valid dump (mzk_srs_save/load) */ };
 
-/* Select the device for this process, create streams/workspace.  Idempotent. */
+/* Select the device for this process, create streams/workspace.  Idempotent.  (SURVEY 8b sketched mzk_init(n_devices);
+ * one process per GPU is the primary model, so the argument is the ordinal -- mzk_init_devices is the n-device form.) */
 int mzk_init(int device_ordinal);
+/* One process driving several GPUs: context r = (device_ordinals[r], its own stream, workspace and table caches).
+ * Duplicate ordinals are allowed (several contexts on one GPU).  Context 0 is current afterwards; every entry point
+ * of this header works on the CURRENT context (mzk_ctx_select), the *_multi entry points walk all of them. */
+int mzk_init_devices(const int* device_ordinals, int n_devices);
+int mzk_ctx_count(void);
+int mzk_ctx_select(int index);
+int mzk_ctx_device(int index);   /* device ordinal of a context, -1 if it does not exist */
 void mzk_shutdown(void);
 const char* mzk_last_error(void);
 /* ABI version: bump on any signature change. */
@@ -143,7 +157,9 @@ int mzk_merkle_commit_bytes(const uint8_t* leaves, const uint64_t* offsets, size
  * alpha = F::sample(prover_fiat_shamir(32)) into alpha_out, canonical limbs); then split-and-fold, omega and
  * offset squared.  roots: num_rounds x 48 bytes (root_len[r] = 32, or the leaf length once a codeword has one
  * element); codewords_out: the num_rounds codewords concatenated (n + n/2 + ... elements). */
-typedef void (*mzk_fri_challenge_fn)(void* user, int round, int last, const uint8_t* root, size_t root_len, uint64_t* alpha_out);
+/* The callback returns 0 on success; any other value aborts the loop with MZK_E_CALLBACK (a transcript error must
+ * never let the prover fold with a default challenge).  alpha_out is pre-filled with all-ones (non-canonical). */
+typedef int (*mzk_fri_challenge_fn)(void* user, int round, int last, const uint8_t* root, size_t root_len, uint64_t* alpha_out);
 int mzk_fri_commit(int field_id, const uint64_t* codeword, size_t n, const uint64_t* omega, const uint64_t* offset, int num_rounds,
                    mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out);
 
@@ -175,6 +191,25 @@ int mzk_msm_g1_bn254_dev(const void* d_scalars, const void* d_points_xy, size_t 
 int mzk_msm_g1_bn254_partial_dev(const void* d_scalars, const void* d_points_xy, size_t n,
                                  void* d_partial16, void* stream);
 int mzk_g1_fold_partials_dev(const void* d_partials16, int count, void* d_out_xy, void* stream);
+/* ---- the same sharding inside ONE process (contexts of mzk_init_devices; BASELINE configs[3] without Python) ----
+ * Context r owns the contiguous slice mzk_shard_range(n, r, world) of scalars and points, reduces it to one XYZZ
+ * partial on its own GPU; the W 128-byte records are gathered on context 0 (pinned host buffer: no peer access or
+ * collective library needed for 128 bytes per GPU) and folded there.  All W pipelines run concurrently.  Blocking. */
+void mzk_shard_range(size_t n, int rank, int world, size_t* lo, size_t* hi);
+int mzk_msm_g1_bn254_multi(const uint64_t* scalars, const uint64_t* points_xy, size_t n, uint64_t out_xy[8]);
+typedef struct mzk_srs_multi mzk_srs_multi;
+/* PublicKeyKZG.powers_1 sharded over the contexts: from host points, or built on the GPUs (setup_kzg, kzg.rs:27-40:
+ * context r computes powers [lo_r, hi_r) itself; with_tables as in mzk_srs_from_device_ex). */
+int mzk_srs_upload_multi(const uint64_t* powers_xy, size_t n, mzk_srs_multi** out);
+int mzk_kzg_setup_srs_multi(const uint64_t alpha[4], const uint64_t g1_xy[8], size_t max_d, int with_tables, mzk_srs_multi** out);
+void mzk_srs_multi_free(mzk_srs_multi* h);
+int mzk_srs_multi_world(const mzk_srs_multi* h);
+size_t mzk_srs_multi_shard_lo(const mzk_srs_multi* h, int rank);   /* rank = world gives n */
+/* commit_kzg (kzg.rs:57-59) over the sharded SRS: coefficients in host memory, or d_coef_shards[r] = device pointer
+ * on context r's GPU to coefficients [lo_r, min(hi_r, n)), complete before the call. */
+int mzk_kzg_commit_srs_multi(const mzk_srs_multi* h, const uint64_t* coef, size_t n, uint64_t out_xy[8]);
+int mzk_kzg_commit_srs_multi_dev(const mzk_srs_multi* h, const void* const* d_coef_shards, size_t n, uint64_t out_xy[8]);
+
 /* commit against a device-resident SRS with device-resident coefficients; out_partial != 0 writes the
  * 16-limb XYZZ partial (multi-GPU shard) instead of the 8-limb affine point. */
 int mzk_kzg_commit_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, void* d_out, int out_partial,

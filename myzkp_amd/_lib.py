@@ -14,7 +14,7 @@ MODULUS = {
     FIELD_FQ: 21888242871839275222246405745257275088696311157297823662689037894645226208583,
 }
 ERRORS = {0: "MZK_OK", -1: "MZK_E_ARG", -2: "MZK_E_NOT_POW2", -3: "MZK_E_ROOT_ORDER", -4: "MZK_E_ROOT_PRIM",
-          -5: "MZK_E_LENGTH", -6: "MZK_E_RANGE", -7: "MZK_E_HIP", -8: "MZK_E_NOGPU"}
+          -5: "MZK_E_LENGTH", -6: "MZK_E_RANGE", -7: "MZK_E_HIP", -8: "MZK_E_NOGPU", -9: "MZK_E_CALLBACK", -10: "MZK_E_IO"}
 
 
 class MzkError(RuntimeError):
@@ -316,7 +316,7 @@ def merkle_commit_field(fid, elems):
     return bytes(buf[:ln.value])
 
 
-_FRI_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t,
+_FRI_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t,
                            ctypes.POINTER(ctypes.c_uint64))
 
 
@@ -326,11 +326,24 @@ def fri_commit(fid, codeword, omega, offset, num_rounds, challenge):
     c = _arr(fid, codeword)
     n, nl = c.shape[0], LIMBS[fid]
 
+    failure = []
+
     def cb(user, rnd, last, root, root_len, alpha_out):
-        a = challenge(rnd, bool(last), bytes(root[:root_len]))
-        a = int(a or 0)
-        for j in range(nl):
-            alpha_out[j] = (a >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+        # An exception must not escape into C (ctypes would print it and carry on with whatever alpha_out holds):
+        # keep it, make the C loop stop (non-zero status -> MZK_E_CALLBACK), re-raise below.
+        try:
+            a = challenge(rnd, bool(last), bytes(root[:root_len]))
+            if last:
+                return 0
+            if a is None:
+                raise ValueError("challenge(%d) returned no alpha" % rnd)
+            a = int(a)
+            for j in range(nl):
+                alpha_out[j] = (a >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+            return 0
+        except BaseException as ex:      # noqa: BLE001 -- re-raised by fri_commit
+            failure.append(ex)
+            return 1
 
     total = sum(n >> r for r in range(num_rounds))
     roots = (ctypes.c_uint8 * (48 * max(num_rounds, 1)))()
@@ -338,7 +351,10 @@ def fri_commit(fid, codeword, omega, offset, num_rounds, challenge):
     allcw = np.zeros((max(total, 1), nl), dtype=np.uint64)
     w, o = _one(fid, omega), _one(fid, offset)
     fn = _FRI_CB(cb)
-    _check(lib().mzk_fri_commit(fid, _p(c), ctypes.c_size_t(n), _p(w), _p(o), int(num_rounds), fn, None, roots, lens, _p(allcw)))
+    rc = lib().mzk_fri_commit(fid, _p(c), ctypes.c_size_t(n), _p(w), _p(o), int(num_rounds), fn, None, roots, lens, _p(allcw))
+    if failure:
+        raise failure[0]
+    _check(rc)
     cws, rts, at = [], [], 0
     raw = bytes(roots)
     for r in range(num_rounds):

@@ -19,14 +19,28 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   return MZK_E_HIP;
 }
 
-static Context g_ctx;
-Context& ctx() { return g_ctx; }
-
-struct WsBuf { void* p = nullptr; size_t cap = 0; };
-static WsBuf g_ws[WS_COUNT];
+static Context g_ctxs[MZK_MAX_CTX];
+static int g_nctx = 0, g_cur = 0;
+static uint64_t g_gen_counter = 1;
+Context& ctx() { return g_ctxs[g_cur]; }
+int ctx_count() { return g_nctx; }
+int ctx_select(int index) {
+  if (index < 0 || index >= g_nctx || !g_ctxs[index].ready) { set_error("context %d does not exist (%d initialised)", index, g_nctx); return MZK_E_ARG; }
+  MZK_HIP(hipSetDevice(g_ctxs[index].device));
+  g_cur = index;
+  return MZK_OK;
+}
+CtxScope::CtxScope(int index) : prev_ctx(g_cur), prev_dev(-1), ok(false) {
+  if (hipGetDevice(&prev_dev) != hipSuccess) prev_dev = -1;
+  ok = ctx_select(index) == MZK_OK;
+}
+CtxScope::~CtxScope() {
+  g_cur = prev_ctx;
+  if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
+}
 
 int ws_get(WsSlot slot, size_t bytes, void** out) {
-  WsBuf& b = g_ws[slot];
+  WsBuf& b = ctx().ws[slot];
   if (bytes > b.cap) {
     if (b.p) {
       MZK_HIP(hipDeviceSynchronize());
@@ -40,14 +54,30 @@ int ws_get(WsSlot slot, size_t bytes, void** out) {
   *out = b.p;
   return MZK_OK;
 }
-static uint64_t g_ws_generation = 1;
-uint64_t ws_generation() { return g_ws_generation; }
+uint64_t ws_generation() { return ctx().ws_gen; }
 void ws_release_all() {
-  g_ws_generation++;
-  for (auto& b : g_ws) {
+  Context& c = ctx();
+  c.ws_gen = ++g_gen_counter;
+  for (auto& b : c.ws) {
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr; b.cap = 0;
   }
+}
+// The workspace slots are shared by every entry point of a context.  *_dev calls only enqueue work, so a call on
+// stream B could overwrite slots that kernels of an earlier call on stream A are still reading: the guard orders B
+// behind the last user's completion event (no host synchronisation), and records its own at scope exit.
+WsGuard::WsGuard(hipStream_t s_) : s(s_) {
+  Context& c = ctx();
+  if (!c.ready) return;
+  if (c.ws_used && c.ws_last != s && c.ws_event) (void)hipStreamWaitEvent(s, c.ws_event, 0);
+}
+WsGuard::~WsGuard() {
+  Context& c = ctx();
+  if (!c.ready) return;
+  if (!c.ws_event && hipEventCreateWithFlags(&c.ws_event, hipEventDisableTiming) != hipSuccess) { c.ws_event = nullptr; return; }
+  (void)hipEventRecord(c.ws_event, s);
+  c.ws_last = s;
+  c.ws_used = true;
 }
 
 // ---- profiling --------------------------------------------------------------------------------------
@@ -89,8 +119,8 @@ static void prof_drain() {
 }
 
 int ensure_init() {
-  if (g_ctx.ready) return MZK_OK;
-  return mzk_init(g_ctx.device >= 0 ? g_ctx.device : 0);
+  if (g_nctx > 0 && ctx().ready) return MZK_OK;
+  return mzk_init(0);
 }
 
 // ---- host parameter math --------------------------------------------------------------------------
@@ -231,11 +261,10 @@ using namespace mzk;
 
 extern "C" {
 
-int mzk_abi_version(void) { return 1; }
+int mzk_abi_version(void) { return 2; }
 const char* mzk_last_error(void) { return g_err; }
 
-int mzk_init(int device_ordinal) {
-  if (g_ctx.ready && g_ctx.device == device_ordinal) return MZK_OK;
+static int check_device(int device_ordinal, int* num_cu) {
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0) {
@@ -244,29 +273,58 @@ int mzk_init(int device_ordinal) {
     return MZK_E_NOGPU;
   }
   if (device_ordinal < 0 || device_ordinal >= count) { set_error("mzk_init: device %d out of range (%d visible)", device_ordinal, count); return MZK_E_ARG; }
-  MZK_HIP(hipSetDevice(device_ordinal));
   hipDeviceProp_t prop;
   MZK_HIP(hipGetDeviceProperties(&prop, device_ordinal));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
     set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device_ordinal, prop.gcnArchName);
     return MZK_E_NOGPU;
   }
-  if (g_ctx.ready) mzk_shutdown();
-  g_ctx.device = device_ordinal;
-  g_ctx.num_cu = prop.multiProcessorCount;
-  MZK_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
-  g_ctx.ready = true;
+  *num_cu = prop.multiProcessorCount;
   return MZK_OK;
 }
 
+int mzk_init_devices(const int* device_ordinals, int n_devices) {
+  if (!device_ordinals || n_devices < 1 || n_devices > MZK_MAX_CTX) { set_error("mzk_init_devices: need 1..%d device ordinals", MZK_MAX_CTX); return MZK_E_ARG; }
+  bool same = g_nctx == n_devices;
+  for (int i = 0; same && i < n_devices; i++) same = g_ctxs[i].ready && g_ctxs[i].device == device_ordinals[i];
+  if (same) return ctx_select(0);
+  int ncu[MZK_MAX_CTX];
+  for (int i = 0; i < n_devices; i++) MZK_TRY(check_device(device_ordinals[i], &ncu[i]));
+  if (g_nctx) mzk_shutdown();
+  for (int i = 0; i < n_devices; i++) {
+    Context& c = g_ctxs[i];
+    c = Context();
+    c.index = i;
+    c.device = device_ordinals[i];
+    c.num_cu = ncu[i];
+    c.ws_gen = ++g_gen_counter;
+    MZK_HIP(hipSetDevice(c.device));
+    MZK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    c.ready = true;
+    g_nctx = i + 1;
+  }
+  return ctx_select(0);
+}
+int mzk_init(int device_ordinal) { return mzk_init_devices(&device_ordinal, 1); }
+int mzk_ctx_count(void) { return g_nctx; }
+int mzk_ctx_select(int index) { return ctx_select(index); }
+int mzk_ctx_device(int index) { return (index >= 0 && index < g_nctx) ? g_ctxs[index].device : -1; }
+
 void mzk_shutdown(void) {
-  if (!g_ctx.ready) return;
-  (void)hipDeviceSynchronize();
-  ntt_release_plans();
-  ws_release_all();
-  if (g_ctx.stream) (void)hipStreamDestroy(g_ctx.stream);
-  g_ctx.stream = nullptr;
-  g_ctx.ready = false;
+  for (int i = 0; i < g_nctx; i++) {
+    Context& c = g_ctxs[i];
+    if (!c.ready) continue;
+    g_cur = i;
+    (void)hipSetDevice(c.device);
+    (void)hipDeviceSynchronize();
+    ntt_release_plans();
+    ws_release_all();
+    if (c.ws_event) (void)hipEventDestroy(c.ws_event);
+    if (c.stream) (void)hipStreamDestroy(c.stream);
+    c = Context();
+  }
+  g_nctx = 0;
+  g_cur = 0;
 }
 
 int mzk_prof_enable(int on) { g_prof_on = on != 0; return MZK_OK; }
@@ -338,7 +396,8 @@ int mzk_ntt(int field_id, const uint64_t* root, const uint64_t* in, uint64_t* ou
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("ntt: bad field id %d", field_id); return MZK_E_ARG; }
   if (n == 0) return MZK_OK;
   if (!in || !out) { set_error("ntt: null pointer"); return MZK_E_ARG; }
-  hipStream_t s = g_ctx.stream;
+  hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
   const size_t bytes = n * field_bytes(field_id);
   void *d_in, *d_out;
   MZK_TRY(stage_in(WS_NTT_IO_A, in, bytes, &d_in, s));
@@ -351,6 +410,7 @@ int mzk_ntt(int field_id, const uint64_t* root, const uint64_t* in, uint64_t* ou
 
 int mzk_ntt_dev(int field_id, const uint64_t* root_host, const void* d_in, void* d_out, size_t n, int inverse, void* stream) {
   MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
   return ntt_dev_impl(field_id, root_host, d_in, d_out, n, inverse, nullptr, (hipStream_t)stream);
 }
 
@@ -361,7 +421,8 @@ int mzk_coset_lde(int field_id, const uint64_t* coef, size_t n_coef, const uint6
   if (n_coef > order) { set_error("attempt to subtract with overflow (order - polynomial.coef.len())"); return MZK_E_LENGTH; }
   if (order == 0) return MZK_OK;
   if (!out || (!coef && n_coef)) { set_error("coset_lde: null pointer"); return MZK_E_ARG; }
-  hipStream_t s = g_ctx.stream;
+  hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
   const size_t esz = field_bytes(field_id);
   void *d_coef, *d_out;
   MZK_TRY(stage_in(WS_MISC_A, coef, n_coef * esz, &d_coef, s));
@@ -375,6 +436,7 @@ int mzk_coset_lde(int field_id, const uint64_t* coef, size_t n_coef, const uint6
 int mzk_coset_lde_dev(int field_id, const void* d_coef, size_t n_coef, const uint64_t* offset_host,
                       const uint64_t* generator_host, void* d_out, size_t order, void* stream) {
   MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
   return coset_lde_dev_impl(field_id, d_coef, n_coef, offset_host, generator_host, d_out, order, (hipStream_t)stream);
 }
 
@@ -418,7 +480,8 @@ int mzk_fft_multiply(int field_id, const uint64_t* a, size_t la, const uint64_t*
   size_t n = 1;
   while (n < m) n <<= 1;
   const int nl = field_limbs64(field_id);
-  hipStream_t s = g_ctx.stream;
+  hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
   const size_t esz = field_bytes(field_id);
   if (m == 0) { *out_len = 0; return MZK_OK; }
   if (!out) { set_error("fft_multiply: null pointer"); return MZK_E_ARG; }
@@ -462,7 +525,8 @@ int mzk_fast_multiply(int field_id, const uint64_t* a, size_t la, const uint64_t
   const size_t da = trimmed_len(a, la, nl), db = trimmed_len(b, lb, nl);
   if (da == 0 || db == 0) { *out_len = 0; return MZK_OK; }  // ntt.rs:78-80
   const size_t degree = (da - 1) + (db - 1);
-  hipStream_t s = g_ctx.stream;
+  hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
   const size_t esz = field_bytes(field_id);
   if (!out) { set_error("fast_multiply: null pointer"); return MZK_E_ARG; }
   uint64_t r[4] = {0, 0, 0, 0};
@@ -550,7 +614,8 @@ int mzk_fast_coset_divide(int field_id, const uint64_t* lhs, size_t ll, const ui
     if (tl & (tl - 1)) { set_error("cannot compute ntt of non-power-of-two sequence"); return MZK_E_NOT_POW2; }
     set_error("primitive root must be nth root of unity, where n is len(values)"); return MZK_E_ROOT_ORDER;
   }
-  hipStream_t s = g_ctx.stream;
+  hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
   const size_t esz = field_bytes(field_id);
   void *d_l, *d_r, *d_o;
   MZK_TRY(stage_in(WS_MISC_C, lhs, tl * esz, &d_l, s));
@@ -564,20 +629,18 @@ int mzk_fast_coset_divide(int field_id, const uint64_t* lhs, size_t ll, const ui
 }
 
 // ---- MSM / KZG ---------------------------------------------------------------------------------------------
-struct mzk_srs {
-  void* d_points_mont;   // msm_table_windows(window_bits) x n window tables when has_tables, else n prepared points + their n phi images
-  size_t n;
-  bool has_tables;
-  int window_bits;
-  int kind() const { return has_tables ? MSM_PTS_TABLES_C(window_bits) : MSM_PTS_MONT; }
-};
 // Below this size the per-call bucket overhead of 16-bit windows dominates: keep plain prepared points.
 static const size_t SRS_TABLE_MIN_N = (size_t)1 << 14;
+static int srs_check_ctx(const mzk_srs* srs) {
+  if (srs->ctx_index != ctx().index) { set_error("SRS handle lives on context %d, the current context is %d (mzk_ctx_select)", srs->ctx_index, ctx().index); return MZK_E_ARG; }
+  return MZK_OK;
+}
 
 int mzk_msm_g1_bn254(const uint64_t* scalars, const uint64_t* points_xy, size_t n, uint64_t out_xy[8]) {
   MZK_TRY(ensure_init());
   if (!out_xy || ((!scalars || !points_xy) && n)) { set_error("msm: null pointer"); return MZK_E_ARG; }
-  hipStream_t s = g_ctx.stream;
+  hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
   void *d_s, *d_p, *d_o;
   MZK_TRY(stage_in(WS_MSM_SCALARS, scalars, n * 32, &d_s, s));
   MZK_TRY(stage_in(WS_MISC_A, points_xy, n * 64, &d_p, s));
@@ -589,22 +652,26 @@ int mzk_msm_g1_bn254(const uint64_t* scalars, const uint64_t* points_xy, size_t 
 }
 int mzk_msm_g1_bn254_dev(const void* d_scalars, const void* d_points_xy, size_t n, void* d_out_xy, void* stream) {
   MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
   return msm_dev_impl(d_scalars, d_points_xy, n, MSM_PTS_PLAIN, 0, d_out_xy, false, (hipStream_t)stream);
 }
 int mzk_msm_g1_bn254_partial_dev(const void* d_scalars, const void* d_points_xy, size_t n, void* d_partial16, void* stream) {
   MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
   return msm_dev_impl(d_scalars, d_points_xy, n, MSM_PTS_PLAIN, 0, d_partial16, true, (hipStream_t)stream);
 }
 int mzk_g1_fold_partials_dev(const void* d_partials16, int count, void* d_out_xy, void* stream) {
   MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
   return msm_fold_partials_impl(d_partials16, count, d_out_xy, (hipStream_t)stream);
 }
 
 int mzk_srs_upload(const uint64_t* powers_xy, size_t n, mzk_srs** out) {
   MZK_TRY(ensure_init());
   if (!out || (!powers_xy && n)) { set_error("srs_upload: null pointer"); return MZK_E_ARG; }
-  hipStream_t s = g_ctx.stream;
-  mzk_srs* h = new mzk_srs{nullptr, n, n >= SRS_TABLE_MIN_N, msm_srs_window_bits(n)};
+  hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
+  mzk_srs* h = new mzk_srs{nullptr, n, n >= SRS_TABLE_MIN_N, msm_srs_window_bits(n), ctx().index};
   if (n) {
     void *d_plain, *d_mont;
     const size_t copies = h->has_tables ? (size_t)msm_table_windows(h->window_bits) : 2;   // no tables: P_i, then phi(P_i) (GLV layout)
@@ -631,8 +698,10 @@ void mzk_srs_free(mzk_srs* srs) {
 int mzk_kzg_commit_srs(const mzk_srs* srs, const uint64_t* coef, size_t n, uint64_t out_xy[8]) {
   MZK_TRY(ensure_init());
   if (!srs || !out_xy || (!coef && n)) { set_error("commit_srs: null pointer"); return MZK_E_ARG; }
+  MZK_TRY(srs_check_ctx(srs));
   if (n > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }  // powers[i], polynomial.rs:162
-  hipStream_t s = g_ctx.stream;
+  hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
   void *d_s, *d_o;
   MZK_TRY(stage_in(WS_MSM_SCALARS, coef, n * 32, &d_s, s));
   MZK_TRY(ws_get(WS_MISC_B, 256, &d_o));
@@ -644,7 +713,9 @@ int mzk_kzg_commit_srs(const mzk_srs* srs, const uint64_t* coef, size_t n, uint6
 
 int mzk_kzg_commit_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, void* d_out, int out_partial, void* stream) {
   MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
   if (!srs || !d_out || (!d_coef && n)) { set_error("commit_srs_dev: null pointer"); return MZK_E_ARG; }
+  MZK_TRY(srs_check_ctx(srs));
   if (n > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }
   return msm_dev_impl(d_coef, srs->d_points_mont, n, srs->kind(), srs->n, d_out, out_partial != 0,
                       (hipStream_t)stream);
@@ -652,21 +723,26 @@ int mzk_kzg_commit_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, voi
 
 int mzk_kzg_open_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, const uint64_t u_host[4], void* d_y, void* d_w_xy, void* stream) {
   MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
   if (!srs) { set_error("open_srs_dev: null srs"); return MZK_E_ARG; }
+  MZK_TRY(srs_check_ctx(srs));
   if (n > 1 && n - 1 > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }
   return kzg_open_dev(d_coef, n, u_host, srs->d_points_mont, srs->kind(), srs->n, d_y, d_w_xy, nullptr, (hipStream_t)stream);
 }
 int mzk_kzg_setup_g1_dev(const uint64_t alpha_host[4], const uint64_t g1_xy_host[8], size_t max_d, void* d_powers_xy, void* stream) {
   MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
   return kzg_setup_g1_dev(alpha_host, g1_xy_host, 0, max_d + 1, d_powers_xy, (hipStream_t)stream);
 }
 int mzk_kzg_setup_g1_range_dev(const uint64_t alpha_host[4], const uint64_t g1_xy_host[8], size_t first, size_t count, void* d_powers_xy,
                                void* stream) {
   MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
   return kzg_setup_g1_dev(alpha_host, g1_xy_host, first, count, d_powers_xy, (hipStream_t)stream);
 }
 int mzk_kzg_open_quotient_dev(const void* d_coef, size_t n, const uint64_t u_host[4], void* d_y, void* d_q, void* stream) {
   MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
   if (!d_q && n > 1) { set_error("open_quotient: null pointer"); return MZK_E_ARG; }
   int dummy;
   return kzg_open_dev(d_coef, n, u_host, nullptr, MSM_PTS_PLAIN, 0, d_y, nullptr, d_q ? d_q : (void*)&dummy, (hipStream_t)stream);
@@ -676,10 +752,11 @@ int mzk_srs_from_device(const void* d_powers_xy, size_t n, mzk_srs** out, void* 
 }
 int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, mzk_srs** out, void* stream) {
   MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
   if (!out || (!d_powers_xy && n)) { set_error("srs_from_device: null pointer"); return MZK_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
   if (with_tables < 0 || (with_tables > 1 && (with_tables < 12 || with_tables > 22))) { set_error("srs_from_device: with_tables must be 0, 1 or a window width 12..22"); return MZK_E_ARG; }
-  mzk_srs* h = new mzk_srs{nullptr, n, with_tables > 1 || (with_tables && n >= SRS_TABLE_MIN_N), with_tables > 1 ? with_tables : msm_srs_window_bits(n)};
+  mzk_srs* h = new mzk_srs{nullptr, n, with_tables > 1 || (with_tables && n >= SRS_TABLE_MIN_N), with_tables > 1 ? with_tables : msm_srs_window_bits(n), ctx().index};
   if (n) {
     void* d_mont;
     const size_t copies = h->has_tables ? (size_t)msm_table_windows(h->window_bits) : 2;   // no tables: P_i, then phi(P_i) (GLV layout)
@@ -702,6 +779,7 @@ int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, m
 int mzk_fri_fold_dev(int field_id, const void* d_codeword, size_t n, const uint64_t* alpha_host, const uint64_t* offset_host,
                      const uint64_t* omega_host, void* d_out, void* stream) {
   MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
   return fri_fold_dev_impl(field_id, d_codeword, n, alpha_host, offset_host, omega_host, d_out, (hipStream_t)stream);
 }
 int mzk_fri_fold(int field_id, const uint64_t* codeword, size_t n, const uint64_t* alpha, const uint64_t* offset,
@@ -710,7 +788,8 @@ int mzk_fri_fold(int field_id, const uint64_t* codeword, size_t n, const uint64_
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fri_fold: bad field id %d", field_id); return MZK_E_ARG; }
   if (n / 2 == 0) return MZK_OK;
   if (!codeword || !out) { set_error("fri_fold: null pointer"); return MZK_E_ARG; }
-  hipStream_t s = g_ctx.stream;
+  hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
   const size_t esz = field_bytes(field_id);
   void *d_in, *d_out;
   MZK_TRY(stage_in(WS_NTT_IO_A, codeword, n * esz, &d_in, s));
@@ -725,7 +804,8 @@ int mzk_kzg_batch_open(const uint64_t* coef, size_t n, const uint64_t* us, size_
                        uint64_t w_xy[8]) {
   MZK_TRY(ensure_init());
   if (!w_xy || (!coef && n) || ((!us || !ys) && k) || (!powers_xy && n > k)) { set_error("batch_open: null pointer"); return MZK_E_ARG; }
-  hipStream_t s = g_ctx.stream;
+  hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
   const size_t nq = n > k ? n - k : 0;
   void *d_c, *d_p, *d_o;
   MZK_TRY(stage_in(WS_MSM_SCALARS, coef, n * 32, &d_c, s));
@@ -755,7 +835,8 @@ int mzk_kzg_prove_degree_bound(const uint64_t* coef, size_t n, const uint64_t* p
 int mzk_kzg_setup_g1(const uint64_t alpha[4], const uint64_t g1_xy[8], size_t max_d, uint64_t* powers_xy) {
   MZK_TRY(ensure_init());
   if (!alpha || !g1_xy || !powers_xy) { set_error("kzg_setup: null pointer"); return MZK_E_ARG; }
-  hipStream_t s = g_ctx.stream;
+  hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
   const size_t count = max_d + 1;  // `for _ in 0..1 + max_d`, kzg.rs:32
   void* d_p;
   MZK_TRY(ws_get(WS_MSM_POINTS, count * 64, &d_p));
@@ -768,7 +849,8 @@ int mzk_kzg_setup_g1(const uint64_t alpha[4], const uint64_t g1_xy[8], size_t ma
 int mzk_kzg_open(const uint64_t* coef, size_t n, const uint64_t u[4], const uint64_t* powers_xy, uint64_t y[4], uint64_t w_xy[8]) {
   MZK_TRY(ensure_init());
   if (!u || !y || !w_xy || (!coef && n) || (!powers_xy && n > 1)) { set_error("kzg_open: null pointer"); return MZK_E_ARG; }
-  hipStream_t s = g_ctx.stream;
+  hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
   void *d_c, *d_p, *d_o;
   MZK_TRY(stage_in(WS_MSM_SCALARS, coef, n * 32, &d_c, s));
   MZK_TRY(stage_in(WS_NTT_IO_A, powers_xy, (n > 1 ? n - 1 : 0) * 64, &d_p, s));
@@ -784,11 +866,13 @@ int mzk_kzg_open(const uint64_t* coef, size_t n, const uint64_t u[4], const uint
 
 int mzk_synth_field_dev(int field_id, uint64_t seed, size_t n, void* d_out, void* stream) {
   MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
   if (!d_out && n) { set_error("synth: null pointer"); return MZK_E_ARG; }
   return synth_field_impl(field_id, seed, n, d_out, (hipStream_t)stream);
 }
 int mzk_synth_g1_points_dev(uint64_t seed, size_t n, void* d_out_xy, void* stream) {
   MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
   if (!d_out_xy && n) { set_error("synth: null pointer"); return MZK_E_ARG; }
   return synth_g1_impl(seed, n, d_out_xy, (hipStream_t)stream);
 }

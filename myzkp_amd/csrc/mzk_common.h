@@ -27,23 +27,54 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
     if (_rc != MZK_OK) return _rc; \
   } while (0)
 
-// ---- context ----------------------------------------------------------------------------------------
+// ---- contexts -----------------------------------------------------------------------------------------
+// A context = (device ordinal, library-owned stream, grow-only workspace, cached tables).  mzk_init creates one;
+// mzk_init_devices creates one per listed ordinal (duplicates allowed: several contexts may share one GPU, which is
+// how the multi-GPU path is exercised on a one-GPU box).  Every entry point works on the CURRENT context
+// (mzk_ctx_select; context 0 after init); the *_multi entry points walk all of them.
+constexpr int MZK_MAX_CTX = 16;
+struct WsBuf { void* p = nullptr; size_t cap = 0; };
+enum WsSlot { WS_NTT_TMP = 0, WS_NTT_IO_A, WS_NTT_IO_B, WS_MSM_POINTS, WS_MSM_SCALARS, WS_MSM_COUNTS, WS_MSM_OFFSETS,
+              WS_MSM_CURSOR, WS_MSM_ENTRIES, WS_MSM_BUCKETS, WS_MSM_RED_A, WS_MSM_RED_B, WS_MSM_SCAN, WS_MSM_OUT, WS_MSM_SLOTS, WS_MSM_WGHIST, WS_BATCHINV, WS_XYZZ_TMP, WS_MERKLE_NODES, WS_FB_TABLE16, WS_FB_TABLE8, WS_NTT_PRE, WS_NTT_PRE_M128,
+              WS_MISC_A, WS_MISC_B, WS_MISC_C, WS_MISC_D, WS_MISC_E, WS_MISC_F, WS_COUNT };
+enum AttrFlag { ATTR_FINE_SCATTER4 = 0, ATTR_FINE_SCATTER8, ATTR_DIGITS_LDS, ATTR_SMALL_MSM, ATTR_COUNT };
 struct Context {
   bool ready = false;
+  int index = 0;                 // position in the context table (keys the per-context caches of the other translation units)
   int device = -1;
   int num_cu = 256;
   hipStream_t stream = nullptr;  // library-owned stream for the host-buffer entry points
+  WsBuf ws[WS_COUNT];
+  uint64_t ws_gen = 1;           // bumps whenever every workspace buffer has been released (cached device tables die with it)
+  // Stream-order guard of the shared workspace: the last entry point recorded ws_event on ws_last; an entry point on
+  // another stream waits for it before touching the slots (WsGuard).
+  hipEvent_t ws_event = nullptr;
+  hipStream_t ws_last = nullptr;
+  bool ws_used = false;
+  bool attr_done[ATTR_COUNT] = {};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applied on this context's device
 };
 Context& ctx();
+int ctx_count();
+int ctx_select(int index);       // hipSetDevice + make it current
 int ensure_init();
+// Makes context `index` current for a scope and restores the previous context AND the caller's HIP device on exit
+// (torch keeps its own idea of the current device).
+struct CtxScope {
+  int prev_ctx, prev_dev; bool ok;
+  explicit CtxScope(int index);
+  ~CtxScope();
+};
 
-// Grow-only device scratch buffers, keyed by slot, so steady-state calls never hipMalloc.
-enum WsSlot { WS_NTT_TMP = 0, WS_NTT_IO_A, WS_NTT_IO_B, WS_MSM_POINTS, WS_MSM_SCALARS, WS_MSM_COUNTS, WS_MSM_OFFSETS,
-              WS_MSM_CURSOR, WS_MSM_ENTRIES, WS_MSM_BUCKETS, WS_MSM_RED_A, WS_MSM_RED_B, WS_MSM_SCAN, WS_MSM_OUT, WS_MSM_SLOTS, WS_MSM_WGHIST, WS_BATCHINV, WS_XYZZ_TMP, WS_MERKLE_NODES, WS_FB_TABLE16, WS_FB_TABLE8, WS_NTT_PRE, WS_NTT_PRE_M128,
-              WS_MISC_A, WS_MISC_B, WS_MISC_C, WS_MISC_D, WS_COUNT };
+// Grow-only device scratch buffers of the current context, keyed by slot, so steady-state calls never hipMalloc.
 int ws_get(WsSlot slot, size_t bytes, void** out);
 void ws_release_all();
-uint64_t ws_generation();   // bumps whenever every workspace buffer has been released (cached device tables die with it)
+uint64_t ws_generation();
+// Put one at the top of every entry point that enqueues work using workspace slots on stream s.
+struct WsGuard {
+  hipStream_t s;
+  explicit WsGuard(hipStream_t s_);
+  ~WsGuard();
+};
 
 // ---- per-phase timing (no-ops unless mzk_prof_enable(1)) ---------------------------------------------
 void prof_begin(hipStream_t s, int phase);
@@ -88,7 +119,7 @@ int kzg_batch_open_dev(const void* d_coef, size_t n, const uint64_t* us_host, si
 enum { MSM_PTS_PLAIN = 0, MSM_PTS_MONT = 1, MSM_PTS_TABLES = 2 };
 // Fixed-base window tables: c-bit signed windows, 254 / c + 1 of them.  point_kind carries c in bits 8..15
 // (MSM_PTS_TABLES alone = 16).  The default is 16 bits at every size: wider windows (fewer additions per pair, more
-// buckets) were measured and lose -- 2^24 pairs: c = 16 25.7 ms, 18 28.5, 20 28.2, 22 32.8 (scratch/window_sweep.py);
+// buckets) were measured and lose -- 2^24 pairs: c = 16 25.7 ms, 18 28.5, 20 28.2, 22 32.8 (tools/timing/window_sweep.py);
 // the sort grows with the bucket count and the accumulate kernel gains nothing (shorter bucket runs, more flushes).
 // Other widths stay selectable through mzk_srs_from_device_ex for tuning and tests.
 static inline int msm_table_windows(int c) { return 254 / c + 1; }
@@ -108,3 +139,13 @@ int kzg_open_dev(const void* d_coef, size_t n, const uint64_t* u_host, const voi
                  void* d_y, void* d_w_xy, void* d_q_out, hipStream_t s);
 
 }  // namespace mzk
+
+// Device-resident PublicKeyKZG.powers_1 (kzg.rs:8-11)
+struct mzk_srs {
+  void* d_points_mont;   // msm_table_windows(window_bits) x n window tables when has_tables, else n prepared points + their n phi images
+  size_t n;
+  bool has_tables;
+  int window_bits;
+  int ctx_index;         // the context (device) that owns d_points_mont
+  int kind() const { return has_tables ? (mzk::MSM_PTS_TABLES | (window_bits << 8)) : (int)mzk::MSM_PTS_MONT; }
+};

@@ -20,7 +20,7 @@ template <int K> __device__ __forceinline__ u32 quad_bcast_u32(u32 v) {
   u32 r = (u32)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55, 0xF, 0xF, true);   // quad_perm [K,K,K,K]
   // Keep it a plain v_mov_b32_dpp: when the DPP-combine pass folded the broadcast into a consuming v_sub_u32
   // (the lazy subtraction a + k p - b, b broadcast) the result was wrong on gfx950 with ROCm 7.2
-  // (scratch/quad_test3.hip: Y3 differed per lane).  The empty asm makes the value opaque to that pass.
+  // (tools/microbench/dpp_combine_miscompile_repro.hip: Y3 differed per lane).  The empty asm makes the value opaque to that pass.
   asm volatile("" : "+v"(r));
   return r;
 }

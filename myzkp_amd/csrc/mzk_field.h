@@ -9,7 +9,7 @@
 // radix R = 2^(29 L).  Why 29 bits: on gfx950 v_mad_u64_u32 (32x32+64 -> 64) issues at half rate and
 // takes its 64-bit addend for free, so a product-scanning column sum  col += a_i * b_j  costs exactly
 // one instruction and no carry handling as long as a column never exceeds 64 bits; 18 terms of
-// 29x29 bits do not.  Measured on MI355X (profiles/r01_ubench_instr_rates.txt, scratch/mm29.hip):
+// 29x29 bits do not.  Measured on MI355X (profiles/r01_ubench_instr_rates.txt, tools/microbench/mm29.hip):
 // 154 G Montgomery mul/s in this form vs 93 G/s for saturated 8x32 CIOS (carry chains: 300 v_mov +
 // 138 v_lshl_add_u64 per product).
 //

@@ -91,6 +91,7 @@ extern "C" {
 
 int mzk_msm_g2_bn254_dev(const void* d_scalars, const void* d_points_xy, size_t n, void* d_out_xy, void* stream) {
   MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
   return g2_msm_dev_impl(d_scalars, d_points_xy, n, d_out_xy, (hipStream_t)stream);
 }
 int mzk_msm_g2_bn254(const uint64_t* scalars, const uint64_t* points_xy, size_t n, uint64_t out_xy[16]) {
@@ -100,6 +101,7 @@ int mzk_msm_g2_bn254(const uint64_t* scalars, const uint64_t* points_xy, size_t 
   for (size_t i = 0; i < 4 * n; i++)
     if (!h_is_canonical(fq, points_xy + 4 * i)) { set_error("msm_g2: point coordinate %zu not canonical", i); return MZK_E_RANGE; }
   hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
   void *d_s, *d_p, *d_o;
   MZK_TRY(ws_get(WS_MSM_SCALARS, n ? n * 32 : 16, &d_s));
   MZK_TRY(ws_get(WS_MSM_POINTS, n ? n * 128 : 16, &d_p));
@@ -121,6 +123,7 @@ int mzk_kzg_setup_g2(const uint64_t alpha[4], const uint64_t g2_xy[16], size_t m
   for (int i = 0; i < 4; i++) if (!h_is_canonical(fq, g2_xy + 4 * i)) { set_error("kzg_setup_g2: generator not canonical"); return MZK_E_RANGE; }
   const size_t count = max_d + 1;                       // `for _ in 0..1 + max_d` (kzg.rs:48)
   hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
   void *d_g, *d_o;
   MZK_TRY(ws_get(WS_MSM_OUT, 4096, &d_g));
   MZK_TRY(ws_get(WS_MSM_POINTS, count * 128, &d_o));

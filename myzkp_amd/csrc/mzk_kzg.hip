@@ -226,7 +226,8 @@ int kzg_setup_g1_dev(const uint64_t* alpha_host, const uint64_t* g1_host, size_t
   // The fixed-base tables depend only on g1 (in practice always BN128::generator_g1()) and their construction is a
   // latency chain (248 serial doublings for the window bases + two inversions: ~1.4 ms, more than a whole 2^16-power
   // setup), so they are kept across calls, keyed by g1 and by the workspace generation.
-  static struct { uint64_t g[8]; uint64_t gen; bool have8, have16; hipEvent_t ready; } cache = {{0}, 0, false, false, nullptr};
+  static struct { uint64_t g[8]; uint64_t gen; bool have8, have16; hipEvent_t ready; } cache_all[MZK_MAX_CTX] = {};
+  auto& cache = cache_all[ctx().index];
   if (cache.gen != ws_generation() || memcmp(cache.g, g1_host, sizeof cache.g) != 0) {
     cache.gen = ws_generation(); cache.have8 = cache.have16 = false;
     memcpy(cache.g, g1_host, sizeof cache.g);

@@ -316,6 +316,7 @@ extern "C" {
 
 int mzk_merkle_build_field_dev(int field_id, const void* d_elems, size_t n, mzk_merkle** out, void* stream) {
   MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("merkle: bad field id %d", field_id); return MZK_E_ARG; }
   return merkle_build(0, field_id, d_elems, true, n * field_bytes(field_id), nullptr, n, out, (hipStream_t)stream);
 }
@@ -327,6 +328,7 @@ int mzk_merkle_build_field(int field_id, const uint64_t* elems, size_t n, mzk_me
     for (size_t i = 0; i < n; i++)
       if (!h_is_canonical(hf, elems + (size_t)hf->nl * i)) { set_error("merkle: element %zu not canonical", i); return MZK_E_RANGE; }
   }
+  WsGuard wsg(ctx().stream);
   MZK_TRY(merkle_build(0, field_id, elems, false, n * field_bytes(field_id), nullptr, n, out, ctx().stream));
   MZK_HIP(hipStreamSynchronize(ctx().stream));
   return MZK_OK;
@@ -342,6 +344,7 @@ int mzk_merkle_build_bytes(const uint8_t* leaves, const uint64_t* offsets, size_
   // offsets are rebased to the copied range
   std::vector<uint64_t> off(n + 1);
   for (size_t i = 0; i <= n; i++) off[i] = offsets[i] - offsets[0];
+  WsGuard wsg(ctx().stream);
   return merkle_build(1, -1, leaves + offsets[0], false, total, off.data(), n, out, ctx().stream);
 }
 
@@ -423,6 +426,7 @@ void mzk_merkle_free(mzk_merkle* t) {
 // retained, the node levels live in workspace.  root: 32 bytes (n >= 2) or the leaf bytes (n == 1; cap >= 41).
 int mzk_merkle_commit_field_dev(int field_id, const void* d_elems, size_t n, uint8_t* root, size_t cap, size_t* root_len, void* stream) {
   MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("merkle: bad field id %d", field_id); return MZK_E_ARG; }
   if (n == 0) { set_error("merkle: empty leaf set (Merkle::commit recurses forever on it, merkle.rs:20-22)"); return MZK_E_LENGTH; }
   if (!is_pow2(n)) { set_error("merkle: leaf count must be a power of two"); return MZK_E_NOT_POW2; }
@@ -483,6 +487,7 @@ int mzk_fri_commit(int field_id, const uint64_t* codeword, size_t n, const uint6
   const HostField* hf = host_field(field_id);
   if (!h_is_canonical(hf, omega) || !h_is_canonical(hf, offset)) { set_error("fri_commit: parameter not canonical"); return MZK_E_RANGE; }
   hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
   const size_t esz = field_bytes(field_id);
   const int nl = hf->nl;
   size_t total = 0;
@@ -511,8 +516,9 @@ int mzk_fri_commit(int field_id, const uint64_t* codeword, size_t n, const uint6
       root_len[r] = 32;
     }
     const int last = (r == num_rounds - 1);
-    memset(alpha, 0, sizeof alpha);
-    challenge(user, r, last, root, (size_t)root_len[r], alpha);
+    memset(alpha, 0xff, sizeof alpha);     // a callback that forgets alpha leaves a non-canonical value, never a silent 0
+    const int crc = challenge(user, r, last, root, (size_t)root_len[r], alpha);
+    if (crc != 0) { set_error("fri_commit: challenge callback failed in round %d (status %d)", r, crc); return MZK_E_CALLBACK; }
     if (last) break;
     if (!h_is_canonical(hf, alpha)) { set_error("fri_commit: challenge of round %d not canonical", r); return MZK_E_RANGE; }
     uint8_t* next = cur + len * esz;

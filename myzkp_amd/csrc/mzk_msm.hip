@@ -887,7 +887,7 @@ static int sort_records(const SortArgs& a, hipStream_t s) {
                      (const u32*)(a.scan3 + a.sb_f), a.n_fine);
   if (a.F <= STAGE_F_MAX) {
     const size_t lds = ((size_t)3 * a.F + SORT2_THREADS + STAGE_CAP) * 4 + (size_t)STAGE_CAP * 2;
-    static bool staged_attr = false;     // one flag per instantiation
+    bool& staged_attr = ctx().attr_done[sizeof(R) == 4 ? ATTR_FINE_SCATTER4 : ATTR_FINE_SCATTER8];     // per instantiation and context
     if (!staged_attr) {
       MZK_HIP(hipFuncSetAttribute((const void*)k_fine_scatter<REC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       staged_attr = true;
@@ -938,6 +938,15 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     pts = (const u32*)pm;
   }
   const size_t E_max = n * (size_t)(L.glv ? 2 * sh.nwin : sh.nwin);
+  // entries pack the point reference into 31 bits (+ sign) and entry positions into 32: reject shapes that overflow
+  // (window widths below 16 on a > 2^26-point SRS) instead of gathering a wrong table row
+  {
+    const size_t ref_limit = L.merged ? (size_t)sh.nwin * table_stride : L.phi_offset + n;
+    if (ref_limit > ((size_t)1 << 31) || E_max >= ((size_t)1 << 32)) {
+      set_error("msm: %zu pairs x %d windows (table stride %zu) exceed the 31-bit point references / 32-bit entry offsets", n, sh.nwin, table_stride);
+      return MZK_E_ARG;
+    }
+  }
   int lgseg = 4;
   while ((E_max >> lgseg) > ((size_t)1 << 18) && lgseg < 16) lgseg++;
   // (segment length swept at 2^20 pairs: 32 / 64 / 128 / 256 entries -> 1.35 / 1.31 / 1.38 / 1.52 ms)
@@ -1006,7 +1015,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     u32* wg_hist;
     MZK_TRY(ws_get(WS_MSM_WGHIST, (size_t)nwg * NB * 4, (void**)&wg_hist));
     const size_t lds = NB * 4;
-    static bool lds_attr_set = false;
+    bool& lds_attr_set = ctx().attr_done[ATTR_DIGITS_LDS];
     if (!lds_attr_set) {
       MZK_HIP(hipFuncSetAttribute((const void*)k_digits_count_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       MZK_HIP(hipFuncSetAttribute((const void*)k_digits_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

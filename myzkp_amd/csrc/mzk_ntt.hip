@@ -330,7 +330,8 @@ struct NttPlan {
   int has_last_scale = 0;
   uint64_t stamp = 0;
 };
-static std::vector<NttPlan*> g_plans;
+static std::vector<NttPlan*> g_plans_all[MZK_MAX_CTX];      // per context (device)
+#define g_plans g_plans_all[ctx().index]
 static uint64_t g_stamp = 0;
 constexpr size_t MAX_PLANS = 12;
 
@@ -556,8 +557,8 @@ int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_
     // offset^(j M) and offset^col tables: like the plan's twiddles they depend only on (field, offset, size) -- a STARK
     // prover evaluates every polynomial on ONE coset -- so the last pair per field is kept (workspace generation and
     // stream order checked like the fixed-base tables in mzk_kzg.hip).
-    static struct { uint64_t off[4]; unsigned logn; uint64_t gen; bool valid; hipEvent_t ready; } cache[2] = {};
-    auto& ce = cache[fid == MZK_FIELD_M128 ? 1 : 0];
+    static struct { uint64_t off[4]; unsigned logn; uint64_t gen; bool valid; hipEvent_t ready; } cache[MZK_MAX_CTX][2] = {};
+    auto& ce = cache[ctx().index][fid == MZK_FIELD_M128 ? 1 : 0];
     void* tabs = nullptr;
     MZK_TRY(ws_get(fid == MZK_FIELD_M128 ? WS_NTT_PRE_M128 : WS_NTT_PRE, (nrow + ncol) * field_bytes(fid), &tabs));
     u32* pre_row = (u32*)tabs;

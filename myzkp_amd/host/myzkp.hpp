@@ -28,6 +28,7 @@
 #include <string>
 #include <type_traits>
 #include <vector>
+#include <exception>
 #include "../../include/mzk.h"
 
 namespace myzkp {
@@ -352,10 +353,18 @@ template <class F> struct FriCommitment { std::vector<std::vector<F>> codewords;
 template <class F, class Fn>
 FriCommitment<F> fri_commit(const std::vector<F>& initial_codeword, const F& omega, const F& offset, int num_rounds, Fn&& challenge) {
   typedef typename std::remove_reference<Fn>::type Callee;
-  struct Ctx { Callee* fn; } cx{&challenge};
-  auto tramp = [](void* user, int round, int last, const uint8_t* root, size_t root_len, uint64_t* alpha_out) {
-    F a = (*static_cast<Ctx*>(user)->fn)(round, last != 0, MerkleRoot(root, root + root_len));
-    std::memcpy(alpha_out, a.value.data(), 8 * a.value.size());
+  // a throwing transcript must not unwind through the C library: report failure (-> MZK_E_CALLBACK), rethrow below
+  struct Ctx { Callee* fn; std::exception_ptr err; } cx{&challenge, nullptr};
+  auto tramp = [](void* user, int round, int last, const uint8_t* root, size_t root_len, uint64_t* alpha_out) -> int {
+    Ctx* c = static_cast<Ctx*>(user);
+    try {
+      F a = (*c->fn)(round, last != 0, MerkleRoot(root, root + root_len));
+      std::memcpy(alpha_out, a.value.data(), 8 * a.value.size());
+      return 0;
+    } catch (...) {
+      c->err = std::current_exception();
+      return 1;
+    }
   };
   const size_t n = initial_codeword.size(), nl = F().value.size();
   size_t total = 0;
@@ -363,8 +372,10 @@ FriCommitment<F> fri_commit(const std::vector<F>& initial_codeword, const F& ome
   auto c = to_wire(initial_codeword);
   std::vector<uint8_t> roots(48 * (size_t)(num_rounds > 0 ? num_rounds : 0) + 1);
   std::vector<uint64_t> lens(num_rounds > 0 ? num_rounds : 1), all((total + 1) * nl);
-  expect(mzk_fri_commit(Polynomial<F>::field_id(), c.data(), n, omega.value.data(), offset.value.data(), num_rounds, +tramp, &cx, roots.data(),
-                        lens.data(), all.data()));
+  const int frc = mzk_fri_commit(Polynomial<F>::field_id(), c.data(), n, omega.value.data(), offset.value.data(), num_rounds, +tramp, &cx, roots.data(),
+                                 lens.data(), all.data());
+  if (cx.err) std::rethrow_exception(cx.err);
+  expect(frc);
   FriCommitment<F> out;
   size_t at = 0;
   for (int r = 0; r < num_rounds; r++) {

@@ -18,7 +18,7 @@ def test_exports_every_declared_symbol(mz):
     assert len(mz.DECLARED_SYMBOLS) >= 20
     missing = [s for s in mz.DECLARED_SYMBOLS if s not in mz.exported_symbols()]
     assert missing == []
-    assert mz.lib().mzk_abi_version() == 1
+    assert mz.lib().mzk_abi_version() == 2
 
 
 def test_root_of_unity_is_host_math(mz):
