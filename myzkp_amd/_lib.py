@@ -74,6 +74,26 @@ def shutdown():
     lib().mzk_shutdown()
 
 
+def init_devices(ordinals):
+    """One process driving several GPUs: context r = ordinals[r] (duplicates allowed).  Context 0 becomes current."""
+    arr = (ctypes.c_int * len(ordinals))(*[int(o) for o in ordinals])
+    _check(lib().mzk_init_devices(arr, len(ordinals)))
+
+
+def ctx_count():
+    return int(lib().mzk_ctx_count())
+
+
+def ctx_select(index):
+    _check(lib().mzk_ctx_select(int(index)))
+
+
+def shard_range(n, rank, world):
+    lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+    lib().mzk_shard_range(ctypes.c_size_t(n), int(rank), int(world), ctypes.byref(lo), ctypes.byref(hi))
+    return lo.value, hi.value
+
+
 def to_limbs(vals, nl):
     a = np.zeros((len(vals), nl), dtype=np.uint64)
     for i, v in enumerate(vals):
@@ -176,6 +196,60 @@ def msm_g1(scalars, points):
 
 
 kzg_commit = msm_g1
+
+
+def msm_g1_multi(scalars, points):
+    """The same MSM sharded over every context of init_devices (contiguous shards, gather of 128-byte partials, fold)."""
+    s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    p = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+    if p.shape[0] < s.shape[0]:
+        raise MzkError(-5, "index out of bounds: the len is %d but the index is %d" % (p.shape[0], p.shape[0]))
+    out = np.zeros((1, 8), dtype=np.uint64)
+    _check(lib().mzk_msm_g1_bn254_multi(_p(s), _p(p), ctypes.c_size_t(s.shape[0]), _p(out)))
+    return array_to_points(out)[0]
+
+
+class SrsMulti:
+    """PublicKeyKZG.powers_1 sharded over the contexts of init_devices (kzg.rs:8-11): from host points, or built on
+    the GPUs from (alpha, g1) like setup_kzg (kzg.rs:27-40)."""
+
+    def __init__(self, powers=None, alpha=None, max_d=None, g1=(1, 2), with_tables=1):
+        self._h = ctypes.c_void_p()
+        if powers is not None:
+            p = np.ascontiguousarray(powers, dtype=np.uint64).reshape(-1, 8)
+            self.n = p.shape[0]
+            _check(lib().mzk_srs_upload_multi(_p(p), ctypes.c_size_t(self.n), ctypes.byref(self._h)))
+        else:
+            a, g = _one(FIELD_FR, alpha), points_to_array([g1])
+            self.n = max_d + 1
+            _check(lib().mzk_kzg_setup_srs_multi(_p(a), _p(g), ctypes.c_size_t(max_d), int(with_tables), ctypes.byref(self._h)))
+        lib().mzk_srs_multi_shard_lo.restype = ctypes.c_size_t
+        self.world = int(lib().mzk_srs_multi_world(self._h))
+        self.lo = [int(lib().mzk_srs_multi_shard_lo(self._h, r)) for r in range(self.world + 1)]
+
+    def commit(self, coef):
+        c = np.ascontiguousarray(coef, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros((1, 8), dtype=np.uint64)
+        _check(lib().mzk_kzg_commit_srs_multi(self._h, _p(c), ctypes.c_size_t(c.shape[0]), _p(out)))
+        return array_to_points(out)[0]
+
+    def commit_dev(self, shard_ptrs, n):
+        """shard_ptrs[r]: device pointer (int) on context r's GPU to coefficients [lo[r], min(lo[r+1], n))."""
+        arr = (ctypes.c_void_p * self.world)(*[ctypes.c_void_p(int(x)) for x in shard_ptrs])
+        out = np.zeros((1, 8), dtype=np.uint64)
+        _check(lib().mzk_kzg_commit_srs_multi_dev(self._h, arr, ctypes.c_size_t(n), _p(out)))
+        return array_to_points(out)[0]
+
+    def close(self):
+        if self._h:
+            lib().mzk_srs_multi_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def kzg_setup_g1(alpha, max_d, g1=(1, 2)):

@@ -18,6 +18,7 @@
 //                          (madd-2008-s), exception-complete; k_seg_combine sums a bucket's partials
 //   5. k_halve_step / k_reduce_tail   sum_b (b+1) B_b per bucket set by in-place halving
 //   6. k_window_combine (mzk_msm_tail.hip)  Horner over the bucket sets, XYZZ -> affine (one inversion)
+#include <stdlib.h>
 #include "mzk_common.h"
 #include "mzk_ec.h"
 #include "mzk_coop.h"
@@ -617,21 +618,28 @@ __global__ __launch_bounds__(256) void k_scan_finish(u32* __restrict__ offsets, 
 }
 
 // ---- 4. bucket accumulation, segmented ------------------------------------------------------------------
-// The sorted entry array is cut into fixed segments of SEG entries, one lane per segment, so the work
+// The sorted entry array is cut into fixed segments of `seg` entries, one lane per segment, so the work
 // per lane is equal whatever the scalar distribution (no Poisson tail, no skew cliff).  A lane walks
 // its segment, keeps one XYZZ accumulator, and flushes it whenever the bucket changes.  The partial
 // of (segment t, bucket b) goes to slot t + b: (t, b) pairs met in order strictly increase t + b, so
 // slots are unique, and all partials of bucket b sit in the contiguous slot range
-// [offsets[b] / SEG + b, offsets[b+1] / SEG + b + 1) -- pass 2 sums that range (every slot of that range is
+// [offsets[b] / seg + b, (offsets[b+1] - 1) / seg + b] -- pass 2 sums that range (every slot of that range is
 // written: segment t overlaps bucket b exactly when slot t + b lies in it).
+// `seg` is chosen by the host so that the grid is ONE full round of resident waves (see accumulate_segment): the
+// kernel is a long dependent loop per lane, so a partial second round would run at a fraction of the occupancy.
+//
+// PREFETCH = true keeps the next entry's point in 16 extra registers (139 VGPRs -> 3 waves per SIMD); false loads the
+// point where it is used (123 VGPRs -> 4 waves per SIMD) and leaves the latency to the other three waves.
+template <bool PREFETCH>
 __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ points_mont, const u32* __restrict__ offsets,
                                                          const u32* __restrict__ entries, u32* __restrict__ slots, size_t nbuckets,
-                                                         int lgseg) {
+                                                         u32 seg) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 total_entries = offsets[nbuckets];
-  const u32 e0 = (u32)(t << lgseg);
-  if (e0 >= total_entries) return;
-  const u32 e1 = (e0 + (1u << lgseg) < total_entries) ? e0 + (1u << lgseg) : total_entries;
+  const u64 e0w = (u64)t * seg;
+  if (e0w >= total_entries) return;
+  const u32 e0 = (u32)e0w;
+  const u32 e1 = (e0w + seg < total_entries) ? e0 + seg : total_entries;
   // bucket of entry e0: last b with offsets[b] <= e0
   size_t lo = 0, hi = nbuckets;  // invariant: offsets[lo] <= e0 < offsets[hi] (offsets[nbuckets] = total)
   while (hi - lo > 1) {
@@ -641,11 +649,11 @@ __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ 
   size_t b = lo;
   u32 bend = offsets[b + 1];
   Xyzz acc = xyzz_inf();
-  // software pipeline: the point of entry e+1 is requested before the ~3000-instruction madd of entry e,
-  // so the dependent entries[] -> points[] gather is in flight behind arithmetic instead of in front of it
   u32 ent_next = entries[e0];
   u32 wn[16];
-  {
+  if (PREFETCH) {
+    // software pipeline: the point of entry e+1 is requested before the ~3000-instruction madd of entry e,
+    // so the dependent entries[] -> points[] gather is in flight behind arithmetic instead of in front of it
     const size_t idx = ent_next & 0x7fffffffu;
     load_words8(points_mont + idx * 16, wn);
     load_words8(points_mont + idx * 16 + 8, wn + 8);
@@ -653,13 +661,21 @@ __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ 
   for (u32 e = e0; e < e1; e++) {
     const u32 ent = ent_next;
     u32 w[16];
+    if (PREFETCH) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) w[k] = wn[k];
+      for (int k = 0; k < 16; k++) w[k] = wn[k];
+    } else {
+      const size_t idx = ent & 0x7fffffffu;
+      load_words8(points_mont + idx * 16, w);
+      load_words8(points_mont + idx * 16 + 8, w + 8);
+    }
     if (e + 1 < e1) {
       ent_next = entries[e + 1];
-      const size_t idx = ent_next & 0x7fffffffu;
-      load_words8(points_mont + idx * 16, wn);
-      load_words8(points_mont + idx * 16 + 8, wn + 8);
+      if (PREFETCH) {
+        const size_t idx = ent_next & 0x7fffffffu;
+        load_words8(points_mont + idx * 16, wn);
+        load_words8(points_mont + idx * 16 + 8, wn + 8);
+      }
     }
     if (e >= bend) {
       xyzz_gstore(slots, t + b, acc);
@@ -673,8 +689,8 @@ __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ 
   }
   xyzz_gstore(slots, t + b, acc);
 }
-// pass 2: buckets[b] = sum of slots [offsets[b] >> lgseg + b, offsets[b+1] >> lgseg + b]   (inclusive end:
-// the last entry of bucket b is offsets[b+1]-1, whose segment is <= offsets[b+1] >> lgseg)
+// pass 2: buckets[b] = sum of slots [offsets[b] / seg + b, (offsets[b+1] - 1) / seg + b]   (inclusive end:
+// the last entry of bucket b is offsets[b+1]-1)
 // Buckets with more than HEAVY_SLOTS partials (skewed scalars: bit vectors, repeated values) would be one long
 // serial chain; they are queued in `heavy` (count at heavy[0], bucket ids from heavy[1]) and summed by a whole
 // workgroup each (k_seg_combine_heavy).
@@ -687,20 +703,20 @@ __device__ __forceinline__ bool defer_heavy(size_t b, size_t s0, size_t s1, u32*
 // one lane per bucket: with 2^19 buckets of one or two partials each (generic layout) the kernel is bound by
 // the record traffic, not by a dependent chain
 __global__ __launch_bounds__(128) void k_seg_combine_wide(const u32* __restrict__ slots, const u32* __restrict__ offsets,
-                                                           u32* __restrict__ buckets, size_t nbuckets, int lgseg, u32* __restrict__ heavy) {
+                                                           u32* __restrict__ buckets, size_t nbuckets, u32 seg, u32* __restrict__ heavy) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbuckets) return;
   const u32 o0 = offsets[b], o1 = offsets[b + 1];
   Xyzz acc = xyzz_inf();
   if (o1 > o0) {
-    const size_t s0 = (size_t)(o0 >> lgseg) + b, s1 = (size_t)((o1 - 1) >> lgseg) + b;
+    const size_t s0 = (size_t)(o0 / seg) + b, s1 = (size_t)((o1 - 1) / seg) + b;
     if (defer_heavy(b, s0, s1, heavy, true)) return;
     for (size_t sl = s0; sl <= s1; sl++) acc = xyzz_add(acc, xyzz_gload(slots, sl));
   }
   xyzz_gstore(buckets, b, acc);
 }
 __global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slots, const u32* __restrict__ offsets, u32* __restrict__ buckets,
-                                                      size_t nbuckets, int lgseg, u32* __restrict__ heavy) {
+                                                      size_t nbuckets, u32 seg, u32* __restrict__ heavy) {
   // one DPP quad per bucket: a bucket's partials form a serial chain of additions (about nine at 2^20 merged),
   // so the quad-cooperative addition cuts the kernel's latency; the quad also splits the 128-byte records.
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -710,7 +726,7 @@ __global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slo
   const u32 o0 = offsets[b], o1 = offsets[b + 1];
   Xyzz acc = xyzz_inf();
   if (o1 > o0) {
-    const size_t s0 = (size_t)(o0 >> lgseg) + b, s1 = (size_t)((o1 - 1) >> lgseg) + b;
+    const size_t s0 = (size_t)(o0 / seg) + b, s1 = (size_t)((o1 - 1) / seg) + b;
     if (defer_heavy(b, s0, s1, heavy, lane == 0)) return;       // quad-uniform
     acc = xyzz_gload_quad(slots, s0, lane);
     for (size_t sl = s0 + 1; sl <= s1; sl++) acc = xyzz_add_quad(acc, xyzz_gload_quad(slots, sl, lane), lane);
@@ -720,14 +736,14 @@ __global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slo
 constexpr int HEAVY_THREADS = 256;
 constexpr int HEAVY_QUADS = HEAVY_THREADS / 4;
 __global__ __launch_bounds__(HEAVY_THREADS) void k_seg_combine_heavy(const u32* __restrict__ slots, const u32* __restrict__ offsets,
-                                                                      u32* __restrict__ buckets, int lgseg, const u32* __restrict__ heavy) {
+                                                                      u32* __restrict__ buckets, u32 seg, const u32* __restrict__ heavy) {
   __shared__ __attribute__((aligned(16))) u32 sh[HEAVY_QUADS * 32];
   const u32 count = heavy[0];
   const int lane = threadIdx.x & 3, quad = threadIdx.x >> 2;
   for (u32 h = blockIdx.x; h < count; h += gridDim.x) {
     const size_t b = heavy[1 + h];
     const u32 o0 = offsets[b], o1 = offsets[b + 1];
-    const size_t s0 = (size_t)(o0 >> lgseg) + b, s1 = (size_t)((o1 - 1) >> lgseg) + b;
+    const size_t s0 = (size_t)(o0 / seg) + b, s1 = (size_t)((o1 - 1) / seg) + b;
     Xyzz acc = xyzz_inf();
     for (size_t sl = s0 + quad; sl <= s1; sl += HEAVY_QUADS) acc = xyzz_add_quad(acc, xyzz_gload_quad(slots, sl, lane), lane);
     xyzz_gstore_quad(sh, quad, acc, lane);
@@ -947,10 +963,19 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
       return MZK_E_ARG;
     }
   }
-  int lgseg = 4;
-  while ((E_max >> lgseg) > ((size_t)1 << 18) && lgseg < 16) lgseg++;
-  // (segment length swept at 2^20 pairs: 32 / 64 / 128 / 256 entries -> 1.35 / 1.31 / 1.38 / 1.52 ms)
-  const size_t T = (E_max + ((size_t)1 << lgseg) - 1) >> lgseg;
+  // Segment length: one lane per segment, and the grid should be ONE full round of resident waves -- the kernel is a
+  // long dependent loop, so the waves of a partial second round would run alone on their SIMDs.  k_seg_accumulate
+  // <PREFETCH = false> needs 123 VGPRs = 4 waves per SIMD, <true> 139 = 3 (tools/timing/acc_sweep.py sweeps both and
+  // the segment length through MZK_ACC_PREFETCH / MZK_ACC_SEG).
+  static const int env_prefetch = getenv("MZK_ACC_PREFETCH") ? atoi(getenv("MZK_ACC_PREFETCH")) : -1;
+  static const int env_seg = getenv("MZK_ACC_SEG") ? atoi(getenv("MZK_ACC_SEG")) : 0;
+  const bool acc_prefetch = env_prefetch >= 0 ? env_prefetch != 0 : false;
+  const size_t resident_lanes = (size_t)ctx().num_cu * 4 * (acc_prefetch ? 3 : 4) * 64;
+  size_t seg_sz = (E_max + resident_lanes - 1) / resident_lanes;
+  if (seg_sz < 16) seg_sz = 16;
+  if (env_seg > 0) seg_sz = (size_t)env_seg;
+  const u32 seg = (u32)seg_sz;
+  const size_t T = (E_max + seg_sz - 1) / seg_sz;
   const size_t nslots = T + NB + 1;
   const size_t heavy_words = 4 + (T + NB) / HEAVY_SLOTS;         // count + at most (T + NB) / 33 heavy buckets
   u32 *counts, *offsets, *ranks, *entries, *scan_tmp, *buckets, *slots;
@@ -1040,12 +1065,15 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   prof_end(s, MZK_PH_MSM_SORT);
   prof_begin(s, MZK_PH_MSM_ACCUMULATE);
   // the true entry count lives in offsets[NB] on the device; lanes past it exit (E_max bounds it)
-  hipLaunchKernelGGL(k_seg_accumulate, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, pts, offsets, entries, slots, NB, lgseg);
-  if (NB >= ((size_t)1 << 17))
-    hipLaunchKernelGGL(k_seg_combine_wide, dim3((unsigned)((NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, lgseg, heavy);
+  if (acc_prefetch)
+    hipLaunchKernelGGL(k_seg_accumulate<true>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, pts, offsets, entries, slots, NB, seg);
   else
-    hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, lgseg, heavy);
-  hipLaunchKernelGGL(k_seg_combine_heavy, dim3(512), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)offsets, buckets, lgseg, (const u32*)heavy);
+    hipLaunchKernelGGL(k_seg_accumulate<false>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, pts, offsets, entries, slots, NB, seg);
+  if (NB >= ((size_t)1 << 17))
+    hipLaunchKernelGGL(k_seg_combine_wide, dim3((unsigned)((NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy);
+  else
+    hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy);
+  hipLaunchKernelGGL(k_seg_combine_heavy, dim3(512), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)offsets, buckets, seg, (const u32*)heavy);
   MZK_HIP(hipGetLastError());
   prof_end(s, MZK_PH_MSM_ACCUMULATE);
   prof_begin(s, MZK_PH_MSM_REDUCE);

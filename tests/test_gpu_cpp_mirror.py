@@ -8,10 +8,13 @@ ROOT = orc.ROOT
 EXE = os.path.join(ROOT, "tests", "cpp", "test_reference_style")
 
 
-def build_exe():
+EXE_MULTI = os.path.join(ROOT, "tests", "cpp", "test_multi_device")
+
+
+def build_exe(name="test_reference_style"):
     orc.lib()
-    src = os.path.join(ROOT, "tests", "cpp", "test_reference_style.cpp")
-    cmd = ["g++", "-O1", "-std=c++17", src, "-o", EXE,
+    src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
+    cmd = ["g++", "-O1", "-std=c++17", src, "-o", os.path.join(ROOT, "tests", "cpp", name),
            "-L" + os.path.join(ROOT, "myzkp_amd"), "-lmzk_hip", "-L" + os.path.join(ROOT, "oracle"), "-lmzk_oracle",
            "-Wl,-rpath," + os.path.join(ROOT, "myzkp_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
            "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
@@ -23,7 +26,8 @@ def test_cpp_mirror_compiles():
     import myzkp_amd.build as b
     b.build()
     build_exe()
-    assert os.path.exists(EXE)
+    build_exe("test_multi_device")
+    assert os.path.exists(EXE) and os.path.exists(EXE_MULTI)
 
 
 @pytest.mark.gpu
@@ -32,3 +36,14 @@ def test_cpp_mirror_runs_on_gpu():
     out = subprocess.run([EXE], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all reference-style tests passed" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_multi_device_runs_world_1_to_8():
+    """Multi-GPU MSM / KZG commit through the C ABI from a plain C++ program (no Python, no torch in the process)."""
+    build_exe("test_multi_device")
+    # count devices without initialising the GPU in this process (torch.cuda.device_count() does not)
+    import torch
+    out = subprocess.run([EXE_MULTI, str(max(torch.cuda.device_count(), 1))], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "multi-device C ABI test passed" in out.stdout
