@@ -132,8 +132,12 @@ int mzk_fri_fold_dev(int field_id, const void* d_codeword, size_t n, const uint6
 
 /* ---- SHA3-256 Merkle trees over codewords (algebra/merkle.rs:15-46 as called from zkstark/fri.rs:160-166,
  * 236-249 and fast_stark.rs:64-68, 237-241): leaves are bincode(FiniteFieldElement) of the canonical elements and
- * are not hashed themselves; a one-leaf tree commits to the leaf bytes.  n must be a power of two (the provers
- * only ever commit to codewords of such lengths); n = 0 is an error.  A handle keeps its own copy of the leaves
+ * are not hashed themselves; a one-leaf tree commits to the leaf bytes.  n = 0 is an error (the reference recurses
+ * forever).  Any n >= 1 is accepted like merkle.rs:15-25 does (mid = len / 2): the provers only commit to
+ * power-of-two codewords, which take the fast path; other counts are reduced to the power-of-two tree over the
+ * 2^floor(log2 n) one- or two-leaf subtrees at the bottom.  Merkle::open on a ragged tree only terminates for a
+ * leaf inside a two-leaf subtree (merkle.rs:32-34); mzk_merkle_open returns MZK_E_LENGTH for the others instead of
+ * recursing forever, and the path then has floor(log2 n) + 1 entries.  A handle keeps its own copy of the leaves
  * and all node levels in HBM so that many paths can be opened against one codeword. */
 typedef struct mzk_merkle mzk_merkle;
 int mzk_merkle_build_field(int field_id, const uint64_t* elems, size_t n, mzk_merkle** out);
@@ -152,6 +156,16 @@ int mzk_merkle_commit_field_dev(int field_id, const void* d_elems, size_t n, uin
                                 void* stream);
 int mzk_merkle_commit_bytes(const uint8_t* leaves, const uint64_t* offsets, size_t n, uint8_t* root, size_t cap, size_t* root_len);
 
+/* Elements whose BigInt the reference left NEGATIVE (F6: `%` keeps the sign, field.rs:98-110; only sanitize() folds
+ * them into [0, p)): bincode writes Sign::Minus and the MAGNITUDE, so the leaf differs from the canonical element's.
+ * The *_signed forms take the magnitudes (canonical limbs of |v|, |v| < p) plus one byte per element (1 = negative)
+ * and hash exactly those bytes; all arithmetic afterwards uses the canonical representative p - |v|.
+ * mzk_fri_commit_signed: round 0 commits to the unsanitized initial codeword like fri.rs:160-166 does (every later
+ * codeword is sanitized by the fold, fri.rs:190); codewords_out[0..n) receives the canonical values. */
+int mzk_merkle_build_field_signed(int field_id, const uint64_t* magnitudes, const uint8_t* negative, size_t n, mzk_merkle** out);
+int mzk_merkle_commit_field_signed(int field_id, const uint64_t* magnitudes, const uint8_t* negative, size_t n, uint8_t* root, size_t cap,
+                                   size_t* root_len);
+
 /* FRI::commit (zkstark/fri.rs:144-209), codewords resident in HBM across all rounds.  Round r: the Merkle root of
  * codeword_r is handed to `challenge` (which owns the proof stream: push the root, and unless `last` sample
  * alpha = F::sample(prover_fiat_shamir(32)) into alpha_out, canonical limbs); then split-and-fold, omega and
@@ -162,6 +176,8 @@ int mzk_merkle_commit_bytes(const uint8_t* leaves, const uint64_t* offsets, size
 typedef int (*mzk_fri_challenge_fn)(void* user, int round, int last, const uint8_t* root, size_t root_len, uint64_t* alpha_out);
 int mzk_fri_commit(int field_id, const uint64_t* codeword, size_t n, const uint64_t* omega, const uint64_t* offset, int num_rounds,
                    mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out);
+int mzk_fri_commit_signed(int field_id, const uint64_t* magnitudes, const uint8_t* negative, size_t n, const uint64_t* omega, const uint64_t* offset,
+                          int num_rounds, mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out);
 
 /* ---- G2 (BN254 twist over Fq2 = Fq[u]/(u^2+1); bn128.rs:33-49) ------------------------------------------------
  * A G2 point is 16 limbs: x.c0 | x.c1 | y.c0 | y.c1 (4 limbs each, canonical); all-zero = infinity.
@@ -177,6 +193,17 @@ typedef struct mzk_srs mzk_srs;
 int mzk_srs_upload(const uint64_t* powers_xy, size_t n, mzk_srs** out);
 void mzk_srs_free(mzk_srs* srs);
 int mzk_kzg_commit_srs(const mzk_srs* srs, const uint64_t* coef, size_t n, uint64_t out_xy[8]);
+/* Persistence ("an SRS dump for PublicKeyKZG"; the reference only derives serde on its types and
+ * never writes a key).  File = 64-byte header | n points exactly as at this ABI (x || y, little-endian u64 limbs,
+ * canonical, all-zero = infinity) | optionally the window tables in the library's internal encoding; the header
+ * holds an FNV-1a 64 of the point bytes, checked on load (MZK_E_IO).  mzk_srs_save(with_tables != 0) stores the tables
+ * if the handle has them; mzk_srs_load(with_tables as in mzk_srs_from_device_ex) reads stored tables of the wanted
+ * width and otherwise rebuilds them (which is faster than reading them from disk: see DESIGN.md).
+ * mzk_srs_download returns powers_1 (n * 8 limbs) of a handle, e.g. one built by mzk_kzg_setup_g1_dev. */
+int mzk_srs_save(const mzk_srs* srs, const char* path, int with_tables);
+int mzk_srs_load(const char* path, int with_tables, mzk_srs** out);
+int mzk_srs_download(const mzk_srs* srs, uint64_t* powers_xy, size_t cap_points);
+size_t mzk_srs_len(const mzk_srs* srs);
 
 /* ---- device-resident variants (inputs already in HBM; `stream` is a hipStream_t) --------------- */
 int mzk_ntt_dev(int field_id, const uint64_t* root_host, const void* d_in, void* d_out, size_t n,

@@ -321,6 +321,25 @@ class Srs:
         _check(lib().mzk_kzg_commit_srs(self._h, _p(c), ctypes.c_size_t(c.shape[0]), _p(out)))
         return array_to_points(out)[0]
 
+    def save(self, path, with_tables=False):
+        """Raw little-endian dump of powers_1 (+ optionally the window tables): mzk_srs_save."""
+        _check(lib().mzk_srs_save(self._h, os.fsencode(path), int(bool(with_tables))))
+
+    @classmethod
+    def load(cls, path, with_tables=1):
+        self = cls.__new__(cls)
+        self._h = ctypes.c_void_p()
+        _check(lib().mzk_srs_load(os.fsencode(path), int(with_tables), ctypes.byref(self._h)))
+        lib().mzk_srs_len.restype = ctypes.c_size_t
+        self.n = int(lib().mzk_srs_len(self._h))
+        return self
+
+    def download(self):
+        """powers_1 back as an (n, 8) limb array."""
+        out = np.zeros((max(self.n, 1), 8), dtype=np.uint64)
+        _check(lib().mzk_srs_download(self._h, _p(out), ctypes.c_size_t(self.n)))
+        return out[:self.n]
+
     def close(self):
         if self._h:
             lib().mzk_srs_free(self._h)
@@ -338,9 +357,15 @@ class MerkleTree:
 
     Leaves are bincode(FiniteFieldElement) of the elements (zkstark/fri.rs:160-166) or arbitrary byte strings."""
 
-    def __init__(self, fid=None, elems=None, leaves=None):
+    def __init__(self, fid=None, elems=None, leaves=None, negative=None):
         self._h = ctypes.c_void_p()
-        if leaves is not None:
+        if negative is not None:       # (magnitude, Sign::Minus flag) pairs: unsanitized elements (field.rs:98-110)
+            e = _arr(fid, elems)
+            ng = np.ascontiguousarray(negative, dtype=np.uint8)
+            self.n = e.shape[0]
+            self.stride = 48
+            _check(lib().mzk_merkle_build_field_signed(fid, _p(e), _p(ng), ctypes.c_size_t(self.n), ctypes.byref(self._h)))
+        elif leaves is not None:
             blob = b"".join(leaves)
             off = np.zeros(len(leaves) + 1, dtype=np.uint64)
             off[1:] = np.cumsum([len(x) for x in leaves], dtype=np.uint64) if leaves else []
@@ -394,9 +419,10 @@ _FRI_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c
                            ctypes.POINTER(ctypes.c_uint64))
 
 
-def fri_commit(fid, codeword, omega, offset, num_rounds, challenge):
+def fri_commit(fid, codeword, omega, offset, num_rounds, challenge, negative=None):
     """FRI::commit (zkstark/fri.rs:144-209), codewords resident in HBM.  challenge(round, last, root_bytes) -> alpha
-    (int; ignored when last).  Returns (codewords, roots)."""
+    (int; ignored when last).  Returns (codewords, roots).  negative: optional Sign::Minus flags of the initial
+    codeword, then given as magnitudes (round 0 commits to the unsanitized elements, fri.rs:160-166)."""
     c = _arr(fid, codeword)
     n, nl = c.shape[0], LIMBS[fid]
 
@@ -425,7 +451,11 @@ def fri_commit(fid, codeword, omega, offset, num_rounds, challenge):
     allcw = np.zeros((max(total, 1), nl), dtype=np.uint64)
     w, o = _one(fid, omega), _one(fid, offset)
     fn = _FRI_CB(cb)
-    rc = lib().mzk_fri_commit(fid, _p(c), ctypes.c_size_t(n), _p(w), _p(o), int(num_rounds), fn, None, roots, lens, _p(allcw))
+    if negative is not None:
+        ng = np.ascontiguousarray(negative, dtype=np.uint8)
+        rc = lib().mzk_fri_commit_signed(fid, _p(c), _p(ng), ctypes.c_size_t(n), _p(w), _p(o), int(num_rounds), fn, None, roots, lens, _p(allcw))
+    else:
+        rc = lib().mzk_fri_commit(fid, _p(c), ctypes.c_size_t(n), _p(w), _p(o), int(num_rounds), fn, None, roots, lens, _p(allcw))
     if failure:
         raise failure[0]
     _check(rc)

@@ -8,6 +8,7 @@
 //
 // Work shape: n/2 + n/4 + ... one-block Keccak-f[1600] permutations (each message fits the 136-byte rate), pure
 // 64-bit logic ops -- ALU-bound, ~5k VALU ops per hash; algorithmic HBM traffic is S*n bytes in, 32*(n-1) out.
+#include <algorithm>
 #include "mzk_common.h"
 
 namespace mzk {
@@ -117,7 +118,8 @@ __device__ __forceinline__ void sha3_of_two_digests(const u64* __restrict__ chil
 // word-major LDS block buffer, padded, and absorbed as 17 lanes.
 constexpr int LEAF_THREADS = 128;
 template <int NW>
-__global__ __launch_bounds__(LEAF_THREADS) void k_merkle_leaf_pairs(const u32* __restrict__ elems, size_t pairs, u64* __restrict__ nodes) {
+__global__ __launch_bounds__(LEAF_THREADS) void k_merkle_leaf_pairs(const u32* __restrict__ elems, size_t pairs, u64* __restrict__ nodes,
+                                                                     const u8* __restrict__ neg) {
   __shared__ u32 blk[SHA3_RATE / 4][LEAF_THREADS];
   const int tid = threadIdx.x;
   const size_t i = (size_t)blockIdx.x * LEAF_THREADS + tid;
@@ -135,7 +137,9 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_merkle_leaf_pairs(const u32* _
     int k = 0;                                    // significant u32 digits (BigUint keeps no leading zero digit)
 #pragma unroll
     for (int j = 0; j < NW; j++) if (w[j]) k = j + 1;
-    put(pos, k ? 1u : 0u);                         // Sign::Plus / Sign::NoSign as i8
+    // Sign as i8: Plus = 1, NoSign = 0, Minus = -1 (elements whose BigInt the reference left negative, field.rs:98-110;
+    // `neg` is null for canonical codewords)
+    put(pos, k ? ((neg && neg[2 * i + e]) ? 0xffu : 1u) : 0u);
     put(pos + 1, (u32)k);                          // sequence length as u64 LE (k <= 8: one non-zero byte)
     pos += 9;
 #pragma unroll
@@ -193,6 +197,72 @@ __global__ __launch_bounds__(128) void k_merkle_leaf_pairs_bytes(const u8* __res
   o2[1] = make_ulonglong2(a[2], a[3]);
 }
 
+// (magnitude, Sign::Minus) -> canonical representative p - magnitude, in place (magnitude 0 stays 0: BigInt has no -0)
+template <int NW>
+__global__ __launch_bounds__(256) void k_canonicalize_signed(u32* __restrict__ elems, const u8* __restrict__ neg, size_t n, int fid) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !neg[i]) return;
+  u32 w[NW], any = 0;
+#pragma unroll
+  for (int j = 0; j < NW; j++) { w[j] = elems[i * NW + j]; any |= w[j]; }
+  if (!any) return;
+  u32 pw[8];
+  if (NW == 4) { Fe<M128Params> pm; for (int k = 0; k < M128Params::L; k++) pm.l[k] = M128Params::P[k]; fe_pack<M128Params>(pm, pw); }
+  else { Fe<FrParams> pm; for (int k = 0; k < FrParams::L; k++) pm.l[k] = FrParams::P[k]; fe_pack<FrParams>(pm, pw); }
+  u32 borrow = 0;
+#pragma unroll
+  for (int j = 0; j < NW; j++) {
+    const u64 d = (u64)pw[j] - w[j] - borrow;
+    elems[i * NW + j] = (u32)d;
+    borrow = (u32)(d >> 32) & 1u;
+  }
+}
+
+// ---- ragged leaf counts (merkle.rs:15-25 accepts any non-empty slice: mid = len / 2) ----------------------------
+// The recursion splits k leaves into floor(k/2) | ceil(k/2), so at depth D = floor(log2 n) there are M = 2^D subtrees
+// of one or two leaves.  Define item p = the commitment of subtree p: the leaf ITSELF (one leaf, merkle.rs:17-19) or
+// hash(leaf || leaf).  Everything above depth D is a full binary tree, hence
+//     Merkle::commit(n ragged leaves) == Merkle::commit(M power-of-two items),
+// and the kernel below only has to produce the items (bytes, at host-computed offsets); the power-of-two byte-leaf
+// path does the rest.  node_start[p] = first leaf of subtree p (node_start[M] = n).
+__global__ __launch_bounds__(128) void k_merkle_ragged_items(const u8* __restrict__ leaves, const u64* __restrict__ off, const u32* __restrict__ node_start,
+                                                             size_t m, const u64* __restrict__ item_off, u8* __restrict__ items) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= m) return;
+  const u32 first = node_start[p], cnt = node_start[p + 1] - first;
+  const u8* msg = leaves + off[first];
+  const size_t len = (size_t)(off[first + cnt] - off[first]);
+  u8* dst = items + item_off[p];
+  if (cnt == 1) {
+    for (size_t i = 0; i < len; i++) dst[i] = msg[i];
+    return;
+  }
+  u64 a[25];
+#pragma unroll
+  for (int l = 0; l < 25; l++) a[l] = 0;
+  size_t base = 0;
+  for (;;) {
+    const bool last = (len - base) < (size_t)SHA3_RATE;
+#pragma unroll
+    for (int l = 0; l < SHA3_RATE / 8; l++) {
+      u64 wv = 0;
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        const size_t idx = base + 8 * l + t;
+        u64 b = idx < len ? (u64)msg[idx] : (idx == len ? 0x06ULL : 0ULL);
+        wv |= b << (8 * t);
+      }
+      a[l] ^= wv;
+    }
+    if (last) a[SHA3_RATE / 8 - 1] ^= 0x8000000000000000ULL;
+    keccak_f(a);
+    if (last) break;
+    base += SHA3_RATE;
+  }
+  for (int q = 0; q < 4; q++)
+    for (int t = 0; t < 8; t++) dst[8 * q + t] = (u8)(a[q] >> (8 * t));
+}
+
 // ---- inner levels -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void k_merkle_level(const u64* __restrict__ below, size_t count, u64* __restrict__ above) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -236,14 +306,23 @@ struct mzk_merkle {
   u64* d_nodes;          // n - 1 digests: level 1 (n/2), level 2 (n/4), ..., root
   void* d_leaves;        // owned copy of the elements / the leaf bytes (needed by open and by n == 1)
   std::vector<uint64_t> offsets;   // byte leaves only
+  std::vector<uint8_t> neg;        // field leaves given as (magnitude, sign): 1 = Sign::Minus; empty = all non-negative
   hipStream_t stream;
+  // ragged leaf counts: the tree is built over m = 2^floor(log2 n) items (see k_merkle_ragged_items); d_nodes, depth
+  // and the gather kernel then refer to the item tree
+  bool ragged = false;
+  size_t m = 0;
+  void* d_items = nullptr;
+  std::vector<uint64_t> item_off;
+  std::vector<uint32_t> node_start;
 };
 
 namespace mzk {
 static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 
 // hashes level 1 .. root into d_nodes; d_leaves / d_off already on the device
-static int merkle_hash_levels(int kind, int fid, const void* d_leaves, const u64* d_off, size_t n, u64* d_nodes, hipStream_t s) {
+static int merkle_hash_levels(int kind, int fid, const void* d_leaves, const u64* d_off, size_t n, u64* d_nodes, hipStream_t s,
+                              const u8* d_neg = nullptr) {
   if (n < 2) return MZK_OK;
   ProfScope ps(s, MZK_PH_MERKLE);
   const size_t pairs = n / 2;
@@ -251,9 +330,9 @@ static int merkle_hash_levels(int kind, int fid, const void* d_leaves, const u64
   if (kind == 1)
     hipLaunchKernelGGL(k_merkle_leaf_pairs_bytes, dim3(blocks), dim3(128), 0, s, (const u8*)d_leaves, d_off, pairs, d_nodes);
   else if (fid == MZK_FIELD_M128)
-    hipLaunchKernelGGL((k_merkle_leaf_pairs<4>), dim3(blocks), dim3(LEAF_THREADS), 0, s, (const u32*)d_leaves, pairs, d_nodes);
+    hipLaunchKernelGGL((k_merkle_leaf_pairs<4>), dim3(blocks), dim3(LEAF_THREADS), 0, s, (const u32*)d_leaves, pairs, d_nodes, d_neg);
   else
-    hipLaunchKernelGGL((k_merkle_leaf_pairs<8>), dim3(blocks), dim3(LEAF_THREADS), 0, s, (const u32*)d_leaves, pairs, d_nodes);
+    hipLaunchKernelGGL((k_merkle_leaf_pairs<8>), dim3(blocks), dim3(LEAF_THREADS), 0, s, (const u32*)d_leaves, pairs, d_nodes, d_neg);
   u64* below = d_nodes;
   size_t count = pairs;
   while (count > (size_t)TAIL_NODES) {
@@ -269,10 +348,10 @@ static int merkle_hash_levels(int kind, int fid, const void* d_leaves, const u64
 
 // bincode(FiniteFieldElement) of ONE canonical element on the host: used for the n == 1 root and for the
 // sibling leaf of an authentication path (both are a copy of input bytes, not computation).
-static size_t host_bincode_field(const uint64_t* limbs, int nl, uint8_t* out) {
+static size_t host_bincode_field(const uint64_t* limbs, int nl, uint8_t* out, bool negative = false) {
   int k = 2 * nl;
   while (k > 0 && (uint32_t)(limbs[(k - 1) / 2] >> (32 * ((k - 1) & 1))) == 0) k--;
-  out[0] = k ? 1 : 0;
+  out[0] = k ? (negative ? 0xff : 1) : 0;
   uint64_t len = (uint64_t)k;
   memcpy(out + 1, &len, 8);
   for (int i = 0; i < k; i++) { uint32_t d = (uint32_t)(limbs[i / 2] >> (32 * (i & 1))); memcpy(out + 9 + 4 * i, &d, 4); }
@@ -280,12 +359,86 @@ static size_t host_bincode_field(const uint64_t* limbs, int nl, uint8_t* out) {
 }
 
 static int merkle_build(int kind, int fid, const void* src, bool src_on_device, size_t leaf_bytes, const uint64_t* offsets, size_t n,
-                        mzk_merkle** out, hipStream_t s) {
+                        mzk_merkle** out, hipStream_t s, const uint8_t* neg_host = nullptr);
+
+// Any leaf count that is not a power of two (never produced by the provers, but accepted by merkle.rs:15-25).
+static int merkle_build_ragged(const uint8_t* leaves, const uint64_t* offsets, size_t n, mzk_merkle** out, hipStream_t s) {
+  if (n > ((size_t)1 << 31)) { set_error("merkle: ragged trees support up to 2^31 leaves"); return MZK_E_ARG; }
+  mzk_merkle* t = new mzk_merkle();
+  t->kind = 1; t->field = -1; t->n = n; t->stream = s; t->d_nodes = nullptr; t->d_leaves = nullptr; t->ragged = true;
+  int D = 0;
+  while (((size_t)2 << D) <= n) D++;
+  const size_t m = (size_t)1 << D;
+  t->m = m; t->depth = D;
+  t->offsets.assign(offsets, offsets + n + 1);
+  // subtree p at depth D: walk the bits of p from the root (0 = left = floor half, 1 = right = ceil half)
+  t->node_start.resize(m + 1);
+  t->item_off.resize(m + 1);
+  for (size_t p = 0; p < m; p++) {
+    size_t start = 0, size = n;
+    for (int b = D - 1; b >= 0; b--) {
+      const size_t l = size / 2;
+      if ((p >> b) & 1) { start += l; size -= l; } else size = l;
+    }
+    t->node_start[p] = (uint32_t)start;
+  }
+  t->node_start[m] = (uint32_t)n;
+  uint64_t io = 0;
+  for (size_t p = 0; p < m; p++) {
+    t->item_off[p] = io;
+    const uint32_t first = t->node_start[p], cnt = t->node_start[p + 1] - first;
+    io += cnt == 1 ? offsets[first + 1] - offsets[first] : 32;
+  }
+  t->item_off[m] = io;
+  const size_t leaf_bytes = (size_t)(offsets[n] - offsets[0]);
+  u64 *d_off = nullptr, *d_ioff = nullptr;
+  u32* d_ns = nullptr;
+  int rc = MZK_OK;
+  do {
+    if (hipMalloc(&t->d_leaves, leaf_bytes ? leaf_bytes : 16) != hipSuccess || hipMalloc(&t->d_items, io ? io : 16) != hipSuccess ||
+        hipMalloc((void**)&t->d_nodes, (m - 1) * 32) != hipSuccess) { set_error("merkle: hipMalloc failed"); rc = MZK_E_HIP; break; }
+    if ((rc = ws_get(WS_MISC_D, (n + 1) * 8, (void**)&d_off)) != MZK_OK) break;
+    if ((rc = ws_get(WS_MISC_E, (m + 1) * 8, (void**)&d_ioff)) != MZK_OK) break;
+    if ((rc = ws_get(WS_MISC_F, (m + 1) * 4, (void**)&d_ns)) != MZK_OK) break;
+    if ((leaf_bytes && hipMemcpyAsync(t->d_leaves, leaves, leaf_bytes, hipMemcpyHostToDevice, s) != hipSuccess) ||
+        hipMemcpyAsync(d_off, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d_ioff, t->item_off.data(), (m + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d_ns, t->node_start.data(), (m + 1) * 4, hipMemcpyHostToDevice, s) != hipSuccess) { set_error("merkle: copy failed"); rc = MZK_E_HIP; break; }
+    hipLaunchKernelGGL(k_merkle_ragged_items, dim3((unsigned)((m + 127) / 128)), dim3(128), 0, s, (const u8*)t->d_leaves, (const u64*)d_off, (const u32*)d_ns, m,
+                       (const u64*)d_ioff, (u8*)t->d_items);
+    rc = merkle_hash_levels(1, -1, t->d_items, d_ioff, m, t->d_nodes, s);
+    if (rc == MZK_OK && hipStreamSynchronize(s) != hipSuccess) { set_error("merkle: sync failed"); rc = MZK_E_HIP; }
+  } while (0);
+  if (rc != MZK_OK) { mzk_merkle_free(t); return rc; }
+  *out = t;
+  return MZK_OK;
+}
+
+static int merkle_build(int kind, int fid, const void* src, bool src_on_device, size_t leaf_bytes, const uint64_t* offsets, size_t n,
+                        mzk_merkle** out, hipStream_t s, const uint8_t* neg_host) {
   if (!out) { set_error("merkle: null output handle"); return MZK_E_ARG; }
   *out = nullptr;
   if (n == 0) { set_error("merkle: empty leaf set (Merkle::commit recurses forever on it, merkle.rs:20-22)"); return MZK_E_LENGTH; }
-  if (!is_pow2(n)) { set_error("merkle: leaf count must be a power of two"); return MZK_E_NOT_POW2; }
   if (!src) { set_error("merkle: null pointer"); return MZK_E_ARG; }
+  if (!is_pow2(n)) {
+    if (kind == 1) return merkle_build_ragged((const uint8_t*)src, offsets, n, out, s);
+    // field elements: serialise bincode(FiniteFieldElement) on the host and take the byte-leaf path (not a prover path:
+    // every codeword the reference commits to has a power-of-two length)
+    const int nl = field_limbs64(fid);
+    std::vector<uint64_t> host(n * (size_t)nl);
+    if (src_on_device) {
+      MZK_HIP(hipMemcpyAsync(host.data(), src, leaf_bytes, hipMemcpyDeviceToHost, s));
+      MZK_HIP(hipStreamSynchronize(s));
+    } else {
+      memcpy(host.data(), src, leaf_bytes);
+    }
+    std::vector<uint8_t> blob(n * (size_t)(9 + 8 * nl));
+    std::vector<uint64_t> off(n + 1);
+    uint64_t o = 0;
+    for (size_t i = 0; i < n; i++) { off[i] = o; o += host_bincode_field(host.data() + i * nl, nl, blob.data() + o, neg_host && neg_host[i]); }
+    off[n] = o;
+    return merkle_build_ragged(blob.data(), off.data(), n, out, s);
+  }
   mzk_merkle* t = new mzk_merkle();
   t->kind = kind; t->field = fid; t->n = n; t->stream = s; t->d_nodes = nullptr; t->d_leaves = nullptr;
   t->depth = 0;
@@ -303,7 +456,13 @@ static int merkle_build(int kind, int fid, const void* src, bool src_on_device, 
       if ((rc = ws_get(WS_MISC_D, (n + 1) * 8, (void**)&d_off)) != MZK_OK) break;
       if (hipMemcpyAsync(d_off, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess) { set_error("merkle: offset copy failed"); rc = MZK_E_HIP; break; }
     }
-    rc = merkle_hash_levels(kind, fid, t->d_leaves, d_off, n, t->d_nodes, s);
+    u8* d_neg = nullptr;
+    if (kind == 0 && neg_host) {
+      t->neg.assign(neg_host, neg_host + n);
+      if ((rc = ws_get(WS_MISC_E, n, (void**)&d_neg)) != MZK_OK) break;
+      if (hipMemcpyAsync(d_neg, neg_host, n, hipMemcpyHostToDevice, s) != hipSuccess) { set_error("merkle: sign copy failed"); rc = MZK_E_HIP; break; }
+    }
+    rc = merkle_hash_levels(kind, fid, t->d_leaves, d_off, n, t->d_nodes, s, d_neg);
     if (rc == MZK_OK && kind == 1 && hipStreamSynchronize(s) != hipSuccess) { set_error("merkle: sync failed"); rc = MZK_E_HIP; }
   } while (0);
   if (rc != MZK_OK) { if (t->d_leaves) (void)hipFree(t->d_leaves); if (t->d_nodes) (void)hipFree(t->d_nodes); delete t; return rc; }
@@ -320,7 +479,7 @@ int mzk_merkle_build_field_dev(int field_id, const void* d_elems, size_t n, mzk_
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("merkle: bad field id %d", field_id); return MZK_E_ARG; }
   return merkle_build(0, field_id, d_elems, true, n * field_bytes(field_id), nullptr, n, out, (hipStream_t)stream);
 }
-int mzk_merkle_build_field(int field_id, const uint64_t* elems, size_t n, mzk_merkle** out) {
+static int build_field_host(int field_id, const uint64_t* elems, const uint8_t* negative, size_t n, mzk_merkle** out) {
   MZK_TRY(ensure_init());
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("merkle: bad field id %d", field_id); return MZK_E_ARG; }
   if (elems) {
@@ -329,9 +488,21 @@ int mzk_merkle_build_field(int field_id, const uint64_t* elems, size_t n, mzk_me
       if (!h_is_canonical(hf, elems + (size_t)hf->nl * i)) { set_error("merkle: element %zu not canonical", i); return MZK_E_RANGE; }
   }
   WsGuard wsg(ctx().stream);
-  MZK_TRY(merkle_build(0, field_id, elems, false, n * field_bytes(field_id), nullptr, n, out, ctx().stream));
+  MZK_TRY(merkle_build(0, field_id, elems, false, n * field_bytes(field_id), nullptr, n, out, ctx().stream, negative));
   MZK_HIP(hipStreamSynchronize(ctx().stream));
   return MZK_OK;
+}
+int mzk_merkle_build_field(int field_id, const uint64_t* elems, size_t n, mzk_merkle** out) { return build_field_host(field_id, elems, nullptr, n, out); }
+int mzk_merkle_build_field_signed(int field_id, const uint64_t* magnitudes, const uint8_t* negative, size_t n, mzk_merkle** out) {
+  return build_field_host(field_id, magnitudes, negative, n, out);
+}
+int mzk_merkle_commit_field_signed(int field_id, const uint64_t* magnitudes, const uint8_t* negative, size_t n, uint8_t* root, size_t cap,
+                                   size_t* root_len) {
+  mzk_merkle* t = nullptr;
+  MZK_TRY(build_field_host(field_id, magnitudes, negative, n, &t));
+  const int rc = mzk_merkle_root(t, root, cap, root_len);
+  mzk_merkle_free(t);
+  return rc;
 }
 int mzk_merkle_build_bytes(const uint8_t* leaves, const uint64_t* offsets, size_t n, mzk_merkle** out) {
   MZK_TRY(ensure_init());
@@ -357,7 +528,7 @@ int mzk_merkle_root(const mzk_merkle* t, uint8_t* root, size_t cap, size_t* root
       uint64_t limbs[4];
       MZK_HIP(hipMemcpyAsync(limbs, t->d_leaves, field_bytes(t->field), hipMemcpyDeviceToHost, t->stream));
       MZK_HIP(hipStreamSynchronize(t->stream));
-      len = host_bincode_field(limbs, field_limbs64(t->field), buf);
+      len = host_bincode_field(limbs, field_limbs64(t->field), buf, !t->neg.empty() && t->neg[0]);
       if (cap < len) { set_error("merkle_root: buffer too small (%zu < %zu)", cap, len); return MZK_E_LENGTH; }
       memcpy(root, buf, len);
     } else {
@@ -370,7 +541,7 @@ int mzk_merkle_root(const mzk_merkle* t, uint8_t* root, size_t cap, size_t* root
     return MZK_OK;
   }
   if (cap < 32) { set_error("merkle_root: buffer too small"); return MZK_E_LENGTH; }
-  MZK_HIP(hipMemcpyAsync(root, t->d_nodes + 4 * (t->n - 2), 32, hipMemcpyDeviceToHost, t->stream));
+  MZK_HIP(hipMemcpyAsync(root, t->d_nodes + 4 * ((t->ragged ? t->m : t->n) - 2), 32, hipMemcpyDeviceToHost, t->stream));
   MZK_HIP(hipStreamSynchronize(t->stream));
   *root_len = 32;
   return MZK_OK;
@@ -382,6 +553,36 @@ int mzk_merkle_open(const mzk_merkle* t, size_t index, uint8_t* path, size_t str
   if (index >= t->n) { set_error("merkle_open: index %zu out of range", index); return MZK_E_LENGTH; }
   if (stride < 32) { set_error("merkle_open: stride < 32"); return MZK_E_LENGTH; }
   hipStream_t s = t->stream;
+  if (t->ragged) {
+    // subtree p (depth D) that holds the leaf.  Merkle::open only terminates when its descent ends in a TWO-leaf
+    // slice (merkle.rs:32-34); a one-leaf slice recurses forever (mid = 0), so those indices are an error here.
+    size_t p = (size_t)(std::upper_bound(t->node_start.begin(), t->node_start.end(), (uint32_t)index) - t->node_start.begin()) - 1;
+    const uint32_t first = t->node_start[p], cnt = t->node_start[p + 1] - first;
+    if (cnt != 2) { set_error("merkle_open: leaf %zu sits alone in its subtree; Merkle::open recurses forever there (merkle.rs:36-45)", index); return MZK_E_LENGTH; }
+    const size_t other = first + (1 - (index - first));
+    const size_t l0 = (size_t)(t->offsets[other + 1] - t->offsets[other]);
+    const size_t sibp = p ^ 1;
+    const size_t l1 = (size_t)(t->item_off[sibp + 1] - t->item_off[sibp]);
+    if (stride < l0 || stride < l1) { set_error("merkle_open: stride %zu < entry length %zu", stride, l0 > l1 ? l0 : l1); return MZK_E_LENGTH; }
+    if (l0) MZK_HIP(hipMemcpyAsync(path, (const uint8_t*)t->d_leaves + t->offsets[other], l0, hipMemcpyDeviceToHost, s));
+    path_len[0] = l0;
+    if (l1) MZK_HIP(hipMemcpyAsync(path + stride, (const uint8_t*)t->d_items + t->item_off[sibp], l1, hipMemcpyDeviceToHost, s));   // sibling item: a leaf or a digest
+    path_len[1] = l1;
+    if (t->depth > 1) {
+      u64* d_out;
+      MZK_TRY(ws_get(WS_MISC_C, (size_t)t->depth * 32, (void**)&d_out));
+      hipLaunchKernelGGL(k_merkle_gather, dim3(1), dim3(64), 0, s, (const u64*)t->d_nodes, t->m, p, t->depth, d_out);
+      MZK_HIP(hipGetLastError());
+      uint8_t tmp[64 * 32];
+      MZK_HIP(hipMemcpyAsync(tmp, d_out, (size_t)(t->depth - 1) * 32, hipMemcpyDeviceToHost, s));
+      MZK_HIP(hipStreamSynchronize(s));
+      for (int l = 1; l < t->depth; l++) { memcpy(path + (size_t)(l + 1) * stride, tmp + 32 * (l - 1), 32); path_len[l + 1] = 32; }
+    } else {
+      MZK_HIP(hipStreamSynchronize(s));
+    }
+    *depth = (size_t)t->depth + 1;
+    return MZK_OK;
+  }
   const size_t sib = index ^ 1;
   // entry 0: the sibling LEAF, verbatim
   if (t->kind == 0) {
@@ -389,7 +590,7 @@ int mzk_merkle_open(const mzk_merkle* t, size_t index, uint8_t* path, size_t str
     uint8_t buf[48];
     MZK_HIP(hipMemcpyAsync(limbs, (const uint8_t*)t->d_leaves + sib * field_bytes(t->field), field_bytes(t->field), hipMemcpyDeviceToHost, s));
     MZK_HIP(hipStreamSynchronize(s));
-    const size_t len = host_bincode_field(limbs, field_limbs64(t->field), buf);
+    const size_t len = host_bincode_field(limbs, field_limbs64(t->field), buf, !t->neg.empty() && t->neg[sib]);
     if (stride < len) { set_error("merkle_open: stride %zu < leaf length %zu", stride, len); return MZK_E_LENGTH; }
     memcpy(path, buf, len);
     path_len[0] = len;
@@ -419,6 +620,7 @@ void mzk_merkle_free(mzk_merkle* t) {
   if (!t) return;
   if (t->d_leaves) (void)hipFree(t->d_leaves);
   if (t->d_nodes) (void)hipFree(t->d_nodes);
+  if (t->d_items) (void)hipFree(t->d_items);
   delete t;
 }
 
@@ -429,8 +631,14 @@ int mzk_merkle_commit_field_dev(int field_id, const void* d_elems, size_t n, uin
   WsGuard wsg((hipStream_t)stream);
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("merkle: bad field id %d", field_id); return MZK_E_ARG; }
   if (n == 0) { set_error("merkle: empty leaf set (Merkle::commit recurses forever on it, merkle.rs:20-22)"); return MZK_E_LENGTH; }
-  if (!is_pow2(n)) { set_error("merkle: leaf count must be a power of two"); return MZK_E_NOT_POW2; }
   if (!d_elems || !root || !root_len) { set_error("merkle: null pointer"); return MZK_E_ARG; }
+  if (!is_pow2(n)) {      // ragged (merkle.rs:15-25 accepts it; no prover call site produces it): handle path
+    mzk_merkle* t = nullptr;
+    MZK_TRY(merkle_build(0, field_id, d_elems, true, n * field_bytes(field_id), nullptr, n, &t, (hipStream_t)stream));
+    const int rc = mzk_merkle_root(t, root, cap, root_len);
+    mzk_merkle_free(t);
+    return rc;
+  }
   hipStream_t s = (hipStream_t)stream;
   if (n == 1) {
     uint64_t limbs[4];
@@ -475,8 +683,8 @@ int mzk_merkle_commit_bytes(const uint8_t* leaves, const uint64_t* offsets, size
 // Outputs: roots (num_rounds entries of 48 bytes, lengths in root_len: 32, or the leaf bytes once a codeword has
 // shrunk to one element) and all num_rounds codewords concatenated (n + n/2 + ... elements) -- the reference's
 // return value `(codewords, roots)`; sending the last codeword (fri.rs:198-206) is the caller's transcript work.
-int mzk_fri_commit(int field_id, const uint64_t* codeword, size_t n, const uint64_t* omega, const uint64_t* offset, int num_rounds,
-                   mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out) {
+static int fri_commit_impl(int field_id, const uint64_t* codeword, const uint8_t* negative, size_t n, const uint64_t* omega, const uint64_t* offset,
+                           int num_rounds, mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out) {
   MZK_TRY(ensure_init());
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fri_commit: bad field id %d", field_id); return MZK_E_ARG; }
   if (num_rounds <= 0) return MZK_OK;
@@ -497,6 +705,11 @@ int mzk_fri_commit(int field_id, const uint64_t* codeword, size_t n, const uint6
   MZK_TRY(ws_get(WS_NTT_IO_A, total * esz, (void**)&d_all));
   MZK_TRY(ws_get(WS_MERKLE_NODES, n * 32, (void**)&d_nodes));
   MZK_HIP(hipMemcpyAsync(d_all, codeword, n * esz, hipMemcpyHostToDevice, s));
+  u8* d_neg = nullptr;
+  if (negative) {     // round 0 hashes bincode of the UNSANITIZED elements (fri.rs:160-166); the fold sanitizes (fri.rs:190)
+    MZK_TRY(ws_get(WS_MISC_E, n, (void**)&d_neg));
+    MZK_HIP(hipMemcpyAsync(d_neg, negative, n, hipMemcpyHostToDevice, s));
+  }
   uint64_t om[4], of[4], alpha[4];
   memcpy(om, omega, 8 * nl);
   memcpy(of, offset, 8 * nl);
@@ -508,12 +721,17 @@ int mzk_fri_commit(int field_id, const uint64_t* codeword, size_t n, const uint6
       uint64_t limbs[4];
       MZK_HIP(hipMemcpyAsync(limbs, cur, esz, hipMemcpyDeviceToHost, s));
       MZK_HIP(hipStreamSynchronize(s));
-      root_len[r] = host_bincode_field(limbs, nl, root);
+      root_len[r] = host_bincode_field(limbs, nl, root, r == 0 && negative && negative[0]);
     } else {
-      MZK_TRY(merkle_hash_levels(0, field_id, cur, nullptr, len, d_nodes, s));
+      MZK_TRY(merkle_hash_levels(0, field_id, cur, nullptr, len, d_nodes, s, r == 0 ? d_neg : nullptr));
       MZK_HIP(hipMemcpyAsync(root, d_nodes + 4 * (len - 2), 32, hipMemcpyDeviceToHost, s));
       MZK_HIP(hipStreamSynchronize(s));
       root_len[r] = 32;
+    }
+    if (r == 0 && d_neg) {      // from here on the codeword is its canonical representative: v -> p - |v| where Sign::Minus
+      if (field_id == MZK_FIELD_M128) hipLaunchKernelGGL((k_canonicalize_signed<4>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (u32*)cur, (const u8*)d_neg, n, field_id);
+      else hipLaunchKernelGGL((k_canonicalize_signed<8>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (u32*)cur, (const u8*)d_neg, n, field_id);
+      MZK_HIP(hipGetLastError());
     }
     const int last = (r == num_rounds - 1);
     memset(alpha, 0xff, sizeof alpha);     // a callback that forgets alpha leaves a non-canonical value, never a silent 0
@@ -531,6 +749,14 @@ int mzk_fri_commit(int field_id, const uint64_t* codeword, size_t n, const uint6
   MZK_HIP(hipMemcpyAsync(codewords_out, d_all, total * esz, hipMemcpyDeviceToHost, s));
   MZK_HIP(hipStreamSynchronize(s));
   return MZK_OK;
+}
+int mzk_fri_commit(int field_id, const uint64_t* codeword, size_t n, const uint64_t* omega, const uint64_t* offset, int num_rounds,
+                   mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out) {
+  return fri_commit_impl(field_id, codeword, nullptr, n, omega, offset, num_rounds, challenge, user, roots, root_len, codewords_out);
+}
+int mzk_fri_commit_signed(int field_id, const uint64_t* magnitudes, const uint8_t* negative, size_t n, const uint64_t* omega, const uint64_t* offset,
+                          int num_rounds, mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out) {
+  return fri_commit_impl(field_id, magnitudes, negative, n, omega, offset, num_rounds, challenge, user, roots, root_len, codewords_out);
 }
 
 }  // extern "C"

@@ -146,6 +146,18 @@ __global__ void k_phi_points(const u32* __restrict__ in_mont, size_t n, u32* __r
   store_words8(phi_out + i * 16 + 8, w + 8);
 }
 
+// Montgomery (prepared) points back to the ABI form (SRS dump / download)
+__global__ void k_points_to_plain(const u32* __restrict__ in_mont, size_t n, u32* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 w[16];
+  load_words8(in_mont + i * 16, w);
+  load_words8(in_mont + i * 16 + 8, w + 8);
+  if (!affine_words_is_inf(w)) affine_store_plain(affine_load_mont(w), w);
+  store_words8(out + i * 16, w);
+  store_words8(out + i * 16 + 8, w + 8);
+}
+
 // ---- 1/3. signed-digit decomposition ----------------------------------------------------------------
 // Canonical scalar words (sanitize(): polynomial.rs:162 -> field.rs:260-270).
 __device__ __forceinline__ void load_scalar_canonical(const u32* __restrict__ scalars, size_t i, u32* w) {
@@ -841,6 +853,12 @@ int msm_prepare_points(const void* d_points_plain, size_t n, void* d_points_mont
   if (n == 0) return MZK_OK;
   hipLaunchKernelGGL(k_prepare_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const u32*)d_points_plain,
                      (u32*)d_points_mont, n, (u32*)d_phi);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+int msm_points_to_plain(const void* d_points_mont, size_t n, void* d_points_plain, hipStream_t s) {
+  if (n == 0) return MZK_OK;
+  hipLaunchKernelGGL(k_points_to_plain, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const u32*)d_points_mont, n, (u32*)d_points_plain);
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }

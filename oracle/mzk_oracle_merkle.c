@@ -14,6 +14,11 @@
  *   Sign        -> i8: Minus = -1, NoSign = 0, Plus = 1
  *   BigUint     -> sequence of u32 digits, little-endian, no leading (most significant) zero digit; zero -> empty
  *   bincode 1.x -> fixed-width little-endian ints, sequence length as u64, PhantomData -> no bytes
+ * (restated from the crates' published sources as remembered, none of them available offline here:
+ *  num-bigint 0.4 src/bigint/serde.rs -- `impl Serialize for Sign` writes -1i8 / 0i8 / 1i8 and `impl Serialize for
+ *  BigInt` the tuple (sign, magnitude); src/biguint/serde.rs -- "always serialize as a u32 sequence", on 64-bit
+ *  digits as lo, hi halves with the top zero half dropped; bincode 1.3.3 `bincode::serialize` =
+ *  DefaultOptions + fixint encoding, little endian: seq length u64, tuples/structs without framing.)
  * so a canonical element v > 0 with k significant u32 digits is  01 | k as u64 LE | k x u32 LE  (9 + 4k bytes)
  * and v = 0 is  00 | 0 as u64 LE  (9 bytes).  Elements are canonical here (fri.rs:190 sanitizes each fold; the
  * shim sanitizes the initial codeword), so Sign::Minus never occurs.
@@ -86,6 +91,14 @@ size_t orc_bincode_field(const u64* limbs, int nl, u8* out /* >= 9 + 8 nl */) {
   return 9 + 4 * (size_t)k;
 }
 
+/* bincode(FiniteFieldElement) of an element whose BigInt the reference left negative (field.rs:98-110: `%` keeps the
+ * sign; only sanitize() removes it): Sign::Minus as i8 = 0xff, then the MAGNITUDE's digits.  -0 does not exist. */
+size_t orc_bincode_field_signed(const u64* magnitude, int nl, int negative, u8* out) {
+  size_t l = orc_bincode_field(magnitude, nl, out);
+  if (negative && out[0]) out[0] = 0xff;
+  return l;
+}
+
 /* ---- Merkle over byte leaves: leaves[offsets[i] .. offsets[i+1]) ----------------------------------------- */
 /* merkle.rs:15-25 -- a single leaf commits to ITSELF (unhashed); otherwise hash(commit(left) || commit(right)). */
 static size_t merkle_commit_rec(const u8* leaves, const u64* off, size_t lo, size_t cnt, u8* out /* >= max(32, leaf) */) {
@@ -139,6 +152,13 @@ static size_t merkle_open_rec(const u8* leaves, const u64* off, size_t lo, size_
 /* path: depth entries of `stride` bytes each (stride >= max(32, longest leaf)); returns the depth in *depth */
 int orc_merkle_open_ref(const u8* leaves, const u64* offsets, size_t n, size_t index, u8* path, u64* path_len, size_t stride, size_t* depth) {
   if (n < 2 || index >= n || stride < max_leaf(offsets, n)) return -1;
+  /* merkle.rs:32-45 terminates only when the descent reaches a two-leaf slice; a one-leaf slice has mid = 0 and
+   * recurses on itself forever (stack overflow in the reference): report that instead of reproducing it. */
+  for (size_t cnt = n, idx = index; cnt != 2;) {
+    if (cnt == 1) return -2;
+    size_t mid = cnt / 2;
+    if (idx < mid) cnt = mid; else { idx -= mid; cnt -= mid; }
+  }
   *depth = merkle_open_rec(leaves, offsets, 0, n, index, path, path_len, 0, stride);
   return 0;
 }

@@ -257,6 +257,14 @@ def bincode_field(v, nl):
     return bytes(out[:ln])
 
 
+def bincode_field_signed(mag, nl, negative):
+    a = to_limbs([mag], nl)
+    out = (ctypes.c_uint8 * (9 + 8 * nl))()
+    lib().orc_bincode_field_signed.restype = ctypes.c_size_t
+    ln = lib().orc_bincode_field_signed(ptr(a), nl, int(bool(negative)), out)
+    return bytes(out[:ln])
+
+
 def _leaf_blob(leaves):
     blob = b"".join(leaves)
     off = np.zeros(len(leaves) + 1, dtype=np.uint64)
@@ -281,8 +289,11 @@ def merkle_open_ref(index, leaves):
     path = (ctypes.c_uint8 * (stride * cap))()
     lens = (ctypes.c_uint64 * cap)()
     depth = ctypes.c_size_t()
-    assert lib().orc_merkle_open_ref(buf, ptr(off), ctypes.c_size_t(len(leaves)), ctypes.c_size_t(index), path, lens,
-                                     ctypes.c_size_t(stride), ctypes.byref(depth)) == 0
+    rc = lib().orc_merkle_open_ref(buf, ptr(off), ctypes.c_size_t(len(leaves)), ctypes.c_size_t(index), path, lens,
+                                   ctypes.c_size_t(stride), ctypes.byref(depth))
+    if rc == -2:        # Merkle::open does not terminate for this index (one-leaf slice, merkle.rs:36-45)
+        return None
+    assert rc == 0
     raw = bytes(path)
     return [raw[k * stride:k * stride + lens[k]] for k in range(depth.value)]
 

@@ -82,9 +82,6 @@ def test_contract_violations(mz):
     with pytest.raises(mz.MzkError) as e:
         mz.merkle_commit_field(M128, np.zeros((0, 2), dtype=np.uint64))
     assert e.value.code == -5
-    with pytest.raises(mz.MzkError) as e:
-        mz.merkle_commit_field(M128, orc.synth_vector(M128, 1, 3))
-    assert e.value.code == -2
     bad = orc.synth_vector(M128, 1, 4)
     bad[2] = orc.to_limbs([orc.MOD[M128]], 2)[0]
     with pytest.raises(mz.MzkError) as e:
@@ -96,6 +93,52 @@ def test_contract_violations(mz):
     one = mz.MerkleTree(M128, orc.synth_vector(M128, 1, 1))
     with pytest.raises(mz.MzkError):
         one.open(0)
+
+
+@pytest.mark.parametrize("n", [3, 5, 6, 7, 9, 12, 13, 100, 1000, 1025, 4097, 12345])
+def test_ragged_leaf_counts_match_the_reference_recursion(mz, n):
+    """merkle.rs:15-25 splits at mid = len / 2 for ANY length: byte leaves of mixed lengths, and field codewords, on
+    leaf counts that are not powers of two; roots and every terminating authentication path equal the oracle's
+    literal recursion, the non-terminating ones (leaf alone in its subtree: Merkle::open recurses forever) are errors."""
+    rnd = random.Random(n)
+    leaves = [bytes(rnd.randrange(256) for _ in range(rnd.choice([0, 1, 9, 25, 32, 41, 135, 136, 137, 300]))) for _ in range(n)]
+    t = mz.MerkleTree(leaves=leaves)
+    root = t.root()
+    assert root == orc.merkle_commit_ref(leaves)
+    opened = refused = 0
+    for idx in (range(n) if n <= 13 else sorted({0, 1, 2, n - 1, n - 2, n // 2, n // 3} | {rnd.randrange(n) for _ in range(10)})):
+        want = orc.merkle_open_ref(idx, leaves)
+        if want is None:
+            with pytest.raises(mz.MzkError) as e:
+                t.open(idx)
+            assert e.value.code == -5
+            refused += 1
+        else:
+            path = t.open(idx)
+            assert path == want, idx
+            opened += 1
+    assert opened > 0 and (refused > 0 or n in (6, 12))      # 6 and 12 split into two-leaf subtrees only
+    t.close()
+    for fid in (M128, FR):
+        arr = _edge_vector(fid, 500 + n, n)
+        want = orc.merkle_commit_ref(orc.field_leaves(fid, arr))
+        assert mz.merkle_commit_field(fid, arr) == want
+        tt = mz.MerkleTree(fid, arr)
+        assert tt.root() == want
+        tt.close()
+
+
+def test_ragged_one_shot_device_commit(mz):
+    import torch
+    L = mz.lib()
+    dev = torch.device("cuda", 0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    n = 777
+    arr = _edge_vector(M128, 42, n)
+    d = torch.from_numpy(arr.view(np.int64).reshape(-1).copy()).to(dev)
+    root, ln = (ctypes.c_uint8 * 48)(), ctypes.c_size_t()
+    assert L.mzk_merkle_commit_field_dev(M128, ctypes.c_void_p(d.data_ptr()), ctypes.c_size_t(n), root, ctypes.c_size_t(48), ctypes.byref(ln), st) == 0
+    assert bytes(root[:ln.value]) == orc.merkle_commit_ref(orc.field_leaves(M128, arr))
 
 
 def test_device_resident_fri_commit_loop(mz):
@@ -181,3 +224,63 @@ def test_fri_commit_contract_violations(mz):
     with pytest.raises(mz.MzkError) as e:
         mz.fri_commit(M128, cw, orc.root_of(M128, 3), 3, 2, lambda *a: orc.MOD[M128])   # non-canonical challenge
     assert e.value.code == -6
+
+
+@pytest.mark.parametrize("fid,n", [(M128, 1), (M128, 2), (M128, 64), (FR, 256), (M128, 1000)])
+def test_signed_leaves_reproduce_bincode_of_unsanitized_elements(mz, fid, n):
+    """SURVEY F6 / VERDICT r01 weak #8: the reference's round-0 FRI root hashes bincode(c) of UNSANITIZED elements
+    (fri.rs:160-166); a negative BigInt serialises as Sign::Minus + magnitude.  The *_signed entry points take
+    (magnitude, negative) and must hash exactly those bytes; paths too."""
+    nl = orc.LIMBS[fid]
+    mag = _edge_vector(fid, 600 + n, n)
+    rnd = random.Random(n)
+    neg = np.array([rnd.randrange(2) for _ in range(n)], dtype=np.uint8)
+    leaves = [orc.bincode_field_signed(v, nl, s) for v, s in zip(orc.from_limbs(mag), neg)]
+    assert any(l[0] == 0xff for l in leaves) or n < 4
+    t = mz.MerkleTree(fid, mag, negative=neg)
+    assert t.root() == orc.merkle_commit_ref(leaves)
+    if n >= 2:
+        for idx in {0, 1, n - 1, n // 2}:
+            want = orc.merkle_open_ref(idx, leaves)
+            if want is not None:
+                assert t.open(idx) == want
+    t.close()
+
+
+def test_fri_commit_signed_round0_root_then_canonical_folds(mz):
+    fid, lg, rounds = M128, 8, 4
+    n, p = 1 << lg, orc.MOD[M128]
+    mag = _edge_vector(fid, 777, n)
+    neg = np.array([(i * 7) % 3 == 0 for i in range(n)], dtype=np.uint8)
+    omega, offset = orc.root_of(fid, lg), orc.M128_GEN
+
+    def challenge(rnd, last, root):
+        return None if last else int.from_bytes(hashlib.sha3_256(root + bytes([rnd])).digest(), "little") % p
+
+    cws, roots = mz.fri_commit(fid, mag, omega, offset, rounds, challenge, negative=neg)
+    leaves0 = [orc.bincode_field_signed(v, 2, s) for v, s in zip(orc.from_limbs(mag), neg)]
+    assert roots[0] == orc.merkle_commit_ref(leaves0)
+    canon = orc.to_limbs([(p - v) % p if s else v for v, s in zip(orc.from_limbs(mag), neg)], 2)
+    assert np.array_equal(cws[0], canon)
+    cur, om, of = canon, omega, offset
+    for r in range(rounds - 1):
+        alpha = int.from_bytes(hashlib.sha3_256(roots[r] + bytes([r])).digest(), "little") % p
+        cur = orc.fri_fold_ref(fid, cur, alpha, of, om)
+        om, of = om * om % p, of * of % p
+        assert np.array_equal(cws[r + 1], cur)
+        assert roots[r + 1] == orc.merkle_commit_ref(orc.field_leaves(fid, cur))
+
+
+def test_fri_commit_callback_exception_aborts_instead_of_folding_with_zero(mz):
+    """an exception in the transcript callback must surface, not fold with alpha = 0."""
+    cw = orc.synth_vector(M128, 3, 16)
+
+    def challenge(rnd, last, root):
+        if rnd == 1:
+            raise KeyError("transcript exploded")
+        return 5
+
+    with pytest.raises(KeyError):
+        mz.fri_commit(M128, cw, orc.root_of(M128, 4), orc.M128_GEN, 3, challenge)
+    with pytest.raises(ValueError):
+        mz.fri_commit(M128, cw, orc.root_of(M128, 4), orc.M128_GEN, 3, lambda *a: None)      # forgot to return alpha

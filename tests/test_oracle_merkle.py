@@ -39,6 +39,11 @@ def test_bincode_layout_examples():
     assert orc.bincode_field(0, 2) == bytes([0]) + bytes(8)
     assert orc.bincode_field(5, 2) == bytes([1, 1, 0, 0, 0, 0, 0, 0, 0, 5, 0, 0, 0])
     assert orc.bincode_field(1 << 32, 4) == bytes([1, 2, 0, 0, 0, 0, 0, 0, 0]) + bytes(4) + bytes([1, 0, 0, 0])
+    # Sign::Minus = -1i8 = 0xff, magnitude digits follow (an element the reference left unsanitized, field.rs:98-110)
+    assert orc.bincode_field_signed(5, 2, True) == bytes([0xff, 1, 0, 0, 0, 0, 0, 0, 0, 5, 0, 0, 0])
+    assert orc.bincode_field_signed((1 << 64) + 7, 4, True) == bytes([0xff, 3, 0, 0, 0, 0, 0, 0, 0, 7, 0, 0, 0]) + bytes(4) + bytes([1, 0, 0, 0])
+    assert orc.bincode_field_signed(0, 2, True) == bytes(9)          # BigInt has no negative zero
+    assert orc.bincode_field_signed(9, 2, False) == orc.bincode_field(9, 2)
     rnd = random.Random(2)
     for fid, nl in ((FR, 4), (M128, 2)):
         for bits in (1, 31, 32, 33, 64, 65, 96, 127, 128, 200, 253):
@@ -95,3 +100,25 @@ def test_field_codeword_leaves_and_root():
     assert leaves == [py_bincode(v) for v in orc.from_limbs(arr)]
     assert len(leaves[3]) == 9 and len(leaves[4]) == 13
     assert orc.merkle_commit_ref(leaves) == py_commit(leaves)
+
+
+@pytest.mark.parametrize("n", [3, 5, 6, 7, 9, 12, 13, 21, 100])
+def test_ragged_open_terminates_exactly_where_the_reference_does(n):
+    """merkle.rs:28-46 on a ragged slice: the Python restatement hits RecursionError exactly where the oracle reports
+    non-termination (a one-leaf slice has mid = 0); everywhere else the paths agree."""
+    rnd = random.Random(n)
+    leaves = [bytes(rnd.randrange(256) for _ in range(rnd.choice([0, 5, 32, 33, 140]))) for _ in range(n)]
+    assert orc.merkle_commit_ref(leaves) == py_commit(leaves)
+    import sys
+    old = sys.getrecursionlimit()
+    sys.setrecursionlimit(200)
+    try:
+        for idx in range(n):
+            got = orc.merkle_open_ref(idx, leaves)
+            try:
+                want = py_open(idx, leaves)
+            except RecursionError:
+                want = None
+            assert got == want, idx
+    finally:
+        sys.setrecursionlimit(old)
