@@ -135,9 +135,9 @@ int mzk_fri_fold_dev(int field_id, const void* d_codeword, size_t n, const uint6
  * are not hashed themselves; a one-leaf tree commits to the leaf bytes.  n = 0 is an error (the reference recurses
  * forever).  Any n >= 1 is accepted like merkle.rs:15-25 does (mid = len / 2): the provers only commit to
  * power-of-two codewords, which take the fast path; other counts are reduced to the power-of-two tree over the
- * 2^floor(log2 n) one- or two-leaf subtrees at the bottom.  Merkle::open on a ragged tree only terminates for a
- * leaf inside a two-leaf subtree (merkle.rs:32-34); mzk_merkle_open returns MZK_E_LENGTH for the others instead of
- * recursing forever, and the path then has floor(log2 n) + 1 entries.  A handle keeps its own copy of the leaves
+ * 2^floor(log2 n) one- or two-leaf subtrees at the bottom.  Merkle::open on a ragged tree only terminates when its
+ * descent ends on a two-leaf slice (merkle.rs:32-34); for the one-leaf half of a three-leaf slice it recurses
+ * forever, and mzk_merkle_open returns MZK_E_LENGTH there.  Paths have floor(log2 n) or floor(log2 n) + 1 entries.  A handle keeps its own copy of the leaves
  * and all node levels in HBM so that many paths can be opened against one codeword. */
 typedef struct mzk_merkle mzk_merkle;
 int mzk_merkle_build_field(int field_id, const uint64_t* elems, size_t n, mzk_merkle** out);

@@ -105,6 +105,7 @@ static inline size_t field_bytes(int fid) { return fid == MZK_FIELD_M128 ? 16 : 
 // ---- entry points implemented per translation unit ------------------------------------------------
 int ntt_dev_impl(int fid, const uint64_t* root_host, const void* d_in, void* d_out, size_t n, int inverse,
                  const uint64_t* extra_scale_host, hipStream_t s);
+int ntt_batch_dev_impl(int fid, const uint64_t* root_host, const void* d_in, void* d_out, size_t n, size_t batch, int inverse, hipStream_t s);
 int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_t* offset_host,
                        const uint64_t* generator_host, void* d_out, size_t order, hipStream_t s);
 int coset_divide_dev_impl(int fid, const void* d_lhs, size_t tl, const void* d_rhs, size_t tr, const uint64_t* offset_host,

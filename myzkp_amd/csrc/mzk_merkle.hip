@@ -558,16 +558,27 @@ int mzk_merkle_open(const mzk_merkle* t, size_t index, uint8_t* path, size_t str
     // slice (merkle.rs:32-34); a one-leaf slice recurses forever (mid = 0), so those indices are an error here.
     size_t p = (size_t)(std::upper_bound(t->node_start.begin(), t->node_start.end(), (uint32_t)index) - t->node_start.begin()) - 1;
     const uint32_t first = t->node_start[p], cnt = t->node_start[p + 1] - first;
-    if (cnt != 2) { set_error("merkle_open: leaf %zu sits alone in its subtree; Merkle::open recurses forever there (merkle.rs:36-45)", index); return MZK_E_LENGTH; }
-    const size_t other = first + (1 - (index - first));
-    const size_t l0 = (size_t)(t->offsets[other + 1] - t->offsets[other]);
     const size_t sibp = p ^ 1;
+    const uint32_t sib_cnt = t->node_start[sibp + 1] - t->node_start[sibp];
+    if (cnt == 1 && sib_cnt != 1) {
+      set_error("merkle_open: leaf %zu is the one-leaf half of a three-leaf slice; Merkle::open recurses forever there (merkle.rs:36-45)", index);
+      return MZK_E_LENGTH;
+    }
+    // cnt == 2: the recursion ends inside subtree p (entry 0 = the other leaf), then climbs the item tree;
+    // cnt == 1 with a one-leaf sibling: it ends one level higher, on the two-leaf slice {p, p ^ 1} -- the item path itself.
+    int k = 0;
+    if (cnt == 2) {
+      const size_t other = first + (1 - (index - first));
+      const size_t l0 = (size_t)(t->offsets[other + 1] - t->offsets[other]);
+      if (stride < l0) { set_error("merkle_open: stride %zu < entry length %zu", stride, l0); return MZK_E_LENGTH; }
+      if (l0) MZK_HIP(hipMemcpyAsync(path, (const uint8_t*)t->d_leaves + t->offsets[other], l0, hipMemcpyDeviceToHost, s));
+      path_len[0] = l0;
+      k = 1;
+    }
     const size_t l1 = (size_t)(t->item_off[sibp + 1] - t->item_off[sibp]);
-    if (stride < l0 || stride < l1) { set_error("merkle_open: stride %zu < entry length %zu", stride, l0 > l1 ? l0 : l1); return MZK_E_LENGTH; }
-    if (l0) MZK_HIP(hipMemcpyAsync(path, (const uint8_t*)t->d_leaves + t->offsets[other], l0, hipMemcpyDeviceToHost, s));
-    path_len[0] = l0;
-    if (l1) MZK_HIP(hipMemcpyAsync(path + stride, (const uint8_t*)t->d_items + t->item_off[sibp], l1, hipMemcpyDeviceToHost, s));   // sibling item: a leaf or a digest
-    path_len[1] = l1;
+    if (stride < l1) { set_error("merkle_open: stride %zu < entry length %zu", stride, l1); return MZK_E_LENGTH; }
+    if (l1) MZK_HIP(hipMemcpyAsync(path + (size_t)k * stride, (const uint8_t*)t->d_items + t->item_off[sibp], l1, hipMemcpyDeviceToHost, s));   // sibling item: a leaf or a digest
+    path_len[k] = l1;
     if (t->depth > 1) {
       u64* d_out;
       MZK_TRY(ws_get(WS_MISC_C, (size_t)t->depth * 32, (void**)&d_out));
@@ -576,11 +587,11 @@ int mzk_merkle_open(const mzk_merkle* t, size_t index, uint8_t* path, size_t str
       uint8_t tmp[64 * 32];
       MZK_HIP(hipMemcpyAsync(tmp, d_out, (size_t)(t->depth - 1) * 32, hipMemcpyDeviceToHost, s));
       MZK_HIP(hipStreamSynchronize(s));
-      for (int l = 1; l < t->depth; l++) { memcpy(path + (size_t)(l + 1) * stride, tmp + 32 * (l - 1), 32); path_len[l + 1] = 32; }
+      for (int l = 1; l < t->depth; l++) { memcpy(path + (size_t)(l + k) * stride, tmp + 32 * (l - 1), 32); path_len[l + k] = 32; }
     } else {
       MZK_HIP(hipStreamSynchronize(s));
     }
-    *depth = (size_t)t->depth + 1;
+    *depth = (size_t)t->depth + k;
     return MZK_OK;
   }
   const size_t sib = index ^ 1;

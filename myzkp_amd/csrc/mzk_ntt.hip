@@ -214,26 +214,34 @@ __global__ __launch_bounds__(NTHREADS) void k_ntt_strided(const u32* __restrict_
 }
 
 // Last pass: contiguous rows of 2^lgn, transposed scatter; optional final scale (n^-1 for a
-// single-pass inverse), canonical output.
+// single-pass inverse), canonical output.  The grid may cover a BATCH of transforms stored back to back (row
+// r = blockIdx * 2^lgr + rr belongs to transform r >> lg_rows): the product trees of mzk_poly.hip transform hundreds
+// of small polynomials per launch.
 template <class P>
 __global__ __launch_bounds__(NTHREADS) void k_ntt_last(const u32* __restrict__ in, u32* __restrict__ out,
                                                         const u32* __restrict__ tw_tile, LevelInfo li, int lgn, int lgr,
-                                                        int lg_rows, Words8 scale, int has_scale) {
+                                                        int lg_rows, Words8 scale, int has_scale, size_t total_rows) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   const int tid = threadIdx.x;
   const size_t p0 = (size_t)blockIdx.x << lgr;
   const int rmask = (1 << lgr) - 1, nmask = (1 << lgn) - 1;
   const int tile_elems = 1 << (lgn + lgr);
+  const size_t rowmask = ((size_t)1 << lg_rows) - 1;
+  const int logn = lg_rows + lgn;
   u32* twl = lds + P::L * TILE;
   stage_twiddles<P>(twl, tw_tile, lgn);
   for (int e = tid; e < tile_elems; e += NTHREADS) {
     const int rr = e >> lgn, j = e & nmask;
-    size_t rem = p0 + rr, row = 0;
-    for (int i = 0; i < li.nlev - 1; i++) {
-      row = (row << li.lg[i]) | (rem & (((size_t)1 << li.lg[i]) - 1));
-      rem >>= li.lg[i];
+    const size_t r = p0 + rr;
+    Fe<P> v = fe_zero<P>();
+    if (r < total_rows) {
+      size_t rem = r & rowmask, row = 0;
+      for (int i = 0; i < li.nlev - 1; i++) {
+        row = (row << li.lg[i]) | (rem & (((size_t)1 << li.lg[i]) - 1));
+        rem >>= li.lg[i];
+      }
+      v = gload<P>(in, ((r >> lg_rows) << logn) + (row << lgn) + j);
     }
-    Fe<P> v = gload<P>(in, (row << lgn) + j);
     const int k = (lgn == 0) ? 0 : (int)(__brev((unsigned)j) >> (32 - lgn));
     lds_store<P>(lds, (k << lgr) | rr, v);
   }
@@ -243,9 +251,11 @@ __global__ __launch_bounds__(NTHREADS) void k_ntt_last(const u32* __restrict__ i
   if (has_scale) sc = fe_unpack<P>(scale.w);
   for (int e = tid; e < tile_elems; e += NTHREADS) {
     const int rr = e & rmask, k = e >> lgr;
+    const size_t r = p0 + rr;
+    if (r >= total_rows) continue;
     Fe<P> v = lds_load<P>(lds, (k << lgr) | rr);
     if (has_scale) v = fe_mul<P>(v, sc);
-    gstore<P>(out, p0 + rr + ((size_t)k << lg_rows), fe_reduce<P>(v));
+    gstore<P>(out, ((r >> lg_rows) << logn) + (r & rowmask) + ((size_t)k << lg_rows), fe_reduce<P>(v));
   }
 }
 
@@ -471,19 +481,19 @@ static int get_plan(int fid, unsigned logn, bool inverse, const uint64_t* root, 
 }
 
 template <class P>
-static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t s, const PreArgs* pre = nullptr) {
+static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t s, const PreArgs* pre = nullptr, size_t batch = 1) {
   const LevelInfo& li = pl->li;
   const unsigned logn = pl->logn;
 
   auto lds_for = [](int lgn) { return sizeof(u32) * P::L * ((size_t)TILE + (lgn >= 2 ? ((size_t)1 << (lgn - 1)) : 1)); };  // tile + in-tile twiddles
   const u32* src = d_in;
   u32* tmp = nullptr;
-  if (li.nlev > 1) MZK_TRY(ws_get(WS_NTT_TMP, ((size_t)1 << logn) * sizeof(u32) * P::NW, (void**)&tmp));
+  if (li.nlev > 1) MZK_TRY(ws_get(WS_NTT_TMP, (batch << logn) * sizeof(u32) * P::NW, (void**)&tmp));
   int lg_after = (int)logn;
   for (int t = 0; t < li.nlev - 1; t++) {
     const int lgn = li.lg[t], lgM = lg_after - lgn;
     const int lgc = TILE_LOG - lgn;
-    const unsigned blocks = (unsigned)((size_t)1 << (logn - TILE_LOG));
+    const unsigned blocks = (unsigned)(batch << (logn - TILE_LOG));      // `o` in the kernel runs over the batch too
     {
       ProfScope ps(s, MZK_PH_NTT_PASS0 + t);
       if (t == 0 && pre)
@@ -499,12 +509,13 @@ static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t 
   {
     const int lgn = li.lg[li.nlev - 1];
     const int lg_rows = (int)logn - lgn;
+    const size_t total_rows = batch << lg_rows;
     int lgr = TILE_LOG - lgn;
-    if (lgr > lg_rows) lgr = lg_rows;
-    const unsigned blocks = (unsigned)((size_t)1 << (lg_rows - lgr));
+    while (lgr > 0 && ((size_t)1 << lgr) > total_rows) lgr--;
+    const unsigned blocks = (unsigned)((total_rows + ((size_t)1 << lgr) - 1) >> lgr);
     ProfScope ps(s, MZK_PH_NTT_PASS0 + li.nlev - 1);
     hipLaunchKernelGGL((k_ntt_last<P>), dim3(blocks), dim3(NTHREADS), lds_for(lgn), s, src, d_out,
-                       pl->tw_tile[li.nlev - 1], li, lgn, lgr, lg_rows, pl->last_scale, pl->has_last_scale);
+                       pl->tw_tile[li.nlev - 1], li, lgn, lgr, lg_rows, pl->last_scale, pl->has_last_scale, total_rows);
   }
   MZK_HIP(hipGetLastError());
   return MZK_OK;
@@ -533,6 +544,22 @@ int ntt_dev_impl(int fid, const uint64_t* root_host, const void* d_in, void* d_o
   MZK_TRY(get_plan(fid, ilog2(n), inverse != 0, root_host, extra_scale_host, s, &pl));
   if (fid == MZK_FIELD_M128) return run_plan<M128Params>(pl, (const u32*)d_in, (u32*)d_out, s);
   return run_plan<FrParams>(pl, (const u32*)d_in, (u32*)d_out, s);
+}
+
+// `batch` transforms of n points each, stored back to back (in place allowed); same root for all
+int ntt_batch_dev_impl(int fid, const uint64_t* root_host, const void* d_in, void* d_out, size_t n, size_t batch, int inverse, hipStream_t s) {
+  if (batch == 0 || n == 0) return MZK_OK;
+  if (batch == 1) return ntt_dev_impl(fid, root_host, d_in, d_out, n, inverse, nullptr, s);
+  if (fid != MZK_FIELD_FR && fid != MZK_FIELD_M128) { set_error("ntt: field id %d has no NTT on this path", fid); return MZK_E_ARG; }
+  if (!is_pow2(n)) { set_error("cannot compute ntt of non-power-of-two sequence"); return MZK_E_NOT_POW2; }
+  if (n == 1) {
+    if (d_in != d_out) MZK_HIP(hipMemcpyAsync(d_out, d_in, batch * field_bytes(fid), hipMemcpyDeviceToDevice, s));
+    return MZK_OK;
+  }
+  NttPlan* pl = nullptr;
+  MZK_TRY(get_plan(fid, ilog2(n), inverse != 0, root_host, nullptr, s, &pl));
+  if (fid == MZK_FIELD_M128) return run_plan<M128Params>(pl, (const u32*)d_in, (u32*)d_out, s, nullptr, batch);
+  return run_plan<FrParams>(pl, (const u32*)d_in, (u32*)d_out, s, nullptr, batch);
 }
 
 int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_t* offset_host,

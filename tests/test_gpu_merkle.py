@@ -117,7 +117,7 @@ def test_ragged_leaf_counts_match_the_reference_recursion(mz, n):
             path = t.open(idx)
             assert path == want, idx
             opened += 1
-    assert opened > 0 and (refused > 0 or n in (6, 12))      # 6 and 12 split into two-leaf subtrees only
+    assert opened > 0 and (refused > 0 or n > 13)      # every ragged count has a three-leaf slice somewhere
     t.close()
     for fid in (M128, FR):
         arr = _edge_vector(fid, 500 + n, n)
