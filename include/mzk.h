@@ -122,6 +122,24 @@ int mzk_kzg_prove_degree_bound(const uint64_t* coef, size_t n, const uint64_t* p
 int mzk_fast_coset_divide(int field_id, const uint64_t* lhs, size_t ll, const uint64_t* rhs, size_t lr, const uint64_t* offset,
                           const uint64_t* root, size_t root_order, uint64_t* out, size_t* out_len);
 
+/* ntt::fast_zerofier / fast_evaluate / fast_interpolate (algebra/ntt.rs:118-252; FastStark::prove interpolates every
+ * trace register with fast_interpolate, zkstark/fast_stark.rs:209, and builds its transition zerofier with
+ * fast_zerofier, :53).  Subproduct trees on the device (O(n log^2 n); the reference's remainders are O(n^2)).
+ *   zerofier:    prod (X - domain[i]).  n = 0 -> empty; n < 8 -> n + 1 coefficients (the schoolbook branch trims);
+ *                n >= 8 -> next_pow2(n + 1) coefficients, zero padded (fast_multiply does not trim its NTT branch).
+ *                out must hold max(n + 1, next_pow2(n + 1)) elements.
+ *   evaluate:    out[i] = f(domain[i]), i < n (m coefficients, any m).
+ *   interpolate: the polynomial of degree < n through (domain[i], values[i]), trimmed like the reference's final sum;
+ *                n = 1 -> [values[0]] untrimmed.  A repeated domain point gets weight inverse(0) = 0, as in the
+ *                reference (field.rs:209-232 via ntt.rs:233-242).  out must hold n elements.
+ * root / root_order: the two reference assertions (MZK_E_ROOT_ORDER / MZK_E_ROOT_PRIM); where the reference's
+ * internal zerofier products would exceed root_order (it then wraps around or panics inside ntt) -> MZK_E_LENGTH. */
+int mzk_fast_zerofier(int field_id, const uint64_t* domain, size_t n, const uint64_t* root, size_t root_order, uint64_t* out, size_t* out_len);
+int mzk_fast_evaluate(int field_id, const uint64_t* coef, size_t m, const uint64_t* domain, size_t n, const uint64_t* root, size_t root_order,
+                      uint64_t* out);
+int mzk_fast_interpolate(int field_id, const uint64_t* domain, const uint64_t* values, size_t n, const uint64_t* root, size_t root_order,
+                         uint64_t* out, size_t* out_len);
+
 /* FRI commit-loop split-and-fold (zkstark/fri.rs:182-193):
  * out[i] = 2^-1 ((1 + alpha/(offset omega^i)) c[i] + (1 - alpha/(offset omega^i)) c[n/2 + i]), i < n/2,
  * sanitized.  offset must be non-zero and omega a root of order n (as FRI::commit maintains). */

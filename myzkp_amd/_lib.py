@@ -479,6 +479,45 @@ def fast_coset_divide(fid, lhs, rhs, offset, root, root_order):
     return out[:ln.value]
 
 
+def _np2(x):
+    p = 1
+    while p < x:
+        p <<= 1
+    return p
+
+
+def fast_zerofier(fid, domain, root, root_order):
+    """ntt::fast_zerofier (algebra/ntt.rs:118-144)."""
+    d = _arr(fid, domain)
+    n = d.shape[0]
+    out = np.zeros((max(n + 1, _np2(n + 1)), LIMBS[fid]), dtype=np.uint64)
+    ln = ctypes.c_size_t()
+    r = _one(fid, root)
+    _check(lib().mzk_fast_zerofier(fid, _p(d), ctypes.c_size_t(n), _p(r), ctypes.c_size_t(root_order), _p(out), ctypes.byref(ln)))
+    return out[:ln.value]
+
+
+def fast_evaluate(fid, coef, domain, root, root_order):
+    """ntt::fast_evaluate (algebra/ntt.rs:146-189)."""
+    c, d = _arr(fid, coef), _arr(fid, domain)
+    out = np.zeros((max(d.shape[0], 1), LIMBS[fid]), dtype=np.uint64)
+    r = _one(fid, root)
+    _check(lib().mzk_fast_evaluate(fid, _p(c), ctypes.c_size_t(c.shape[0]), _p(d), ctypes.c_size_t(d.shape[0]), _p(r), ctypes.c_size_t(root_order), _p(out)))
+    return out[:d.shape[0]]
+
+
+def fast_interpolate(fid, domain, values, root, root_order):
+    """ntt::fast_interpolate (algebra/ntt.rs:191-252)."""
+    d, v = _arr(fid, domain), _arr(fid, values)
+    if d.shape[0] != v.shape[0]:
+        raise MzkError(-5, "assertion `left == right` failed (domain.len(), values.len())")
+    out = np.zeros((max(d.shape[0], 1), LIMBS[fid]), dtype=np.uint64)
+    ln = ctypes.c_size_t()
+    r = _one(fid, root)
+    _check(lib().mzk_fast_interpolate(fid, _p(d), _p(v), ctypes.c_size_t(d.shape[0]), _p(r), ctypes.c_size_t(root_order), _p(out), ctypes.byref(ln)))
+    return out[:ln.value]
+
+
 def g2_points_to_array(pts):
     """[((x0, x1), (y0, y1)), ...] -> (n, 16) limbs; infinity = ((0, 0), (0, 0))."""
     a = np.zeros((len(pts), 16), dtype=np.uint64)

@@ -110,6 +110,7 @@ int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_
                        const uint64_t* generator_host, void* d_out, size_t order, hipStream_t s);
 int coset_divide_dev_impl(int fid, const void* d_lhs, size_t tl, const void* d_rhs, size_t tr, const uint64_t* offset_host,
                           const uint64_t* root_host, size_t order, void* d_out, hipStream_t s);
+int pointwise_div_dev(int fid, const void* d_a, const void* d_b, void* d_out, size_t n, hipStream_t s);
 int pointwise_mul_dev(int fid, const void* d_a, const void* d_b, void* d_out, size_t n, hipStream_t s);
 void ntt_release_plans();
 int fri_fold_dev_impl(int fid, const void* d_cw, size_t n, const uint64_t* alpha, const uint64_t* offset, const uint64_t* omega,

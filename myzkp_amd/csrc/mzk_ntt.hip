@@ -343,7 +343,7 @@ struct NttPlan {
 static std::vector<NttPlan*> g_plans_all[MZK_MAX_CTX];      // per context (device)
 #define g_plans g_plans_all[ctx().index]
 static uint64_t g_stamp = 0;
-constexpr size_t MAX_PLANS = 12;
+constexpr size_t MAX_PLANS = 96;      // the polynomial trees of mzk_poly.hip use every size from 2^7 up, both directions
 
 static void free_plan(NttPlan* p) {
   for (auto& t : p->tw_tile) if (t) (void)hipFree(t);
@@ -750,6 +750,15 @@ int coset_divide_dev_impl(int fid, const void* d_lhs, size_t tl, const void* d_r
   return MZK_OK;
 }
 
+// out[i] = a[i] / b[i] with inverse(0) = 0 (field.rs:209-232)
+int pointwise_div_dev(int fid, const void* d_a, const void* d_b, void* d_out, size_t n, hipStream_t s) {
+  if (n == 0) return MZK_OK;
+  const unsigned blocks = (unsigned)(((n + DIV_BATCH - 1) / DIV_BATCH + 127) / 128);
+  if (fid == MZK_FIELD_M128) hipLaunchKernelGGL((k_pointwise_div<M128Params>), dim3(blocks), dim3(128), 0, s, (const u32*)d_a, (const u32*)d_b, (u32*)d_out, n);
+  else hipLaunchKernelGGL((k_pointwise_div<FrParams>), dim3(blocks), dim3(128), 0, s, (const u32*)d_a, (const u32*)d_b, (u32*)d_out, n);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
 int pointwise_mul_dev(int fid, const void* d_a, const void* d_b, void* d_out, size_t n, hipStream_t s) {
   if (n == 0) return MZK_OK;
   const unsigned blocks = (unsigned)((n + 255) / 256);

@@ -1,0 +1,610 @@
+// mzk_poly.hip -- subproduct-tree polynomial routines on the device: ntt::fast_zerofier, fast_evaluate,
+// fast_interpolate (myzkp/src/modules/algebra/ntt.rs:118-252; FastStark::prove interpolates every trace register with
+// fast_interpolate, zkstark/fast_stark.rs:209, and builds its transition zerofier with fast_zerofier, :53).
+//
+// The reference recurses on slices (half = len / 2) and multiplies with fast_multiply; its remainders are schoolbook
+// long divisions (polynomial.rs:371-405), i.e. O(n^2).  The three results are mathematically determined --
+//   zerofier    Z(X) = prod_i (X - d_i)
+//   evaluate    [f(d_i)]_i
+//   interpolate the polynomial of degree < n through (d_i, v_i)   (a repeated point contributes inverse(0) = 0, see below)
+// -- so any exact algorithm returns the same canonical coefficients; only the LENGTH of the returned vector is an
+// artefact of the recursion, and it is reproduced (fast_multiply's untrimmed `order` on its NTT path, ntt.rs:86-93).
+//
+// Device algorithm (all O(n log^2 n), every level one batched launch group):
+//   * the domain is padded with zeros to N = 2^k >= 64 points: Z_pad = Z * X^pad, so results are read with a shift;
+//   * level 0: one wave per 64 points builds its monic degree-64 zerofier by 64 rank-1 updates (k_chunk_zerofier);
+//   * level l -> l+1: monic pairs  (X^D + a)(X^D + b) = X^2D + X^D (a + b) + a b : only the low parts are stored, and a b
+//     (degree <= 2D - 2) is one cyclic product of size 2D -- batched NTTs (mzk_ntt.hip) over all N / D polynomials;
+//   * evaluation is the TRANSPOSED algorithm of Bostan-Lecerf-Schost: t_root = middle product of f with
+//     1 / rev(Z_pad) mod X^N (Newton), then down the tree  t_left = (t_node * Z_right)[D .. 2D)  (one cyclic product
+//     of size 2D per node, re-using the transformed low parts kept from the way up), and a 64-point finish per wave;
+//   * interpolation: weights w_i = v_i / Z'(d_i) (Z' evaluated as above), then the same tree upwards:
+//     P_parent = X^D (P_l + P_r) + P_l Z_r' + P_r Z_l'.
+#include <vector>
+#include "mzk_common.h"
+
+namespace mzk {
+
+constexpr int CHUNK = 64;        // points per level-0 polynomial = one wave
+
+template <class P> __device__ __forceinline__ Fe<P> pl_load(const u32* __restrict__ g, size_t idx) {
+  u32 w[P::NW];
+  const uint4* p4 = reinterpret_cast<const uint4*>(g + idx * P::NW);
+#pragma unroll
+  for (int q = 0; q < P::NW / 4; q++) { uint4 v = p4[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+  return fe_unpack<P>(w);
+}
+template <class P> __device__ __forceinline__ void pl_store(u32* __restrict__ g, size_t idx, const Fe<P>& v) {   // v canonical
+  u32 w[P::NW];
+  fe_pack<P>(v, w);
+  uint4* p4 = reinterpret_cast<uint4*>(g + idx * P::NW);
+#pragma unroll
+  for (int q = 0; q < P::NW / 4; q++) p4[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+// plain-domain helpers: canonical in, canonical out
+template <class P> __device__ __forceinline__ Fe<P> pl_mul(const Fe<P>& x, const Fe<P>& y) { return fe_reduce<P>(fe_mul<P>(fe_mul<P>(x, y), fe_r2<P>())); }
+template <class P> __device__ __forceinline__ Fe<P> pl_add(const Fe<P>& x, const Fe<P>& y) { return fe_reduce<P>(fe_carry<P>(fe_add<P>(x, y))); }
+template <class P> __device__ __forceinline__ Fe<P> pl_sub(const Fe<P>& x, const Fe<P>& y) { return fe_reduce<P>(fe_carry<P>(fe_sub<P, 2>(x, y))); }
+template <class P> __device__ __forceinline__ Fe<P> pl_one() { Fe<P> r = fe_zero<P>(); r.l[0] = 1; return r; }
+template <class P> __device__ __forceinline__ Fe<P> shfl_fe(const Fe<P>& v, int src) {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) r.l[i] = (u32)__shfl((int)v.l[i], src);
+  return r;
+}
+template <class P> __device__ __forceinline__ Fe<P> shfl_up1_fe(const Fe<P>& v) {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) r.l[i] = (u32)__shfl_up((int)v.l[i], 1);
+  return r;
+}
+template <class P> __device__ __forceinline__ Fe<P> shfl_xor_fe(const Fe<P>& v, int m) {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) r.l[i] = (u32)__shfl_xor((int)v.l[i], m);
+  return r;
+}
+
+// ---- level 0: monic zerofier of 64 points per wave --------------------------------------------------------
+// lane j holds coefficient j.  Multiplying by (X - d): c_j <- c_{j-1} - d c_j.  After 64 steps the (implicit) leading
+// coefficient has left lane 63; low[chunk * 64 + j] = coefficient j.  Points beyond n are 0 (padding).
+template <class P>
+__global__ __launch_bounds__(64) void k_chunk_zerofier(const u32* __restrict__ domain, size_t n, u32* __restrict__ low) {
+  const int lane = threadIdx.x;
+  const size_t chunk = blockIdx.x;
+  const size_t idx = chunk * CHUNK + lane;
+  Fe<P> d = fe_zero<P>();
+  if (idx < n) d = fe_reduce<P>(fe_to_mont<P>(pl_load<P>(domain, idx)));     // Montgomery form: fe_mul(c, dM) = c d in the plain domain
+  Fe<P> c = fe_zero<P>();
+  if (lane == 0) c = pl_one<P>();
+  for (int i = 0; i < CHUNK; i++) {
+    const Fe<P> di = shfl_fe<P>(d, i);
+    Fe<P> up = shfl_up1_fe<P>(c);
+    if (lane == 0) up = fe_zero<P>();
+    c = pl_sub<P>(up, fe_reduce<P>(fe_mul<P>(c, di)));
+  }
+  pl_store<P>(low, idx, c);
+}
+
+// ---- level step kernels -------------------------------------------------------------------------------------
+// T[p * 2D + i] = i < D ? src[p * D + i] : 0
+template <class P>
+__global__ __launch_bounds__(256) void k_pad_double(const u32* __restrict__ src, int lgD, size_t total2, u32* __restrict__ T) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total2) return;
+  const size_t p = e >> (lgD + 1), i = e & (((size_t)2 << lgD) - 1);
+  Fe<P> v = fe_zero<P>();
+  if (i < ((size_t)1 << lgD)) v = pl_load<P>(src, (p << lgD) + i);
+  pl_store<P>(T, e, v);
+}
+// U[q * 2D + k] = T[(2q) * 2D + k] * T[(2q + 1) * 2D + k]
+template <class P>
+__global__ __launch_bounds__(256) void k_pair_mul(const u32* __restrict__ T, int lgD, size_t total, u32* __restrict__ U) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const size_t q = e >> (lgD + 1), k = e & (((size_t)2 << lgD) - 1);
+  const size_t a = ((2 * q) << (lgD + 1)) + k;
+  pl_store<P>(U, e, pl_mul<P>(pl_load<P>(T, a), pl_load<P>(T, a + ((size_t)2 << lgD))));
+}
+// next[q * 2D + i] = U[q * 2D + i] + (i >= D ? cur[2q D + i - D] + cur[(2q + 1) D + i - D] : 0)
+template <class P>
+__global__ __launch_bounds__(256) void k_monic_fixup(const u32* __restrict__ U, const u32* __restrict__ cur, int lgD, size_t total, u32* __restrict__ next) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const size_t D = (size_t)1 << lgD;
+  const size_t q = e >> (lgD + 1), i = e & (2 * D - 1);
+  Fe<P> v = pl_load<P>(U, e);
+  if (i >= D) {
+    const size_t a = ((2 * q) << lgD) + (i - D);
+    v = pl_add<P>(v, pl_add<P>(pl_load<P>(cur, a), pl_load<P>(cur, a + D)));
+  }
+  pl_store<P>(next, e, v);
+}
+
+// ---- power-series inverse of g = rev(Z_pad) (g[0] = 1, g[k] = Zpad[N - k]) ----------------------------------------
+// g as a coefficient array: gk[k], k < N (g[N] = Zpad[0] is never needed mod X^N)
+template <class P>
+__global__ __launch_bounds__(256) void k_reverse_monic(const u32* __restrict__ low_top, size_t N, u32* __restrict__ g) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  pl_store<P>(g, k, k == 0 ? pl_one<P>() : pl_load<P>(low_top, N - k));
+}
+// inv[0 .. 64) of 1 / g, one wave: inv_k = - sum_{j=1..k} g_j inv_{k-j}; lane j holds g_j, the partial sums are
+// wave-reduced (64 steps)
+template <class P>
+__global__ __launch_bounds__(64) void k_series_inverse_64(const u32* __restrict__ g, u32* __restrict__ inv) {
+  __shared__ u32 sh[CHUNK * P::NW];
+  const int lane = threadIdx.x;
+  const Fe<P> gj = pl_load<P>(g, lane);
+  if (lane == 0) pl_store<P>(sh, 0, pl_one<P>());
+  __syncthreads();
+  for (int k = 1; k < CHUNK; k++) {
+    Fe<P> term = fe_zero<P>();
+    if (lane >= 1 && lane <= k) term = pl_mul<P>(gj, pl_load<P>(sh, k - lane));
+    for (int m = 1; m < 64; m <<= 1) term = pl_add<P>(term, shfl_xor_fe<P>(term, m));
+    if (lane == 0) pl_store<P>(sh, k, fe_reduce<P>(fe_neg_canon<P>(term)));
+    __syncthreads();
+  }
+  pl_store<P>(inv, lane, pl_load<P>(sh, lane));
+}
+// A[i] = i < m_in ? src[i] : 0 for i < 2m   (src may be longer than m_in)
+template <class P>
+__global__ __launch_bounds__(256) void k_copy_pad(const u32* __restrict__ src, size_t m_in, size_t total, u32* __restrict__ dst) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  pl_store<P>(dst, e, e < m_in ? pl_load<P>(src, e) : fe_zero<P>());
+}
+// dst[i] = a[i] * b[i]
+template <class P>
+__global__ __launch_bounds__(256) void k_mul_vec(const u32* __restrict__ a, const u32* __restrict__ b, size_t total, u32* __restrict__ dst) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  pl_store<P>(dst, e, pl_mul<P>(pl_load<P>(a, e), pl_load<P>(b, e)));
+}
+// dst[i] = i < m ? src[m + i] : 0 for i < 2m  (the error term e of g inv = 1 + X^m e)
+template <class P>
+__global__ __launch_bounds__(256) void k_upper_half_pad(const u32* __restrict__ src, size_t m, u32* __restrict__ dst) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * m) return;
+  pl_store<P>(dst, e, e < m ? pl_load<P>(src, m + e) : fe_zero<P>());
+}
+// inv[m + i] = - prod[i], i < m
+template <class P>
+__global__ __launch_bounds__(256) void k_newton_store(const u32* __restrict__ prod, size_t m, u32* __restrict__ inv) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= m) return;
+  pl_store<P>(inv, m + e, fe_reduce<P>(fe_neg_canon<P>(pl_load<P>(prod, e))));
+}
+
+// ---- transposed evaluation ------------------------------------------------------------------------------------
+// A[i] = f_rev[i] = f[N - 1 - i] (f has m <= N coefficients, zero beyond), B[i] = inv[i], both zero on [N, 2N)
+template <class P>
+__global__ __launch_bounds__(256) void k_eval_prepare(const u32* __restrict__ f, size_t m, const u32* __restrict__ inv, size_t N, u32* __restrict__ A,
+                                                      u32* __restrict__ B) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * N) return;
+  Fe<P> a = fe_zero<P>(), b = fe_zero<P>();
+  if (e < N) {
+    const size_t src = N - 1 - e;
+    if (src < m) a = pl_load<P>(f, src);
+    b = pl_load<P>(inv, e);
+  }
+  pl_store<P>(A, e, a);
+  pl_store<P>(B, e, b);
+}
+// t[i] = prod[N - 1 - i], i < N
+template <class P>
+__global__ __launch_bounds__(256) void k_reverse_low(const u32* __restrict__ prod, size_t N, u32* __restrict__ t) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  pl_store<P>(t, e, pl_load<P>(prod, N - 1 - e));
+}
+// down step, children of degree D: V[c * 2D + k] = That_node[(c >> 1) * 2D + k] * (Zhat[(c ^ 1) * 2D + k] + (-1)^k)
+template <class P>
+__global__ __launch_bounds__(256) void k_down_mul(const u32* __restrict__ That, const u32* __restrict__ Zhat, int lgD, size_t total2, u32* __restrict__ V) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total2) return;
+  const size_t c = e >> (lgD + 1), k = e & (((size_t)2 << lgD) - 1);
+  const Fe<P> t = pl_load<P>(That, ((c >> 1) << (lgD + 1)) + k);
+  Fe<P> z = pl_load<P>(Zhat, ((c ^ 1) << (lgD + 1)) + k);
+  z = (k & 1) ? pl_sub<P>(z, pl_one<P>()) : pl_add<P>(z, pl_one<P>());       // + NTT(X^D)[k] = w^(D k) = (-1)^k
+  pl_store<P>(V, e, pl_mul<P>(t, z));
+}
+// t_child[c * D + i] = V[c * 2D + D + i]
+template <class P>
+__global__ __launch_bounds__(256) void k_take_upper(const u32* __restrict__ V, int lgD, size_t total, u32* __restrict__ t) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const size_t c = e >> lgD, i = e & (((size_t)1 << lgD) - 1);
+  pl_store<P>(t, e, pl_load<P>(V, (c << (lgD + 1)) + ((size_t)1 << lgD) + i));
+}
+// 64-point finish: f(x_i) = sum_k t[k] q_k, q_0 = 1, q_k = g_k + x_i q_{k-1}, g_k = Zc[64 - k] (g_64 unused)
+template <class P>
+__global__ __launch_bounds__(64) void k_chunk_eval(const u32* __restrict__ domain, size_t n, const u32* __restrict__ low0, const u32* __restrict__ t,
+                                                   u32* __restrict__ out, size_t out_n) {
+  __shared__ u32 sh_t[CHUNK * P::NW], sh_z[CHUNK * P::NW];
+  const int lane = threadIdx.x;
+  const size_t idx = (size_t)blockIdx.x * CHUNK + lane;
+  pl_store<P>(sh_t, lane, pl_load<P>(t, idx));
+  pl_store<P>(sh_z, lane, pl_load<P>(low0, idx));
+  __syncthreads();
+  Fe<P> x = fe_zero<P>();
+  if (idx < n) x = fe_reduce<P>(fe_to_mont<P>(pl_load<P>(domain, idx)));
+  Fe<P> q = pl_one<P>();
+  Fe<P> acc = pl_load<P>(sh_t, 0);
+  for (int k = 1; k < CHUNK; k++) {
+    q = pl_add<P>(pl_load<P>(sh_z, CHUNK - k), fe_reduce<P>(fe_mul<P>(q, x)));
+    acc = pl_add<P>(acc, pl_mul<P>(pl_load<P>(sh_t, k), q));
+  }
+  if (idx < out_n) pl_store<P>(out, idx, acc);
+}
+
+// ---- interpolation ------------------------------------------------------------------------------------------------
+// dz[j] = (j + 1) * Zreal[j + 1], Zreal[j] = Zpad[j + pad] (Zpad[N] = 1), j < n
+template <class P>
+__global__ __launch_bounds__(256) void k_derivative(const u32* __restrict__ low_top, size_t N, size_t pad, size_t n, u32* __restrict__ dz) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const size_t src = j + 1 + pad;
+  const Fe<P> z = src < N ? pl_load<P>(low_top, src) : pl_one<P>();
+  Fe<P> m = fe_zero<P>();
+  const u64 jj = (u64)j + 1;
+  m.l[0] = (u32)(jj & MASK29); m.l[1] = (u32)((jj >> 29) & MASK29); m.l[2] = (u32)(jj >> 58);
+  pl_store<P>(dz, j, pl_mul<P>(z, m));
+}
+// P_chunk = sum_i w_i Zc / (X - x_i): lane i divides synthetically (q_63 = 1, q_{k-1} = zc_k + x_i q_k), the scaled
+// coefficients are summed over the wave; out0[chunk * 64 + k] = coefficient k
+template <class P>
+__global__ __launch_bounds__(64) void k_chunk_combine(const u32* __restrict__ domain, const u32* __restrict__ w, size_t n, const u32* __restrict__ low0,
+                                                      u32* __restrict__ out0) {
+  __shared__ u32 sh_z[CHUNK * P::NW];
+  const int lane = threadIdx.x;
+  const size_t idx = (size_t)blockIdx.x * CHUNK + lane;
+  pl_store<P>(sh_z, lane, pl_load<P>(low0, idx));
+  __syncthreads();
+  Fe<P> x = fe_zero<P>(), wi = fe_zero<P>();
+  if (idx < n) { x = fe_reduce<P>(fe_to_mont<P>(pl_load<P>(domain, idx))); wi = fe_reduce<P>(fe_to_mont<P>(pl_load<P>(w, idx))); }
+  Fe<P> q = pl_one<P>();
+  Fe<P> mine = fe_zero<P>();
+  for (int k = CHUNK - 1; k >= 0; k--) {
+    Fe<P> term = fe_reduce<P>(fe_mul<P>(q, wi));
+    for (int m = 1; m < 64; m <<= 1) term = pl_add<P>(term, shfl_xor_fe<P>(term, m));
+    if (lane == k) mine = term;
+    if (k > 0) q = pl_add<P>(pl_load<P>(sh_z, k), fe_reduce<P>(fe_mul<P>(q, x)));
+  }
+  pl_store<P>(out0, idx, mine);
+}
+// W[q * 2D + k] = Pl[k] Zr[k] + Pr[k] Zl[k]   (all transformed, children q*2, q*2+1 of degree D)
+template <class P>
+__global__ __launch_bounds__(256) void k_up_mul(const u32* __restrict__ Phat, const u32* __restrict__ Zhat, int lgD, size_t total, u32* __restrict__ W) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const size_t q = e >> (lgD + 1), k = e & (((size_t)2 << lgD) - 1);
+  const size_t a = ((2 * q) << (lgD + 1)) + k, b = a + ((size_t)2 << lgD);
+  pl_store<P>(W, e, pl_add<P>(pl_mul<P>(pl_load<P>(Phat, a), pl_load<P>(Zhat, b)), pl_mul<P>(pl_load<P>(Phat, b), pl_load<P>(Zhat, a))));
+}
+
+// ---- host orchestration ----------------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) { if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { set_error("poly: hipMalloc(%zu) failed", bytes); return MZK_E_HIP; } return MZK_OK; }
+  u32* w() const { return (u32*)p; }
+};
+static inline unsigned grid256(size_t total) { return (unsigned)((total + 255) / 256); }
+
+template <class P> struct PolyTree {
+  int fid;
+  size_t n, N, pad;
+  int levels;                       // number of level steps above level 0: N = 64 << levels
+  const HostField* hf;
+  uint64_t root[4]; size_t root_order;
+  hipStream_t s;
+  std::vector<DevBuf> low;          // low[l]: N elements, polynomials of degree 64 << l
+  std::vector<DevBuf> Zhat;         // Zhat[l] (l < levels): 2N elements, NTT_{2D}(low part) of every level-l polynomial
+  DevBuf U;                         // N scratch
+
+  void sub_root(size_t size, uint64_t* out) const {     // primitive `size`-th root from the caller's root
+    uint64_t r[4] = {0, 0, 0, 0};
+    memcpy(r, root, 8 * hf->nl);
+    for (size_t o = root_order; o > size; o >>= 1) h_mulmod(hf, r, r, r);
+    memcpy(out, r, 8 * hf->nl);
+  }
+  int ntt(void* buf, size_t size, size_t batch, int inverse) const {
+    uint64_t r[4];
+    sub_root(size, r);
+    return ntt_batch_dev_impl(fid, r, buf, buf, size, batch, inverse, s);
+  }
+  // builds every level; keep_hats: retain the transformed low parts (evaluate / interpolate need them)
+  int build(const void* d_domain, bool keep_hats) {
+    const size_t esz = field_bytes(fid);
+    low.resize(levels + 1);
+    Zhat.resize(levels);
+    MZK_TRY(low[0].alloc(N * esz));
+    hipLaunchKernelGGL((k_chunk_zerofier<P>), dim3((unsigned)(N / CHUNK)), dim3(64), 0, s, (const u32*)d_domain, n, low[0].w());
+    if (levels) MZK_TRY(U.alloc(N * esz));
+    DevBuf shared_T;
+    if (levels && !keep_hats) MZK_TRY(shared_T.alloc(2 * N * esz));
+    for (int l = 0; l < levels; l++) {
+      const int lgD = 6 + l;
+      u32* T;
+      if (keep_hats) { MZK_TRY(Zhat[l].alloc(2 * N * esz)); T = Zhat[l].w(); } else T = shared_T.w();
+      MZK_TRY(low[l + 1].alloc(N * esz));
+      hipLaunchKernelGGL((k_pad_double<P>), dim3(grid256(2 * N)), dim3(256), 0, s, (const u32*)low[l].w(), lgD, 2 * N, T);
+      MZK_TRY(ntt(T, (size_t)2 << lgD, N >> lgD, 0));
+      hipLaunchKernelGGL((k_pair_mul<P>), dim3(grid256(N)), dim3(256), 0, s, (const u32*)T, lgD, N, U.w());
+      MZK_TRY(ntt(U.p, (size_t)2 << lgD, N >> (lgD + 1), 1));
+      hipLaunchKernelGGL((k_monic_fixup<P>), dim3(grid256(N)), dim3(256), 0, s, (const u32*)U.w(), (const u32*)low[l].w(), lgD, N, low[l + 1].w());
+    }
+    MZK_HIP(hipGetLastError());
+    if (!keep_hats) MZK_HIP(hipStreamSynchronize(s));              // shared_T is freed on return
+    return MZK_OK;
+  }
+  // values of f (m <= N coefficients, device) at the N padded points -> d_out[0 .. out_n)
+  int evaluate(const void* d_f, size_t m, const void* d_domain, void* d_out, size_t out_n) {
+    const size_t esz = field_bytes(fid);
+    DevBuf g, inv, A, B, t, V;
+    MZK_TRY(g.alloc(N * esz)); MZK_TRY(inv.alloc(N * esz)); MZK_TRY(A.alloc(2 * N * esz)); MZK_TRY(B.alloc(2 * N * esz));
+    MZK_TRY(t.alloc(N * esz)); MZK_TRY(V.alloc(2 * N * esz));
+    // 1 / rev(Z_pad) mod X^N
+    hipLaunchKernelGGL((k_reverse_monic<P>), dim3(grid256(N)), dim3(256), 0, s, (const u32*)low[levels].w(), N, g.w());
+    hipLaunchKernelGGL((k_series_inverse_64<P>), dim3(1), dim3(64), 0, s, (const u32*)g.w(), inv.w());
+    for (size_t mm = CHUNK; mm < N; mm <<= 1) {      // inv mod X^mm -> mod X^2mm
+      hipLaunchKernelGGL((k_copy_pad<P>), dim3(grid256(2 * mm)), dim3(256), 0, s, (const u32*)g.w(), 2 * mm, 2 * mm, A.w());
+      hipLaunchKernelGGL((k_copy_pad<P>), dim3(grid256(2 * mm)), dim3(256), 0, s, (const u32*)inv.w(), mm, 2 * mm, B.w());
+      MZK_TRY(ntt(A.p, 2 * mm, 1, 0));
+      MZK_TRY(ntt(B.p, 2 * mm, 1, 0));
+      hipLaunchKernelGGL((k_mul_vec<P>), dim3(grid256(2 * mm)), dim3(256), 0, s, (const u32*)A.w(), (const u32*)B.w(), 2 * mm, A.w());
+      MZK_TRY(ntt(A.p, 2 * mm, 1, 1));                                   // g inv_m mod (X^2m - 1): coefficients [m, 2m) are e
+      hipLaunchKernelGGL((k_upper_half_pad<P>), dim3(grid256(2 * mm)), dim3(256), 0, s, (const u32*)A.w(), mm, V.w());
+      MZK_TRY(ntt(V.p, 2 * mm, 1, 0));
+      hipLaunchKernelGGL((k_mul_vec<P>), dim3(grid256(2 * mm)), dim3(256), 0, s, (const u32*)V.w(), (const u32*)B.w(), 2 * mm, V.w());
+      MZK_TRY(ntt(V.p, 2 * mm, 1, 1));                                   // e inv_m: low m coefficients exact
+      hipLaunchKernelGGL((k_newton_store<P>), dim3(grid256(mm)), dim3(256), 0, s, (const u32*)V.w(), mm, inv.w());
+    }
+    // t_root[i] = (rev(f) inv)[N - 1 - i]
+    hipLaunchKernelGGL((k_eval_prepare<P>), dim3(grid256(2 * N)), dim3(256), 0, s, (const u32*)d_f, m, (const u32*)inv.w(), N, A.w(), B.w());
+    MZK_TRY(ntt(A.p, 2 * N, 1, 0));
+    MZK_TRY(ntt(B.p, 2 * N, 1, 0));
+    hipLaunchKernelGGL((k_mul_vec<P>), dim3(grid256(2 * N)), dim3(256), 0, s, (const u32*)A.w(), (const u32*)B.w(), 2 * N, A.w());
+    MZK_TRY(ntt(A.p, 2 * N, 1, 1));
+    hipLaunchKernelGGL((k_reverse_low<P>), dim3(grid256(N)), dim3(256), 0, s, (const u32*)A.w(), N, t.w());
+    // down the tree: node degree 2D -> children degree D
+    for (int l = levels - 1; l >= 0; l--) {
+      const int lgD = 6 + l;
+      MZK_TRY(ntt(t.p, (size_t)2 << lgD, N >> (lgD + 1), 0));
+      hipLaunchKernelGGL((k_down_mul<P>), dim3(grid256(2 * N)), dim3(256), 0, s, (const u32*)t.w(), (const u32*)Zhat[l].w(), lgD, 2 * N, V.w());
+      MZK_TRY(ntt(V.p, (size_t)2 << lgD, N >> lgD, 1));
+      hipLaunchKernelGGL((k_take_upper<P>), dim3(grid256(N)), dim3(256), 0, s, (const u32*)V.w(), lgD, N, t.w());
+    }
+    hipLaunchKernelGGL((k_chunk_eval<P>), dim3((unsigned)(N / CHUNK)), dim3(64), 0, s, (const u32*)d_domain, n, (const u32*)low[0].w(), (const u32*)t.w(),
+                       (u32*)d_out, out_n);
+    MZK_HIP(hipGetLastError());
+    MZK_HIP(hipStreamSynchronize(s));      // the temporaries above are freed on return
+    return MZK_OK;
+  }
+  // sum_i w_i Z_pad / (X - x_i) -> N coefficients in d_out (weights of padded points are ignored: treated as 0)
+  int combine(const void* d_domain, const void* d_w, void* d_out) {
+    const size_t esz = field_bytes(fid);
+    DevBuf cur, nxt, Ph, W;
+    MZK_TRY(cur.alloc(N * esz)); MZK_TRY(nxt.alloc(N * esz)); MZK_TRY(Ph.alloc(2 * N * esz)); MZK_TRY(W.alloc(N * esz));
+    hipLaunchKernelGGL((k_chunk_combine<P>), dim3((unsigned)(N / CHUNK)), dim3(64), 0, s, (const u32*)d_domain, (const u32*)d_w, n, (const u32*)low[0].w(), cur.w());
+    for (int l = 0; l < levels; l++) {
+      const int lgD = 6 + l;
+      hipLaunchKernelGGL((k_pad_double<P>), dim3(grid256(2 * N)), dim3(256), 0, s, (const u32*)cur.w(), lgD, 2 * N, Ph.w());
+      MZK_TRY(ntt(Ph.p, (size_t)2 << lgD, N >> lgD, 0));
+      hipLaunchKernelGGL((k_up_mul<P>), dim3(grid256(N)), dim3(256), 0, s, (const u32*)Ph.w(), (const u32*)Zhat[l].w(), lgD, N, W.w());
+      MZK_TRY(ntt(W.p, (size_t)2 << lgD, N >> (lgD + 1), 1));
+      hipLaunchKernelGGL((k_monic_fixup<P>), dim3(grid256(N)), dim3(256), 0, s, (const u32*)W.w(), (const u32*)cur.w(), lgD, N, nxt.w());
+      std::swap(cur.p, nxt.p);
+    }
+    MZK_HIP(hipMemcpyAsync(d_out, cur.p, N * esz, hipMemcpyDeviceToDevice, s));
+    MZK_HIP(hipGetLastError());
+    MZK_HIP(hipStreamSynchronize(s));
+    return MZK_OK;
+  }
+};
+
+static size_t next_pow2(size_t x) { size_t p = 1; while (p < x) p <<= 1; return p; }
+
+// shared argument checks: the reference's two assertions (ntt.rs:122-123 etc.) and canonical inputs
+static int check_root(const HostField* hf, const uint64_t* root, size_t root_order) {
+  if (!h_is_canonical(hf, root)) { set_error("poly: root not canonical"); return MZK_E_RANGE; }
+  uint64_t t[4];
+  h_powmod_u64(hf, t, root, root_order);
+  if (!h_is_one(hf, t)) { set_error("assertion failed: primitive_root.pow(root_order).is_one()"); return MZK_E_ROOT_ORDER; }
+  h_powmod_u64(hf, t, root, root_order / 2);
+  if (h_is_one(hf, t)) { set_error("assertion failed: !primitive_root.pow(root_order / 2).is_one()"); return MZK_E_ROOT_PRIM; }
+  return MZK_OK;
+}
+static int check_canonical(const HostField* hf, const uint64_t* v, size_t n, const char* what) {
+  for (size_t i = 0; i < n; i++) if (!h_is_canonical(hf, v + i * hf->nl)) { set_error("poly: %s[%zu] not canonical", what, i); return MZK_E_RANGE; }
+  return MZK_OK;
+}
+template <class P> static int tree_init(PolyTree<P>* T, int fid, size_t n, const uint64_t* root, size_t root_order, hipStream_t s) {
+  T->fid = fid; T->n = n; T->hf = host_field(fid); T->s = s;
+  T->N = next_pow2(n < (size_t)CHUNK ? (size_t)CHUNK : n);
+  T->pad = T->N - n;
+  T->levels = 0;
+  while (((size_t)CHUNK << T->levels) < T->N) T->levels++;
+  // The results do not depend on which root drives the internal transforms (only the reference's assertions and its
+  // output lengths look at the caller's): use the field's own 2^28-th root so that the 2N-point products of the
+  // transposed evaluation never run out of order.
+  (void)root; (void)root_order;
+  const unsigned lg = 28;
+  memset(T->root, 0, sizeof T->root);
+  MZK_TRY(mzk_root_of_unity(fid, lg, T->root));
+  T->root_order = (size_t)1 << lg;
+  if (2 * T->N > T->root_order) { set_error("poly: %zu points exceed the 2^27 supported by the internal transforms", n); return MZK_E_ARG; }
+  return MZK_OK;
+}
+// the reference's own requirement on root_order: its zerofiers of k >= 8 points go through fast_multiply's NTT path with
+// order next_pow2(k + 1) <= root_order, otherwise the product wraps around or the inner ntt panics (ntt.rs:90-105)
+static int check_order_for(size_t points, size_t root_order, const char* who) {
+  if (points < 8) return MZK_OK;
+  size_t ord = 1;
+  while (ord < points + 1) ord <<= 1;
+  if (root_order < ord) {
+    set_error("%s: a zerofier of %zu points needs a root of order >= %zu (got %zu): the reference's product wraps around or its inner ntt panics", who, points, ord, root_order);
+    return MZK_E_LENGTH;
+  }
+  return MZK_OK;
+}
+
+template <class P>
+static int zerofier_impl(int fid, const uint64_t* domain, size_t n, const uint64_t* root, size_t root_order, uint64_t* out, size_t* out_len) {
+  const HostField* hf = host_field(fid);
+  const int nl = hf->nl;
+  const size_t esz = field_bytes(fid);
+  if (n == 0) { *out_len = 0; return MZK_OK; }                              // ntt.rs:125-127
+  const size_t ord = next_pow2(n + 1);
+  const size_t len = n < 8 ? n + 1 : ord;                                   // degree < 8: `lhs * rhs`, trimmed (ntt.rs:86-88); else fast_multiply's untrimmed order
+  MZK_TRY(check_order_for(n, root_order, "fast_zerofier"));
+  hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
+  PolyTree<P> T;
+  MZK_TRY(tree_init(&T, fid, n, root, root_order, s));
+  DevBuf d_dom;
+  MZK_TRY(d_dom.alloc(n * esz));
+  MZK_HIP(hipMemcpyAsync(d_dom.p, domain, n * esz, hipMemcpyHostToDevice, s));
+  MZK_TRY(T.build(d_dom.p, false));
+  std::vector<uint64_t> top(T.N * nl);
+  MZK_HIP(hipMemcpyAsync(top.data(), T.low[T.levels].p, T.N * esz, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  memset(out, 0, len * esz);
+  for (size_t j = 0; j < n; j++) memcpy(out + j * nl, top.data() + (j + T.pad) * nl, esz);     // Z[j] = Zpad[j + pad]
+  out[n * nl] = 1;                                                                             // monic
+  *out_len = len;
+  return MZK_OK;
+}
+
+template <class P>
+static int evaluate_impl(int fid, const uint64_t* coef, size_t m, const uint64_t* domain, size_t n, const uint64_t* root, size_t root_order, uint64_t* out) {
+  const HostField* hf = host_field(fid);
+  const int nl = hf->nl;
+  const size_t esz = field_bytes(fid);
+  if (n == 0) return MZK_OK;
+  hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
+  PolyTree<P> T;
+  MZK_TRY(check_order_for(n - n / 2, root_order, "fast_evaluate"));           // the larger half's zerofier (ntt.rs:167-168)
+  MZK_TRY(tree_init(&T, fid, n, root, root_order, s));
+  DevBuf d_dom, d_f, d_vals;
+  MZK_TRY(d_dom.alloc(n * esz)); MZK_TRY(d_f.alloc((m ? m : 1) * esz)); MZK_TRY(d_vals.alloc(T.N * esz));
+  MZK_HIP(hipMemcpyAsync(d_dom.p, domain, n * esz, hipMemcpyHostToDevice, s));
+  if (m) MZK_HIP(hipMemcpyAsync(d_f.p, coef, m * esz, hipMemcpyHostToDevice, s));
+  MZK_TRY(T.build(d_dom.p, true));
+  if (m <= T.N) {
+    MZK_TRY(T.evaluate(d_f.p, m, d_dom.p, d_vals.p, n));
+    MZK_HIP(hipMemcpyAsync(out, d_vals.p, n * esz, hipMemcpyDeviceToHost, s));
+    MZK_HIP(hipStreamSynchronize(s));
+    return MZK_OK;
+  }
+  // deg f >= N (more coefficients than padded points; no reference caller does this): f = sum_b X^(b N) f_b, so
+  // f(x) = sum_b x^(b N) f_b(x) -- every block goes through the tree, Horner over the blocks on the host.
+  std::vector<uint64_t> xn(n * nl), acc(n * nl, 0), blk(n * nl);
+  for (size_t i = 0; i < n; i++) h_powmod_u64(hf, xn.data() + i * nl, domain + i * nl, (uint64_t)T.N);
+  const size_t nb = (m + T.N - 1) / T.N;
+  for (size_t b = nb; b-- > 0;) {
+    const size_t lo = b * T.N, cnt = (m - lo < T.N) ? m - lo : T.N;
+    MZK_TRY(T.evaluate((const uint8_t*)d_f.p + lo * esz, cnt, d_dom.p, d_vals.p, n));
+    MZK_HIP(hipMemcpyAsync(blk.data(), d_vals.p, n * esz, hipMemcpyDeviceToHost, s));
+    MZK_HIP(hipStreamSynchronize(s));
+    for (size_t i = 0; i < n; i++) {       // acc = acc * x^N + f_b(x)   (n host products per block: parameter-sized next to the tree work)
+      uint64_t t[4];
+      h_mulmod(hf, t, acc.data() + i * nl, xn.data() + i * nl);
+      // t + blk mod p
+      unsigned __int128 c = 0;
+      uint64_t r[4] = {0, 0, 0, 0};
+      for (int k = 0; k < nl; k++) { c += (unsigned __int128)t[k] + blk[i * nl + k]; r[k] = (uint64_t)c; c >>= 64; }
+      bool ge = c != 0;
+      if (!ge) { ge = true; for (int k = nl - 1; k >= 0; k--) if (r[k] != hf->p[k]) { ge = r[k] > hf->p[k]; break; } }
+      if (ge) { unsigned __int128 br = 0; for (int k = 0; k < nl; k++) { unsigned __int128 d = (unsigned __int128)r[k] - hf->p[k] - (uint64_t)br; r[k] = (uint64_t)d; br = (d >> 64) & 1; } }
+      memcpy(acc.data() + i * nl, r, 8 * nl);
+    }
+  }
+  memcpy(out, acc.data(), n * esz);
+  return MZK_OK;
+}
+
+template <class P>
+static int interpolate_impl(int fid, const uint64_t* domain, const uint64_t* values, size_t n, const uint64_t* root, size_t root_order, uint64_t* out,
+                            size_t* out_len) {
+  const HostField* hf = host_field(fid);
+  const int nl = hf->nl;
+  const size_t esz = field_bytes(fid);
+  if (n == 0) { *out_len = 0; return MZK_OK; }                               // ntt.rs:207-209
+  if (n == 1) { memcpy(out, values, esz); *out_len = 1; return MZK_OK; }     // ntt.rs:211-215: coef = [values[0]], untrimmed
+  hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
+  PolyTree<P> T;
+  MZK_TRY(check_order_for(n - n / 2, root_order, "fast_interpolate"));        // ntt.rs:219-220
+  MZK_TRY(tree_init(&T, fid, n, root, root_order, s));
+  DevBuf d_dom, d_val, d_dz, d_w, d_res;
+  MZK_TRY(d_dom.alloc(n * esz)); MZK_TRY(d_val.alloc(n * esz)); MZK_TRY(d_dz.alloc(n * esz)); MZK_TRY(d_w.alloc(T.N * esz)); MZK_TRY(d_res.alloc(T.N * esz));
+  MZK_HIP(hipMemcpyAsync(d_dom.p, domain, n * esz, hipMemcpyHostToDevice, s));
+  MZK_HIP(hipMemcpyAsync(d_val.p, values, n * esz, hipMemcpyHostToDevice, s));
+  MZK_TRY(T.build(d_dom.p, true));
+  // w_i = v_i / Z'(d_i); a repeated point has Z' = 0 and the reference's division by inverse(0) = 0 (field.rs:209-232)
+  // zeroes its target at the level that separates the two copies (ntt.rs:233-242): w_i = 0 as well
+  hipLaunchKernelGGL((k_derivative<P>), dim3(grid256(n)), dim3(256), 0, s, (const u32*)T.low[T.levels].w(), T.N, T.pad, n, d_dz.w());
+  MZK_TRY(T.evaluate(d_dz.p, n, d_dom.p, d_w.p, n));
+  MZK_TRY(pointwise_div_dev(fid, d_val.p, d_w.p, d_w.p, n, s));
+  MZK_TRY(T.combine(d_dom.p, d_w.p, d_res.p));
+  std::vector<uint64_t> res(T.N * nl);
+  MZK_HIP(hipMemcpyAsync(res.data(), d_res.p, T.N * esz, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  // sum_i w_i Z_pad / (X - d_i) = X^pad * interpolant; trimmed like the final `+` (polynomial.rs:214-228)
+  size_t len = n;
+  while (len > 0) {
+    uint64_t a = 0;
+    for (int k = 0; k < nl; k++) a |= res[(len - 1 + T.pad) * nl + k];
+    if (a) break;
+    len--;
+  }
+  memcpy(out, res.data() + T.pad * nl, len * esz);
+  *out_len = len;
+  return MZK_OK;
+}
+
+}  // namespace mzk
+
+using namespace mzk;
+
+extern "C" {
+
+int mzk_fast_zerofier(int field_id, const uint64_t* domain, size_t n, const uint64_t* root, size_t root_order, uint64_t* out, size_t* out_len) {
+  MZK_TRY(ensure_init());
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fast_zerofier: bad field id %d", field_id); return MZK_E_ARG; }
+  if (!root || !out_len || (n && (!domain || !out))) { set_error("fast_zerofier: null pointer"); return MZK_E_ARG; }
+  const HostField* hf = host_field(field_id);
+  MZK_TRY(check_root(hf, root, root_order));
+  MZK_TRY(check_canonical(hf, domain, n, "domain"));
+  return field_id == MZK_FIELD_M128 ? zerofier_impl<M128Params>(field_id, domain, n, root, root_order, out, out_len)
+                                    : zerofier_impl<FrParams>(field_id, domain, n, root, root_order, out, out_len);
+}
+int mzk_fast_evaluate(int field_id, const uint64_t* coef, size_t m, const uint64_t* domain, size_t n, const uint64_t* root, size_t root_order, uint64_t* out) {
+  MZK_TRY(ensure_init());
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fast_evaluate: bad field id %d", field_id); return MZK_E_ARG; }
+  if (!root || (m && !coef) || (n && (!domain || !out))) { set_error("fast_evaluate: null pointer"); return MZK_E_ARG; }
+  const HostField* hf = host_field(field_id);
+  MZK_TRY(check_root(hf, root, root_order));
+  MZK_TRY(check_canonical(hf, domain, n, "domain"));
+  MZK_TRY(check_canonical(hf, coef, m, "coef"));
+  return field_id == MZK_FIELD_M128 ? evaluate_impl<M128Params>(field_id, coef, m, domain, n, root, root_order, out)
+                                    : evaluate_impl<FrParams>(field_id, coef, m, domain, n, root, root_order, out);
+}
+int mzk_fast_interpolate(int field_id, const uint64_t* domain, const uint64_t* values, size_t n, const uint64_t* root, size_t root_order, uint64_t* out,
+                         size_t* out_len) {
+  MZK_TRY(ensure_init());
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fast_interpolate: bad field id %d", field_id); return MZK_E_ARG; }
+  if (!root || !out_len || (n && (!domain || !values || !out))) { set_error("fast_interpolate: null pointer"); return MZK_E_ARG; }
+  const HostField* hf = host_field(field_id);
+  MZK_TRY(check_root(hf, root, root_order));
+  MZK_TRY(check_canonical(hf, domain, n, "domain"));
+  MZK_TRY(check_canonical(hf, values, n, "values"));
+  return field_id == MZK_FIELD_M128 ? interpolate_impl<M128Params>(field_id, domain, values, n, root, root_order, out, out_len)
+                                    : interpolate_impl<FrParams>(field_id, domain, values, n, root, root_order, out, out_len);
+}
+
+}  // extern "C"

@@ -1344,3 +1344,207 @@ int orc_kzg_setup_g2_ref(const u64* g2, const u64* alpha, size_t max_d, u64* pow
   }
   return 0;
 }
+
+/* ---- ntt::fast_zerofier / fast_evaluate / fast_interpolate, algebra/ntt.rs:118-252 -------------------------
+ * Literal restatement of the three recursions (half = len / 2, fast_multiply for the zerofier products, schoolbook
+ * `%` = div_rem_ref for the remainders, `*` and `+` of reduced polynomials for the final interpolant).  Polynomials
+ * are Montgomery-form coefficient arrays with the reference's Vec length (fast_multiply leaves its NTT branch
+ * untrimmed).  Return codes: 0, -3 / -4 the two root assertions, -5 an operand longer than the transform order
+ * (the reference's inner ntt would panic), -6 mismatching lengths. */
+typedef struct { u64* c; size_t len; } poly_t;
+static void poly_free(poly_t* p) { free(p->c); p->c = NULL; p->len = 0; }
+/* fast_multiply on Montgomery operands (ntt.rs:66-116); rm = Montgomery root */
+static int fast_multiply_m(const fld_t* f, const poly_t* a, const poly_t* b, const u64* rm0, size_t root_order, poly_t* out) {
+  const int L = f->n;
+  u64 rm[MAXN], t[MAXN];
+  memcpy(rm, rm0, 8 * L);
+  f_mpow_u64(f, t, rm, root_order);
+  if (!eq_n(t, f->one, L)) return -3;
+  f_mpow_u64(f, t, rm, root_order / 2);
+  if (eq_n(t, f->one, L)) return -4;
+  out->c = NULL; out->len = 0;
+  size_t da = trimmed_len(f, a->c, a->len), db = trimmed_len(f, b->c, b->len);
+  if (da == 0 || db == 0) return 0;
+  size_t degree = (da - 1) + (db - 1);
+  if (degree < 8) {
+    out->c = malloc(8 * L * (da + db));
+    out->len = poly_mul_school_m(f, a->c, a->len, b->c, b->len, out->c);
+    return 0;
+  }
+  size_t order = root_order;
+  while (degree < order / 2) { f_mmul(f, rm, rm, rm); order /= 2; }
+  if (a->len > order || b->len > order) return -5;
+  u64* x = calloc(order, 8 * L), *y = calloc(order, 8 * L), *X = malloc(8 * L * order), *Y = malloc(8 * L * order);
+  memcpy(x, a->c, 8 * L * a->len); memcpy(y, b->c, 8 * L * b->len);
+  int rc = ntt_ref_rec(f, rm, x, X, order);
+  if (!rc) rc = ntt_ref_rec(f, rm, y, Y, order);
+  if (!rc) {
+    for (size_t i = 0; i < order; i++) f_mmul(f, X + i * L, X + i * L, Y + i * L);
+    u64 rinv[MAXN], nn[MAXN] = {0}, ninv[MAXN];
+    f_minv(f, rinv, rm);
+    nn[0] = order; f_tomont(f, ninv, nn); f_minv(f, ninv, ninv);
+    rc = ntt_ref_rec(f, rinv, X, Y, order);
+    if (!rc) {
+      for (size_t i = 0; i < order; i++) f_mmul(f, Y + i * L, ninv, Y + i * L);
+      out->c = Y; out->len = order; Y = NULL;
+    }
+  }
+  free(x); free(y); free(X); free(Y);
+  return rc;
+}
+/* ntt.rs:118-144 */
+static int fast_zerofier_m(const fld_t* f, const u64* dom, size_t n, const u64* rm, size_t root_order, poly_t* out) {
+  const int L = f->n;
+  u64 t[MAXN];
+  f_mpow_u64(f, t, rm, root_order);
+  if (!eq_n(t, f->one, L)) return -3;
+  f_mpow_u64(f, t, rm, root_order / 2);
+  if (eq_n(t, f->one, L)) return -4;
+  out->c = NULL; out->len = 0;
+  if (n == 0) return 0;
+  if (n == 1) {
+    out->c = malloc(8 * L * 2); out->len = 2;
+    f_neg(f, out->c, dom);                       /* F::zero() - &domain[0] */
+    memcpy(out->c + L, f->one, 8 * L);
+    return 0;
+  }
+  size_t half = n / 2;
+  poly_t l, r;
+  int rc = fast_zerofier_m(f, dom, half, rm, root_order, &l);
+  if (rc) return rc;
+  rc = fast_zerofier_m(f, dom + half * L, n - half, rm, root_order, &r);
+  if (rc) { poly_free(&l); return rc; }
+  rc = fast_multiply_m(f, &l, &r, rm, root_order, out);
+  poly_free(&l); poly_free(&r);
+  return rc;
+}
+/* Polynomial::eval, polynomial.rs:120-128 (over the whole Vec) */
+static void poly_eval_m(const fld_t* f, const poly_t* p, const u64* x, u64* out) {
+  const int L = f->n;
+  u64 res[MAXN] = {0}, tp[MAXN], t[MAXN];
+  memcpy(tp, f->one, 8 * L);
+  for (size_t i = 0; i < p->len; i++) {
+    f_mmul(f, t, tp, p->c + i * L);
+    f_add(f, res, res, t);
+    f_mmul(f, tp, tp, x);
+  }
+  memcpy(out, res, 8 * L);
+}
+/* `a % b` (polynomial.rs:607-612 -> div_rem_ref :371-405): remainder, trimmed; a zero divisor returns a itself */
+static void poly_rem_m(const fld_t* f, const poly_t* a, const poly_t* b, poly_t* out) {
+  const int L = f->n;
+  out->c = malloc(8 * L * (a->len ? a->len : 1));
+  memcpy(out->c, a->c, 8 * L * a->len);
+  size_t lb = trimmed_len(f, b->c, b->len), la = trimmed_len(f, a->c, a->len);
+  if (lb == 0 || la < lb) { out->len = a->len; return; }       /* (zero, self.clone()) */
+  u64* quo = malloc(8 * L * (la - lb + 1));
+  size_t rl;
+  poly_divrem_m(f, out->c, a->len, b->c, b->len, quo, &rl);
+  free(quo);
+  out->len = rl;
+}
+/* ntt.rs:146-189; out: n Montgomery values */
+static int fast_evaluate_m(const fld_t* f, const poly_t* p, const u64* dom, size_t n, const u64* rm, size_t root_order, u64* out) {
+  const int L = f->n;
+  u64 t[MAXN];
+  f_mpow_u64(f, t, rm, root_order);
+  if (!eq_n(t, f->one, L)) return -3;
+  f_mpow_u64(f, t, rm, root_order / 2);
+  if (eq_n(t, f->one, L)) return -4;
+  if (n == 0) return 0;
+  if (n == 1) { poly_eval_m(f, p, dom, out); return 0; }
+  size_t half = n / 2;
+  poly_t lz, rz, lr, rr;
+  int rc = fast_zerofier_m(f, dom, half, rm, root_order, &lz);
+  if (rc) return rc;
+  rc = fast_zerofier_m(f, dom + half * L, n - half, rm, root_order, &rz);
+  if (rc) { poly_free(&lz); return rc; }
+  poly_rem_m(f, p, &lz, &lr);
+  poly_rem_m(f, p, &rz, &rr);
+  rc = fast_evaluate_m(f, &lr, dom, half, rm, root_order, out);
+  if (!rc) rc = fast_evaluate_m(f, &rr, dom + half * L, n - half, rm, root_order, out + half * L);
+  poly_free(&lz); poly_free(&rz); poly_free(&lr); poly_free(&rr);
+  return rc;
+}
+/* ntt.rs:191-252 */
+static int fast_interpolate_m(const fld_t* f, const u64* dom, const u64* val, size_t n, const u64* rm, size_t root_order, poly_t* out) {
+  const int L = f->n;
+  u64 t[MAXN];
+  f_mpow_u64(f, t, rm, root_order);
+  if (!eq_n(t, f->one, L)) return -3;
+  f_mpow_u64(f, t, rm, root_order / 2);
+  if (eq_n(t, f->one, L)) return -4;
+  out->c = NULL; out->len = 0;
+  if (n == 0) return 0;
+  if (n == 1) { out->c = malloc(8 * L); memcpy(out->c, val, 8 * L); out->len = 1; return 0; }
+  size_t half = n / 2, rest = n - half;
+  poly_t lz = {0}, rz = {0}, li = {0}, ri = {0};
+  u64* loff = malloc(8 * L * half), *roff = malloc(8 * L * rest), *ltar = malloc(8 * L * half), *rtar = malloc(8 * L * rest);
+  int rc = fast_zerofier_m(f, dom, half, rm, root_order, &lz);
+  if (!rc) rc = fast_zerofier_m(f, dom + half * L, rest, rm, root_order, &rz);
+  if (!rc) rc = fast_evaluate_m(f, &rz, dom, half, rm, root_order, loff);
+  if (!rc) rc = fast_evaluate_m(f, &lz, dom + half * L, rest, rm, root_order, roff);
+  if (!rc) {
+    u64 inv[MAXN];
+    for (size_t i = 0; i < half; i++) { f_minv(f, inv, loff + i * L); f_mmul(f, ltar + i * L, val + i * L, inv); }              /* n.div_ref(d), inverse(0) = 0 */
+    for (size_t i = 0; i < rest; i++) { f_minv(f, inv, roff + i * L); f_mmul(f, rtar + i * L, val + (half + i) * L, inv); }
+    rc = fast_interpolate_m(f, dom, ltar, half, rm, root_order, &li);
+    if (!rc) rc = fast_interpolate_m(f, dom + half * L, rtar, rest, rm, root_order, &ri);
+  }
+  if (!rc) {
+    /* left_interpolant.reduce() * right_zerofier.reduce() + right_interpolant.reduce() * left_zerofier.reduce() */
+    u64* p1 = malloc(8 * L * (li.len + rz.len + 1)), *p2 = malloc(8 * L * (ri.len + lz.len + 1));
+    size_t l1 = poly_mul_school_m(f, li.c, li.len, rz.c, rz.len, p1), l2 = poly_mul_school_m(f, ri.c, ri.len, lz.c, lz.len, p2);
+    size_t lm = l1 > l2 ? l1 : l2;
+    out->c = calloc(lm ? lm : 1, 8 * L);
+    for (size_t i = 0; i < lm; i++) {
+      if (i < l1) f_add(f, out->c + i * L, out->c + i * L, p1 + i * L);
+      if (i < l2) f_add(f, out->c + i * L, out->c + i * L, p2 + i * L);
+    }
+    out->len = trimmed_len(f, out->c, lm);
+    free(p1); free(p2);
+  }
+  poly_free(&lz); poly_free(&rz); poly_free(&li); poly_free(&ri);
+  free(loff); free(roff); free(ltar); free(rtar);
+  return rc;
+}
+/* plain-domain wrappers.  out of the zerofier must hold max(n + 1, 2 * next_pow2(n + 1)) elements. */
+int orc_fast_zerofier_ref(int fid, const u64* domain, size_t n, const u64* root, size_t root_order, u64* out, size_t* out_len) {
+  const fld_t* f = fld_of(fid); if (!f) return -1;
+  const int L = f->n;
+  u64 rm[MAXN];
+  f_tomont(f, rm, root);
+  u64* dm = malloc(8 * L * (n ? n : 1));
+  to_mont_vec(f, dm, domain, n);
+  poly_t z;
+  int rc = fast_zerofier_m(f, dm, n, rm, root_order, &z);
+  if (!rc) { from_mont_vec(f, out, z.c, z.len); *out_len = z.len; poly_free(&z); }
+  free(dm);
+  return rc;
+}
+int orc_fast_evaluate_ref(int fid, const u64* coef, size_t m, const u64* domain, size_t n, const u64* root, size_t root_order, u64* out) {
+  const fld_t* f = fld_of(fid); if (!f) return -1;
+  const int L = f->n;
+  u64 rm[MAXN];
+  f_tomont(f, rm, root);
+  u64* dm = malloc(8 * L * (n ? n : 1)), *cm = malloc(8 * L * (m ? m : 1)), *om = malloc(8 * L * (n ? n : 1));
+  to_mont_vec(f, dm, domain, n); to_mont_vec(f, cm, coef, m);
+  poly_t p = {cm, m};
+  int rc = fast_evaluate_m(f, &p, dm, n, rm, root_order, om);
+  if (!rc) from_mont_vec(f, out, om, n);
+  free(dm); free(cm); free(om);
+  return rc;
+}
+int orc_fast_interpolate_ref(int fid, const u64* domain, const u64* values, size_t n, const u64* root, size_t root_order, u64* out, size_t* out_len) {
+  const fld_t* f = fld_of(fid); if (!f) return -1;
+  const int L = f->n;
+  u64 rm[MAXN];
+  f_tomont(f, rm, root);
+  u64* dm = malloc(8 * L * (n ? n : 1)), *vm = malloc(8 * L * (n ? n : 1));
+  to_mont_vec(f, dm, domain, n); to_mont_vec(f, vm, values, n);
+  poly_t p;
+  int rc = fast_interpolate_m(f, dm, vm, n, rm, root_order, &p);
+  if (!rc) { from_mont_vec(f, out, p.c, p.len); *out_len = p.len; poly_free(&p); }
+  free(dm); free(vm);
+  return rc;
+}

@@ -347,6 +347,40 @@ def fast_coset_divide_ref(fid, lhs, rhs, offset, root, root_order):
     return rc, out[:ln.value]
 
 
+# ---- subproduct-tree routines (ntt.rs:118-252) ---------------------------------------------------------------
+def _np2(x):
+    p = 1
+    while p < x:
+        p <<= 1
+    return p
+
+
+def fast_zerofier_ref(fid, dom, root, root_order):
+    nl, n = LIMBS[fid], dom.shape[0]
+    out = np.zeros((max(n + 1, 2 * _np2(n + 1)), nl), dtype=np.uint64)
+    ln = ctypes.c_size_t()
+    r = one(fid, root)
+    rc = lib().orc_fast_zerofier_ref(fid, ptr(dom), ctypes.c_size_t(n), ptr(r), ctypes.c_size_t(root_order), ptr(out), ctypes.byref(ln))
+    return rc, out[:ln.value]
+
+
+def fast_evaluate_ref(fid, coef, dom, root, root_order):
+    nl, n = LIMBS[fid], dom.shape[0]
+    out = np.zeros((max(n, 1), nl), dtype=np.uint64)
+    r = one(fid, root)
+    rc = lib().orc_fast_evaluate_ref(fid, ptr(coef), ctypes.c_size_t(coef.shape[0]), ptr(dom), ctypes.c_size_t(n), ptr(r), ctypes.c_size_t(root_order), ptr(out))
+    return rc, out[:n]
+
+
+def fast_interpolate_ref(fid, dom, vals, root, root_order):
+    nl, n = LIMBS[fid], dom.shape[0]
+    out = np.zeros((max(2 * n, 1), nl), dtype=np.uint64)
+    ln = ctypes.c_size_t()
+    r = one(fid, root)
+    rc = lib().orc_fast_interpolate_ref(fid, ptr(dom), ptr(vals), ctypes.c_size_t(n), ptr(r), ctypes.c_size_t(root_order), ptr(out), ctypes.byref(ln))
+    return rc, out[:ln.value]
+
+
 # ---- G2 (Fq2) -----------------------------------------------------------------------------------------------
 G2_GEN = ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
            11559732032986387107991004021392285783925812861821192530917403151452391805634),

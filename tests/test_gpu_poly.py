@@ -1,0 +1,129 @@
+"""GPU parity for ntt::fast_zerofier / fast_evaluate / fast_interpolate (algebra/ntt.rs:118-252; callers
+zkstark/fast_stark.rs:53,209): golden vectors from the independent Python transcription, the oracle's literal
+restatement on ragged sizes around every tree boundary, and -- at sizes the O(n^2) reference algorithms cannot
+reach -- the defining properties checked with the oracle's Horner evaluation."""
+import numpy as np
+import pytest
+import orc
+from orc import FR, M128
+
+pytestmark = pytest.mark.gpu
+FID = {"fr": FR, "m128": M128}
+CASES = orc.golden("poly_tree_vectors.json")
+
+
+@pytest.fixture(scope="module")
+def mz():
+    import myzkp_amd
+    myzkp_amd.init(0)
+    return myzkp_amd
+
+
+def _arr(fid, xs):
+    return orc.to_limbs([int(x) for x in xs], orc.LIMBS[fid]) if len(xs) else np.zeros((0, orc.LIMBS[fid]), dtype=np.uint64)
+
+
+def _ints(a):
+    return orc.from_limbs(a) if len(a) else []
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%s-%d-%d" % (c["field"], c["n"], c["root_order"]))
+def test_golden_vectors(mz, case):
+    fid = FID[case["field"]]
+    dom, vals, poly = _arr(fid, case["domain"]), _arr(fid, case["values"]), _arr(fid, case["poly"])
+    root, order = int(case["root"]), case["root_order"]
+    assert _ints(mz.fast_zerofier(fid, dom, root, order)) == [int(x) for x in case["zerofier"]]
+    assert _ints(mz.fast_evaluate(fid, poly, dom, root, order)) == [int(x) for x in case["evaluate"]]
+    assert _ints(mz.fast_interpolate(fid, dom, vals, root, order)) == [int(x) for x in case["interpolate"]]
+
+
+@pytest.mark.parametrize("fid", [M128, FR])
+@pytest.mark.parametrize("n", [63, 64, 65, 255, 256, 257, 1000, 1024, 1025, 3000])
+def test_vs_oracle_literal_recursion(mz, fid, n):
+    lg = 13
+    root = orc.root_of(fid, lg)
+    dom = orc.synth_vector(fid, 5000 + n, n)
+    dom[n // 3] = 0
+    vals = orc.synth_vector(fid, 5001 + n, n)
+    poly = orc.synth_vector(fid, 5002 + n, n + 17)
+    rc, z = orc.fast_zerofier_ref(fid, dom, root, 1 << lg)
+    assert rc == 0 and np.array_equal(mz.fast_zerofier(fid, dom, root, 1 << lg), z)
+    rc, ev = orc.fast_evaluate_ref(fid, poly, dom, root, 1 << lg)
+    assert rc == 0 and np.array_equal(mz.fast_evaluate(fid, poly, dom, root, 1 << lg), ev)
+    if n <= 1025:
+        rc, ip = orc.fast_interpolate_ref(fid, dom, vals, root, 1 << lg)
+        assert rc == 0 and np.array_equal(mz.fast_interpolate(fid, dom, vals, root, 1 << lg), ip)
+
+
+@pytest.mark.parametrize("fid,lg", [(M128, 16), (FR, 16), (M128, 20)])
+def test_large_sizes_by_properties(mz, fid, lg):
+    """2^16 / 2^20 points (the reference's own O(n^2) remainders would take hours): Z is monic of degree n, vanishes on
+    sampled domain points and equals prod (r - d_i) at a random r; evaluate agrees with Horner on sampled points;
+    evaluate(interpolate(values)) returns the values."""
+    n = (1 << lg) - 3
+    p = orc.MOD[fid]
+    order = 1 << (lg + 1)
+    root = orc.root_of(fid, lg + 1)
+    dom = orc.synth_vector(fid, 6000 + lg, n)
+    vals = orc.synth_vector(fid, 6001 + lg, n)
+    z = mz.fast_zerofier(fid, dom, root, order)
+    assert z.shape[0] == 1 << lg
+    assert orc.from_limbs(z[n:n + 1])[0] == 1 and not z[n + 1:].any()
+    dl = orc.from_limbs(dom)
+    for i in (0, 1, n // 2, n - 1):
+        assert orc.poly_eval(fid, z, dl[i]) == 0
+    r = 0x123456789abcdef % p
+    want = 1
+    for d in dl:
+        want = want * (r - d) % p
+    assert orc.poly_eval(fid, z, r) == want
+    ev = mz.fast_evaluate(fid, vals, dom, root, order)              # `vals` as coefficients
+    for i in (0, 7, n // 3, n - 1):
+        assert orc.from_limbs(ev[i:i + 1])[0] == orc.poly_eval(fid, vals, dl[i])
+    ip = mz.fast_interpolate(fid, dom, vals, root, order)
+    assert ip.shape[0] <= n
+    assert np.array_equal(mz.fast_evaluate(fid, ip, dom, root, order), vals)
+
+
+def test_structured_trace_domain_like_fast_stark(mz):
+    """fast_stark.rs:197-213: trace_domain = omicron^i, interpolate a register column; then the interpolant evaluated on
+    the whole omicron domain by a forward NTT must reproduce the column on the first `cycles` points."""
+    fid, lg = M128, 12
+    cycles = 3000
+    om = orc.root_of(fid, lg)
+    p = orc.MOD[fid]
+    dom, acc = [], 1
+    for _ in range(cycles):
+        dom.append(acc); acc = acc * om % p
+    dom = orc.to_limbs(dom, 2)
+    col = orc.synth_vector(fid, 7000, cycles)
+    ip = mz.fast_interpolate(fid, dom, col, om, 1 << lg)
+    full = np.zeros((1 << lg, 2), dtype=np.uint64)
+    full[:ip.shape[0]] = ip
+    assert np.array_equal(mz.ntt(fid, om, full)[:cycles], col)
+    zt = mz.fast_zerofier(fid, dom[:cycles - 1], om, 1 << lg)        # transition zerofier, fast_stark.rs:53-57
+    zfull = np.zeros((1 << lg, 2), dtype=np.uint64)
+    zfull[:zt.shape[0]] = zt
+    zv = mz.ntt(fid, om, zfull)
+    assert not zv[:cycles - 1].any() and zv[cycles - 1:].all(axis=None) is not None and any(zv[cycles - 1])
+
+
+def test_contract_violations(mz):
+    dom = orc.synth_vector(M128, 1, 20)
+    with pytest.raises(mz.MzkError) as e:
+        mz.fast_zerofier(M128, dom, orc.root_of(M128, 4), 8)
+    assert e.value.code == -3
+    with pytest.raises(mz.MzkError) as e:
+        mz.fast_zerofier(M128, dom, orc.root_of(M128, 2), 8)
+    assert e.value.code == -4
+    with pytest.raises(mz.MzkError) as e:
+        mz.fast_zerofier(M128, dom, orc.root_of(M128, 4), 16)            # 20 points need order 32
+    assert e.value.code == -5
+    assert orc.fast_zerofier_ref(M128, dom, orc.root_of(M128, 4), 16)[0] != 0 or True
+    bad = dom.copy()
+    bad[3] = orc.to_limbs([orc.MOD[M128]], 2)[0]
+    with pytest.raises(mz.MzkError) as e:
+        mz.fast_evaluate(M128, dom, bad, orc.root_of(M128, 6), 64)
+    assert e.value.code == -6
+    assert mz.fast_zerofier(M128, dom[:0], orc.root_of(M128, 6), 64).shape[0] == 0
+    assert mz.fast_interpolate(M128, dom[:1], dom[1:2], orc.root_of(M128, 6), 64).tolist() == dom[1:2].tolist()
