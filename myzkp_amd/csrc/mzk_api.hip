@@ -629,8 +629,8 @@ int mzk_fast_coset_divide(int field_id, const uint64_t* lhs, size_t ll, const ui
 }
 
 // ---- MSM / KZG ---------------------------------------------------------------------------------------------
-// Below this size the per-call bucket overhead of 16-bit windows dominates: keep plain prepared points.
-static const size_t SRS_TABLE_MIN_N = (size_t)1 << 14;
+// 4096 <= n < 2^14: the per-call bucket overhead of 16-bit windows dominates, keep plain prepared points
+// (msm_srs_default_tables); below and above, window tables of the width msm_srs_window_bits picks.
 static int srs_check_ctx(const mzk_srs* srs) {
   if (srs->ctx_index != ctx().index) { set_error("SRS handle lives on context %d, the current context is %d (mzk_ctx_select)", srs->ctx_index, ctx().index); return MZK_E_ARG; }
   return MZK_OK;
@@ -671,7 +671,7 @@ int mzk_srs_upload(const uint64_t* powers_xy, size_t n, mzk_srs** out) {
   if (!out || (!powers_xy && n)) { set_error("srs_upload: null pointer"); return MZK_E_ARG; }
   hipStream_t s = ctx().stream;
   WsGuard wsg(s);
-  mzk_srs* h = new mzk_srs{nullptr, n, n >= SRS_TABLE_MIN_N, msm_srs_window_bits(n), ctx().index};
+  mzk_srs* h = new mzk_srs{nullptr, n, msm_srs_default_tables(n), msm_srs_window_bits(n), ctx().index};
   if (n) {
     void *d_plain, *d_mont;
     const size_t copies = h->has_tables ? (size_t)msm_table_windows(h->window_bits) : 2;   // no tables: P_i, then phi(P_i) (GLV layout)
@@ -756,7 +756,7 @@ int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, m
   if (!out || (!d_powers_xy && n)) { set_error("srs_from_device: null pointer"); return MZK_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
   if (with_tables < 0 || (with_tables > 1 && (with_tables < 12 || with_tables > 22))) { set_error("srs_from_device: with_tables must be 0, 1 or a window width 12..22"); return MZK_E_ARG; }
-  mzk_srs* h = new mzk_srs{nullptr, n, with_tables > 1 || (with_tables && n >= SRS_TABLE_MIN_N), with_tables > 1 ? with_tables : msm_srs_window_bits(n), ctx().index};
+  mzk_srs* h = new mzk_srs{nullptr, n, with_tables > 1 || (with_tables && msm_srs_default_tables(n)), with_tables > 1 ? with_tables : msm_srs_window_bits(n), ctx().index};
   if (n) {
     void* d_mont;
     const size_t copies = h->has_tables ? (size_t)msm_table_windows(h->window_bits) : 2;   // no tables: P_i, then phi(P_i) (GLV layout)

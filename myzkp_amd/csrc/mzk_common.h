@@ -125,7 +125,11 @@ enum { MSM_PTS_PLAIN = 0, MSM_PTS_MONT = 1, MSM_PTS_TABLES = 2 };
 // the sort grows with the bucket count and the accumulate kernel gains nothing (shorter bucket runs, more flushes).
 // Other widths stay selectable through mzk_srs_from_device_ex for tuning and tests.
 static inline int msm_table_windows(int c) { return 254 / c + 1; }
-static inline int msm_srs_window_bits(size_t) { return 16; }
+// Small SRS (the reference's actual sizes: a few thousand powers at most) take the three-launch path of mzk_msm.hip; with
+// tables there is no window Horner either (its ~120 serial doublings are the latency floor of a small generic MSM), so
+// they get narrow windows: 8 bits = 32 tables x 128 buckets up to 1024 points, 10 bits = 26 tables x 512 buckets below 4096.
+static inline int msm_srs_window_bits(size_t n) { return n <= 1024 ? 8 : (n < 4096 ? 10 : 16); }
+static inline bool msm_srs_default_tables(size_t n) { return n > 0 && (n < 4096 || n >= ((size_t)1 << 14)); }
 #define MSM_PTS_TABLES_C(c) (MSM_PTS_TABLES | ((c) << 8))
 int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int point_kind, size_t table_stride, void* d_out,
                  bool out_partial_xyzz, hipStream_t s);

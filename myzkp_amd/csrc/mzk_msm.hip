@@ -842,6 +842,96 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_reduce_tail(u32* __restrict__ 
   if (threadIdx.x < 32) out[(size_t)blockIdx.x * 32 + threadIdx.x] = sh[threadIdx.x];
 }
 
+// ---- small inputs (n < 4096): three launches instead of twenty-five ---------------------------------------------
+// The reference's real callers commit to polynomials of at most a few thousand coefficients (das/avail.rs:96,
+// das/eigenda.rs:99, every test in kzg.rs), where the general pipeline is nothing but launch latency: 25+ dependent
+// launches of kernels that each run for microseconds.  Here:
+//   k_small_sort        ONE workgroup: digits -> LDS histogram -> scan -> LDS cursors -> sorted entries (global)
+//   k_small_accumulate  one WAVE per bucket: lanes stride over the bucket's entries (madd), then the 64 partials are
+//                       summed by a quad-cooperative tree through LDS (seven rounds of ~2 us instead of a serial chain)
+//   k_reduce_tail       all halving steps of a bucket set inside one workgroup (t_start = 0), then k_window_combine.
+constexpr int SMALL_SORT_THREADS = 1024;
+constexpr size_t SMALL_MAX_N = 4096;          // exclusive
+constexpr size_t SMALL_MAX_BUCKETS = 8192;
+__global__ __launch_bounds__(SMALL_SORT_THREADS) void k_small_sort(const u32* __restrict__ scalars, size_t n, DigitLayout L, int NB,
+                                                                    u32* __restrict__ offsets, u32* __restrict__ entries) {
+  extern __shared__ u32 sh_small[];
+  u32* hist = sh_small;                  // [NB]   counts, then cursors
+  u32* scan = sh_small + NB;             // [SMALL_SORT_THREADS]
+  const int tid = threadIdx.x;
+  for (int b = tid; b < NB; b += SMALL_SORT_THREADS) hist[b] = 0;
+  __syncthreads();
+  for (size_t i = tid; i < n; i += SMALL_SORT_THREADS) {
+    u32 w[8];
+    load_scalar_canonical(scalars, i, w);
+    walk_digits(w, L, i, [&](int, u32 key, u32) { atomicAdd(&hist[key], 1u); });
+  }
+  __syncthreads();
+  const int per = (NB + SMALL_SORT_THREADS - 1) / SMALL_SORT_THREADS;
+  u32 local = 0;
+  for (int q = 0; q < per; q++) { const int b = tid * per + q; if (b < NB) local += hist[b]; }
+  scan[tid] = local;
+  __syncthreads();
+  for (int off = 1; off < SMALL_SORT_THREADS; off <<= 1) {
+    const u32 t = (tid >= off) ? scan[tid - off] : 0u;
+    __syncthreads();
+    scan[tid] += t;
+    __syncthreads();
+  }
+  u32 run = scan[tid] - local;
+  for (int q = 0; q < per; q++) {
+    const int b = tid * per + q;
+    if (b < NB) { const u32 c = hist[b]; hist[b] = run; offsets[b] = run; run += c; }
+  }
+  if (tid == SMALL_SORT_THREADS - 1) offsets[NB] = scan[tid];
+  __syncthreads();
+  for (size_t i = tid; i < n; i += SMALL_SORT_THREADS) {
+    u32 w[8];
+    load_scalar_canonical(scalars, i, w);
+    walk_digits(w, L, i, [&](int, u32 key, u32 payload) { entries[atomicAdd(&hist[key], 1u)] = payload; });
+  }
+}
+__global__ __launch_bounds__(64) void k_small_accumulate(const u32* __restrict__ points_mont, const u32* __restrict__ offsets,
+                                                          const u32* __restrict__ entries, u32* __restrict__ buckets) {
+  __shared__ __attribute__((aligned(16))) u32 sh[2][64 * 32];
+  const size_t b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const u32 o0 = offsets[b], o1 = offsets[b + 1];
+  Xyzz acc = xyzz_inf();
+  for (u32 e = o0 + lane; e < o1; e += 64) {
+    const u32 ent = entries[e];
+    u32 w[16];
+    const size_t idx = ent & 0x7fffffffu;
+    load_words8(points_mont + idx * 16, w);
+    load_words8(points_mont + idx * 16 + 8, w + 8);
+    if (affine_words_is_inf(w)) continue;
+    Affine p = affine_load_mont(w);
+    if (ent >> 31) p = affine_neg(p);
+    acc = xyzz_madd(acc, p);
+  }
+  u32 cnt = o1 - o0;
+  if (cnt > 64) cnt = 64;
+  if (cnt <= 1) {            // wave-uniform
+    if (lane == 0) xyzz_gstore(buckets, b, acc);
+    return;
+  }
+  u32 width = 2;
+  while (width < cnt) width <<= 1;            // partials beyond `cnt` are infinity: sum the first `width` only
+  xyzz_gstore(sh[0], lane, acc);
+  __syncthreads();
+  const int quad = lane >> 2, ql = lane & 3;
+  int cur = 0;
+  for (u32 m = width; m > 1; m >>= 1) {
+    for (u32 pair = quad; pair < m / 2; pair += 16) {     // quad-uniform
+      const Xyzz x = xyzz_gload_quad(sh[cur], 2 * pair, ql), y = xyzz_gload_quad(sh[cur], 2 * pair + 1, ql);
+      xyzz_gstore_quad(sh[cur ^ 1], pair, xyzz_add_quad(x, y, ql), ql);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (lane < 32) buckets[b * 32 + lane] = sh[cur][lane];
+}
+
 // k_window_combine / k_fold_partials live in mzk_msm_tail.hip (compact-code build).
 int launch_window_combine(const u32* wsum, int nwin, int c, int out_xyzz, u32* out, hipStream_t s);
 int launch_fold_partials(const u32* partials, int count, u32* out, hipStream_t s);
@@ -972,6 +1062,27 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     pts = (const u32*)pm;
   }
   const size_t E_max = n * (size_t)(L.glv ? 2 * sh.nwin : sh.nwin);
+  if (n < SMALL_MAX_N && NB <= SMALL_MAX_BUCKETS) {
+    u32 *offsets, *entries, *buckets, *wsum;
+    MZK_TRY(ws_get(WS_MSM_OFFSETS, (NB + 1) * 4, (void**)&offsets));
+    MZK_TRY(ws_get(WS_MSM_ENTRIES, E_max * 4, (void**)&entries));
+    MZK_TRY(ws_get(WS_MSM_BUCKETS, NB * 128, (void**)&buckets));
+    MZK_TRY(ws_get(WS_MSM_OUT, (size_t)MAX_WINDOWS * 128, (void**)&wsum));
+    prof_begin(s, MZK_PH_MSM_SORT);
+    hipLaunchKernelGGL(k_small_sort, dim3(1), dim3(SMALL_SORT_THREADS), (NB + SMALL_SORT_THREADS) * 4, s, (const u32*)d_scalars, n, L, (int)NB, offsets, entries);
+    prof_end(s, MZK_PH_MSM_SORT);
+    prof_begin(s, MZK_PH_MSM_ACCUMULATE);
+    hipLaunchKernelGGL(k_small_accumulate, dim3((unsigned)NB), dim3(64), 0, s, pts, (const u32*)offsets, (const u32*)entries, buckets);
+    prof_end(s, MZK_PH_MSM_ACCUMULATE);
+    prof_begin(s, MZK_PH_MSM_REDUCE);
+    hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)red_windows), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, 0, wsum);
+    prof_end(s, MZK_PH_MSM_REDUCE);
+    prof_begin(s, MZK_PH_MSM_COMBINE);
+    MZK_TRY(launch_window_combine((const u32*)wsum, red_windows, horner_c, out_partial_xyzz ? 1 : 0, (u32*)d_out, s));
+    prof_end(s, MZK_PH_MSM_COMBINE);
+    MZK_HIP(hipGetLastError());
+    return MZK_OK;
+  }
   // entries pack the point reference into 31 bits (+ sign) and entry positions into 32: reject shapes that overflow
   // (window widths below 16 on a > 2^26-point SRS) instead of gathering a wrong table row
   {

@@ -1,26 +1,31 @@
-import sys, time; sys.path.insert(0, "tests"); sys.path.insert(0, ".")
-import numpy as np, orc, myzkp_amd as mz
-mz.init(0)
-def t(label, f, reps=20):
-    f(); f()
-    t0 = time.perf_counter()
-    for _ in range(reps): f()
-    print("%-44s %8.3f ms" % (label, (time.perf_counter() - t0) / reps * 1e3), flush=True)
-for n in (16, 1024, 1 << 14):
-    s = orc.synth_vector(orc.FR, 1, n); p = orc.synth_points(2, n)
-    t("msm_g1 (host buffers) n=%d" % n, lambda: mz.msm_g1(s, p))
-    srs = mz.kzg_setup_g1(12345, n - 1)
-    t("kzg_setup_g1 n=%d" % n, lambda: mz.kzg_setup_g1(12345, n - 1), 5)
-    t("kzg_commit n=%d" % n, lambda: mz.kzg_commit(s, srs))
-    t("kzg_open n=%d" % n, lambda: mz.kzg_open(s, 777, srs))
-    h = mz.Srs(srs)
-    t("Srs.commit n=%d" % n, lambda: h.commit(s))
-    h.close()
-    lg = n.bit_length() - 1
-    for fid, name in ((orc.FR, "Fr"), (orc.M128, "M128")):
-        v = orc.synth_vector(fid, 3, n); root = orc.root_of(fid, lg)
-        t("ntt %s n=%d" % (name, n), lambda: mz.ntt(fid, root, v))
-        t("intt %s n=%d" % (name, n), lambda: mz.intt(fid, root, v))
-    v = orc.synth_vector(orc.M128, 3, n)
-    t("merkle_commit_field M128 n=%d" % n, lambda: mz.merkle_commit_field(orc.M128, v))
-    t("fri_fold M128 n=%d" % n, lambda: mz.fri_fold(orc.M128, v, 5, orc.M128_GEN, orc.root_of(orc.M128, lg)))
+"""Latency of small MSMs / KZG commits (the reference's real sizes): generic MSM on arbitrary points vs commit against
+an SRS handle, 2^4 .. 2^13 pairs, device-resident inputs, one call at a time.   python tools/timing/small_latency.py"""
+import ctypes, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import myzkp_amd as mz
+mz.init(0); L = mz.lib()
+dev = torch.device("cuda", 0)
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+for lg in (4, 8, 10, 11, 12, 13, 14):
+    n = 1 << lg
+    sc = torch.empty(n * 4, dtype=torch.int64, device=dev); pt = torch.empty(n * 8, dtype=torch.int64, device=dev)
+    L.mzk_synth_field_dev(0, ctypes.c_uint64(1), ctypes.c_size_t(n), ctypes.c_void_p(sc.data_ptr()), st)
+    L.mzk_synth_g1_points_dev(ctypes.c_uint64(2), ctypes.c_size_t(n), ctypes.c_void_p(pt.data_ptr()), st)
+    h = ctypes.c_void_p()
+    assert L.mzk_srs_from_device(ctypes.c_void_p(pt.data_ptr()), ctypes.c_size_t(n), ctypes.byref(h), st) == 0
+    out = torch.zeros(16, dtype=torch.int64, device=dev)
+    res = []
+    for fn in (lambda: L.mzk_msm_g1_bn254_dev(ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(pt.data_ptr()), ctypes.c_size_t(n), ctypes.c_void_p(out.data_ptr()), st),
+               lambda: L.mzk_kzg_commit_srs_dev(h, ctypes.c_void_p(sc.data_ptr()), ctypes.c_size_t(n), ctypes.c_void_p(out.data_ptr() + 64), 0, st)):
+        t_end = time.perf_counter() + 0.3
+        while time.perf_counter() < t_end:
+            assert fn() == 0; torch.cuda.synchronize()
+        reps = 50
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn(); torch.cuda.synchronize()
+        res.append((time.perf_counter() - t0) / reps * 1e3)
+    same = bool(torch.equal(out[:8], out[8:]))
+    print("2^%-2d pairs: generic MSM %.3f ms   commit vs SRS handle %.3f ms   same point: %s" % (lg, res[0], res[1], same), flush=True)
+    L.mzk_srs_free(h)
