@@ -292,8 +292,14 @@ int mzk_synth_g1_points_dev(uint64_t seed, size_t n, void* d_out_xy, void* strea
 /* ---- per-phase device timing (HIP events recorded on the launch stream around each kernel group) ---- */
 enum { MZK_PH_MSM_PREPARE = 0, MZK_PH_MSM_SORT = 1, MZK_PH_MSM_ACCUMULATE = 2, MZK_PH_MSM_REDUCE = 3,
        MZK_PH_MSM_COMBINE = 4, MZK_PH_NTT_PASS0 = 5, MZK_PH_NTT_PASS1 = 6, MZK_PH_NTT_PASS2 = 7,
-       MZK_PH_NTT_PASS3 = 8, MZK_PH_NTT_PRESCALE = 9, MZK_PH_MERKLE = 10, MZK_PH_COUNT = 11 };
+       MZK_PH_NTT_PASS3 = 8, MZK_PH_NTT_PRESCALE = 9, MZK_PH_MERKLE = 10,
+       MZK_PH_MSM_SEG_COMBINE = 11,   /* k_seg_combine (+ heavy): sums a bucket's segment partials; MSM_ACCUMULATE is k_seg_accumulate alone */
+       MZK_PH_NTT_TOTAL = 12,         /* one pair around all passes of a transform */
+       MZK_PH_COUNT = 13 };
 int mzk_prof_enable(int on);
+/* bit p set = phase p gets its event pair while profiling is on (default: all).  An event pair costs a few
+ * microseconds of stream time, so a timed region instruments only the kernel it prices. */
+int mzk_prof_select(uint32_t phase_mask);
 int mzk_prof_reset(void);
 /* Synchronises the device, folds all pending event pairs, returns accumulated ms and launch count. */
 int mzk_prof_read(int phase, double* total_ms, uint64_t* launches);

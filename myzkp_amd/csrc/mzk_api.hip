@@ -66,22 +66,28 @@ void ws_release_all() {
 // The workspace slots are shared by every entry point of a context.  *_dev calls only enqueue work, so a call on
 // stream B could overwrite slots that kernels of an earlier call on stream A are still reading: the guard orders B
 // behind the last user's completion event (no host synchronisation), and records its own at scope exit.
+// The event is recorded LAZILY, on the previous user's stream, at the moment a different stream shows up: that still
+// covers everything enqueued there, and steady single-stream use (every benchmark loop) pays no marker per call.
 WsGuard::WsGuard(hipStream_t s_) : s(s_) {
   Context& c = ctx();
   if (!c.ready) return;
-  if (c.ws_used && c.ws_last != s && c.ws_event) (void)hipStreamWaitEvent(s, c.ws_event, 0);
+  if (c.ws_used && c.ws_last != s) {
+    if (!c.ws_event && hipEventCreateWithFlags(&c.ws_event, hipEventDisableTiming) != hipSuccess) c.ws_event = nullptr;
+    // (the previous stream may be gone by now -- a destroyed caller stream: fall back to a device-wide wait)
+    if (c.ws_event && hipEventRecord(c.ws_event, c.ws_last) == hipSuccess) (void)hipStreamWaitEvent(s, c.ws_event, 0);
+    else { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }
+  }
 }
 WsGuard::~WsGuard() {
   Context& c = ctx();
   if (!c.ready) return;
-  if (!c.ws_event && hipEventCreateWithFlags(&c.ws_event, hipEventDisableTiming) != hipSuccess) { c.ws_event = nullptr; return; }
-  (void)hipEventRecord(c.ws_event, s);
   c.ws_last = s;
   c.ws_used = true;
 }
 
 // ---- profiling --------------------------------------------------------------------------------------
 static bool g_prof_on = false;
+static uint32_t g_prof_mask = 0xffffffffu;     // phases that get event pairs while profiling is on
 struct ProfPair { hipEvent_t a, b; int phase; };
 static std::vector<ProfPair> g_prof_pending;
 static std::vector<hipEvent_t> g_prof_pool;
@@ -95,7 +101,7 @@ static hipEvent_t prof_event() {
   return e;
 }
 void prof_begin(hipStream_t s, int phase) {
-  if (!g_prof_on) return;
+  if (!g_prof_on || !((g_prof_mask >> phase) & 1u)) return;
   hipEvent_t e = prof_event();
   (void)hipEventRecord(e, s);
   g_prof_open[phase] = e;
@@ -328,6 +334,7 @@ void mzk_shutdown(void) {
 }
 
 int mzk_prof_enable(int on) { g_prof_on = on != 0; return MZK_OK; }
+int mzk_prof_select(uint32_t phase_mask) { g_prof_mask = phase_mask; return MZK_OK; }
 int mzk_prof_reset(void) {
   prof_drain();
   for (int i = 0; i < MZK_PH_COUNT; i++) { g_prof_ms[i] = 0; g_prof_cnt[i] = 0; }
@@ -342,7 +349,8 @@ int mzk_prof_read(int phase, double* total_ms, uint64_t* launches) {
 }
 const char* mzk_prof_name(int phase) {
   static const char* names[MZK_PH_COUNT] = {"msm_prepare_points", "msm_digit_sort", "msm_bucket_accumulate", "msm_bucket_reduce",
-                                            "msm_window_combine", "ntt_pass0", "ntt_pass1", "ntt_pass2", "ntt_pass3", "ntt_coset_prescale", "merkle_sha3_levels"};
+                                            "msm_window_combine", "ntt_pass0", "ntt_pass1", "ntt_pass2", "ntt_pass3", "ntt_coset_prescale", "merkle_sha3_levels",
+                                            "msm_segment_combine", "ntt_whole_transform"};
   return (phase >= 0 && phase < MZK_PH_COUNT) ? names[phase] : "?";
 }
 

@@ -46,8 +46,8 @@ struct Context {
   hipStream_t stream = nullptr;  // library-owned stream for the host-buffer entry points
   WsBuf ws[WS_COUNT];
   uint64_t ws_gen = 1;           // bumps whenever every workspace buffer has been released (cached device tables die with it)
-  // Stream-order guard of the shared workspace: the last entry point recorded ws_event on ws_last; an entry point on
-  // another stream waits for it before touching the slots (WsGuard).
+  // Stream-order guard of the shared workspace: ws_last = stream of the last entry point; an entry point on another
+  // stream records ws_event on ws_last and waits for it before touching the slots (WsGuard).
   hipEvent_t ws_event = nullptr;
   hipStream_t ws_last = nullptr;
   bool ws_used = false;

@@ -1198,13 +1198,15 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     hipLaunchKernelGGL(k_seg_accumulate<true>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, pts, offsets, entries, slots, NB, seg);
   else
     hipLaunchKernelGGL(k_seg_accumulate<false>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, pts, offsets, entries, slots, NB, seg);
+  prof_end(s, MZK_PH_MSM_ACCUMULATE);
+  prof_begin(s, MZK_PH_MSM_SEG_COMBINE);
   if (NB >= ((size_t)1 << 17))
     hipLaunchKernelGGL(k_seg_combine_wide, dim3((unsigned)((NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy);
   else
     hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy);
   hipLaunchKernelGGL(k_seg_combine_heavy, dim3(512), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)offsets, buckets, seg, (const u32*)heavy);
   MZK_HIP(hipGetLastError());
-  prof_end(s, MZK_PH_MSM_ACCUMULATE);
+  prof_end(s, MZK_PH_MSM_SEG_COMBINE);
   prof_begin(s, MZK_PH_MSM_REDUCE);
 
   // bucket reduction: sum_b (b+1) B_b per bucket set (in-place halving), then the window Horner

@@ -485,6 +485,7 @@ static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t 
   const LevelInfo& li = pl->li;
   const unsigned logn = pl->logn;
 
+  ProfScope whole(s, MZK_PH_NTT_TOTAL);
   auto lds_for = [](int lgn) { return sizeof(u32) * P::L * ((size_t)TILE + (lgn >= 2 ? ((size_t)1 << (lgn - 1)) : 1)); };  // tile + in-tile twiddles
   const u32* src = d_in;
   u32* tmp = nullptr;
