@@ -629,6 +629,43 @@ __global__ __launch_bounds__(256) void k_scan_finish(u32* __restrict__ offsets, 
   }
 }
 
+// Up to SCAN_SINGLE_MAX counters: ONE workgroup scans the whole array (three dependent launches of tiny kernels
+// were ~25 us of pure launch latency, twice per MSM).  Lane t owns the contiguous run [t per, (t+1) per).
+constexpr int SCAN_SINGLE_THREADS = 1024;
+constexpr size_t SCAN_SINGLE_MAX = (size_t)1 << 18;
+__global__ __launch_bounds__(SCAN_SINGLE_THREADS) void k_scan_single(const u32* in, u32* out, size_t n) {      // in == out allowed: no __restrict__
+  __shared__ u32 sh[SCAN_SINGLE_THREADS];
+  const int tid = threadIdx.x;
+  const size_t per = (n + SCAN_SINGLE_THREADS - 1) / SCAN_SINGLE_THREADS;
+  const size_t lo = (size_t)tid * per, hi = (lo + per < n) ? lo + per : n;
+  u32 sum = 0;
+  for (size_t i = lo; i < hi; i++) sum += in[i];
+  sh[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < SCAN_SINGLE_THREADS; off <<= 1) {
+    const u32 t = (tid >= off) ? sh[tid - off] : 0u;
+    __syncthreads();
+    sh[tid] += t;
+    __syncthreads();
+  }
+  u32 run = sh[tid] - sum;
+  for (size_t i = lo; i < hi; i++) { const u32 v = in[i]; out[i] = run; run += v; }     // in == out allowed: read before write
+  if (tid == SCAN_SINGLE_THREADS - 1) out[n] = sh[tid];
+}
+// out[i] = sum_{j<i} in[j] for i <= n (out[n] = total); in == out allowed; scratch: (ceil(n / SCAN_BLOCK) + 2) words
+static int launch_exclusive_scan(const u32* in, u32* out, size_t n, u32* scratch, hipStream_t s) {
+  if (n <= SCAN_SINGLE_MAX) {
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(SCAN_SINGLE_THREADS), 0, s, in, out, n);
+  } else {
+    const size_t sb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)sb), dim3(256), 0, s, in, out, scratch, n);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, scratch, sb, scratch + sb);
+    hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s, out, (const u32*)scratch, (const u32*)(scratch + sb), n);
+  }
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+
 // ---- 4. bucket accumulation, segmented ------------------------------------------------------------------
 // The sorted entry array is cut into fixed segments of `seg` entries, one lane per segment, so the work
 // per lane is equal whatever the scalar distribution (no Poisson tail, no skew cliff).  A lane walks
@@ -812,7 +849,9 @@ constexpr int TAIL_THREADS = 512;
 constexpr int TAIL_QUADS = TAIL_THREADS / 4;
 // Remaining steps t_start..lgB-1 inside one workgroup per bucket set, then the weighted sum
 // buf[0] + sum_j 2^j buf[2^j] (quad j doubles j times, LDS tree sum).  out[w] = XYZZ result of set w.
-__global__ __launch_bounds__(TAIL_THREADS) void k_reduce_tail(u32* __restrict__ buckets, int lgB, int t_start, u32* __restrict__ out) {
+// finish_affine (single bucket set only): convert the sum to the canonical affine point here (one safegcd inversion on
+// lane 0) instead of handing a 128-byte record to k_window_combine -- one dependent launch less on the merged path.
+__global__ __launch_bounds__(TAIL_THREADS) void k_reduce_tail(u32* __restrict__ buckets, int lgB, int t_start, u32* __restrict__ out, int finish_affine) {
   __shared__ __attribute__((aligned(16))) u32 sh[32 * 32];
   u32* buf = buckets + ((size_t)blockIdx.x << lgB) * 32;
   const int lane = threadIdx.x & 3, quad = threadIdx.x >> 2;
@@ -838,6 +877,16 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_reduce_tail(u32* __restrict__ 
       xyzz_gstore_quad(sh, quad, xyzz_add_quad(a, b, lane), lane);
     }
     __syncthreads();
+  }
+  if (finish_affine) {
+    if (threadIdx.x == 0) {
+      u32 wds[16];
+      Affine af;
+      if (xyzz_to_affine<true>(xyzz_load(sh), &af)) affine_store_plain(af, wds);
+      else for (int i = 0; i < 16; i++) wds[i] = 0;
+      for (int i = 0; i < 16; i++) out[i] = wds[i];
+    }
+    return;
   }
   if (threadIdx.x < 32) out[(size_t)blockIdx.x * 32 + threadIdx.x] = sh[threadIdx.x];
 }
@@ -1005,10 +1054,7 @@ static int sort_records(const SortArgs& a, hipStream_t s) {
                      (const u32*)a.binhist, a.nwg, (R*)a.tmp);
   hipLaunchKernelGGL((k_fine_count<REC>), dim3(COARSE_BINS, a.S), dim3(SORT2_THREADS), 0, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg, a.F, a.S,
                      a.fb, a.finehist);
-  hipLaunchKernelGGL(k_scan_local, dim3((unsigned)a.sb_f), dim3(256), 0, s, (const u32*)a.finehist, a.finehist, a.scan3, a.n_fine);
-  hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, a.scan3, a.sb_f, a.scan3 + a.sb_f);
-  hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((a.n_fine + 1 + 255) / 256)), dim3(256), 0, s, a.finehist, (const u32*)a.scan3,
-                     (const u32*)(a.scan3 + a.sb_f), a.n_fine);
+  MZK_TRY(launch_exclusive_scan((const u32*)a.finehist, a.finehist, a.n_fine, a.scan3, s));
   if (a.F <= STAGE_F_MAX) {
     const size_t lds = ((size_t)3 * a.F + SORT2_THREADS + STAGE_CAP) * 4 + (size_t)STAGE_CAP * 2;
     bool& staged_attr = ctx().attr_done[sizeof(R) == 4 ? ATTR_FINE_SCATTER4 : ATTR_FINE_SCATTER8];     // per instantiation and context
@@ -1075,11 +1121,16 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     hipLaunchKernelGGL(k_small_accumulate, dim3((unsigned)NB), dim3(64), 0, s, pts, (const u32*)offsets, (const u32*)entries, buckets);
     prof_end(s, MZK_PH_MSM_ACCUMULATE);
     prof_begin(s, MZK_PH_MSM_REDUCE);
-    hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)red_windows), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, 0, wsum);
-    prof_end(s, MZK_PH_MSM_REDUCE);
-    prof_begin(s, MZK_PH_MSM_COMBINE);
-    MZK_TRY(launch_window_combine((const u32*)wsum, red_windows, horner_c, out_partial_xyzz ? 1 : 0, (u32*)d_out, s));
-    prof_end(s, MZK_PH_MSM_COMBINE);
+    if (L.merged) {      // one bucket set: the tail writes the result itself (affine point or the XYZZ partial record)
+      hipLaunchKernelGGL(k_reduce_tail, dim3(1), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, 0, (u32*)d_out, out_partial_xyzz ? 0 : 1);
+      prof_end(s, MZK_PH_MSM_REDUCE);
+    } else {
+      hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)red_windows), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, 0, wsum, 0);
+      prof_end(s, MZK_PH_MSM_REDUCE);
+      prof_begin(s, MZK_PH_MSM_COMBINE);
+      MZK_TRY(launch_window_combine((const u32*)wsum, red_windows, horner_c, out_partial_xyzz ? 1 : 0, (u32*)d_out, s));
+      prof_end(s, MZK_PH_MSM_COMBINE);
+    }
     MZK_HIP(hipGetLastError());
     return MZK_OK;
   }
@@ -1149,9 +1200,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     u32* scan2;
     MZK_TRY(ws_get(WS_MSM_SCAN, (sb_c + sb_f + 4) * 4, (void**)&scan2));
     hipLaunchKernelGGL(k_coarse_count, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
-    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)sb_c), dim3(256), 0, s, (const u32*)binhist, binhist, scan2, n_coarse);
-    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, scan2, sb_c, scan2 + sb_c);
-    hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((n_coarse + 1 + 255) / 256)), dim3(256), 0, s, binhist, (const u32*)scan2, (const u32*)(scan2 + sb_c), n_coarse);
+    MZK_TRY(launch_exclusive_scan((const u32*)binhist, binhist, n_coarse, scan2, s));
     int fb = 0;
     while ((1 << fb) < F) fb++;
     // largest point reference: merged nwin * stride, generic phi_offset + n
@@ -1177,17 +1226,13 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     }
     hipLaunchKernelGGL(k_digits_count_lds, dim3(nwg), dim3(LDS_SORT_THREADS), lds, s, (const u32*)d_scalars, n, per_wg, L, wg_hist, ranks);
     hipLaunchKernelGGL(k_wg_hist_prefix, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, s, wg_hist, nwg, (int)NB, counts);
-    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)scan_blocks), dim3(256), 0, s, counts, offsets, scan_tmp, NB);
-    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, scan_tmp, scan_blocks, scan_tmp + scan_blocks);
-    hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((NB + 1 + 255) / 256)), dim3(256), 0, s, offsets, scan_tmp, scan_tmp + scan_blocks, NB);
+    MZK_TRY(launch_exclusive_scan((const u32*)counts, offsets, NB, scan_tmp, s));
     hipLaunchKernelGGL(k_digits_scatter_lds, dim3(nwg), dim3(LDS_SORT_THREADS), lds, s, (const u32*)d_scalars, n, per_wg, L, (const u32*)offsets,
                        (const u32*)wg_hist, (const u32*)ranks, entries);
   } else {
     MZK_HIP(hipMemsetAsync(counts, 0, NB * 4, s));
     hipLaunchKernelGGL(k_digits_count, dim3(nblk), dim3(256), 0, s, (const u32*)d_scalars, n, L, counts, ranks);
-    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)scan_blocks), dim3(256), 0, s, counts, offsets, scan_tmp, NB);
-    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, scan_tmp, scan_blocks, scan_tmp + scan_blocks);
-    hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((NB + 1 + 255) / 256)), dim3(256), 0, s, offsets, scan_tmp, scan_tmp + scan_blocks, NB);
+    MZK_TRY(launch_exclusive_scan((const u32*)counts, offsets, NB, scan_tmp, s));
     hipLaunchKernelGGL(k_digits_scatter, dim3(nblk), dim3(256), 0, s, (const u32*)d_scalars, n, L, offsets, ranks, entries);
   }
   MZK_HIP(hipGetLastError());
@@ -1221,12 +1266,18 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     else
       hipLaunchKernelGGL(k_halve_step, dim3((unsigned)((4 * total + 127) / 128), (unsigned)red_windows), dim3(128), 0, s, buckets, sh.lgB, t);
   }
-  hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)red_windows), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, t_start, wsum);
-  MZK_HIP(hipGetLastError());
-  prof_end(s, MZK_PH_MSM_REDUCE);
-  prof_begin(s, MZK_PH_MSM_COMBINE);
-  MZK_TRY(launch_window_combine((const u32*)wsum, red_windows, horner_c, out_partial_xyzz ? 1 : 0, (u32*)d_out, s));
-  prof_end(s, MZK_PH_MSM_COMBINE);
+  if (L.merged) {
+    hipLaunchKernelGGL(k_reduce_tail, dim3(1), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, t_start, (u32*)d_out, out_partial_xyzz ? 0 : 1);
+    MZK_HIP(hipGetLastError());
+    prof_end(s, MZK_PH_MSM_REDUCE);
+  } else {
+    hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)red_windows), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, t_start, wsum, 0);
+    MZK_HIP(hipGetLastError());
+    prof_end(s, MZK_PH_MSM_REDUCE);
+    prof_begin(s, MZK_PH_MSM_COMBINE);
+    MZK_TRY(launch_window_combine((const u32*)wsum, red_windows, horner_c, out_partial_xyzz ? 1 : 0, (u32*)d_out, s));
+    prof_end(s, MZK_PH_MSM_COMBINE);
+  }
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }

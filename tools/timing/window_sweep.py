@@ -26,7 +26,7 @@ for lg in [int(x) for x in sys.argv[1].split(",")]:
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
         L.mzk_prof_enable(0)
         ph = {}
-        for p in range(11):
+        for p in range(13):
             ms, cnt = ctypes.c_double(0), ctypes.c_uint64(0)
             L.mzk_prof_read(p, ctypes.byref(ms), ctypes.byref(cnt))
             if cnt.value: ph[L.mzk_prof_name(p).decode()[4:]] = round(ms.value / cnt.value, 3)
