@@ -629,39 +629,14 @@ __global__ __launch_bounds__(256) void k_scan_finish(u32* __restrict__ offsets, 
   }
 }
 
-// Up to SCAN_SINGLE_MAX counters: ONE workgroup scans the whole array (three dependent launches of tiny kernels
-// were ~25 us of pure launch latency, twice per MSM).  Lane t owns the contiguous run [t per, (t+1) per).
-constexpr int SCAN_SINGLE_THREADS = 1024;
-constexpr size_t SCAN_SINGLE_MAX = (size_t)1 << 18;
-__global__ __launch_bounds__(SCAN_SINGLE_THREADS) void k_scan_single(const u32* in, u32* out, size_t n) {      // in == out allowed: no __restrict__
-  __shared__ u32 sh[SCAN_SINGLE_THREADS];
-  const int tid = threadIdx.x;
-  const size_t per = (n + SCAN_SINGLE_THREADS - 1) / SCAN_SINGLE_THREADS;
-  const size_t lo = (size_t)tid * per, hi = (lo + per < n) ? lo + per : n;
-  u32 sum = 0;
-  for (size_t i = lo; i < hi; i++) sum += in[i];
-  sh[tid] = sum;
-  __syncthreads();
-  for (int off = 1; off < SCAN_SINGLE_THREADS; off <<= 1) {
-    const u32 t = (tid >= off) ? sh[tid - off] : 0u;
-    __syncthreads();
-    sh[tid] += t;
-    __syncthreads();
-  }
-  u32 run = sh[tid] - sum;
-  for (size_t i = lo; i < hi; i++) { const u32 v = in[i]; out[i] = run; run += v; }     // in == out allowed: read before write
-  if (tid == SCAN_SINGLE_THREADS - 1) out[n] = sh[tid];
-}
 // out[i] = sum_{j<i} in[j] for i <= n (out[n] = total); in == out allowed; scratch: (ceil(n / SCAN_BLOCK) + 2) words
+// (A single-workgroup scan of the 65536 counters was measured: 40 us SLOWER per scan than these three launches -- one CU
+// cannot stream and shuffle-scan 256 KiB as fast as 32 workgroups do, launch latency included.)
 static int launch_exclusive_scan(const u32* in, u32* out, size_t n, u32* scratch, hipStream_t s) {
-  if (n <= SCAN_SINGLE_MAX) {
-    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(SCAN_SINGLE_THREADS), 0, s, in, out, n);
-  } else {
-    const size_t sb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)sb), dim3(256), 0, s, in, out, scratch, n);
-    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, scratch, sb, scratch + sb);
-    hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s, out, (const u32*)scratch, (const u32*)(scratch + sb), n);
-  }
+  const size_t sb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  hipLaunchKernelGGL(k_scan_local, dim3((unsigned)sb), dim3(256), 0, s, in, out, scratch, n);
+  hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, scratch, sb, scratch + sb);
+  hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s, out, (const u32*)scratch, (const u32*)(scratch + sb), n);
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }
