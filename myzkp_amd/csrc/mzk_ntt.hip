@@ -27,7 +27,6 @@
 namespace mzk {
 
 constexpr int TILE_LOG = 10;
-constexpr int TILE = 1 << TILE_LOG;
 #ifndef MZK_NTT_THREADS
 #define MZK_NTT_THREADS 256
 #endif
@@ -36,6 +35,21 @@ constexpr int NTHREADS = MZK_NTT_THREADS;
 #define MZK_NTT_MAX_LEVEL_LOG 8
 #endif
 constexpr int MAX_LEVEL_LOG = MZK_NTT_MAX_LEVEL_LOG;
+// Tile geometry.  Small (1024 elements, 256 lanes, levels of <= 2^8): every size below 2^20.  Large (4096 elements,
+// 1024 lanes = one workgroup per CU, levels of <= 2^10): from 2^20 points on, where 256+ workgroups exist -- a 2^20
+// transform is TWO passes of 2^10 levels instead of three (one global round trip and one inter-pass twiddle product
+// per element less), each tile still 4+ adjacent columns wide (>= 128-byte runs).  The Fr tile is 144 KiB of limbs, so
+// its in-tile twiddles are staged as packed words (16 KiB: 160 KiB exactly) and unpacked at use.
+template <int TL_, int NT_, int MAXLV_> struct Geo {
+  static constexpr int TL = TL_, TILE = 1 << TL_, NT = NT_, MAXLV = MAXLV_;
+  template <class P> static constexpr bool twpack() { return (size_t)4 * P::L * (TILE + (1 << (MAXLV_ - 1))) > (size_t)160 * 1024; }
+  template <class P> static constexpr size_t lds_bytes(int lgn) {
+    return sizeof(u32) * ((size_t)P::L * TILE + (size_t)(twpack<P>() ? P::NW : P::L) * (lgn >= 2 ? ((size_t)1 << (lgn - 1)) : 1));
+  }
+};
+typedef Geo<TILE_LOG, NTHREADS, MAX_LEVEL_LOG> GeoS;
+typedef Geo<12, 1024, 10> GeoL;
+constexpr unsigned LARGE_GEO_MIN_LOGN = 20;
 
 struct Words8 { u32 w[8]; };
 
@@ -69,40 +83,52 @@ template <class P> __device__ __forceinline__ Fe<P> fe_fit(const Fe<P>& v) {
 }
 
 __device__ __forceinline__ int lds_phys(int pos) { return pos ^ ((pos >> 5) & 31); }
-template <class P> __device__ __forceinline__ Fe<P> lds_load(const u32* lds, int pos) {
+template <class P, class G> __device__ __forceinline__ Fe<P> lds_load(const u32* lds, int pos) {
   Fe<P> r;
   const int ph = lds_phys(pos);
 #pragma unroll
-  for (int i = 0; i < P::L; i++) r.l[i] = lds[i * TILE + ph];
+  for (int i = 0; i < P::L; i++) r.l[i] = lds[i * G::TILE + ph];
   return r;
 }
-template <class P> __device__ __forceinline__ void lds_store(u32* lds, int pos, const Fe<P>& v) {
+template <class P, class G> __device__ __forceinline__ void lds_store(u32* lds, int pos, const Fe<P>& v) {
   const int ph = lds_phys(pos);
 #pragma unroll
-  for (int i = 0; i < P::L; i++) lds[i * TILE + ph] = v.l[i];
+  for (int i = 0; i < P::L; i++) lds[i * G::TILE + ph] = v.l[i];
 }
 
 // In-tile twiddles w_n^j (j < n/2) staged in LDS in limb form, limb-major, so a butterfly fetches its
 // twiddle with L ds_read_b32 and no unpacking.
-template <class P>
+template <class P, class G>
 __device__ __forceinline__ void stage_twiddles(u32* twl, const u32* __restrict__ tw, int lgn) {
   const int cnt = (lgn >= 2) ? (1 << (lgn - 1)) : 0;
-  for (int j = threadIdx.x; j < cnt; j += NTHREADS) {
-    Fe<P> w = gload<P>(tw, j);
+  for (int j = threadIdx.x; j < cnt; j += G::NT) {
+    if constexpr (G::template twpack<P>()) {      // packed words, word-major
 #pragma unroll
-    for (int i = 0; i < P::L; i++) twl[i * cnt + j] = w.l[i];
+      for (int i = 0; i < P::NW; i++) twl[i * cnt + j] = tw[(size_t)j * P::NW + i];
+    } else {
+      Fe<P> w = gload<P>(tw, j);
+#pragma unroll
+      for (int i = 0; i < P::L; i++) twl[i * cnt + j] = w.l[i];
+    }
   }
 }
 // One DIT butterfly in registers: (lo, hi) <- (lo + w hi, lo - w hi).  `trivial` (w = 1) skips the product;
 // then hi must still be brought below the 4 p the K = 8 subtraction tolerates, unless it is a raw input
 // (stage 1: < 2^(32 NW)).
-template <class P>
+template <class P, class G>
 __device__ __forceinline__ void bfly(Fe<P>& lo, Fe<P>& hi, const u32* twl, int tws, int ti, bool trivial, bool raw) {
   Fe<P> t = hi;
   if (!trivial) {
     Fe<P> w;
+    if constexpr (G::template twpack<P>()) {
+      u32 ww[P::NW];
 #pragma unroll
-    for (int i = 0; i < P::L; i++) w.l[i] = twl[i * tws + ti];
+      for (int i = 0; i < P::NW; i++) ww[i] = twl[i * tws + ti];
+      w = fe_unpack<P>(ww);
+    } else {
+#pragma unroll
+      for (int i = 0; i < P::L; i++) w.l[i] = twl[i * tws + ti];
+    }
     t = fe_mul<P>(t, w);
   } else if (!raw) {
     t = fe_weak_reduce<P>(t);
@@ -116,7 +142,7 @@ __device__ __forceinline__ void bfly(Fe<P>& lo, Fe<P>& hi, const u32* twl, int t
 // arithmetic and barriers of one-stage-at-a-time); an odd lgn starts with one radix-2 stage.  Groups are
 // enumerated twiddle-major (all groups with twiddle index 0 first), so whole waves skip the products by
 // w^0 = 1: about one stage's worth of products per level.
-template <class P>
+template <class P, class G>
 __device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, int lgc) {
   const int tid = threadIdx.x;
   const int cmask = (1 << lgc) - 1;
@@ -124,13 +150,13 @@ __device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, i
   int s = 1;
   if (lgn & 1) {  // stage 1 alone: every twiddle is 1
     const int nbf = 1 << (lgn + lgc - 1);
-    for (int b = tid; b < nbf; b += NTHREADS) {
+    for (int b = tid; b < nbf; b += G::NT) {
       const int c = b & cmask, grp = b >> lgc;
       const int plo = ((grp << 1) << lgc) | c, phi = plo + (1 << lgc);
-      Fe<P> x0 = lds_load<P>(lds, plo), x1 = lds_load<P>(lds, phi);
-      bfly<P>(x0, x1, twl, tws, 0, true, true);
-      lds_store<P>(lds, plo, x0);
-      lds_store<P>(lds, phi, x1);
+      Fe<P> x0 = lds_load<P, G>(lds, plo), x1 = lds_load<P, G>(lds, phi);
+      bfly<P, G>(x0, x1, twl, tws, 0, true, true);
+      lds_store<P, G>(lds, plo, x0);
+      lds_store<P, G>(lds, phi, x1);
     }
     __syncthreads();
     s = 2;
@@ -139,26 +165,26 @@ __device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, i
   for (; s + 1 <= lgn; s += 2) {
     const int lgh = s - 1;                 // log2 of the first stage's half-distance (in k)
     const int lgrest = lgg - lgh;
-    for (int g = tid; g < (1 << lgg); g += NTHREADS) {
+    for (int g = tid; g < (1 << lgg); g += G::NT) {
       const int j1 = g >> lgrest;
       const int rest = g & ((1 << lgrest) - 1);
       const int c = rest & cmask, grp = rest >> lgc;
       const int k0 = (grp << (s + 1)) | j1;
       const int p0 = (k0 << lgc) | c;
       const int d1 = 1 << (lgh + lgc), d2 = d1 << 1;
-      Fe<P> x0 = lds_load<P>(lds, p0), x1 = lds_load<P>(lds, p0 + d1);
-      Fe<P> x2 = lds_load<P>(lds, p0 + d2), x3 = lds_load<P>(lds, p0 + d2 + d1);
+      Fe<P> x0 = lds_load<P, G>(lds, p0), x1 = lds_load<P, G>(lds, p0 + d1);
+      Fe<P> x2 = lds_load<P, G>(lds, p0 + d2), x3 = lds_load<P, G>(lds, p0 + d2 + d1);
       const bool triv = (j1 == 0);
       const bool raw = (s == 1);
       const int t1 = j1 << (lgn - s);
-      bfly<P>(x0, x1, twl, tws, t1, triv, raw);
-      bfly<P>(x2, x3, twl, tws, t1, triv, raw);
-      bfly<P>(x0, x2, twl, tws, j1 << (lgn - s - 1), triv, false);
-      bfly<P>(x1, x3, twl, tws, (j1 + (1 << lgh)) << (lgn - s - 1), false, false);
-      lds_store<P>(lds, p0, x0);
-      lds_store<P>(lds, p0 + d1, x1);
-      lds_store<P>(lds, p0 + d2, x2);
-      lds_store<P>(lds, p0 + d2 + d1, x3);
+      bfly<P, G>(x0, x1, twl, tws, t1, triv, raw);
+      bfly<P, G>(x2, x3, twl, tws, t1, triv, raw);
+      bfly<P, G>(x0, x2, twl, tws, j1 << (lgn - s - 1), triv, false);
+      bfly<P, G>(x1, x3, twl, tws, (j1 + (1 << lgh)) << (lgn - s - 1), false, false);
+      lds_store<P, G>(lds, p0, x0);
+      lds_store<P, G>(lds, p0 + d1, x1);
+      lds_store<P, G>(lds, p0 + d2, x2);
+      lds_store<P, G>(lds, p0 + d2 + d1, x3);
     }
     __syncthreads();
   }
@@ -170,8 +196,8 @@ __device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, i
 // of their own.  offset^idx = offset^(j1 M) * offset^col comes from two small per-call tables (pre_row: 2^lgn
 // entries, pre_col: M entries, Montgomery form).
 struct PreArgs { const u32* coef; size_t n_coef; const u32* pre_row; const u32* pre_col; };
-template <class P, bool PRE>
-__global__ __launch_bounds__(NTHREADS) void k_ntt_strided(const u32* __restrict__ in, u32* __restrict__ out,
+template <class P, bool PRE, class G>
+__global__ __launch_bounds__(G::NT) void k_ntt_strided(const u32* __restrict__ in, u32* __restrict__ out,
                                                            const u32* __restrict__ tw_tile,
                                                            const u32* __restrict__ tw_inter, int lgn, int lgM, int lgc, PreArgs pre) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -182,9 +208,9 @@ __global__ __launch_bounds__(NTHREADS) void k_ntt_strided(const u32* __restrict_
   const size_t base = (o << (lgn + lgM)) + (ct << lgc);
   const int cmask = (1 << lgc) - 1;
   const int tile_elems = 1 << (lgn + lgc);
-  u32* twl = lds + P::L * TILE;
-  stage_twiddles<P>(twl, tw_tile, lgn);
-  for (int e = tid; e < tile_elems; e += NTHREADS) {
+  u32* twl = lds + P::L * G::TILE;
+  stage_twiddles<P, G>(twl, tw_tile, lgn);
+  for (int e = tid; e < tile_elems; e += G::NT) {
     const int j1 = e >> lgc, c = e & cmask;
     Fe<P> v;
     if constexpr (PRE) {
@@ -200,14 +226,14 @@ __global__ __launch_bounds__(NTHREADS) void k_ntt_strided(const u32* __restrict_
       v = gload<P>(in, base + ((size_t)j1 << lgM) + c);
     }
     const int k = (int)(__brev((unsigned)j1) >> (32 - lgn));
-    lds_store<P>(lds, (k << lgc) | c, v);
+    lds_store<P, G>(lds, (k << lgc) | c, v);
   }
   __syncthreads();
-  tile_stages<P>(lds, twl, lgn, lgc);
-  for (int e = tid; e < tile_elems; e += NTHREADS) {
+  tile_stages<P, G>(lds, twl, lgn, lgc);
+  for (int e = tid; e < tile_elems; e += G::NT) {
     const int k = e >> lgc, c = e & cmask;
     const size_t off = ((size_t)k << lgM) + (ct << lgc) + c;
-    Fe<P> v = lds_load<P>(lds, (k << lgc) | c);
+    Fe<P> v = lds_load<P, G>(lds, (k << lgc) | c);
     Fe<P> w = gload<P>(tw_inter, off);
     gstore<P>(out, (o << (lgn + lgM)) + off, fe_fit<P>(fe_mul<P>(v, w)));
   }
@@ -217,8 +243,8 @@ __global__ __launch_bounds__(NTHREADS) void k_ntt_strided(const u32* __restrict_
 // single-pass inverse), canonical output.  The grid may cover a BATCH of transforms stored back to back (row
 // r = blockIdx * 2^lgr + rr belongs to transform r >> lg_rows): the product trees of mzk_poly.hip transform hundreds
 // of small polynomials per launch.
-template <class P>
-__global__ __launch_bounds__(NTHREADS) void k_ntt_last(const u32* __restrict__ in, u32* __restrict__ out,
+template <class P, class G>
+__global__ __launch_bounds__(G::NT) void k_ntt_last(const u32* __restrict__ in, u32* __restrict__ out,
                                                         const u32* __restrict__ tw_tile, LevelInfo li, int lgn, int lgr,
                                                         int lg_rows, Words8 scale, int has_scale, size_t total_rows) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -228,9 +254,9 @@ __global__ __launch_bounds__(NTHREADS) void k_ntt_last(const u32* __restrict__ i
   const int tile_elems = 1 << (lgn + lgr);
   const size_t rowmask = ((size_t)1 << lg_rows) - 1;
   const int logn = lg_rows + lgn;
-  u32* twl = lds + P::L * TILE;
-  stage_twiddles<P>(twl, tw_tile, lgn);
-  for (int e = tid; e < tile_elems; e += NTHREADS) {
+  u32* twl = lds + P::L * G::TILE;
+  stage_twiddles<P, G>(twl, tw_tile, lgn);
+  for (int e = tid; e < tile_elems; e += G::NT) {
     const int rr = e >> lgn, j = e & nmask;
     const size_t r = p0 + rr;
     Fe<P> v = fe_zero<P>();
@@ -243,17 +269,17 @@ __global__ __launch_bounds__(NTHREADS) void k_ntt_last(const u32* __restrict__ i
       v = gload<P>(in, ((r >> lg_rows) << logn) + (row << lgn) + j);
     }
     const int k = (lgn == 0) ? 0 : (int)(__brev((unsigned)j) >> (32 - lgn));
-    lds_store<P>(lds, (k << lgr) | rr, v);
+    lds_store<P, G>(lds, (k << lgr) | rr, v);
   }
   __syncthreads();
-  tile_stages<P>(lds, twl, lgn, lgr);
+  tile_stages<P, G>(lds, twl, lgn, lgr);
   Fe<P> sc;
   if (has_scale) sc = fe_unpack<P>(scale.w);
-  for (int e = tid; e < tile_elems; e += NTHREADS) {
+  for (int e = tid; e < tile_elems; e += G::NT) {
     const int rr = e & rmask, k = e >> lgr;
     const size_t r = p0 + rr;
     if (r >= total_rows) continue;
-    Fe<P> v = lds_load<P>(lds, (k << lgr) | rr);
+    Fe<P> v = lds_load<P, G>(lds, (k << lgr) | rr);
     if (has_scale) v = fe_mul<P>(v, sc);
     gstore<P>(out, ((r >> lg_rows) << logn) + (r & rowmask) + ((size_t)k << lg_rows), fe_reduce<P>(v));
   }
@@ -362,7 +388,8 @@ static LevelInfo choose_levels(unsigned logn) {
     li.lg[0] = (int)logn;
     return li;
   }
-  int k = (int)((logn + MAX_LEVEL_LOG - 1) / MAX_LEVEL_LOG);
+  const int maxlv = logn >= LARGE_GEO_MIN_LOGN ? GeoL::MAXLV : MAX_LEVEL_LOG;
+  int k = (int)((logn + maxlv - 1) / maxlv);
   li.nlev = k;
   int base = (int)logn / k, extra = (int)logn % k;
   for (int i = 0; i < k; i++) li.lg[i] = base + (i < extra ? 1 : 0);
@@ -480,28 +507,36 @@ static int get_plan(int fid, unsigned logn, bool inverse, const uint64_t* root, 
   return MZK_OK;
 }
 
-template <class P>
-static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t s, const PreArgs* pre = nullptr, size_t batch = 1) {
+template <class P, class G>
+static int run_plan_geo(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t s, const PreArgs* pre, size_t batch) {
   const LevelInfo& li = pl->li;
   const unsigned logn = pl->logn;
 
   ProfScope whole(s, MZK_PH_NTT_TOTAL);
-  auto lds_for = [](int lgn) { return sizeof(u32) * P::L * ((size_t)TILE + (lgn >= 2 ? ((size_t)1 << (lgn - 1)) : 1)); };  // tile + in-tile twiddles
+  if (G::TL != TILE_LOG) {        // tiles above 64 KiB of LDS need the attribute, once per context and instantiation
+    bool& done = ctx().attr_done[P::NW == 4 ? ATTR_NTT_LARGE_M128 : ATTR_NTT_LARGE_FR];
+    if (!done) {
+      MZK_HIP(hipFuncSetAttribute((const void*)k_ntt_strided<P, true, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      MZK_HIP(hipFuncSetAttribute((const void*)k_ntt_strided<P, false, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      MZK_HIP(hipFuncSetAttribute((const void*)k_ntt_last<P, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      done = true;
+    }
+  }
   const u32* src = d_in;
   u32* tmp = nullptr;
   if (li.nlev > 1) MZK_TRY(ws_get(WS_NTT_TMP, (batch << logn) * sizeof(u32) * P::NW, (void**)&tmp));
   int lg_after = (int)logn;
   for (int t = 0; t < li.nlev - 1; t++) {
     const int lgn = li.lg[t], lgM = lg_after - lgn;
-    const int lgc = TILE_LOG - lgn;
-    const unsigned blocks = (unsigned)(batch << (logn - TILE_LOG));      // `o` in the kernel runs over the batch too
+    const int lgc = G::TL - lgn;
+    const unsigned blocks = (unsigned)(batch << (logn - G::TL));      // `o` in the kernel runs over the batch too
     {
       ProfScope ps(s, MZK_PH_NTT_PASS0 + t);
       if (t == 0 && pre)
-        hipLaunchKernelGGL((k_ntt_strided<P, true>), dim3(blocks), dim3(NTHREADS), lds_for(lgn), s, src, tmp, pl->tw_tile[t],
+        hipLaunchKernelGGL((k_ntt_strided<P, true, G>), dim3(blocks), dim3(G::NT), G::template lds_bytes<P>(lgn), s, src, tmp, pl->tw_tile[t],
                            pl->tw_inter[t], lgn, lgM, lgc, *pre);
       else
-        hipLaunchKernelGGL((k_ntt_strided<P, false>), dim3(blocks), dim3(NTHREADS), lds_for(lgn), s, src, tmp, pl->tw_tile[t],
+        hipLaunchKernelGGL((k_ntt_strided<P, false, G>), dim3(blocks), dim3(G::NT), G::template lds_bytes<P>(lgn), s, src, tmp, pl->tw_tile[t],
                            pl->tw_inter[t], lgn, lgM, lgc, PreArgs{nullptr, 0, nullptr, nullptr});
     }
     src = tmp;
@@ -511,15 +546,20 @@ static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t 
     const int lgn = li.lg[li.nlev - 1];
     const int lg_rows = (int)logn - lgn;
     const size_t total_rows = batch << lg_rows;
-    int lgr = TILE_LOG - lgn;
+    int lgr = G::TL - lgn;
     while (lgr > 0 && ((size_t)1 << lgr) > total_rows) lgr--;
     const unsigned blocks = (unsigned)((total_rows + ((size_t)1 << lgr) - 1) >> lgr);
     ProfScope ps(s, MZK_PH_NTT_PASS0 + li.nlev - 1);
-    hipLaunchKernelGGL((k_ntt_last<P>), dim3(blocks), dim3(NTHREADS), lds_for(lgn), s, src, d_out,
+    hipLaunchKernelGGL((k_ntt_last<P, G>), dim3(blocks), dim3(G::NT), G::template lds_bytes<P>(lgn), s, src, d_out,
                        pl->tw_tile[li.nlev - 1], li, lgn, lgr, lg_rows, pl->last_scale, pl->has_last_scale, total_rows);
   }
   MZK_HIP(hipGetLastError());
   return MZK_OK;
+}
+template <class P>
+static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t s, const PreArgs* pre = nullptr, size_t batch = 1) {
+  if (pl->logn >= LARGE_GEO_MIN_LOGN) return run_plan_geo<P, GeoL>(pl, d_in, d_out, s, pre, batch);
+  return run_plan_geo<P, GeoS>(pl, d_in, d_out, s, pre, batch);
 }
 
 static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
