@@ -49,7 +49,18 @@ template <int TL_, int NT_, int MAXLV_> struct Geo {
 };
 typedef Geo<TILE_LOG, NTHREADS, MAX_LEVEL_LOG> GeoS;
 typedef Geo<12, 1024, 10> GeoL;
-constexpr unsigned LARGE_GEO_MIN_LOGN = 20;
+// The large geometry is used exactly where it saves a whole pass: 2^20 (two passes of 2^10 instead of 7/7/6: measured
+// Fr 0.147 -> 0.137 ms, M128 0.063 -> 0.056 ms) and 2^25 .. 2^30.  Where both geometries need three passes the small
+// tiles win (2^21 .. 2^24: Fr +8 %, M128 +16 % with large tiles; tools/timing/time_ntt.py with MZK_NTT_LARGE_FR /
+// MZK_NTT_LARGE_M128 = smallest log2 size forced onto the large geometry, 99 = never).
+static bool large_geo(int fid, unsigned logn) {
+  static const int env_fr = getenv("MZK_NTT_LARGE_FR") ? atoi(getenv("MZK_NTT_LARGE_FR")) : -1;
+  static const int env_m = getenv("MZK_NTT_LARGE_M128") ? atoi(getenv("MZK_NTT_LARGE_M128")) : -1;
+  const int env = fid == MZK_FIELD_M128 ? env_m : env_fr;
+  if (env >= 0) return logn >= (unsigned)env && logn >= 14;
+  if (logn < 20) return false;
+  return (logn + 9) / 10 < (logn + MAX_LEVEL_LOG - 1) / MAX_LEVEL_LOG;
+}
 
 struct Words8 { u32 w[8]; };
 
@@ -381,14 +392,14 @@ void ntt_release_plans() {
   g_plans.clear();
 }
 
-static LevelInfo choose_levels(unsigned logn) {
+static LevelInfo choose_levels(unsigned logn, int fid) {
   LevelInfo li{};
   if (logn <= TILE_LOG) {
     li.nlev = 1;
     li.lg[0] = (int)logn;
     return li;
   }
-  const int maxlv = logn >= LARGE_GEO_MIN_LOGN ? GeoL::MAXLV : MAX_LEVEL_LOG;
+  const int maxlv = large_geo(fid, logn) ? GeoL::MAXLV : MAX_LEVEL_LOG;
   int k = (int)((logn + maxlv - 1) / maxlv);
   li.nlev = k;
   int base = (int)logn / k, extra = (int)logn % k;
@@ -468,7 +479,7 @@ static int get_plan(int fid, unsigned logn, bool inverse, const uint64_t* root, 
   pl->fid = fid; pl->logn = logn; pl->inverse = inverse;
   memcpy(pl->root, root, 8 * hf->nl);
   memcpy(pl->scale, sc, 8 * hf->nl);
-  pl->li = choose_levels(logn);
+  pl->li = choose_levels(logn, fid);
   pl->stamp = ++g_stamp;
   uint64_t eff_root[4] = {0, 0, 0, 0}, fold[4] = {0, 0, 0, 0};
   memcpy(fold, sc, 8 * hf->nl);
@@ -558,7 +569,7 @@ static int run_plan_geo(const NttPlan* pl, const u32* d_in, u32* d_out, hipStrea
 }
 template <class P>
 static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t s, const PreArgs* pre = nullptr, size_t batch = 1) {
-  if (pl->logn >= LARGE_GEO_MIN_LOGN) return run_plan_geo<P, GeoL>(pl, d_in, d_out, s, pre, batch);
+  if (large_geo(pl->fid, pl->logn)) return run_plan_geo<P, GeoL>(pl, d_in, d_out, s, pre, batch);
   return run_plan_geo<P, GeoS>(pl, d_in, d_out, s, pre, batch);
 }
 
@@ -615,7 +626,7 @@ int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_
   Words8 offw;
   to_words(offset_host, hf->nl, &offw);
   const unsigned logn = ilog2(order);
-  if (order > 1 && choose_levels(logn).nlev > 1) {
+  if (order > 1 && choose_levels(logn, fid).nlev > 1) {
     // multi-pass transform: Polynomial::scale + padding fused into the first pass (PreArgs)
     if (!h_is_canonical(hf, generator_host)) { set_error("coset_lde: parameter not canonical"); return MZK_E_RANGE; }
     NttPlan* pl = nullptr;

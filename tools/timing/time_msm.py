@@ -1,5 +1,5 @@
 import ctypes, sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import myzkp_amd as mz
 mz.init(0); L = mz.lib()
