@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--strong-log2n", type=int, default=24,
                     help="total size of the fixed-size MSM split over all ranks (BASELINE configs[3]; 0 = skip)")
     ap.add_argument("--extra-sizes", type=str, default="24", help="comma list of extra log2 sizes timed once each (rank 0 view)")
+    ap.add_argument("--inproc-devices", type=str, default="",
+                    help="comma list of device ordinals: additionally run the fixed-size MSM (configs[3]) from THIS one process over "
+                         "those GPUs through the C ABI's mzk_*_multi entry points (no torch.distributed); single-process runs only")
     args = ap.parse_args()
 
     import numpy as np
@@ -612,6 +615,53 @@ def main():
         if hs:
             L.mzk_srs_free(hs)
         torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ one process, several GPUs, C ABI only (optional)
+    if args.inproc_devices and world == 1 and args.strong_log2n > 0:
+        ords = [int(x) for x in args.inproc_devices.split(",") if x != ""]
+        tot = 1 << args.strong_log2n
+        rec = {"devices": ords, "total_pairs": tot,
+               "what": "mzk_init_devices + mzk_kzg_setup_srs_multi + mzk_kzg_commit_srs_multi_dev: contiguous shards, every GPU builds its own "
+                       "SRS slice and commits it, 128-byte partials gathered through pinned host memory, fold on context 0"}
+        try:
+            if srs._h:
+                L.mzk_srs_free(srs._h); srs._h = None
+            torch.cuda.empty_cache()
+            mz.init_devices(ords)
+            alpha = orc.from_limbs(orc.synth_vector(orc.FR, SEED + 901, 1))[0]
+            t0 = time.perf_counter()
+            hm = mz.SrsMulti(alpha=alpha, max_d=tot - 1)
+            rec["srs_setup_and_tables_ms"] = (time.perf_counter() - t0) * 1e3
+            shards, fa = [], 0
+            for r, o in enumerate(ords):
+                lo_r, hi_r = hm.lo[r], hm.lo[r + 1]
+                t = torch.empty((hi_r - lo_r) * 4, dtype=torch.int64, device=torch.device("cuda", o))
+                mz.ctx_select(r)
+                check(L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(SEED + 7000 + r), ctypes.c_size_t(hi_r - lo_r), dptr(t), None))
+                shards.append(t)
+                sr = orc.synth_vector(orc.FR, SEED + 7000 + r, hi_r - lo_r, os.cpu_count() or 1)
+                fa = (fa + orc.poly_eval(orc.FR, sr, alpha) * pow(alpha, lo_r, orc.P_FR)) % orc.P_FR
+            mz.ctx_select(0)
+            for o in set(ords):
+                torch.cuda.synchronize(o)
+            ptrs = [t.data_ptr() for t in shards]
+            got = hm.commit_dev(ptrs, tot)
+            reps = 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                got = hm.commit_dev(ptrs, tot)
+            dt = (time.perf_counter() - t0) / reps
+            rec.update({"ms_per_commit": dt * 1e3, "value": tot / dt, "unit": "pairs/s",
+                        "trapdoor_identity_holds": bool(got == orc.ec_mul(0, (1, 2), fa))})
+            hm.close()
+        except Exception as ex:
+            rec["error"] = str(ex)[:300]
+        finally:
+            try:
+                mz.init(local_rank)
+            except Exception:
+                pass
+        out["strong_scaling_msm_single_process"] = rec
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only, bounded sample)
     if rank == 0 and world == 1 and not args.skip_cpu:
