@@ -639,8 +639,14 @@ int mzk_fast_coset_divide(int field_id, const uint64_t* lhs, size_t ll, const ui
 // ---- MSM / KZG ---------------------------------------------------------------------------------------------
 // 4096 <= n < 2^14: the per-call bucket overhead of 16-bit windows dominates, keep plain prepared points
 // (msm_srs_default_tables); below and above, window tables of the width msm_srs_window_bits picks.
+// A handle is plain device memory: any context on the SAME GPU may commit against it (two contexts on one device
+// keep two commits in flight: the latency-bound tail of one overlaps the sort / accumulate of the next).
 static int srs_check_ctx(const mzk_srs* srs) {
-  if (srs->ctx_index != ctx().index) { set_error("SRS handle lives on context %d, the current context is %d (mzk_ctx_select)", srs->ctx_index, ctx().index); return MZK_E_ARG; }
+  if (srs->ctx_index != ctx().index && mzk_ctx_device(srs->ctx_index) != ctx().device) {
+    set_error("SRS handle lives on context %d (device %d), the current context %d drives device %d (mzk_ctx_select)", srs->ctx_index,
+              mzk_ctx_device(srs->ctx_index), ctx().index, ctx().device);
+    return MZK_E_ARG;
+  }
   return MZK_OK;
 }
 

@@ -99,14 +99,25 @@ def test_every_visible_device(mz):
     h.close()
 
 
-def test_srs_handle_is_bound_to_its_context(mz):
+def test_srs_handle_is_shared_by_contexts_on_the_same_device(mz):
+    """A handle is plain device memory: a second context on the SAME GPU (own stream + workspace) may commit against it --
+    that is how two commits are kept in flight (bench.py `kzg_commit_two_in_flight`).  Only a context on another
+    device is refused (MZK_E_ARG; needs two GPUs to provoke)."""
+    import torch
     mz.init_devices([0, 0])
-    s, p = _inputs(64, 55)
-    h = mz.Srs(p)                        # lives on context 0
-    mz.ctx_select(1)
-    with pytest.raises(mz.MzkError) as e:
-        h.commit(s)
-    assert e.value.code == -1
-    mz.ctx_select(0)
-    assert h.commit(s) == orc.msm_fast(s, p)
-    h.close()
+    for n in (64, (1 << 14) + 5):
+        s, p = _inputs(n, 55 + n)
+        want = orc.msm_fast(s, p)
+        h = mz.Srs(p)                        # built on context 0
+        mz.ctx_select(1)
+        assert h.commit(s) == want
+        mz.ctx_select(0)
+        assert h.commit(s) == want
+        if torch.cuda.device_count() > 1:
+            mz.init_devices([0, 1])
+            mz.ctx_select(1)
+            with pytest.raises(mz.MzkError) as e:
+                h.commit(s)
+            assert e.value.code == -1
+            mz.init_devices([0, 0])
+        h.close()
