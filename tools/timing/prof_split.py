@@ -1,27 +1,37 @@
-# classify each MSM's kernels as merged (SRS) or generic by the Grid_Size_Y of the k_reduce_tail that follows
-import csv,sys,collections
-rows=sorted(csv.DictReader(open(sys.argv[1])), key=lambda r:int(r['Start_Timestamp']))
-cur=[]; out=collections.defaultdict(lambda: collections.defaultdict(list))
+"""Kernel time per MSM from a rocprofv3 kernel trace: python tools/timing/prof_split.py <..._kernel_trace.csv>
+An MSM ends at its k_reduce_tail when that runs ONE workgroup (merged layout: the tail writes the result itself), or
+at the k_window_combine that follows a multi-workgroup k_reduce_tail (generic layout: one bucket set per window).
+Kernels outside any MSM (NTT, Merkle, table building, synthetic inputs) are skipped."""
+import csv, sys, collections
+SKIP = ("k_ntt", "merkle", "coset", "k_gen_", "k_synth", "k_srs_", "k_xyzz_batch", "k_fb_", "k_alpha", "k_pointwise", "k_fri", "vectorized_elementwise", "k_suffix", "k_horner")
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+out = collections.defaultdict(lambda: collections.defaultdict(list))
+cur, pending_generic = [], False
 for r in rows:
-    nm=r['Kernel_Name'].replace('mzk::','').split('(')[0]
-    if nm.startswith('k_ntt') or 'merkle' in nm or 'coset' in nm: continue
-    cur.append((nm,(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3))
-    if nm=='k_window_combine':
-        kind=None
-        for r2 in cur:
-            pass
-        # find reduce_tail grid in this group
-        kind = 'merged' if any(n=='k_reduce_tail' and g=='512' for n,g in [(x['Kernel_Name'].replace('mzk::','').split('(')[0], x['Grid_Size_X']) for x in grp]) else 'generic'
-        agg=collections.defaultdict(float)
-        for n,d in cur: agg[n]+=d
-        for n,d in agg.items(): out[kind][n].append(d)
-        cur=[]; grp=[]
+    nm = r["Kernel_Name"].replace("mzk::", "").replace("void ", "").split("(")[0]
+    if any(s in nm for s in SKIP) or nm.startswith("__amd_rocclr_copy"):
         continue
-    try: grp.append(r)
-    except NameError: grp=[r]
-for kind in out:
-    print('==',kind)
-    tot=0
-    for n,v in sorted(out[kind].items(), key=lambda kv:-sum(kv[1])/len(kv[1])):
-        print('  %-28s %5d  %8.1f us per MSM'%(n,len(v),sum(v)/len(v))); tot+=sum(v)/len(v)
-    print('  total kernel time %.1f us'%tot)
+    cur.append((nm, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    kind = None
+    if nm == "k_reduce_tail":
+        if int(r["Grid_Size_X"]) <= 512:
+            kind = "merged (KZG commit against SRS tables)"
+        else:
+            pending_generic = True
+    elif nm == "k_window_combine" and pending_generic:
+        kind, pending_generic = "generic (arbitrary points, GLV)", False
+    if kind:
+        agg = collections.defaultdict(float)
+        for n, d in cur:
+            agg[n] += d
+        for n, d in agg.items():
+            out[kind][n].append(d)
+        cur = []
+for kind in sorted(out):
+    nmsm = max(len(v) for v in out[kind].values())
+    print("==", kind, "--", nmsm, "MSMs (all sizes launched by the command)")
+    tot = 0
+    for n, v in sorted(out[kind].items(), key=lambda kv: -sum(kv[1]) / nmsm):
+        print("  %-34s %5d  %8.1f us per MSM" % (n, len(v), sum(v) / nmsm))
+        tot += sum(v) / nmsm
+    print("  total kernel time %.1f us" % tot)
