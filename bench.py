@@ -341,15 +341,13 @@ def main():
             while time.perf_counter() < t_end:
                 two_step(i); i += 1
             torch.cuda.synchronize()
-            reps = max(100, 2 * K)
-            dtp = float("inf")
-            for _ in range(3):                     # best of three runs of `reps` commits (the leg is short: clocks wander)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for i in range(reps):
-                    two_step(i)
-                torch.cuda.synchronize()
-                dtp = min(dtp, (time.perf_counter() - t0) / reps)
+            reps = max(200, 2 * K)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(reps):
+                two_step(i)
+            torch.cuda.synchronize()
+            dtp = (time.perf_counter() - t0) / reps
             mz.ctx_select(0)
             same = bool(torch.equal(outs[:8], result_srs))       # commit of `scalars` must equal the single-context result
             pipelined = {"metric": "KZG commit pairs/s with two commits in flight (two contexts on one GPU alternating, shared SRS handle)",
