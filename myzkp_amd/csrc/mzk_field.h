@@ -45,6 +45,22 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 typedef int32_t i32;
 
+// col + a * b.  With -DMZK_MAD_ASM (device code only) the multiply-add is pinned as ONE v_mad_u64_u32 whose addend is
+// the running column: hipcc otherwise starts every column of a product from zero and adds the previous column's carry
+// with an extra v_lshl_add_u64 (17 more half-rate instructions per product, bought for instruction-level parallelism).
+// Measured (tools/microbench/batched_affine_bound.hip, xyzz_madd loop): pinned 16.13 vs 15.91 G additions/s at 4
+// workgroups per CU (+1.4 %), but 9.9 vs 12.6 G/s at one wave per SIMD (-22 %: the latency-bound tail kernels live
+// there) -- so it stays off.
+#if defined(MZK_MAD_ASM) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint64_t mzk_mad(uint32_t a, uint32_t b, uint64_t c) {
+  uint64_t r, carry;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+#else
+MZK_HD uint64_t mzk_mad(uint32_t a, uint32_t b, uint64_t c) { return c + (uint64_t)a * b; }
+#endif
+
 constexpr int W29 = 29;
 constexpr u32 MASK29 = (1u << 29) - 1u;
 
@@ -91,19 +107,19 @@ template <class P> MZK_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
 #pragma unroll
   for (int k = 0; k < L; k++) {
 #pragma unroll
-    for (int i = 0; i <= k; i++) col += (u64)a.l[i] * b.l[k - i];
+    for (int i = 0; i <= k; i++) col = mzk_mad(a.l[i], b.l[k - i], col);
 #pragma unroll
-    for (int i = 0; i < k; i++) col += (u64)m[i] * P::P[k - i];
+    for (int i = 0; i < k; i++) if (P::P[k - i] != 0) col = mzk_mad(m[i], P::P[k - i], col);
     m[k] = ((u32)col * P::N0) & MASK29;
-    col += (u64)m[k] * P::P[0];
+    if (P::P[0] != 0) col = mzk_mad(m[k], P::P[0], col);
     col >>= W29;
   }
 #pragma unroll
   for (int k = L; k < 2 * L - 1; k++) {
 #pragma unroll
-    for (int i = k - L + 1; i < L; i++) col += (u64)a.l[i] * b.l[k - i];
+    for (int i = k - L + 1; i < L; i++) col = mzk_mad(a.l[i], b.l[k - i], col);
 #pragma unroll
-    for (int i = k - L + 1; i < L; i++) col += (u64)m[i] * P::P[k - i];
+    for (int i = k - L + 1; i < L; i++) if (P::P[k - i] != 0) col = mzk_mad(m[i], P::P[k - i], col);
     r.l[k - L] = (u32)col & MASK29;
     col >>= W29;
   }
@@ -136,23 +152,23 @@ template <class P> MZK_HD Fe<P> fe_mul_add2(const Fe<P>& a, const Fe<P>& b, cons
 #pragma unroll
   for (int k = 0; k < L; k++) {
 #pragma unroll
-    for (int i = 0; i <= k; i++) col += (u64)a.l[i] * b.l[k - i];
+    for (int i = 0; i <= k; i++) col = mzk_mad(a.l[i], b.l[k - i], col);
 #pragma unroll
-    for (int i = 0; i <= k; i++) col += (u64)c.l[i] * d.l[k - i];
+    for (int i = 0; i <= k; i++) col = mzk_mad(c.l[i], d.l[k - i], col);
 #pragma unroll
-    for (int i = 0; i < k; i++) col += (u64)m[i] * P::P[k - i];
+    for (int i = 0; i < k; i++) if (P::P[k - i] != 0) col = mzk_mad(m[i], P::P[k - i], col);
     m[k] = ((u32)col * P::N0) & MASK29;
-    col += (u64)m[k] * P::P[0];
+    if (P::P[0] != 0) col = mzk_mad(m[k], P::P[0], col);
     col >>= W29;
   }
 #pragma unroll
   for (int k = L; k < 2 * L - 1; k++) {
 #pragma unroll
-    for (int i = k - L + 1; i < L; i++) col += (u64)a.l[i] * b.l[k - i];
+    for (int i = k - L + 1; i < L; i++) col = mzk_mad(a.l[i], b.l[k - i], col);
 #pragma unroll
-    for (int i = k - L + 1; i < L; i++) col += (u64)c.l[i] * d.l[k - i];
+    for (int i = k - L + 1; i < L; i++) col = mzk_mad(c.l[i], d.l[k - i], col);
 #pragma unroll
-    for (int i = k - L + 1; i < L; i++) col += (u64)m[i] * P::P[k - i];
+    for (int i = k - L + 1; i < L; i++) if (P::P[k - i] != 0) col = mzk_mad(m[i], P::P[k - i], col);
     r.l[k - L] = (u32)col & MASK29;
     col >>= W29;
   }
@@ -192,21 +208,21 @@ template <class P> MZK_HD Fe<P> fe_sqr(const Fe<P>& a) {
 #pragma unroll
   for (int k = 0; k < L; k++) {
 #pragma unroll
-    for (int i = 0; 2 * i < k; i++) col += (u64)a2[i] * a.l[k - i];
-    if ((k & 1) == 0) col += (u64)a.l[k / 2] * a.l[k / 2];
+    for (int i = 0; 2 * i < k; i++) col = mzk_mad(a2[i], a.l[k - i], col);
+    if ((k & 1) == 0) col = mzk_mad(a.l[k / 2], a.l[k / 2], col);
 #pragma unroll
-    for (int i = 0; i < k; i++) col += (u64)m[i] * P::P[k - i];
+    for (int i = 0; i < k; i++) if (P::P[k - i] != 0) col = mzk_mad(m[i], P::P[k - i], col);
     m[k] = ((u32)col * P::N0) & MASK29;
-    col += (u64)m[k] * P::P[0];
+    if (P::P[0] != 0) col = mzk_mad(m[k], P::P[0], col);
     col >>= W29;
   }
 #pragma unroll
   for (int k = L; k < 2 * L - 1; k++) {
 #pragma unroll
-    for (int i = k - L + 1; 2 * i < k; i++) col += (u64)a2[i] * a.l[k - i];
-    if ((k & 1) == 0) col += (u64)a.l[k / 2] * a.l[k / 2];
+    for (int i = k - L + 1; 2 * i < k; i++) col = mzk_mad(a2[i], a.l[k - i], col);
+    if ((k & 1) == 0) col = mzk_mad(a.l[k / 2], a.l[k / 2], col);
 #pragma unroll
-    for (int i = k - L + 1; i < L; i++) col += (u64)m[i] * P::P[k - i];
+    for (int i = k - L + 1; i < L; i++) if (P::P[k - i] != 0) col = mzk_mad(m[i], P::P[k - i], col);
     r.l[k - L] = (u32)col & MASK29;
     col >>= W29;
   }
