@@ -147,7 +147,7 @@ def main():
         if attempt == 0:
             L.mzk_srs_free(hh)
     srs._h = hh
-    srs_table_windows = 254 // 16 + 1 if n >= (1 << 14) else (254 // (8 if n <= 1024 else 10) + 1 if n < 4096 else 2)
+    srs_table_windows = 254 // (8 if n <= 1024 else (10 if n < 4096 else (13 if n < (1 << 14) else 16))) + 1
     progress("SRS handle built")
     result_srs = torch.zeros(8, dtype=torch.int64, device=dev)
 

@@ -637,8 +637,8 @@ int mzk_fast_coset_divide(int field_id, const uint64_t* lhs, size_t ll, const ui
 }
 
 // ---- MSM / KZG ---------------------------------------------------------------------------------------------
-// 4096 <= n < 2^14: the per-call bucket overhead of 16-bit windows dominates, keep plain prepared points
-// (msm_srs_default_tables); below and above, window tables of the width msm_srs_window_bits picks.
+// Every SRS handle gets window tables of the width msm_srs_window_bits picks for its size, unless the caller asks for
+// plain prepared points (mzk_srs_from_device_ex(with_tables = 0): the one-shot pipelines).
 // A handle is plain device memory: any context on the SAME GPU may commit against it (two contexts on one device
 // keep two commits in flight: the latency-bound tail of one overlaps the sort / accumulate of the next).
 static int srs_check_ctx(const mzk_srs* srs) {
