@@ -100,6 +100,47 @@ __device__ __forceinline__ void xyzz_gstore(u32* __restrict__ g, size_t idx, con
   for (int q = 0; q < 4; q++) store_words8(g + idx * 32 + 8 * q, w + 8 * q);
 }
 
+// Segment partials travel from k_seg_accumulate to k_seg_combine as RAW limbs (4 x 9 words = 144 bytes, coordinate-major):
+// a flush then costs 9 stores instead of four canonical reductions + packing (~700 instructions, a quarter of a mixed
+// addition).  That matters because a wave pays for a flush whenever ANY of its lanes crosses a bucket boundary -- nearly
+// every iteration in the generic layout (64-entry buckets, 64-entry segments).  Limbs are whatever the accumulator held:
+// normalised, value < 2.5 p, exactly what xyzz_add accepts; infinity is all-zero.
+constexpr int SLOT_WORDS = 4 * FqParams::L;      // 36
+__device__ __forceinline__ void xyzz_gstore_raw(u32* __restrict__ g, size_t idx, const Xyzz& p) {
+  u32 w[SLOT_WORDS];
+  const bool inf = xyzz_is_inf(p);
+#pragma unroll
+  for (int i = 0; i < FqParams::L; i++) {
+    w[i] = inf ? 0u : p.X.l[i]; w[9 + i] = inf ? 0u : p.Y.l[i]; w[18 + i] = inf ? 0u : p.ZZ.l[i]; w[27 + i] = inf ? 0u : p.ZZZ.l[i];
+  }
+  uint4* p4 = reinterpret_cast<uint4*>(g + idx * SLOT_WORDS);
+#pragma unroll
+  for (int q = 0; q < SLOT_WORDS / 4; q++) p4[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+__device__ __forceinline__ Xyzz xyzz_gload_raw(const u32* __restrict__ g, size_t idx) {
+  u32 w[SLOT_WORDS];
+  const uint4* p4 = reinterpret_cast<const uint4*>(g + idx * SLOT_WORDS);
+#pragma unroll
+  for (int q = 0; q < SLOT_WORDS / 4; q++) { const uint4 v = p4[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+  Xyzz p;
+#pragma unroll
+  for (int i = 0; i < FqParams::L; i++) { p.X.l[i] = w[i]; p.Y.l[i] = w[9 + i]; p.ZZ.l[i] = w[18 + i]; p.ZZZ.l[i] = w[27 + i]; }
+  return p;
+}
+// quad form: lane k fetches coordinate k (9 words) and the quad exchanges them
+__device__ __forceinline__ Xyzz xyzz_gload_raw_quad(const u32* __restrict__ g, size_t idx, int lane) {
+  Fq mine;
+  const u32* src = g + idx * SLOT_WORDS + 9 * lane;
+#pragma unroll
+  for (int i = 0; i < FqParams::L; i++) mine.l[i] = src[i];
+  Xyzz p;
+  p.X = quad_bcast<0>(mine);
+  p.Y = quad_bcast<1>(mine);
+  p.ZZ = quad_bcast<2>(mine);
+  p.ZZZ = quad_bcast<3>(mine);
+  return p;
+}
+
 // ---- 0. point preparation ------------------------------------------------------------------------------
 __global__ void k_prepare_points(const u32* __restrict__ in, u32* __restrict__ out, size_t n, u32* __restrict__ phi_out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -702,7 +743,7 @@ __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ 
       }
     }
     if (e >= bend) {
-      xyzz_gstore(slots, t + b, acc);
+      xyzz_gstore_raw(slots, t + b, acc);
       acc = xyzz_inf();
       do { b++; bend = offsets[b + 1]; } while (e >= bend);
     }
@@ -711,7 +752,7 @@ __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ 
     if (ent >> 31) p = affine_neg(p);
     acc = xyzz_madd(acc, p);
   }
-  xyzz_gstore(slots, t + b, acc);
+  xyzz_gstore_raw(slots, t + b, acc);
 }
 // pass 2: buckets[b] = sum of slots [offsets[b] / seg + b, (offsets[b+1] - 1) / seg + b]   (inclusive end:
 // the last entry of bucket b is offsets[b+1]-1)
@@ -735,7 +776,7 @@ __global__ __launch_bounds__(128) void k_seg_combine_wide(const u32* __restrict_
   if (o1 > o0) {
     const size_t s0 = (size_t)(o0 / seg) + b, s1 = (size_t)((o1 - 1) / seg) + b;
     if (defer_heavy(b, s0, s1, heavy, true)) return;
-    for (size_t sl = s0; sl <= s1; sl++) acc = xyzz_add(acc, xyzz_gload(slots, sl));
+    for (size_t sl = s0; sl <= s1; sl++) acc = xyzz_add(acc, xyzz_gload_raw(slots, sl));
   }
   xyzz_gstore(buckets, b, acc);
 }
@@ -752,8 +793,8 @@ __global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slo
   if (o1 > o0) {
     const size_t s0 = (size_t)(o0 / seg) + b, s1 = (size_t)((o1 - 1) / seg) + b;
     if (defer_heavy(b, s0, s1, heavy, lane == 0)) return;       // quad-uniform
-    acc = xyzz_gload_quad(slots, s0, lane);
-    for (size_t sl = s0 + 1; sl <= s1; sl++) acc = xyzz_add_quad(acc, xyzz_gload_quad(slots, sl, lane), lane);
+    acc = xyzz_gload_raw_quad(slots, s0, lane);
+    for (size_t sl = s0 + 1; sl <= s1; sl++) acc = xyzz_add_quad(acc, xyzz_gload_raw_quad(slots, sl, lane), lane);
   }
   xyzz_gstore_quad(buckets, b, acc, lane);
 }
@@ -769,7 +810,7 @@ __global__ __launch_bounds__(HEAVY_THREADS) void k_seg_combine_heavy(const u32* 
     const u32 o0 = offsets[b], o1 = offsets[b + 1];
     const size_t s0 = (size_t)(o0 / seg) + b, s1 = (size_t)((o1 - 1) / seg) + b;
     Xyzz acc = xyzz_inf();
-    for (size_t sl = s0 + quad; sl <= s1; sl += HEAVY_QUADS) acc = xyzz_add_quad(acc, xyzz_gload_quad(slots, sl, lane), lane);
+    for (size_t sl = s0 + quad; sl <= s1; sl += HEAVY_QUADS) acc = xyzz_add_quad(acc, xyzz_gload_raw_quad(slots, sl, lane), lane);
     xyzz_gstore_quad(sh, quad, acc, lane);
     __syncthreads();
     for (int off = HEAVY_QUADS / 2; off >= 1; off >>= 1) {
@@ -1146,8 +1187,8 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   MZK_TRY(ws_get(WS_MSM_ENTRIES, E_max * 4, (void**)&entries));
   MZK_TRY(ws_get(WS_MSM_SCAN, (scan_blocks + 1) * 4, (void**)&scan_tmp));
   MZK_TRY(ws_get(WS_MSM_BUCKETS, NB * 128, (void**)&buckets));
-  MZK_TRY(ws_get(WS_MSM_SLOTS, nslots * 128 + heavy_words * 4, (void**)&slots));
-  u32* heavy = slots + nslots * 32;
+  MZK_TRY(ws_get(WS_MSM_SLOTS, nslots * SLOT_WORDS * 4 + heavy_words * 4, (void**)&slots));
+  u32* heavy = slots + nslots * SLOT_WORDS;
   prof_begin(s, MZK_PH_MSM_SORT);
   // every slot k_seg_combine reads is written by k_seg_accumulate first (slot t + b exists exactly when segment t
   // overlaps bucket b; checked by poisoning the array under the whole GPU suite), so only the heavy-bucket counter
