@@ -53,6 +53,7 @@ int mzk_init_devices(const int* device_ordinals, int n_devices);
 int mzk_ctx_count(void);
 int mzk_ctx_select(int index);
 int mzk_ctx_device(int index);   /* device ordinal of a context, -1 if it does not exist */
+void* mzk_ctx_stream(int index); /* the context's own hipStream_t (non-blocking), usable as the `stream` of its *_dev calls */
 /* Two contexts on ONE device keep two calls in flight (each has its own stream and workspace; an mzk_srs handle is
  * plain device memory and serves every context of its device): alternating commits between them overlaps the
  * latency-bound tail of one MSM with the sort / accumulate of the next -- 2^20 pairs: 1.72 -> 1.55 ms per commit. */

@@ -305,7 +305,16 @@ int mzk_init_devices(const int* device_ordinals, int n_devices) {
     c.num_cu = ncu[i];
     c.ws_gen = ++g_gen_counter;
     MZK_HIP(hipSetDevice(c.device));
-    MZK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    // Contexts that share a GPU are there to keep several calls in flight: give each its own stream PRIORITY level, which
+    // also puts them on different hardware queues (streams of one priority may share a queue and then serialise).
+    int dup = 0;
+    for (int j = 0; j < i; j++) dup += g_ctxs[j].device == c.device;
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    int prio = prio_least - dup;                        // numerically lower = higher priority
+    if (prio < prio_greatest) prio = prio_greatest;
+    if (dup == 0) MZK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    else MZK_HIP(hipStreamCreateWithPriority(&c.stream, hipStreamNonBlocking, prio));
     c.ready = true;
     g_nctx = i + 1;
   }
@@ -315,6 +324,7 @@ int mzk_init(int device_ordinal) { return mzk_init_devices(&device_ordinal, 1); 
 int mzk_ctx_count(void) { return g_nctx; }
 int mzk_ctx_select(int index) { return ctx_select(index); }
 int mzk_ctx_device(int index) { return (index >= 0 && index < g_nctx) ? g_ctxs[index].device : -1; }
+void* mzk_ctx_stream(int index) { return (index >= 0 && index < g_nctx) ? (void*)g_ctxs[index].stream : nullptr; }
 
 void mzk_shutdown(void) {
   for (int i = 0; i < g_nctx; i++) {
