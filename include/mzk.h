@@ -282,7 +282,7 @@ int mzk_kzg_open_quotient_dev(const void* d_coef, size_t n, const uint64_t u_hos
  * 10 below 4096, 13 below 2^14, 16 from there on (254 / c + 1 tables of n points each). */
 int mzk_srs_from_device(const void* d_powers_xy, size_t n, mzk_srs** out, void* stream);
 int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, mzk_srs** out, void* stream);
-/* with_tables: 0 = plain prepared points, 1 = tables with the default 16-bit windows, 12..22 = that window width
+/* with_tables: 0 = plain prepared points, 1 = tables with the default window width for n (above), 12..22 = that window width
  * (tuning / tests; wider windows were measured and do not pay). */
 
 /* Host-side parameter arithmetic of the library (roots, inverses, offsets: O(log n) scalar work per call, never on the
