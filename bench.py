@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--strong-log2n", type=int, default=24,
                     help="total size of the fixed-size MSM split over all ranks (BASELINE configs[3]; 0 = skip)")
     ap.add_argument("--extra-sizes", type=str, default="24", help="comma list of extra log2 sizes timed once each (rank 0 view)")
+    ap.add_argument("--no-two-in-flight", action="store_true",
+                    help="skip the two-commits-in-flight leg (profiler runs: overlapped kernels would distort the per-kernel averages)")
     ap.add_argument("--inproc-devices", type=str, default="",
                     help="comma list of device ordinals: additionally run the fixed-size MSM (configs[3]) from THIS one process over "
                          "those GPUs through the C ABI's mzk_*_multi entry points (no torch.distributed); single-process runs only")
@@ -309,7 +311,7 @@ def main():
         return max_over_ranks(dt), phases
 
     def run_two_in_flight():
-        if world != 1:
+        if world != 1 or args.no_two_in_flight:
             return None
         try:
             sc_b = torch.empty_like(scalars)

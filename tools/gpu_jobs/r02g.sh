@@ -9,7 +9,7 @@ echo "pytest rc=$?" >> $O/r02g_pytest.log
 timeout 1200 python bench.py > $O/r02g_bench.json 2> $O/r02g_bench.err
 python tools/timing/small_latency.py > $O/r02g_small_latency.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-BENCH="$R/bench.py --steps 10 --warmup 2 --skip-cpu --extra-sizes= --e2e-log2n 0 --strong-log2n 0"
+BENCH="$R/bench.py --steps 10 --warmup 2 --skip-cpu --extra-sizes= --e2e-log2n 0 --strong-log2n 0 --no-two-in-flight"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r02g_prof -- python3 $BENCH > $O/r02g_bench_under_rocprof.json 2> $O/r02g_prof.err
 find $O/r02g_prof -name "*kernel_stats.csv" -exec cp {} $O/r02g_bench_kernel_stats.csv \;
 python3 $R/tools/timing/prof_split.py $(find $O/r02g_prof -name "*kernel_trace.csv" | head -1) > $O/r02g_per_msm_kernel_budget.txt 2>&1
