@@ -4,7 +4,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SO = os.path.join(HERE, "libmzk_hip.so")
+SO = os.environ.get("MZK_HIP_LIB") or os.path.join(HERE, "libmzk_hip.so")   # MZK_HIP_LIB: experimental builds (tools/)
 
 FIELD_FR, FIELD_M128, FIELD_FQ = 0, 1, 2
 LIMBS = {FIELD_FR: 4, FIELD_M128: 2, FIELD_FQ: 4}

@@ -27,6 +27,10 @@ def build(force=False, verbose=False):
     consts = os.path.join(CSRC, "mzk_constants.h")
     if os.path.exists(gen) and _newer(gen, consts):
         subprocess.check_call([sys.executable, gen, consts])
+    gen_asm = os.path.join(ROOT, "tools", "gen_field_asm.py")
+    asm_h = os.path.join(CSRC, "mzk_field_asm.h")
+    if os.path.exists(gen_asm) and (_newer(gen_asm, asm_h) or _newer(gen, asm_h)):
+        subprocess.check_call([sys.executable, gen_asm, asm_h])
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     objs, procs = [], []

@@ -12,6 +12,7 @@
 // < 2.01.  With rho = p/R ~ 2^-7.4 a product of inputs (va, vb) is < va*vb*rho + 1.
 #pragma once
 #include "mzk_field.h"
+#include "mzk_field_asm.h"
 
 namespace mzk {
 
@@ -81,11 +82,20 @@ MZK_HD Xyzz xyzz_dbl(const Xyzz& p) {
 }
 
 // acc + (affine q) -> XYZZ   (madd-2008-s): 8M + 2S.  Exception-complete.
-MZK_HD Xyzz xyzz_madd(const Xyzz& a, const Affine& q) {
+// A = the product routines: FeCpp (portable C++, scheduled by the compiler: best for the latency-bound tail kernels)
+// or FeAsm (mzk_field_asm.h: one inline-asm chain per product, fewer instructions: best at 3+ waves per SIMD).  Both
+// compute the same column sums, so the result limbs are identical.
+template <class P> struct FeCpp {
+  static MZK_HD Fe<P> mul(const Fe<P>& a, const Fe<P>& b) { return fe_mul<P>(a, b); }
+  static MZK_HD Fe<P> sqr(const Fe<P>& a) { return fe_sqr<P>(a); }
+  static MZK_HD Fe<P> mul_add2(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) { return fe_mul_add2<P>(a, b, c, d); }
+};
+template <template <class> class A> MZK_HD Xyzz xyzz_madd_with(const Xyzz& a, const Affine& q) {
   typedef FqParams P;
+  typedef A<P> F;
   if (xyzz_is_inf(a)) return xyzz_from_affine(q);
-  Fq U2 = fe_mul<P>(q.x, a.ZZ);                  // < 1.02
-  Fq S2 = fe_mul<P>(q.y, a.ZZZ);                 // < 1.02
+  Fq U2 = F::mul(q.x, a.ZZ);                     // < 1.02
+  Fq S2 = F::mul(q.y, a.ZZZ);                    // < 1.02
   Fq Pd = fe_carry<P>(fe_sub<P, 8>(U2, a.X));    // U2 - X1 (+8p) < 9.02, N
   Fq Rd = fe_carry<P>(fe_sub<P, 8>(S2, a.Y));    // < 9.02, N
   if (fe_is_zero_mod<P, 10>(Pd)) {               // same x: q == +-a   (curve.rs:111-115)
@@ -93,29 +103,31 @@ MZK_HD Xyzz xyzz_madd(const Xyzz& a, const Affine& q) {
     return xyzz_inf();
   }
   Xyzz r;
-  Fq PP = fe_sqr<P>(Pd);                         // < 1.49
-  Fq PPP = fe_mul<P>(Pd, PP);                    // < 1.08
-  Fq Q = fe_mul<P>(a.X, PP);                     // < 1.03
-  Fq RR = fe_sqr<P>(Rd);                         // < 1.49
+  Fq PP = F::sqr(Pd);                            // < 1.49
+  Fq PPP = F::mul(Pd, PP);                       // < 1.08
+  Fq Q = F::mul(a.X, PP);                        // < 1.03
+  Fq RR = F::sqr(Rd);                            // < 1.49
   Fq X3 = fe_weak_reduce<P>(fe_sub<P, 4>(fe_sub<P, 4>(fe_sub<P, 4>(RR, PPP), Q), Q));  // (+12p) < 13.5 -> < 2.01
   Fq Vd = fe_carry<P>(fe_sub<P, 8>(Q, X3));      // < 9.03
   r.X = X3;
   // Y3 = Rd (Q - X3) - Y1 PPP as one fused product pair: Rd Vd + (8p - Y1) PPP, single reduction
-  r.Y = fe_mul_add2<P>(Rd, Vd, fe_neg_lazy<P, 8>(a.Y), PPP);   // < (9.02*9.03 + 8*1.08) rho + 1 < 1.54
-  r.ZZ = fe_mul<P>(a.ZZ, PP);
-  r.ZZZ = fe_mul<P>(a.ZZZ, PPP);
+  r.Y = F::mul_add2(Rd, Vd, fe_neg_lazy<P, 8>(a.Y), PPP);      // < (9.02*9.03 + 8*1.08) rho + 1 < 1.54
+  r.ZZ = F::mul(a.ZZ, PP);
+  r.ZZZ = F::mul(a.ZZZ, PPP);
   return r;
 }
+MZK_HD Xyzz xyzz_madd(const Xyzz& a, const Affine& q) { return xyzz_madd_with<FeCpp>(a, q); }
 
-// a + b, both XYZZ   (add-2008-s): 12M + 2S.  Exception-complete.
-MZK_HD Xyzz xyzz_add(const Xyzz& a, const Xyzz& b) {
+// a + b, both XYZZ   (add-2008-s): 12M + 2S.  Exception-complete.  A as in xyzz_madd_with.
+template <template <class> class A> MZK_HD Xyzz xyzz_add_with(const Xyzz& a, const Xyzz& b) {
   typedef FqParams P;
+  typedef A<P> F;
   if (xyzz_is_inf(a)) return b;
   if (xyzz_is_inf(b)) return a;
-  Fq U1 = fe_mul<P>(a.X, b.ZZ);                  // < 1.04
-  Fq U2 = fe_mul<P>(b.X, a.ZZ);
-  Fq S1 = fe_mul<P>(a.Y, b.ZZZ);
-  Fq S2 = fe_mul<P>(b.Y, a.ZZZ);
+  Fq U1 = F::mul(a.X, b.ZZ);                     // < 1.04
+  Fq U2 = F::mul(b.X, a.ZZ);
+  Fq S1 = F::mul(a.Y, b.ZZZ);
+  Fq S2 = F::mul(b.Y, a.ZZZ);
   Fq Pd = fe_carry<P>(fe_sub<P, 4>(U2, U1));     // < 5.04, N
   Fq Rd = fe_carry<P>(fe_sub<P, 4>(S2, S1));
   if (fe_is_zero_mod<P, 6>(Pd)) {
@@ -123,18 +135,19 @@ MZK_HD Xyzz xyzz_add(const Xyzz& a, const Xyzz& b) {
     return xyzz_inf();
   }
   Xyzz r;
-  Fq PP = fe_sqr<P>(Pd);                         // < 1.15
-  Fq PPP = fe_mul<P>(Pd, PP);                    // < 1.04
-  Fq Q = fe_mul<P>(U1, PP);                      // < 1.01
-  Fq RR = fe_sqr<P>(Rd);                         // < 1.15
+  Fq PP = F::sqr(Pd);                            // < 1.15
+  Fq PPP = F::mul(Pd, PP);                       // < 1.04
+  Fq Q = F::mul(U1, PP);                         // < 1.01
+  Fq RR = F::sqr(Rd);                            // < 1.15
   Fq X3 = fe_weak_reduce<P>(fe_sub<P, 4>(fe_sub<P, 4>(fe_sub<P, 4>(RR, PPP), Q), Q));
   Fq Vd = fe_carry<P>(fe_sub<P, 8>(Q, X3));      // < 9.02
   r.X = X3;
-  r.Y = fe_mul_add2<P>(Rd, Vd, fe_neg_lazy<P, 4>(S1), PPP);    // Rd Vd + (4p - S1) PPP: < 1.3
-  r.ZZ = fe_mul<P>(fe_mul<P>(a.ZZ, b.ZZ), PP);
-  r.ZZZ = fe_mul<P>(fe_mul<P>(a.ZZZ, b.ZZZ), PPP);
+  r.Y = F::mul_add2(Rd, Vd, fe_neg_lazy<P, 4>(S1), PPP);       // Rd Vd + (4p - S1) PPP: < 1.3
+  r.ZZ = F::mul(F::mul(a.ZZ, b.ZZ), PP);
+  r.ZZZ = F::mul(F::mul(a.ZZZ, b.ZZZ), PPP);
   return r;
 }
+MZK_HD Xyzz xyzz_add(const Xyzz& a, const Xyzz& b) { return xyzz_add_with<FeCpp>(a, b); }
 
 // XYZZ -> canonical affine (Montgomery form); returns false for infinity.  SERIAL selects the
 // single-lane inversion (tail kernels); the default is the divergence-free Fermat ladder.

@@ -750,7 +750,7 @@ __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ 
     if (affine_words_is_inf(w)) continue;  // infinity contributes nothing (curve.rs:107-109)
     Affine p = affine_load_mont(w);
     if (ent >> 31) p = affine_neg(p);
-    acc = xyzz_madd(acc, p);
+    acc = xyzz_madd_with<FeAsm>(acc, p);
   }
   xyzz_gstore_raw(slots, t + b, acc);
 }
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(128) void k_seg_combine_wide(const u32* __restrict_
   if (o1 > o0) {
     const size_t s0 = (size_t)(o0 / seg) + b, s1 = (size_t)((o1 - 1) / seg) + b;
     if (defer_heavy(b, s0, s1, heavy, true)) return;
-    for (size_t sl = s0; sl <= s1; sl++) acc = xyzz_add(acc, xyzz_gload_raw(slots, sl));
+    for (size_t sl = s0; sl <= s1; sl++) acc = xyzz_add_with<FeAsm>(acc, xyzz_gload_raw(slots, sl));
   }
   xyzz_gstore(buckets, b, acc);
 }
@@ -852,7 +852,7 @@ __global__ __launch_bounds__(128) void k_halve_step_wide(u32* __restrict__ bucke
   const int lgh = lgB - t - 1;
   const size_t a = id >> lgh, j = id & (((size_t)1 << lgh) - 1);
   const size_t idx = ((a == 0) ? 0 : ((size_t)1 << (lgB - a))) + j;
-  xyzz_gstore(buf, idx, xyzz_add(xyzz_gload(buf, idx), xyzz_gload(buf, idx + ((size_t)1 << lgh))));
+  xyzz_gstore(buf, idx, xyzz_add_with<FeAsm>(xyzz_gload(buf, idx), xyzz_gload(buf, idx + ((size_t)1 << lgh))));
 }
 __global__ __launch_bounds__(128) void k_halve_step(u32* __restrict__ buckets, int lgB, int t) {
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -19,10 +19,11 @@
 // fe_mul(x, wR) = x w exactly, so no element is ever converted into or out of Montgomery form.
 //
 // LDS layout: structure-of-arrays, limb-major (lds[limb][position]) so every access is a
-// conflict-light ds_read_b32 / ds_write_b32; positions are XOR-swizzled (pos ^ (pos >> 5 & 31)) so the
-// bit-reversed scatter of the load phase does not serialise on one bank.
+// ds_read_b32 / ds_write_b32; positions are XOR-swizzled (Geo::phys) so that neither the bit-reversed scatter of the
+// load phase nor the strided stage accesses serialise on a bank.
 #include <stdlib.h>
 #include "mzk_common.h"
+#include "mzk_field_asm.h"
 
 namespace mzk {
 
@@ -42,6 +43,18 @@ constexpr int MAX_LEVEL_LOG = MZK_NTT_MAX_LEVEL_LOG;
 // its in-tile twiddles are staged as packed words (16 KiB: 160 KiB exactly) and unpacked at use.
 template <int TL_, int NT_, int MAXLV_> struct Geo {
   static constexpr int TL = TL_, TILE = 1 << TL_, NT = NT_, MAXLV = MAXLV_;
+  // Logical tile position -> LDS word index inside a limb row.  The low five bits (the bank) are XORed with a GF(2)-linear
+  // function of the upper bits, chosen by simulating every wave-level access of the kernels (bit-reversed scatter of
+  // the load phase, the four loads and stores of every radix-4 stage pair, all level sizes the geometry runs;
+  // tools/timing/lds_swizzle_search.py) so that each 32-lane half of an access touches every bank at most once:
+  // small tiles, 2^7 and 2^8 levels: 288 cycles per tile (conflict-free) instead of 544 with the round-1 swizzle
+  // pos ^ (pos >> 5 & 31); large tiles, 2^10 levels: 1408 (conflict-free) instead of 3840.  (Measured effect on the
+  // transform time: none -- the LDS traffic hides behind the products; what-if builds in DESIGN.md section 4.)
+  static __device__ __forceinline__ int phys(int pos) {
+    const int h = pos >> 5;
+    const int x = (TL_ == 10) ? (h ^ (h << 2) ^ (h << 3)) : ((h >> 2) ^ (h << 1) ^ (h << 3));
+    return pos ^ (x & 31);
+  }
   template <class P> static constexpr bool twpack() { return (size_t)4 * P::L * (TILE + (1 << (MAXLV_ - 1))) > (size_t)160 * 1024; }
   template <class P> static constexpr size_t lds_bytes(int lgn) {
     return sizeof(u32) * ((size_t)P::L * TILE + (size_t)(twpack<P>() ? P::NW : P::L) * (lgn >= 2 ? ((size_t)1 << (lgn - 1)) : 1));
@@ -93,16 +106,15 @@ template <class P> __device__ __forceinline__ Fe<P> fe_fit(const Fe<P>& v) {
   else return v;
 }
 
-__device__ __forceinline__ int lds_phys(int pos) { return pos ^ ((pos >> 5) & 31); }
 template <class P, class G> __device__ __forceinline__ Fe<P> lds_load(const u32* lds, int pos) {
   Fe<P> r;
-  const int ph = lds_phys(pos);
+  const int ph = G::phys(pos);
 #pragma unroll
   for (int i = 0; i < P::L; i++) r.l[i] = lds[i * G::TILE + ph];
   return r;
 }
 template <class P, class G> __device__ __forceinline__ void lds_store(u32* lds, int pos, const Fe<P>& v) {
-  const int ph = lds_phys(pos);
+  const int ph = G::phys(pos);
 #pragma unroll
   for (int i = 0; i < P::L; i++) lds[i * G::TILE + ph] = v.l[i];
 }
@@ -140,7 +152,7 @@ __device__ __forceinline__ void bfly(Fe<P>& lo, Fe<P>& hi, const u32* twl, int t
 #pragma unroll
       for (int i = 0; i < P::L; i++) w.l[i] = twl[i * tws + ti];
     }
-    t = fe_mul<P>(t, w);
+    t = FeAsm<P>::mul(t, w);
   } else if (!raw) {
     t = fe_weak_reduce<P>(t);
   }
@@ -229,7 +241,7 @@ __global__ __launch_bounds__(G::NT) void k_ntt_strided(const u32* __restrict__ i
       if (idx < pre.n_coef) {
         const Fe<P> x = gload<P>(pre.coef, idx);
         const Fe<P> wc = gload<P>(pre.pre_col, (ct << lgc) + c), wr = gload<P>(pre.pre_row, (size_t)j1);
-        v = fe_fit<P>(fe_mul<P>(fe_mul<P>(x, wc), wr));            // plain * Montgomery * Montgomery = plain
+        v = fe_fit<P>(FeAsm<P>::mul(FeAsm<P>::mul(x, wc), wr));    // plain * Montgomery * Montgomery = plain
       } else {
         v = fe_zero<P>();
       }
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(G::NT) void k_ntt_strided(const u32* __restrict__ i
     const size_t off = ((size_t)k << lgM) + (ct << lgc) + c;
     Fe<P> v = lds_load<P, G>(lds, (k << lgc) | c);
     Fe<P> w = gload<P>(tw_inter, off);
-    gstore<P>(out, (o << (lgn + lgM)) + off, fe_fit<P>(fe_mul<P>(v, w)));
+    gstore<P>(out, (o << (lgn + lgM)) + off, fe_fit<P>(FeAsm<P>::mul(v, w)));
   }
 }
 
@@ -291,7 +303,7 @@ __global__ __launch_bounds__(G::NT) void k_ntt_last(const u32* __restrict__ in, 
     const size_t r = p0 + rr;
     if (r >= total_rows) continue;
     Fe<P> v = lds_load<P, G>(lds, (k << lgr) | rr);
-    if (has_scale) v = fe_mul<P>(v, sc);
+    if (has_scale) v = FeAsm<P>::mul(v, sc);
     gstore<P>(out, ((r >> lg_rows) << logn) + (r & rowmask) + ((size_t)k << lg_rows), fe_reduce<P>(v));
   }
 }
@@ -359,7 +371,7 @@ __global__ void k_pointwise_mul(const u32* __restrict__ a, const u32* __restrict
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fe<P> x = gload<P>(a, i), y = gload<P>(b, i);
-  Fe<P> t = fe_mul<P>(fe_mul<P>(x, y), fe_r2<P>());
+  Fe<P> t = FeAsm<P>::mul(FeAsm<P>::mul(x, y), fe_r2<P>());
   gstore<P>(out, i, fe_reduce<P>(t));
 }
 
