@@ -290,6 +290,12 @@ int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, m
  * bit-serial reference implementation.  field_id may also be MZK_FIELD_FQ. */
 int mzk_host_field_op(int field_id, int op, const uint64_t* a, const uint64_t* b, uint64_t* out);
 
+/* Device self-check: the throughput kernels compute their Montgomery products with hand-scheduled inline-asm blocks
+ * (myzkp_amd/csrc/mzk_field_asm.h); this runs both forms (asm and portable C++) over n operand sets per field -- random,
+ * all-ones, zero and the widest lazy limbs -- and returns the number of differing results (must be 0).
+ * field_id may also be MZK_FIELD_FQ. */
+int mzk_selftest_field_asm(int field_id, uint64_t seed, size_t n, uint64_t* mismatches);
+
 /* Deterministic synthetic inputs (bench + tests): bit-identical to the oracle's orc_synth_*. */
 int mzk_synth_field_dev(int field_id, uint64_t seed, size_t n, void* d_out, void* stream);
 int mzk_synth_g1_points_dev(uint64_t seed, size_t n, void* d_out_xy, void* stream);

@@ -894,6 +894,12 @@ int mzk_synth_field_dev(int field_id, uint64_t seed, size_t n, void* d_out, void
   if (!d_out && n) { set_error("synth: null pointer"); return MZK_E_ARG; }
   return synth_field_impl(field_id, seed, n, d_out, (hipStream_t)stream);
 }
+int mzk_selftest_field_asm(int field_id, uint64_t seed, size_t n, uint64_t* mismatches) {
+  MZK_TRY(ensure_init());
+  if (!mismatches) { set_error("selftest: null pointer"); return MZK_E_ARG; }
+  WsGuard wsg(ctx().stream);
+  return selftest_field_asm_impl(field_id, seed, n, mismatches, ctx().stream);
+}
 int mzk_synth_g1_points_dev(uint64_t seed, size_t n, void* d_out_xy, void* stream) {
   MZK_TRY(ensure_init());
   WsGuard wsg((hipStream_t)stream);

@@ -1,0 +1,76 @@
+// mzk_selftest.hip -- on-device self-check of the inline-asm field products (mzk_field_asm.h) against the portable C++
+// forms of mzk_field.h.  The asm blocks exist only in device code, so the host-compiled bounds-checked unit tests
+// (tests/hostcheck) cannot reach them; this kernel feeds both forms the same operands -- random limbs, all-ones limbs,
+// zeros, and the widest lazy operands the callers produce (limbs up to 2^30.6 against normalised ones) -- and counts
+// the lanes whose results differ in any limb.  Called by tests/test_gpu_field_asm.py through mzk_selftest_field_asm.
+#include "mzk_common.h"
+#include "mzk_field_asm.h"
+
+namespace mzk {
+
+__device__ __forceinline__ u64 st_mix(u64& s) {
+  u64 z = (s += 0x9e3779b97f4a7c15ULL);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  return z ^ (z >> 31);
+}
+// kind 0: normalised random limbs (< 2^29, top limb < 2^29 too); 1: every limb 2^29 - 1; 2: zero;
+// 3: lazy limbs up to 2^30.6 (the borrow-friendly K p - b forms); 4: a single non-zero limb
+template <class P> __device__ Fe<P> st_operand(u64& s, int kind) {
+  Fe<P> r;
+  const u32 lazy_max = 0x60000000u;      // 2^30.58
+  for (int i = 0; i < P::L; i++) {
+    const u32 v = (u32)st_mix(s);
+    switch (kind) {
+      case 0: r.l[i] = v & MASK29; break;
+      case 1: r.l[i] = MASK29; break;
+      case 2: r.l[i] = 0; break;
+      case 3: r.l[i] = v % lazy_max; break;
+      default: r.l[i] = 0; break;
+    }
+  }
+  if (kind == 4) r.l[(u32)st_mix(s) % P::L] = (u32)st_mix(s) & MASK29;
+  return r;
+}
+template <class P> __device__ bool st_same(const Fe<P>& a, const Fe<P>& b) {
+  u32 d = 0;
+  for (int i = 0; i < P::L; i++) d |= a.l[i] ^ b.l[i];
+  return d == 0;
+}
+template <class P>
+__global__ void k_selftest_field_asm(u64 seed, size_t n, unsigned long long* __restrict__ mismatches) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 s = seed ^ (i * 0xd1342543de82ef95ULL);
+  const int ka = (int)(i % 5), kb = (int)((i / 5) % 3);      // b stays normalised (kinds 0..2): the callers' contract
+  const Fe<P> a = st_operand<P>(s, ka), b = st_operand<P>(s, kb);
+  const Fe<P> c = st_operand<P>(s, (int)((i / 15) % 5)), d = st_operand<P>(s, (int)((i / 75) % 3));
+  int bad = 0;
+  bad += !st_same<P>(fe_mul<P>(a, b), FeAsm<P>::mul(a, b));
+  const Fe<P> q = (ka == 3) ? b : a;            // squares only ever see carried operands (limbs < 2^30)
+  bad += !st_same<P>(fe_sqr<P>(q), FeAsm<P>::sqr(q));
+  // the fused pair needs L (|a||b| + |c||d|) + L 2^58 < 2^64: both lazy operands at 2^30.6 fit against normalised ones
+  bad += !st_same<P>(fe_mul_add2<P>(a, b, c, d), FeAsm<P>::mul_add2(a, b, c, d));
+  if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
+int selftest_field_asm_impl(int fid, uint64_t seed, size_t n, uint64_t* mismatches_host, hipStream_t s) {
+  unsigned long long* d;
+  MZK_TRY(ws_get(WS_MISC_A, 8, (void**)&d));
+  MZK_HIP(hipMemsetAsync(d, 0, 8, s));
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  if (n) {
+    if (fid == MZK_FIELD_FR) hipLaunchKernelGGL(k_selftest_field_asm<FrParams>, dim3(blocks), dim3(256), 0, s, seed, n, d);
+    else if (fid == MZK_FIELD_FQ) hipLaunchKernelGGL(k_selftest_field_asm<FqParams>, dim3(blocks), dim3(256), 0, s, seed, n, d);
+    else if (fid == MZK_FIELD_M128) hipLaunchKernelGGL(k_selftest_field_asm<M128Params>, dim3(blocks), dim3(256), 0, s, seed, n, d);
+    else { set_error("selftest: unknown field id %d", fid); return MZK_E_ARG; }
+    MZK_HIP(hipGetLastError());
+  }
+  unsigned long long h = 0;
+  MZK_HIP(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  *mismatches_host = (uint64_t)h;
+  return MZK_OK;
+}
+
+}  // namespace mzk
