@@ -7,7 +7,7 @@ import myzkp_amd as mz
 mz.init(0); L = mz.lib()
 dev = torch.device("cuda", 0)
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-for lg in (4, 8, 10, 11, 12, 13, 14):
+for lg in ([int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else (4, 8, 10, 11, 12, 13, 14)):
     n = 1 << lg
     sc = torch.empty(n * 4, dtype=torch.int64, device=dev); pt = torch.empty(n * 8, dtype=torch.int64, device=dev)
     L.mzk_synth_field_dev(0, ctypes.c_uint64(1), ctypes.c_size_t(n), ctypes.c_void_p(sc.data_ptr()), st)
