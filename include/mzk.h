@@ -264,6 +264,18 @@ int mzk_kzg_commit_srs_multi_dev(const mzk_srs_multi* h, const void* const* d_co
 int mzk_kzg_commit_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, void* d_out, int out_partial,
                            void* stream);
 
+/* `count` commitments against one SRS -- commit_kzg (kzg.rs:57-59) once per polynomial, as the reference's callers do in
+ * a loop -- with results bit-identical to `count` single calls.  coefs: count vectors of n coefficients back to back
+ * (count * n * 4 limbs), out_xy: count affine points (count * 8 limbs).  One commit is kept in flight per context of the
+ * current GPU (at most four; mzk_init_devices with the same ordinal repeated makes them: own stream and workspace each,
+ * the SRS handle shared), so the latency-bound tail of one commit runs under the bucket accumulation of the others:
+ * 1.40 instead of 1.64 ms per 2^20-coefficient commit with four contexts.  With a single context the commits simply
+ * run one after the other.  The _dev form forks from and joins `stream`; max_in_flight caps the contexts it uses
+ * (0 = all of this GPU's, at most four: more measured slower). */
+int mzk_kzg_commit_srs_batch(const mzk_srs* srs, const uint64_t* coefs, size_t n, size_t count, uint64_t* out_xy);
+int mzk_kzg_commit_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, void* d_out_xy, int max_in_flight,
+                                 void* stream);
+
 /* open_kzg / setup_kzg with everything device-resident (end-to-end pipelines: iNTT -> commit -> open).
  * d_y: 4 limbs, d_w_xy: 8 limbs on the device; u / alpha / g1 are host parameters. */
 int mzk_kzg_open_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, const uint64_t u_host[4], void* d_y,

@@ -321,6 +321,18 @@ class Srs:
         _check(lib().mzk_kzg_commit_srs(self._h, _p(c), ctypes.c_size_t(c.shape[0]), _p(out)))
         return array_to_points(out)[0]
 
+    def commit_batch(self, coefs):
+        """commit_kzg of every row of `coefs` (count x n x 4 limbs; all polynomials of one length), one commit in flight
+        per context of this GPU (init_devices([d, d, d, d])): mzk_kzg_commit_srs_batch."""
+        c = np.ascontiguousarray(coefs, dtype=np.uint64)
+        count = c.shape[0]
+        if count == 0:
+            return []
+        c = c.reshape(count, -1, 4)
+        out = np.zeros((max(count, 1), 8), dtype=np.uint64)
+        _check(lib().mzk_kzg_commit_srs_batch(self._h, _p(c), ctypes.c_size_t(c.shape[1]), ctypes.c_size_t(count), _p(out)))
+        return array_to_points(out[:count])
+
     def save(self, path, with_tables=False):
         """Raw little-endian dump of powers_1 (+ optionally the window tables): mzk_srs_save."""
         _check(lib().mzk_srs_save(self._h, os.fsencode(path), int(bool(with_tables))))

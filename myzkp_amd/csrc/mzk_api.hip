@@ -336,6 +336,8 @@ void mzk_shutdown(void) {
     ntt_release_plans();
     ws_release_all();
     if (c.ws_event) (void)hipEventDestroy(c.ws_event);
+    if (c.fork_event) (void)hipEventDestroy(c.fork_event);
+    if (c.join_event) (void)hipEventDestroy(c.join_event);
     if (c.stream) (void)hipStreamDestroy(c.stream);
     c = Context();
   }
@@ -743,6 +745,82 @@ int mzk_kzg_commit_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, voi
   if (n > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }
   return msm_dev_impl(d_coef, srs->d_points_mont, n, srs->kind(), srs->n, d_out, out_partial != 0,
                       (hipStream_t)stream);
+}
+
+// count commitments against one SRS, one commit in flight per context of this GPU.  Context k of the same device runs
+// polynomials k, k + K, ... on its own stream and workspace (the bucket reduction / inversion tail and the memory-bound
+// sort of one commit run under the accumulation of the others); the caller's stream forks into them and joins them.
+int mzk_kzg_commit_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, void* d_out_xy, int max_in_flight,
+                                 void* stream) {
+  MZK_TRY(ensure_init());
+  if (!srs || ((!d_coefs || !d_out_xy) && count)) { set_error("commit_srs_batch_dev: null pointer"); return MZK_E_ARG; }
+  MZK_TRY(srs_check_ctx(srs));
+  if (n > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }
+  if (count == 0) return MZK_OK;
+  hipStream_t caller = (hipStream_t)stream;
+  const int home = ctx().index, dev = ctx().device;
+  int lanes[MZK_MAX_CTX], K = 0;
+  lanes[K++] = home;
+  const int cap = (max_in_flight >= 1 && max_in_flight < 4) ? max_in_flight : 4;      // more than four in flight measured slower
+  for (int i = 0; i < g_nctx && K < cap; i++)
+    if (i != home && g_ctxs[i].ready && g_ctxs[i].device == dev) lanes[K++] = i;
+  if ((size_t)K > count) K = (int)count;
+  const char* coefs = (const char*)d_coefs;
+  char* outs = (char*)d_out_xy;
+  if (K == 1) {                                         // no second context on this GPU: plain sequence on the caller's stream
+    WsGuard wsg(caller);
+    for (size_t i = 0; i < count; i++)
+      MZK_TRY(msm_dev_impl(coefs + i * n * 32, srs->d_points_mont, n, srs->kind(), srs->n, outs + i * 64, false, caller));
+    return MZK_OK;
+  }
+  // Lane 0 is the current context ON THE CALLER'S STREAM (no further stream: one of the same priority as the caller's
+  // may share its hardware queue, and the join below would then hold that lane back until all others are done --
+  // measured: 1.87 instead of 1.51 ms per commit with two lanes); lanes 1.. are the other contexts on their own streams.
+  // fork: those streams wait for what the caller's stream has enqueued so far (the inputs)
+  Context& h = g_ctxs[home];
+  if (!h.fork_event) MZK_HIP(hipEventCreateWithFlags(&h.fork_event, hipEventDisableTiming));
+  MZK_HIP(hipEventRecord(h.fork_event, caller));
+  int rc = MZK_OK;
+  for (int k = 1; k < K && rc == MZK_OK; k++)
+    if (hipStreamWaitEvent(g_ctxs[lanes[k]].stream, h.fork_event, 0) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipStreamWaitEvent", __FILE__, __LINE__);
+  // polynomial i goes to lane i mod K, enqueued in that order: the lanes start one enqueue time apart and stay staggered,
+  // which is what puts one commit's tail under another's accumulation (lane by lane they would start a whole lane's work
+  // apart and run their accumulations side by side)
+  for (size_t i = 0; i < count && rc == MZK_OK; i++) {
+    const int k = (int)(i % (size_t)K);
+    CtxScope scope(lanes[k]);
+    if (!scope.ok) { rc = MZK_E_ARG; break; }
+    hipStream_t ls = k == 0 ? caller : ctx().stream;
+    WsGuard wsg(ls);
+    rc = msm_dev_impl(coefs + i * n * 32, srs->d_points_mont, n, srs->kind(), srs->n, outs + i * 64, false, ls);
+  }
+  // join: the caller's stream continues after every lane's last commit (also after a failure: nothing may be left running
+  // behind the caller's back)
+  for (int k = 1; k < K; k++) {
+    Context& c = g_ctxs[lanes[k]];
+    if (!c.join_event && hipEventCreateWithFlags(&c.join_event, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(c.stream); continue; }
+    if (hipEventRecord(c.join_event, c.stream) != hipSuccess || hipStreamWaitEvent(caller, c.join_event, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(c.stream);
+    }
+  }
+  return rc;
+}
+int mzk_kzg_commit_srs_batch(const mzk_srs* srs, const uint64_t* coefs, size_t n, size_t count, uint64_t* out_xy) {
+  MZK_TRY(ensure_init());
+  if (!srs || ((!coefs || !out_xy) && count)) { set_error("commit_srs_batch: null pointer"); return MZK_E_ARG; }
+  if (count == 0) return MZK_OK;
+  hipStream_t s = ctx().stream;
+  void *d_c, *d_o;
+  {
+    WsGuard wsg(s);
+    MZK_TRY(stage_in(WS_MISC_E, coefs, count * n * 32, &d_c, s));
+    MZK_TRY(ws_get(WS_MISC_F, count * 64, &d_o));
+  }
+  MZK_TRY(mzk_kzg_commit_srs_batch_dev(srs, d_c, n, count, d_o, 0, s));
+  MZK_HIP(hipMemcpyAsync(out_xy, d_o, count * 64, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  return MZK_OK;
 }
 
 int mzk_kzg_open_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, const uint64_t u_host[4], void* d_y, void* d_w_xy, void* stream) {

@@ -49,6 +49,7 @@ struct Context {
   // Stream-order guard of the shared workspace: ws_last = stream of the last entry point; an entry point on another
   // stream records ws_event on ws_last and waits for it before touching the slots (WsGuard).
   hipEvent_t ws_event = nullptr;
+  hipEvent_t fork_event = nullptr, join_event = nullptr;     // mzk_kzg_commit_srs_batch_dev: caller stream -> lanes -> caller stream
   hipStream_t ws_last = nullptr;
   bool ws_used = false;
   bool attr_done[ATTR_COUNT] = {};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applied on this context's device

@@ -121,3 +121,50 @@ def test_srs_handle_is_shared_by_contexts_on_the_same_device(mz):
             assert e.value.code == -1
             mz.init_devices([0, 0])
         h.close()
+
+
+@pytest.mark.parametrize("nctx", [1, 2, 4])
+def test_commit_batch_equals_single_commits(mz, nctx):
+    """mzk_kzg_commit_srs_batch: `count` commit_kzg calls (kzg.rs:57-59) with one commit in flight per context of the
+    GPU -- every point equal to the oracle's and to the one-at-a-time result, for ragged lane assignments (count not a
+    multiple of the contexts), the small path (n < 4096) and the general one, and count = 0."""
+    mz.init_devices([0] * nctx)
+    for n, count in ((300, 5), ((1 << 13) + 3, 7), (1 << 12, 1)):
+        p = orc.synth_points(900 + n, n)
+        h = mz.Srs(p)
+        coefs = np.stack([orc.synth_vector(FR, 1000 + 17 * k + n, n) for k in range(count)])
+        coefs[0][1] = 0
+        got = h.commit_batch(coefs)
+        assert len(got) == count
+        for k in range(count):
+            assert got[k] == orc.msm_fast(coefs[k], p), (n, k)
+            assert got[k] == h.commit(coefs[k])
+        assert h.commit_batch(np.zeros((0, n, 4), dtype=np.uint64)) == []
+        h.close()
+
+
+def test_commit_batch_dev_forks_from_and_joins_the_callers_stream(mz):
+    """The device form on a caller stream that is not a context stream: inputs produced on that stream just before the
+    call, results consumed on it right after -- no host synchronisation in between."""
+    import ctypes, torch
+    mz.init_devices([0, 0, 0])
+    L = mz.lib()
+    n, count = 1 << 12, 6
+    p = orc.synth_points(77, n)
+    h = mz.Srs(p)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        sp = ctypes.c_void_p(st.cuda_stream)
+        d_c = torch.empty(count * n * 4, dtype=torch.int64, device="cuda")
+        for k in range(count):      # synthetic coefficients written on the caller's stream
+            assert L.mzk_synth_field_dev(0, ctypes.c_uint64(500 + k), ctypes.c_size_t(n), ctypes.c_void_p(d_c.data_ptr() + k * n * 32), sp) == 0
+        d_o = torch.zeros(count * 8, dtype=torch.int64, device="cuda")
+        rc = L.mzk_kzg_commit_srs_batch_dev(h._h, ctypes.c_void_p(d_c.data_ptr()), ctypes.c_size_t(n), ctypes.c_size_t(count),
+                                            ctypes.c_void_p(d_o.data_ptr()), ctypes.c_int(0), sp)
+        assert rc == 0, L.mzk_last_error()
+        res = d_o.clone()           # enqueued on the caller's stream behind the join
+    st.synchronize()
+    got = mz.array_to_points(res.cpu().numpy().view(np.uint64).reshape(count, 8))
+    for k in range(count):
+        assert got[k] == orc.msm_fast(orc.synth_vector(FR, 500 + k, n), p)
+    h.close()
