@@ -60,36 +60,40 @@ MZK_HD Xyzz xyzz_dbl_affine(const Affine& a) {
   return r;
 }
 
-// 2 * (XYZZ) -> XYZZ   (dbl-2008-s-1, a = 0): 6M + 3S.  inf -> inf.
-MZK_HD Xyzz xyzz_dbl(const Xyzz& p) {
-  typedef FqParams P;
-  if (xyzz_is_inf(p)) return p;
-  Xyzz r;
-  Fq U = fe_dbl<P>(p.Y);                         // < 5, limbs < 2^30
-  Fq V = fe_sqr<P>(U);                           // < 1.15
-  Fq W = fe_mul<P>(U, V);                        // < 1.04
-  Fq S = fe_mul<P>(p.X, V);                      // < 1.02
-  Fq X2 = fe_sqr<P>(p.X);                        // < 1.04
-  Fq M = fe_carry<P>(fe_add<P>(fe_dbl<P>(X2), X2));  // < 3.12, N
-  Fq MM = fe_sqr<P>(M);                          // < 1.06
-  Fq X3 = fe_weak_reduce<P>(fe_sub<P, 4>(fe_sub<P, 4>(MM, S), S));
-  Fq Vd = fe_carry<P>(fe_sub<P, 8>(S, X3));      // < 9.02
-  r.X = X3;
-  r.Y = fe_mul_add2<P>(M, Vd, fe_neg_lazy<P, 8>(p.Y), W);      // M (S - X3) - Y1 W: < 1.22
-  r.ZZ = fe_mul<P>(V, p.ZZ);
-  r.ZZZ = fe_mul<P>(W, p.ZZZ);
-  return r;
-}
-
-// acc + (affine q) -> XYZZ   (madd-2008-s): 8M + 2S.  Exception-complete.
-// A = the product routines: FeCpp (portable C++, scheduled by the compiler: best for the latency-bound tail kernels)
-// or FeAsm (mzk_field_asm.h: one inline-asm chain per product, fewer instructions: best at 3+ waves per SIMD).  Both
-// compute the same column sums, so the result limbs are identical.
+// Product routines of the group law: FeCpp (portable C++, scheduled by the compiler: best for the latency-bound tail
+// kernels) or FeAsm (mzk_field_asm.h: one inline-asm chain per product, fewer instructions: best at 3+ waves per SIMD).
+// Both compute the same column sums, so the result limbs are identical.
 template <class P> struct FeCpp {
   static MZK_HD Fe<P> mul(const Fe<P>& a, const Fe<P>& b) { return fe_mul<P>(a, b); }
   static MZK_HD Fe<P> sqr(const Fe<P>& a) { return fe_sqr<P>(a); }
   static MZK_HD Fe<P> mul_add2(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) { return fe_mul_add2<P>(a, b, c, d); }
 };
+
+// 2 * (XYZZ) -> XYZZ   (dbl-2008-s-1, a = 0): 6M + 3S.  inf -> inf.
+template <template <class> class A> MZK_HD Xyzz xyzz_dbl_with(const Xyzz& p) {
+  typedef FqParams P;
+  typedef A<P> F;
+  if (xyzz_is_inf(p)) return p;
+  Xyzz r;
+  Fq U = fe_dbl<P>(p.Y);                         // < 5, limbs < 2^30
+  Fq V = F::sqr(U);                              // < 1.15
+  Fq W = F::mul(U, V);                           // < 1.04
+  Fq S = F::mul(p.X, V);                         // < 1.02
+  Fq X2 = F::sqr(p.X);                           // < 1.04
+  Fq M = fe_carry<P>(fe_add<P>(fe_dbl<P>(X2), X2));  // < 3.12, N
+  Fq MM = F::sqr(M);                             // < 1.06
+  Fq X3 = fe_weak_reduce<P>(fe_sub<P, 4>(fe_sub<P, 4>(MM, S), S));
+  Fq Vd = fe_carry<P>(fe_sub<P, 8>(S, X3));      // < 9.02
+  r.X = X3;
+  r.Y = F::mul_add2(M, Vd, fe_neg_lazy<P, 8>(p.Y), W);         // M (S - X3) - Y1 W: < 1.22
+  r.ZZ = F::mul(V, p.ZZ);
+  r.ZZZ = F::mul(W, p.ZZZ);
+  return r;
+}
+MZK_HD Xyzz xyzz_dbl(const Xyzz& p) { return xyzz_dbl_with<FeCpp>(p); }
+
+// acc + (affine q) -> XYZZ   (madd-2008-s): 8M + 2S.  Exception-complete.
+// A: FeCpp or FeAsm (above).
 template <template <class> class A> MZK_HD Xyzz xyzz_madd_with(const Xyzz& a, const Affine& q) {
   typedef FqParams P;
   typedef A<P> F;

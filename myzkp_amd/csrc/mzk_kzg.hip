@@ -159,12 +159,12 @@ __global__ __launch_bounds__(128) void k_xyzz_batch_to_affine(const u32* __restr
     ld8(xyzz + 32 * (i0 + j) + 16, w);       // ZZ
     ld8(xyzz + 32 * (i0 + j) + 24, w + 8);   // ZZZ
     const bool inf = affine_words_is_inf(w);
-    Fq d = fe_mul<P>(fe_unpack<P>(w), fe_unpack<P>(w + 8));
+    Fq d = FeAsm<P>::mul(fe_unpack<P>(w), fe_unpack<P>(w + 8));
     if (inf) d = fe_one<P>();
     // prefix BEFORE including element j
 #pragma unroll
     for (int k = 0; k < P::L; k++) scratch[(i0 + j) * P::L + k] = run.l[k];
-    run = fe_mul<P>(run, d);
+    run = FeAsm<P>::mul(run, d);
   }
   Fq inv = fe_inv<P>(run);
   for (int j = len - 1; j >= 0; j--) {
@@ -176,18 +176,18 @@ __global__ __launch_bounds__(128) void k_xyzz_batch_to_affine(const u32* __restr
     Fq pre;
 #pragma unroll
     for (int k = 0; k < P::L; k++) pre.l[k] = scratch[(i0 + j) * P::L + k];
-    const Fq dinv = fe_mul<P>(inv, pre);                       // 1 / (ZZ ZZZ) of element j
-    Fq d = fe_mul<P>(ZZ, ZZZ);
+    const Fq dinv = FeAsm<P>::mul(inv, pre);                       // 1 / (ZZ ZZZ) of element j
+    Fq d = FeAsm<P>::mul(ZZ, ZZZ);
     if (inf) d = fe_one<P>();
-    inv = fe_mul<P>(inv, d);                                   // drop element j from the running inverse
+    inv = FeAsm<P>::mul(inv, d);                                   // drop element j from the running inverse
     u32 o[16];
     if (inf) {
 #pragma unroll
       for (int k = 0; k < 16; k++) o[k] = 0;
     } else {
       Affine a;
-      a.x = fe_reduce<P>(fe_mul<P>(X, fe_mul<P>(dinv, ZZZ)));   // X / ZZ
-      a.y = fe_reduce<P>(fe_mul<P>(Y, fe_mul<P>(dinv, ZZ)));    // Y / ZZZ
+      a.x = fe_reduce<P>(FeAsm<P>::mul(X, FeAsm<P>::mul(dinv, ZZZ)));   // X / ZZ
+      a.y = fe_reduce<P>(FeAsm<P>::mul(Y, FeAsm<P>::mul(dinv, ZZ)));    // Y / ZZZ
       if (out_mont) affine_store_mont(a, o); else affine_store_plain(a, o);
     }
     st8(out + 16 * (i0 + j), o);

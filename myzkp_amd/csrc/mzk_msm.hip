@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(128) void k_srs_window_step(u32* __restrict__ state
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Xyzz p = xyzz_gload(state, i);
-  for (int d = 0; d < c; d++) p = xyzz_dbl(p);
+  for (int d = 0; d < c; d++) p = xyzz_dbl_with<FeAsm>(p);
   xyzz_gstore(state, i, p);
 }
 int msm_build_tables(const void* d_points_mont, size_t n, void* d_tables, int window_bits, hipStream_t s) {

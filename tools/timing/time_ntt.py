@@ -9,7 +9,7 @@ mz.init(0); L = mz.lib()
 dev = torch.device("cuda", 0)
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 for fid, name, nl in ((0, "Fr", 4), (1, "M128", 2)):
-    for lg in (19, 20, 21, 22, 24):
+    for lg in ([int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else (19, 20, 21, 22, 24)):
         n = 1 << lg
         vin = torch.empty(n*nl, dtype=torch.int64, device=dev); vout = torch.empty(n*nl, dtype=torch.int64, device=dev)
         L.mzk_synth_field_dev(fid, ctypes.c_uint64(5), ctypes.c_size_t(n), ctypes.c_void_p(vin.data_ptr()), st)
@@ -19,7 +19,7 @@ for fid, name, nl in ((0, "Fr", 4), (1, "M128", 2)):
             assert rc == 0, L.mzk_last_error()
         run(); run(); torch.cuda.synchronize()
         ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
-        reps = 40 if lg <= 20 else 8
+        reps = 200 if lg <= 16 else 40 if lg <= 20 else 8
         ev0.record()
         for _ in range(reps): run()
         ev1.record(); torch.cuda.synchronize()
