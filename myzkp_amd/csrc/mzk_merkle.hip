@@ -28,71 +28,57 @@ __constant__ u64 KECCAK_RC[24] = {
     0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
 
 // Keccak-f[1600], FIPS 202 section 3.2/3.3: theta, rho+pi (fused with the theta xor), chi, iota; lane (x, y) = a[x + 5y].
-__device__ __forceinline__ void keccak_f(u64 (&a)[25]) {
+// The 64-bit lanes are handled as explicit 32-bit halves: a rotation is then two v_alignbit_b32 (hipcc turns a 64-bit
+// rotate into two 64-bit shifts and an or) and chi's a ^ (~b & c) one v_bitop3_b32 per half (instead of v_bfi + v_xor):
+// with the column parities as two three-input xors (v_bitop3_b32 again) 190 instructions per round instead of ~330 -- the tree's upper levels are one hash per lane on a nearly empty GPU,
+// i.e. pure instruction latency.
+struct KW { u32 lo, hi; };
+__device__ __forceinline__ KW kw_xor(KW a, KW b) { return KW{a.lo ^ b.lo, a.hi ^ b.hi}; }
+template <int R> __device__ __forceinline__ KW kw_rot(KW x) {
+  if constexpr (R == 0) return x;
+  else if constexpr (R == 32) return KW{x.hi, x.lo};
+  else if constexpr (R < 32) return KW{__builtin_amdgcn_alignbit(x.lo, x.hi, 32 - R), __builtin_amdgcn_alignbit(x.hi, x.lo, 32 - R)};
+  else return KW{__builtin_amdgcn_alignbit(x.hi, x.lo, 64 - R), __builtin_amdgcn_alignbit(x.lo, x.hi, 64 - R)};
+}
+__device__ __forceinline__ KW kw_chi(KW a, KW b, KW c) { return KW{a.lo ^ (~b.lo & c.lo), a.hi ^ (~b.hi & c.hi)}; }
+// a ^ b ^ c as one v_bitop3_b32 (truth table 0x96) per half: the five-lane column parities of theta in two steps
+__device__ __forceinline__ KW kw_xor3(KW a, KW b, KW c) {
+  return KW{(u32)__builtin_amdgcn_bitop3_b32((int)a.lo, (int)b.lo, (int)c.lo, 0x96), (u32)__builtin_amdgcn_bitop3_b32((int)a.hi, (int)b.hi, (int)c.hi, 0x96)};
+}
+__device__ __forceinline__ void keccak_f(u64 (&st)[25]) {
+  KW a[25];
+#pragma unroll
+  for (int i = 0; i < 25; i++) a[i] = KW{(u32)st[i], (u32)(st[i] >> 32)};
 #pragma unroll 1
   for (int rnd = 0; rnd < 24; rnd++) {
-    const u64 c0 = a[0] ^ a[5] ^ a[10] ^ a[15] ^ a[20];
-    const u64 c1 = a[1] ^ a[6] ^ a[11] ^ a[16] ^ a[21];
-    const u64 c2 = a[2] ^ a[7] ^ a[12] ^ a[17] ^ a[22];
-    const u64 c3 = a[3] ^ a[8] ^ a[13] ^ a[18] ^ a[23];
-    const u64 c4 = a[4] ^ a[9] ^ a[14] ^ a[19] ^ a[24];
-    const u64 d0 = c4 ^ rotl64<1>(c1);
-    const u64 d1 = c0 ^ rotl64<1>(c2);
-    const u64 d2 = c1 ^ rotl64<1>(c3);
-    const u64 d3 = c2 ^ rotl64<1>(c4);
-    const u64 d4 = c3 ^ rotl64<1>(c0);
-    const u64 b0 = rotl64<0>(a[0] ^ d0);
-    const u64 b16 = rotl64<36>(a[5] ^ d0);
-    const u64 b7 = rotl64<3>(a[10] ^ d0);
-    const u64 b23 = rotl64<41>(a[15] ^ d0);
-    const u64 b14 = rotl64<18>(a[20] ^ d0);
-    const u64 b10 = rotl64<1>(a[1] ^ d1);
-    const u64 b1 = rotl64<44>(a[6] ^ d1);
-    const u64 b17 = rotl64<10>(a[11] ^ d1);
-    const u64 b8 = rotl64<45>(a[16] ^ d1);
-    const u64 b24 = rotl64<2>(a[21] ^ d1);
-    const u64 b20 = rotl64<62>(a[2] ^ d2);
-    const u64 b11 = rotl64<6>(a[7] ^ d2);
-    const u64 b2 = rotl64<43>(a[12] ^ d2);
-    const u64 b18 = rotl64<15>(a[17] ^ d2);
-    const u64 b9 = rotl64<61>(a[22] ^ d2);
-    const u64 b5 = rotl64<28>(a[3] ^ d3);
-    const u64 b21 = rotl64<55>(a[8] ^ d3);
-    const u64 b12 = rotl64<25>(a[13] ^ d3);
-    const u64 b3 = rotl64<21>(a[18] ^ d3);
-    const u64 b19 = rotl64<56>(a[23] ^ d3);
-    const u64 b15 = rotl64<27>(a[4] ^ d4);
-    const u64 b6 = rotl64<20>(a[9] ^ d4);
-    const u64 b22 = rotl64<39>(a[14] ^ d4);
-    const u64 b13 = rotl64<8>(a[19] ^ d4);
-    const u64 b4 = rotl64<14>(a[24] ^ d4);
-    a[0] = b0 ^ (~b1 & b2);
-    a[1] = b1 ^ (~b2 & b3);
-    a[2] = b2 ^ (~b3 & b4);
-    a[3] = b3 ^ (~b4 & b0);
-    a[4] = b4 ^ (~b0 & b1);
-    a[5] = b5 ^ (~b6 & b7);
-    a[6] = b6 ^ (~b7 & b8);
-    a[7] = b7 ^ (~b8 & b9);
-    a[8] = b8 ^ (~b9 & b5);
-    a[9] = b9 ^ (~b5 & b6);
-    a[10] = b10 ^ (~b11 & b12);
-    a[11] = b11 ^ (~b12 & b13);
-    a[12] = b12 ^ (~b13 & b14);
-    a[13] = b13 ^ (~b14 & b10);
-    a[14] = b14 ^ (~b10 & b11);
-    a[15] = b15 ^ (~b16 & b17);
-    a[16] = b16 ^ (~b17 & b18);
-    a[17] = b17 ^ (~b18 & b19);
-    a[18] = b18 ^ (~b19 & b15);
-    a[19] = b19 ^ (~b15 & b16);
-    a[20] = b20 ^ (~b21 & b22);
-    a[21] = b21 ^ (~b22 & b23);
-    a[22] = b22 ^ (~b23 & b24);
-    a[23] = b23 ^ (~b24 & b20);
-    a[24] = b24 ^ (~b20 & b21);
-    a[0] ^= KECCAK_RC[rnd];
+    const KW c0 = kw_xor3(kw_xor3(a[0], a[5], a[10]), a[15], a[20]);
+    const KW c1 = kw_xor3(kw_xor3(a[1], a[6], a[11]), a[16], a[21]);
+    const KW c2 = kw_xor3(kw_xor3(a[2], a[7], a[12]), a[17], a[22]);
+    const KW c3 = kw_xor3(kw_xor3(a[3], a[8], a[13]), a[18], a[23]);
+    const KW c4 = kw_xor3(kw_xor3(a[4], a[9], a[14]), a[19], a[24]);
+    const KW d0 = kw_xor(c4, kw_rot<1>(c1)), d1 = kw_xor(c0, kw_rot<1>(c2)), d2 = kw_xor(c1, kw_rot<1>(c3));
+    const KW d3 = kw_xor(c2, kw_rot<1>(c4)), d4 = kw_xor(c3, kw_rot<1>(c0));
+    const KW b0 = kw_rot<0>(kw_xor(a[0], d0)), b16 = kw_rot<36>(kw_xor(a[5], d0)), b7 = kw_rot<3>(kw_xor(a[10], d0));
+    const KW b23 = kw_rot<41>(kw_xor(a[15], d0)), b14 = kw_rot<18>(kw_xor(a[20], d0));
+    const KW b10 = kw_rot<1>(kw_xor(a[1], d1)), b1 = kw_rot<44>(kw_xor(a[6], d1)), b17 = kw_rot<10>(kw_xor(a[11], d1));
+    const KW b8 = kw_rot<45>(kw_xor(a[16], d1)), b24 = kw_rot<2>(kw_xor(a[21], d1));
+    const KW b20 = kw_rot<62>(kw_xor(a[2], d2)), b11 = kw_rot<6>(kw_xor(a[7], d2)), b2 = kw_rot<43>(kw_xor(a[12], d2));
+    const KW b18 = kw_rot<15>(kw_xor(a[17], d2)), b9 = kw_rot<61>(kw_xor(a[22], d2));
+    const KW b5 = kw_rot<28>(kw_xor(a[3], d3)), b21 = kw_rot<55>(kw_xor(a[8], d3)), b12 = kw_rot<25>(kw_xor(a[13], d3));
+    const KW b3 = kw_rot<21>(kw_xor(a[18], d3)), b19 = kw_rot<56>(kw_xor(a[23], d3));
+    const KW b15 = kw_rot<27>(kw_xor(a[4], d4)), b6 = kw_rot<20>(kw_xor(a[9], d4)), b22 = kw_rot<39>(kw_xor(a[14], d4));
+    const KW b13 = kw_rot<8>(kw_xor(a[19], d4)), b4 = kw_rot<14>(kw_xor(a[24], d4));
+    a[0] = kw_chi(b0, b1, b2); a[1] = kw_chi(b1, b2, b3); a[2] = kw_chi(b2, b3, b4); a[3] = kw_chi(b3, b4, b0); a[4] = kw_chi(b4, b0, b1);
+    a[5] = kw_chi(b5, b6, b7); a[6] = kw_chi(b6, b7, b8); a[7] = kw_chi(b7, b8, b9); a[8] = kw_chi(b8, b9, b5); a[9] = kw_chi(b9, b5, b6);
+    a[10] = kw_chi(b10, b11, b12); a[11] = kw_chi(b11, b12, b13); a[12] = kw_chi(b12, b13, b14); a[13] = kw_chi(b13, b14, b10); a[14] = kw_chi(b14, b10, b11);
+    a[15] = kw_chi(b15, b16, b17); a[16] = kw_chi(b16, b17, b18); a[17] = kw_chi(b17, b18, b19); a[18] = kw_chi(b18, b19, b15); a[19] = kw_chi(b19, b15, b16);
+    a[20] = kw_chi(b20, b21, b22); a[21] = kw_chi(b21, b22, b23); a[22] = kw_chi(b22, b23, b24); a[23] = kw_chi(b23, b24, b20); a[24] = kw_chi(b24, b20, b21);
+    const u64 rc = KECCAK_RC[rnd];
+    a[0].lo ^= (u32)rc;
+    a[0].hi ^= (u32)(rc >> 32);
   }
+#pragma unroll
+  for (int i = 0; i < 25; i++) st[i] = ((u64)a[i].hi << 32) | a[i].lo;
 }
 
 constexpr int SHA3_RATE = 136;
