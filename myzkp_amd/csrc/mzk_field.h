@@ -568,130 +568,131 @@ template <class P> MZK_HD Fe<P> fe_inv_serial(const Fe<P>& a) {
   return fe_mul<P>(fe_unpack<P>(r), r3);
 }
 
-// ---- inverse by safegcd (Bernstein-Yang divsteps), 62 divsteps per batch ---------------------------------
+// ---- inverse by safegcd (Bernstein-Yang divsteps), 30 divsteps per batch ---------------------------------
 // The single-lane tails (one inversion ends every MSM / fold) are pure latency, and both other inversions are
 // long dependent chains (Fermat: ~380 dependent products; binary Euclid: ~760 dependent multi-word steps).
-// Divsteps work on the LOW 64 bits of f, g for 62 steps, collect the steps in a 2x2 integer matrix and apply it
-// to the full-width f, g and to the cofactors d, e once per batch: ~10 batches for a 254-bit modulus.
-// Signed 62-bit limbs (5 of them hold up to 310 bits), variable time (ctz skips zero runs): single lane only.
+// Divsteps work on the LOW 32 bits of f, g for 30 steps, collect the steps in a 2x2 integer matrix and apply it
+// to the full-width f, g and to the cofactors d, e once per batch: ~20 batches for a 254-bit modulus.
+// Signed 30-bit limbs and 32-bit matrix entries, so that every product of the batch updates is one
+// v_mad_i64_i32 on this 32-bit ALU (round 1 used 62-bit limbs and __int128 products -- about sixteen instructions
+// each here: ~2.4 x the instructions for the same inversion).  Variable time (ctz skips zero runs): single lane only.
 // Invariants: d x == f, e x == g (mod p) up to the common power of two that the batch update divides out
-// with the p^-1 mod 2^62 trick; d, e stay in (-2p, p).
-struct Sgn62 { int64_t v[5]; };
-struct DivMat { int64_t u, v, q, r; };
-typedef __int128 i128;
-MZK_HD int sg_ctz64(uint64_t x) { return __builtin_ctzll(x); }
-MZK_HD int64_t sg_divsteps_62(int64_t eta, uint64_t f0, uint64_t g0, DivMat* t) {
-  uint64_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0, m;
-  uint32_t w;
-  int i = 62;
+// with the p^-1 mod 2^30 trick; d, e stay in (-2p, p).
+template <int NL> struct Sgn30 { i32 v[NL]; };
+struct DivMat { i32 u, v, q, r; };
+MZK_HD int sg_ctz32(u32 x) { return __builtin_ctz(x); }
+MZK_HD i32 sg_divsteps_30(i32 eta, u32 f0, u32 g0, DivMat* t) {
+  u32 u = 1, v = 0, q = 0, r = 1, f = f0, g = g0, m, w;
+  int i = 30;
   for (;;) {
-    const int zeros = sg_ctz64(g | (~(uint64_t)0 << i));
+    const int zeros = sg_ctz32(g | (~(u32)0 << i));
     g >>= zeros; u <<= zeros; v <<= zeros; eta -= zeros; i -= zeros;
     if (i == 0) break;
     // f and g odd here
     if (eta < 0) {
-      uint64_t tmp;
+      u32 tmp;
       eta = -eta;
-      tmp = f; f = g; g = (uint64_t)0 - tmp;
-      tmp = u; u = q; q = (uint64_t)0 - tmp;
-      tmp = v; v = r; r = (uint64_t)0 - tmp;
-      const int limit = ((int)eta + 1) > i ? i : ((int)eta + 1);     // up to 6 steps at once: w = -g / f mod 2^limit
-      m = (~(uint64_t)0 >> (64 - limit)) & 63u;
-      w = (uint32_t)((f * g * (f * f - 2)) & m);
+      tmp = f; f = g; g = (u32)0 - tmp;
+      tmp = u; u = q; q = (u32)0 - tmp;
+      tmp = v; v = r; r = (u32)0 - tmp;
+      const int limit = (eta + 1) > i ? i : (eta + 1);     // up to 6 steps at once: w = -g / f mod 2^limit
+      m = (~(u32)0 >> (32 - limit)) & 63u;
+      w = (f * g * (f * f - 2)) & m;
     } else {
-      const int limit = ((int)eta + 1) > i ? i : ((int)eta + 1);     // up to 4 steps at once
-      m = (~(uint64_t)0 >> (64 - limit)) & 15u;
-      w = (uint32_t)(f + (((f + 1) & 4) << 1));
-      w = (uint32_t)(((uint64_t)0 - (uint64_t)w) * g & m);
+      const int limit = (eta + 1) > i ? i : (eta + 1);     // up to 4 steps at once
+      m = (~(u32)0 >> (32 - limit)) & 15u;
+      w = f + (((f + 1) & 4) << 1);
+      w = (((u32)0 - w) * g) & m;
     }
     g += f * w; q += u * w; r += v * w;
   }
-  t->u = (int64_t)u; t->v = (int64_t)v; t->q = (int64_t)q; t->r = (int64_t)r;
+  t->u = (i32)u; t->v = (i32)v; t->q = (i32)q; t->r = (i32)r;
   return eta;
 }
-// (f, g) <- t (f, g) / 2^62  (exact)
-MZK_HD void sg_update_fg(Sgn62* f, Sgn62* g, const DivMat* t) {
-  const uint64_t M62 = ~(uint64_t)0 >> 2;
+// (f, g) <- t (f, g) / 2^30  (exact)
+template <int NL> MZK_HD void sg_update_fg(Sgn30<NL>* f, Sgn30<NL>* g, const DivMat* t) {
+  const i32 M30 = (i32)(~(u32)0 >> 2);
   const int64_t u = t->u, v = t->v, q = t->q, r = t->r;
-  i128 cf = (i128)u * f->v[0] + (i128)v * g->v[0];
-  i128 cg = (i128)q * f->v[0] + (i128)r * g->v[0];
-  cf >>= 62; cg >>= 62;
+  int64_t cf = u * f->v[0] + v * g->v[0];
+  int64_t cg = q * f->v[0] + r * g->v[0];
+  cf >>= 30; cg >>= 30;
 #pragma unroll
-  for (int i = 1; i < 5; i++) {
-    cf += (i128)u * f->v[i] + (i128)v * g->v[i];
-    cg += (i128)q * f->v[i] + (i128)r * g->v[i];
-    f->v[i - 1] = (int64_t)((uint64_t)cf & M62); cf >>= 62;
-    g->v[i - 1] = (int64_t)((uint64_t)cg & M62); cg >>= 62;
+  for (int i = 1; i < NL; i++) {
+    cf += u * f->v[i] + v * g->v[i];
+    cg += q * f->v[i] + r * g->v[i];
+    f->v[i - 1] = (i32)cf & M30; cf >>= 30;
+    g->v[i - 1] = (i32)cg & M30; cg >>= 30;
   }
-  f->v[4] = (int64_t)cf;
-  g->v[4] = (int64_t)cg;
+  f->v[NL - 1] = (i32)cf;
+  g->v[NL - 1] = (i32)cg;
 }
-// (d, e) <- t (d, e) / 2^62 mod p, result again in (-2p, p)
-MZK_HD void sg_update_de(Sgn62* d, Sgn62* e, const DivMat* t, const Sgn62* mod, uint64_t pinv62) {
-  const uint64_t M62 = ~(uint64_t)0 >> 2;
+// (d, e) <- t (d, e) / 2^30 mod p, result again in (-2p, p)
+template <int NL> MZK_HD void sg_update_de(Sgn30<NL>* d, Sgn30<NL>* e, const DivMat* t, const Sgn30<NL>* mod, u32 pinv30) {
+  const i32 M30 = (i32)(~(u32)0 >> 2);
   const int64_t u = t->u, v = t->v, q = t->q, r = t->r;
-  const int64_t sd = d->v[4] >> 63, se = e->v[4] >> 63;
-  int64_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
-  i128 cd = (i128)u * d->v[0] + (i128)v * e->v[0];
-  i128 ce = (i128)q * d->v[0] + (i128)r * e->v[0];
-  md -= (int64_t)((pinv62 * (uint64_t)cd + (uint64_t)md) & M62);
-  me -= (int64_t)((pinv62 * (uint64_t)ce + (uint64_t)me) & M62);
-  cd += (i128)mod->v[0] * md;
-  ce += (i128)mod->v[0] * me;
-  cd >>= 62; ce >>= 62;
+  const i32 sd = d->v[NL - 1] >> 31, se = e->v[NL - 1] >> 31;
+  i32 md = (t->u & sd) + (t->v & se), me = (t->q & sd) + (t->r & se);
+  int64_t cd = u * d->v[0] + v * e->v[0];
+  int64_t ce = q * d->v[0] + r * e->v[0];
+  md -= (i32)((pinv30 * (u32)cd + (u32)md) & (u32)M30);
+  me -= (i32)((pinv30 * (u32)ce + (u32)me) & (u32)M30);
+  cd += (int64_t)mod->v[0] * md;
+  ce += (int64_t)mod->v[0] * me;
+  cd >>= 30; ce >>= 30;
 #pragma unroll
-  for (int i = 1; i < 5; i++) {
-    cd += (i128)u * d->v[i] + (i128)v * e->v[i] + (i128)mod->v[i] * md;
-    ce += (i128)q * d->v[i] + (i128)r * e->v[i] + (i128)mod->v[i] * me;
-    d->v[i - 1] = (int64_t)((uint64_t)cd & M62); cd >>= 62;
-    e->v[i - 1] = (int64_t)((uint64_t)ce & M62); ce >>= 62;
+  for (int i = 1; i < NL; i++) {
+    cd += u * d->v[i] + v * e->v[i] + (int64_t)mod->v[i] * md;
+    ce += q * d->v[i] + r * e->v[i] + (int64_t)mod->v[i] * me;
+    d->v[i - 1] = (i32)cd & M30; cd >>= 30;
+    e->v[i - 1] = (i32)ce & M30; ce >>= 30;
   }
-  d->v[4] = (int64_t)cd;
-  e->v[4] = (int64_t)ce;
+  d->v[NL - 1] = (i32)cd;
+  e->v[NL - 1] = (i32)ce;
 }
 // r in (-2p, p), sign < 0 -> negate; result in [0, p)
-MZK_HD void sg_normalize(Sgn62* r, int64_t sign, const Sgn62* mod) {
-  const int64_t M62 = (int64_t)(~(uint64_t)0 >> 2);
-  int64_t c[5];
-  int64_t add = r->v[4] >> 63;
+template <int NL> MZK_HD void sg_normalize(Sgn30<NL>* r, i32 sign, const Sgn30<NL>* mod) {
+  const i32 M30 = (i32)(~(u32)0 >> 2);
+  i32 c[NL];
+  i32 add = r->v[NL - 1] >> 31;
 #pragma unroll
-  for (int i = 0; i < 5; i++) c[i] = r->v[i] + (mod->v[i] & add);
-  const int64_t neg = sign >> 63;
+  for (int i = 0; i < NL; i++) c[i] = r->v[i] + (mod->v[i] & add);
+  const i32 neg = sign >> 31;
 #pragma unroll
-  for (int i = 0; i < 5; i++) c[i] = (c[i] ^ neg) - neg;
+  for (int i = 0; i < NL; i++) c[i] = (c[i] ^ neg) - neg;
 #pragma unroll
-  for (int i = 0; i < 4; i++) { c[i + 1] += c[i] >> 62; c[i] &= M62; }
-  add = c[4] >> 63;
+  for (int i = 0; i < NL - 1; i++) { c[i + 1] += c[i] >> 30; c[i] &= M30; }
+  add = c[NL - 1] >> 31;
 #pragma unroll
-  for (int i = 0; i < 5; i++) c[i] += mod->v[i] & add;
+  for (int i = 0; i < NL; i++) c[i] += mod->v[i] & add;
 #pragma unroll
-  for (int i = 0; i < 4; i++) { c[i + 1] += c[i] >> 62; c[i] &= M62; }
+  for (int i = 0; i < NL - 1; i++) { c[i + 1] += c[i] >> 30; c[i] &= M30; }
 #pragma unroll
-  for (int i = 0; i < 5; i++) r->v[i] = c[i];
+  for (int i = 0; i < NL; i++) r->v[i] = c[i];
 }
-template <int NW> MZK_HD void sg_from_words(const u32* w, Sgn62* o) {   // NW u32 words (<= 8) -> 62-bit limbs
-  uint64_t x[5] = {0, 0, 0, 0, 0};   // 64-bit words
+template <int NW, int NL> MZK_HD void sg_from_words(const u32* w, Sgn30<NL>* o) {   // NW u32 words -> 30-bit limbs
 #pragma unroll
-  for (int i = 0; i < NW; i++) x[i >> 1] |= (uint64_t)w[i] << (32 * (i & 1));
-  const uint64_t M62 = ~(uint64_t)0 >> 2;
-  o->v[0] = (int64_t)(x[0] & M62);
-  o->v[1] = (int64_t)(((x[0] >> 62) | (x[1] << 2)) & M62);
-  o->v[2] = (int64_t)(((x[1] >> 60) | (x[2] << 4)) & M62);
-  o->v[3] = (int64_t)(((x[2] >> 58) | (x[3] << 6)) & M62);
-  o->v[4] = (int64_t)((x[3] >> 56) | (x[4] << 8));
+  for (int i = 0; i < NL; i++) {
+    const int bit = 30 * i, k = bit >> 5, sh = bit & 31;
+    u64 x = (k < NW) ? w[k] : 0u;
+    if (k + 1 < NW) x |= (u64)w[k + 1] << 32;
+    o->v[i] = (i32)((u32)(x >> sh) & (~(u32)0 >> 2));
+  }
 }
-template <int NW> MZK_HD void sg_to_words(const Sgn62* a, u32* w) {     // canonical value in [0, p) back to u32 words
-  const uint64_t a0 = (uint64_t)a->v[0], a1 = (uint64_t)a->v[1], a2 = (uint64_t)a->v[2], a3 = (uint64_t)a->v[3], a4 = (uint64_t)a->v[4];
-  uint64_t x[4];
-  x[0] = a0 | (a1 << 62);
-  x[1] = (a1 >> 2) | (a2 << 60);
-  x[2] = (a2 >> 4) | (a3 << 58);
-  x[3] = (a3 >> 6) | (a4 << 56);
+template <int NW, int NL> MZK_HD void sg_to_words(const Sgn30<NL>* a, u32* w) {     // canonical value in [0, p) back to u32 words
 #pragma unroll
-  for (int i = 0; i < NW; i++) w[i] = (u32)(x[i >> 1] >> (32 * (i & 1)));
+  for (int k = 0; k < NW; k++) {
+    // word k = bits [32k, 32k+32): from limb i = 32k / 30 (and the next one or two)
+    const int bit = 32 * k, i = bit / 30, sh = bit - 30 * i;
+    u64 x = (u64)(u32)a->v[i];
+    if (i + 1 < NL) x |= (u64)(u32)a->v[i + 1] << 30;
+    if (i + 2 < NL) x |= (u64)(u32)a->v[i + 2] << 60;
+    w[k] = (u32)(x >> sh);
+  }
 }
 template <class P> MZK_HD Fe<P> fe_inv_safegcd(const Fe<P>& a) {
   constexpr int NW = P::NW;
+  constexpr int NL = (32 * NW + 29) / 30 + 0;      // 9 limbs for 256 bits, 5 for 128: the top limb carries the sign
+  static_assert(30 * NL >= P::BITS + 2, "signed 30-bit limbs must hold values in (-2p, p)");
   u32 xw[NW], pw[NW];
   {
     Fe<P> c = fe_reduce<P>(a);
@@ -700,29 +701,32 @@ template <class P> MZK_HD Fe<P> fe_inv_safegcd(const Fe<P>& a) {
   }
 #pragma unroll
   for (int i = 0; i < NW; i++) pw[i] = P::PW[i];
-  Sgn62 mod, f, g, d, e;
-  sg_from_words<NW>(pw, &mod);
-  sg_from_words<NW>(xw, &g);
+  Sgn30<NL> mod, f, g, d, e;
+  sg_from_words<NW, NL>(pw, &mod);
+  sg_from_words<NW, NL>(xw, &g);
   f = mod;
 #pragma unroll
-  for (int i = 0; i < 5; i++) { d.v[i] = 0; e.v[i] = 0; }
+  for (int i = 0; i < NL; i++) { d.v[i] = 0; e.v[i] = 0; }
   e.v[0] = 1;
-  // p^-1 mod 2^62 by Newton from p0 (p odd: p0 * p0 == 1 mod 8)
-  uint64_t pinv = (uint64_t)mod.v[0];
+  // p^-1 mod 2^30 by Newton from p0 (p odd: p0 * p0 == 1 mod 8)
+  u32 pinv = (u32)mod.v[0];
 #pragma unroll
-  for (int it = 0; it < 5; it++) pinv *= 2 - (uint64_t)mod.v[0] * pinv;
-  pinv &= ~(uint64_t)0 >> 2;
-  int64_t eta = -1;
-  for (int batch = 0; batch < 16; batch++) {       // 12 batches bound 254-bit inputs; g == 0 ends it (~9-10)
+  for (int it = 0; it < 4; it++) pinv *= 2 - (u32)mod.v[0] * pinv;
+  pinv &= ~(u32)0 >> 2;
+  i32 eta = -1;
+  for (int batch = 0; batch < 32; batch++) {       // 25 batches bound 254-bit inputs; g == 0 ends it (~19-20)
     DivMat t;
-    eta = sg_divsteps_62(eta, (uint64_t)f.v[0], (uint64_t)g.v[0], &t);
-    sg_update_de(&d, &e, &t, &mod, pinv);
-    sg_update_fg(&f, &g, &t);
-    if ((g.v[0] | g.v[1] | g.v[2] | g.v[3] | g.v[4]) == 0) break;
+    eta = sg_divsteps_30(eta, (u32)f.v[0], (u32)g.v[0], &t);
+    sg_update_de<NL>(&d, &e, &t, &mod, pinv);
+    sg_update_fg<NL>(&f, &g, &t);
+    i32 gz = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) gz |= g.v[i];
+    if (gz == 0) break;
   }
-  sg_normalize(&d, f.v[4], &mod);                   // f = +-1, d = +-x^-1
+  sg_normalize<NL>(&d, f.v[NL - 1], &mod);           // f = +-1, d = +-x^-1
   u32 rw[NW];
-  sg_to_words<NW>(&d, rw);
+  sg_to_words<NW, NL>(&d, rw);
   // rw = (aR)^-1 = a^-1 R^-1 (plain words); Montgomery form of a^-1 is a^-1 R = mont(rw, R^3)
   Fe<P> r3;
 #pragma unroll
