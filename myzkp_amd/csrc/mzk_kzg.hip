@@ -133,7 +133,7 @@ __global__ __launch_bounds__(128) void k_fb_powers(Words8k alpha_plain, const u3
     ld8(table + 16 * idx, tw);
     ld8(table + 16 * idx + 8, tw + 8);
     if (affine_words_is_inf(tw)) continue;
-    acc = xyzz_madd(acc, affine_load_mont(tw));
+    acc = xyzz_madd_with<FeAsm>(acc, affine_load_mont(tw));
   }
   u32 o[32];
   xyzz_store(acc, o);
