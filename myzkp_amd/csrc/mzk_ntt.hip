@@ -358,8 +358,8 @@ __global__ void k_coset_scale_pad(const u32* __restrict__ coef, size_t n_coef, W
   for (int i = 0; i < GEN_CHUNK && j0 + i < order; i++) {
     if (j0 + i < n_coef) {
       Fe<P> c = gload<P>(coef, j0 + i);
-      gstore<P>(out, j0 + i, fe_reduce<P>(fe_mul<P>(c, cur)));
-      cur = fe_mul<P>(cur, g);
+      gstore<P>(out, j0 + i, fe_reduce<P>(FeAsm<P>::mul(c, cur)));
+      cur = FeAsm<P>::mul(cur, g);
     } else {
       gstore<P>(out, j0 + i, fe_zero<P>());
     }
@@ -704,14 +704,14 @@ __global__ void k_fri_fold(const u32* __restrict__ cw, size_t h, Words8 r0_mont,
   const size_t i0 = chunk * GEN_CHUNK;
   if (i0 >= h) return;
   const Fe<P> winv = fe_unpack<P>(winv_mont.w), half = fe_unpack<P>(half_mont.w);
-  Fe<P> r = fe_mul<P>(fe_unpack<P>(r0_mont.w), fe_pow_u64<P>(winv, i0));   // r_{i0}, Montgomery form
+  Fe<P> r = FeAsm<P>::mul(fe_unpack<P>(r0_mont.w), fe_pow_u64<P>(winv, i0));   // r_{i0}, Montgomery form
   for (int t = 0; t < GEN_CHUNK && i0 + t < h; t++) {
     const Fe<P> a = gload<P>(cw, i0 + t), b = gload<P>(cw, h + i0 + t);     // canonical, plain domain
     const Fe<P> sum = fe_add<P>(a, b);                                       // < 2p, limbs < 2^30
     const Fe<P> dif = fe_carry<P>(fe_sub<P, 4>(a, b));                       // a - b + 4p
-    const Fe<P> o = fe_add<P>(fe_mul<P>(sum, half), fe_mul<P>(dif, r));      // plain * Montgomery constant = plain
+    const Fe<P> o = fe_add<P>(FeAsm<P>::mul(sum, half), FeAsm<P>::mul(dif, r));      // plain * Montgomery constant = plain
     gstore<P>(out, i0 + t, fe_reduce<P>(o));                                 // .sanitize()
-    r = fe_mul<P>(r, winv);
+    r = FeAsm<P>::mul(r, winv);
   }
 }
 int fri_fold_dev_impl(int fid, const void* d_cw, size_t n, const uint64_t* alpha, const uint64_t* offset, const uint64_t* omega,
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(128) void k_pointwise_div(const u32* __restrict__ a
       pre[j] = run;                                          // product of the earlier non-zero denominators (Montgomery)
       Fe<P> ym = fe_to_mont<P>(y);
       if (fe_is_zero_canon<P>(y)) ym = fe_one<P>();
-      run = fe_mul<P>(run, ym);
+      run = FeAsm<P>::mul(run, ym);
     }
   }
   Fe<P> inv = fe_inv<P>(run);
@@ -768,12 +768,12 @@ __global__ __launch_bounds__(128) void k_pointwise_div(const u32* __restrict__ a
     {
       const Fe<P> y = gload<P>(b, i0 + j);
       const bool zero = fe_is_zero_canon<P>(y);
-      const Fe<P> yinv = fe_mul<P>(inv, pre[j]);             // Montgomery form of 1 / y_j
+      const Fe<P> yinv = FeAsm<P>::mul(inv, pre[j]);             // Montgomery form of 1 / y_j
       Fe<P> ym = fe_to_mont<P>(y);
       if (zero) ym = fe_one<P>();
-      inv = fe_mul<P>(inv, ym);
+      inv = FeAsm<P>::mul(inv, ym);
       const Fe<P> x = gload<P>(a, i0 + j);
-      const Fe<P> q = fe_reduce<P>(fe_mul<P>(x, yinv));       // plain * Montgomery = plain
+      const Fe<P> q = fe_reduce<P>(FeAsm<P>::mul(x, yinv));       // plain * Montgomery = plain
       gstore<P>(out, i0 + j, zero ? fe_zero<P>() : q);
     }
   }
