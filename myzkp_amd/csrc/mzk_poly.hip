@@ -22,6 +22,7 @@
 //     P_parent = X^D (P_l + P_r) + P_l Z_r' + P_r Z_l'.
 #include <vector>
 #include "mzk_common.h"
+#include "mzk_field_asm.h"
 
 namespace mzk {
 
@@ -42,7 +43,7 @@ template <class P> __device__ __forceinline__ void pl_store(u32* __restrict__ g,
   for (int q = 0; q < P::NW / 4; q++) p4[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
 }
 // plain-domain helpers: canonical in, canonical out
-template <class P> __device__ __forceinline__ Fe<P> pl_mul(const Fe<P>& x, const Fe<P>& y) { return fe_reduce<P>(fe_mul<P>(fe_mul<P>(x, y), fe_r2<P>())); }
+template <class P> __device__ __forceinline__ Fe<P> pl_mul(const Fe<P>& x, const Fe<P>& y) { return fe_reduce<P>(FeAsm<P>::mul(FeAsm<P>::mul(x, y), fe_r2<P>())); }
 template <class P> __device__ __forceinline__ Fe<P> pl_add(const Fe<P>& x, const Fe<P>& y) { return fe_reduce<P>(fe_carry<P>(fe_add<P>(x, y))); }
 template <class P> __device__ __forceinline__ Fe<P> pl_sub(const Fe<P>& x, const Fe<P>& y) { return fe_reduce<P>(fe_carry<P>(fe_sub<P, 2>(x, y))); }
 template <class P> __device__ __forceinline__ Fe<P> pl_one() { Fe<P> r = fe_zero<P>(); r.l[0] = 1; return r; }
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(64) void k_chunk_zerofier(const u32* __restrict__ d
     const Fe<P> di = shfl_fe<P>(d, i);
     Fe<P> up = shfl_up1_fe<P>(c);
     if (lane == 0) up = fe_zero<P>();
-    c = pl_sub<P>(up, fe_reduce<P>(fe_mul<P>(c, di)));
+    c = pl_sub<P>(up, fe_reduce<P>(FeAsm<P>::mul(c, di)));
   }
   pl_store<P>(low, idx, c);
 }
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(64) void k_chunk_eval(const u32* __restrict__ domai
   Fe<P> q = pl_one<P>();
   Fe<P> acc = pl_load<P>(sh_t, 0);
   for (int k = 1; k < CHUNK; k++) {
-    q = pl_add<P>(pl_load<P>(sh_z, CHUNK - k), fe_reduce<P>(fe_mul<P>(q, x)));
+    q = pl_add<P>(pl_load<P>(sh_z, CHUNK - k), fe_reduce<P>(FeAsm<P>::mul(q, x)));
     acc = pl_add<P>(acc, pl_mul<P>(pl_load<P>(sh_t, k), q));
   }
   if (idx < out_n) pl_store<P>(out, idx, acc);
@@ -267,10 +268,10 @@ __global__ __launch_bounds__(64) void k_chunk_combine(const u32* __restrict__ do
   Fe<P> q = pl_one<P>();
   Fe<P> mine = fe_zero<P>();
   for (int k = CHUNK - 1; k >= 0; k--) {
-    Fe<P> term = fe_reduce<P>(fe_mul<P>(q, wi));
+    Fe<P> term = fe_reduce<P>(FeAsm<P>::mul(q, wi));
     for (int m = 1; m < 64; m <<= 1) term = pl_add<P>(term, shfl_xor_fe<P>(term, m));
     if (lane == k) mine = term;
-    if (k > 0) q = pl_add<P>(pl_load<P>(sh_z, k), fe_reduce<P>(fe_mul<P>(q, x)));
+    if (k > 0) q = pl_add<P>(pl_load<P>(sh_z, k), fe_reduce<P>(FeAsm<P>::mul(q, x)));
   }
   pl_store<P>(out0, idx, mine);
 }
