@@ -593,7 +593,13 @@ def main():
             for record in (False, True):
                 stage("commit_and_open_overlapped", commit_and_open, record)
             overlapped_ms = stages.pop("commit_and_open_overlapped")
-            overlapped_same = bool(torch.equal(rec_c2, rec_c) and torch.equal(rec_w2, rec_w))
+            # partial records are XYZZ (projective: the entry order inside a bucket comes from atomics, so the representation of
+            # the same point differs from run to run): compare the canonical affine points
+            aff = torch.zeros(4 * 8, dtype=torch.int64, device=dev)
+            for k, r in enumerate((rec_c, rec_c2, rec_w, rec_w2)):
+                check(L.mzk_g1_fold_partials_dev(dptr(r), ctypes.c_int(1), ctypes.c_void_p(aff.data_ptr() + 64 * k), stream))
+            torch.cuda.synchronize()
+            overlapped_same = bool(torch.equal(aff[0:8], aff[8:16]) and torch.equal(aff[16:24], aff[24:32]))
         except Exception as ex:
             err = str(ex)[:300]
         # every rank reaches this point; only fold if all local stages succeeded everywhere
