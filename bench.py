@@ -409,12 +409,12 @@ def main():
     srs_roof["kernel"] = "k_seg_accumulate"
     srs_roof["measured"] = "HIP-event pair around the kernel on its launch stream, inside the timed region (the only instrumented kernel there)"
     if args.log2n == 20:
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r02b_hbm_traffic_pmc.txt: per launch of
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r02o_hbm_traffic_pmc.txt: per launch of
         # k_seg_accumulate at 2^20 pairs, raw counters (64-byte random gathers: the gfx950 x2 FETCH_SIZE correction for wide
         # coalesced streams is not applied; with it the figure doubles).  The fixed-base method reads each of the 16 table
         # points of a pair once (16 x 64 B = 1.07 GB); the 128-byte fetch granule doubles that.  Served by L2 / Infinity Cache.
-        srs_roof["traffic"] = (2023380 + 49023) * 1024
-        srs_roof["traffic_source"] = "profiles/r02b_hbm_traffic_pmc.txt (recorded rocprofv3 --pmc passes of this bench command, not collected by this run)"
+        srs_roof["traffic"] = (2065355 + 59442) * 1024
+        srs_roof["traffic_source"] = "profiles/r02o_hbm_traffic_pmc.txt (recorded rocprofv3 --pmc passes of the same kernel at the same size, tools/gpu_jobs/r02o.sh; not collected by this run)"
     srs_roof["algorithmic_bytes_per_launch"] = 96 * n
     alu["kzg_commit_accumulate_frac"] = msm_mads / (srs_acc_ms * 1e-3) / MAD_PEAK_PER_S if srs_acc_ms == srs_acc_ms else None
     out = {
