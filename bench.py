@@ -361,6 +361,36 @@ def main():
     # Reported beside `value`, which stays one commit at a time.
     pipelined = run_in_flight(2)
     pipelined4 = run_in_flight(4)
+
+    def run_other_width(c):
+        """The same commit against a handle with c-bit windows (mzk_srs_from_device_ex): `value` stays at the 16 bits BASELINE
+        configs[2] names; this is what the width knob is worth at this size."""
+        if world != 1 or args.no_two_in_flight:
+            return None
+        hw = ctypes.c_void_p()
+        try:
+            check(L.mzk_srs_from_device_ex(dptr(points), ctypes.c_size_t(n), ctypes.c_int(c), ctypes.byref(hw), stream))
+            outw = torch.zeros(8, dtype=torch.int64, device=dev)
+
+            def stepw():
+                check(L.mzk_kzg_commit_srs_dev(hw, dptr(scalars), ctypes.c_size_t(n), dptr(outw), ctypes.c_int(0), stream))
+            for _ in range(max(W, 2)):
+                stepw()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                stepw()
+            torch.cuda.synchronize()
+            dtw = (time.perf_counter() - t0) / K
+            return {"window_bits": c, "tables": 254 // c + 1, "ms_per_step": dtw * 1e3, "value": n / dtw, "unit": "pairs/s",
+                    "same_point_as_16_bit_windows": bool(torch.equal(outw, result_srs))}
+        except Exception as ex:
+            return {"error": str(ex)[:300]}
+        finally:
+            if hw:
+                L.mzk_srs_free(hw)
+            torch.cuda.empty_cache()
+    width17 = run_other_width(17) if args.log2n >= 20 else None
     progress("timed legs done")
     msm_ms = msm_dt / K * 1e3
     ntt_ms = ntt_dt / K * 1e3
@@ -438,6 +468,7 @@ def main():
                            "note": "table build is outside the timed region; one KZG setup is followed by many commits/opens against the same powers_1 (kzg.rs:57-72)"},
         "kzg_commit_two_in_flight": pipelined,
         "kzg_commit_four_in_flight": pipelined4,
+        "kzg_commit_17_bit_windows": width17,
         "msm_generic": {"metric": "G1 MSM pairs/sec, arbitrary points every call (no per-point-set precomputation; 16 bucket sets + window Horner)",
                         "value": msm_rate, "unit": "pairs/s", "ms_per_step": msm_ms, "phases": msm_ph, "roofline": roof},
         "ntt": {"metric": "NTT elems/sec", "value": ntt_rate, "unit": "elems/s", "ms_per_step": ntt_ms, "field": "BN254 Fr",
