@@ -391,6 +391,47 @@ def main():
                 L.mzk_srs_free(hw)
             torch.cuda.empty_cache()
     width17 = run_other_width(17) if args.log2n >= 20 else None
+
+    def run_ntt_batched():
+        """Many transforms per call (mzk_ntt_batch_dev): a prover interpolates / extends every column of a trace, and a batch
+        gives the kernels several rounds of workgroups per CU, i.e. loads and stores under other tiles' butterflies."""
+        if world != 1 or args.no_two_in_flight:
+            return None
+        res = {}
+        try:
+            for lgb, batch in ((args.log2n, 16), (16, 64), (12, 64)):
+                if lgb > args.log2n:
+                    continue
+                nb = 1 << lgb
+                vb = torch.empty(batch * nb * 4, dtype=torch.int64, device=dev)
+                for k in range(batch):
+                    check(L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(SEED + 7000 + k), ctypes.c_size_t(nb), ctypes.c_void_p(vb.data_ptr() + k * nb * 32), stream))
+                ob = torch.empty_like(vb)
+                rb = mz.to_limbs([mz.root_of_unity(mz.FIELD_FR, lgb)], 4)
+
+                def stepb():
+                    check(L.mzk_ntt_batch_dev(mz.FIELD_FR, rb.ctypes.data_as(ctypes.c_void_p), dptr(vb), dptr(ob), ctypes.c_size_t(nb), ctypes.c_size_t(batch), 0, stream))
+                for _ in range(3):
+                    stepb()
+                torch.cuda.synchronize()
+                reps = max(K, 10)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    stepb()
+                torch.cuda.synchronize()
+                dtb = (time.perf_counter() - t0) / reps
+                # row 0 of the batch against the single-transform entry point
+                one = torch.empty(nb * 4, dtype=torch.int64, device=dev)
+                check(L.mzk_ntt_dev(mz.FIELD_FR, rb.ctypes.data_as(ctypes.c_void_p), dptr(vb), dptr(one), ctypes.c_size_t(nb), 0, stream))
+                torch.cuda.synchronize()
+                res["%d x 2^%d" % (batch, lgb)] = {"ms_per_call": dtb * 1e3, "ms_per_transform": dtb * 1e3 / batch, "value": batch * nb / dtb, "unit": "elems/s",
+                                                  "row_0_equals_single_transform": bool(torch.equal(one, ob[:nb * 4]))}
+                del vb, ob, one
+                torch.cuda.empty_cache()
+        except Exception as ex:
+            res["error"] = str(ex)[:300]
+        return res
+    ntt_batched = run_ntt_batched()
     progress("timed legs done")
     msm_ms = msm_dt / K * 1e3
     ntt_ms = ntt_dt / K * 1e3
@@ -469,6 +510,7 @@ def main():
         "kzg_commit_two_in_flight": pipelined,
         "kzg_commit_four_in_flight": pipelined4,
         "kzg_commit_17_bit_windows": width17,
+        "ntt_batched_fr": ntt_batched,
         "msm_generic": {"metric": "G1 MSM pairs/sec, arbitrary points every call (no per-point-set precomputation; 16 bucket sets + window Horner)",
                         "value": msm_rate, "unit": "pairs/s", "ms_per_step": msm_ms, "phases": msm_ph, "roofline": roof},
         "ntt": {"metric": "NTT elems/sec", "value": ntt_rate, "unit": "elems/s", "ms_per_step": ntt_ms, "field": "BN254 Fr",

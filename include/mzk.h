@@ -230,6 +230,13 @@ size_t mzk_srs_len(const mzk_srs* srs);
 /* ---- device-resident variants (inputs already in HBM; `stream` is a hipStream_t) --------------- */
 int mzk_ntt_dev(int field_id, const uint64_t* root_host, const void* d_in, void* d_out, size_t n,
                 int inverse, void* stream);
+/* `batch` transforms of n points each, stored back to back (batch * n elements), all with the same root: what a prover
+ * does column by column in a loop (ntt.rs:7-64 per column; fast_stark.rs interpolates and extends every register) as ONE
+ * launch per pass, so that small transforms fill the GPU (2^12 points: 27 us for one transform, and about the same for
+ * 64 of them).  Results are bit-identical to `batch` single calls.  In place allowed (d_in == d_out). */
+int mzk_ntt_batch(int field_id, const uint64_t* root, const uint64_t* in, uint64_t* out, size_t n, size_t batch, int inverse);
+int mzk_ntt_batch_dev(int field_id, const uint64_t* root, const void* d_in, void* d_out, size_t n, size_t batch, int inverse,
+                      void* stream);
 int mzk_coset_lde_dev(int field_id, const void* d_coef, size_t n_coef, const uint64_t* offset_host,
                       const uint64_t* generator_host, void* d_out, size_t order, void* stream);
 /* d_out_xy: 8 limbs on the device */

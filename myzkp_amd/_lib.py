@@ -148,6 +148,19 @@ def intt(fid, root, values):
     return ntt(fid, root, values, inverse=True)
 
 
+def ntt_batch(fid, root, columns, inverse=False):
+    """ntt::ntt / ntt::intt of every row of `columns` (batch x n x limbs) in one launch per pass: mzk_ntt_batch."""
+    v = np.ascontiguousarray(columns, dtype=np.uint64)
+    batch = v.shape[0]
+    if batch == 0:
+        return v.copy()
+    v = v.reshape(batch, -1, LIMBS[fid])
+    out = np.empty_like(v)
+    r = _one(fid, root)
+    _check(lib().mzk_ntt_batch(fid, _p(r), _p(v), _p(out), ctypes.c_size_t(v.shape[1]), ctypes.c_size_t(batch), int(bool(inverse))))
+    return out
+
+
 def coset_lde(fid, coef, offset, generator, order):
     """ntt::fast_coset_evaluate (algebra/ntt.rs:254-269)."""
     c = _arr(fid, coef)

@@ -434,6 +434,27 @@ int mzk_ntt_dev(int field_id, const uint64_t* root_host, const void* d_in, void*
   return ntt_dev_impl(field_id, root_host, d_in, d_out, n, inverse, nullptr, (hipStream_t)stream);
 }
 
+int mzk_ntt_batch_dev(int field_id, const uint64_t* root_host, const void* d_in, void* d_out, size_t n, size_t batch, int inverse, void* stream) {
+  MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
+  return ntt_batch_dev_impl(field_id, root_host, d_in, d_out, n, batch, inverse, (hipStream_t)stream);
+}
+int mzk_ntt_batch(int field_id, const uint64_t* root, const uint64_t* in, uint64_t* out, size_t n, size_t batch, int inverse) {
+  MZK_TRY(ensure_init());
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("ntt: bad field id %d", field_id); return MZK_E_ARG; }
+  if (n == 0 || batch == 0) return MZK_OK;
+  if (!in || !out) { set_error("ntt: null pointer"); return MZK_E_ARG; }
+  hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
+  const size_t bytes = batch * n * field_bytes(field_id);
+  void* d;
+  MZK_TRY(stage_in(WS_NTT_IO_A, in, bytes, &d, s));
+  MZK_TRY(ntt_batch_dev_impl(field_id, root, d, d, n, batch, inverse, s));
+  MZK_HIP(hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  return MZK_OK;
+}
+
 int mzk_coset_lde(int field_id, const uint64_t* coef, size_t n_coef, const uint64_t* offset, const uint64_t* generator,
                   uint64_t* out, size_t order) {
   MZK_TRY(ensure_init());

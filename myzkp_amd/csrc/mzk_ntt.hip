@@ -66,12 +66,17 @@ typedef Geo<12, 1024, 10> GeoL;
 // Fr 0.147 -> 0.137 ms, M128 0.063 -> 0.056 ms) and 2^25 .. 2^30.  Where both geometries need three passes the small
 // tiles win (2^21 .. 2^24: Fr +8 %, M128 +16 % with large tiles; tools/timing/time_ntt.py with MZK_NTT_LARGE_FR /
 // MZK_NTT_LARGE_M128 = smallest log2 size forced onto the large geometry, 99 = never).
-static bool large_geo(int fid, unsigned logn) {
+// A BATCH of transforms gives the small tiles what a single 2^20 transform lacks: several rounds of workgroups per CU,
+// so the loads and stores of one tile run under the butterflies of its neighbours (four small-tile workgroups share a
+// CU; the large tile owns it) -- from three Fr / two M128 transforms of 2^20 on, three overlapped passes beat two
+// exposed ones (tools/timing/ntt_batch.py: Fr 0.1045 vs 0.1131 ms per transform at batch 16, M128 0.041 vs 0.048).
+static bool large_geo(int fid, unsigned logn, size_t batch = 1) {
   static const int env_fr = getenv("MZK_NTT_LARGE_FR") ? atoi(getenv("MZK_NTT_LARGE_FR")) : -1;
   static const int env_m = getenv("MZK_NTT_LARGE_M128") ? atoi(getenv("MZK_NTT_LARGE_M128")) : -1;
   const int env = fid == MZK_FIELD_M128 ? env_m : env_fr;
   if (env >= 0) return logn >= (unsigned)env && logn >= 14;
   if (logn < 20) return false;
+  if (batch > (fid == MZK_FIELD_M128 ? 1u : 2u)) return false;
   return (logn + 9) / 10 < (logn + MAX_LEVEL_LOG - 1) / MAX_LEVEL_LOG;
 }
 
@@ -380,6 +385,7 @@ struct NttPlan {
   int fid = -1;
   unsigned logn = 0;
   bool inverse = false;
+  bool large = false;                  // tile geometry the level split and the tables were built for (large_geo)
   uint64_t root[4] = {0, 0, 0, 0};     // forward root as passed by the caller
   uint64_t scale[4] = {0, 0, 0, 0};    // extra plain scale folded into the tables (1 if none)
   LevelInfo li{};
@@ -404,14 +410,14 @@ void ntt_release_plans() {
   g_plans.clear();
 }
 
-static LevelInfo choose_levels(unsigned logn, int fid) {
+static LevelInfo choose_levels(unsigned logn, bool large) {
   LevelInfo li{};
   if (logn <= TILE_LOG) {
     li.nlev = 1;
     li.lg[0] = (int)logn;
     return li;
   }
-  const int maxlv = large_geo(fid, logn) ? GeoL::MAXLV : MAX_LEVEL_LOG;
+  const int maxlv = large ? GeoL::MAXLV : MAX_LEVEL_LOG;
   int k = (int)((logn + maxlv - 1) / maxlv);
   li.nlev = k;
   int base = (int)logn / k, extra = (int)logn % k;
@@ -467,12 +473,13 @@ static int build_tables(NttPlan* pl, const uint64_t* eff_root, const uint64_t* f
 }
 
 static int get_plan(int fid, unsigned logn, bool inverse, const uint64_t* root, const uint64_t* extra_scale,
-                    hipStream_t s, NttPlan** out) {
+                    hipStream_t s, NttPlan** out, size_t batch = 1) {
+  const bool large = large_geo(fid, logn, batch);
   const HostField* hf = host_field(fid);
   uint64_t one[4] = {1, 0, 0, 0};
   const uint64_t* sc = extra_scale ? extra_scale : one;
   for (auto* p : g_plans) {
-    if (p->fid == fid && p->logn == logn && p->inverse == inverse && !memcmp(p->root, root, 8 * hf->nl) &&
+    if (p->fid == fid && p->logn == logn && p->inverse == inverse && p->large == large && !memcmp(p->root, root, 8 * hf->nl) &&
         !memcmp(p->scale, sc, 8 * hf->nl)) {
       p->stamp = ++g_stamp;
       *out = p;
@@ -488,10 +495,10 @@ static int get_plan(int fid, unsigned logn, bool inverse, const uint64_t* root, 
   if (h_is_one(hf, t)) { set_error("primitive root is not primitive nth root of unity, where n is len(values)"); return MZK_E_ROOT_PRIM; }
 
   NttPlan* pl = new NttPlan();
-  pl->fid = fid; pl->logn = logn; pl->inverse = inverse;
+  pl->fid = fid; pl->logn = logn; pl->inverse = inverse; pl->large = large;
   memcpy(pl->root, root, 8 * hf->nl);
   memcpy(pl->scale, sc, 8 * hf->nl);
-  pl->li = choose_levels(logn, fid);
+  pl->li = choose_levels(logn, large);
   pl->stamp = ++g_stamp;
   uint64_t eff_root[4] = {0, 0, 0, 0}, fold[4] = {0, 0, 0, 0};
   memcpy(fold, sc, 8 * hf->nl);
@@ -581,7 +588,7 @@ static int run_plan_geo(const NttPlan* pl, const u32* d_in, u32* d_out, hipStrea
 }
 template <class P>
 static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t s, const PreArgs* pre = nullptr, size_t batch = 1) {
-  if (large_geo(pl->fid, pl->logn)) return run_plan_geo<P, GeoL>(pl, d_in, d_out, s, pre, batch);
+  if (pl->large) return run_plan_geo<P, GeoL>(pl, d_in, d_out, s, pre, batch);
   return run_plan_geo<P, GeoS>(pl, d_in, d_out, s, pre, batch);
 }
 
@@ -616,12 +623,15 @@ int ntt_batch_dev_impl(int fid, const uint64_t* root_host, const void* d_in, voi
   if (batch == 1) return ntt_dev_impl(fid, root_host, d_in, d_out, n, inverse, nullptr, s);
   if (fid != MZK_FIELD_FR && fid != MZK_FIELD_M128) { set_error("ntt: field id %d has no NTT on this path", fid); return MZK_E_ARG; }
   if (!is_pow2(n)) { set_error("cannot compute ntt of non-power-of-two sequence"); return MZK_E_NOT_POW2; }
+  if (!d_in || !d_out || (!root_host && n > 1)) { set_error("ntt: null pointer"); return MZK_E_ARG; }
+  if (n > 1 && !h_is_canonical(host_field(fid), root_host)) { set_error("ntt: root not canonical"); return MZK_E_RANGE; }
+  if (ilog2(n) > 32 || batch > ((size_t)1 << 40) / n) { set_error("ntt: batch too large"); return MZK_E_ARG; }
   if (n == 1) {
     if (d_in != d_out) MZK_HIP(hipMemcpyAsync(d_out, d_in, batch * field_bytes(fid), hipMemcpyDeviceToDevice, s));
     return MZK_OK;
   }
   NttPlan* pl = nullptr;
-  MZK_TRY(get_plan(fid, ilog2(n), inverse != 0, root_host, nullptr, s, &pl));
+  MZK_TRY(get_plan(fid, ilog2(n), inverse != 0, root_host, nullptr, s, &pl, batch));
   if (fid == MZK_FIELD_M128) return run_plan<M128Params>(pl, (const u32*)d_in, (u32*)d_out, s, nullptr, batch);
   return run_plan<FrParams>(pl, (const u32*)d_in, (u32*)d_out, s, nullptr, batch);
 }
@@ -638,7 +648,7 @@ int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_
   Words8 offw;
   to_words(offset_host, hf->nl, &offw);
   const unsigned logn = ilog2(order);
-  if (order > 1 && choose_levels(logn, fid).nlev > 1) {
+  if (order > 1 && choose_levels(logn, large_geo(fid, logn)).nlev > 1) {
     // multi-pass transform: Polynomial::scale + padding fused into the first pass (PreArgs)
     if (!h_is_canonical(hf, generator_host)) { set_error("coset_lde: parameter not canonical"); return MZK_E_RANGE; }
     NttPlan* pl = nullptr;

@@ -161,3 +161,26 @@ def test_coset_lde_fused_prescale_and_table_cache(mz, fid):
                 rc, want = orc.ntt_fast(fid, gen, arr)
                 assert rc == 0
             assert np.array_equal(got, want), (lg, ncoef, off)
+
+
+@pytest.mark.parametrize("fid", [0, 1])
+def test_batched_transforms_equal_single_calls(fid):
+    """mzk_ntt_batch: `batch` transforms stored back to back, one launch per pass -- every row bit-identical to the single
+    call (ntt.rs:7-64), forward and inverse, sizes on every code path (one level, two levels, the 2^20 large tiles are
+    covered by the single-transform tests), batch counts that do not fill the last workgroup, and the trivial sizes."""
+    import myzkp_amd as mz
+    mz.init(0)
+    rng = np.random.default_rng(77 + fid)
+    nl = mz.LIMBS[fid]
+    for lg, batch in ((0, 3), (1, 5), (3, 7), (6, 33), (10, 9), (12, 5), (14, 3)):
+        n = 1 << lg
+        root = mz.root_of_unity(fid, lg)
+        cols = np.stack([orc.synth_vector(fid, 9000 + 31 * k + lg, n) for k in range(batch)])
+        got = mz.ntt_batch(fid, root, cols)
+        back = mz.ntt_batch(fid, root, got, inverse=True)
+        for k in range(batch):
+            assert np.array_equal(got[k], mz.ntt(fid, root, cols[k])), (lg, k)
+        assert np.array_equal(back.reshape(cols.shape), cols)
+    assert mz.ntt_batch(fid, mz.root_of_unity(fid, 4), np.zeros((0, 16, nl), dtype=np.uint64)).shape[0] == 0
+    with pytest.raises(mz.MzkError):
+        mz.ntt_batch(fid, mz.root_of_unity(fid, 4), np.zeros((2, 12, nl), dtype=np.uint64))      # not a power of two
