@@ -239,6 +239,13 @@ int mzk_ntt_batch_dev(int field_id, const uint64_t* root, const void* d_in, void
                       void* stream);
 int mzk_coset_lde_dev(int field_id, const void* d_coef, size_t n_coef, const uint64_t* offset_host,
                       const uint64_t* generator_host, void* d_out, size_t order, void* stream);
+/* fast_coset_evaluate (ntt.rs:254-269) of `batch` polynomials of n_coef coefficients each onto ONE coset -- the low-degree
+ * extension of every column of a trace (fast_stark.rs:231,282,329 call it per polynomial) -- in one launch per pass:
+ * coefs = batch * n_coef elements back to back, out = batch * order.  Bit-identical to `batch` single calls. */
+int mzk_coset_lde_batch(int field_id, const uint64_t* coefs, size_t n_coef, const uint64_t* offset, const uint64_t* generator,
+                        uint64_t* out, size_t order, size_t batch);
+int mzk_coset_lde_batch_dev(int field_id, const void* d_coefs, size_t n_coef, const uint64_t* offset_host, const uint64_t* generator_host,
+                            void* d_out, size_t order, size_t batch, void* stream);
 /* d_out_xy: 8 limbs on the device */
 int mzk_msm_g1_bn254_dev(const void* d_scalars, const void* d_points_xy, size_t n, void* d_out_xy, void* stream);
 /* Multi-GPU sharding (one process per GPU): each rank reduces its shard to one XYZZ partial

@@ -148,6 +148,17 @@ def intt(fid, root, values):
     return ntt(fid, root, values, inverse=True)
 
 
+def coset_lde_batch(fid, coefs, offset, generator, order):
+    """ntt::fast_coset_evaluate of every row of `coefs` (batch x n_coef x limbs) onto one coset: mzk_coset_lde_batch."""
+    c = np.ascontiguousarray(coefs, dtype=np.uint64)
+    batch = c.shape[0]
+    c = c.reshape(batch, -1, LIMBS[fid]) if batch else c.reshape(0, 0, LIMBS[fid])
+    out = np.empty((batch, order, LIMBS[fid]), dtype=np.uint64)
+    _check(lib().mzk_coset_lde_batch(fid, _p(c), ctypes.c_size_t(c.shape[1]), _p(_one(fid, offset)), _p(_one(fid, generator)), _p(out),
+                                     ctypes.c_size_t(order), ctypes.c_size_t(batch)))
+    return out
+
+
 def ntt_batch(fid, root, columns, inverse=False):
     """ntt::ntt / ntt::intt of every row of `columns` (batch x n x limbs) in one launch per pass: mzk_ntt_batch."""
     v = np.ascontiguousarray(columns, dtype=np.uint64)

@@ -434,6 +434,30 @@ int mzk_ntt_dev(int field_id, const uint64_t* root_host, const void* d_in, void*
   return ntt_dev_impl(field_id, root_host, d_in, d_out, n, inverse, nullptr, (hipStream_t)stream);
 }
 
+int mzk_coset_lde_batch_dev(int field_id, const void* d_coefs, size_t n_coef, const uint64_t* offset_host, const uint64_t* generator_host,
+                            void* d_out, size_t order, size_t batch, void* stream) {
+  MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
+  return coset_lde_dev_impl(field_id, d_coefs, n_coef, offset_host, generator_host, d_out, order, (hipStream_t)stream, batch);
+}
+int mzk_coset_lde_batch(int field_id, const uint64_t* coefs, size_t n_coef, const uint64_t* offset, const uint64_t* generator,
+                        uint64_t* out, size_t order, size_t batch) {
+  MZK_TRY(ensure_init());
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("coset_lde: bad field id %d", field_id); return MZK_E_ARG; }
+  if (n_coef > order) { set_error("attempt to subtract with overflow (order - polynomial.coef.len())"); return MZK_E_LENGTH; }
+  if (order == 0 || batch == 0) return MZK_OK;
+  if (!out || (!coefs && n_coef)) { set_error("coset_lde: null pointer"); return MZK_E_ARG; }
+  hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
+  const size_t esz = field_bytes(field_id);
+  void *d_coef, *d_out;
+  MZK_TRY(stage_in(WS_MISC_A, coefs, batch * n_coef * esz, &d_coef, s));
+  MZK_TRY(ws_get(WS_NTT_IO_B, batch * order * esz, &d_out));
+  MZK_TRY(coset_lde_dev_impl(field_id, d_coef, n_coef, offset, generator, d_out, order, s, batch));
+  MZK_HIP(hipMemcpyAsync(out, d_out, batch * order * esz, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  return MZK_OK;
+}
 int mzk_ntt_batch_dev(int field_id, const uint64_t* root_host, const void* d_in, void* d_out, size_t n, size_t batch, int inverse, void* stream) {
   MZK_TRY(ensure_init());
   WsGuard wsg((hipStream_t)stream);

@@ -242,9 +242,11 @@ __global__ __launch_bounds__(G::NT) void k_ntt_strided(const u32* __restrict__ i
     const int j1 = e >> lgc, c = e & cmask;
     Fe<P> v;
     if constexpr (PRE) {
-      const size_t idx = base + ((size_t)j1 << lgM) + c;          // o == 0 in the first pass
+      // position inside transform `o` (the first pass spans a whole transform: lgn + lgM = log2 order); a batch stores
+      // the coefficient vectors back to back, n_coef apart
+      const size_t idx = ((size_t)j1 << lgM) + (ct << lgc) + c;
       if (idx < pre.n_coef) {
-        const Fe<P> x = gload<P>(pre.coef, idx);
+        const Fe<P> x = gload<P>(pre.coef, o * pre.n_coef + idx);
         const Fe<P> wc = gload<P>(pre.pre_col, (ct << lgc) + c), wr = gload<P>(pre.pre_row, (size_t)j1);
         v = fe_fit<P>(FeAsm<P>::mul(FeAsm<P>::mul(x, wc), wr));    // plain * Montgomery * Montgomery = plain
       } else {
@@ -350,10 +352,14 @@ __global__ void k_gen_inter_table(Words8 root_plain, uint64_t emul, int lgn, int
 // for i < n_coef, 0 for n_coef <= i < order.
 template <class P>
 __global__ void k_coset_scale_pad(const u32* __restrict__ coef, size_t n_coef, Words8 offset_plain,
-                                  u32* __restrict__ out, size_t order) {
+                                  u32* __restrict__ out, size_t order, size_t chunks_per, size_t batch) {
   const size_t chunk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t j0 = chunk * GEN_CHUNK;
+  const size_t o = chunk / chunks_per;                 // transform of the batch (vectors back to back: n_coef in, order out)
+  if (o >= batch) return;
+  const size_t j0 = (chunk - o * chunks_per) * GEN_CHUNK;
   if (j0 >= order) return;
+  coef += o * n_coef * P::NW;
+  out += o * order * P::NW;
   if (j0 >= n_coef) {
     for (int i = 0; i < GEN_CHUNK && j0 + i < order; i++) gstore<P>(out, j0 + i, fe_zero<P>());
     return;
@@ -637,7 +643,8 @@ int ntt_batch_dev_impl(int fid, const uint64_t* root_host, const void* d_in, voi
 }
 
 int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_t* offset_host,
-                       const uint64_t* generator_host, void* d_out, size_t order, hipStream_t s) {
+                       const uint64_t* generator_host, void* d_out, size_t order, hipStream_t s, size_t batch) {
+  if (batch == 0) return MZK_OK;
   if (fid != MZK_FIELD_FR && fid != MZK_FIELD_M128) { set_error("coset_lde: bad field id %d", fid); return MZK_E_ARG; }
   if (n_coef > order) { set_error("attempt to subtract with overflow (order - polynomial.coef.len())"); return MZK_E_LENGTH; }
   if (order == 0) return MZK_OK;
@@ -648,24 +655,25 @@ int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_
   Words8 offw;
   to_words(offset_host, hf->nl, &offw);
   const unsigned logn = ilog2(order);
-  if (order > 1 && choose_levels(logn, large_geo(fid, logn)).nlev > 1) {
+  if (logn > 32 || batch > ((size_t)1 << 40) / order) { set_error("coset_lde: order * batch too large"); return MZK_E_ARG; }
+  if (order > 1 && choose_levels(logn, large_geo(fid, logn, batch)).nlev > 1) {
     // multi-pass transform: Polynomial::scale + padding fused into the first pass (PreArgs)
     if (!h_is_canonical(hf, generator_host)) { set_error("coset_lde: parameter not canonical"); return MZK_E_RANGE; }
     NttPlan* pl = nullptr;
-    MZK_TRY(get_plan(fid, logn, false, generator_host, nullptr, s, &pl));
+    MZK_TRY(get_plan(fid, logn, false, generator_host, nullptr, s, &pl, batch));
     const int lgn0 = pl->li.lg[0], lgM0 = (int)logn - lgn0;
     const size_t nrow = (size_t)1 << lgn0, ncol = (size_t)1 << lgM0;
     // offset^(j M) and offset^col tables: like the plan's twiddles they depend only on (field, offset, size) -- a STARK
     // prover evaluates every polynomial on ONE coset -- so the last pair per field is kept (workspace generation and
     // stream order checked like the fixed-base tables in mzk_kzg.hip).
-    static struct { uint64_t off[4]; unsigned logn; uint64_t gen; bool valid; hipEvent_t ready; } cache[MZK_MAX_CTX][2] = {};
+    static struct { uint64_t off[4]; unsigned logn; int lgn0; uint64_t gen; bool valid; hipEvent_t ready; } cache[MZK_MAX_CTX][2] = {};
     auto& ce = cache[ctx().index][fid == MZK_FIELD_M128 ? 1 : 0];
     void* tabs = nullptr;
     MZK_TRY(ws_get(fid == MZK_FIELD_M128 ? WS_NTT_PRE_M128 : WS_NTT_PRE, (nrow + ncol) * field_bytes(fid), &tabs));
     u32* pre_row = (u32*)tabs;
     u32* pre_col = pre_row + nrow * field_words(fid);
     if (!ce.ready) MZK_HIP(hipEventCreateWithFlags(&ce.ready, hipEventDisableTiming));
-    const bool hit = ce.valid && ce.gen == ws_generation() && ce.logn == logn && memcmp(ce.off, offset_host, 8 * hf->nl) == 0;
+    const bool hit = ce.valid && ce.gen == ws_generation() && ce.logn == logn && ce.lgn0 == lgn0 && memcmp(ce.off, offset_host, 8 * hf->nl) == 0;
     if (!hit) {
       // a regrown slot or another size invalidates the pointers: wait for earlier users of the old contents
       prof_begin(s, MZK_PH_NTT_PRESCALE);
@@ -681,27 +689,27 @@ int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_
       prof_end(s, MZK_PH_NTT_PRESCALE);
       memset(ce.off, 0, sizeof ce.off);
       memcpy(ce.off, offset_host, 8 * hf->nl);
-      ce.logn = logn; ce.gen = ws_generation(); ce.valid = true;
+      ce.logn = logn; ce.lgn0 = lgn0; ce.gen = ws_generation(); ce.valid = true;
       MZK_HIP(hipEventRecord(ce.ready, s));
     } else {
       MZK_HIP(hipStreamWaitEvent(s, ce.ready, 0));
     }
     const PreArgs pre{(const u32*)d_coef, n_coef, pre_row, pre_col};
-    if (fid == MZK_FIELD_M128) return run_plan<M128Params>(pl, (const u32*)d_coef, (u32*)d_out, s, &pre);
-    return run_plan<FrParams>(pl, (const u32*)d_coef, (u32*)d_out, s, &pre);
+    if (fid == MZK_FIELD_M128) return run_plan<M128Params>(pl, (const u32*)d_coef, (u32*)d_out, s, &pre, batch);
+    return run_plan<FrParams>(pl, (const u32*)d_coef, (u32*)d_out, s, &pre, batch);
   }
   void* scaled = nullptr;
-  MZK_TRY(ws_get(WS_NTT_IO_A, order * field_bytes(fid), &scaled));
-  const size_t chunks = (order + GEN_CHUNK - 1) / GEN_CHUNK;
-  const unsigned blocks = (unsigned)((chunks + 255) / 256);
+  MZK_TRY(ws_get(WS_NTT_IO_A, batch * order * field_bytes(fid), &scaled));
+  const size_t chunks_per = (order + GEN_CHUNK - 1) / GEN_CHUNK;
+  const unsigned blocks = (unsigned)((chunks_per * batch + 255) / 256);
   prof_begin(s, MZK_PH_NTT_PRESCALE);
   if (fid == MZK_FIELD_M128)
-    hipLaunchKernelGGL((k_coset_scale_pad<M128Params>), dim3(blocks), dim3(256), 0, s, (const u32*)d_coef, n_coef, offw, (u32*)scaled, order);
+    hipLaunchKernelGGL((k_coset_scale_pad<M128Params>), dim3(blocks), dim3(256), 0, s, (const u32*)d_coef, n_coef, offw, (u32*)scaled, order, chunks_per, batch);
   else
-    hipLaunchKernelGGL((k_coset_scale_pad<FrParams>), dim3(blocks), dim3(256), 0, s, (const u32*)d_coef, n_coef, offw, (u32*)scaled, order);
+    hipLaunchKernelGGL((k_coset_scale_pad<FrParams>), dim3(blocks), dim3(256), 0, s, (const u32*)d_coef, n_coef, offw, (u32*)scaled, order, chunks_per, batch);
   MZK_HIP(hipGetLastError());
   prof_end(s, MZK_PH_NTT_PRESCALE);
-  return ntt_dev_impl(fid, generator_host, scaled, d_out, order, 0, nullptr, s);
+  return ntt_batch_dev_impl(fid, generator_host, scaled, d_out, order, batch, 0, s);
 }
 
 // FRI split-and-fold (zkstark/fri.rs:182-193).  With q_i = alpha / (offset omega^i):
@@ -817,9 +825,9 @@ int coset_divide_dev_impl(int fid, const void* d_lhs, size_t tl, const void* d_r
   const size_t chunks = (ql + GEN_CHUNK - 1) / GEN_CHUNK;
   const unsigned sblocks = (unsigned)((chunks + 255) / 256);
   if (fid == MZK_FIELD_M128)
-    hipLaunchKernelGGL((k_coset_scale_pad<M128Params>), dim3(sblocks), dim3(256), 0, s, (const u32*)eb, ql, ow, (u32*)d_out, ql);
+    hipLaunchKernelGGL((k_coset_scale_pad<M128Params>), dim3(sblocks), dim3(256), 0, s, (const u32*)eb, ql, ow, (u32*)d_out, ql, chunks, (size_t)1);
   else
-    hipLaunchKernelGGL((k_coset_scale_pad<FrParams>), dim3(sblocks), dim3(256), 0, s, (const u32*)eb, ql, ow, (u32*)d_out, ql);
+    hipLaunchKernelGGL((k_coset_scale_pad<FrParams>), dim3(sblocks), dim3(256), 0, s, (const u32*)eb, ql, ow, (u32*)d_out, ql, chunks, (size_t)1);
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }

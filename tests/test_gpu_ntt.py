@@ -184,3 +184,35 @@ def test_batched_transforms_equal_single_calls(fid):
     assert mz.ntt_batch(fid, mz.root_of_unity(fid, 4), np.zeros((0, 16, nl), dtype=np.uint64)).shape[0] == 0
     with pytest.raises(mz.MzkError):
         mz.ntt_batch(fid, mz.root_of_unity(fid, 4), np.zeros((2, 12, nl), dtype=np.uint64))      # not a power of two
+
+
+@pytest.mark.parametrize("fid", [0, 1])
+def test_batched_coset_lde_equals_single_calls(fid):
+    """mzk_coset_lde_batch: fast_coset_evaluate (ntt.rs:254-269) of several polynomials onto one coset -- every row equal to
+    the single call: single-pass orders (the scale / pad kernel runs over the batch), multi-pass orders (scale and padding
+    fused into the first pass, coefficient vectors n_coef apart), ragged n_coef, n_coef == order, batch of one and of none."""
+    import myzkp_amd as mz
+    mz.init(0)
+    nl = mz.LIMBS[fid]
+    off = orc.M128_GEN if fid == 1 else 5
+    for lg_order, n_coef, batch in ((4, 5, 3), (10, 1024, 2), (10, 300, 7), (12, 1000, 5), (14, 4096, 3), (16, 16384 + 7, 2), (12, 0, 2), (12, 9, 1)):
+        order = 1 << lg_order
+        gen = mz.root_of_unity(fid, lg_order)
+        coefs = np.stack([orc.synth_vector(fid, 4000 + 13 * k + lg_order, max(n_coef, 1))[:n_coef] for k in range(batch)]).reshape(batch, n_coef, nl)
+        got = mz.coset_lde_batch(fid, coefs, off, gen, order)
+        assert got.shape == (batch, order, nl)
+        for k in range(batch):
+            assert np.array_equal(got[k], mz.coset_lde(fid, coefs[k], off, gen, order)), (lg_order, n_coef, k)
+    # 2^20: a batch switches the plan to the small tiles (three passes), the single call uses the large ones (two): both
+    # geometries, their own pre-scale tables, same numbers
+    order, n_coef, batch = 1 << 20, (1 << 18) + 3, 3
+    gen = mz.root_of_unity(fid, 20)
+    coefs = np.stack([orc.synth_vector(fid, 5100 + k, n_coef) for k in range(batch)])
+    got = mz.coset_lde_batch(fid, coefs, off, gen, order)
+    for k in (0, batch - 1):
+        assert np.array_equal(got[k], mz.coset_lde(fid, coefs[k], off, gen, order))
+    tb = mz.ntt_batch(fid, gen, got)
+    assert np.array_equal(tb[1], mz.ntt(fid, gen, got[1]))
+    assert mz.coset_lde_batch(fid, np.zeros((0, 4, nl), dtype=np.uint64), off, mz.root_of_unity(fid, 4), 16).shape == (0, 16, nl)
+    with pytest.raises(mz.MzkError):
+        mz.coset_lde_batch(fid, np.zeros((2, 40, nl), dtype=np.uint64), off, mz.root_of_unity(fid, 5), 32)      # n_coef > order
