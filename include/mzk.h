@@ -176,6 +176,13 @@ void mzk_merkle_free(mzk_merkle* tree);
 int mzk_merkle_commit_field(int field_id, const uint64_t* elems, size_t n, uint8_t* root, size_t cap, size_t* root_len);
 int mzk_merkle_commit_field_dev(int field_id, const void* d_elems, size_t n, uint8_t* root_host, size_t cap, size_t* root_len,
                                 void* stream);
+/* Merkle::commit (merkle.rs:15-25) of `batch` codewords of n elements each, stored back to back -- the per-register loop of
+ * the provers (fast_stark.rs:231-243: fast_coset_evaluate, serialize, Merkle::commit for every register) as one call.
+ * roots: batch * 32 bytes (host).  n must be a power of two >= 2 (every codeword the provers commit to is; other leaf
+ * counts: the single-tree calls).  The upper levels of a tree are one dependent hash per level on a nearly empty GPU; side
+ * by side the trees share them: 16 codewords of 2^16 elements in 0.26 ms instead of 16 x 0.18. */
+int mzk_merkle_commit_field_batch(int field_id, const uint64_t* elems, size_t n, size_t batch, uint8_t* roots);
+int mzk_merkle_commit_field_batch_dev(int field_id, const void* d_elems, size_t n, size_t batch, uint8_t* roots, void* stream);
 int mzk_merkle_commit_bytes(const uint8_t* leaves, const uint64_t* offsets, size_t n, uint8_t* root, size_t cap, size_t* root_len);
 
 /* Elements whose BigInt the reference left NEGATIVE (F6: `%` keeps the sign, field.rs:98-110; only sanitize() folds

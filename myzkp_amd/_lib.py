@@ -148,6 +148,19 @@ def intt(fid, root, values):
     return ntt(fid, root, values, inverse=True)
 
 
+def merkle_commit_field_batch(fid, codewords):
+    """Merkle::commit of every row of `codewords` (batch x n x limbs, n a power of two): list of 32-byte roots."""
+    c = np.ascontiguousarray(codewords, dtype=np.uint64)
+    batch = c.shape[0]
+    if batch == 0:
+        return []
+    c = c.reshape(batch, -1, LIMBS[fid])
+    roots = (ctypes.c_uint8 * (32 * batch))()
+    _check(lib().mzk_merkle_commit_field_batch(fid, _p(c), ctypes.c_size_t(c.shape[1]), ctypes.c_size_t(batch), roots))
+    raw = bytes(roots)
+    return [raw[32 * k: 32 * k + 32] for k in range(batch)]
+
+
 def coset_lde_batch(fid, coefs, offset, generator, order):
     """ntt::fast_coset_evaluate of every row of `coefs` (batch x n_coef x limbs) onto one coset: mzk_coset_lde_batch."""
     c = np.ascontiguousarray(coefs, dtype=np.uint64)

@@ -327,10 +327,11 @@ __global__ __launch_bounds__(128) void k_merkle_level_pair(const u64* __restrict
 }
 // the last levels (<= TAIL_NODES nodes each) in one workgroup: no launch per level; one lane pair per hash
 constexpr int TAIL_NODES = 512;
-__global__ __launch_bounds__(TAIL_NODES) void k_merkle_tail(u64* __restrict__ level, size_t count) {
-  // `level` holds `count` nodes; the levels above follow contiguously (count/2, count/4, ... 1)
+__global__ __launch_bounds__(TAIL_NODES) void k_merkle_tail(u64* __restrict__ level, size_t count, size_t stop) {
+  // `level` holds `count` nodes; the levels above follow contiguously (count/2, count/4, ... stop); stop = 1 for one tree,
+  // the number of trees for a batch (their roots are the last level)
   u64* below = level;
-  while (count > 1) {
+  while (count > stop) {
     const size_t up = count / 2;
     u64* above = below + 4 * count;
     if ((threadIdx.x >> 1) < up) sha3_of_two_digests_pair(below + 8 * (threadIdx.x >> 1), above + 4 * (threadIdx.x >> 1), threadIdx.x & 1);
@@ -377,8 +378,11 @@ namespace mzk {
 static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 
 // hashes level 1 .. root into d_nodes; d_leaves / d_off already on the device
+// `trees` > 1: n = trees * (leaves per tree), all trees of one power-of-two size, leaves back to back.  Level l of the whole
+// array is then level l of every tree side by side (pairs never straddle trees), so a batch is the bottom of one big tree,
+// hashed down to `trees` nodes: the roots, at d_nodes + 4 * (n - 2 * trees).
 static int merkle_hash_levels(int kind, int fid, const void* d_leaves, const u64* d_off, size_t n, u64* d_nodes, hipStream_t s,
-                              const u8* d_neg = nullptr) {
+                              const u8* d_neg = nullptr, size_t trees = 1) {
   if (n < 2) return MZK_OK;
   ProfScope ps(s, MZK_PH_MERKLE);
   const size_t pairs = n / 2;
@@ -391,7 +395,7 @@ static int merkle_hash_levels(int kind, int fid, const void* d_leaves, const u64
     hipLaunchKernelGGL((k_merkle_leaf_pairs<8>), dim3(blocks), dim3(LEAF_THREADS), 0, s, (const u32*)d_leaves, pairs, d_nodes, d_neg);
   u64* below = d_nodes;
   size_t count = pairs;
-  while (count > (size_t)TAIL_NODES) {
+  while (count > (size_t)TAIL_NODES && count > trees) {
     u64* above = below + 4 * count;
     if (count / 2 <= LEVEL_PAIR_MAX)
       hipLaunchKernelGGL(k_merkle_level_pair, dim3((unsigned)((count + 127) / 128)), dim3(128), 0, s, (const u64*)below, count / 2, above);
@@ -400,7 +404,7 @@ static int merkle_hash_levels(int kind, int fid, const void* d_leaves, const u64
     below = above;
     count /= 2;
   }
-  if (count > 1) hipLaunchKernelGGL(k_merkle_tail, dim3(1), dim3(TAIL_NODES), 0, s, below, count);
+  if (count > trees) hipLaunchKernelGGL(k_merkle_tail, dim3(1), dim3(TAIL_NODES), 0, s, below, count, trees);
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }
@@ -729,6 +733,40 @@ int mzk_merkle_commit_field_dev(int field_id, const void* d_elems, size_t n, uin
   MZK_HIP(hipStreamSynchronize(s));
   *root_len = 32;
   return MZK_OK;
+}
+// Merkle::commit of `batch` codewords of n elements each (n a power of two >= 2), roots only: one set of launches for all
+// trees, so the latency-bound upper levels of the trees run side by side.
+int mzk_merkle_commit_field_batch_dev(int field_id, const void* d_elems, size_t n, size_t batch, uint8_t* roots, void* stream) {
+  MZK_TRY(ensure_init());
+  WsGuard wsg((hipStream_t)stream);
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("merkle: bad field id %d", field_id); return MZK_E_ARG; }
+  if (batch == 0) return MZK_OK;
+  if (n == 0) { set_error("merkle: empty leaf set (Merkle::commit recurses forever on it, merkle.rs:20-22)"); return MZK_E_LENGTH; }
+  if (!d_elems || !roots) { set_error("merkle: null pointer"); return MZK_E_ARG; }
+  if (!is_pow2(n) || n < 2) { set_error("merkle batch: codewords of %zu elements (need a power of two >= 2; use the single-tree calls)", n); return MZK_E_NOT_POW2; }
+  if (batch > ((size_t)1 << 36) / n) { set_error("merkle batch: too many leaves"); return MZK_E_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = n * batch;
+  u64* d_nodes;
+  MZK_TRY(ws_get(WS_MERKLE_NODES, (total - batch) * 32, (void**)&d_nodes));
+  MZK_TRY(merkle_hash_levels(0, field_id, d_elems, nullptr, total, d_nodes, s, nullptr, batch));
+  MZK_HIP(hipMemcpyAsync(roots, d_nodes + 4 * (total - 2 * batch), batch * 32, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  return MZK_OK;
+}
+int mzk_merkle_commit_field_batch(int field_id, const uint64_t* elems, size_t n, size_t batch, uint8_t* roots) {
+  MZK_TRY(ensure_init());
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("merkle: bad field id %d", field_id); return MZK_E_ARG; }
+  if (batch == 0) return MZK_OK;
+  if (!elems) { set_error("merkle: null pointer"); return MZK_E_ARG; }
+  hipStream_t s = ctx().stream;
+  void* d;
+  {
+    WsGuard wsg(s);
+    MZK_TRY(ws_get(WS_MISC_D, n * batch * field_bytes(field_id) + 16, &d));
+    MZK_HIP(hipMemcpyAsync(d, elems, n * batch * field_bytes(field_id), hipMemcpyHostToDevice, s));
+  }
+  return mzk_merkle_commit_field_batch_dev(field_id, d, n, batch, roots, s);
 }
 int mzk_merkle_commit_field(int field_id, const uint64_t* elems, size_t n, uint8_t* root, size_t cap, size_t* root_len) {
   mzk_merkle* t = nullptr;

@@ -284,3 +284,23 @@ def test_fri_commit_callback_exception_aborts_instead_of_folding_with_zero(mz):
         mz.fri_commit(M128, cw, orc.root_of(M128, 4), orc.M128_GEN, 3, challenge)
     with pytest.raises(ValueError):
         mz.fri_commit(M128, cw, orc.root_of(M128, 4), orc.M128_GEN, 3, lambda *a: None)      # forgot to return alpha
+
+
+@pytest.mark.parametrize("fid", [0, 1])
+def test_batched_commit_equals_single_commits(fid):
+    """mzk_merkle_commit_field_batch: the provers' per-register loop (fast_stark.rs:231-243) as one call -- every root equal
+    to Merkle::commit of that codeword alone: two-leaf trees, trees that end inside the one-workgroup tail, more trees
+    than the tail holds nodes, a batch count that is not a power of two; other leaf counts are refused."""
+    import myzkp_amd as mz
+    mz.init(0)
+    nl = mz.LIMBS[fid]
+    for n, batch in ((2, 5), (4, 1), (8, 3), (1024, 16), (1 << 14, 7), (4, 600), (1 << 12, 33)):
+        cws = np.stack([orc.synth_vector(fid, 700 + 11 * k + n, n) for k in range(batch)])
+        roots = mz.merkle_commit_field_batch(fid, cws)
+        assert len(roots) == batch
+        for k in sorted({0, 1 % batch, batch // 2, batch - 1}):
+            assert roots[k] == mz.merkle_commit_field(fid, cws[k]), (n, batch, k)
+    assert mz.merkle_commit_field_batch(fid, np.zeros((0, 8, nl), dtype=np.uint64)) == []
+    for bad in (1, 6):
+        with pytest.raises(mz.MzkError):
+            mz.merkle_commit_field_batch(fid, np.zeros((2, bad, nl), dtype=np.uint64))
