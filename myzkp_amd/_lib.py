@@ -567,6 +567,24 @@ def fast_interpolate(fid, domain, values, root, root_order):
     return out[:ln.value]
 
 
+def fast_interpolate_batch(fid, domain, values, root, root_order):
+    """ntt::fast_interpolate of every row of `values` (batch x n x limbs) over one domain: list of coefficient arrays."""
+    d = _arr(fid, domain)
+    v = np.ascontiguousarray(values, dtype=np.uint64)
+    batch = v.shape[0]
+    if batch == 0:
+        return []
+    v = v.reshape(batch, -1, LIMBS[fid])
+    if d.shape[0] != v.shape[1]:
+        raise MzkError(-5, "assertion `left == right` failed (domain.len(), values.len())")
+    n = d.shape[0]
+    out = np.zeros((batch, max(n, 1), LIMBS[fid]), dtype=np.uint64)
+    lens = (ctypes.c_size_t * batch)()
+    r = _one(fid, root)
+    _check(lib().mzk_fast_interpolate_batch(fid, _p(d), _p(v), ctypes.c_size_t(n), ctypes.c_size_t(batch), _p(r), ctypes.c_size_t(root_order), _p(out), lens))
+    return [out[k, :lens[k]] for k in range(batch)]
+
+
 def g2_points_to_array(pts):
     """[((x0, x1), (y0, y1)), ...] -> (n, 16) limbs; infinity = ((0, 0), (0, 0))."""
     a = np.zeros((len(pts), 16), dtype=np.uint64)

@@ -528,43 +528,55 @@ static int evaluate_impl(int fid, const uint64_t* coef, size_t m, const uint64_t
   return MZK_OK;
 }
 
+// `batch` value vectors over ONE domain (the registers of a trace, fast_stark.rs:203-215): the subproduct tree and the
+// Z'(d_i) are built once, each register costs a pointwise division and one up-sweep.  out: batch rows of n elements
+// (row r holds out_lens[r] coefficients, zero-padded).
 template <class P>
-static int interpolate_impl(int fid, const uint64_t* domain, const uint64_t* values, size_t n, const uint64_t* root, size_t root_order, uint64_t* out,
-                            size_t* out_len) {
+static int interpolate_impl(int fid, const uint64_t* domain, const uint64_t* values, size_t n, size_t batch, const uint64_t* root, size_t root_order,
+                            uint64_t* out, size_t* out_lens) {
   const HostField* hf = host_field(fid);
   const int nl = hf->nl;
   const size_t esz = field_bytes(fid);
-  if (n == 0) { *out_len = 0; return MZK_OK; }                               // ntt.rs:207-209
-  if (n == 1) { memcpy(out, values, esz); *out_len = 1; return MZK_OK; }     // ntt.rs:211-215: coef = [values[0]], untrimmed
+  if (n == 0) { for (size_t r = 0; r < batch; r++) out_lens[r] = 0; return MZK_OK; }                 // ntt.rs:207-209
+  if (n == 1) {                                                                                      // ntt.rs:211-215: coef = [values[0]], untrimmed
+    memcpy(out, values, batch * esz);
+    for (size_t r = 0; r < batch; r++) out_lens[r] = 1;
+    return MZK_OK;
+  }
   hipStream_t s = ctx().stream;
   WsGuard wsg(s);
   PolyTree<P> T;
   MZK_TRY(check_order_for(n - n / 2, root_order, "fast_interpolate"));        // ntt.rs:219-220
   MZK_TRY(tree_init(&T, fid, n, root, root_order, s));
-  DevBuf d_dom, d_val, d_dz, d_w, d_res;
-  MZK_TRY(d_dom.alloc(n * esz)); MZK_TRY(d_val.alloc(n * esz)); MZK_TRY(d_dz.alloc(n * esz)); MZK_TRY(d_w.alloc(T.N * esz)); MZK_TRY(d_res.alloc(T.N * esz));
+  DevBuf d_dom, d_val, d_dz, d_zp, d_w, d_res;
+  MZK_TRY(d_dom.alloc(n * esz)); MZK_TRY(d_val.alloc(n * esz)); MZK_TRY(d_dz.alloc(n * esz)); MZK_TRY(d_zp.alloc(T.N * esz));
+  MZK_TRY(d_w.alloc(T.N * esz)); MZK_TRY(d_res.alloc(T.N * esz));
   MZK_HIP(hipMemcpyAsync(d_dom.p, domain, n * esz, hipMemcpyHostToDevice, s));
-  MZK_HIP(hipMemcpyAsync(d_val.p, values, n * esz, hipMemcpyHostToDevice, s));
   MZK_TRY(T.build(d_dom.p, true));
   // w_i = v_i / Z'(d_i); a repeated point has Z' = 0 and the reference's division by inverse(0) = 0 (field.rs:209-232)
   // zeroes its target at the level that separates the two copies (ntt.rs:233-242): w_i = 0 as well
   hipLaunchKernelGGL((k_derivative<P>), dim3(grid256(n)), dim3(256), 0, s, (const u32*)T.low[T.levels].w(), T.N, T.pad, n, d_dz.w());
-  MZK_TRY(T.evaluate(d_dz.p, n, d_dom.p, d_w.p, n));
-  MZK_TRY(pointwise_div_dev(fid, d_val.p, d_w.p, d_w.p, n, s));
-  MZK_TRY(T.combine(d_dom.p, d_w.p, d_res.p));
+  MZK_TRY(T.evaluate(d_dz.p, n, d_dom.p, d_zp.p, n));
   std::vector<uint64_t> res(T.N * nl);
-  MZK_HIP(hipMemcpyAsync(res.data(), d_res.p, T.N * esz, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
-  // sum_i w_i Z_pad / (X - d_i) = X^pad * interpolant; trimmed like the final `+` (polynomial.rs:214-228)
-  size_t len = n;
-  while (len > 0) {
-    uint64_t a = 0;
-    for (int k = 0; k < nl; k++) a |= res[(len - 1 + T.pad) * nl + k];
-    if (a) break;
-    len--;
+  for (size_t r = 0; r < batch; r++) {
+    MZK_HIP(hipMemcpyAsync(d_val.p, values + r * n * nl, n * esz, hipMemcpyHostToDevice, s));
+    MZK_HIP(hipMemsetAsync(d_w.p, 0, T.N * esz, s));
+    MZK_TRY(pointwise_div_dev(fid, d_val.p, d_zp.p, d_w.p, n, s));
+    MZK_TRY(T.combine(d_dom.p, d_w.p, d_res.p));
+    MZK_HIP(hipMemcpyAsync(res.data(), d_res.p, T.N * esz, hipMemcpyDeviceToHost, s));
+    MZK_HIP(hipStreamSynchronize(s));
+    // sum_i w_i Z_pad / (X - d_i) = X^pad * interpolant; trimmed like the final `+` (polynomial.rs:214-228)
+    size_t len = n;
+    while (len > 0) {
+      uint64_t a = 0;
+      for (int k = 0; k < nl; k++) a |= res[(len - 1 + T.pad) * nl + k];
+      if (a) break;
+      len--;
+    }
+    memcpy(out + r * n * nl, res.data() + T.pad * nl, len * esz);
+    if (batch > 1 && len < n) memset(out + (r * n + len) * nl, 0, (n - len) * esz);
+    out_lens[r] = len;
   }
-  memcpy(out, res.data() + T.pad * nl, len * esz);
-  *out_len = len;
   return MZK_OK;
 }
 
@@ -604,8 +616,21 @@ int mzk_fast_interpolate(int field_id, const uint64_t* domain, const uint64_t* v
   MZK_TRY(check_root(hf, root, root_order));
   MZK_TRY(check_canonical(hf, domain, n, "domain"));
   MZK_TRY(check_canonical(hf, values, n, "values"));
-  return field_id == MZK_FIELD_M128 ? interpolate_impl<M128Params>(field_id, domain, values, n, root, root_order, out, out_len)
-                                    : interpolate_impl<FrParams>(field_id, domain, values, n, root, root_order, out, out_len);
+  return field_id == MZK_FIELD_M128 ? interpolate_impl<M128Params>(field_id, domain, values, n, 1, root, root_order, out, out_len)
+                                    : interpolate_impl<FrParams>(field_id, domain, values, n, 1, root, root_order, out, out_len);
+}
+int mzk_fast_interpolate_batch(int field_id, const uint64_t* domain, const uint64_t* values, size_t n, size_t batch, const uint64_t* root,
+                               size_t root_order, uint64_t* out, size_t* out_lens) {
+  MZK_TRY(ensure_init());
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fast_interpolate: bad field id %d", field_id); return MZK_E_ARG; }
+  if (batch == 0) return MZK_OK;
+  if (!root || !out_lens || (n && (!domain || !values || !out))) { set_error("fast_interpolate: null pointer"); return MZK_E_ARG; }
+  const HostField* hf = host_field(field_id);
+  MZK_TRY(check_root(hf, root, root_order));
+  MZK_TRY(check_canonical(hf, domain, n, "domain"));
+  MZK_TRY(check_canonical(hf, values, n * batch, "values"));
+  return field_id == MZK_FIELD_M128 ? interpolate_impl<M128Params>(field_id, domain, values, n, batch, root, root_order, out, out_lens)
+                                    : interpolate_impl<FrParams>(field_id, domain, values, n, batch, root, root_order, out, out_lens);
 }
 
 }  // extern "C"

@@ -127,3 +127,28 @@ def test_contract_violations(mz):
     assert e.value.code == -6
     assert mz.fast_zerofier(M128, dom[:0], orc.root_of(M128, 6), 64).shape[0] == 0
     assert mz.fast_interpolate(M128, dom[:1], dom[1:2], orc.root_of(M128, 6), 64).tolist() == dom[1:2].tolist()
+
+
+@pytest.mark.parametrize("fid", [FR, M128])
+def test_batched_interpolation_shares_the_tree_and_equals_single_calls(mz, fid):
+    """mzk_fast_interpolate_batch: the registers of a trace over one domain (fast_stark.rs:203-215) -- every row equal to
+    the single call, including a row of zeros (empty interpolant), a constant row (degree 0: trimmed to one coefficient),
+    the n = 1 and n = 0 conventions, a repeated domain point, and a ragged size just above a tree boundary."""
+    nl = orc.LIMBS[fid]
+    p = orc.MOD[fid]
+    for n, lg in ((1, 3), (2, 3), (65, 8), (300, 10), (1025, 12)):
+        om = orc.root_of(fid, lg)
+        dom = orc.synth_vector(fid, 31 + n, n)
+        if n >= 65:
+            dom[7] = dom[3]                       # repeated point: the reference's inverse(0) = 0 convention
+        vals = np.stack([orc.synth_vector(fid, 900 + k + n, n) for k in range(4)])
+        vals[1] = 0
+        vals[2] = vals[2][0]                      # constant register
+        got = mz.fast_interpolate_batch(fid, dom, vals, om, 1 << lg)
+        assert len(got) == 4
+        for k in range(4):
+            want = mz.fast_interpolate(fid, dom, vals[k], om, 1 << lg)
+            assert got[k].shape == want.shape and np.array_equal(got[k], want), (n, k)
+    empty = mz.fast_interpolate_batch(fid, np.zeros((0, nl), dtype=np.uint64), np.zeros((3, 0, nl), dtype=np.uint64), orc.root_of(fid, 3), 8)
+    assert len(empty) == 3 and all(len(e) == 0 for e in empty)                     # ntt.rs:207-209 per register
+    assert mz.fast_interpolate_batch(fid, orc.synth_vector(fid, 1, 4), np.zeros((0, 4, nl), dtype=np.uint64), orc.root_of(fid, 3), 8) == []
