@@ -302,6 +302,11 @@ int mzk_kzg_commit_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, voi
 int mzk_kzg_commit_srs_batch(const mzk_srs* srs, const uint64_t* coefs, size_t n, size_t count, uint64_t* out_xy);
 int mzk_kzg_commit_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, void* d_out_xy, int max_in_flight,
                                  void* stream);
+/* open_kzg (kzg.rs:61-72) of `count` polynomials of n coefficients each against one SRS, polynomial i at us[4 i .. 4 i + 4)
+ * (repeat the point to open all at one place): d_ys = count * 4 limbs, d_ws_xy = count * 8 limbs, both on the device.  Same
+ * lanes as the batch commit; every (y_i, w_i) bit-identical to mzk_kzg_open_srs_dev. */
+int mzk_kzg_open_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, const uint64_t* us, void* d_ys, void* d_ws_xy,
+                               int max_in_flight, void* stream);
 
 /* open_kzg / setup_kzg with everything device-resident (end-to-end pipelines: iNTT -> commit -> open).
  * d_y: 4 limbs, d_w_xy: 8 limbs on the device; u / alpha / g1 are host parameters. */

@@ -792,17 +792,14 @@ int mzk_kzg_commit_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, voi
                       (hipStream_t)stream);
 }
 
-// count commitments against one SRS, one commit in flight per context of this GPU.  Context k of the same device runs
-// polynomials k, k + K, ... on its own stream and workspace (the bucket reduction / inversion tail and the memory-bound
-// sort of one commit run under the accumulation of the others); the caller's stream forks into them and joins them.
-int mzk_kzg_commit_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, void* d_out_xy, int max_in_flight,
-                                 void* stream) {
-  MZK_TRY(ensure_init());
-  if (!srs || ((!d_coefs || !d_out_xy) && count)) { set_error("commit_srs_batch_dev: null pointer"); return MZK_E_ARG; }
-  MZK_TRY(srs_check_ctx(srs));
-  if (n > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }
-  if (count == 0) return MZK_OK;
-  hipStream_t caller = (hipStream_t)stream;
+}  // extern "C" (the lane scheduler is a template)
+
+// `count` independent jobs (commitments, openings) against one SRS, one job in flight per context of this GPU.  Context k of
+// the same device runs jobs k, k + K, ... on its own stream and workspace (the bucket reduction / inversion tail and the
+// memory-bound sort of one MSM run under the accumulation of the others); the caller's stream forks into them and joins
+// them.  job(i, stream) enqueues job i under the current context.
+template <class JOB>
+static int run_in_flight(size_t count, int max_in_flight, hipStream_t caller, JOB job) {
   const int home = ctx().index, dev = ctx().device;
   int lanes[MZK_MAX_CTX], K = 0;
   lanes[K++] = home;
@@ -810,12 +807,9 @@ int mzk_kzg_commit_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t
   for (int i = 0; i < g_nctx && K < cap; i++)
     if (i != home && g_ctxs[i].ready && g_ctxs[i].device == dev) lanes[K++] = i;
   if ((size_t)K > count) K = (int)count;
-  const char* coefs = (const char*)d_coefs;
-  char* outs = (char*)d_out_xy;
   if (K == 1) {                                         // no second context on this GPU: plain sequence on the caller's stream
     WsGuard wsg(caller);
-    for (size_t i = 0; i < count; i++)
-      MZK_TRY(msm_dev_impl(coefs + i * n * 32, srs->d_points_mont, n, srs->kind(), srs->n, outs + i * 64, false, caller));
+    for (size_t i = 0; i < count; i++) MZK_TRY(job(i, caller));
     return MZK_OK;
   }
   // Lane 0 is the current context ON THE CALLER'S STREAM (no further stream: one of the same priority as the caller's
@@ -828,8 +822,8 @@ int mzk_kzg_commit_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t
   int rc = MZK_OK;
   for (int k = 1; k < K && rc == MZK_OK; k++)
     if (hipStreamWaitEvent(g_ctxs[lanes[k]].stream, h.fork_event, 0) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipStreamWaitEvent", __FILE__, __LINE__);
-  // polynomial i goes to lane i mod K, enqueued in that order: the lanes start one enqueue time apart and stay staggered,
-  // which is what puts one commit's tail under another's accumulation (lane by lane they would start a whole lane's work
+  // job i goes to lane i mod K, enqueued in that order: the lanes start one enqueue time apart and stay staggered,
+  // which is what puts one MSM's tail under another's accumulation (lane by lane they would start a whole lane's work
   // apart and run their accumulations side by side)
   for (size_t i = 0; i < count && rc == MZK_OK; i++) {
     const int k = (int)(i % (size_t)K);
@@ -837,9 +831,9 @@ int mzk_kzg_commit_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t
     if (!scope.ok) { rc = MZK_E_ARG; break; }
     hipStream_t ls = k == 0 ? caller : ctx().stream;
     WsGuard wsg(ls);
-    rc = msm_dev_impl(coefs + i * n * 32, srs->d_points_mont, n, srs->kind(), srs->n, outs + i * 64, false, ls);
+    rc = job(i, ls);
   }
-  // join: the caller's stream continues after every lane's last commit (also after a failure: nothing may be left running
+  // join: the caller's stream continues after every lane's last job (also after a failure: nothing may be left running
   // behind the caller's back)
   for (int k = 1; k < K; k++) {
     Context& c = g_ctxs[lanes[k]];
@@ -850,6 +844,37 @@ int mzk_kzg_commit_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t
     }
   }
   return rc;
+}
+
+extern "C" {
+
+int mzk_kzg_commit_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, void* d_out_xy, int max_in_flight,
+                                 void* stream) {
+  MZK_TRY(ensure_init());
+  if (!srs || ((!d_coefs || !d_out_xy) && count)) { set_error("commit_srs_batch_dev: null pointer"); return MZK_E_ARG; }
+  MZK_TRY(srs_check_ctx(srs));
+  if (n > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }
+  if (count == 0) return MZK_OK;
+  const char* coefs = (const char*)d_coefs;
+  char* outs = (char*)d_out_xy;
+  return run_in_flight(count, max_in_flight, (hipStream_t)stream, [&](size_t i, hipStream_t ls) {
+    return msm_dev_impl(coefs + i * n * 32, srs->d_points_mont, n, srs->kind(), srs->n, outs + i * 64, false, ls);
+  });
+}
+// open_kzg (kzg.rs:61-72) of `count` polynomials, polynomial i at the point us[i]: y_i = f_i(u_i) and the witness
+// commitment w_i, the quotient and its MSM of each opening on one lane
+int mzk_kzg_open_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, const uint64_t* us_host, void* d_ys, void* d_ws_xy,
+                               int max_in_flight, void* stream) {
+  MZK_TRY(ensure_init());
+  if (!srs || ((!d_coefs || !us_host || !d_ys || !d_ws_xy) && count)) { set_error("open_srs_batch_dev: null pointer"); return MZK_E_ARG; }
+  MZK_TRY(srs_check_ctx(srs));
+  if (n > 1 && n - 1 > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }
+  if (count == 0) return MZK_OK;
+  const char* coefs = (const char*)d_coefs;
+  char *ys = (char*)d_ys, *ws = (char*)d_ws_xy;
+  return run_in_flight(count, max_in_flight, (hipStream_t)stream, [&](size_t i, hipStream_t ls) {
+    return kzg_open_dev(coefs + i * n * 32, n, us_host + 4 * i, srs->d_points_mont, srs->kind(), srs->n, ys + i * 32, ws + i * 64, nullptr, ls);
+  });
 }
 int mzk_kzg_commit_srs_batch(const mzk_srs* srs, const uint64_t* coefs, size_t n, size_t count, uint64_t* out_xy) {
   MZK_TRY(ensure_init());

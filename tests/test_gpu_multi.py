@@ -168,3 +168,39 @@ def test_commit_batch_dev_forks_from_and_joins_the_callers_stream(mz):
     for k in range(count):
         assert got[k] == orc.msm_fast(orc.synth_vector(FR, 500 + k, n), p)
     h.close()
+
+
+@pytest.mark.parametrize("nctx", [1, 3])
+def test_open_batch_equals_single_openings(mz, nctx):
+    """mzk_kzg_open_srs_batch_dev: open_kzg (kzg.rs:61-72) of several polynomials, each at its own point, one opening in
+    flight per context -- every (y, w) equal to the single device call and to the definition: y = f(u) by the oracle's
+    Horner, w = the commitment of (f - y) / (X - u)."""
+    import ctypes, torch
+    mz.init_devices([0] * nctx)
+    L = mz.lib()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n, count in ((257, 5), ((1 << 12) + 1, 4)):
+        p = orc.synth_points(300 + n, n)
+        h = mz.Srs(p)
+        coefs = np.stack([orc.synth_vector(FR, 2000 + 7 * k + n, n) for k in range(count)])
+        us = orc.synth_vector(FR, 4000 + n, count)
+        us[1] = us[0]                                     # two polynomials at one point
+        d_c = torch.from_numpy(coefs.view(np.int64).reshape(-1).copy()).cuda()
+        d_y = torch.zeros(count * 4, dtype=torch.int64, device="cuda")
+        d_w = torch.zeros(count * 8, dtype=torch.int64, device="cuda")
+        rc = L.mzk_kzg_open_srs_batch_dev(h._h, ctypes.c_void_p(d_c.data_ptr()), ctypes.c_size_t(n), ctypes.c_size_t(count),
+                                          us.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_y.data_ptr()), ctypes.c_void_p(d_w.data_ptr()), ctypes.c_int(0), st)
+        assert rc == 0, L.mzk_last_error()
+        torch.cuda.synchronize()
+        ys = orc.from_limbs(d_y.cpu().numpy().view(np.uint64).reshape(count, 4))
+        ws = mz.array_to_points(d_w.cpu().numpy().view(np.uint64).reshape(count, 8))
+        y1 = torch.zeros(4, dtype=torch.int64, device="cuda"); w1 = torch.zeros(8, dtype=torch.int64, device="cuda")
+        for k in range(count):
+            u = orc.from_limbs(us[k:k + 1])[0]
+            assert ys[k] == orc.poly_eval(FR, coefs[k], u), (n, k)
+            assert L.mzk_kzg_open_srs_dev(h._h, ctypes.c_void_p(d_c.data_ptr() + k * n * 32), ctypes.c_size_t(n), us[k].ctypes.data_as(ctypes.c_void_p),
+                                          ctypes.c_void_p(y1.data_ptr()), ctypes.c_void_p(w1.data_ptr()), st) == 0
+            torch.cuda.synchronize()
+            assert orc.from_limbs(y1.cpu().numpy().view(np.uint64).reshape(1, 4))[0] == ys[k]
+            assert mz.array_to_points(w1.cpu().numpy().view(np.uint64).reshape(1, 8))[0] == ws[k]
+        h.close()
