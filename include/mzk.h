@@ -298,7 +298,8 @@ int mzk_kzg_commit_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, voi
  * the SRS handle shared), so the latency-bound tail of one commit runs under the bucket accumulation of the others:
  * 1.40 instead of 1.64 ms per 2^20-coefficient commit with four contexts.  With a single context the commits simply
  * run one after the other.  The _dev form forks from and joins `stream`; max_in_flight caps the contexts it uses
- * (0 = all of this GPU's, at most four: more measured slower). */
+ * (0 = up to four: more measured slower except for the smallest commitments; an explicit value may go up to eight).  The
+ * lanes want hardware queues of their own: with more than four streams alive on the GPU set GPU_MAX_HW_QUEUES=8. */
 int mzk_kzg_commit_srs_batch(const mzk_srs* srs, const uint64_t* coefs, size_t n, size_t count, uint64_t* out_xy);
 int mzk_kzg_commit_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, void* d_out_xy, int max_in_flight,
                                  void* stream);

@@ -803,7 +803,8 @@ static int run_in_flight(size_t count, int max_in_flight, hipStream_t caller, JO
   const int home = ctx().index, dev = ctx().device;
   int lanes[MZK_MAX_CTX], K = 0;
   lanes[K++] = home;
-  const int cap = (max_in_flight >= 1 && max_in_flight < 4) ? max_in_flight : 4;      // more than four in flight measured slower
+  // default four: more in flight measured slower at 2^20; an explicit request may go up to eight
+  const int cap = max_in_flight < 1 ? 4 : (max_in_flight > 8 ? 8 : max_in_flight);
   for (int i = 0; i < g_nctx && K < cap; i++)
     if (i != home && g_ctxs[i].ready && g_ctxs[i].device == dev) lanes[K++] = i;
   if ((size_t)K > count) K = (int)count;
