@@ -45,21 +45,10 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 typedef int32_t i32;
 
-// col + a * b.  With -DMZK_MAD_ASM (device code only) the multiply-add is pinned as ONE v_mad_u64_u32 whose addend is
-// the running column: hipcc otherwise starts every column of a product from zero and adds the previous column's carry
-// with an extra v_lshl_add_u64 (17 more half-rate instructions per product, bought for instruction-level parallelism).
-// Measured (tools/microbench/batched_affine_bound.hip, xyzz_madd loop): pinned 16.13 vs 15.91 G additions/s at 4
-// workgroups per CU (+1.4 %), but 9.9 vs 12.6 G/s at one wave per SIMD (-22 %: the latency-bound tail kernels live
-// there) -- so it stays off.
-#if defined(MZK_MAD_ASM) && defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ uint64_t mzk_mad(uint32_t a, uint32_t b, uint64_t c) {
-  uint64_t r, carry;
-  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-#else
+// col + a * b: one v_mad_u64_u32.  hipcc starts every column of a product from zero and adds the previous column's carry
+// with an extra v_lshl_add_u64 (instruction-level parallelism for a lone wave); the throughput kernels use the
+// hand-scheduled single-chain forms of mzk_field_asm.h instead (FeAsm: 214 instead of ~255 instructions per product).
 MZK_HD uint64_t mzk_mad(uint32_t a, uint32_t b, uint64_t c) { return c + (uint64_t)a * b; }
-#endif
 
 constexpr int W29 = 29;
 constexpr u32 MASK29 = (1u << 29) - 1u;
