@@ -177,6 +177,13 @@ int mzk_merkle_root(const mzk_merkle* tree, uint8_t* root, size_t cap, size_t* r
 /* Merkle::open (merkle.rs:28-46): entry k of the bottom-up path goes to path + k * stride, its length to
  * path_len[k] (entry 0 is the sibling leaf verbatim, the rest are 32-byte digests); *depth = log2 n entries. */
 int mzk_merkle_open(const mzk_merkle* tree, size_t index, uint8_t* path, size_t stride, uint64_t* path_len, size_t* depth);
+/* `count` openings of one tree in one gather and one copy -- the FRI query phase opens three indices per colinearity test
+ * and round (fri.rs:211-260; the reference's Merkle::open re-hashes the whole tree for each).  Path q, entry l:
+ * paths[(q * depth + l) * stride ..], length path_lens[q * depth + l]; *depth entries per path, each path exactly what
+ * mzk_merkle_open returns for indices[q].  Trees over field elements with a power-of-two leaf count (every codeword the
+ * provers commit to); byte-leaf and ragged trees: MZK_E_ARG, open those one by one. */
+int mzk_merkle_open_batch(const mzk_merkle* tree, const uint64_t* indices, size_t count, uint8_t* paths, size_t stride, uint64_t* path_lens,
+                          size_t* depth);
 void mzk_merkle_free(mzk_merkle* tree);
 /* one-shot Merkle::commit(codeword.map(bincode::serialize)) */
 int mzk_merkle_commit_field(int field_id, const uint64_t* elems, size_t n, uint8_t* root, size_t cap, size_t* root_len);

@@ -443,6 +443,18 @@ class MerkleTree:
         raw = bytes(buf)
         return [raw[k * self.stride:k * self.stride + lens[k]] for k in range(depth.value)]
 
+    def open_many(self, indices):
+        """Merkle::open for every index in one gather (mzk_merkle_open_batch): list of paths as `open` returns them."""
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        count = idx.shape[0]
+        depth_cap = max(self.n.bit_length(), 1)
+        buf = (ctypes.c_uint8 * max(self.stride * depth_cap * count, 1))()
+        lens = (ctypes.c_uint64 * max(depth_cap * count, 1))()
+        depth = ctypes.c_size_t()
+        _check(lib().mzk_merkle_open_batch(self._h, _p(idx), ctypes.c_size_t(count), buf, ctypes.c_size_t(self.stride), lens, ctypes.byref(depth)))
+        raw, d = bytes(buf), depth.value
+        return [[raw[(q * d + k) * self.stride:(q * d + k) * self.stride + lens[q * d + k]] for k in range(d)] for q in range(count)]
+
     def close(self):
         if self._h:
             lib().mzk_merkle_free(self._h)

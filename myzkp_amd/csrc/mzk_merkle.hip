@@ -351,6 +351,23 @@ __global__ void k_merkle_gather(const u64* __restrict__ nodes, size_t n, size_t 
   for (int q = 0; q < 4; q++) out[4 * (l - 1) + q] = src[q];
 }
 
+// many authentication paths at once (the FRI query phase opens three indices per colinearity test and round): block q
+// gathers the digests of path q and the limbs of its sibling leaf
+__global__ __launch_bounds__(64) void k_merkle_gather_batch(const u64* __restrict__ nodes, const u32* __restrict__ leaves, int leaf_words, size_t n,
+                                                            const u64* __restrict__ indices, int depth, u64* __restrict__ out_nodes,
+                                                            u32* __restrict__ out_leaves) {
+  const size_t q = blockIdx.x;
+  const size_t index = indices[q];
+  const int l = 1 + threadIdx.x;
+  if (l < depth) {
+    const size_t start = n - (n >> (l - 1));
+    const u64* src = nodes + 4 * (start + ((index >> l) ^ 1));
+#pragma unroll
+    for (int k = 0; k < 4; k++) out_nodes[(q * (size_t)(depth - 1) + (l - 1)) * 4 + k] = src[k];
+  }
+  if ((int)threadIdx.x < leaf_words) out_leaves[q * leaf_words + threadIdx.x] = leaves[(index ^ 1) * leaf_words + threadIdx.x];
+}
+
 }  // namespace mzk
 
 using namespace mzk;
@@ -687,6 +704,60 @@ int mzk_merkle_open(const mzk_merkle* t, size_t index, uint8_t* path, size_t str
     MZK_HIP(hipStreamSynchronize(s));
   }
   *depth = (size_t)t->depth;
+  return MZK_OK;
+}
+
+// `count` openings of one tree: paths[(q * depth + l) * stride ..] / path_lens[q * depth + l] as mzk_merkle_open writes them
+// for index indices[q]; *depth entries per path.  Field-element trees with a power-of-two leaf count (every codeword of
+// the provers): ONE gather launch and ONE copy for all paths.  Byte-leaf and ragged trees: MZK_E_ARG (open one by one).
+int mzk_merkle_open_batch(const mzk_merkle* t, const uint64_t* indices, size_t count, uint8_t* paths, size_t stride, uint64_t* path_lens,
+                          size_t* depth) {
+  if (!t || !depth || ((!indices || !paths || !path_lens) && count)) { set_error("merkle_open_batch: null pointer"); return MZK_E_ARG; }
+  if (t->n < 2) { set_error("merkle_open: needs at least two leaves (merkle.rs:32)"); return MZK_E_LENGTH; }
+  if (t->ragged || t->kind != 0) {
+    set_error("merkle_open_batch: field-element trees with a power-of-two leaf count only (this one: %s); open its paths one by one",
+              t->kind != 0 ? "byte leaves" : "ragged");
+    return MZK_E_ARG;
+  }
+  *depth = (size_t)t->depth;
+  if (count == 0) return MZK_OK;
+  if (stride < 32) { set_error("merkle_open: stride < 32"); return MZK_E_LENGTH; }
+  for (size_t q = 0; q < count; q++)
+    if (indices[q] >= t->n) { set_error("merkle_open: index %llu out of range", (unsigned long long)indices[q]); return MZK_E_LENGTH; }
+  MZK_TRY(ensure_init());
+  hipStream_t s = t->stream;
+  WsGuard wsg(s);
+  const int lw = (int)field_words(t->field), nl = field_limbs64(t->field);
+  const size_t node_words64 = count * (size_t)(t->depth - 1) * 4;
+  u64 *d_idx, *d_on;
+  u32* d_ol;
+  MZK_TRY(ws_get(WS_MISC_C, count * 8 + node_words64 * 8 + count * (size_t)lw * 4 + 64, (void**)&d_idx));
+  d_on = d_idx + count;
+  d_ol = (u32*)(d_on + node_words64);
+  MZK_HIP(hipMemcpyAsync(d_idx, indices, count * 8, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_merkle_gather_batch, dim3((unsigned)count), dim3(64), 0, s, (const u64*)t->d_nodes, (const u32*)t->d_leaves, lw, t->n,
+                     (const u64*)d_idx, t->depth, d_on, d_ol);
+  MZK_HIP(hipGetLastError());
+  std::vector<uint64_t> hn(node_words64 + 1);
+  std::vector<uint32_t> hl(count * (size_t)lw);
+  if (node_words64) MZK_HIP(hipMemcpyAsync(hn.data(), d_on, node_words64 * 8, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipMemcpyAsync(hl.data(), d_ol, count * (size_t)lw * 4, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  for (size_t q = 0; q < count; q++) {
+    uint64_t limbs[4] = {0, 0, 0, 0};
+    memcpy(limbs, hl.data() + q * lw, (size_t)lw * 4);
+    uint8_t buf[48];
+    const size_t sib = (size_t)indices[q] ^ 1;
+    const size_t len = host_bincode_field(limbs, nl, buf, !t->neg.empty() && t->neg[sib]);
+    if (stride < len) { set_error("merkle_open: stride %zu < leaf length %zu", stride, len); return MZK_E_LENGTH; }
+    uint8_t* pq = paths + q * (size_t)t->depth * stride;
+    memcpy(pq, buf, len);
+    path_lens[q * (size_t)t->depth] = len;
+    for (int l = 1; l < t->depth; l++) {
+      memcpy(pq + (size_t)l * stride, hn.data() + (q * (size_t)(t->depth - 1) + (l - 1)) * 4, 32);
+      path_lens[q * (size_t)t->depth + l] = 32;
+    }
+  }
   return MZK_OK;
 }
 

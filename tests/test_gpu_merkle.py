@@ -304,3 +304,35 @@ def test_batched_commit_equals_single_commits(fid):
     for bad in (1, 6):
         with pytest.raises(mz.MzkError):
             mz.merkle_commit_field_batch(fid, np.zeros((2, bad, nl), dtype=np.uint64))
+
+
+@pytest.mark.parametrize("fid,lg", [(M128, 1), (M128, 2), (M128, 12), (FR, 5), (FR, 11)])
+def test_open_many_equals_single_openings_and_the_oracle(mz, fid, lg):
+    """mzk_merkle_open_batch: the FRI query phase's openings (fri.rs:211-260) in one gather -- every path equal to
+    Merkle::open (merkle.rs:27-46) by the oracle and to the single call; repeated indices, the signed-leaf tree, zero
+    openings; byte-leaf and ragged trees are refused."""
+    n = 1 << lg
+    arr = _edge_vector(fid, 900 + lg, n)
+    leaves = orc.field_leaves(fid, arr)
+    t = mz.MerkleTree(fid, arr)
+    rnd = random.Random(100 + lg)
+    idx = [0, 1, n - 1, n // 2, 0] + [rnd.randrange(n) for _ in range(40)]
+    paths = t.open_many(idx)
+    assert len(paths) == len(idx)
+    for q, i in enumerate(idx):
+        assert paths[q] == orc.merkle_open_ref(i, leaves), (q, i)
+    assert paths[3] == t.open(n // 2)
+    assert t.open_many([]) == []
+    with pytest.raises(mz.MzkError):
+        t.open_many([n])
+    t.close()
+    if lg >= 2:
+        neg = np.array([(k % 3) == 0 for k in range(n)], dtype=np.uint8)
+        ts = mz.MerkleTree(fid, arr, negative=neg)
+        ps = ts.open_many([1, n - 2])
+        assert ps == [ts.open(1), ts.open(n - 2)]
+        ts.close()
+        tb = mz.MerkleTree(leaves=[b"a", b"bb", b"ccc", b"dddd"])
+        with pytest.raises(mz.MzkError):
+            tb.open_many([1])
+        tb.close()
