@@ -627,6 +627,8 @@ int mzk_merkle_root(const mzk_merkle* t, uint8_t* root, size_t cap, size_t* root
   return MZK_OK;
 }
 
+int mzk_merkle_open_batch(const mzk_merkle* t, const uint64_t* indices, size_t count, uint8_t* paths, size_t stride, uint64_t* path_lens,
+                          size_t* depth);
 int mzk_merkle_open(const mzk_merkle* t, size_t index, uint8_t* path, size_t stride, uint64_t* path_len, size_t* depth) {
   if (!t || !path || !path_len || !depth) { set_error("merkle_open: null pointer"); return MZK_E_ARG; }
   if (t->n < 2) { set_error("merkle_open: needs at least two leaves (merkle.rs:32)"); return MZK_E_LENGTH; }
@@ -674,18 +676,13 @@ int mzk_merkle_open(const mzk_merkle* t, size_t index, uint8_t* path, size_t str
     *depth = (size_t)t->depth + k;
     return MZK_OK;
   }
+  if (t->kind == 0) {        // field-element tree: sibling leaf and digests in one gather and one synchronisation
+    const uint64_t idx64 = (uint64_t)index;
+    return mzk_merkle_open_batch(t, &idx64, 1, path, stride, path_len, depth);
+  }
   const size_t sib = index ^ 1;
-  // entry 0: the sibling LEAF, verbatim
-  if (t->kind == 0) {
-    uint64_t limbs[4];
-    uint8_t buf[48];
-    MZK_HIP(hipMemcpyAsync(limbs, (const uint8_t*)t->d_leaves + sib * field_bytes(t->field), field_bytes(t->field), hipMemcpyDeviceToHost, s));
-    MZK_HIP(hipStreamSynchronize(s));
-    const size_t len = host_bincode_field(limbs, field_limbs64(t->field), buf, !t->neg.empty() && t->neg[sib]);
-    if (stride < len) { set_error("merkle_open: stride %zu < leaf length %zu", stride, len); return MZK_E_LENGTH; }
-    memcpy(path, buf, len);
-    path_len[0] = len;
-  } else {
+  // byte leaves: entry 0 is the sibling LEAF, verbatim
+  {
     const size_t len = (size_t)(t->offsets[sib + 1] - t->offsets[sib]);
     if (stride < len) { set_error("merkle_open: stride %zu < leaf length %zu", stride, len); return MZK_E_LENGTH; }
     if (len) MZK_HIP(hipMemcpyAsync(path, (const uint8_t*)t->d_leaves + t->offsets[sib], len, hipMemcpyDeviceToHost, s));
