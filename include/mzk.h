@@ -220,6 +220,13 @@ int mzk_fri_commit(int field_id, const uint64_t* codeword, size_t n, const uint6
                    mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out);
 int mzk_fri_commit_signed(int field_id, const uint64_t* magnitudes, const uint8_t* negative, size_t n, const uint64_t* omega, const uint64_t* offset,
                           int num_rounds, mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out);
+/* The same loop (negative may be NULL: then `magnitudes` are the canonical elements), and the Merkle tree of every round
+ * stays on the device for the query phase: trees_out[r] (num_rounds handles, NULL for a one-element round) opens with
+ * mzk_merkle_open / mzk_merkle_open_batch exactly as Merkle::open on that round's codeword would (fri.rs:211-260); free each
+ * with mzk_merkle_free. */
+int mzk_fri_commit_keep_trees(int field_id, const uint64_t* magnitudes, const uint8_t* negative, size_t n, const uint64_t* omega,
+                              const uint64_t* offset, int num_rounds, mzk_fri_challenge_fn challenge, void* user, uint8_t* roots,
+                              uint64_t* root_len, uint64_t* codewords_out, mzk_merkle** trees_out);
 
 /* ---- G2 (BN254 twist over Fq2 = Fq[u]/(u^2+1); bn128.rs:33-49) ------------------------------------------------
  * A G2 point is 16 limbs: x.c0 | x.c1 | y.c0 | y.c1 (4 limbs each, canonical); all-zero = infinity.

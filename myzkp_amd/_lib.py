@@ -480,10 +480,12 @@ _FRI_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c
                            ctypes.POINTER(ctypes.c_uint64))
 
 
-def fri_commit(fid, codeword, omega, offset, num_rounds, challenge, negative=None):
+def fri_commit(fid, codeword, omega, offset, num_rounds, challenge, negative=None, keep_trees=False):
     """FRI::commit (zkstark/fri.rs:144-209), codewords resident in HBM.  challenge(round, last, root_bytes) -> alpha
     (int; ignored when last).  Returns (codewords, roots).  negative: optional Sign::Minus flags of the initial
-    codeword, then given as magnitudes (round 0 commits to the unsanitized elements, fri.rs:160-166)."""
+    codeword, then given as magnitudes (round 0 commits to the unsanitized elements, fri.rs:160-166).
+    keep_trees: also return the rounds' Merkle trees (MerkleTree objects on the device, None for a one-element round)
+    for the query phase: (codewords, roots, trees)."""
     c = _arr(fid, codeword)
     n, nl = c.shape[0], LIMBS[fid]
 
@@ -512,7 +514,12 @@ def fri_commit(fid, codeword, omega, offset, num_rounds, challenge, negative=Non
     allcw = np.zeros((max(total, 1), nl), dtype=np.uint64)
     w, o = _one(fid, omega), _one(fid, offset)
     fn = _FRI_CB(cb)
-    if negative is not None:
+    handles = (ctypes.c_void_p * max(num_rounds, 1))()
+    if keep_trees:
+        ng = None if negative is None else np.ascontiguousarray(negative, dtype=np.uint8)
+        rc = lib().mzk_fri_commit_keep_trees(fid, _p(c), None if ng is None else _p(ng), ctypes.c_size_t(n), _p(w), _p(o), int(num_rounds), fn, None,
+                                             roots, lens, _p(allcw), handles)
+    elif negative is not None:
         ng = np.ascontiguousarray(negative, dtype=np.uint8)
         rc = lib().mzk_fri_commit_signed(fid, _p(c), _p(ng), ctypes.c_size_t(n), _p(w), _p(o), int(num_rounds), fn, None, roots, lens, _p(allcw))
     else:
@@ -526,6 +533,18 @@ def fri_commit(fid, codeword, omega, offset, num_rounds, challenge, negative=Non
         cws.append(allcw[at:at + (n >> r)].copy())
         rts.append(raw[48 * r:48 * r + lens[r]])
         at += n >> r
+    if keep_trees:
+        trees = []
+        for r in range(num_rounds):
+            if not handles[r]:
+                trees.append(None)
+                continue
+            t = MerkleTree.__new__(MerkleTree)
+            t._h = ctypes.c_void_p(handles[r])
+            t.n = n >> r
+            t.stride = 48
+            trees.append(t)
+        return cws, rts, trees
     return cws, rts
 
 

@@ -859,8 +859,24 @@ int mzk_merkle_commit_bytes(const uint8_t* leaves, const uint64_t* offsets, size
 // Outputs: roots (num_rounds entries of 48 bytes, lengths in root_len: 32, or the leaf bytes once a codeword has
 // shrunk to one element) and all num_rounds codewords concatenated (n + n/2 + ... elements) -- the reference's
 // return value `(codewords, roots)`; sending the last codeword (fri.rs:198-206) is the caller's transcript work.
+static int fri_commit_rounds(int field_id, const uint64_t* codeword, const uint8_t* negative, size_t n, const uint64_t* omega, const uint64_t* offset,
+                             int num_rounds, mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out,
+                             mzk_merkle** trees_out);
+// trees_out (optional, num_rounds entries): the Merkle tree of every round's codeword stays on the device as a handle for the
+// query phase (mzk_merkle_open_batch; fri.rs:211-260 opens from exactly these codewords); a one-element round gets NULL.
+// On failure every handle made so far is released.
 static int fri_commit_impl(int field_id, const uint64_t* codeword, const uint8_t* negative, size_t n, const uint64_t* omega, const uint64_t* offset,
-                           int num_rounds, mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out) {
+                           int num_rounds, mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out,
+                           mzk_merkle** trees_out = nullptr) {
+  if (trees_out) for (int r = 0; r < num_rounds; r++) trees_out[r] = nullptr;
+  const int rc = fri_commit_rounds(field_id, codeword, negative, n, omega, offset, num_rounds, challenge, user, roots, root_len, codewords_out, trees_out);
+  if (rc != MZK_OK && trees_out)
+    for (int r = 0; r < num_rounds; r++) { if (trees_out[r]) mzk_merkle_free(trees_out[r]); trees_out[r] = nullptr; }
+  return rc;
+}
+static int fri_commit_rounds(int field_id, const uint64_t* codeword, const uint8_t* negative, size_t n, const uint64_t* omega, const uint64_t* offset,
+                             int num_rounds, mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out,
+                             mzk_merkle** trees_out) {
   MZK_TRY(ensure_init());
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fri_commit: bad field id %d", field_id); return MZK_E_ARG; }
   if (num_rounds <= 0) return MZK_OK;
@@ -901,6 +917,17 @@ static int fri_commit_impl(int field_id, const uint64_t* codeword, const uint8_t
     } else {
       MZK_TRY(merkle_hash_levels(0, field_id, cur, nullptr, len, d_nodes, s, r == 0 ? d_neg : nullptr));
       MZK_HIP(hipMemcpyAsync(root, d_nodes + 4 * (len - 2), 32, hipMemcpyDeviceToHost, s));
+      if (trees_out) {      // keep this round's tree: its own copy of the leaves (round 0: still unsanitized) and of the digests
+        mzk_merkle* t = new mzk_merkle();
+        t->kind = 0; t->field = field_id; t->n = len; t->stream = s; t->d_nodes = nullptr; t->d_leaves = nullptr;
+        t->depth = 0;
+        while (((size_t)1 << t->depth) < len) t->depth++;
+        trees_out[r] = t;
+        if (hipMalloc(&t->d_leaves, len * esz) != hipSuccess || hipMalloc((void**)&t->d_nodes, (len - 1) * 32) != hipSuccess) { set_error("fri_commit: hipMalloc failed"); return MZK_E_HIP; }
+        MZK_HIP(hipMemcpyAsync(t->d_leaves, cur, len * esz, hipMemcpyDeviceToDevice, s));
+        MZK_HIP(hipMemcpyAsync(t->d_nodes, d_nodes, (len - 1) * 32, hipMemcpyDeviceToDevice, s));
+        if (r == 0 && negative) t->neg.assign(negative, negative + n);
+      }
       MZK_HIP(hipStreamSynchronize(s));
       root_len[r] = 32;
     }
@@ -933,6 +960,12 @@ int mzk_fri_commit(int field_id, const uint64_t* codeword, size_t n, const uint6
 int mzk_fri_commit_signed(int field_id, const uint64_t* magnitudes, const uint8_t* negative, size_t n, const uint64_t* omega, const uint64_t* offset,
                           int num_rounds, mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out) {
   return fri_commit_impl(field_id, magnitudes, negative, n, omega, offset, num_rounds, challenge, user, roots, root_len, codewords_out);
+}
+int mzk_fri_commit_keep_trees(int field_id, const uint64_t* magnitudes, const uint8_t* negative, size_t n, const uint64_t* omega, const uint64_t* offset,
+                              int num_rounds, mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out,
+                              mzk_merkle** trees_out) {
+  if (!trees_out && num_rounds > 0) { set_error("fri_commit_keep_trees: null handle array"); return MZK_E_ARG; }
+  return fri_commit_impl(field_id, magnitudes, negative, n, omega, offset, num_rounds, challenge, user, roots, root_len, codewords_out, trees_out);
 }
 
 }  // extern "C"

@@ -336,3 +336,41 @@ def test_open_many_equals_single_openings_and_the_oracle(mz, fid, lg):
         with pytest.raises(mz.MzkError):
             tb.open_many([1])
         tb.close()
+
+
+@pytest.mark.parametrize("fid,lg,rounds,signed", [(M128, 10, 6, False), (FR, 6, 4, False), (M128, 3, 4, False), (M128, 8, 5, True)])
+def test_fri_commit_keeps_the_round_trees_for_the_query_phase(mz, fid, lg, rounds, signed):
+    """mzk_fri_commit_keep_trees: same codewords and roots as the plain loop, plus one device-resident tree per round whose
+    openings are Merkle::open on that round's codeword (fri.rs:211-260 opens a, b from round r and c from round r + 1);
+    a one-element round has no tree; round 0 of the signed form opens the unsanitized leaves."""
+    n = 1 << lg
+    p = orc.MOD[fid]
+    cw = orc.synth_vector(fid, 1300 + lg, n)
+    neg = np.array([(k % 5) == 1 for k in range(n)], dtype=np.uint8) if signed else None
+    omega, offset = orc.root_of(fid, lg), (orc.M128_GEN if fid == M128 else 5)
+
+    def challenge(rnd, last, root):
+        return None if last else int.from_bytes(hashlib.sha3_256(root + bytes([rnd])).digest(), "little") % p
+
+    cws0, roots0 = mz.fri_commit(fid, cw, omega, offset, rounds, challenge, negative=neg)
+    cws, roots, trees = mz.fri_commit(fid, cw, omega, offset, rounds, challenge, negative=neg, keep_trees=True)
+    assert roots == roots0 and all(np.array_equal(a, b) for a, b in zip(cws, cws0))
+    rnd = random.Random(lg)
+    for r in range(rounds):
+        m = n >> r
+        if m < 2:
+            assert trees[r] is None
+            continue
+        if r == 0 and signed:
+            leaves = [orc.bincode_field_signed(v, orc.LIMBS[fid], s) for v, s in zip(orc.from_limbs(cw), neg)]
+        else:
+            leaves = orc.field_leaves(fid, cws[r])
+        assert trees[r].root() == roots[r]
+        idx = [rnd.randrange(m) for _ in range(9)] + [0, m - 1]
+        paths = trees[r].open_many(idx)
+        for q, i in enumerate(idx):
+            assert paths[q] == orc.merkle_open_ref(i, leaves), (r, i)
+            assert orc.merkle_verify_ref(roots[r], i, paths[q], leaves[i])
+    for t in trees:
+        if t is not None:
+            t.close()
