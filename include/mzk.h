@@ -145,7 +145,7 @@ int mzk_fast_interpolate(int field_id, const uint64_t* domain, const uint64_t* v
                          uint64_t* out, size_t* out_len);
 /* fast_interpolate of `batch` value vectors over ONE domain -- the registers of a trace (fast_stark.rs:203-215 calls it
  * once per register with the same trace_domain): the subproduct tree and the derivative values Z'(d_i), ~80 % of one
- * interpolation, are built once.  values: batch * n elements; out: batch rows of n elements (row r holds out_lens[r]
+ * interpolation, are built once, and the registers share the launches of the up-sweep.  values: batch * n elements; out: batch rows of n elements (row r holds out_lens[r]
  * coefficients, zero-padded).  Each row bit-identical to the single call. */
 int mzk_fast_interpolate_batch(int field_id, const uint64_t* domain, const uint64_t* values, size_t n, size_t batch, const uint64_t* root,
                                size_t root_order, uint64_t* out, size_t* out_lens);

@@ -20,6 +20,7 @@
 //     of size 2D per node, re-using the transformed low parts kept from the way up), and a 64-point finish per wave;
 //   * interpolation: weights w_i = v_i / Z'(d_i) (Z' evaluated as above), then the same tree upwards:
 //     P_parent = X^D (P_l + P_r) + P_l Z_r' + P_r Z_l'.
+#include <algorithm>
 #include <vector>
 #include "mzk_common.h"
 #include "mzk_field_asm.h"
@@ -257,10 +258,15 @@ __global__ __launch_bounds__(256) void k_derivative(const u32* __restrict__ low_
 // coefficients are summed over the wave; out0[chunk * 64 + k] = coefficient k
 template <class P>
 __global__ __launch_bounds__(64) void k_chunk_combine(const u32* __restrict__ domain, const u32* __restrict__ w, size_t n, const u32* __restrict__ low0,
-                                                      u32* __restrict__ out0) {
+                                                      u32* __restrict__ out0, size_t chunks) {
+  // blockIdx.x = register * chunks + chunk: the weights and the output of register r are N = chunks * 64 elements apart,
+  // the domain and the level-0 zerofiers are shared
   __shared__ u32 sh_z[CHUNK * P::NW];
   const int lane = threadIdx.x;
-  const size_t idx = (size_t)blockIdx.x * CHUNK + lane;
+  const size_t reg = blockIdx.x / chunks;
+  const size_t idx = ((size_t)blockIdx.x - reg * chunks) * CHUNK + lane;
+  w += reg * chunks * CHUNK * P::NW;
+  out0 += reg * chunks * CHUNK * P::NW;
   pl_store<P>(sh_z, lane, pl_load<P>(low0, idx));
   __syncthreads();
   Fe<P> x = fe_zero<P>(), wi = fe_zero<P>();
@@ -277,12 +283,14 @@ __global__ __launch_bounds__(64) void k_chunk_combine(const u32* __restrict__ do
 }
 // W[q * 2D + k] = Pl[k] Zr[k] + Pr[k] Zl[k]   (all transformed, children q*2, q*2+1 of degree D)
 template <class P>
-__global__ __launch_bounds__(256) void k_up_mul(const u32* __restrict__ Phat, const u32* __restrict__ Zhat, int lgD, size_t total, u32* __restrict__ W) {
+__global__ __launch_bounds__(256) void k_up_mul(const u32* __restrict__ Phat, const u32* __restrict__ Zhat, int lgD, size_t total, u32* __restrict__ W,
+                                                size_t zmask) {
+  // several registers back to back share one tree: Phat / W run over all of them, Zhat (2N elements) is indexed modulo 2N
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
   const size_t q = e >> (lgD + 1), k = e & (((size_t)2 << lgD) - 1);
   const size_t a = ((2 * q) << (lgD + 1)) + k, b = a + ((size_t)2 << lgD);
-  pl_store<P>(W, e, pl_add<P>(pl_mul<P>(pl_load<P>(Phat, a), pl_load<P>(Zhat, b)), pl_mul<P>(pl_load<P>(Phat, b), pl_load<P>(Zhat, a))));
+  pl_store<P>(W, e, pl_add<P>(pl_mul<P>(pl_load<P>(Phat, a), pl_load<P>(Zhat, b & zmask)), pl_mul<P>(pl_load<P>(Phat, b), pl_load<P>(Zhat, a & zmask))));
 }
 
 // ---- host orchestration ----------------------------------------------------------------------------------------
@@ -385,21 +393,24 @@ template <class P> struct PolyTree {
     return MZK_OK;
   }
   // sum_i w_i Z_pad / (X - x_i) -> N coefficients in d_out (weights of padded points are ignored: treated as 0)
-  int combine(const void* d_domain, const void* d_w, void* d_out) {
+  // d_w: regs weight vectors, N elements apart; d_out: regs results of N coefficients each
+  int combine(const void* d_domain, const void* d_w, void* d_out, size_t regs = 1) {
     const size_t esz = field_bytes(fid);
+    const size_t M = N * regs;
     DevBuf cur, nxt, Ph, W;
-    MZK_TRY(cur.alloc(N * esz)); MZK_TRY(nxt.alloc(N * esz)); MZK_TRY(Ph.alloc(2 * N * esz)); MZK_TRY(W.alloc(N * esz));
-    hipLaunchKernelGGL((k_chunk_combine<P>), dim3((unsigned)(N / CHUNK)), dim3(64), 0, s, (const u32*)d_domain, (const u32*)d_w, n, (const u32*)low[0].w(), cur.w());
+    MZK_TRY(cur.alloc(M * esz)); MZK_TRY(nxt.alloc(M * esz)); MZK_TRY(Ph.alloc(2 * M * esz)); MZK_TRY(W.alloc(M * esz));
+    hipLaunchKernelGGL((k_chunk_combine<P>), dim3((unsigned)(M / CHUNK)), dim3(64), 0, s, (const u32*)d_domain, (const u32*)d_w, n, (const u32*)low[0].w(), cur.w(),
+                       N / CHUNK);
     for (int l = 0; l < levels; l++) {
       const int lgD = 6 + l;
-      hipLaunchKernelGGL((k_pad_double<P>), dim3(grid256(2 * N)), dim3(256), 0, s, (const u32*)cur.w(), lgD, 2 * N, Ph.w());
-      MZK_TRY(ntt(Ph.p, (size_t)2 << lgD, N >> lgD, 0));
-      hipLaunchKernelGGL((k_up_mul<P>), dim3(grid256(N)), dim3(256), 0, s, (const u32*)Ph.w(), (const u32*)Zhat[l].w(), lgD, N, W.w());
-      MZK_TRY(ntt(W.p, (size_t)2 << lgD, N >> (lgD + 1), 1));
-      hipLaunchKernelGGL((k_monic_fixup<P>), dim3(grid256(N)), dim3(256), 0, s, (const u32*)W.w(), (const u32*)cur.w(), lgD, N, nxt.w());
+      hipLaunchKernelGGL((k_pad_double<P>), dim3(grid256(2 * M)), dim3(256), 0, s, (const u32*)cur.w(), lgD, 2 * M, Ph.w());
+      MZK_TRY(ntt(Ph.p, (size_t)2 << lgD, M >> lgD, 0));
+      hipLaunchKernelGGL((k_up_mul<P>), dim3(grid256(M)), dim3(256), 0, s, (const u32*)Ph.w(), (const u32*)Zhat[l].w(), lgD, M, W.w(), 2 * N - 1);
+      MZK_TRY(ntt(W.p, (size_t)2 << lgD, M >> (lgD + 1), 1));
+      hipLaunchKernelGGL((k_monic_fixup<P>), dim3(grid256(M)), dim3(256), 0, s, (const u32*)W.w(), (const u32*)cur.w(), lgD, M, nxt.w());
       std::swap(cur.p, nxt.p);
     }
-    MZK_HIP(hipMemcpyAsync(d_out, cur.p, N * esz, hipMemcpyDeviceToDevice, s));
+    MZK_HIP(hipMemcpyAsync(d_out, cur.p, M * esz, hipMemcpyDeviceToDevice, s));
     MZK_HIP(hipGetLastError());
     MZK_HIP(hipStreamSynchronize(s));
     return MZK_OK;
@@ -548,34 +559,43 @@ static int interpolate_impl(int fid, const uint64_t* domain, const uint64_t* val
   PolyTree<P> T;
   MZK_TRY(check_order_for(n - n / 2, root_order, "fast_interpolate"));        // ntt.rs:219-220
   MZK_TRY(tree_init(&T, fid, n, root, root_order, s));
-  DevBuf d_dom, d_val, d_dz, d_zp, d_w, d_res;
-  MZK_TRY(d_dom.alloc(n * esz)); MZK_TRY(d_val.alloc(n * esz)); MZK_TRY(d_dz.alloc(n * esz)); MZK_TRY(d_zp.alloc(T.N * esz));
-  MZK_TRY(d_w.alloc(T.N * esz)); MZK_TRY(d_res.alloc(T.N * esz));
+  DevBuf d_dom, d_dz, d_zp;
+  MZK_TRY(d_dom.alloc(n * esz)); MZK_TRY(d_dz.alloc(n * esz)); MZK_TRY(d_zp.alloc(T.N * esz));
   MZK_HIP(hipMemcpyAsync(d_dom.p, domain, n * esz, hipMemcpyHostToDevice, s));
   MZK_TRY(T.build(d_dom.p, true));
   // w_i = v_i / Z'(d_i); a repeated point has Z' = 0 and the reference's division by inverse(0) = 0 (field.rs:209-232)
   // zeroes its target at the level that separates the two copies (ntt.rs:233-242): w_i = 0 as well
   hipLaunchKernelGGL((k_derivative<P>), dim3(grid256(n)), dim3(256), 0, s, (const u32*)T.low[T.levels].w(), T.N, T.pad, n, d_dz.w());
   MZK_TRY(T.evaluate(d_dz.p, n, d_dom.p, d_zp.p, n));
-  std::vector<uint64_t> res(T.N * nl);
-  for (size_t r = 0; r < batch; r++) {
-    MZK_HIP(hipMemcpyAsync(d_val.p, values + r * n * nl, n * esz, hipMemcpyHostToDevice, s));
-    MZK_HIP(hipMemsetAsync(d_w.p, 0, T.N * esz, s));
-    MZK_TRY(pointwise_div_dev(fid, d_val.p, d_zp.p, d_w.p, n, s));
-    MZK_TRY(T.combine(d_dom.p, d_w.p, d_res.p));
-    MZK_HIP(hipMemcpyAsync(res.data(), d_res.p, T.N * esz, hipMemcpyDeviceToHost, s));
+  // registers go through the up-sweep in groups (at most 2^24 elements per buffer)
+  const size_t group = std::max<size_t>(1, std::min<size_t>(batch, ((size_t)1 << 24) / T.N));
+  DevBuf d_vals, d_ws, d_ress;
+  MZK_TRY(d_vals.alloc(group * n * esz)); MZK_TRY(d_ws.alloc(group * T.N * esz)); MZK_TRY(d_ress.alloc(group * T.N * esz));
+  std::vector<uint64_t> res(group * T.N * nl);
+  for (size_t r0 = 0; r0 < batch; r0 += group) {
+    const size_t g = std::min(group, batch - r0);
+    MZK_HIP(hipMemcpyAsync(d_vals.p, values + r0 * n * nl, g * n * esz, hipMemcpyHostToDevice, s));
+    MZK_HIP(hipMemsetAsync(d_ws.p, 0, g * T.N * esz, s));
+    for (size_t r = 0; r < g; r++)
+      MZK_TRY(pointwise_div_dev(fid, (const char*)d_vals.p + r * n * esz, d_zp.p, (char*)d_ws.p + r * T.N * esz, n, s));
+    MZK_TRY(T.combine(d_dom.p, d_ws.p, d_ress.p, g));
+    MZK_HIP(hipMemcpyAsync(res.data(), d_ress.p, g * T.N * esz, hipMemcpyDeviceToHost, s));
     MZK_HIP(hipStreamSynchronize(s));
-    // sum_i w_i Z_pad / (X - d_i) = X^pad * interpolant; trimmed like the final `+` (polynomial.rs:214-228)
-    size_t len = n;
-    while (len > 0) {
-      uint64_t a = 0;
-      for (int k = 0; k < nl; k++) a |= res[(len - 1 + T.pad) * nl + k];
-      if (a) break;
-      len--;
+    for (size_t r = 0; r < g; r++) {
+      const uint64_t* rr = res.data() + r * T.N * nl;
+      // sum_i w_i Z_pad / (X - d_i) = X^pad * interpolant; trimmed like the final `+` (polynomial.rs:214-228)
+      size_t len = n;
+      while (len > 0) {
+        uint64_t a = 0;
+        for (int k = 0; k < nl; k++) a |= rr[(len - 1 + T.pad) * nl + k];
+        if (a) break;
+        len--;
+      }
+      uint64_t* dst = out + (r0 + r) * n * nl;
+      memcpy(dst, rr + T.pad * nl, len * esz);
+      if (batch > 1 && len < n) memset(dst + len * nl, 0, (n - len) * esz);
+      out_lens[r0 + r] = len;
     }
-    memcpy(out + r * n * nl, res.data() + T.pad * nl, len * esz);
-    if (batch > 1 && len < n) memset(out + (r * n + len) * nl, 0, (n - len) * esz);
-    out_lens[r] = len;
   }
   return MZK_OK;
 }
