@@ -310,11 +310,13 @@ def main():
             phases[k + "_in_timed_region"] = v
         return max_over_ranks(dt), phases
 
-    def run_in_flight(nctx):
+    def run_in_flight(nctx, handle=None, what="KZG commit"):
         """`nctx` commits in flight through ONE C-ABI call per batch: mzk_kzg_commit_srs_batch_dev spreads the polynomials of
-        a batch over the contexts of this GPU (the process made four in mz.init_devices above; max_in_flight = nctx)."""
+        a batch over the contexts of this GPU (the process made four in mz.init_devices above; max_in_flight = nctx).
+        handle: the SRS handle to commit against (default: the one with window tables)."""
         if world != 1 or args.no_two_in_flight:
             return None
+        hsrs = srs._h if handle is None else handle
         try:
             batch = 32          # polynomials per call: the pipeline drains at the end of every call, so short batches overlap less
             coefs = torch.empty(batch * n * 4, dtype=torch.int64, device=dev)
@@ -326,7 +328,7 @@ def main():
             lanes = ctypes.c_int(nctx)
 
             def one_batch():
-                check(L.mzk_kzg_commit_srs_batch_dev(srs._h, dptr(coefs), ctypes.c_size_t(n), ctypes.c_size_t(batch), dptr(outs), lanes, stream))
+                check(L.mzk_kzg_commit_srs_batch_dev(hsrs, dptr(coefs), ctypes.c_size_t(n), ctypes.c_size_t(batch), dptr(outs), lanes, stream))
             for _ in range(4):
                 one_batch()
             torch.cuda.synchronize()
@@ -339,8 +341,8 @@ def main():
             check(L.mzk_kzg_commit_srs_dev(srs._h, dptr(scalars), ctypes.c_size_t(n), dptr(result_srs), ctypes.c_int(0), stream))
             torch.cuda.synchronize()
             same = bool(torch.equal(outs[:8], result_srs))       # polynomial 0 of the batch is `scalars`: same point as the single call
-            return {"metric": "KZG commit pairs/s, batches of %d polynomials through mzk_kzg_commit_srs_batch_dev with %d commits in flight "
-                              "(%d contexts on one GPU, shared SRS handle)" % (batch, nctx, nctx),
+            return {"metric": "%s pairs/s, batches of %d polynomials through mzk_kzg_commit_srs_batch_dev with %d commits in flight "
+                              "(%d contexts on one GPU, shared SRS handle)" % (what, batch, nctx, nctx),
                     "value": n / dtp, "unit": "pairs/s", "ms_per_commit": dtp * 1e3, "commits_timed": reps * batch,
                     "same_point_as_single_call": same}
         except Exception as ex:
@@ -361,6 +363,22 @@ def main():
     # Reported beside `value`, which stays one commit at a time.
     pipelined = run_in_flight(2)
     pipelined4 = run_in_flight(4)
+    # the same against a handle WITHOUT window tables (prepared points only: the GLV / Horner layout of the generic MSM, no
+    # precomputation beyond the Montgomery conversion): what several commits in flight are worth where 40 % of one MSM is
+    # sort, reduction tails and the window Horner
+    generic4 = None
+    if world == 1 and not args.no_two_in_flight:
+        hplain = ctypes.c_void_p()
+        try:
+            check(L.mzk_srs_from_device_ex(dptr(points), ctypes.c_size_t(n), ctypes.c_int(0), ctypes.byref(hplain), stream))
+            generic4 = {"one_at_a_time": run_in_flight(1, hplain, "G1 MSM against prepared points (no window tables)"),
+                        "four_in_flight": run_in_flight(4, hplain, "G1 MSM against prepared points (no window tables)")}
+        except Exception as ex:
+            generic4 = {"error": str(ex)[:300]}
+        finally:
+            if hplain:
+                L.mzk_srs_free(hplain)
+            torch.cuda.empty_cache()
 
     def run_other_width(c):
         """The same commit against a handle with c-bit windows (mzk_srs_from_device_ex): `value` stays at the 16 bits BASELINE
@@ -537,6 +555,7 @@ def main():
         "kzg_commit_two_in_flight": pipelined,
         "kzg_commit_four_in_flight": pipelined4,
         "kzg_commit_17_bit_windows": width17,
+        "msm_no_tables_in_flight": generic4,
         "ntt_batched": ntt_batched,
         "msm_generic": {"metric": "G1 MSM pairs/sec, arbitrary points every call (no per-point-set precomputation; 16 bucket sets + window Horner)",
                         "value": msm_rate, "unit": "pairs/s", "ms_per_step": msm_ms, "phases": msm_ph, "roofline": roof},
