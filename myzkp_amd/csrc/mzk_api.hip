@@ -334,6 +334,7 @@ void mzk_shutdown(void) {
     (void)hipSetDevice(c.device);
     (void)hipDeviceSynchronize();
     ntt_release_plans();
+    poly_release_pool();
     ws_release_all();
     if (c.ws_event) (void)hipEventDestroy(c.ws_event);
     if (c.fork_event) (void)hipEventDestroy(c.fork_event);

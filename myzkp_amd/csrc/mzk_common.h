@@ -114,6 +114,7 @@ int coset_divide_dev_impl(int fid, const void* d_lhs, size_t tl, const void* d_r
 int pointwise_div_dev(int fid, const void* d_a, const void* d_b, void* d_out, size_t n, hipStream_t s);
 int pointwise_mul_dev(int fid, const void* d_a, const void* d_b, void* d_out, size_t n, hipStream_t s);
 void ntt_release_plans();
+void poly_release_pool();       // mzk_poly.hip: parked scratch blocks of the current context
 int fri_fold_dev_impl(int fid, const void* d_cw, size_t n, const uint64_t* alpha, const uint64_t* offset, const uint64_t* omega,
                       void* d_out, hipStream_t s);
 int kzg_batch_open_dev(const void* d_coef, size_t n, const uint64_t* us_host, size_t k, const void* d_points, int point_kind,

@@ -294,10 +294,52 @@ __global__ __launch_bounds__(256) void k_up_mul(const u32* __restrict__ Phat, co
 }
 
 // ---- host orchestration ----------------------------------------------------------------------------------------
+// Device scratch of the tree routines.  A call makes a dozen buffers whose sizes repeat from call to call; hipMalloc /
+// hipFree cost more than the kernels of a small tree (and hipFree synchronises the device), so released blocks wait in a
+// per-context pool and are handed out again (everything here runs on the context's own stream, so reuse is stream-ordered).
+struct PolyPool {
+  struct Block { void* p; size_t cap; };
+  std::vector<Block> free_blocks;
+  size_t bytes = 0;
+};
+static PolyPool g_poly_pool[MZK_MAX_CTX];
+constexpr size_t POLY_POOL_MAX_BYTES = (size_t)2 << 30;
+void poly_release_pool() {
+  PolyPool& pool = g_poly_pool[ctx().index];
+  for (auto& b : pool.free_blocks) (void)hipFree(b.p);
+  pool.free_blocks.clear();
+  pool.bytes = 0;
+}
 struct DevBuf {
   void* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  int alloc(size_t bytes) { if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { set_error("poly: hipMalloc(%zu) failed", bytes); return MZK_E_HIP; } return MZK_OK; }
+  size_t cap = 0;
+  ~DevBuf() {
+    if (!p) return;
+    PolyPool& pool = g_poly_pool[ctx().index];
+    if (pool.bytes + cap > POLY_POOL_MAX_BYTES) { (void)hipFree(p); return; }
+    pool.free_blocks.push_back({p, cap});
+    pool.bytes += cap;
+  }
+  int alloc(size_t bytes) {
+    size_t want = 4096;
+    while (want < bytes) want <<= 1;                 // sizes are N * element size: powers of two anyway
+    PolyPool& pool = g_poly_pool[ctx().index];
+    for (size_t i = pool.free_blocks.size(); i-- > 0;) {
+      if (pool.free_blocks[i].cap == want) {
+        p = pool.free_blocks[i].p; cap = want;
+        pool.bytes -= want;
+        pool.free_blocks.erase(pool.free_blocks.begin() + (long)i);
+        return MZK_OK;
+      }
+    }
+    if (hipMalloc(&p, want) != hipSuccess) {
+      (void)hipGetLastError();
+      poly_release_pool();                             // out of memory with blocks parked in the pool: give them back and retry
+      if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; set_error("poly: hipMalloc(%zu) failed", want); return MZK_E_HIP; }
+    }
+    cap = want;
+    return MZK_OK;
+  }
   u32* w() const { return (u32*)p; }
 };
 static inline unsigned grid256(size_t total) { return (unsigned)((total + 255) / 256); }
