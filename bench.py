@@ -151,6 +151,13 @@ def main():
     srs._h = hh
     srs_table_windows = 254 // (8 if n <= 1024 else (10 if n < 4096 else (13 if n < (1 << 14) else 16))) + 1
     progress("SRS handle built")
+    # The HIP runtime stalls once for 35-45 ms a few thousand dispatches into a process (measured: one stall in 120 000
+    # launches, at dispatch ~3500; tools note in DESIGN.md section 8) -- get past it before anything is timed.
+    tiny = torch.empty(64 * 4, dtype=torch.int64, device=dev)
+    for _ in range(6000):
+        L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(1), ctypes.c_size_t(64), dptr(tiny), stream)
+    torch.cuda.synchronize()
+    del tiny
     result_srs = torch.zeros(8, dtype=torch.int64, device=dev)
 
     def srs_step():
