@@ -387,4 +387,129 @@ FriCommitment<F> fri_commit(const std::vector<F>& initial_codeword, const F& ome
   return out;
 }
 
+// ---- extensions: the reference's per-item loops as one call ------------------------------------------------------
+// The reference has no batch forms; its callers loop (fast_stark.rs:231-243 per register, fri.rs:211-260 per query,
+// kzg.rs:57-59 per polynomial).  Each function below returns exactly what that loop over the single call returns.
+namespace batch {
+
+// PublicKeyKZG.powers_1 kept on the GPU (with its window tables) across commitments
+struct SrsHandle {
+  mzk_srs* h = nullptr;
+  explicit SrsHandle(const PublicKeyKZG& pk) {
+    auto p = points_to_wire(pk.powers_1);
+    expect(mzk_srs_upload(p.data(), pk.powers_1.size(), &h));
+  }
+  SrsHandle(const SrsHandle&) = delete;
+  SrsHandle& operator=(const SrsHandle&) = delete;
+  ~SrsHandle() { mzk_srs_free(h); }
+};
+// for f in fs { commit_kzg(f, pk) }   (kzg.rs:57-59); every polynomial padded with zero coefficients to the longest
+inline std::vector<CommitmentKZG> commit_kzg(const std::vector<Polynomial<FqOrder>>& fs, const SrsHandle& srs) {
+  size_t n = 0;
+  for (auto& f : fs) n = f.coef.size() > n ? f.coef.size() : n;
+  std::vector<CommitmentKZG> out(fs.size());
+  if (fs.empty() || n == 0) return out;
+  std::vector<uint64_t> c(fs.size() * n * 4, 0), xy(fs.size() * 8);
+  for (size_t i = 0; i < fs.size(); i++)
+    for (size_t j = 0; j < fs[i].coef.size(); j++) std::memcpy(&c[(i * n + j) * 4], fs[i].coef[j].value.data(), 32);
+  expect(mzk_kzg_commit_srs_batch(srs.h, c.data(), n, fs.size(), xy.data()));
+  for (size_t i = 0; i < fs.size(); i++) out[i] = G1Point::from_wire(&xy[8 * i]);
+  return out;
+}
+
+template <class F> static std::vector<uint64_t> rows_to_wire(const std::vector<std::vector<F>>& rows, size_t n) {
+  const size_t nl = F().value.size();
+  std::vector<uint64_t> w(rows.size() * n * nl, 0);
+  for (size_t i = 0; i < rows.size(); i++) {
+    if (rows[i].size() > n) throw Panic(MZK_E_ARG, "batch rows must have one length");
+    for (size_t j = 0; j < rows[i].size(); j++) std::memcpy(&w[(i * n + j) * nl], rows[i][j].value.data(), 8 * nl);
+  }
+  return w;
+}
+template <class F> static std::vector<std::vector<F>> rows_from_wire(const std::vector<uint64_t>& w, size_t rows, size_t n) {
+  const size_t nl = F().value.size();
+  std::vector<std::vector<F>> out(rows, std::vector<F>(n));
+  for (size_t i = 0; i < rows; i++)
+    for (size_t j = 0; j < n; j++) std::memcpy(out[i][j].value.data(), &w[(i * n + j) * nl], 8 * nl);
+  return out;
+}
+// for v in rows { ntt(root, v) } / intt   (ntt.rs:7-64); all rows of one power-of-two length
+template <class F> std::vector<std::vector<F>> ntt(const F& primitive_root, const std::vector<std::vector<F>>& rows, bool inverse = false) {
+  if (rows.empty()) return {};
+  const size_t n = rows[0].size();
+  for (auto& r : rows) if (r.size() != n) throw Panic(MZK_E_ARG, "batch rows must have one length");
+  auto in = rows_to_wire(rows, n);
+  std::vector<uint64_t> out(in.size());
+  expect(mzk_ntt_batch(Polynomial<F>::field_id(), primitive_root.value.data(), in.data(), out.data(), n, rows.size(), inverse ? 1 : 0));
+  return rows_from_wire<F>(out, rows.size(), n);
+}
+// for p in polys { fast_coset_evaluate(p, offset, generator, order) }   (ntt.rs:254-269); coefficients zero-padded to
+// the longest polynomial (a power of two after padding is the caller's business, as in the reference)
+template <class F>
+std::vector<std::vector<F>> fast_coset_evaluate(const std::vector<Polynomial<F>>& polys, const F& offset, const F& generator, size_t order) {
+  if (polys.empty()) return {};
+  size_t n = 1;
+  for (auto& p : polys) n = p.coef.size() > n ? p.coef.size() : n;
+  std::vector<std::vector<F>> rows;
+  for (auto& p : polys) rows.push_back(p.coef);
+  auto in = rows_to_wire(rows, n);
+  std::vector<uint64_t> out(polys.size() * order * F().value.size());
+  expect(mzk_coset_lde_batch(Polynomial<F>::field_id(), in.data(), n, offset.value.data(), generator.value.data(), out.data(), order, polys.size()));
+  return rows_from_wire<F>(out, polys.size(), order);
+}
+// for c in codewords { Merkle::commit(c.map(serialize)) }   (fast_stark.rs:231-243); one power-of-two length >= 2
+template <class F> std::vector<MerkleRoot> commit_codewords(const std::vector<std::vector<F>>& codewords) {
+  if (codewords.empty()) return {};
+  const size_t n = codewords[0].size();
+  for (auto& r : codewords) if (r.size() != n) throw Panic(MZK_E_ARG, "batch rows must have one length");
+  auto in = rows_to_wire(codewords, n);
+  std::vector<uint8_t> roots(32 * codewords.size());
+  expect(mzk_merkle_commit_field_batch(Polynomial<F>::field_id(), in.data(), n, codewords.size(), roots.data()));
+  std::vector<MerkleRoot> out;
+  for (size_t i = 0; i < codewords.size(); i++) out.emplace_back(roots.begin() + 32 * i, roots.begin() + 32 * (i + 1));
+  return out;
+}
+// for i in indices { Merkle::open(i, codeword.map(serialize)) }   (fri.rs:211-260): the tree is hashed once
+template <class F> std::vector<MerklePath> open_codeword(const std::vector<size_t>& indices, const std::vector<F>& codeword) {
+  auto c = to_wire(codeword);
+  mzk_merkle* t = nullptr;
+  expect(mzk_merkle_build_field(Polynomial<F>::field_id(), c.data(), codeword.size(), &t));
+  const size_t stride = 48;
+  std::vector<uint64_t> idx(indices.begin(), indices.end()), lens(indices.size() * 64);
+  std::vector<uint8_t> buf(indices.size() * 64 * stride);
+  size_t depth = 0;
+  const int rc = mzk_merkle_open_batch(t, idx.data(), idx.size(), buf.data(), stride, lens.data(), &depth);
+  mzk_merkle_free(t);
+  expect(rc);
+  std::vector<MerklePath> out(indices.size());
+  for (size_t q = 0; q < indices.size(); q++)
+    for (size_t l = 0; l < depth; l++) {
+      const uint8_t* e = &buf[(q * depth + l) * stride];
+      out[q].emplace_back(e, e + lens[q * depth + l]);
+    }
+  return out;
+}
+// for v in value_rows { fast_interpolate(domain, v, root, root_order) }   (ntt.rs:211-252): one subproduct tree
+template <class F>
+std::vector<Polynomial<F>> fast_interpolate(const std::vector<F>& domain, const std::vector<std::vector<F>>& value_rows, const F& primitive_root,
+                                            size_t root_order) {
+  if (value_rows.empty()) return {};
+  const size_t n = domain.size(), nl = F().value.size();
+  for (auto& r : value_rows) if (r.size() != n) throw Panic(MZK_E_ARG, "batch rows must have one length");
+  auto d = to_wire(domain);
+  auto v = rows_to_wire(value_rows, n);
+  std::vector<uint64_t> out(value_rows.size() * (n ? n : 1) * nl);
+  std::vector<size_t> lens(value_rows.size());
+  expect(mzk_fast_interpolate_batch(Polynomial<F>::field_id(), d.data(), v.data(), n, value_rows.size(), primitive_root.value.data(), root_order,
+                                    out.data(), lens.data()));
+  std::vector<Polynomial<F>> res(value_rows.size());
+  for (size_t i = 0; i < value_rows.size(); i++) {
+    std::vector<uint64_t> w(out.begin() + i * n * nl, out.begin() + (i * n + lens[i]) * nl);
+    res[i].coef = from_wire<F>(w, lens[i]);
+  }
+  return res;
+}
+
+}  // namespace batch
+
 }  // namespace myzkp

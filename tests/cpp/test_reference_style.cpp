@@ -8,6 +8,7 @@
 //   test_merkle         <- algebra/merkle.rs:76-93
 //   test_g2             <- algebra/curve/bn128.rs:306-323 and algebra/kzg.rs:110-114
 //   test_fri_commit     <- zkstark/fri.rs:144-209 (commit phase; transcript stood in for by a deterministic challenge)
+//   test_batch_extensions  the batch:: forms against the loops of single calls they replace
 #include <cstdio>
 #include <cstdlib>
 #include "../../myzkp_amd/host/myzkp.hpp"
@@ -254,6 +255,89 @@ static void test_g2() {   // bn128.rs:306-323 through the MSM, plus the G2 side 
   CHECK(eval_with_powers_on_curve_g2(z, p2) == G2Point::from_wire(w));
 }
 
+
+// the batch:: extensions against the loops over single calls they stand for
+static void test_batch_extensions() {
+  typedef FiniteFieldElement<M128> F;
+  const unsigned logn = 9;
+  const size_t n = 1u << logn, rows = 5;
+  std::vector<std::vector<F>> regs(rows, std::vector<F>(n));
+  std::vector<uint64_t> raw(2 * n * rows);
+  orc_synth_vector(MZK_FIELD_M128, 77, n * rows, raw.data(), 1);
+  for (size_t r = 0; r < rows; r++)
+    for (size_t i = 0; i < n; i++) regs[r][i] = F::from_limbs(&raw[2 * (r * n + i)]);
+  F root = get_nth_root_of_m128(logn);
+  auto fwd = batch::ntt(root, regs);
+  auto back = batch::ntt(root, fwd, true);
+  for (size_t r = 0; r < rows; r++) {
+    CHECK(fwd[r] == ntt(root, regs[r]));
+    CHECK(back[r] == regs[r]);
+  }
+  // low-degree extension of all registers, then one Merkle root per codeword (fast_stark.rs:231-243)
+  const size_t order = 4 * n;
+  F big = get_nth_root_of_m128(logn + 2), offset = F::from_value(3);
+  std::vector<Polynomial<F>> polys;
+  for (auto& r : regs) polys.push_back(Polynomial<F>{r});
+  auto lde = batch::fast_coset_evaluate(polys, offset, big, order);
+  auto roots = batch::commit_codewords(lde);
+  CHECK(lde.size() == rows && roots.size() == rows);
+  for (size_t r = 0; r < rows; r++) {
+    CHECK(lde[r] == fast_coset_evaluate(polys[r], offset, big, order));
+    CHECK(roots[r] == commit_codeword(lde[r]));
+  }
+  // openings of one codeword: same paths as Merkle::open on the serialized leaves, and they verify
+  {
+    auto w = to_wire(lde[1]);
+    std::vector<uint8_t> blob(order * 25);
+    std::vector<uint64_t> off(order + 1);
+    orc_bincode_field_vector(w.data(), 2, order, blob.data(), off.data());
+    std::vector<std::vector<uint8_t>> leafs;
+    for (size_t i = 0; i < order; i++) leafs.emplace_back(blob.begin() + off[i], blob.begin() + off[i + 1]);
+    std::vector<size_t> idx{0, 5, order / 2 + 5, order - 1, 5};
+    auto paths = batch::open_codeword(idx, lde[1]);
+    CHECK(paths.size() == idx.size());
+    for (size_t q = 0; q < idx.size(); q++) {
+      CHECK(paths[q] == Merkle::open(idx[q], leafs));
+      CHECK(oracle_verify(roots[1], idx[q], paths[q], leafs[idx[q]]));
+    }
+  }
+  // interpolation of all registers over the trace domain (fast_stark.rs:203-215)
+  {
+    std::vector<F> domain(n);
+    uint64_t x[2] = {1, 0};
+    for (size_t i = 0; i < n; i++) { domain[i] = F::from_limbs(x); uint64_t y[2]; orc_field_mul(MZK_FIELD_M128, x, root.value.data(), y); x[0] = y[0]; x[1] = y[1]; }
+    F big3 = get_nth_root_of_m128(logn + 1);
+    auto ps = batch::fast_interpolate(domain, regs, big3, 2 * n);
+    auto d = to_wire(domain);
+    for (size_t r = 0; r < rows; r++) {
+      auto v = to_wire(regs[r]);
+      std::vector<uint64_t> out(2 * n);
+      size_t len = 0;
+      expect(mzk_fast_interpolate(MZK_FIELD_M128, d.data(), v.data(), n, big3.value.data(), 2 * n, out.data(), &len));
+      out.resize(2 * len);
+      CHECK(ps[r].coef.size() == len && to_wire(ps[r].coef) == out);
+      CHECK(ps[r].coef == intt(root, regs[r]));   // on the subgroup itself interpolation is the inverse transform
+    }
+  }
+  // commitments against a resident SRS
+  {
+    auto g1 = BN128::generator_g1();
+    const size_t deg = 300;
+    auto pk = setup_kzg_with_alpha(g1, FqOrder::from_value(7), deg);
+    std::vector<uint64_t> sc(4 * (deg + 1) * 3);
+    orc_synth_vector(MZK_FIELD_FR, 9, (deg + 1) * 3, sc.data(), 1);
+    std::vector<Polynomial<FqOrder>> fs(3);
+    const size_t lens[3] = {deg + 1, 17, 1};
+    for (size_t k = 0; k < 3; k++)
+      for (size_t i = 0; i < lens[k]; i++) fs[k].coef.push_back(FqOrder::from_limbs(&sc[4 * (k * (deg + 1) + i)]));
+    batch::SrsHandle srs(pk);
+    auto cs = batch::commit_kzg(fs, srs);
+    CHECK(cs.size() == 3);
+    for (size_t k = 0; k < 3; k++) CHECK(cs[k] == commit_kzg(fs[k], pk));
+    CHECK(batch::commit_kzg({}, srs).empty());
+  }
+}
+
 int main() {
   expect(mzk_init(0));
   test_ntt();
@@ -265,6 +349,7 @@ int main() {
   test_merkle();
   test_fri_commit();
   test_g2();
+  test_batch_extensions();
   mzk_shutdown();
   if (failures) { printf("%d check(s) failed\n", failures); return 1; }
   printf("all reference-style tests passed\n");
