@@ -62,6 +62,13 @@ const char* mzk_last_error(void);
 /* ABI version: bump on any signature change. */
 int mzk_abi_version(void);
 
+/* Size limits (tests/test_gpu_max_sizes.py runs them on one MI355X; profiles/r02u_max_sizes.txt has the timings):
+ *   MSM / commit / open / SRS handles   n <= 2^27 pairs (MZK_E_ARG above; 2^27 pairs x 16 windows = 2^31 sort records, and an
+ *                                       SRS handle with 16-bit window tables holds 16 n points = 128 GiB at 2^27 -- pass
+ *                                       with_tables = 0 to mzk_srs_from_device_ex to keep only the prepared points)
+ *   transforms                          n <= 2^28 over Fr (its 2-adicity); over M128 up to 2^32 nominally, memory-bound in
+ *                                       practice: in + out + (passes - 1) twiddle tables of n elements each
+ *   subproduct trees (mzk_fast_*)       n <= 2^27 points (the internal products are transforms of 2 n <= 2^28 points) */
 /* ---- NTT family ------------------------------------------------------------------------------- */
 /* ntt::ntt (algebra/ntt.rs:7-48) when inverse == 0: out[k] = sum_j in[j] * root^(j k), natural order
  * in and out, n a power of two, root a primitive n-th root.  n <= 1 copies the input.
