@@ -273,6 +273,12 @@ int mzk_ntt_batch_dev(int field_id, const uint64_t* root, const void* d_in, void
                       void* stream);
 int mzk_coset_lde_dev(int field_id, const void* d_coef, size_t n_coef, const uint64_t* offset_host,
                       const uint64_t* generator_host, void* d_out, size_t order, void* stream);
+/* Polynomial::scale (polynomial.rs:167-174) with an optional leading constant: out[i] = lead * coef[i] * ratio^i (lead == NULL: 1);
+ * in place allowed.  Also the twiddle step between the local transforms of a transform sharded over several GPUs
+ * (myzkp_amd/sharded.py: ratio = w^rank) and its n^-1 (ratio = 1). */
+int mzk_poly_scale(int field_id, const uint64_t* coef, size_t n, const uint64_t* ratio, const uint64_t* lead, uint64_t* out);
+int mzk_poly_scale_dev(int field_id, const void* d_coef, size_t n, const uint64_t* ratio_host, const uint64_t* lead_host, void* d_out,
+                       void* stream);
 /* fast_coset_evaluate (ntt.rs:254-269) of `batch` polynomials of n_coef coefficients each onto ONE coset -- the low-degree
  * extension of every column of a trace (fast_stark.rs:231,282,329 call it per polynomial) -- in one launch per pass:
  * coefs = batch * n_coef elements back to back, out = batch * order.  Bit-identical to `batch` single calls. */

@@ -194,6 +194,14 @@ def coset_lde(fid, coef, offset, generator, order):
     return out
 
 
+def poly_scale(fid, coef, ratio, lead=None):
+    """Polynomial::scale (algebra/polynomial.rs:167-174), optionally times a leading constant: lead * coef[i] * ratio^i."""
+    c = _arr(fid, coef)
+    out = np.empty_like(c)
+    _check(lib().mzk_poly_scale(fid, _p(c), ctypes.c_size_t(c.shape[0]), _p(_one(fid, ratio)), _p(_one(fid, lead)) if lead is not None else None, _p(out)))
+    return out
+
+
 def fft_multiply(fid, a, b, omega):
     """Polynomial::fft_multiply (algebra/polynomial.rs:242-276)."""
     a, b = _arr(fid, a), _arr(fid, b)

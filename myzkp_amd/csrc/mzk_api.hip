@@ -506,6 +506,26 @@ int mzk_coset_lde_dev(int field_id, const void* d_coef, size_t n_coef, const uin
   return coset_lde_dev_impl(field_id, d_coef, n_coef, offset_host, generator_host, d_out, order, (hipStream_t)stream);
 }
 
+int mzk_poly_scale(int field_id, const uint64_t* coef, size_t n, const uint64_t* ratio, const uint64_t* lead, uint64_t* out) {
+  MZK_TRY(ensure_init());
+  if (n == 0) return MZK_OK;
+  if (!coef || !out) { set_error("poly_scale: null pointer"); return MZK_E_ARG; }
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("poly_scale: bad field id %d", field_id); return MZK_E_ARG; }
+  hipStream_t s = ctx().stream;
+  WsGuard wsg(s);
+  const size_t esz = field_bytes(field_id);
+  void* d;
+  MZK_TRY(stage_in(WS_MISC_A, coef, n * esz, &d, s));
+  MZK_TRY(poly_scale_dev_impl(field_id, d, n, ratio, lead, d, s));
+  MZK_HIP(hipMemcpyAsync(out, d, n * esz, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  return MZK_OK;
+}
+int mzk_poly_scale_dev(int field_id, const void* d_coef, size_t n, const uint64_t* ratio_host, const uint64_t* lead_host, void* d_out, void* stream) {
+  MZK_TRY(ensure_init());
+  return poly_scale_dev_impl(field_id, d_coef, n, ratio_host, lead_host, d_out, (hipStream_t)stream);
+}
+
 static size_t trimmed_len(const uint64_t* c, size_t n, int nl) {
   while (n > 0) {
     uint64_t acc = 0;

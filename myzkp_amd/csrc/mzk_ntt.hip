@@ -376,6 +376,21 @@ __global__ void k_coset_scale_pad(const u32* __restrict__ coef, size_t n_coef, W
     }
   }
 }
+// Polynomial::scale (polynomial.rs:167-174) with a leading constant: out[i] = lead * in[i] * ratio^i, plain in and out,
+// in place allowed.  The twiddle step of the sharded transforms (myzkp_amd/sharded.py) and their n^-1.
+template <class P>
+__global__ void k_poly_scale(const u32* __restrict__ in, size_t n, Words8 ratio_plain, Words8 lead_plain, u32* __restrict__ out) {
+  const size_t chunk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t j0 = chunk * GEN_CHUNK;
+  if (j0 >= n) return;
+  const Fe<P> g = fe_to_mont<P>(fe_unpack<P>(ratio_plain.w));
+  Fe<P> cur = FeAsm<P>::mul(fe_pow_u64<P>(g, j0), fe_to_mont<P>(fe_unpack<P>(lead_plain.w)));
+  for (int i = 0; i < GEN_CHUNK && j0 + i < n; i++) {
+    const Fe<P> c = gload<P>(in, j0 + i);
+    gstore<P>(out, j0 + i, fe_reduce<P>(FeAsm<P>::mul(c, cur)));
+    cur = FeAsm<P>::mul(cur, g);
+  }
+}
 // out[i] = a[i] * b[i] (plain domain in and out; Hadamard step of the polynomial products)
 template <class P>
 __global__ void k_pointwise_mul(const u32* __restrict__ a, const u32* __restrict__ b, u32* __restrict__ out, size_t n) {
@@ -640,6 +655,26 @@ int ntt_batch_dev_impl(int fid, const uint64_t* root_host, const void* d_in, voi
   MZK_TRY(get_plan(fid, ilog2(n), inverse != 0, root_host, nullptr, s, &pl, batch));
   if (fid == MZK_FIELD_M128) return run_plan<M128Params>(pl, (const u32*)d_in, (u32*)d_out, s, nullptr, batch);
   return run_plan<FrParams>(pl, (const u32*)d_in, (u32*)d_out, s, nullptr, batch);
+}
+
+int poly_scale_dev_impl(int fid, const void* d_in, size_t n, const uint64_t* ratio_host, const uint64_t* lead_host, void* d_out, hipStream_t s) {
+  if (fid != MZK_FIELD_FR && fid != MZK_FIELD_M128) { set_error("poly_scale: bad field id %d", fid); return MZK_E_ARG; }
+  if (n == 0) return MZK_OK;
+  if (!d_in || !d_out || !ratio_host) { set_error("poly_scale: null pointer"); return MZK_E_ARG; }
+  const HostField* hf = host_field(fid);
+  if (!h_is_canonical(hf, ratio_host) || (lead_host && !h_is_canonical(hf, lead_host))) { set_error("poly_scale: parameter not canonical"); return MZK_E_RANGE; }
+  const uint64_t one[4] = {1, 0, 0, 0};
+  Words8 rw, lw;
+  to_words(ratio_host, hf->nl, &rw);
+  to_words(lead_host ? lead_host : one, hf->nl, &lw);
+  const size_t chunks = (n + GEN_CHUNK - 1) / GEN_CHUNK;
+  const unsigned blocks = (unsigned)((chunks + 255) / 256);
+  if (fid == MZK_FIELD_M128)
+    hipLaunchKernelGGL((k_poly_scale<M128Params>), dim3(blocks), dim3(256), 0, s, (const u32*)d_in, n, rw, lw, (u32*)d_out);
+  else
+    hipLaunchKernelGGL((k_poly_scale<FrParams>), dim3(blocks), dim3(256), 0, s, (const u32*)d_in, n, rw, lw, (u32*)d_out);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
 }
 
 int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_t* offset_host,

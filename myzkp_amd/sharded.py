@@ -31,3 +31,156 @@ def all_gather_partials(partial):
 def sharded_msm(local_partial_fn, fold_fn):
     """local_partial_fn() -> this rank's partial record (tensor); fold_fn(records) -> final result."""
     return fold_fn(all_gather_partials(local_partial_fn()))
+
+
+# ---- one transform sharded over the ranks (SURVEY 8e: the four-step layout with an all-to-all) ---------------------------
+# n = W m points over W ranks (W a power of two, W^2 <= n), natural order in and out as in ntt.rs:7-64.  Two layouts of a
+# distributed vector:   "contiguous": rank r holds x[r m .. (r+1) m)          "cyclic": rank r holds x[r], x[r + W], ...
+# Write j = a m + t (a = rank of a contiguous input) and k = W k2 + k1:
+#     X[W k2 + k1] = sum_t  w_m^(t k2) * w^(t k1) * [ sum_a x[a m + t] w_W^(a k1) ]          w_m = w^W,  w_W = w^m
+# "dif" (contiguous in -> cyclic out, two exchanges):
+#     all-to-all (rank s gets the slice t in [s m/W, (s+1) m/W) of every rank) -> m/W transforms of W points across the
+#     ranks' values -> all-to-all (rank k1 gets y[k1][all t]) -> the m-point transform of y[k1][t] * (w^k1)^t, which IS
+#     fast_coset_evaluate with offset w^k1 and generator w^W (ntt.rs:254-269: the twiddle costs no pass of its own).
+# "dit" (cyclic in -> contiguous out, two exchanges), from j = j2 W + j1, k = k1 m + k2:
+#     X[k1 m + k2] = sum_j1 w_W^(j1 k1) * [ w^(j1 k2) * sum_j2 x[j2 W + j1] w_m^(j2 k2) ]
+#     local m-point transform -> Polynomial::scale by w^j1 (polynomial.rs:167-174) -> all-to-all -> W-point transforms
+#     -> all-to-all.
+# Contiguous in AND out costs a third all-to-all (dif + redistribution of the cyclic result); a forward transform followed
+# by an inverse one (polynomial products, quotients) should keep the cyclic layout in between: 2 + 2 exchanges, not 3 + 3.
+# Every exchange moves (W-1)/W of the rank's n/W elements, each to a different peer: on xGMI all seven links of a GPU carry
+# one seventh of it at the same time.  The inverse transform uses w^-1 in the same schedule, with W^-1 and m^-1 supplied by
+# the local inverse transforms (mzk_ntt_batch_dev / mzk_ntt_dev, inverse = 1).
+# The local compute is injected (`ops`), like the MSM's: DeviceOps below is the GPU path (C ABI calls on HBM-resident
+# buffers + torch for the two transposes and the collective); the gloo test runs the same schedule with the oracle.
+
+def _ilog2(n):
+    l = n.bit_length() - 1
+    if n <= 0 or (1 << l) != n:
+        raise ValueError("cannot compute ntt of non-power-of-two sequence")
+    return l
+
+
+def ntt_sharded_steps(modulus, log2n, world, root, inverse, layout_in, layout_out):
+    """The schedule as a list of steps: None = all-to-all of W equal chunks, else fn(ops, rank, buf) -> buf."""
+    n, W = 1 << log2n, world
+    _ilog2(W)
+    if W * W > n:
+        raise ValueError("sharded transform needs world^2 <= n")
+    if (layout_in, layout_out) not in (("contiguous", "contiguous"), ("contiguous", "cyclic"), ("cyclic", "contiguous")):
+        raise ValueError("layouts: contiguous->contiguous, contiguous->cyclic or cyclic->contiguous")
+    m = n // W
+    p = modulus
+    w = pow(root, p - 2, p) if inverse else root           # the root the sums run over
+    root_W, root_m = pow(root, m, p), pow(root, W, p)      # forward roots of the W- and m-point transforms (as the callers pass them)
+    if W == 1:
+        return [lambda ops, r, b: ops.ntt(b, m, root_m, inverse)]
+
+    def across(ops, r, b):            # [a][t'] -> m/W transforms over a -> [k1][t']
+        b = ops.transpose(b, W, m // W)
+        b = ops.ntt_rows(b, m // W, W, root_W, inverse)
+        return ops.transpose(b, m // W, W)
+
+    def local_dif(ops, r, b):
+        if not inverse:
+            return ops.lde(b, m, pow(w, r, p), root_m)
+        return ops.ntt(ops.scale(b, m, pow(w, r, p)), m, root_m, True)
+
+    def local_dit(ops, r, b):
+        return ops.scale(ops.ntt(b, m, root_m, inverse), m, pow(w, r, p))
+
+    def interleave(ops, r, b):        # [k1][k2'] -> k2' W + k1
+        return ops.transpose(b, W, m // W)
+
+    if layout_in == "cyclic":
+        return [local_dit, None, across, None]
+    steps = [None, across, None, local_dif]
+    if layout_out == "contiguous":
+        steps += [None, interleave]
+    return steps
+
+
+class DeviceOps:
+    """Local steps on the GPU: flat int64 device tensors of (elements x limbs), C ABI calls on torch's current stream."""
+
+    def __init__(self, fid):
+        import ctypes
+        import myzkp_amd as mz
+        self.ct, self.mz, self.fid, self.nl, self.L = ctypes, mz, fid, mz.LIMBS[fid], mz.lib()
+
+    def _st(self):
+        return self.ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _one(self, v):
+        a = self.mz.to_limbs([v], self.nl)
+        return a, a.ctypes.data_as(self.ct.c_void_p)
+
+    def _ok(self, rc):
+        if rc != 0:
+            raise self.mz.MzkError(rc, self.L.mzk_last_error().decode())
+
+    def ntt(self, b, m, root, inverse):
+        keep, r = self._one(root)
+        p = self.ct.c_void_p(b.data_ptr())
+        self._ok(self.L.mzk_ntt_dev(self.fid, r, p, p, self.ct.c_size_t(m), int(bool(inverse)), self._st()))
+        return b
+
+    def ntt_rows(self, b, rows, n, root, inverse):
+        keep, r = self._one(root)
+        p = self.ct.c_void_p(b.data_ptr())
+        self._ok(self.L.mzk_ntt_batch_dev(self.fid, r, p, p, self.ct.c_size_t(n), self.ct.c_size_t(rows), int(bool(inverse)), self._st()))
+        return b
+
+    def lde(self, b, m, offset, generator):
+        k1, o = self._one(offset)
+        k2, g = self._one(generator)
+        out = torch.empty_like(b)
+        self._ok(self.L.mzk_coset_lde_dev(self.fid, self.ct.c_void_p(b.data_ptr()), self.ct.c_size_t(m), o, g, self.ct.c_void_p(out.data_ptr()),
+                                          self.ct.c_size_t(m), self._st()))
+        return out
+
+    def scale(self, b, m, ratio):
+        keep, r = self._one(ratio)
+        p = self.ct.c_void_p(b.data_ptr())
+        self._ok(self.L.mzk_poly_scale_dev(self.fid, p, self.ct.c_size_t(m), r, None, p, self._st()))
+        return b
+
+    def transpose(self, b, rows, cols):
+        return b.view(rows, cols, self.nl).transpose(0, 1).contiguous().view(-1)
+
+    def chunks(self, b, W):
+        return list(b.chunk(W))
+
+    def cat(self, parts):
+        return torch.cat(parts)
+
+    def all_to_all(self, b, group=None):
+        out = torch.empty_like(b)
+        dist.all_to_all_single(out, b.contiguous(), group=group)
+        return out
+
+
+def ntt_sharded(x_local, modulus, log2n, root, ops, inverse=False, layout_in="contiguous", layout_out="contiguous", group=None):
+    """This rank's part of ONE n-point transform (ntt.rs:7-64) whose vector is spread over the ranks of `group`."""
+    if not dist.is_available() or not dist.is_initialized():
+        rank, world = 0, 1
+    else:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    buf = x_local
+    for step in ntt_sharded_steps(modulus, log2n, world, root, inverse, layout_in, layout_out):
+        buf = ops.all_to_all(buf, group) if step is None else step(ops, rank, buf)
+    return buf
+
+
+def ntt_sharded_simulate(xs, modulus, log2n, root, ops, inverse=False, layout_in="contiguous", layout_out="contiguous"):
+    """The same schedule for ALL ranks inside one process (xs[r] = rank r's part): the exchanges become slicing.  Tests, and a
+    one-GPU rehearsal of the multi-GPU path."""
+    W = len(xs)
+    bufs = list(xs)
+    for step in ntt_sharded_steps(modulus, log2n, W, root, inverse, layout_in, layout_out):
+        if step is None:
+            parts = [ops.chunks(b, W) for b in bufs]
+            bufs = [ops.cat([parts[src][dst] for src in range(W)]) for dst in range(W)]
+        else:
+            bufs = [step(ops, r, bufs[r]) for r in range(W)]
+    return bufs
