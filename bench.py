@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--e2e-log2n", type=int, default=22, help="degree of the end-to-end KZG run (0 = skip)")
     ap.add_argument("--strong-log2n", type=int, default=24,
                     help="total size of the fixed-size MSM split over all ranks (BASELINE configs[3]; 0 = skip)")
+    ap.add_argument("--strong-ntt-log2n", type=int, default=24, help="size of the ONE transform sharded over all ranks (0 = skip)")
     ap.add_argument("--extra-sizes", type=str, default="24", help="comma list of extra log2 sizes timed once each (rank 0 view)")
     ap.add_argument("--no-two-in-flight", action="store_true",
                     help="skip the two-commits-in-flight leg (profiler runs: overlapped kernels would distort the per-kernel averages)")
@@ -567,7 +568,7 @@ def main():
         "msm_generic": {"metric": "G1 MSM pairs/sec, arbitrary points every call (no per-point-set precomputation; 16 bucket sets + window Horner)",
                         "value": msm_rate, "unit": "pairs/s", "ms_per_step": msm_ms, "phases": msm_ph, "roofline": roof},
         "ntt": {"metric": "NTT elems/sec", "value": ntt_rate, "unit": "elems/s", "ms_per_step": ntt_ms, "field": "BN254 Fr",
-                "log2n": args.log2n, "multi_gpu": "replicas only (one independent transform per GPU)", "roofline": ntt_roof,
+                "log2n": args.log2n, "multi_gpu": "replicas (one independent transform per GPU); ONE transform sharded over the ranks is the strong_scaling_ntt leg", "roofline": ntt_roof,
                 "phases": ntt_ph},
         "ntt_m128": {"metric": "NTT elems/sec", "value": world * n / (nttm_dt / K), "unit": "elems/s", "ms_per_step": nttm_dt / K * 1e3,
                      "field": "M128 = 1 + 407*2^119 (fri.rs:408)", "log2n": args.log2n, "phases": nttm_ph,
@@ -815,6 +816,62 @@ def main():
         out["strong_scaling_msm"] = strong
         if hs:
             L.mzk_srs_free(hs)
+        torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ ONE transform sharded over all ranks (SURVEY 8e four-step layout)
+    # A 2^strong_ntt_log2n-point Fr transform whose vector is spread over the ranks in contiguous slices: all-to-all, W-point
+    # transforms across the ranks, all-to-all, local n/W-point coset transform (the twiddle rides in the LDE's offset), and a
+    # third all-to-all when the result has to be contiguous again (myzkp_amd/sharded.py).  Every rank checks its part against
+    # the single-GPU transform of the whole vector, which it computes itself.  At N = 1 this is the plain transform.
+    progress("sharded transform leg")
+    if args.strong_ntt_log2n > 0 and world * world <= (1 << args.strong_ntt_log2n):
+        lgt = args.strong_ntt_log2n
+        tot = 1 << lgt
+        mt = tot // world
+        wt = mz.root_of_unity(mz.FIELD_FR, lgt)
+        sn = {"log2n": lgt, "n_gpus": world, "field": "BN254 Fr", "points_per_gpu": mt,
+              "what": "one 2^%d-point transform (ntt.rs:7-64), vector sharded over the ranks; all_to_all_single (RCCL) exchanges of "
+                      "(N-1)/N of each rank's n/N elements; time should fall with the number of GPUs" % lgt}
+        err, fns = None, {}
+        try:
+            ops = sharded.DeviceOps(mz.FIELD_FR)
+            PFR = mz.MODULUS[mz.FIELD_FR]
+            if shared_gpu_test:
+                _a2a = ops.all_to_all
+                ops.all_to_all = lambda b, group=None: _a2a(b.cpu(), group).to(dev)
+            full = torch.empty(tot * 4, dtype=torch.int64, device=dev)
+            for r in range(world):
+                check(L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(SEED + 7000 + 1000003 * r), ctypes.c_size_t(mt), ctypes.c_void_p(full.data_ptr() + r * mt * 32), stream))
+            xloc = full.view(world, -1)[rank].clone()
+            want = torch.empty_like(full)
+            rt24 = mz.to_limbs([wt], 4)
+            check(L.mzk_ntt_dev(mz.FIELD_FR, rt24.ctypes.data_as(ctypes.c_void_p), dptr(full), dptr(want), ctypes.c_size_t(tot), 0, stream))
+            torch.cuda.synchronize()
+            want_contig = want.view(world, -1)[rank].clone()
+            want_cyclic = want.view(-1, 4)[rank::world].contiguous().view(-1)
+            del full, want
+            torch.cuda.empty_cache()
+            res = {}
+            fns["contiguous_to_contiguous"] = lambda: res.__setitem__("cc", sharded.ntt_sharded(xloc, PFR, lgt, wt, ops, False, "contiguous", "contiguous"))
+            fns["contiguous_to_cyclic"] = lambda: res.__setitem__("cy", sharded.ntt_sharded(xloc, PFR, lgt, wt, ops, False, "contiguous", "cyclic"))
+            fns["inverse_cyclic_to_contiguous"] = lambda: res.__setitem__("inv", sharded.ntt_sharded(want_cyclic, PFR, lgt, wt, ops, True, "cyclic", "contiguous"))
+        except Exception as ex:
+            err = str(ex)[:300]
+        if max_over_ranks(0.0 if err is None else 1.0) == 0.0:
+            Kn = max(3, min(K, 5))
+            for name, fn in fns.items():
+                dtn, _ = timed(fn, Kn, 1)
+                sn[name + "_ms"] = dtn / Kn * 1e3
+            torch.cuda.synchronize()
+            okn = bool(torch.equal(res["cc"], want_contig) and torch.equal(res["cy"], want_cyclic) and torch.equal(res["inv"], xloc))
+            sn["every_part_equals_single_gpu_transform"] = max_over_ranks(0.0 if okn else 1.0) == 0.0
+            sn.update({"ms_per_step": sn["contiguous_to_contiguous_ms"], "value": tot / (sn["contiguous_to_contiguous_ms"] * 1e-3), "unit": "elems/s",
+                       "exchanges": {"contiguous_to_contiguous": 3 if world > 1 else 0, "contiguous_to_cyclic": 2 if world > 1 else 0,
+                                     "inverse_cyclic_to_contiguous": 2 if world > 1 else 0},
+                       "bytes_sent_per_rank_per_exchange": (world - 1) * (mt // world) * 32})
+        else:
+            sn["error"] = err or "a rank failed"
+        out["strong_scaling_ntt"] = sn
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ one process, several GPUs, C ABI only (optional)

@@ -119,11 +119,12 @@ class DeviceOps:
         if rc != 0:
             raise self.mz.MzkError(rc, self.L.mzk_last_error().decode())
 
-    def ntt(self, b, m, root, inverse):
+    def ntt(self, b, m, root, inverse):        # out of place: the caller's part is never overwritten
         keep, r = self._one(root)
-        p = self.ct.c_void_p(b.data_ptr())
-        self._ok(self.L.mzk_ntt_dev(self.fid, r, p, p, self.ct.c_size_t(m), int(bool(inverse)), self._st()))
-        return b
+        out = torch.empty_like(b)
+        self._ok(self.L.mzk_ntt_dev(self.fid, r, self.ct.c_void_p(b.data_ptr()), self.ct.c_void_p(out.data_ptr()), self.ct.c_size_t(m),
+                                    int(bool(inverse)), self._st()))
+        return out
 
     def ntt_rows(self, b, rows, n, root, inverse):
         keep, r = self._one(root)
