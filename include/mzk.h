@@ -273,6 +273,11 @@ int mzk_ntt_batch_dev(int field_id, const uint64_t* root, const void* d_in, void
                       void* stream);
 int mzk_coset_lde_dev(int field_id, const void* d_coef, size_t n_coef, const uint64_t* offset_host,
                       const uint64_t* generator_host, void* d_out, size_t order, void* stream);
+/* `cols` transforms (ntt / intt, ntt.rs:7-64) of n_points = 2, 4, 8 or 16 points each, stored COLUMN-major: element i of
+ * transform c at [i * cols + c], in and out (not in place).  One trip over the data; the step across the ranks of a transform
+ * sharded over several GPUs (myzkp_amd/sharded.py), where after the first exchange a rank holds [source rank][its slice]. */
+int mzk_ntt_columns_dev(int field_id, const uint64_t* root, const void* d_in, void* d_out, size_t n_points, size_t cols, int inverse,
+                        void* stream);
 /* Polynomial::scale (polynomial.rs:167-174) with an optional leading constant: out[i] = lead * coef[i] * ratio^i (lead == NULL: 1);
  * in place allowed.  Also the twiddle step between the local transforms of a transform sharded over several GPUs
  * (myzkp_amd/sharded.py: ratio = w^rank) and its n^-1 (ratio = 1). */

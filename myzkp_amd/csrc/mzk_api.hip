@@ -506,6 +506,10 @@ int mzk_coset_lde_dev(int field_id, const void* d_coef, size_t n_coef, const uin
   return coset_lde_dev_impl(field_id, d_coef, n_coef, offset_host, generator_host, d_out, order, (hipStream_t)stream);
 }
 
+int mzk_ntt_columns_dev(int field_id, const uint64_t* root, const void* d_in, void* d_out, size_t n_points, size_t cols, int inverse, void* stream) {
+  MZK_TRY(ensure_init());
+  return ntt_columns_dev_impl(field_id, root, d_in, d_out, n_points, cols, inverse, (hipStream_t)stream);
+}
 int mzk_poly_scale(int field_id, const uint64_t* coef, size_t n, const uint64_t* ratio, const uint64_t* lead, uint64_t* out) {
   MZK_TRY(ensure_init());
   if (n == 0) return MZK_OK;

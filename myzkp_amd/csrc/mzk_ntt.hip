@@ -315,6 +315,44 @@ __global__ __launch_bounds__(G::NT) void k_ntt_last(const u32* __restrict__ in, 
   }
 }
 
+// `cols` transforms of W = 2^LGW points each, COLUMN-major: element i of transform c sits at [i * cols + c] (in and out).  One
+// lane per column: W strided loads (consecutive lanes read consecutive elements), the radix-2 DIT stages in registers, W
+// strided stores -- one trip over the data.  This is the step ACROSS the ranks of a transform sharded over several GPUs
+// (myzkp_amd/sharded.py: after the first all-to-all a rank holds [rank a][its slice of t]); the transposes + row transforms
+// it replaces were three trips.  tw: w^j, j < W/2, Montgomery (a plan's in-tile table); has_scale: W^-1 of the inverse.
+template <class P, int LGW>
+__global__ __launch_bounds__(256) void k_ntt_columns(const u32* __restrict__ in, u32* __restrict__ out, size_t cols,
+                                                      const u32* __restrict__ tw, Words8 scale, int has_scale) {
+  constexpr int W = 1 << LGW;
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  Fe<P> x[W];
+#pragma unroll
+  for (int i = 0; i < W; i++) x[(int)(__brev((unsigned)i) >> (32 - LGW))] = gload<P>(in, (size_t)i * cols + c);
+#pragma unroll
+  for (int s = 1; s <= LGW; s++) {
+    const int half = 1 << (s - 1);
+#pragma unroll
+    for (int b = 0; b < W / 2; b++) {
+      const int j = b & (half - 1), g = b >> (s - 1);
+      const int lo = (g << s) | j, hi = lo + half;
+      Fe<P> t = x[hi];
+      if (j != 0) t = FeAsm<P>::mul(t, gload<P>(tw, (size_t)(j << (LGW - s))));
+      else if (s != 1) t = fe_weak_reduce<P>(t);
+      x[hi] = fe_sub_carry<P, 8>(x[lo], t);
+      x[lo] = fe_add_carry<P>(x[lo], t);
+    }
+  }
+  Fe<P> sc;
+  if (has_scale) sc = fe_unpack<P>(scale.w);
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    Fe<P> v = x[k];
+    if (has_scale) v = FeAsm<P>::mul(v, sc);
+    gstore<P>(out, (size_t)k * cols + c, fe_reduce<P>(v));
+  }
+}
+
 // ---- table generation ------------------------------------------------------------------------------
 constexpr int GEN_CHUNK = 16;
 // out[j] = g^j (Montgomery, canonical), j < count, g = root^emul
@@ -655,6 +693,38 @@ int ntt_batch_dev_impl(int fid, const uint64_t* root_host, const void* d_in, voi
   MZK_TRY(get_plan(fid, ilog2(n), inverse != 0, root_host, nullptr, s, &pl, batch));
   if (fid == MZK_FIELD_M128) return run_plan<M128Params>(pl, (const u32*)d_in, (u32*)d_out, s, nullptr, batch);
   return run_plan<FrParams>(pl, (const u32*)d_in, (u32*)d_out, s, nullptr, batch);
+}
+
+template <class P, int LGW>
+static void launch_columns(const NttPlan* pl, const void* d_in, void* d_out, size_t cols, hipStream_t s) {
+  hipLaunchKernelGGL((k_ntt_columns<P, LGW>), dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, (const u32*)d_in, (u32*)d_out, cols,
+                     (const u32*)pl->tw_tile[0], pl->last_scale, pl->has_last_scale ? 1 : 0);
+}
+template <class P>
+static int columns_dispatch(const NttPlan* pl, unsigned lgw, const void* d_in, void* d_out, size_t cols, hipStream_t s) {
+  switch (lgw) {
+    case 1: launch_columns<P, 1>(pl, d_in, d_out, cols, s); break;
+    case 2: launch_columns<P, 2>(pl, d_in, d_out, cols, s); break;
+    case 3: launch_columns<P, 3>(pl, d_in, d_out, cols, s); break;
+    case 4: launch_columns<P, 4>(pl, d_in, d_out, cols, s); break;
+    default: set_error("ntt_columns: 2..16 points per transform"); return MZK_E_ARG;
+  }
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+// cols transforms of n_points (2, 4, 8 or 16) each, column-major; the same root checks and inverse convention as ntt_dev_impl
+int ntt_columns_dev_impl(int fid, const uint64_t* root_host, const void* d_in, void* d_out, size_t n_points, size_t cols, int inverse, hipStream_t s) {
+  if (fid != MZK_FIELD_FR && fid != MZK_FIELD_M128) { set_error("ntt_columns: field id %d has no NTT on this path", fid); return MZK_E_ARG; }
+  if (cols == 0 || n_points == 0) return MZK_OK;
+  if (!is_pow2(n_points)) { set_error("cannot compute ntt of non-power-of-two sequence"); return MZK_E_NOT_POW2; }
+  if (n_points < 2 || n_points > 16) { set_error("ntt_columns: 2..16 points per transform"); return MZK_E_ARG; }
+  if (!d_in || !d_out || !root_host) { set_error("ntt_columns: null pointer"); return MZK_E_ARG; }
+  if (d_in == d_out) { set_error("ntt_columns: in place is not supported"); return MZK_E_ARG; }
+  if (!h_is_canonical(host_field(fid), root_host)) { set_error("ntt: root not canonical"); return MZK_E_RANGE; }
+  NttPlan* pl = nullptr;
+  MZK_TRY(get_plan(fid, ilog2(n_points), inverse != 0, root_host, nullptr, s, &pl));
+  if (fid == MZK_FIELD_M128) return columns_dispatch<M128Params>(pl, ilog2(n_points), d_in, d_out, cols, s);
+  return columns_dispatch<FrParams>(pl, ilog2(n_points), d_in, d_out, cols, s);
 }
 
 int poly_scale_dev_impl(int fid, const void* d_in, size_t n, const uint64_t* ratio_host, const uint64_t* lead_host, void* d_out, hipStream_t s) {

@@ -40,7 +40,7 @@ def sharded_msm(local_partial_fn, fold_fn):
 #     X[W k2 + k1] = sum_t  w_m^(t k2) * w^(t k1) * [ sum_a x[a m + t] w_W^(a k1) ]          w_m = w^W,  w_W = w^m
 # "dif" (contiguous in -> cyclic out, two exchanges):
 #     all-to-all (rank s gets the slice t in [s m/W, (s+1) m/W) of every rank) -> m/W transforms of W points across the
-#     ranks' values -> all-to-all (rank k1 gets y[k1][all t]) -> the m-point transform of y[k1][t] * (w^k1)^t, which IS
+#     ranks' values (mzk_ntt_columns_dev: one trip over the data) -> all-to-all (rank k1 gets y[k1][all t]) -> the m-point transform of y[k1][t] * (w^k1)^t, which IS
 #     fast_coset_evaluate with offset w^k1 and generator w^W (ntt.rs:254-269: the twiddle costs no pass of its own).
 # "dit" (cyclic in -> contiguous out, two exchanges), from j = j2 W + j1, k = k1 m + k2:
 #     X[k1 m + k2] = sum_j1 w_W^(j1 k1) * [ w^(j1 k2) * sum_j2 x[j2 W + j1] w_m^(j2 k2) ]
@@ -77,6 +77,10 @@ def ntt_sharded_steps(modulus, log2n, world, root, inverse, layout_in, layout_ou
         return [lambda ops, r, b: ops.ntt(b, m, root_m, inverse)]
 
     def across(ops, r, b):            # [a][t'] -> m/W transforms over a -> [k1][t']
+        fused = getattr(ops, "ntt_columns", None)
+        out = fused(b, W, m // W, root_W, inverse) if fused else None       # one trip over the data where the backend has it
+        if out is not None:
+            return out
         b = ops.transpose(b, W, m // W)
         b = ops.ntt_rows(b, m // W, W, root_W, inverse)
         return ops.transpose(b, m // W, W)
@@ -131,6 +135,15 @@ class DeviceOps:
         p = self.ct.c_void_p(b.data_ptr())
         self._ok(self.L.mzk_ntt_batch_dev(self.fid, r, p, p, self.ct.c_size_t(n), self.ct.c_size_t(rows), int(bool(inverse)), self._st()))
         return b
+
+    def ntt_columns(self, b, W, cols, root, inverse):
+        if W > 16:
+            return None                      # the schedule falls back to transpose + row transforms + transpose
+        keep, r = self._one(root)
+        out = torch.empty_like(b)
+        self._ok(self.L.mzk_ntt_columns_dev(self.fid, r, self.ct.c_void_p(b.data_ptr()), self.ct.c_void_p(out.data_ptr()), self.ct.c_size_t(W),
+                                            self.ct.c_size_t(cols), int(bool(inverse)), self._st()))
+        return out
 
     def lde(self, b, m, offset, generator):
         k1, o = self._one(offset)

@@ -73,3 +73,40 @@ def test_poly_scale_against_python_integers(env, fid, nl):
     out = np.empty_like(c)
     rc = L.mzk_poly_scale(fid, c.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(4), bad.ctypes.data_as(ctypes.c_void_p), None, out.ctypes.data_as(ctypes.c_void_p))
     assert rc == -6   # MZK_E_RANGE
+
+
+@pytest.mark.parametrize("fid,nl", [(FR, 4), (M128, 2)])
+def test_ntt_columns_equals_row_transforms_of_the_transposed_data(env, fid, nl):
+    """mzk_ntt_columns_dev (column-major batch of 2..16-point transforms, one trip over the data) against the oracle's
+    transform of every column (ntt.rs:7-64), forward and inverse, ragged column counts."""
+    torch, mz, sharded, L, dev, st = env
+    for W in (2, 4, 8, 16):
+        lgw = W.bit_length() - 1
+        w = orc.root_of(fid, lgw)
+        root = mz.to_limbs([w], nl)
+        for cols in (1, 255, 256, 1000):
+            x = orc.synth_vector(fid, 300 + W + cols, W * cols)
+            xd = torch.from_numpy(x.view(np.int64).reshape(-1).copy()).to(dev)
+            yd = torch.empty_like(xd)
+            for inverse in (0, 1):
+                assert L.mzk_ntt_columns_dev(fid, root.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(yd.data_ptr()),
+                                             ctypes.c_size_t(W), ctypes.c_size_t(cols), inverse, st) == 0, L.mzk_last_error().decode()
+                torch.cuda.synchronize()
+                got = yd.cpu().numpy().view(np.uint64).reshape(W, cols, nl)
+                xs = x.reshape(W, cols, nl)
+                for c in (0, cols // 2, cols - 1):
+                    rc, ref = orc.ntt_fast(fid, w, np.ascontiguousarray(xs[:, c, :]), bool(inverse), 1)
+                    assert rc == 0 and np.array_equal(got[:, c, :], ref), (W, cols, inverse, c)
+                # all columns at once against the batched row transforms of the transposed data
+                rows = np.ascontiguousarray(xs.transpose(1, 0, 2))
+                want = mz.ntt_batch(fid, w, rows, bool(inverse)).transpose(1, 0, 2)
+                assert np.array_equal(got, want)
+    x = torch.zeros(32 * 4 * nl, dtype=torch.int64, device=dev)
+    y = torch.zeros_like(x)
+    r32 = mz.to_limbs([orc.root_of(fid, 5)], nl).ctypes.data_as(ctypes.c_void_p)
+    r4 = mz.to_limbs([orc.root_of(fid, 2)], nl)
+    assert L.mzk_ntt_columns_dev(fid, r32, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), ctypes.c_size_t(32), ctypes.c_size_t(4), 0, st) == -1
+    assert L.mzk_ntt_columns_dev(fid, r4.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr()), ctypes.c_size_t(4), ctypes.c_size_t(4), 0, st) == -1
+    assert L.mzk_ntt_columns_dev(fid, r4.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), ctypes.c_size_t(3), ctypes.c_size_t(4), 0, st) == -2
+    # a root of the wrong order is refused like everywhere else (ntt.rs:15-22)
+    assert L.mzk_ntt_columns_dev(fid, r32, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), ctypes.c_size_t(4), ctypes.c_size_t(4), 0, st) == -3
