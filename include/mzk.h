@@ -305,6 +305,19 @@ int mzk_g1_fold_partials_dev(const void* d_partials16, int count, void* d_out_xy
  * collective library needed for 128 bytes per GPU) and folded there.  All W pipelines run concurrently.  Blocking. */
 void mzk_shard_range(size_t n, int rank, int world, size_t* lo, size_t* hi);
 int mzk_msm_g1_bn254_multi(const uint64_t* scalars, const uint64_t* points_xy, size_t n, uint64_t out_xy[8]);
+/* ONE n-point transform (ntt / intt, ntt.rs:7-64; natural order) whose vector is spread over the W contexts -- the four-step
+ * layout of SURVEY 8e: W-point transforms across the GPUs (mzk_ntt_columns_dev), the local n/W-point transform with the
+ * twiddle fused into it (fast_coset_evaluate with offset root^rank), and all-to-all exchanges between them (peer copies,
+ * each destination pulling its chunk of every source).  Layouts of a distributed vector: CONTIGUOUS = part r is
+ * x[r n/W, (r+1) n/W); CYCLIC = part r is x[r], x[r + W], ...  contiguous -> cyclic and cyclic -> contiguous cost two
+ * exchanges, contiguous -> contiguous three (cyclic -> cyclic: MZK_E_ARG); keep the cyclic layout between a forward and an
+ * inverse transform.  W a power of two <= 16 with W^2 <= n.  d_in_parts[r] / d_out_parts[r]: n/W elements on context r's
+ * GPU, inputs complete before the call, not overwritten; blocking.  One process per GPU: myzkp_amd/sharded.py runs the
+ * same schedule over RCCL's all-to-all. */
+enum { MZK_LAYOUT_CONTIGUOUS = 0, MZK_LAYOUT_CYCLIC = 1 };
+int mzk_ntt_multi_dev(int field_id, const uint64_t* root, const void* const* d_in_parts, void* const* d_out_parts, size_t n, int inverse,
+                      int layout_in, int layout_out);
+int mzk_ntt_multi(int field_id, const uint64_t* root, const uint64_t* in, uint64_t* out, size_t n, int inverse);
 typedef struct mzk_srs_multi mzk_srs_multi;
 /* PublicKeyKZG.powers_1 sharded over the contexts: from host points, or built on the GPUs (setup_kzg, kzg.rs:27-40:
  * context r computes powers [lo_r, hi_r) itself; with_tables as in mzk_srs_from_device_ex). */

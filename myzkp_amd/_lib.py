@@ -254,6 +254,25 @@ def msm_g1_multi(scalars, points):
     return array_to_points(out)[0]
 
 
+LAYOUT_CONTIGUOUS, LAYOUT_CYCLIC = 0, 1
+
+
+def ntt_multi(fid, root, values, inverse=False):
+    """ntt::ntt / ntt::intt of ONE vector spread over every context of init_devices (four-step layout, mzk_ntt_multi)."""
+    v = _arr(fid, values)
+    out = np.empty_like(v)
+    _check(lib().mzk_ntt_multi(fid, _p(_one(fid, root)), _p(v), _p(out), ctypes.c_size_t(v.shape[0]), int(bool(inverse))))
+    return out
+
+
+def ntt_multi_dev(fid, root, in_ptrs, out_ptrs, n, inverse=False, layout_in=LAYOUT_CONTIGUOUS, layout_out=LAYOUT_CONTIGUOUS):
+    """The same with the parts resident in HBM: in_ptrs[r] / out_ptrs[r] = device pointers (ints) on context r's GPU."""
+    W = len(in_ptrs)
+    ins = (ctypes.c_void_p * W)(*[ctypes.c_void_p(int(p)) for p in in_ptrs])
+    outs = (ctypes.c_void_p * W)(*[ctypes.c_void_p(int(p)) for p in out_ptrs])
+    _check(lib().mzk_ntt_multi_dev(fid, _p(_one(fid, root)), ins, outs, ctypes.c_size_t(n), int(bool(inverse)), int(layout_in), int(layout_out)))
+
+
 class SrsMulti:
     """PublicKeyKZG.powers_1 sharded over the contexts of init_devices (kzg.rs:8-11): from host points, or built on
     the GPUs from (alpha, g1) like setup_kzg (kzg.rs:27-40)."""

@@ -110,6 +110,7 @@ int ntt_batch_dev_impl(int fid, const uint64_t* root_host, const void* d_in, voi
 int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_t* offset_host,
                        const uint64_t* generator_host, void* d_out, size_t order, hipStream_t s, size_t batch = 1);
 int ntt_columns_dev_impl(int fid, const uint64_t* root_host, const void* d_in, void* d_out, size_t n_points, size_t cols, int inverse, hipStream_t s);
+int transpose_elems_dev_impl(int fid, const void* d_in, void* d_out, size_t rows, size_t cols, hipStream_t s);
 int poly_scale_dev_impl(int fid, const void* d_in, size_t n, const uint64_t* ratio_host, const uint64_t* lead_host, void* d_out, hipStream_t s);
 int coset_divide_dev_impl(int fid, const void* d_lhs, size_t tl, const void* d_rhs, size_t tr, const uint64_t* offset_host,
                           const uint64_t* root_host, size_t order, void* d_out, hipStream_t s);

@@ -59,6 +59,142 @@ static int gather_and_fold(int world, const uint64_t* h_records, uint64_t out_xy
   return MZK_OK;
 }
 
+
+// ---- one transform sharded over the contexts (the four-step layout; schedule and layouts as in
+// myzkp_amd/sharded.py, which runs the same steps one process per GPU over RCCL's all-to-all) ---------------------------
+// Context r holds part r of the vector.  An "exchange" is W x W chunk copies (peer copies between GPUs, device copies when
+// contexts share one): destination d pulls chunk d of every source's buffer on ITS OWN stream after waiting for the event
+// the source recorded behind the step that produced the buffer.  Three scratch buffers per context (A, B, C: n / W elements
+// each) are each written once per phase and only re-used after every reader is known to be done (the waits above).
+struct Exchange {
+  int W;
+  size_t chunk_bytes;
+  hipEvent_t ev[MZK_MAX_CTX];
+};
+static int record_all(Exchange& x) {
+  for (int r = 0; r < x.W; r++) {
+    CtxScope sc(r);
+    if (!sc.ok) return MZK_E_ARG;
+    MZK_HIP(hipEventRecord(x.ev[r], ctx().stream));
+  }
+  return MZK_OK;
+}
+// dst[d] + s * chunk  <-  src[s] + d * chunk, for every (d, s); wait_events: the sources were produced by this call
+static int exchange(Exchange& x, void* const* src, void* const* dst, bool wait_events) {
+  for (int d = 0; d < x.W; d++) {
+    CtxScope sc(d);
+    if (!sc.ok) return MZK_E_ARG;
+    hipStream_t st = ctx().stream;
+    const int dev_d = ctx().device;
+    for (int s = 0; s < x.W; s++) {
+      if (wait_events && s != d) MZK_HIP(hipStreamWaitEvent(st, x.ev[s], 0));
+      const char* from = (const char*)src[s] + (size_t)d * x.chunk_bytes;
+      char* to = (char*)dst[d] + (size_t)s * x.chunk_bytes;
+      const int dev_s = mzk_ctx_device(s);
+      if (dev_s == dev_d) MZK_HIP(hipMemcpyAsync(to, from, x.chunk_bytes, hipMemcpyDeviceToDevice, st));
+      else MZK_HIP(hipMemcpyPeerAsync(to, dev_d, from, dev_s, x.chunk_bytes, st));
+    }
+  }
+  return MZK_OK;
+}
+static int ntt_multi_impl(int fid, const uint64_t* root, const void* const* in, void* const* out, size_t n, int inverse, int layout_in, int layout_out) {
+  if (fid != MZK_FIELD_FR && fid != MZK_FIELD_M128) { set_error("ntt_multi: field id %d has no NTT on this path", fid); return MZK_E_ARG; }
+  if (n == 0) return MZK_OK;
+  if (n & (n - 1)) { set_error("cannot compute ntt of non-power-of-two sequence"); return MZK_E_NOT_POW2; }
+  if (!root || !in || !out) { set_error("ntt_multi: null pointer"); return MZK_E_ARG; }
+  const int W = ctx_count();
+  if ((W & (W - 1)) || (size_t)W * W > n || W > 16) { set_error("ntt_multi: %d contexts: need a power of two <= 16 with world^2 <= n", W); return MZK_E_ARG; }
+  const bool cyc_in = layout_in == MZK_LAYOUT_CYCLIC, cyc_out = layout_out == MZK_LAYOUT_CYCLIC;
+  if ((layout_in != MZK_LAYOUT_CONTIGUOUS && !cyc_in) || (layout_out != MZK_LAYOUT_CONTIGUOUS && !cyc_out) || (cyc_in && cyc_out)) {
+    set_error("ntt_multi: layouts are contiguous->contiguous, contiguous->cyclic or cyclic->contiguous"); return MZK_E_ARG;
+  }
+  for (int r = 0; r < W; r++) if (!in[r] || !out[r]) { set_error("ntt_multi: null part pointer for context %d", r); return MZK_E_ARG; }
+  const HostField* hf = host_field(fid);
+  if (!h_is_canonical(hf, root)) { set_error("ntt: root not canonical"); return MZK_E_RANGE; }
+  const size_t esz = field_bytes(fid), m = n / (size_t)W, cols = m / (size_t)W;
+  if (W == 1) {
+    CtxScope sc(0);
+    if (!sc.ok) return MZK_E_ARG;
+    WsGuard wsg(ctx().stream);
+    MZK_TRY(ntt_dev_impl(fid, root, in[0], out[0], n, inverse, nullptr, ctx().stream));
+    MZK_HIP(hipStreamSynchronize(ctx().stream));
+    return MZK_OK;
+  }
+  // the reference's two assertions on the root (ntt.rs:15-22), before anything is enqueued
+  uint64_t t[4], w[4] = {0, 0, 0, 0}, root_W[4], root_m[4];
+  h_powmod_u64(hf, t, root, n);
+  if (!h_is_one(hf, t)) { set_error("primitive root must be nth root of unity, where n is len(values)"); return MZK_E_ROOT_ORDER; }
+  h_powmod_u64(hf, t, root, n / 2);
+  if (h_is_one(hf, t)) { set_error("primitive root is not primitive nth root of unity, where n is len(values)"); return MZK_E_ROOT_PRIM; }
+  h_powmod_u64(hf, root_W, root, m);            // forward roots of the W- and m-point transforms, as their callers pass them
+  h_powmod_u64(hf, root_m, root, (uint64_t)W);
+  if (inverse) h_powmod_u64(hf, w, root, n - 1); else memcpy(w, root, 8 * hf->nl);      // the root the sums run over
+
+  Exchange x{W, cols * esz, {}};
+  void *A[MZK_MAX_CTX], *B[MZK_MAX_CTX], *C[MZK_MAX_CTX];
+  int rc = MZK_OK;
+  int made = 0;
+  for (int r = 0; r < W && rc == MZK_OK; r++) {
+    CtxScope sc(r);
+    if (!sc.ok) { rc = MZK_E_ARG; break; }
+    if (hipEventCreateWithFlags(&x.ev[r], hipEventDisableTiming) != hipSuccess) { set_error("ntt_multi: hipEventCreate failed"); rc = MZK_E_HIP; break; }
+    made = r + 1;
+    rc = ws_get(WS_MISC_D, m * esz, &A[r]);
+    if (rc == MZK_OK) rc = ws_get(WS_MISC_E, m * esz, &B[r]);
+    if (rc == MZK_OK) rc = ws_get(WS_MISC_F, m * esz, &C[r]);
+  }
+  // a local step on every context: fn(r, stream)
+  auto each = [&](auto fn) -> int {
+    for (int r = 0; r < W; r++) {
+      CtxScope sc(r);
+      if (!sc.ok) return MZK_E_ARG;
+      WsGuard wsg(ctx().stream);
+      MZK_TRY(fn(r, ctx().stream));
+    }
+    return MZK_OK;
+  };
+  auto twiddle = [&](int r, uint64_t* o) { h_powmod_u64(hf, o, w, (uint64_t)r); };
+  if (rc == MZK_OK && !cyc_in) {
+    // contiguous in: exchange, W-point transforms across the ranks, exchange, local transform with its twiddle fused
+    // (fast_coset_evaluate with offset w^rank, ntt.rs:254-269), [exchange + interleave for a contiguous result]
+    rc = exchange(x, (void* const*)in, A, false);
+    if (rc == MZK_OK) rc = each([&](int r, hipStream_t s) { return ntt_columns_dev_impl(fid, root_W, A[r], B[r], (size_t)W, cols, inverse, s); });
+    if (rc == MZK_OK) rc = record_all(x);
+    if (rc == MZK_OK) rc = exchange(x, B, C, true);
+    if (rc == MZK_OK) rc = each([&](int r, hipStream_t s) -> int {
+      uint64_t tw[4] = {0, 0, 0, 0};
+      twiddle(r, tw);
+      void* dst = cyc_out ? out[r] : A[r];
+      if (!inverse) return coset_lde_dev_impl(fid, C[r], m, tw, root_m, dst, m, s);
+      MZK_TRY(poly_scale_dev_impl(fid, C[r], m, tw, nullptr, C[r], s));
+      return ntt_dev_impl(fid, root_m, C[r], dst, m, 1, nullptr, s);
+    });
+    if (rc == MZK_OK && !cyc_out) {
+      rc = record_all(x);
+      if (rc == MZK_OK) rc = exchange(x, A, B, true);
+      if (rc == MZK_OK) rc = each([&](int r, hipStream_t s) { return transpose_elems_dev_impl(fid, B[r], out[r], (size_t)W, cols, s); });
+    }
+  } else if (rc == MZK_OK) {
+    // cyclic in: local transform, Polynomial::scale by w^rank (polynomial.rs:167-174), exchange, W-point transforms, exchange
+    rc = each([&](int r, hipStream_t s) -> int {
+      uint64_t tw[4] = {0, 0, 0, 0};
+      twiddle(r, tw);
+      MZK_TRY(ntt_dev_impl(fid, root_m, in[r], A[r], m, inverse, nullptr, s));
+      return poly_scale_dev_impl(fid, A[r], m, tw, nullptr, A[r], s);
+    });
+    if (rc == MZK_OK) rc = record_all(x);
+    if (rc == MZK_OK) rc = exchange(x, A, B, true);
+    if (rc == MZK_OK) rc = each([&](int r, hipStream_t s) { return ntt_columns_dev_impl(fid, root_W, B[r], C[r], (size_t)W, cols, inverse, s); });
+    if (rc == MZK_OK) rc = record_all(x);
+    if (rc == MZK_OK) rc = exchange(x, C, (void* const*)out, true);
+  }
+  for (int r = 0; r < made; r++) {
+    CtxScope sc(r);
+    if (sc.ok) { (void)hipStreamSynchronize(ctx().stream); (void)hipEventDestroy(x.ev[r]); }
+  }
+  return rc;
+}
+
 }  // namespace mzk
 
 extern "C" {
@@ -200,6 +336,42 @@ int mzk_kzg_commit_srs_multi(const mzk_srs_multi* h, const uint64_t* coef, size_
 }
 int mzk_kzg_commit_srs_multi_dev(const mzk_srs_multi* h, const void* const* d_coef_shards, size_t n, uint64_t out_xy[8]) {
   return commit_multi(h, nullptr, d_coef_shards, n, out_xy);
+}
+
+// One n-point transform (ntt / intt, ntt.rs:7-64) whose vector is spread over the contexts; see include/mzk.h.
+int mzk_ntt_multi_dev(int field_id, const uint64_t* root, const void* const* d_in_parts, void* const* d_out_parts, size_t n, int inverse,
+                      int layout_in, int layout_out) {
+  MZK_TRY(ensure_init());
+  return ntt_multi_impl(field_id, root, d_in_parts, d_out_parts, n, inverse, layout_in, layout_out);
+}
+// host vector in natural order: context r gets x[r n/W, (r+1) n/W) and returns the same slice of the result
+int mzk_ntt_multi(int field_id, const uint64_t* root, const uint64_t* in, uint64_t* out, size_t n, int inverse) {
+  MZK_TRY(ensure_init());
+  if (n == 0) return MZK_OK;
+  if (!in || !out) { set_error("ntt_multi: null pointer"); return MZK_E_ARG; }
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("ntt_multi: field id %d has no NTT on this path", field_id); return MZK_E_ARG; }
+  const int W = ctx_count();
+  if (n % (size_t)W) { set_error("ntt_multi: %d contexts do not divide n", W); return MZK_E_ARG; }
+  const size_t esz = field_bytes(field_id), m = n / (size_t)W;
+  void *din[MZK_MAX_CTX], *dout[MZK_MAX_CTX];
+  for (int r = 0; r < W; r++) {
+    CtxScope sc(r);
+    if (!sc.ok) return MZK_E_ARG;
+    hipStream_t s = ctx().stream;
+    WsGuard wsg(s);
+    MZK_TRY(ws_get(WS_NTT_IO_B, m * esz, &din[r]));
+    MZK_TRY(ws_get(WS_MISC_C, m * esz, &dout[r]));
+    MZK_HIP(hipMemcpyAsync(din[r], (const char*)in + (size_t)r * m * esz, m * esz, hipMemcpyHostToDevice, s));
+  }
+  for (int r = 0; r < W; r++) { CtxScope sc(r); if (!sc.ok) return MZK_E_ARG; MZK_HIP(hipStreamSynchronize(ctx().stream)); }
+  MZK_TRY(ntt_multi_impl(field_id, root, (const void* const*)din, dout, n, inverse, MZK_LAYOUT_CONTIGUOUS, MZK_LAYOUT_CONTIGUOUS));
+  for (int r = 0; r < W; r++) {
+    CtxScope sc(r);
+    if (!sc.ok) return MZK_E_ARG;
+    MZK_HIP(hipMemcpyAsync((char*)out + (size_t)r * m * esz, dout[r], m * esz, hipMemcpyDeviceToHost, ctx().stream));
+    MZK_HIP(hipStreamSynchronize(ctx().stream));
+  }
+  return MZK_OK;
 }
 
 }  // extern "C"

@@ -353,6 +353,19 @@ __global__ __launch_bounds__(256) void k_ntt_columns(const u32* __restrict__ in,
   }
 }
 
+// out[c * rows + r] = in[r * cols + c] over whole elements (NW words each): the interleave that turns the landing buffer of
+// the last exchange of a sharded transform, [source rank][k2'], into natural order k2' * W + rank.
+template <int NW>
+__global__ void k_transpose_elems(const u32* __restrict__ in, u32* __restrict__ out, size_t rows, size_t cols) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // output element index: c * rows + r
+  if (i >= rows * cols) return;
+  const size_t c = i / rows, r = i - c * rows;
+  const uint4* src = reinterpret_cast<const uint4*>(in + (r * cols + c) * NW);
+  uint4* dst = reinterpret_cast<uint4*>(out + i * NW);
+#pragma unroll
+  for (int q = 0; q < NW / 4; q++) dst[q] = src[q];
+}
+
 // ---- table generation ------------------------------------------------------------------------------
 constexpr int GEN_CHUNK = 16;
 // out[j] = g^j (Montgomery, canonical), j < count, g = root^emul
@@ -725,6 +738,16 @@ int ntt_columns_dev_impl(int fid, const uint64_t* root_host, const void* d_in, v
   MZK_TRY(get_plan(fid, ilog2(n_points), inverse != 0, root_host, nullptr, s, &pl));
   if (fid == MZK_FIELD_M128) return columns_dispatch<M128Params>(pl, ilog2(n_points), d_in, d_out, cols, s);
   return columns_dispatch<FrParams>(pl, ilog2(n_points), d_in, d_out, cols, s);
+}
+
+int transpose_elems_dev_impl(int fid, const void* d_in, void* d_out, size_t rows, size_t cols, hipStream_t s) {
+  const size_t total = rows * cols;
+  if (total == 0) return MZK_OK;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (fid == MZK_FIELD_M128) hipLaunchKernelGGL((k_transpose_elems<4>), dim3(blocks), dim3(256), 0, s, (const u32*)d_in, (u32*)d_out, rows, cols);
+  else hipLaunchKernelGGL((k_transpose_elems<8>), dim3(blocks), dim3(256), 0, s, (const u32*)d_in, (u32*)d_out, rows, cols);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
 }
 
 int poly_scale_dev_impl(int fid, const void* d_in, size_t n, const uint64_t* ratio_host, const uint64_t* lead_host, void* d_out, hipStream_t s) {

@@ -204,3 +204,80 @@ def test_open_batch_equals_single_openings(mz, nctx):
             assert orc.from_limbs(y1.cpu().numpy().view(np.uint64).reshape(1, 4))[0] == ys[k]
             assert mz.array_to_points(w1.cpu().numpy().view(np.uint64).reshape(1, 8))[0] == ws[k]
         h.close()
+
+
+# ---- one transform sharded over the contexts (mzk_ntt_multi[_dev]; SURVEY 8e four-step layout) ------------------------------
+@pytest.mark.parametrize("world", [1, 2, 4, 8, 16])
+def test_ntt_multi_host_vector_equals_oracle(mz, world):
+    mz.init_devices([0] * world)
+    for fid in (orc.FR, orc.M128):
+        for lg in (8, 13):
+            w = orc.root_of(fid, lg)
+            x = orc.synth_vector(fid, 900 + lg, 1 << lg)
+            for inverse in (False, True):
+                rc, want = orc.ntt_fast(fid, w, x, inverse)
+                assert rc == 0 and np.array_equal(mz.ntt_multi(fid, w, x, inverse), want), (world, fid, lg, inverse)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_ntt_multi_dev_layouts_equal_single_gpu_transform(mz, world):
+    """Parts resident in HBM, the three layout pairs, forward and inverse, 2^20 points: every part bit-identical to the
+    corresponding part of the single-context transform; the inputs are left untouched."""
+    import ctypes, torch
+    mz.init_devices([0] * world)
+    L = mz.lib()
+    dev = torch.device("cuda", 0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lg = 20
+    n = 1 << lg
+    for fid, nl in ((orc.FR, 4), (orc.M128, 2)):
+        w = orc.root_of(fid, lg)
+        root = mz.to_limbs([w], nl)
+        x = torch.empty(n * nl, dtype=torch.int64, device=dev)
+        assert L.mzk_synth_field_dev(fid, ctypes.c_uint64(4242), ctypes.c_size_t(n), ctypes.c_void_p(x.data_ptr()), st) == 0
+        for inverse in (False, True):
+            want = torch.empty_like(x)
+            assert L.mzk_ntt_dev(fid, root.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(want.data_ptr()),
+                                 ctypes.c_size_t(n), int(inverse), st) == 0
+            torch.cuda.synchronize()
+
+            def parts(t, layout):
+                v = t.view(-1, nl)
+                m = n // world
+                if layout == mz.LAYOUT_CONTIGUOUS:
+                    return [v[r * m:(r + 1) * m].contiguous().view(-1) for r in range(world)]
+                return [v[r::world].contiguous().view(-1) for r in range(world)]
+
+            for lin, lout in ((0, 0), (0, 1), (1, 0)):
+                ins = parts(x, lin)
+                keep = [p.clone() for p in ins]
+                outs = [torch.zeros_like(p) for p in ins]
+                torch.cuda.synchronize()
+                mz.ntt_multi_dev(fid, w, [p.data_ptr() for p in ins], [p.data_ptr() for p in outs], n, inverse, lin, lout)
+                for r, (got, exp) in enumerate(zip(outs, parts(want, lout))):
+                    assert torch.equal(got, exp), (world, fid, inverse, lin, lout, r)
+                assert all(torch.equal(a, b) for a, b in zip(ins, keep))
+
+
+def test_ntt_multi_argument_errors(mz):
+    import ctypes
+    L = mz.lib()
+    mz.init_devices([0] * 3)
+    x = orc.synth_vector(orc.FR, 1, 9)
+    with pytest.raises(mz.MzkError) as e:
+        mz.ntt_multi(orc.FR, orc.root_of(orc.FR, 3), x[:9])
+    assert e.value.code in (-1, -2)
+    mz.init_devices([0] * 4)
+    with pytest.raises(mz.MzkError) as e:        # world^2 > n
+        mz.ntt_multi(orc.FR, orc.root_of(orc.FR, 3), x[:8])
+    assert e.value.code == -1
+    x = orc.synth_vector(orc.FR, 1, 64)
+    with pytest.raises(mz.MzkError) as e:        # root of the wrong order (ntt.rs:15-18)
+        mz.ntt_multi(orc.FR, orc.root_of(orc.FR, 7), x)
+    assert e.value.code == -3
+    with pytest.raises(mz.MzkError) as e:        # not primitive (ntt.rs:19-22)
+        mz.ntt_multi(orc.FR, orc.root_of(orc.FR, 5), x)
+    assert e.value.code == -4
+    with pytest.raises(mz.MzkError) as e:        # cyclic -> cyclic is not offered
+        mz.ntt_multi_dev(orc.FR, orc.root_of(orc.FR, 6), [8, 8, 8, 8], [8, 8, 8, 8], 64, False, 1, 1)
+    assert e.value.code == -1
