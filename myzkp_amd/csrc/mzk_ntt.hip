@@ -36,6 +36,10 @@ constexpr int NTHREADS = MZK_NTT_THREADS;
 #define MZK_NTT_MAX_LEVEL_LOG 8
 #endif
 constexpr int MAX_LEVEL_LOG = MZK_NTT_MAX_LEVEL_LOG;
+#ifndef MZK_NTT_LAZY_FIRST
+#define MZK_NTT_LAZY_FIRST 1       // 0: A/B builds of the carry-everywhere butterflies (tools/timing/time_ntt.py with MZK_HIP_LIB)
+#endif
+constexpr bool NTT_LAZY_FIRST = MZK_NTT_LAZY_FIRST != 0;
 // Tile geometry.  Small (1024 elements, 256 lanes, levels of <= 2^8): every size below 2^20.  Large (4096 elements,
 // 1024 lanes = one workgroup per CU, levels of <= 2^10): from 2^20 points on, where 256+ workgroups exist -- a 2^20
 // transform is TWO passes of 2^10 levels instead of three (one global round trip and one inter-pass twiddle product
@@ -143,7 +147,11 @@ __device__ __forceinline__ void stage_twiddles(u32* twl, const u32* __restrict__
 // One DIT butterfly in registers: (lo, hi) <- (lo + w hi, lo - w hi).  `trivial` (w = 1) skips the product;
 // then hi must still be brought below the 4 p the K = 8 subtraction tolerates, unless it is a raw input
 // (stage 1: < 2^(32 NW)).
-template <class P, class G>
+// LAZY: the sums stay limb-wise (no carry propagation) -- the first stage of a register-resident stage pair, whose outputs
+// are only added, subtracted or multiplied again before the second stage normalises them (limbs < 2^29 + 2^30 there: the
+// product takes one operand with limbs up to 3 * 2^30, fe_mul's column bound, and the carrying add/sub any u32 that
+// does not overflow with 8p added).  Same values either way.
+template <class P, class G, bool LAZY = false>
 __device__ __forceinline__ void bfly(Fe<P>& lo, Fe<P>& hi, const u32* twl, int tws, int ti, bool trivial, bool raw) {
   Fe<P> t = hi;
   if (!trivial) {
@@ -161,8 +169,13 @@ __device__ __forceinline__ void bfly(Fe<P>& lo, Fe<P>& hi, const u32* twl, int t
   } else if (!raw) {
     t = fe_weak_reduce<P>(t);
   }
-  hi = fe_sub_carry<P, 8>(lo, t);
-  lo = fe_add_carry<P>(lo, t);
+  if constexpr (LAZY) {
+    hi = fe_sub<P, 8>(lo, t);
+    lo = fe_add<P>(lo, t);
+  } else {
+    hi = fe_sub_carry<P, 8>(lo, t);
+    lo = fe_add_carry<P>(lo, t);
+  }
 }
 // In-LDS radix-2/radix-4 DIT over the k-dimension of a [2^lgn][2^lgc] tile whose rows were stored
 // bit-reversed; leaves natural order.  Stages run in pairs: a lane loads the four elements of a radix-4
@@ -205,8 +218,8 @@ __device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, i
       const bool triv = (j1 == 0);
       const bool raw = (s == 1);
       const int t1 = j1 << (lgn - s);
-      bfly<P, G>(x0, x1, twl, tws, t1, triv, raw);
-      bfly<P, G>(x2, x3, twl, tws, t1, triv, raw);
+      bfly<P, G, NTT_LAZY_FIRST>(x0, x1, twl, tws, t1, triv, raw);
+      bfly<P, G, NTT_LAZY_FIRST>(x2, x3, twl, tws, t1, triv, raw);
       bfly<P, G>(x0, x2, twl, tws, j1 << (lgn - s - 1), triv, false);
       bfly<P, G>(x1, x3, twl, tws, (j1 + (1 << lgh)) << (lgn - s - 1), false, false);
       lds_store<P, G>(lds, p0, x0);

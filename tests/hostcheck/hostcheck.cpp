@@ -3,6 +3,7 @@
 // (29-bit-limb Montgomery field ops, XYZZ group law) against the oracle.  Never shipped.
 #include <stdint.h>
 #include <string.h>
+#include <vector>
 #include "../../myzkp_amd/csrc/mzk_ec.h"
 #include "../../myzkp_amd/csrc/mzk_g2.h"
 #include "../../myzkp_amd/csrc/mzk_glv.h"
@@ -40,12 +41,61 @@ template <class P> static void run_field(int op, const u32* a, const u32* b, u32
   fe_pack<P>(fe_from_mont<P>(r), out);
 }
 
+// The in-tile stage schedule of mzk_ntt.hip (tile_stages / bfly) on a plain array, with the bounds assertions on: radix-2 DIT
+// over bit-reversed input, stages in pairs -- the FIRST stage of a pair keeps its sums limb-wise (fe_add / fe_sub<8>, no carry
+// propagation), the second normalises (fe_add_carry / fe_sub_carry<8>); a twiddle of 1 skips the product (weak reduction
+// instead, except on raw stage-1 inputs); an odd level count starts with one carrying stage.  Data plain, twiddles
+// Montgomery, like the kernels.  words: n x NW in, n x NW out (reduced, natural order); tw: n/2 twiddles w^j, plain words.
+template <class P> static void run_ntt_tile(const u32* words, int lgn, const u32* tw_words, u32* out) {
+  const int n = 1 << lgn;
+  std::vector<Fe<P>> x(n), tw(n / 2 > 0 ? n / 2 : 1);
+  for (int j = 0; j < n / 2; j++) tw[j] = fe_reduce<P>(fe_to_mont<P>(fe_unpack<P>(tw_words + (size_t)j * P::NW)));
+  for (int j = 0; j < n; j++) {
+    int k = 0;
+    for (int b = 0; b < lgn; b++) if (j & (1 << b)) k |= 1 << (lgn - 1 - b);
+    x[k] = fe_unpack<P>(words + (size_t)j * P::NW);
+  }
+  auto bfly = [&](Fe<P>& lo, Fe<P>& hi, int ti, bool trivial, bool raw, bool lazy) {
+    Fe<P> t = hi;
+    if (!trivial) t = fe_mul<P>(t, tw[ti]);
+    else if (!raw) t = fe_weak_reduce<P>(t);
+    if (lazy) { hi = fe_sub<P, 8>(lo, t); lo = fe_add<P>(lo, t); }
+    else { hi = fe_sub_carry<P, 8>(lo, t); lo = fe_add_carry<P>(lo, t); }
+  };
+  int s = 1;
+  if (lgn & 1) {
+    for (int g = 0; g < n / 2; g++) bfly(x[2 * g], x[2 * g + 1], 0, true, true, false);
+    s = 2;
+  }
+  for (; s + 1 <= lgn; s += 2) {
+    const int lgh = s - 1, half = 1 << lgh;
+    for (int grp = 0; grp < (n >> (s + 1)); grp++)
+      for (int j1 = 0; j1 < half; j1++) {
+        const int p0 = (grp << (s + 1)) | j1, d1 = half, d2 = half << 1;
+        const bool triv = j1 == 0, raw = s == 1;
+        const int t1 = j1 << (lgn - s);
+        bfly(x[p0], x[p0 + d1], t1, triv, raw, true);
+        bfly(x[p0 + d2], x[p0 + d2 + d1], t1, triv, raw, true);
+        bfly(x[p0], x[p0 + d2], j1 << (lgn - s - 1), triv, false, false);
+        bfly(x[p0 + d1], x[p0 + d2 + d1], (j1 + half) << (lgn - s - 1), false, false, false);
+      }
+  }
+  for (int k = 0; k < n; k++) fe_pack<P>(fe_reduce<P>(x[k]), out + (size_t)k * P::NW);
+}
+
 extern "C" {
 // fid: 0 = Fr, 1 = M128, 2 = Fq.  Words are the ABI encoding (8 or 4 u32, canonical).
 int hc_field_op(int fid, int op, const u32* a, const u32* b, u32* out) {
   if (fid == 0) run_field<FrParams>(op, a, b, out);
   else if (fid == 1) run_field<M128Params>(op, a, b, out);
   else if (fid == 2) run_field<FqParams>(op, a, b, out);
+  else return -1;
+  return 0;
+}
+// one in-tile transform of 2^lgn points by the kernels' stage schedule (bounds asserted along the way)
+int hc_ntt_tile(int fid, const u32* words, int lgn, const u32* tw_words, u32* out) {
+  if (fid == 0) run_ntt_tile<FrParams>(words, lgn, tw_words, out);
+  else if (fid == 1) run_ntt_tile<M128Params>(words, lgn, tw_words, out);
   else return -1;
   return 0;
 }

@@ -190,3 +190,26 @@ def test_glv_split_identity_and_bounds(hc):
     for kk in (1, 5, 12345678901234567890):
         P = orc.ec_mul(0, (1, 2), kk)
         assert orc.ec_mul(0, P, lam) == (beta * P[0] % P_FQ, P[1])
+
+
+def test_ntt_stage_schedule_with_lazy_first_stages_holds_its_bounds(hc):
+    """The kernels' in-tile stage schedule (mzk_ntt.hip tile_stages: stage pairs, first stage without carry propagation)
+    restated on a plain array in hostcheck.cpp and run with the bounds assertions on: every level count 1..10, seeded random
+    inputs, all p - 1, and raw all-ones words (non-canonical input must not break a limb bound either); canonical inputs
+    against the oracle's transform (ntt.rs:7-48)."""
+    for fid, nl in ((FR, 4), (M128, 2)):
+        p = orc.MOD[fid]
+        nw = 2 * nl
+        for lgn in range(1, 11):
+            n = 1 << lgn
+            w = orc.root_of(fid, lgn)
+            tw = orc.to_limbs([pow(w, j, p) for j in range(max(n // 2, 1))], nl).view(np.uint32).reshape(-1)
+            cases = [orc.synth_vector(fid, 40 + lgn, n, 1), orc.to_limbs([p - 1] * n, nl), orc.to_limbs([1] + [0] * (n - 1), nl)]
+            for x in cases:
+                out = np.zeros(n * nw, dtype=np.uint32)
+                assert hc.hc_ntt_tile(fid, orc.ptr(np.ascontiguousarray(x).view(np.uint32).reshape(-1)), lgn, orc.ptr(tw), orc.ptr(out)) == 0
+                rc, want = orc.ntt_fast(fid, w, np.ascontiguousarray(x), False, 1)
+                assert rc == 0 and np.array_equal(out.view(np.uint64).reshape(n, nl), want), (fid, lgn)
+            raw = np.full(n * nw, 0xFFFFFFFF, dtype=np.uint32)          # bounds only: the asserts inside must hold
+            out = np.zeros(n * nw, dtype=np.uint32)
+            assert hc.hc_ntt_tile(fid, orc.ptr(raw), lgn, orc.ptr(tw), orc.ptr(out)) == 0
