@@ -9,6 +9,7 @@
 //   Polynomial<F>                            algebra/polynomial.rs:69-74
 //     ::eval_with_powers_on_curve            polynomial.rs:156-165      -> mzk_msm_g1_bn254
 //     ::fft_multiply                         polynomial.rs:242-276      -> mzk_fft_multiply
+//     ::scale                                polynomial.rs:167-174      -> mzk_poly_scale
 //   ntt / intt / fast_multiply / fast_coset_evaluate   algebra/ntt.rs:7-116, :254-269
 //   PublicKeyKZG, ProofKZG, setup_kzg_with_alpha / commit_kzg / open_kzg   algebra/kzg.rs:8-72
 //   get_nth_root_of_m128                     zkstark/fri.rs:423-447
@@ -139,6 +140,13 @@ template <class F> struct Polynomial {
     size_t n = 0;
     expect(mzk_fft_multiply(field_id(), a.data(), coef.size(), b.data(), other.coef.size(), omega.value.data(), out.data(), &n));
     return Polynomial{from_wire<F>(out, n)};
+  }
+  // polynomial.rs:167-174: coef[i] * offset^i
+  Polynomial scale(const F& offset) const {
+    auto a = to_wire(coef);
+    std::vector<uint64_t> out(a.size());
+    expect(mzk_poly_scale(field_id(), a.data(), coef.size(), offset.value.data(), nullptr, out.data()));
+    return Polynomial{from_wire<F>(out, coef.size())};
   }
   static int field_id() { return F().value.size() == 2 ? MZK_FIELD_M128 : MZK_FIELD_FR; }
 };
@@ -508,6 +516,15 @@ std::vector<Polynomial<F>> fast_interpolate(const std::vector<F>& domain, const 
     res[i].coef = from_wire<F>(w, lens[i]);
   }
   return res;
+}
+
+
+// ntt / intt (ntt.rs:7-64) of ONE vector spread over every context of mzk_init_devices (four-step layout, mzk_ntt_multi)
+template <class F> std::vector<F> ntt_multi(const F& primitive_root, const std::vector<F>& values, bool inverse = false) {
+  auto in = to_wire(values);
+  std::vector<uint64_t> out(in.size());
+  expect(mzk_ntt_multi(Polynomial<F>::field_id(), primitive_root.value.data(), in.data(), out.data(), values.size(), inverse ? 1 : 0));
+  return from_wire<F>(out, values.size());
 }
 
 }  // namespace batch

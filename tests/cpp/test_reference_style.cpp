@@ -273,6 +273,23 @@ static void test_batch_extensions() {
     CHECK(fwd[r] == ntt(root, regs[r]));
     CHECK(back[r] == regs[r]);
   }
+  // Polynomial::scale (polynomial.rs:167-174) and the transform through the multi-context entry point (one context here)
+  {
+    Polynomial<F> pl{regs[0]};
+    auto sc = pl.scale(F::from_value(3));
+    uint64_t pw[2] = {1, 0}, three[2] = {3, 0};
+    bool ok = sc.coef.size() == n;
+    for (size_t i = 0; i < n && ok; i++) {
+      uint64_t want[2], nx[2];
+      orc_field_mul(MZK_FIELD_M128, regs[0][i].value.data(), pw, want);
+      ok = sc.coef[i] == F::from_limbs(want);
+      orc_field_mul(MZK_FIELD_M128, pw, three, nx);
+      pw[0] = nx[0]; pw[1] = nx[1];
+    }
+    CHECK(ok);
+    CHECK(batch::ntt_multi(root, regs[1]) == fwd[1]);
+    CHECK(batch::ntt_multi(root, fwd[1], true) == regs[1]);
+  }
   // low-degree extension of all registers, then one Merkle root per codeword (fast_stark.rs:231-243)
   const size_t order = 4 * n;
   F big = get_nth_root_of_m128(logn + 2), offset = F::from_value(3);
