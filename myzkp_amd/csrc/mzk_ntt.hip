@@ -102,6 +102,16 @@ template <class P> __device__ __forceinline__ Fe<P> gload(const u32* __restrict_
   }
   return fe_unpack<P>(w);
 }
+// the packed words only: the tile loops issue the loads of ALL their elements first and unpack afterwards, so a lane has
+// several 32-byte requests in flight instead of one per loop trip (load, wait, store to LDS, next)
+template <class P> __device__ __forceinline__ void gload_words(const u32* __restrict__ g, size_t idx, u32 (&w)[P::NW]) {
+  const uint4* p4 = reinterpret_cast<const uint4*>(g + idx * P::NW);
+#pragma unroll
+  for (int q = 0; q < P::NW / 4; q++) {
+    uint4 v = p4[q];
+    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+  }
+}
 template <class P> __device__ __forceinline__ void gstore(u32* __restrict__ g, size_t idx, const Fe<P>& v) {
   u32 w[P::NW];
   fe_pack<P>(v, w);
@@ -251,6 +261,22 @@ __global__ __launch_bounds__(G::NT) void k_ntt_strided(const u32* __restrict__ i
   const int tile_elems = 1 << (lgn + lgc);
   u32* twl = lds + P::L * G::TILE;
   stage_twiddles<P, G>(twl, tw_tile, lgn);
+  constexpr int UNR = G::TILE / G::NT;          // elements per lane and tile (tile_elems == G::TILE here)
+  if constexpr (!PRE) {
+    u32 w[UNR][P::NW];
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      const int e = tid + u * G::NT;
+      gload_words<P>(in, base + ((size_t)(e >> lgc) << lgM) + (e & cmask), w[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      const int e = tid + u * G::NT;
+      const int j1 = e >> lgc, c = e & cmask;
+      const int k = (int)(__brev((unsigned)j1) >> (32 - lgn));
+      lds_store<P, G>(lds, (k << lgc) | c, fe_unpack<P>(w[u]));
+    }
+  } else
   for (int e = tid; e < tile_elems; e += G::NT) {
     const int j1 = e >> lgc, c = e & cmask;
     Fe<P> v;
@@ -273,12 +299,21 @@ __global__ __launch_bounds__(G::NT) void k_ntt_strided(const u32* __restrict__ i
   }
   __syncthreads();
   tile_stages<P, G>(lds, twl, lgn, lgc);
-  for (int e = tid; e < tile_elems; e += G::NT) {
-    const int k = e >> lgc, c = e & cmask;
-    const size_t off = ((size_t)k << lgM) + (ct << lgc) + c;
-    Fe<P> v = lds_load<P, G>(lds, (k << lgc) | c);
-    Fe<P> w = gload<P>(tw_inter, off);
-    gstore<P>(out, (o << (lgn + lgM)) + off, fe_fit<P>(FeAsm<P>::mul(v, w)));
+  {
+    u32 tw[UNR][P::NW];               // the inter-pass twiddles of all the lane's elements, requested before the first product
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      const int e = tid + u * G::NT;
+      gload_words<P>(tw_inter, ((size_t)(e >> lgc) << lgM) + (ct << lgc) + (e & cmask), tw[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      const int e = tid + u * G::NT;
+      const int k = e >> lgc, c = e & cmask;
+      const size_t off = ((size_t)k << lgM) + (ct << lgc) + c;
+      const Fe<P> v = lds_load<P, G>(lds, (k << lgc) | c);
+      gstore<P>(out, (o << (lgn + lgM)) + off, fe_fit<P>(FeAsm<P>::mul(v, fe_unpack<P>(tw[u]))));
+    }
   }
 }
 
@@ -299,20 +334,33 @@ __global__ __launch_bounds__(G::NT) void k_ntt_last(const u32* __restrict__ in, 
   const int logn = lg_rows + lgn;
   u32* twl = lds + P::L * G::TILE;
   stage_twiddles<P, G>(twl, tw_tile, lgn);
-  for (int e = tid; e < tile_elems; e += G::NT) {
-    const int rr = e >> lgn, j = e & nmask;
-    const size_t r = p0 + rr;
-    Fe<P> v = fe_zero<P>();
-    if (r < total_rows) {
-      size_t rem = r & rowmask, row = 0;
-      for (int i = 0; i < li.nlev - 1; i++) {
-        row = (row << li.lg[i]) | (rem & (((size_t)1 << li.lg[i]) - 1));
-        rem >>= li.lg[i];
+  constexpr int UNR = G::TILE / G::NT;
+  for (int e0 = tid; e0 < tile_elems; e0 += UNR * G::NT) {       // one trip for a full tile: all loads first, then the LDS stores
+    u32 w[UNR][P::NW];
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      const int e = e0 + u * G::NT;
+      const int rr = e >> lgn, j = e & nmask;
+      const size_t r = p0 + rr;
+#pragma unroll
+      for (int q = 0; q < P::NW; q++) w[u][q] = 0;
+      if (e < tile_elems && r < total_rows) {
+        size_t rem = r & rowmask, row = 0;
+        for (int i = 0; i < li.nlev - 1; i++) {
+          row = (row << li.lg[i]) | (rem & (((size_t)1 << li.lg[i]) - 1));
+          rem >>= li.lg[i];
+        }
+        gload_words<P>(in, ((r >> lg_rows) << logn) + (row << lgn) + j, w[u]);
       }
-      v = gload<P>(in, ((r >> lg_rows) << logn) + (row << lgn) + j);
     }
-    const int k = (lgn == 0) ? 0 : (int)(__brev((unsigned)j) >> (32 - lgn));
-    lds_store<P, G>(lds, (k << lgr) | rr, v);
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      const int e = e0 + u * G::NT;
+      if (e >= tile_elems) break;
+      const int rr = e >> lgn, j = e & nmask;
+      const int k = (lgn == 0) ? 0 : (int)(__brev((unsigned)j) >> (32 - lgn));
+      lds_store<P, G>(lds, (k << lgr) | rr, fe_unpack<P>(w[u]));
+    }
   }
   __syncthreads();
   tile_stages<P, G>(lds, twl, lgn, lgr);
