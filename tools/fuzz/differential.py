@@ -1,0 +1,181 @@
+"""Randomised differential run of the C ABI against the oracle, with random shapes -- sizes that are not powers of two where the
+entry point takes them, ragged batches, empty inputs, special scalars.  A longer-running companion of tests/ (which pins fixed
+seeds and sizes): every case prints nothing unless it differs; the summary line counts the cases per entry point.
+
+usage: differential.py [seconds=60] [seed=1]
+The oracle (tests/orc.py) is the checker, as in tests/."""
+import os, random, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
+import numpy as np
+import myzkp_amd as mz
+import orc
+from orc import FR, M128
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = random.Random(seed)
+mz.init(0)
+counts, failures = {}, []
+NL = {FR: 4, M128: 2}
+
+
+def vec(fid, n):
+    return orc.synth_vector(fid, rng.getrandbits(40), max(n, 1))[:n]
+
+
+def special_scalars(n):
+    s = orc.synth_vector(FR, rng.getrandbits(40), max(n, 1))[:n].copy()
+    p = orc.P_FR
+    pool = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 1 << 253, (1 << 128) - 1, 1 << 127, 0xFFFF, 0x8000, 0x10000]
+    mode = rng.randrange(4)
+    for i in range(n):
+        if mode == 1 and rng.random() < 0.3 or mode == 2:
+            s[i] = orc.to_limbs([rng.choice(pool)], 4)[0]
+        elif mode == 3:
+            s[i] = s[0]
+    return s
+
+
+def check(name, ok, info):
+    counts[name] = counts.get(name, 0) + 1
+    if not ok:
+        failures.append((name, info))
+        print("DIFF", name, info, flush=True)
+
+
+def case_ntt():
+    fid = rng.choice((FR, M128))
+    lg = rng.choice([0, 1, 2, 3, 5, 8, 10, 11, 12, 13, 14, 15, 16, 17])
+    n = 1 << lg
+    w = orc.root_of(fid, lg) if lg else 1
+    x = vec(fid, n)
+    inv = rng.random() < 0.5
+    rc, want = orc.ntt_fast(fid, w, x, inv)
+    check("ntt", rc == 0 and np.array_equal(mz.ntt(fid, w, x, inv), want), (fid, lg, inv))
+
+
+def case_ntt_batch():
+    fid = rng.choice((FR, M128))
+    lg, batch = rng.choice([1, 2, 4, 7, 9, 10, 12, 14]), rng.choice([1, 2, 3, 5, 17])
+    n = 1 << lg
+    w = orc.root_of(fid, lg)
+    x = vec(fid, n * batch).reshape(batch, n, NL[fid])
+    inv = rng.random() < 0.5
+    got = mz.ntt_batch(fid, w, x, inv)
+    ok = all(np.array_equal(got[b], orc.ntt_fast(fid, w, np.ascontiguousarray(x[b]), inv)[1]) for b in range(batch))
+    check("ntt_batch", ok, (fid, lg, batch, inv))
+
+
+def case_lde():
+    fid = rng.choice((FR, M128))
+    lgo = rng.choice([1, 3, 6, 9, 11, 12, 14, 16])
+    order = 1 << lgo
+    n_coef = rng.choice([0, 1, order, order // 2, max(1, order // 4), rng.randrange(0, order + 1)])
+    p = orc.MOD[fid]
+    offset, g = rng.randrange(1, p), orc.root_of(fid, lgo)
+    c = vec(fid, n_coef)
+    # closed form through the oracle's transform: ntt(g, pad(coef[i] * offset^i))
+    sc = orc.to_limbs([int(v) * pow(offset, i, p) % p for i, v in enumerate(orc.from_limbs(c))] + [0] * (order - n_coef), NL[fid]) if order else c
+    rc, want = orc.ntt_fast(fid, g, sc, False)
+    check("coset_lde", rc == 0 and np.array_equal(mz.coset_lde(fid, c, offset, g, order), want), (fid, lgo, n_coef))
+    if rng.random() < 0.3 and n_coef:
+        batch = rng.choice([2, 3])
+        cs = vec(fid, n_coef * batch).reshape(batch, n_coef, NL[fid])
+        got = mz.coset_lde_batch(fid, cs, offset, g, order)
+        ok = all(np.array_equal(got[b], mz.coset_lde(fid, np.ascontiguousarray(cs[b]), offset, g, order)) for b in range(batch))
+        check("coset_lde_batch", ok, (fid, lgo, n_coef, batch))
+
+
+def case_scale_columns():
+    fid = rng.choice((FR, M128))
+    p = orc.MOD[fid]
+    n = rng.choice([1, 5, 16, 17, 255, 1000, 4097])
+    c = vec(fid, n)
+    ratio, lead = rng.randrange(p), rng.randrange(p)
+    want = [int(v) * lead * pow(ratio, i, p) % p for i, v in enumerate(orc.from_limbs(c))]
+    check("poly_scale", orc.from_limbs(mz.poly_scale(fid, c, ratio, lead)) == want, (fid, n))
+
+
+def case_msm():
+    n = rng.choice([0, 1, 2, 3, 17, 100, 1000, 4095, 4096, 4097, 9000, 20000, rng.randrange(1, 30000)])
+    s = special_scalars(n)
+    pts = orc.synth_points(rng.getrandbits(40), max(n, 1))[:n].copy()
+    if n > 4:
+        for _ in range(rng.randrange(0, 4)):
+            pts[rng.randrange(n)] = 0                                     # points at infinity
+        if rng.random() < 0.3:
+            pts[1] = pts[0]                                               # P next to P
+        if rng.random() < 0.3:
+            q = orc.arr_to_pts(pts[2:3])[0]
+            if q != (0, 0):
+                pts[3] = orc.pts_to_arr([(q[0], orc.P_FQ - q[1])])[0]     # P next to -P
+                s[3] = s[2]
+    want = orc.msm_fast(s, pts)
+    check("msm_g1", mz.msm_g1(s, pts) == want, n)
+    if n:
+        h = mz.Srs(pts)
+        check("commit_srs", h.commit(s) == want, n)
+        m = rng.randrange(0, n + 1)
+        check("commit_srs_prefix", h.commit(s[:m]) == orc.msm_fast(s[:m], pts[:m]), (n, m))
+        h.close()
+
+
+def case_merkle():
+    fid = rng.choice((FR, M128))
+    n = rng.choice([1, 2, 3, 5, 8, 31, 64, 100, 1000, 4096, 5000])
+    x = vec(fid, n)
+    check("merkle_commit", mz.merkle_commit_field(fid, x) == orc.merkle_commit_field_ref(fid, x), (fid, n))
+    if n >= 2:
+        t = mz.MerkleTree(fid, x)
+        leaves = orc.field_leaves(fid, x)
+        i = rng.randrange(n)
+        try:
+            got = [bytes(b) for b in t.open(i)]
+        except mz.MzkError as e:          # Merkle::open does not terminate on the one-leaf half of a three-leaf slice (merkle.rs:36-45): MZK_E_LENGTH
+            got = e.code
+        ref = orc.merkle_open_ref(i, leaves)
+        want = -5 if ref is None else [bytes(b) for b in ref]
+        check("merkle_open", got == want, (fid, n, i))
+        t.close()
+
+
+def case_poly():
+    fid = rng.choice((FR, M128))
+    la, lb = rng.choice([1, 2, 7, 8, 9, 100, 600]), rng.choice([1, 3, 8, 50, 300])
+    a, b = vec(fid, la), vec(fid, lb)
+    lg = max(1, (la + lb - 2).bit_length())
+    w = orc.root_of(fid, lg)
+    rc, want = orc.fft_multiply_ref(fid, a, b, w)
+    check("fft_multiply", rc == 0 and np.array_equal(mz.fft_multiply(fid, a, b, w), want), (fid, la, lb))
+    n = rng.choice([1, 2, 7, 8, 9, 33, 200])
+    dom = orc.to_limbs(rng.sample(range(1, 1 << 60), n), NL[fid])
+    lgr = max(4, (2 * n).bit_length() + 1)
+    root, order = orc.root_of(fid, lgr), 1 << lgr
+    vals = vec(fid, n)
+    rc, want = orc.fast_interpolate_ref(fid, dom, vals, root, order)
+    check("fast_interpolate", rc == 0 and np.array_equal(mz.fast_interpolate(fid, dom, vals, root, order), want), (fid, n))
+    cf = vec(fid, rng.choice([1, n, 2 * n + 1]))
+    rc, want = orc.fast_evaluate_ref(fid, cf, dom, root, order)
+    check("fast_evaluate", rc == 0 and np.array_equal(mz.fast_evaluate(fid, cf, dom, root, order), want), (fid, n))
+
+
+def case_kzg():
+    n = rng.choice([1, 2, 5, 64, 500, 3000])
+    alpha = rng.randrange(1, orc.P_FR)
+    srs = mz.kzg_setup_g1(alpha, n - 1)
+    f = vec(FR, n)
+    u = rng.randrange(orc.P_FR)
+    y, wpt = mz.kzg_open(f, u, srs)
+    fa, fu = orc.poly_eval(FR, f, alpha), orc.poly_eval(FR, f, u)
+    q = (fa - fu) * pow((alpha - u) % orc.P_FR, -1, orc.P_FR) % orc.P_FR if alpha != u else None
+    ok = y == fu and (q is None or wpt == orc.ec_mul(0, (1, 2), q)) and mz.kzg_commit(f, srs) == orc.ec_mul(0, (1, 2), fa)
+    check("kzg_setup_commit_open", ok, n)
+
+
+CASES = [case_ntt, case_ntt_batch, case_lde, case_scale_columns, case_msm, case_merkle, case_poly, case_kzg]
+t0 = time.time()
+while time.time() - t0 < budget:
+    rng.choice(CASES)()
+print("seed %d, %.0f s: %s; %d difference(s)" % (seed, time.time() - t0, ", ".join("%s %d" % kv for kv in sorted(counts.items())), len(failures)), flush=True)
+sys.exit(1 if failures else 0)
