@@ -173,7 +173,64 @@ def case_kzg():
     check("kzg_setup_commit_open", ok, n)
 
 
-CASES = [case_ntt, case_ntt_batch, case_lde, case_scale_columns, case_msm, case_merkle, case_poly, case_kzg]
+def case_fri_fold():
+    fid = rng.choice((FR, M128))
+    p = orc.MOD[fid]
+    lg = rng.choice([0, 1, 2, 3, 6, 10, 13])
+    n = 1 << lg
+    cw = vec(fid, n)
+    alpha, off, om = rng.randrange(p), rng.randrange(1, p), orc.root_of(fid, lg) if lg else 1
+    check("fri_fold", np.array_equal(mz.fri_fold(fid, cw, alpha, off, om), orc.fri_fold_ref(fid, cw, alpha, off, om)), (fid, lg))
+
+
+def case_kzg_next():
+    n = rng.choice([2, 5, 33, 64])
+    alpha = rng.randrange(1, orc.P_FR)
+    srs = mz.kzg_setup_g1(alpha, n - 1)
+    f = vec(FR, n)
+    us = [rng.randrange(orc.P_FR) for _ in range(rng.choice([1, 2, 3, min(n - 1, 5)]))]
+    ys_o, w_o = orc.kzg_batch_open_ref(f, us, srs)
+    ys_g, w_g = mz.kzg_batch_open(f, us, srs)
+    check("kzg_batch_open", list(ys_g) == list(ys_o) and w_g == w_o, (n, len(us)))
+    d = rng.randrange(0, n + 3)
+    rc, want = orc.kzg_degree_bound_ref(f, srs, d)
+    try:
+        got = (0, mz.kzg_prove_degree_bound(f, srs, d))
+    except mz.MzkError as e:
+        got = (e.code, None)
+    check("kzg_prove_degree_bound", (rc == 0 and got == (0, want)) or (rc != 0 and got[0] != 0), (n, d, rc, got[0]))
+
+
+def case_g2():
+    n = rng.choice([0, 1, 2, 7, 40])
+    R = orc.P_FR
+    G2 = orc.G2_GEN
+    base = [orc.g2_mul(G2, rng.randrange(1, R)) for _ in range(min(n, 6))]
+    pts = [base[rng.randrange(len(base))] for _ in range(n)] if n else []
+    if n > 2 and rng.random() < 0.5:
+        pts[1] = orc.G2_INF
+    ks = [rng.choice([0, 1, R - 1, rng.randrange(R)]) for _ in range(n)]
+    sarr, parr = orc.to_limbs(ks, 4), orc.g2_to_arr(pts)
+    check("msm_g2", mz.msm_g2(sarr, parr) == orc.g2_msm_ref(sarr, parr), n)
+
+
+def case_coset_divide():
+    fid = rng.choice((FR, M128))
+    p, nl = orc.MOD[fid], NL[fid]
+    ll, lr = rng.choice([3, 9, 50, 200]), rng.choice([1, 2, 8, 40])
+    lhs, rhs = vec(fid, ll), vec(fid, lr)
+    lg = max(3, (ll + 1).bit_length() + rng.choice([0, 1]))
+    root, order = orc.root_of(fid, lg), 1 << lg
+    offset = rng.randrange(2, 1000)
+    rc, want = orc.fast_coset_divide_ref(fid, lhs, rhs, offset, root, order)
+    try:
+        got = (0, mz.fast_coset_divide(fid, lhs, rhs, offset, root, order))
+    except mz.MzkError as e:
+        got = (e.code, None)
+    check("fast_coset_divide", (rc == 0 and got[0] == 0 and np.array_equal(got[1], want)) or (rc != 0 and got[0] != 0), (fid, ll, lr, lg, rc, got[0]))
+
+
+CASES = [case_fri_fold, case_kzg_next, case_g2, case_coset_divide, case_ntt, case_ntt_batch, case_lde, case_scale_columns, case_msm, case_merkle, case_poly, case_kzg]
 t0 = time.time()
 while time.time() - t0 < budget:
     rng.choice(CASES)()
