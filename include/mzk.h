@@ -369,7 +369,7 @@ int mzk_kzg_open_quotient_dev(const void* d_coef, size_t n, const uint64_t u_hos
 /* Build an SRS handle from points already in HBM (affine canonical, n * 8 limbs).  The _ex form chooses
  * whether the window tables are built (worth it from ~30 commits per SRS on at 2^20 points; a one-shot pipeline keeps
  * the plain prepared points and pays the window Horner instead).  Default widths by size: 8 bits up to 1024 points,
- * 10 below 4096, 13 below 2^14, 16 from there on (254 / c + 1 tables of n points each). */
+ * 10 up to 4096, 13 below 2^14, 16 from there on (254 / c + 1 tables of n points each). */
 int mzk_srs_from_device(const void* d_powers_xy, size_t n, mzk_srs** out, void* stream);
 int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, mzk_srs** out, void* stream);
 /* with_tables: 0 = plain prepared points, 1 = tables with the default window width for n (above), 12..22 = that window width

@@ -135,7 +135,7 @@ static inline int msm_table_windows(int c) { return 254 / c + 1; }
 // they get narrow windows: 8 bits = 32 tables x 128 buckets up to 1024 points, 10 bits = 26 tables x 512 buckets below 4096.
 // 4096 .. 2^14 points: 13-bit windows (20 tables, 4096 buckets) through the general pipeline: 0.49 ms per commit at 2^12 and
 // 2^13 against 0.74 / 0.83 ms without tables (tools/timing/window_sweep.py 12,13 12,13,14,16).
-static inline int msm_srs_window_bits(size_t n) { return n <= 1024 ? 8 : (n < 4096 ? 10 : (n < ((size_t)1 << 14) ? 13 : 16)); }
+static inline int msm_srs_window_bits(size_t n) { return n <= 1024 ? 8 : (n <= 4096 ? 10 : (n < ((size_t)1 << 14) ? 13 : 16)); }
 static inline bool msm_srs_default_tables(size_t n) { return n > 0; }
 #define MSM_PTS_TABLES_C(c) (MSM_PTS_TABLES | ((c) << 8))
 int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int point_kind, size_t table_stride, void* d_out,
