@@ -15,6 +15,7 @@
 //   get_nth_root_of_m128                     zkstark/fri.rs:423-447
 //   fast_coset_divide                        algebra/ntt.rs:271-330
 //   G2Point, eval_with_powers_on_curve_g2, setup_kzg_powers_2_with_alpha   curve/bn128.rs:33-49, algebra/kzg.rs:42-55,114
+//   accumulate_curve_points (G1 and G2)     zksnark/utils.rs:83-92
 //   Merkle::commit / open, commit_codeword   algebra/merkle.rs:15-46, zkstark/fri.rs:160-166
 //   fri_split_and_fold, fri_commit           zkstark/fri.rs:144-209
 //
@@ -299,6 +300,23 @@ inline G2Point eval_with_powers_on_curve_g2(const Polynomial<FqOrder>& f, const 
   std::vector<uint64_t> p(16 * f.coef.size() + 16), out(16);
   for (size_t i = 0; i < f.coef.size(); i++) powers[i].to_wire(&p[16 * i]);
   expect(mzk_msm_g2_bn254(s.data(), p.data(), f.coef.size(), out.data()));
+  return G2Point::from_wire(out.data());
+}
+// zksnark/utils.rs:83-92 accumulate_curve_points -- the reference's second spelling of the MSM: sum_i g_vec[i] * assignment[i]
+// over zip(g_vec, assignment), i.e. the SHORTER of the two lengths (no index panic), G1 or G2 points
+inline G1Point accumulate_curve_points(const std::vector<G1Point>& g_vec, const std::vector<FqOrder>& assignment) {
+  const size_t n = g_vec.size() < assignment.size() ? g_vec.size() : assignment.size();
+  std::vector<uint64_t> s(4 * n + 4), p(8 * n + 8);
+  for (size_t i = 0; i < n; i++) { std::memcpy(&s[4 * i], assignment[i].value.data(), 32); g_vec[i].to_wire(&p[8 * i]); }
+  uint64_t out[8];
+  expect(mzk_msm_g1_bn254(s.data(), p.data(), n, out));
+  return G1Point::from_wire(out);
+}
+inline G2Point accumulate_curve_points(const std::vector<G2Point>& g_vec, const std::vector<FqOrder>& assignment) {
+  const size_t n = g_vec.size() < assignment.size() ? g_vec.size() : assignment.size();
+  std::vector<uint64_t> s(4 * n + 4), p(16 * n + 16), out(16);
+  for (size_t i = 0; i < n; i++) { std::memcpy(&s[4 * i], assignment[i].value.data(), 32); g_vec[i].to_wire(&p[16 * i]); }
+  expect(mzk_msm_g2_bn254(s.data(), p.data(), n, out.data()));
   return G2Point::from_wire(out.data());
 }
 // powers_2 of setup_kzg_with_full_g2 (kzg.rs:42-55) for a caller-supplied alpha

@@ -253,6 +253,20 @@ static void test_g2() {   // bn128.rs:306-323 through the MSM, plus the G2 side 
   uint64_t k8[4] = {8, 0, 0, 0};
   orc_g2_mul(gen, k8, 4, w);
   CHECK(eval_with_powers_on_curve_g2(z, p2) == G2Point::from_wire(w));
+  // zksnark/utils.rs:83-92 accumulate_curve_points: zip semantics (the shorter length wins), G1 and G2
+  {
+    std::vector<G2Point> gv{g2, g2, g2, g2};
+    std::vector<FqOrder> as{FqOrder::from_value(3), FqOrder::from_value(5)};          // 2 weights, 4 points -> 8 g2
+    CHECK(accumulate_curve_points(gv, as) == G2Point::from_wire(w));
+    auto g1 = BN128::generator_g1();
+    std::vector<G1Point> hv{g1, g1};
+    std::vector<FqOrder> bs{FqOrder::from_value(2), FqOrder::from_value(4), FqOrder::from_value(100)};   // 3 weights, 2 points -> 6 g1
+    uint64_t g1w[8], k6[4] = {6, 0, 0, 0}, want6[8];
+    g1.to_wire(g1w);
+    orc_ec_mul(0, g1w, k6, 4, want6);
+    CHECK(accumulate_curve_points(hv, bs) == G1Point::from_wire(want6));
+    CHECK(accumulate_curve_points(std::vector<G1Point>{}, bs) == G1Point::from_wire(std::vector<uint64_t>(8, 0).data()));   // empty -> infinity
+  }
 }
 
 
