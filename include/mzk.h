@@ -191,6 +191,13 @@ int mzk_merkle_open(const mzk_merkle* tree, size_t index, uint8_t* path, size_t 
  * provers commit to); byte-leaf and ragged trees: MZK_E_ARG, open those one by one. */
 int mzk_merkle_open_batch(const mzk_merkle* tree, const uint64_t* indices, size_t count, uint8_t* paths, size_t stride, uint64_t* path_lens,
                           size_t* depth);
+/* Openings of SEVERAL trees in one call -- the query phase of FRI::prove (fri.rs:127-137 with reveal, :211-260) opens the a / b
+ * indices in round i's tree and the c indices in round i+1's, for every round: with the trees of mzk_fri_commit_keep_trees one
+ * call, one copy back and one synchronisation instead of two of each per round.  Tree t takes the next counts[t] entries of
+ * `indices`; its paths follow tree t-1's in paths / path_lens, each tree laid out as mzk_merkle_open_batch lays it out, with
+ * depths[t] entries per path.  counts[t] == 0 skips tree t.  Same kinds of trees as mzk_merkle_open_batch. */
+int mzk_merkle_open_multi(const mzk_merkle* const* trees, size_t n_trees, const uint64_t* indices, const size_t* counts, uint8_t* paths,
+                          size_t stride, uint64_t* path_lens, size_t* depths);
 void mzk_merkle_free(mzk_merkle* tree);
 /* one-shot Merkle::commit(codeword.map(bincode::serialize)) */
 int mzk_merkle_commit_field(int field_id, const uint64_t* elems, size_t n, uint8_t* root, size_t cap, size_t* root_len);

@@ -494,6 +494,30 @@ class MerkleTree:
             pass
 
 
+def merkle_open_multi(trees, index_lists):
+    """Openings of several trees in ONE call (mzk_merkle_open_multi): index_lists[t] are the indices to open in trees[t] (a
+    MerkleTree or None with an empty list).  Returns, per tree, the list of paths `MerkleTree.open` would return."""
+    T = len(trees)
+    counts = [len(ix) for ix in index_lists]
+    flat = np.ascontiguousarray([i for ix in index_lists for i in ix], dtype=np.uint64)
+    handles = (ctypes.c_void_p * max(T, 1))(*[t._h if t is not None else None for t in trees])
+    cnt = (ctypes.c_size_t * max(T, 1))(*counts)
+    depths = (ctypes.c_size_t * max(T, 1))()
+    entries = sum(c * max(t.n.bit_length(), 1) for t, c in zip(trees, counts) if t is not None)
+    stride = 48
+    buf = (ctypes.c_uint8 * max(stride * entries, 1))()
+    lens = (ctypes.c_uint64 * max(entries, 1))()
+    _check(lib().mzk_merkle_open_multi(handles, ctypes.c_size_t(T), _p(flat) if flat.size else None, cnt, buf, ctypes.c_size_t(stride), lens, depths))
+    raw, out, at = memoryview(buf), [], 0
+    for t in range(T):
+        d, paths = depths[t], []
+        for q in range(counts[t]):
+            paths.append([bytes(raw[(at + k) * stride:(at + k) * stride + lens[at + k]]) for k in range(d)])
+            at += d
+        out.append(paths)
+    return out
+
+
 def merkle_commit_field(fid, elems):
     """Merkle::commit(&codeword.map(bincode::serialize)) (fri.rs:160-166)."""
     e = _arr(fid, elems)

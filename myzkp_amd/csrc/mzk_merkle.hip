@@ -758,6 +758,90 @@ int mzk_merkle_open_batch(const mzk_merkle* t, const uint64_t* indices, size_t c
   return MZK_OK;
 }
 
+// Openings of SEVERAL trees in one call: the query phase of FRI::prove (fri.rs:127-137, reveal :211-260) opens the a / b indices
+// in round i's tree and the c indices in round i+1's, for every round -- with the trees of mzk_fri_commit_keep_trees that is one
+// call, one copy back and one synchronisation instead of two of each per round (48 us per call measured).  Tree t takes the
+// next counts[t] entries of `indices`; its paths follow tree t-1's in paths / path_lens, laid out as mzk_merkle_open_batch
+// lays them out with depths[t] entries per path.  counts[t] == 0 skips tree t (which may then be NULL).
+int mzk_merkle_open_multi(const mzk_merkle* const* trees, size_t n_trees, const uint64_t* indices, const size_t* counts, uint8_t* paths,
+                          size_t stride, uint64_t* path_lens, size_t* depths) {
+  if (!trees || !counts || !depths) { set_error("merkle_open_multi: null pointer"); return MZK_E_ARG; }
+  size_t total = 0, total_nodes = 0, total_leaf_words = 0;
+  hipStream_t s = nullptr;
+  for (size_t t = 0; t < n_trees; t++) {
+    depths[t] = trees[t] ? (size_t)trees[t]->depth : 0;
+    if (counts[t] == 0) continue;
+    const mzk_merkle* tr = trees[t];
+    if (!tr || !indices || !paths || !path_lens) { set_error("merkle_open_multi: null pointer"); return MZK_E_ARG; }
+    if (tr->n < 2) { set_error("merkle_open: needs at least two leaves (merkle.rs:32)"); return MZK_E_LENGTH; }
+    if (tr->ragged || tr->kind != 0) {
+      set_error("merkle_open_multi: field-element trees with a power-of-two leaf count only (tree %zu: %s)", t, tr->kind != 0 ? "byte leaves" : "ragged");
+      return MZK_E_ARG;
+    }
+    for (size_t q = 0; q < counts[t]; q++)
+      if (indices[total + q] >= tr->n) { set_error("merkle_open: index %llu out of range (tree %zu)", (unsigned long long)indices[total + q], t); return MZK_E_LENGTH; }
+    if (!s) s = tr->stream;
+    total += counts[t];
+    total_nodes += counts[t] * (size_t)(tr->depth - 1) * 4;
+    total_leaf_words += counts[t] * field_words(tr->field);
+  }
+  if (total == 0) return MZK_OK;
+  if (stride < 32) { set_error("merkle_open: stride < 32"); return MZK_E_LENGTH; }
+  MZK_TRY(ensure_init());
+  WsGuard wsg(s);
+  u64 *d_idx, *d_on;
+  u32* d_ol;
+  MZK_TRY(ws_get(WS_MISC_C, total * 8 + total_nodes * 8 + total_leaf_words * 4 + 64, (void**)&d_idx));
+  d_on = d_idx + total;
+  d_ol = (u32*)(d_on + total_nodes);
+  MZK_HIP(hipMemcpyAsync(d_idx, indices, total * 8, hipMemcpyHostToDevice, s));
+  {
+    size_t at = 0, at_nodes = 0, at_leaf = 0;
+    for (size_t t = 0; t < n_trees; t++) {
+      if (counts[t] == 0) continue;
+      const mzk_merkle* tr = trees[t];
+      const int lw = (int)field_words(tr->field);
+      hipLaunchKernelGGL(k_merkle_gather_batch, dim3((unsigned)counts[t]), dim3(64), 0, s, (const u64*)tr->d_nodes, (const u32*)tr->d_leaves, lw, tr->n,
+                         (const u64*)(d_idx + at), tr->depth, d_on + at_nodes, d_ol + at_leaf);
+      at += counts[t];
+      at_nodes += counts[t] * (size_t)(tr->depth - 1) * 4;
+      at_leaf += counts[t] * (size_t)lw;
+    }
+  }
+  MZK_HIP(hipGetLastError());
+  std::vector<uint64_t> hn(total_nodes + 1);
+  std::vector<uint32_t> hl(total_leaf_words + 1);
+  if (total_nodes) MZK_HIP(hipMemcpyAsync(hn.data(), d_on, total_nodes * 8, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipMemcpyAsync(hl.data(), d_ol, total_leaf_words * 4, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  size_t at = 0, at_nodes = 0, at_leaf = 0, at_entry = 0;
+  for (size_t t = 0; t < n_trees; t++) {
+    if (counts[t] == 0) continue;
+    const mzk_merkle* tr = trees[t];
+    const int lw = (int)field_words(tr->field), nl = field_limbs64(tr->field);
+    for (size_t q = 0; q < counts[t]; q++) {
+      uint64_t limbs[4] = {0, 0, 0, 0};
+      memcpy(limbs, hl.data() + at_leaf + q * lw, (size_t)lw * 4);
+      uint8_t buf[48];
+      const size_t sib = (size_t)indices[at + q] ^ 1;
+      const size_t len = host_bincode_field(limbs, nl, buf, !tr->neg.empty() && tr->neg[sib]);
+      if (stride < len) { set_error("merkle_open: stride %zu < leaf length %zu", stride, len); return MZK_E_LENGTH; }
+      uint8_t* pq = paths + (at_entry + q * (size_t)tr->depth) * stride;
+      memcpy(pq, buf, len);
+      path_lens[at_entry + q * (size_t)tr->depth] = len;
+      for (int l = 1; l < tr->depth; l++) {
+        memcpy(pq + (size_t)l * stride, hn.data() + at_nodes + (q * (size_t)(tr->depth - 1) + (l - 1)) * 4, 32);
+        path_lens[at_entry + q * (size_t)tr->depth + l] = 32;
+      }
+    }
+    at += counts[t];
+    at_nodes += counts[t] * (size_t)(tr->depth - 1) * 4;
+    at_leaf += counts[t] * (size_t)lw;
+    at_entry += counts[t] * (size_t)tr->depth;
+  }
+  return MZK_OK;
+}
+
 void mzk_merkle_free(mzk_merkle* t) {
   if (!t) return;
   if (t->d_leaves) (void)hipFree(t->d_leaves);

@@ -3,7 +3,7 @@ points: degree 63, expansion factor 4, 17 colinearity tests, offset = the M128 g
 
   prover    codeword = polynomial.eval_domain(omega^i)            -> mzk_ntt                       (fri.rs:521-522)
             FRI::commit: Merkle roots + split-and-fold rounds      -> mzk_fri_commit_keep_trees     (fri.rs:144-209)
-            FRI::reveal: a / b / c values and authentication paths -> mzk_merkle_open_batch         (fri.rs:211-260)
+            FRI::reveal: a / b / c values and authentication paths -> mzk_merkle_open_multi         (fri.rs:211-260; all rounds, one call)
   verifier  fri.rs:262-400 restated with Python integers and the oracle's Merkle::verify: last-codeword root, its degree,
             colinearity of every (a, b, c) triple, all authentication paths, and the revealed points equal polynomial.eval
             (fri.rs:527-529); a codeword corrupted as in fri.rs:531-538 must be rejected.
@@ -64,16 +64,27 @@ def prove(mz, codeword, omega, offset, expansion, tests):
     assert roots == roots_seen
     last_leaves = b"".join(orc.field_leaves(M128, codewords[-1]))
     top = sample_indices(h(*roots, last_leaves), codewords[1].shape[0], codewords[-1].shape[0], tests)   # fri.rs:117-123
-    layers, indices = [], list(top)
-    for i in range(len(codewords) - 1):                                      # fri.rs:127-137 + reveal
+    # query phase (fri.rs:127-137 + reveal): the a / b indices of every round in that round's tree, the c indices in the next
+    # round's -- all openings of all rounds in ONE call (mzk_merkle_open_multi); tree i serves b_(i) + a_(i) and c_(i-1)
+    per_round, indices = [], list(top)
+    for i in range(len(codewords) - 1):
         half = codewords[i].shape[0] // 2
         indices = [idx % half for idx in indices]
-        a, b, c = indices, [idx + half for idx in indices], indices
+        per_round.append((list(indices), [idx + half for idx in indices]))
+    wanted = [[] for _ in codewords]
+    for i, (a, b) in enumerate(per_round):
+        wanted[i] += a + b
+        wanted[i + 1] += a                                                    # c indices = a indices, in the next codeword
+    opened = mz.merkle_open_multi(trees, wanted)
+    if len(codewords) > 1:                                                    # the same paths as tree by tree
+        assert opened[0] == trees[0].open_many(wanted[0]) and opened[1] == trees[1].open_many(wanted[1])
+    layers = []
+    for i, (a, b) in enumerate(per_round):
         cur, nxt = orc.from_limbs(codewords[i]), orc.from_limbs(codewords[i + 1])
-        paths_ab = trees[i].open_many(a + b)                                 # one gather for both index sets
-        paths_c = trees[i + 1].open_many(c)
-        layers.append({"a": ([cur[j] for j in a], paths_ab[:tests]), "b": ([cur[j] for j in b], paths_ab[tests:]),
-                       "c": ([nxt[j] for j in c], paths_c)})
+        skip = tests if i > 0 else 0                                         # tree i's list starts with round i-1's c paths
+        pa, pb = opened[i][skip:skip + tests], opened[i][skip + tests:skip + 2 * tests]
+        pc = opened[i + 1][:tests] if i + 1 > 0 else []
+        layers.append({"a": ([cur[j] for j in a], pa), "b": ([cur[j] for j in b], pb), "c": ([nxt[j] for j in a], pc)})
     for t in trees:
         if t is not None:
             t.close()

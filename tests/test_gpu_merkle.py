@@ -374,3 +374,38 @@ def test_fri_commit_keeps_the_round_trees_for_the_query_phase(mz, fid, lg, round
     for t in trees:
         if t is not None:
             t.close()
+
+
+def test_merkle_open_multi_equals_tree_by_tree(mz):
+    """mzk_merkle_open_multi: the openings of several trees (different sizes and fields' worth of leaves, repeated and empty index
+    lists, a skipped NULL tree, signed leaves) in one call == MerkleTree.open_many tree by tree == the oracle's Merkle::open."""
+    import random
+    rnd = random.Random(5)
+    trees, lists = [], []
+    for fid, lg in ((orc.M128, 10), (orc.M128, 4), (orc.FR, 7), (orc.M128, 1)):
+        x = orc.synth_vector(fid, 50 + lg, 1 << lg)
+        trees.append((fid, x, mz.MerkleTree(fid, x)))
+        lists.append([rnd.randrange(1 << lg) for _ in range(rnd.choice([1, 5, 40]))])
+    lists[1] = []                                   # nothing to open in this tree
+    lists[0] += [lists[0][0], 0, (1 << 10) - 1]     # repeated index, first and last leaf
+    handles = [t for _, _, t in trees] + [None]
+    got = mz.merkle_open_multi(handles, lists + [[]])
+    assert len(got) == 5 and got[1] == [] and got[4] == []
+    for (fid, x, t), idx, paths in zip(trees, lists, got):
+        assert paths == t.open_many(idx) if idx else paths == []
+        leaves = orc.field_leaves(fid, x)
+        for i, p in zip(idx, paths):
+            assert [bytes(e) for e in p] == [bytes(e) for e in orc.merkle_open_ref(i, leaves)]
+            assert orc.merkle_verify_ref(t.root(), i, p, leaves[i])
+    # out-of-range index in the second non-empty tree: refused, naming the tree
+    with pytest.raises(mz.MzkError) as e:
+        mz.merkle_open_multi([trees[0][2], trees[2][2]], [[1], [1 << 7]])
+    assert e.value.code == -5
+    # byte-leaf trees are opened one by one (as with open_batch)
+    bt = mz.MerkleTree(leaves=[b"leaf%d" % i for i in range(4)])
+    with pytest.raises(mz.MzkError) as e:
+        mz.merkle_open_multi([bt], [[1]])
+    assert e.value.code == -1
+    bt.close()
+    for _, _, t in trees:
+        t.close()
