@@ -242,6 +242,17 @@ int mzk_fri_commit_keep_trees(int field_id, const uint64_t* magnitudes, const ui
                               const uint64_t* offset, int num_rounds, mzk_fri_challenge_fn challenge, void* user, uint8_t* roots,
                               uint64_t* root_len, uint64_t* codewords_out, mzk_merkle** trees_out);
 
+/* mzk_fri_commit_keep_trees with the initial codeword already in HBM (the output of mzk_coset_lde_dev), complete before the call;
+ * negative: host flags as in mzk_fri_commit_signed, or NULL.  In both keep-trees forms codewords_out may be NULL: the codewords
+ * then never leave the device -- the query phase takes what FRI::reveal sends (fri.rs:211-260) from the trees: the paths with
+ * mzk_merkle_open_multi, the a / b / c values and the last codeword with mzk_merkle_leaves. */
+int mzk_fri_commit_keep_trees_dev(int field_id, const void* d_magnitudes, const uint8_t* negative, size_t n, const uint64_t* omega,
+                                  const uint64_t* offset, int num_rounds, mzk_fri_challenge_fn challenge, void* user, uint8_t* roots,
+                                  uint64_t* root_len, uint64_t* codewords_out, mzk_merkle** trees_out);
+/* The elements a field-element tree was built over, at `count` positions: magnitudes (count x limbs) and, if negative != NULL,
+ * their Sign::Minus flags (all 0 unless the tree was built from signed leaves). */
+int mzk_merkle_leaves(const mzk_merkle* tree, const uint64_t* indices, size_t count, uint64_t* magnitudes, uint8_t* negative);
+
 /* ---- G2 (BN254 twist over Fq2 = Fq[u]/(u^2+1); bn128.rs:33-49) ------------------------------------------------
  * A G2 point is 16 limbs: x.c0 | x.c1 | y.c0 | y.c1 (4 limbs each, canonical); all-zero = infinity.
  * mzk_msm_g2_bn254: Polynomial::eval_with_powers_on_curve over pk.powers_2 (polynomial.rs:156-165 as called from

@@ -435,6 +435,7 @@ class MerkleTree:
 
     def __init__(self, fid=None, elems=None, leaves=None, negative=None):
         self._h = ctypes.c_void_p()
+        self.fid = fid if leaves is None else None
         if negative is not None:       # (magnitude, Sign::Minus flag) pairs: unsanitized elements (field.rs:98-110)
             e = _arr(fid, elems)
             ng = np.ascontiguousarray(negative, dtype=np.uint8)
@@ -481,6 +482,17 @@ class MerkleTree:
         _check(lib().mzk_merkle_open_batch(self._h, _p(idx), ctypes.c_size_t(count), buf, ctypes.c_size_t(self.stride), lens, ctypes.byref(depth)))
         raw, d = bytes(buf), depth.value
         return [[raw[(q * d + k) * self.stride:(q * d + k) * self.stride + lens[q * d + k]] for k in range(d)] for q in range(count)]
+
+    def leaves(self, indices, with_sign=False):
+        """The elements the tree was built over at `indices` (mzk_merkle_leaves): (n, limbs) magnitudes[, Sign::Minus flags]."""
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        nl = LIMBS[self.fid] if getattr(self, "fid", None) is not None else None
+        if nl is None:
+            raise MzkError(-1, "leaves: field-element trees only")
+        out = np.zeros((idx.shape[0], nl), dtype=np.uint64)
+        neg = np.zeros(idx.shape[0], dtype=np.uint8)
+        _check(lib().mzk_merkle_leaves(self._h, _p(idx), ctypes.c_size_t(idx.shape[0]), _p(out), _p(neg) if with_sign else None))
+        return (out, neg) if with_sign else out
 
     def close(self):
         if self._h:
@@ -531,14 +543,21 @@ _FRI_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c
                            ctypes.POINTER(ctypes.c_uint64))
 
 
-def fri_commit(fid, codeword, omega, offset, num_rounds, challenge, negative=None, keep_trees=False):
+def fri_commit(fid, codeword, omega, offset, num_rounds, challenge, negative=None, keep_trees=False, codewords=True, device_ptr=None, n=None):
     """FRI::commit (zkstark/fri.rs:144-209), codewords resident in HBM.  challenge(round, last, root_bytes) -> alpha
     (int; ignored when last).  Returns (codewords, roots).  negative: optional Sign::Minus flags of the initial
     codeword, then given as magnitudes (round 0 commits to the unsanitized elements, fri.rs:160-166).
     keep_trees: also return the rounds' Merkle trees (MerkleTree objects on the device, None for a one-element round)
-    for the query phase: (codewords, roots, trees)."""
-    c = _arr(fid, codeword)
-    n, nl = c.shape[0], LIMBS[fid]
+    for the query phase: (codewords, roots, trees).  codewords=False (with keep_trees): nothing but the roots comes back to
+    the host -- (None, roots, trees); the query phase reads values and paths from the trees (MerkleTree.leaves,
+    merkle_open_multi).  device_ptr / n: the initial codeword is already in HBM (mzk_fri_commit_keep_trees_dev); `codeword`
+    is then ignored."""
+    nl = LIMBS[fid]
+    if device_ptr is None:
+        c = _arr(fid, codeword)
+        n = c.shape[0]
+    elif not keep_trees:
+        raise MzkError(-1, "fri_commit: a device-resident codeword needs keep_trees=True")
 
     failure = []
 
@@ -562,14 +581,19 @@ def fri_commit(fid, codeword, omega, offset, num_rounds, challenge, negative=Non
     total = sum(n >> r for r in range(num_rounds))
     roots = (ctypes.c_uint8 * (48 * max(num_rounds, 1)))()
     lens = (ctypes.c_uint64 * max(num_rounds, 1))()
-    allcw = np.zeros((max(total, 1), nl), dtype=np.uint64)
+    allcw = np.zeros((max(total, 1) if (codewords or not keep_trees) else 1, nl), dtype=np.uint64)
     w, o = _one(fid, omega), _one(fid, offset)
     fn = _FRI_CB(cb)
     handles = (ctypes.c_void_p * max(num_rounds, 1))()
     if keep_trees:
         ng = None if negative is None else np.ascontiguousarray(negative, dtype=np.uint8)
-        rc = lib().mzk_fri_commit_keep_trees(fid, _p(c), None if ng is None else _p(ng), ctypes.c_size_t(n), _p(w), _p(o), int(num_rounds), fn, None,
-                                             roots, lens, _p(allcw), handles)
+        cw_out = _p(allcw) if codewords else None
+        if device_ptr is not None:
+            rc = lib().mzk_fri_commit_keep_trees_dev(fid, ctypes.c_void_p(int(device_ptr)), None if ng is None else _p(ng), ctypes.c_size_t(n), _p(w), _p(o),
+                                                     int(num_rounds), fn, None, roots, lens, cw_out, handles)
+        else:
+            rc = lib().mzk_fri_commit_keep_trees(fid, _p(c), None if ng is None else _p(ng), ctypes.c_size_t(n), _p(w), _p(o), int(num_rounds), fn, None,
+                                                 roots, lens, cw_out, handles)
     elif negative is not None:
         ng = np.ascontiguousarray(negative, dtype=np.uint8)
         rc = lib().mzk_fri_commit_signed(fid, _p(c), _p(ng), ctypes.c_size_t(n), _p(w), _p(o), int(num_rounds), fn, None, roots, lens, _p(allcw))
@@ -581,7 +605,8 @@ def fri_commit(fid, codeword, omega, offset, num_rounds, challenge, negative=Non
     cws, rts, at = [], [], 0
     raw = bytes(roots)
     for r in range(num_rounds):
-        cws.append(allcw[at:at + (n >> r)].copy())
+        if codewords or not keep_trees:
+            cws.append(allcw[at:at + (n >> r)].copy())
         rts.append(raw[48 * r:48 * r + lens[r]])
         at += n >> r
     if keep_trees:
@@ -594,8 +619,9 @@ def fri_commit(fid, codeword, omega, offset, num_rounds, challenge, negative=Non
             t._h = ctypes.c_void_p(handles[r])
             t.n = n >> r
             t.stride = 48
+            t.fid = fid
             trees.append(t)
-        return cws, rts, trees
+        return (cws if codewords else None), rts, trees
     return cws, rts
 
 

@@ -368,6 +368,14 @@ __global__ __launch_bounds__(64) void k_merkle_gather_batch(const u64* __restric
   if ((int)threadIdx.x < leaf_words) out_leaves[q * leaf_words + threadIdx.x] = leaves[(index ^ 1) * leaf_words + threadIdx.x];
 }
 
+// out[q] = leaves[indices[q]] (whole elements of leaf_words 32-bit words)
+__global__ void k_gather_leaves(const u32* __restrict__ leaves, int leaf_words, const u64* __restrict__ indices, size_t count, u32* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count * (size_t)leaf_words) return;
+  const size_t q = i / (size_t)leaf_words, w = i - q * (size_t)leaf_words;
+  out[i] = leaves[indices[q] * (size_t)leaf_words + w];
+}
+
 }  // namespace mzk
 
 using namespace mzk;
@@ -945,26 +953,27 @@ int mzk_merkle_commit_bytes(const uint8_t* leaves, const uint64_t* offsets, size
 // return value `(codewords, roots)`; sending the last codeword (fri.rs:198-206) is the caller's transcript work.
 static int fri_commit_rounds(int field_id, const uint64_t* codeword, const uint8_t* negative, size_t n, const uint64_t* omega, const uint64_t* offset,
                              int num_rounds, mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out,
-                             mzk_merkle** trees_out);
+                             mzk_merkle** trees_out, bool on_device);
 // trees_out (optional, num_rounds entries): the Merkle tree of every round's codeword stays on the device as a handle for the
 // query phase (mzk_merkle_open_batch; fri.rs:211-260 opens from exactly these codewords); a one-element round gets NULL.
 // On failure every handle made so far is released.
 static int fri_commit_impl(int field_id, const uint64_t* codeword, const uint8_t* negative, size_t n, const uint64_t* omega, const uint64_t* offset,
                            int num_rounds, mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out,
-                           mzk_merkle** trees_out = nullptr) {
+                           mzk_merkle** trees_out = nullptr, bool on_device = false) {
   if (trees_out) for (int r = 0; r < num_rounds; r++) trees_out[r] = nullptr;
-  const int rc = fri_commit_rounds(field_id, codeword, negative, n, omega, offset, num_rounds, challenge, user, roots, root_len, codewords_out, trees_out);
+  const int rc = fri_commit_rounds(field_id, codeword, negative, n, omega, offset, num_rounds, challenge, user, roots, root_len, codewords_out, trees_out, on_device);
   if (rc != MZK_OK && trees_out)
     for (int r = 0; r < num_rounds; r++) { if (trees_out[r]) mzk_merkle_free(trees_out[r]); trees_out[r] = nullptr; }
   return rc;
 }
 static int fri_commit_rounds(int field_id, const uint64_t* codeword, const uint8_t* negative, size_t n, const uint64_t* omega, const uint64_t* offset,
                              int num_rounds, mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out,
-                             mzk_merkle** trees_out) {
+                             mzk_merkle** trees_out, bool on_device) {
   MZK_TRY(ensure_init());
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fri_commit: bad field id %d", field_id); return MZK_E_ARG; }
   if (num_rounds <= 0) return MZK_OK;
-  if (!codeword || !omega || !offset || !challenge || !roots || !root_len || !codewords_out) { set_error("fri_commit: null pointer"); return MZK_E_ARG; }
+  if (!codeword || !omega || !offset || !challenge || !roots || !root_len) { set_error("fri_commit: null pointer"); return MZK_E_ARG; }
+  if (!codewords_out && !trees_out) { set_error("fri_commit: no codeword output and no trees kept"); return MZK_E_ARG; }
   if (n == 0) { set_error("fri_commit: empty codeword"); return MZK_E_LENGTH; }
   if (!is_pow2(n)) { set_error("fri_commit: codeword length must be a power of two"); return MZK_E_NOT_POW2; }
   if ((n >> (num_rounds - 1)) == 0) { set_error("fri_commit: %d rounds halve a length-%zu codeword away", num_rounds, n); return MZK_E_LENGTH; }
@@ -980,7 +989,7 @@ static int fri_commit_rounds(int field_id, const uint64_t* codeword, const uint8
   u64* d_nodes;
   MZK_TRY(ws_get(WS_NTT_IO_A, total * esz, (void**)&d_all));
   MZK_TRY(ws_get(WS_MERKLE_NODES, n * 32, (void**)&d_nodes));
-  MZK_HIP(hipMemcpyAsync(d_all, codeword, n * esz, hipMemcpyHostToDevice, s));
+  MZK_HIP(hipMemcpyAsync(d_all, codeword, n * esz, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
   u8* d_neg = nullptr;
   if (negative) {     // round 0 hashes bincode of the UNSANITIZED elements (fri.rs:160-166); the fold sanitizes (fri.rs:190)
     MZK_TRY(ws_get(WS_MISC_E, n, (void**)&d_neg));
@@ -1033,7 +1042,7 @@ static int fri_commit_rounds(int field_id, const uint64_t* codeword, const uint8
     cur = next;
     len /= 2;
   }
-  MZK_HIP(hipMemcpyAsync(codewords_out, d_all, total * esz, hipMemcpyDeviceToHost, s));
+  if (codewords_out) MZK_HIP(hipMemcpyAsync(codewords_out, d_all, total * esz, hipMemcpyDeviceToHost, s));
   MZK_HIP(hipStreamSynchronize(s));
   return MZK_OK;
 }
@@ -1050,6 +1059,38 @@ int mzk_fri_commit_keep_trees(int field_id, const uint64_t* magnitudes, const ui
                               mzk_merkle** trees_out) {
   if (!trees_out && num_rounds > 0) { set_error("fri_commit_keep_trees: null handle array"); return MZK_E_ARG; }
   return fri_commit_impl(field_id, magnitudes, negative, n, omega, offset, num_rounds, challenge, user, roots, root_len, codewords_out, trees_out);
+}
+// the same with the initial codeword already in HBM (the output of mzk_coset_lde_dev: fast_stark.rs commits to what it has just
+// extended); d_codeword must be complete before the call.  negative (host, optional) as in mzk_fri_commit_signed.
+int mzk_fri_commit_keep_trees_dev(int field_id, const void* d_magnitudes, const uint8_t* negative, size_t n, const uint64_t* omega, const uint64_t* offset,
+                                  int num_rounds, mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out,
+                                  mzk_merkle** trees_out) {
+  if (!trees_out && num_rounds > 0) { set_error("fri_commit_keep_trees: null handle array"); return MZK_E_ARG; }
+  return fri_commit_impl(field_id, (const uint64_t*)d_magnitudes, negative, n, omega, offset, num_rounds, challenge, user, roots, root_len, codewords_out, trees_out, true);
+}
+// The elements a tree was built over, at `count` positions: magnitudes (count x limbs) and, if wanted, their Sign::Minus flags --
+// what FRI::reveal sends next to the authentication paths (fri.rs:224-233), without the codewords ever leaving the device.
+int mzk_merkle_leaves(const mzk_merkle* t, const uint64_t* indices, size_t count, uint64_t* magnitudes, uint8_t* negative) {
+  if (!t || ((!indices || !magnitudes) && count)) { set_error("merkle_leaves: null pointer"); return MZK_E_ARG; }
+  if (t->kind != 0) { set_error("merkle_leaves: field-element trees only"); return MZK_E_ARG; }
+  for (size_t q = 0; q < count; q++)
+    if (indices[q] >= t->n) { set_error("merkle_leaves: index %llu out of range", (unsigned long long)indices[q]); return MZK_E_LENGTH; }
+  if (count == 0) return MZK_OK;
+  MZK_TRY(ensure_init());
+  hipStream_t s = t->stream;
+  WsGuard wsg(s);
+  const size_t esz = field_bytes(t->field);
+  const int lw = (int)field_words(t->field);
+  u64* d_idx;
+  MZK_TRY(ws_get(WS_MISC_C, count * 8 + count * esz + 64, (void**)&d_idx));
+  u32* d_out = (u32*)(d_idx + count);
+  MZK_HIP(hipMemcpyAsync(d_idx, indices, count * 8, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_gather_leaves, dim3((unsigned)((count * lw + 255) / 256)), dim3(256), 0, s, (const u32*)t->d_leaves, lw, (const u64*)d_idx, count, d_out);
+  MZK_HIP(hipGetLastError());
+  MZK_HIP(hipMemcpyAsync(magnitudes, d_out, count * esz, hipMemcpyDeviceToHost, s));
+  if (negative) for (size_t q = 0; q < count; q++) negative[q] = (!t->neg.empty() && t->neg[(size_t)indices[q]]) ? 1 : 0;
+  MZK_HIP(hipStreamSynchronize(s));
+  return MZK_OK;
 }
 
 }  // extern "C"

@@ -409,3 +409,51 @@ def test_merkle_open_multi_equals_tree_by_tree(mz):
     bt.close()
     for _, _, t in trees:
         t.close()
+
+
+def test_fri_commit_device_resident_and_values_from_the_trees(mz):
+    """mzk_fri_commit_keep_trees_dev (initial codeword in HBM) with codewords_out = NULL: roots identical to the host form, and the
+    query phase takes everything from the trees -- mzk_merkle_leaves returns exactly the codeword elements (all of the last
+    codeword, sampled positions elsewhere; signs of an unsanitized round 0), mzk_merkle_open_multi the paths."""
+    import torch
+    fid, lg, rounds = orc.M128, 12, 6
+    n = 1 << lg
+    p = orc.MOD[fid]
+    cw = orc.synth_vector(fid, 321, n)
+    omega, offset = orc.root_of(fid, lg), orc.M128_GEN
+    seen = []
+
+    def challenge(rnd, last, root):
+        seen.append(root)
+        return None if last else (int.from_bytes(root[:15], "little") + rnd) % p
+
+    cws, roots, trees = mz.fri_commit(fid, cw, omega, offset, rounds, challenge, keep_trees=True)
+    for t in trees:
+        t.close()
+    d = torch.from_numpy(cw.view(np.int64).reshape(-1).copy()).to("cuda:0")
+    torch.cuda.synchronize()
+    none, roots_d, trees_d = mz.fri_commit(fid, None, omega, offset, rounds, challenge, keep_trees=True, codewords=False, device_ptr=d.data_ptr(), n=n)
+    assert none is None and roots_d == roots
+    for r, t in enumerate(trees_d):
+        m = n >> r
+        idx = list(range(m)) if r == rounds - 1 else [0, 1, m // 2, m - 1, 17 % m, 17 % m]
+        assert np.array_equal(t.leaves(idx), cws[r][idx])
+    opened = mz.merkle_open_multi(trees_d, [[3, 5]] * rounds)
+    for r, t in enumerate(trees_d):
+        leaves = orc.field_leaves(fid, cws[r])
+        assert [bytes(e) for e in opened[r][0]] == [bytes(e) for e in orc.merkle_open_ref(3, leaves)]
+        assert orc.merkle_verify_ref(roots[r], 5, opened[r][1], leaves[5])
+    # out-of-range position
+    with pytest.raises(mz.MzkError) as e:
+        trees_d[0].leaves([n])
+    assert e.value.code == -5
+    for t in trees_d:
+        t.close()
+    # signed round 0: magnitudes and flags come back as given
+    neg = (np.arange(64) % 3 == 0).astype(np.uint8)
+    mag = orc.synth_vector(fid, 9, 64)
+    _, _, ts = mz.fri_commit(fid, mag, orc.root_of(fid, 6), offset, 2, challenge, negative=neg, keep_trees=True, codewords=False)
+    got, sg = ts[0].leaves(list(range(64)), with_sign=True)
+    assert np.array_equal(got, mag) and np.array_equal(sg, neg)
+    for t in ts:
+        t.close()
