@@ -903,16 +903,16 @@ int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_
 
 // FRI split-and-fold (zkstark/fri.rs:182-193).  With q_i = alpha / (offset omega^i):
 //   out[i] = 2^-1 ((1 + q_i) a + (1 - q_i) b) = 2^-1 (a + b) + r_i (a - b),   r_i = 2^-1 alpha offset^-1 omega^-i.
-// r_0 and omega^-1 are host parameters (Montgomery form); each lane walks 16 consecutive i.
+// r_0 and omega^-1 are host parameters (Montgomery form); each lane walks per_lane consecutive i.
 template <class P>
 __global__ void k_fri_fold(const u32* __restrict__ cw, size_t h, Words8 r0_mont, Words8 winv_mont, Words8 half_mont,
-                           u32* __restrict__ out) {
+                           u32* __restrict__ out, int per_lane) {
   const size_t chunk = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t i0 = chunk * GEN_CHUNK;
+  const size_t i0 = chunk * (size_t)per_lane;
   if (i0 >= h) return;
   const Fe<P> winv = fe_unpack<P>(winv_mont.w), half = fe_unpack<P>(half_mont.w);
   Fe<P> r = FeAsm<P>::mul(fe_unpack<P>(r0_mont.w), fe_pow_u64<P>(winv, i0));   // r_{i0}, Montgomery form
-  for (int t = 0; t < GEN_CHUNK && i0 + t < h; t++) {
+  for (int t = 0; t < per_lane && i0 + t < h; t++) {
     const Fe<P> a = gload<P>(cw, i0 + t), b = gload<P>(cw, h + i0 + t);     // canonical, plain domain
     const Fe<P> sum = fe_add<P>(a, b);                                       // < 2p, limbs < 2^30
     const Fe<P> dif = fe_carry<P>(fe_sub<P, 4>(a, b));                       // a - b + 4p
@@ -940,12 +940,15 @@ int fri_fold_dev_impl(int fid, const void* d_cw, size_t n, const uint64_t* alpha
   h_mulmod(hf, r0, r0, rmod); h_mulmod(hf, winv, winv, rmod); h_mulmod(hf, halfv, halfv, rmod);
   Words8 r0w, winvw, halfw;
   to_words(r0, hf->nl, &r0w); to_words(winv, hf->nl, &winvw); to_words(halfv, hf->nl, &halfw);
-  const size_t chunks = (h + GEN_CHUNK - 1) / GEN_CHUNK;
+  // consecutive i per lane: a long walk amortises the lane's omega^-i0 power where there are lanes to spare; the late rounds
+  // of a FRI commit are short codewords on an empty GPU, where the walk itself is the latency (16 steps: 18 us; one: 6 us)
+  const int per_lane = h >= ((size_t)1 << 20) ? GEN_CHUNK : (h >= ((size_t)1 << 16) ? 4 : 1);
+  const size_t chunks = (h + (size_t)per_lane - 1) / (size_t)per_lane;
   const unsigned blocks = (unsigned)((chunks + 127) / 128);
   if (fid == MZK_FIELD_M128)
-    hipLaunchKernelGGL((k_fri_fold<M128Params>), dim3(blocks), dim3(128), 0, s, (const u32*)d_cw, h, r0w, winvw, halfw, (u32*)d_out);
+    hipLaunchKernelGGL((k_fri_fold<M128Params>), dim3(blocks), dim3(128), 0, s, (const u32*)d_cw, h, r0w, winvw, halfw, (u32*)d_out, per_lane);
   else
-    hipLaunchKernelGGL((k_fri_fold<FrParams>), dim3(blocks), dim3(128), 0, s, (const u32*)d_cw, h, r0w, winvw, halfw, (u32*)d_out);
+    hipLaunchKernelGGL((k_fri_fold<FrParams>), dim3(blocks), dim3(128), 0, s, (const u32*)d_cw, h, r0w, winvw, halfw, (u32*)d_out, per_lane);
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }
