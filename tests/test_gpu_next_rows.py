@@ -83,3 +83,26 @@ def test_batch_open_and_degree_bound(mz):
     ys_o, w_o = orc.kzg_batch_open_ref(f[:64], us, srs[:64])
     ys_g, w_g = mz.kzg_batch_open(f[:64], us, srs[:64])
     assert ys_g == ys_o and w_g == w_o
+
+
+@pytest.mark.parametrize("fid,lg", [(M128, 17), (FR, 17), (M128, 21), (FR, 21)])
+def test_fri_fold_every_walk_length(mz, fid, lg):
+    """The fold kernel walks 1, 4 or 16 consecutive positions per lane depending on the codeword length (short late rounds vs
+    long early ones): 2^17 takes the 4-step walk, 2^21 the 16-step one (2^14 and below, above: one step).  The whole vector
+    against the oracle at 2^17, 64 sampled positions against the formula of fri.rs:182-193 at 2^21."""
+    n, h = 1 << lg, 1 << (lg - 1)
+    p = orc.MOD[fid]
+    cw = orc.synth_vector(fid, 170 + lg, n)
+    alpha = orc.from_limbs(orc.synth_vector(fid, 171, 1))[0]
+    off = orc.M128_GEN if fid == M128 else 7
+    om = orc.root_of(fid, lg)
+    got = mz.fri_fold(fid, cw, alpha, off, om)
+    assert got.shape[0] == h
+    if lg <= 17:
+        assert np.array_equal(got, orc.fri_fold_ref(fid, cw, alpha, off, om))
+    rng = np.random.default_rng(lg)
+    half = pow(2, -1, p)
+    for i in [0, 1, 3, 4, 15, 16, 17, h - 1] + [int(k) for k in rng.integers(0, h, 56)]:
+        a, b = orc.from_limbs(cw[i:i + 1])[0], orc.from_limbs(cw[h + i:h + i + 1])[0]
+        q = alpha * pow(off * pow(om, i, p) % p, -1, p) % p
+        assert orc.from_limbs(got[i:i + 1])[0] == half * ((1 + q) * a + (1 - q) * b) % p, i
