@@ -281,3 +281,16 @@ def test_ntt_multi_argument_errors(mz):
     with pytest.raises(mz.MzkError) as e:        # cyclic -> cyclic is not offered
         mz.ntt_multi_dev(orc.FR, orc.root_of(orc.FR, 6), [8, 8, 8, 8], [8, 8, 8, 8], 64, False, 1, 1)
     assert e.value.code == -1
+
+
+def test_srs_multi_shards_of_exactly_4096_points(mz):
+    """8 contexts x 4096 points: every shard is a commit of exactly 4096 coefficients, which takes the three-launch small path
+    (10-bit tables) and writes an XYZZ partial record instead of the affine point."""
+    mz.init_devices([0] * 8)
+    n = 8 * 4096
+    s, p = _inputs(n, 4242)
+    h = mz.SrsMulti(powers=p)
+    assert [h.lo[r + 1] - h.lo[r] for r in range(8)] == [4096] * 8
+    assert h.commit(s) == orc.msm_fast(s, p)
+    assert h.commit(s[:n - 5]) == orc.msm_fast(s[:n - 5], p[:n - 5])       # last shard short by five: 4091 coefficients
+    h.close()
