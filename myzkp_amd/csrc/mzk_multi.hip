@@ -139,6 +139,7 @@ static int ntt_multi_impl(int fid, const uint64_t* root, const void* const* in, 
     if (!sc.ok) { rc = MZK_E_ARG; break; }
     if (hipEventCreateWithFlags(&x.ev[r], hipEventDisableTiming) != hipSuccess) { set_error("ntt_multi: hipEventCreate failed"); rc = MZK_E_HIP; break; }
     made = r + 1;
+    WsGuard wsg(ctx().stream);      // the exchanges below write these slots on the context's stream: order them behind whoever used them last
     rc = ws_get(WS_MISC_D, m * esz, &A[r]);
     if (rc == MZK_OK) rc = ws_get(WS_MISC_E, m * esz, &B[r]);
     if (rc == MZK_OK) rc = ws_get(WS_MISC_F, m * esz, &C[r]);
