@@ -24,6 +24,52 @@ HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 T
 MAD_PEAK_PER_S = 256 * 64 * 2.4e9   # v_mad_u64_u32 is half rate: 64 lanes/clk/CU (profiles/r01_ubench_instr_rates.txt)
 
 
+METRIC = "G1 MSM pairs/sec + NTT elems/sec at 2^20 and 2^24; bit-exact vs CPU"
+
+
+def fail_line(n_gpus, msg, **more):
+    """One JSON line that says why there is no measurement (never a silent 1-rank run), then a non-zero exit."""
+    print(json.dumps({"metric": METRIC, "value": None, "unit": "pairs/s", "n_gpus": n_gpus, "error": msg, **more}), flush=True)
+    return 2
+
+
+def launch_ranks(n_gpus, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks (one process per GPU, RCCL) as a
+    child `python -m torch.distributed.run` and hand on rank 0's JSON line and the exit code.  This process never initialises
+    the GPU (torch.cuda.device_count() does not), so the children are ordinary child processes, not an exec from a GPU process."""
+    import socket, subprocess
+    shared = os.environ.get("MZK_BENCH_SHARED_GPU_TEST") == "1"
+    try:
+        import torch
+        visible = torch.cuda.device_count()
+    except Exception as ex:            # no torch / no driver: say so in the line
+        return fail_line(n_gpus, "cannot count GPUs: %s" % str(ex)[:200])
+    if visible < n_gpus and not shared:
+        return fail_line(n_gpus, "--gpus %d asked for but only %d GPU(s) visible; refusing to run fewer ranks than asked" % (n_gpus, visible),
+                         visible_devices=visible)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    got_line = False
+    for line in proc.stdout:
+        st = line.strip()
+        if st.startswith("{") and '"metric"' in st:
+            got_line = True
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = proc.wait()
+    if not got_line:
+        fail_line(n_gpus, "the %d-rank job exited with code %d without printing a result line" % (n_gpus, rc), launcher_cmd=" ".join(cmd))
+        return rc or 2
+    return rc
+
+
 def main():
     T_START = time.perf_counter()
     ap = argparse.ArgumentParser()
@@ -45,6 +91,10 @@ def main():
                          "those GPUs through the C ABI's mzk_*_multi entry points (no torch.distributed); single-process runs only")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: become the launcher BEFORE anything touches the GPU
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -59,6 +109,15 @@ def main():
     shared_gpu_test = world > 1 and os.environ.get("MZK_BENCH_SHARED_GPU_TEST") == "1"
     if shared_gpu_test:
         local_rank = 0
+    if world != args.gpus:
+        if rank == 0:
+            fail_line(args.gpus, "WORLD_SIZE=%d but --gpus %d: launch `python bench.py --gpus N` (it starts the ranks itself) or "
+                                 "torch.distributed.run --nproc-per-node N bench.py --gpus N" % (world, args.gpus))
+        sys.exit(2)
+    if world > 1 and not shared_gpu_test and torch.cuda.device_count() < world:
+        if rank == 0:
+            fail_line(args.gpus, "%d ranks but only %d GPU(s) visible" % (world, torch.cuda.device_count()), visible_devices=torch.cuda.device_count())
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -79,7 +138,6 @@ def main():
         if os.environ.get("MZK_BENCH_VERBOSE") == "1":
             print("[bench rank %d +%.1fs] %s" % (rank, time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
 
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
     dev = torch.device("cuda", local_rank)
     mz.init_devices([local_rank] * 4)     # context 0: every leg; contexts 1..3 (same GPU): further commits in flight, see below
     L = mz.lib()
@@ -542,7 +600,7 @@ def main():
     srs_roof["algorithmic_bytes_per_launch"] = 96 * n
     alu["kzg_commit_accumulate_frac"] = msm_mads / (srs_acc_ms * 1e-3) / MAD_PEAK_PER_S if srs_acc_ms == srs_acc_ms else None
     out = {
-        "metric": "G1 MSM pairs/sec + NTT elems/sec at 2^20 and 2^24; bit-exact vs CPU",
+        "metric": METRIC,
         "value": srs_rate, "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": srs_ms,
         **({"REHEARSAL_NOT_A_MEASUREMENT": "ranks share one GPU, exchange over gloo via host (MZK_BENCH_SHARED_GPU_TEST=1)"} if shared_gpu_test else {}),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 254-bit Montgomery)",

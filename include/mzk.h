@@ -43,7 +43,9 @@ enum { MZK_OK = 0,
        MZK_E_CALLBACK = -9,   /* a caller-supplied callback reported failure (mzk_fri_commit's challenge) */
        MZK_E_IO = -10         /* file could not be opened / read / written, or is not a valid dump (mzk_srs_save/load) */ };
 
-/* Select the device for this process, create streams/workspace.  Idempotent.  (SURVEY 8b sketched mzk_init(n_devices);
+/* Select the device for this process, create streams/workspace.  Idempotent: when context 0 already drives
+ * `device_ordinal` nothing is torn down (contexts made by mzk_init_devices, their streams and every handle stay valid);
+ * use mzk_init_devices(&ordinal, 1) to go back to exactly one context.  (SURVEY 8b sketched mzk_init(n_devices);
  * one process per GPU is the primary model, so the argument is the ordinal -- mzk_init_devices is the n-device form.) */
 int mzk_init(int device_ordinal);
 /* One process driving several GPUs: context r = (device_ordinals[r], its own stream, workspace and table caches).
@@ -53,6 +55,10 @@ int mzk_init_devices(const int* device_ordinals, int n_devices);
 int mzk_ctx_count(void);
 int mzk_ctx_select(int index);
 int mzk_ctx_device(int index);   /* device ordinal of a context, -1 if it does not exist */
+/* 1 when the devices of contexts a and b can reach each other's memory directly (mzk_init_devices calls
+ * hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess for every pair of distinct ordinals; same device = 1), else 0:
+ * mzk_ntt_multi's exchanges then stage through host memory inside the runtime -- correct, slower. */
+int mzk_ctx_peer_enabled(int index_a, int index_b);
 void* mzk_ctx_stream(int index); /* the context's own hipStream_t (non-blocking), usable as the `stream` of its *_dev calls */
 /* Two contexts on ONE device keep two calls in flight (each has its own stream and workspace; an mzk_srs handle is
  * plain device memory and serves every context of its device): alternating commits between them overlaps the

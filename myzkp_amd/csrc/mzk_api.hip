@@ -21,6 +21,9 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 
 static Context g_ctxs[MZK_MAX_CTX];
 static int g_nctx = 0, g_cur = 0;
+static int g_last_ordinal = 0;                   // what ensure_init() re-initialises on after a shutdown
+static signed char g_peer[MZK_MAX_CTX][MZK_MAX_CTX];
+int ctx_peer_enabled(int a, int b) { return (a >= 0 && b >= 0 && a < g_nctx && b < g_nctx) ? g_peer[a][b] : 0; }
 static uint64_t g_gen_counter = 1;
 Context& ctx() { return g_ctxs[g_cur]; }
 int ctx_count() { return g_nctx; }
@@ -100,14 +103,16 @@ static hipEvent_t prof_event() {
   (void)hipEventCreate(&e);
   return e;
 }
+// Phases are keyed by number only, so only context 0 is instrumented: the lanes of mzk_*_batch_dev enqueue the same phase
+// on several contexts interleaved, and begin/end pairs of different lanes would cross.
 void prof_begin(hipStream_t s, int phase) {
-  if (!g_prof_on || !((g_prof_mask >> phase) & 1u)) return;
+  if (!g_prof_on || !((g_prof_mask >> phase) & 1u) || ctx().index != 0) return;
   hipEvent_t e = prof_event();
   (void)hipEventRecord(e, s);
   g_prof_open[phase] = e;
 }
 void prof_end(hipStream_t s, int phase) {
-  if (!g_prof_on || !g_prof_open[phase]) return;
+  if (!g_prof_on || !g_prof_open[phase] || ctx().index != 0) return;
   hipEvent_t e = prof_event();
   (void)hipEventRecord(e, s);
   g_prof_pending.push_back({g_prof_open[phase], e, phase});
@@ -124,9 +129,15 @@ static void prof_drain() {
   g_prof_pending.clear();
 }
 
+// Every entry point starts here.  torch (or the caller) may have switched the thread's current HIP device since the last
+// call: re-assert the context's device so that allocations and launches land on the GPU the context drives.
 int ensure_init() {
-  if (g_nctx > 0 && ctx().ready) return MZK_OK;
-  return mzk_init(0);
+  if (g_nctx > 0 && ctx().ready) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != ctx().device) MZK_HIP(hipSetDevice(ctx().device));
+    return MZK_OK;
+  }
+  return mzk_init(g_last_ordinal);
 }
 
 // ---- host parameter math --------------------------------------------------------------------------
@@ -318,15 +329,46 @@ int mzk_init_devices(const int* device_ordinals, int n_devices) {
     c.ready = true;
     g_nctx = i + 1;
   }
+  g_last_ordinal = device_ordinals[0];
+  // Peer access between every pair of distinct devices (mzk_ntt_multi's exchanges are device-to-device copies: without it
+  // the runtime may stage them through host memory).  "Already enabled" is fine -- torch or an earlier init did it.
+  for (int a = 0; a < n_devices; a++)
+    for (int b = 0; b < n_devices; b++) {
+      g_peer[a][b] = 1;
+      const int da = g_ctxs[a].device, db = g_ctxs[b].device;
+      if (da == db) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, da, db) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+      if (can) {
+        MZK_HIP(hipSetDevice(da));
+        hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+        if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+        else if (e != hipSuccess) { (void)hipGetLastError(); can = 0; }
+      }
+      g_peer[a][b] = (signed char)can;
+    }
   return ctx_select(0);
 }
-int mzk_init(int device_ordinal) { return mzk_init_devices(&device_ordinal, 1); }
+// Idempotent: when context 0 already drives this ordinal nothing is torn down (further contexts made by mzk_init_devices,
+// their streams, workspaces and the handles that live on them all stay valid).
+int mzk_init(int device_ordinal) {
+  if (g_nctx > 0 && g_ctxs[0].ready && g_ctxs[0].device == device_ordinal) return ctx_select(0);
+  return mzk_init_devices(&device_ordinal, 1);
+}
 int mzk_ctx_count(void) { return g_nctx; }
 int mzk_ctx_select(int index) { return ctx_select(index); }
+int mzk_ctx_peer_enabled(int a, int b) { return ctx_peer_enabled(a, b); }
 int mzk_ctx_device(int index) { return (index >= 0 && index < g_nctx) ? g_ctxs[index].device : -1; }
 void* mzk_ctx_stream(int index) { return (index >= 0 && index < g_nctx) ? (void*)g_ctxs[index].stream : nullptr; }
 
 void mzk_shutdown(void) {
+  if (g_nctx) {        // the profiler's events belong to context 0's device
+    CtxScope sc(0);
+    prof_drain();
+    for (hipEvent_t e : g_prof_pool) (void)hipEventDestroy(e);
+    g_prof_pool.clear();
+    for (auto& e : g_prof_open) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+  }
   for (int i = 0; i < g_nctx; i++) {
     Context& c = g_ctxs[i];
     if (!c.ready) continue;
@@ -334,11 +376,17 @@ void mzk_shutdown(void) {
     (void)hipSetDevice(c.device);
     (void)hipDeviceSynchronize();
     ntt_release_plans();
+    kzg_release_cache();
     poly_release_pool();
     ws_release_all();
     if (c.ws_event) (void)hipEventDestroy(c.ws_event);
     if (c.fork_event) (void)hipEventDestroy(c.fork_event);
     if (c.join_event) (void)hipEventDestroy(c.join_event);
+    if (c.xready) (void)hipEventDestroy(c.xready);
+    for (int k = 0; k < MZK_MAX_CTX; k++) {
+      if (c.xdone[k]) (void)hipEventDestroy(c.xdone[k]);
+      if (c.xstream[k]) (void)hipStreamDestroy(c.xstream[k]);
+    }
     if (c.stream) (void)hipStreamDestroy(c.stream);
     c = Context();
   }

@@ -53,7 +53,16 @@ struct Context {
   hipStream_t ws_last = nullptr;
   bool ws_used = false;
   bool attr_done[ATTR_COUNT] = {};   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applied on this context's device
+  // mzk_ntt_multi's all-to-all: destination context pulls its chunk of every source on a stream of its own per source
+  // (created on first use), so all inbound xGMI links of the GPU carry data at once; xready orders them behind the
+  // context's stream, xdone[k] joins them back.
+  hipStream_t xstream[MZK_MAX_CTX] = {};
+  hipEvent_t xdone[MZK_MAX_CTX] = {};
+  hipEvent_t xready = nullptr;
 };
+// peer access between the devices of two contexts: 1 = enabled (or same device), 0 = the runtime refused (copies then stage
+// through the host inside hipMemcpyPeerAsync; still correct)
+int ctx_peer_enabled(int a, int b);
 Context& ctx();
 int ctx_count();
 int ctx_select(int index);       // hipSetDevice + make it current
@@ -117,6 +126,7 @@ int coset_divide_dev_impl(int fid, const void* d_lhs, size_t tl, const void* d_r
 int pointwise_div_dev(int fid, const void* d_a, const void* d_b, void* d_out, size_t n, hipStream_t s);
 int pointwise_mul_dev(int fid, const void* d_a, const void* d_b, void* d_out, size_t n, hipStream_t s);
 void ntt_release_plans();
+void kzg_release_cache();       // mzk_kzg.hip: fixed-base tables of the current context
 void poly_release_pool();       // mzk_poly.hip: parked scratch blocks of the current context
 int fri_fold_dev_impl(int fid, const void* d_cw, size_t n, const uint64_t* alpha, const uint64_t* offset, const uint64_t* omega,
                       void* d_out, hipStream_t s);

@@ -14,6 +14,15 @@
 #include "mzk_ec.h"
 
 namespace mzk {
+// fixed-base table cache of kzg_setup_g1_dev, one entry per context (the tables live in that context's workspace, the
+// event on its device); kzg_release_cache() drops the current context's entry -- mzk_shutdown calls it, so a re-init that
+// puts another device at the same index starts clean.
+static struct { uint64_t g[8]; uint64_t gen; bool have8, have16; hipEvent_t ready; } g_fb_cache[MZK_MAX_CTX] = {};
+void kzg_release_cache() {
+  auto& c = g_fb_cache[ctx().index];
+  if (c.ready) (void)hipEventDestroy(c.ready);
+  memset(&c, 0, sizeof c);
+}
 
 struct Words8k { u32 w[8]; };
 struct Words16k { u32 w[16]; };
@@ -226,8 +235,7 @@ int kzg_setup_g1_dev(const uint64_t* alpha_host, const uint64_t* g1_host, size_t
   // The fixed-base tables depend only on g1 (in practice always BN128::generator_g1()) and their construction is a
   // latency chain (248 serial doublings for the window bases + two inversions: ~1.4 ms, more than a whole 2^16-power
   // setup), so they are kept across calls, keyed by g1 and by the workspace generation.
-  static struct { uint64_t g[8]; uint64_t gen; bool have8, have16; hipEvent_t ready; } cache_all[MZK_MAX_CTX] = {};
-  auto& cache = cache_all[ctx().index];
+  auto& cache = g_fb_cache[ctx().index];
   if (cache.gen != ws_generation() || memcmp(cache.g, g1_host, sizeof cache.g) != 0) {
     cache.gen = ws_generation(); cache.have8 = cache.have16 = false;
     memcpy(cache.g, g1_host, sizeof cache.g);

@@ -389,7 +389,12 @@ struct mzk_merkle {
   void* d_leaves;        // owned copy of the elements / the leaf bytes (needed by open and by n == 1)
   std::vector<uint64_t> offsets;   // byte leaves only
   std::vector<uint8_t> neg;        // field leaves given as (magnitude, sign): 1 = Sign::Minus; empty = all non-negative
-  hipStream_t stream;
+  hipStream_t stream;    // the stream the tree was BUILT on (a caller stream for the *_dev builders); never used again
+  // Owner: the context (and its device) whose memory holds the tree.  Every later operation enters that context, runs on
+  // ITS stream and workspace (MerkleScope) behind `built`, whatever context is current and whatever became of `stream`.
+  int ctx_index = 0;
+  int device = -1;
+  hipEvent_t built = nullptr;    // recorded behind the last kernel of the build
   // ragged leaf counts: the tree is built over m = 2^floor(log2 n) items (see k_merkle_ragged_items); d_nodes, depth
   // and the gather kernel then refer to the item tree
   bool ragged = false;
@@ -401,6 +406,32 @@ struct mzk_merkle {
 
 namespace mzk {
 static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+
+// end of a successful build on stream s of the current context
+static int merkle_stamp(mzk_merkle* t, hipStream_t s) {
+  t->ctx_index = ctx().index;
+  t->device = ctx().device;
+  if (!t->built) MZK_HIP(hipEventCreateWithFlags(&t->built, hipEventDisableTiming));
+  MZK_HIP(hipEventRecord(t->built, s));
+  return MZK_OK;
+}
+// Enter the owning context of a tree for the scope of one entry point.  rc != MZK_OK: the context is gone or drives another
+// device now (mzk_init_devices since the build) -- MZK_E_ARG, as srs_check_ctx reports a foreign SRS handle.
+struct MerkleScope {
+  CtxScope sc;
+  int rc;
+  hipStream_t s;
+  explicit MerkleScope(const mzk_merkle* t) : sc(t->ctx_index), rc(MZK_OK), s(nullptr) {
+    if (!sc.ok || ctx().device != t->device) {
+      set_error("Merkle tree handle was built on context %d (device %d); that context %s", t->ctx_index, t->device,
+                sc.ok ? "drives another device now" : "no longer exists");
+      rc = MZK_E_ARG;
+      return;
+    }
+    s = ctx().stream;
+    if (t->built && hipStreamWaitEvent(s, t->built, 0) != hipSuccess) { (void)hipGetLastError(); rc = MZK_E_HIP; set_error("merkle: cannot order behind the build"); }
+  }
+};
 
 // hashes level 1 .. root into d_nodes; d_leaves / d_off already on the device
 // `trees` > 1: n = trees * (leaves per tree), all trees of one power-of-two size, leaves back to back.  Level l of the whole
@@ -496,6 +527,7 @@ static int merkle_build_ragged(const uint8_t* leaves, const uint64_t* offsets, s
                        (const u64*)d_ioff, (u8*)t->d_items);
     rc = merkle_hash_levels(1, -1, t->d_items, d_ioff, m, t->d_nodes, s);
     if (rc == MZK_OK && hipStreamSynchronize(s) != hipSuccess) { set_error("merkle: sync failed"); rc = MZK_E_HIP; }
+    if (rc == MZK_OK) rc = merkle_stamp(t, s);
   } while (0);
   if (rc != MZK_OK) { mzk_merkle_free(t); return rc; }
   *out = t;
@@ -552,8 +584,9 @@ static int merkle_build(int kind, int fid, const void* src, bool src_on_device, 
     }
     rc = merkle_hash_levels(kind, fid, t->d_leaves, d_off, n, t->d_nodes, s, d_neg);
     if (rc == MZK_OK && kind == 1 && hipStreamSynchronize(s) != hipSuccess) { set_error("merkle: sync failed"); rc = MZK_E_HIP; }
+    if (rc == MZK_OK) rc = merkle_stamp(t, s);
   } while (0);
-  if (rc != MZK_OK) { if (t->d_leaves) (void)hipFree(t->d_leaves); if (t->d_nodes) (void)hipFree(t->d_nodes); delete t; return rc; }
+  if (rc != MZK_OK) { mzk_merkle_free(t); return rc; }
   *out = t;
   return MZK_OK;
 }
@@ -609,28 +642,31 @@ int mzk_merkle_build_bytes(const uint8_t* leaves, const uint64_t* offsets, size_
 
 int mzk_merkle_root(const mzk_merkle* t, uint8_t* root, size_t cap, size_t* root_len) {
   if (!t || !root || !root_len) { set_error("merkle_root: null pointer"); return MZK_E_ARG; }
+  MZK_TRY(ensure_init());
+  MerkleScope ms(t);
+  MZK_TRY(ms.rc);
   if (t->n == 1) {   // merkle.rs:17-19: the single leaf itself
     uint8_t buf[48];
     size_t len;
     if (t->kind == 0) {
       uint64_t limbs[4];
-      MZK_HIP(hipMemcpyAsync(limbs, t->d_leaves, field_bytes(t->field), hipMemcpyDeviceToHost, t->stream));
-      MZK_HIP(hipStreamSynchronize(t->stream));
+      MZK_HIP(hipMemcpyAsync(limbs, t->d_leaves, field_bytes(t->field), hipMemcpyDeviceToHost, ms.s));
+      MZK_HIP(hipStreamSynchronize(ms.s));
       len = host_bincode_field(limbs, field_limbs64(t->field), buf, !t->neg.empty() && t->neg[0]);
       if (cap < len) { set_error("merkle_root: buffer too small (%zu < %zu)", cap, len); return MZK_E_LENGTH; }
       memcpy(root, buf, len);
     } else {
       len = (size_t)(t->offsets[1] - t->offsets[0]);
       if (cap < len) { set_error("merkle_root: buffer too small (%zu < %zu)", cap, len); return MZK_E_LENGTH; }
-      if (len) MZK_HIP(hipMemcpyAsync(root, t->d_leaves, len, hipMemcpyDeviceToHost, t->stream));
-      MZK_HIP(hipStreamSynchronize(t->stream));
+      if (len) MZK_HIP(hipMemcpyAsync(root, t->d_leaves, len, hipMemcpyDeviceToHost, ms.s));
+      MZK_HIP(hipStreamSynchronize(ms.s));
     }
     *root_len = len;
     return MZK_OK;
   }
   if (cap < 32) { set_error("merkle_root: buffer too small"); return MZK_E_LENGTH; }
-  MZK_HIP(hipMemcpyAsync(root, t->d_nodes + 4 * ((t->ragged ? t->m : t->n) - 2), 32, hipMemcpyDeviceToHost, t->stream));
-  MZK_HIP(hipStreamSynchronize(t->stream));
+  MZK_HIP(hipMemcpyAsync(root, t->d_nodes + 4 * ((t->ragged ? t->m : t->n) - 2), 32, hipMemcpyDeviceToHost, ms.s));
+  MZK_HIP(hipStreamSynchronize(ms.s));
   *root_len = 32;
   return MZK_OK;
 }
@@ -642,7 +678,15 @@ int mzk_merkle_open(const mzk_merkle* t, size_t index, uint8_t* path, size_t str
   if (t->n < 2) { set_error("merkle_open: needs at least two leaves (merkle.rs:32)"); return MZK_E_LENGTH; }
   if (index >= t->n) { set_error("merkle_open: index %zu out of range", index); return MZK_E_LENGTH; }
   if (stride < 32) { set_error("merkle_open: stride < 32"); return MZK_E_LENGTH; }
-  hipStream_t s = t->stream;
+  if (t->kind == 0 && !t->ragged) {        // field-element tree: sibling leaf and digests in one gather and one synchronisation
+    const uint64_t idx64 = (uint64_t)index;
+    return mzk_merkle_open_batch(t, &idx64, 1, path, stride, path_len, depth);
+  }
+  MZK_TRY(ensure_init());
+  MerkleScope ms(t);
+  MZK_TRY(ms.rc);
+  hipStream_t s = ms.s;
+  WsGuard wsg(s);          // WS_MISC_C below is shared with every other entry point of the context
   if (t->ragged) {
     // subtree p (depth D) that holds the leaf.  Merkle::open only terminates when its descent ends in a TWO-leaf
     // slice (merkle.rs:32-34); a one-leaf slice recurses forever (mid = 0), so those indices are an error here.
@@ -683,10 +727,6 @@ int mzk_merkle_open(const mzk_merkle* t, size_t index, uint8_t* path, size_t str
     }
     *depth = (size_t)t->depth + k;
     return MZK_OK;
-  }
-  if (t->kind == 0) {        // field-element tree: sibling leaf and digests in one gather and one synchronisation
-    const uint64_t idx64 = (uint64_t)index;
-    return mzk_merkle_open_batch(t, &idx64, 1, path, stride, path_len, depth);
   }
   const size_t sib = index ^ 1;
   // byte leaves: entry 0 is the sibling LEAF, verbatim
@@ -730,7 +770,9 @@ int mzk_merkle_open_batch(const mzk_merkle* t, const uint64_t* indices, size_t c
   for (size_t q = 0; q < count; q++)
     if (indices[q] >= t->n) { set_error("merkle_open: index %llu out of range", (unsigned long long)indices[q]); return MZK_E_LENGTH; }
   MZK_TRY(ensure_init());
-  hipStream_t s = t->stream;
+  MerkleScope ms(t);
+  MZK_TRY(ms.rc);
+  hipStream_t s = ms.s;
   WsGuard wsg(s);
   const int lw = (int)field_words(t->field), nl = field_limbs64(t->field);
   const size_t node_words64 = count * (size_t)(t->depth - 1) * 4;
@@ -775,7 +817,7 @@ int mzk_merkle_open_multi(const mzk_merkle* const* trees, size_t n_trees, const 
                           size_t stride, uint64_t* path_lens, size_t* depths) {
   if (!trees || !counts || !depths) { set_error("merkle_open_multi: null pointer"); return MZK_E_ARG; }
   size_t total = 0, total_nodes = 0, total_leaf_words = 0;
-  hipStream_t s = nullptr;
+  const mzk_merkle* first = nullptr;
   for (size_t t = 0; t < n_trees; t++) {
     depths[t] = trees[t] ? (size_t)trees[t]->depth : 0;
     if (counts[t] == 0) continue;
@@ -788,7 +830,12 @@ int mzk_merkle_open_multi(const mzk_merkle* const* trees, size_t n_trees, const 
     }
     for (size_t q = 0; q < counts[t]; q++)
       if (indices[total + q] >= tr->n) { set_error("merkle_open: index %llu out of range (tree %zu)", (unsigned long long)indices[total + q], t); return MZK_E_LENGTH; }
-    if (!s) s = tr->stream;
+    if (!first) first = tr;
+    if (tr->ctx_index != first->ctx_index || tr->device != first->device) {
+      set_error("merkle_open_multi: tree %zu lives on context %d, the first opened tree on context %d; one call opens trees of one context", t,
+                tr->ctx_index, first->ctx_index);
+      return MZK_E_ARG;
+    }
     total += counts[t];
     total_nodes += counts[t] * (size_t)(tr->depth - 1) * 4;
     total_leaf_words += counts[t] * field_words(tr->field);
@@ -796,6 +843,11 @@ int mzk_merkle_open_multi(const mzk_merkle* const* trees, size_t n_trees, const 
   if (total == 0) return MZK_OK;
   if (stride < 32) { set_error("merkle_open: stride < 32"); return MZK_E_LENGTH; }
   MZK_TRY(ensure_init());
+  MerkleScope ms(first);
+  MZK_TRY(ms.rc);
+  hipStream_t s = ms.s;
+  for (size_t t = 0; t < n_trees; t++)      // every opened tree's build, not only the first one's
+    if (counts[t] && trees[t]->built) MZK_HIP(hipStreamWaitEvent(s, trees[t]->built, 0));
   WsGuard wsg(s);
   u64 *d_idx, *d_on;
   u32* d_ol;
@@ -855,6 +907,7 @@ void mzk_merkle_free(mzk_merkle* t) {
   if (t->d_leaves) (void)hipFree(t->d_leaves);
   if (t->d_nodes) (void)hipFree(t->d_nodes);
   if (t->d_items) (void)hipFree(t->d_items);
+  if (t->built) (void)hipEventDestroy(t->built);
   delete t;
 }
 
@@ -1020,6 +1073,7 @@ static int fri_commit_rounds(int field_id, const uint64_t* codeword, const uint8
         MZK_HIP(hipMemcpyAsync(t->d_leaves, cur, len * esz, hipMemcpyDeviceToDevice, s));
         MZK_HIP(hipMemcpyAsync(t->d_nodes, d_nodes, (len - 1) * 32, hipMemcpyDeviceToDevice, s));
         if (r == 0 && negative) t->neg.assign(negative, negative + n);
+        MZK_TRY(merkle_stamp(t, s));
       }
       MZK_HIP(hipStreamSynchronize(s));
       root_len[r] = 32;
@@ -1077,7 +1131,9 @@ int mzk_merkle_leaves(const mzk_merkle* t, const uint64_t* indices, size_t count
     if (indices[q] >= t->n) { set_error("merkle_leaves: index %llu out of range", (unsigned long long)indices[q]); return MZK_E_LENGTH; }
   if (count == 0) return MZK_OK;
   MZK_TRY(ensure_init());
-  hipStream_t s = t->stream;
+  MerkleScope ms(t);
+  MZK_TRY(ms.rc);
+  hipStream_t s = ms.s;
   WsGuard wsg(s);
   const size_t esz = field_bytes(t->field);
   const int lw = (int)field_words(t->field);

@@ -79,21 +79,39 @@ static int record_all(Exchange& x) {
   }
   return MZK_OK;
 }
-// dst[d] + s * chunk  <-  src[s] + d * chunk, for every (d, s); wait_events: the sources were produced by this call
+// dst[d] + s * chunk  <-  src[s] + d * chunk, for every (d, s); wait_events: the sources were produced by this call.
+// Destination d drives ALL its inbound links at once: the pull from source (d + k) % W runs on d's k-th exchange stream
+// (its own chunk, k = 0, on the context's stream), so the W - 1 peer copies of a GPU overlap each other, and the
+// staggered start means that at any moment every source is being read by a different destination (xGMI is point to
+// point: W - 1 links per GPU, each carrying one chunk).  The exchange streams start behind the context's stream (xready:
+// the destination buffer's previous readers are done) and the context's stream continues behind all of them (xdone).
 static int exchange(Exchange& x, void* const* src, void* const* dst, bool wait_events) {
   for (int d = 0; d < x.W; d++) {
     CtxScope sc(d);
     if (!sc.ok) return MZK_E_ARG;
-    hipStream_t st = ctx().stream;
-    const int dev_d = ctx().device;
-    for (int s = 0; s < x.W; s++) {
-      if (wait_events && s != d) MZK_HIP(hipStreamWaitEvent(st, x.ev[s], 0));
+    Context& c = ctx();
+    hipStream_t st = c.stream;
+    const int dev_d = c.device;
+    if (!c.xready) MZK_HIP(hipEventCreateWithFlags(&c.xready, hipEventDisableTiming));
+    MZK_HIP(hipEventRecord(c.xready, st));
+    for (int k = 0; k < x.W; k++) {
+      const int s = (d + k) % x.W;
+      hipStream_t xs = st;
+      if (k) {
+        if (!c.xstream[k]) MZK_HIP(hipStreamCreateWithFlags(&c.xstream[k], hipStreamNonBlocking));
+        if (!c.xdone[k]) MZK_HIP(hipEventCreateWithFlags(&c.xdone[k], hipEventDisableTiming));
+        xs = c.xstream[k];
+        MZK_HIP(hipStreamWaitEvent(xs, c.xready, 0));
+        if (wait_events) MZK_HIP(hipStreamWaitEvent(xs, x.ev[s], 0));
+      }
       const char* from = (const char*)src[s] + (size_t)d * x.chunk_bytes;
       char* to = (char*)dst[d] + (size_t)s * x.chunk_bytes;
       const int dev_s = mzk_ctx_device(s);
-      if (dev_s == dev_d) MZK_HIP(hipMemcpyAsync(to, from, x.chunk_bytes, hipMemcpyDeviceToDevice, st));
-      else MZK_HIP(hipMemcpyPeerAsync(to, dev_d, from, dev_s, x.chunk_bytes, st));
+      if (dev_s == dev_d) MZK_HIP(hipMemcpyAsync(to, from, x.chunk_bytes, hipMemcpyDeviceToDevice, xs));
+      else MZK_HIP(hipMemcpyPeerAsync(to, dev_d, from, dev_s, x.chunk_bytes, xs));
+      if (k) MZK_HIP(hipEventRecord(c.xdone[k], xs));
     }
+    for (int k = 1; k < x.W; k++) MZK_HIP(hipStreamWaitEvent(st, c.xdone[k], 0));
   }
   return MZK_OK;
 }

@@ -538,9 +538,15 @@ static void free_plan(NttPlan* p) {
   for (auto& t : p->tw_inter) if (t) (void)hipFree(t);
   delete p;
 }
+// offset-power tables of the fused coset LDE, per (context, field); see coset_lde_dev_impl
+static struct { uint64_t off[4]; unsigned logn; int lgn0; uint64_t gen; bool valid; hipEvent_t ready; } g_lde_cache[MZK_MAX_CTX][2] = {};
 void ntt_release_plans() {
   for (auto* p : g_plans) free_plan(p);
   g_plans.clear();
+  for (auto& ce : g_lde_cache[ctx().index]) {      // mzk_shutdown walks the contexts: drop this one's entries and their events
+    if (ce.ready) (void)hipEventDestroy(ce.ready);
+    memset(&ce, 0, sizeof ce);
+  }
 }
 
 static LevelInfo choose_levels(unsigned logn, bool large) {
@@ -855,8 +861,7 @@ int coset_lde_dev_impl(int fid, const void* d_coef, size_t n_coef, const uint64_
     // offset^(j M) and offset^col tables: like the plan's twiddles they depend only on (field, offset, size) -- a STARK
     // prover evaluates every polynomial on ONE coset -- so the last pair per field is kept (workspace generation and
     // stream order checked like the fixed-base tables in mzk_kzg.hip).
-    static struct { uint64_t off[4]; unsigned logn; int lgn0; uint64_t gen; bool valid; hipEvent_t ready; } cache[MZK_MAX_CTX][2] = {};
-    auto& ce = cache[ctx().index][fid == MZK_FIELD_M128 ? 1 : 0];
+    auto& ce = g_lde_cache[ctx().index][fid == MZK_FIELD_M128 ? 1 : 0];
     void* tabs = nullptr;
     MZK_TRY(ws_get(fid == MZK_FIELD_M128 ? WS_NTT_PRE_M128 : WS_NTT_PRE, (nrow + ncol) * field_bytes(fid), &tabs));
     u32* pre_row = (u32*)tabs;

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def mz():
     import myzkp_amd as m
     yield m
-    m.init(0)          # leave the process in the single-context state the other modules expect
+    m.init_devices([0])   # back to ONE context (mzk_init(0) would keep the extra contexts: it is idempotent)
 
 
 def _inputs(n, seed):
@@ -294,3 +294,39 @@ def test_srs_multi_shards_of_exactly_4096_points(mz):
     assert h.commit(s) == orc.msm_fast(s, p)
     assert h.commit(s[:n - 5]) == orc.msm_fast(s[:n - 5], p[:n - 5])       # last shard short by five: 4091 coefficients
     h.close()
+
+
+def test_merkle_handles_follow_their_context(mz):
+    """a tree handle records its owning context.  Opening it while ANOTHER context is current enters the owner
+    (its stream, its workspace); one open_multi call refuses trees of two contexts; a handle survives re-initialisation on
+    the same device (its build stream is gone, its memory is not)."""
+    fid, n = orc.M128, 1 << 10
+    cw = orc.synth_vector(fid, 4242, n)
+    want_root = orc.merkle_commit_field_ref(fid, cw)
+    mz.init_devices([0, 0])
+    t0 = mz.MerkleTree(fid, elems=cw)
+    mz.ctx_select(1)
+    t1 = mz.MerkleTree(fid, elems=cw)
+    idx = [0, 1, 513, n - 1]
+    try:
+        # current context 1, tree of context 0 (and the other way round)
+        assert t0.root() == want_root and t1.root() == want_root
+        p0 = t0.open_many(idx)
+        mz.ctx_select(0)
+        p1 = t1.open_many(idx)
+        assert p0 == p1
+        for i, path in zip(idx, p0):
+            assert orc.merkle_verify_ref(want_root, i, path, orc.bincode_field(orc.from_limbs(cw[i:i + 1])[0], 2)), i
+        assert np.array_equal(t1.leaves(idx), cw[idx])
+        with pytest.raises(mz.MzkError) as e:
+            mz.merkle_open_multi([t0, t1], [idx, idx])
+        assert e.value.code == -1
+        assert mz.merkle_open_multi([t0, t0], [idx, idx[:2]]) == [p0, p0[:2]]
+        # re-initialise: one context on the same device.  t0's context index still exists there, t1's does not.
+        mz.init_devices([0])
+        assert t0.root() == want_root and t0.open_many(idx) == p0
+        with pytest.raises(mz.MzkError) as e:
+            t1.open_many(idx)
+        assert e.value.code == -1
+    finally:
+        t0.close(); t1.close()

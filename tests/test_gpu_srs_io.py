@@ -64,6 +64,38 @@ def test_corrupted_truncated_and_foreign_files_are_rejected(mz, tmp_path):
     assert e.value.code == -10
 
 
+def test_flipped_byte_in_the_table_section_is_rejected_and_format_1_files_rebuild(mz, tmp_path):
+    """the points checksum alone let a corrupted table row through (every later commit a wrong point, MZK_OK).
+    Format 2 carries a second checksum over the table section; a format-1 file's tables are never trusted."""
+    n = 700
+    p = orc.synth_points(91, n)
+    s = orc.synth_vector(FR, 92, n)
+    want = orc.msm_fast(s, p)
+    h = mz.Srs(p)
+    path = str(tmp_path / "srs.bin")
+    h.save(path, with_tables=True)
+    h.close()
+    raw = bytearray(open(path, "rb").read())
+    assert struct.unpack_from("<I", raw, 8)[0] == 2 and len(raw) > 64 + 64 * n * 2
+    bad = str(tmp_path / "bad.bin")
+    for at in (64 + 64 * n + 5, 64 + 64 * n * 7 + 33, len(raw) - 1):            # first table row, a middle row, the last byte
+        blob = bytearray(raw); blob[at] ^= 0x10
+        open(bad, "wb").write(bytes(blob))
+        with pytest.raises(mz.MzkError) as e:
+            mz.Srs.load(bad, with_tables=1)
+        assert e.value.code == -10, at
+        g = mz.Srs.load(bad, with_tables=0)          # the points section is intact: a load that ignores the tables succeeds
+        assert g.commit(s) == want
+        g.close()
+    # the same bytes relabelled as a format-1 dump (no table checksum) with a corrupted table row: tables are rebuilt, result right
+    blob = bytearray(raw); blob[64 + 64 * n * 3 + 9] ^= 0xff
+    struct.pack_into("<I", blob, 8, 1)
+    open(bad, "wb").write(bytes(blob))
+    g = mz.Srs.load(bad, with_tables=1)
+    assert g.commit(s) == want
+    g.close()
+
+
 def test_setup_on_device_then_dump_equals_oracle_setup(mz, tmp_path):
     """setup_kzg (kzg.rs:27-40) on the GPU -> handle -> file: the bytes are the oracle's powers_1."""
     import ctypes, torch
