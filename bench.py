@@ -33,6 +33,22 @@ def fail_line(n_gpus, msg, **more):
     return 2
 
 
+def recorded_traffic(kernel_prefix):
+    """FETCH_SIZE + WRITE_SIZE per launch (bytes) of a kernel from the newest profiles/r*_hbm_traffic_pmc.txt that names it in
+    its 2^20 KZG-commit section (written by tools/timing/pmc_summary.py under rocprofv3 --pmc; the bench itself never runs
+    under the profiler).  None if no such record exists."""
+    import glob, re
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.txt"))):
+        for line in open(path):
+            m = re.match(r"(.*?)\s+launches=.*FETCH_SIZE avg=\s*([0-9.]+) KiB\s+WRITE_SIZE avg=\s*([0-9.]+) KiB", line)
+            if m and kernel_prefix in m.group(1):
+                best = {"bytes": int((float(m.group(2)) + float(m.group(3))) * 1024),
+                        "source": "profiles/%s (recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, raw counters; not collected by this run)" % os.path.basename(path)}
+                break       # first match per file = the KZG-commit section
+    return best
+
+
 def launch_ranks(n_gpus, argv):
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks (one process per GPU, RCCL) as a
     child `python -m torch.distributed.run` and hand on rank 0's JSON line and the exit code.  This process never initialises
@@ -52,6 +68,7 @@ def launch_ranks(n_gpus, argv):
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MZK_BENCH_LAUNCHED_BY"] = "bench.py launch_ranks (python -m torch.distributed.run child)"
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_gpus)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
@@ -208,7 +225,9 @@ def main():
         if attempt == 0:
             L.mzk_srs_free(hh)
     srs._h = hh
-    srs_table_windows = 254 // (8 if n <= 1024 else (10 if n < 4096 else (13 if n < (1 << 14) else 16))) + 1
+    # msm_srs_window_bits (mzk_common.h): the default window width of an SRS handle by its size
+    srs_window_bits = 8 if n <= 1024 else (10 if n <= 4096 else (13 if n < (1 << 14) else (16 if n < (1 << 19) else 17)))
+    srs_table_windows = 254 // srs_window_bits + 1
     progress("SRS handle built")
     # The HIP runtime stalls once for 35-45 ms a few thousand dispatches into a process (measured: one stall in 120 000
     # launches, at dispatch ~3500; tools note in DESIGN.md section 8) -- get past it before anything is timed.
@@ -447,8 +466,9 @@ def main():
             torch.cuda.empty_cache()
 
     def run_other_width(c):
-        """The same commit against a handle with c-bit windows (mzk_srs_from_device_ex): `value` stays at the 16 bits BASELINE
-        configs[2] names; this is what the width knob is worth at this size."""
+        """The same commit against a handle with c-bit windows (mzk_srs_from_device_ex).  `value` uses the library's default
+        width for the size (17 bits from 2^19 points: profiles/r03b_window_sweep.txt); BASELINE configs[2] names 16-bit
+        windows, so that width is always reported beside it as its own leg."""
         if world != 1 or args.no_two_in_flight:
             return None
         hw = ctypes.c_void_p()
@@ -467,14 +487,14 @@ def main():
             torch.cuda.synchronize()
             dtw = (time.perf_counter() - t0) / K
             return {"window_bits": c, "tables": 254 // c + 1, "ms_per_step": dtw * 1e3, "value": n / dtw, "unit": "pairs/s",
-                    "same_point_as_16_bit_windows": bool(torch.equal(outw, result_srs))}
+                    "same_point_as_default_width": bool(torch.equal(outw, result_srs))}
         except Exception as ex:
             return {"error": str(ex)[:300]}
         finally:
             if hw:
                 L.mzk_srs_free(hw)
             torch.cuda.empty_cache()
-    width17 = run_other_width(17) if args.log2n >= 20 else None
+    width16 = run_other_width(16) if srs_window_bits != 16 else None
 
     def run_ntt_batched():
         """Many transforms per call (mzk_ntt_batch_dev): a prover interpolates / extends every column of a trace, and a batch
@@ -577,8 +597,8 @@ def main():
     ntt_roof["algorithmic_bytes_per_launch"] = 64 * n
     ntt_roof["frac_of_wall_clock"] = 64.0 * n / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
     # integer-multiply roofline (the binding one): v_mad_u64_u32 per Montgomery product = 171
-    nwin, c = 254 // 16 + 1, 16
-    msm_mads = n * nwin * (8 * 171 + 2 * 135)           # madd = 8M + 2S per (pair, window)
+    msm_mads = n * 16 * (8 * 171 + 2 * 135)             # generic layout: 2 x 8 GLV windows; madd = 8M + 2S per (pair, window)
+    srs_mads = n * srs_table_windows * (8 * 171 + 2 * 135)
     ntt_mads = (n // 2) * args.log2n * 171
     alu = {"unit": "v_mad_u64_u32/s", "peak": MAD_PEAK_PER_S,
            "msm_accumulate_frac": msm_mads / (acc_ms * 1e-3) / MAD_PEAK_PER_S if acc_ms == acc_ms else None,
@@ -591,26 +611,35 @@ def main():
     srs_roof["kernel"] = "k_seg_accumulate"
     srs_roof["measured"] = "HIP-event pair around the kernel on its launch stream, inside the timed region (the only instrumented kernel there)"
     if args.log2n == 20:
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r02o_hbm_traffic_pmc.txt: per launch of
-        # k_seg_accumulate at 2^20 pairs, raw counters (64-byte random gathers: the gfx950 x2 FETCH_SIZE correction for wide
-        # coalesced streams is not applied; with it the figure doubles).  The fixed-base method reads each of the 16 table
-        # points of a pair once (16 x 64 B = 1.07 GB); the 128-byte fetch granule doubles that.  Served by L2 / Infinity Cache.
-        srs_roof["traffic"] = (2065355 + 59442) * 1024
-        srs_roof["traffic_source"] = "profiles/r02o_hbm_traffic_pmc.txt (recorded rocprofv3 --pmc passes of the same kernel at the same size, tools/gpu_jobs/r02o.sh; not collected by this run)"
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/gpu_jobs/r03c.sh) of k_seg_accumulate at 2^20 pairs with
+        # the default window width, raw counters (64-byte random gathers: the gfx950 x2 FETCH_SIZE correction for wide coalesced
+        # streams is not applied; with it the figure doubles).  The fixed-base method reads each of the table points of a pair
+        # once (15 x 64 B = 0.96 GiB); the 128-byte fetch granule doubles that.  Served by L2 / Infinity Cache.  A recorded
+        # profile of the same kernel at the same size -- not collected by this run.
+        tr = recorded_traffic("k_seg_accumulate")
+        if tr is not None:
+            srs_roof["traffic"] = tr["bytes"]
+            srs_roof["traffic_source"] = tr["source"]
     srs_roof["algorithmic_bytes_per_launch"] = 96 * n
-    alu["kzg_commit_accumulate_frac"] = msm_mads / (srs_acc_ms * 1e-3) / MAD_PEAK_PER_S if srs_acc_ms == srs_acc_ms else None
+    alu["kzg_commit_accumulate_frac"] = srs_mads / (srs_acc_ms * 1e-3) / MAD_PEAK_PER_S if srs_acc_ms == srs_acc_ms else None
     out = {
         "metric": METRIC,
         "value": srs_rate, "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": srs_ms,
+        "process_group": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None,
+                          "launched_by": os.environ.get("MZK_BENCH_LAUNCHED_BY", "external launcher" if world > 1 else "single process")},
         **({"REHEARSAL_NOT_A_MEASUREMENT": "ranks share one GPU, exchange over gloo via host (MZK_BENCH_SHARED_GPU_TEST=1)"} if shared_gpu_test else {}),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 254-bit Montgomery)",
         "data": "synthetic",
         "config": {"workload": "KZG commit = BN254 G1 Pippenger MSM of 2^%d (scalar, point) pairs per GPU against a device-resident SRS "
-                               "(commit_kzg, kzg.rs:57-59; 16-bit signed windows; the SRS handle holds 16 window tables 2^(16w)*P_i built "
-                               "once at upload like an FFT plan, so all windows share one bucket set); N GPUs = one MSM of N*2^%d pairs "
-                               "(BASELINE configs[2]/[3])" % (args.log2n, args.log2n),
-                   "pairs_per_gpu": n, "seed": SEED, "sharding": "contiguous shards + all_gather of 128 B partials (RCCL) + local fold"},
+                               "(commit_kzg, kzg.rs:57-59; %d-bit signed windows, the library's default at this size -- the 16-bit windows "
+                               "BASELINE configs[2] names are the kzg_commit_16_bit_windows leg; the SRS handle holds %d window tables "
+                               "2^(%d w)*P_i built once at upload like an FFT plan, so all windows share one bucket set); N GPUs = one MSM of "
+                               "N*2^%d pairs (BASELINE configs[2]/[3])" % (args.log2n, srs_window_bits, srs_table_windows, srs_window_bits, args.log2n),
+                   "pairs_per_gpu": n, "seed": SEED, "window_bits": srs_window_bits, "sharding": "contiguous shards + all_gather of 128 B partials (RCCL) + local fold"},
         "roofline": srs_roof,
+        # BASELINE configs[2] read literally -- an MSM on ARBITRARY points, nothing precomputed per point set -- is this rate;
+        # `value` is the KZG-commit special case (fixed SRS, window tables built once: srs_precompute)
+        "msm_pairs_per_s_arbitrary_points": msm_rate,
         "phases": srs_ph,
         # what the headline rests on: `value` commits against window tables built ONCE per SRS (like an FFT plan);
         # `msm_generic` below is the same MSM with no per-point-set precomputation at all
@@ -620,7 +649,7 @@ def main():
                            "note": "table build is outside the timed region; one KZG setup is followed by many commits/opens against the same powers_1 (kzg.rs:57-72)"},
         "kzg_commit_two_in_flight": pipelined,
         "kzg_commit_four_in_flight": pipelined4,
-        "kzg_commit_17_bit_windows": width17,
+        "kzg_commit_16_bit_windows": width16 if width16 is not None else ({"note": "16 bits is the default width at this size: see `value`"} if srs_window_bits == 16 else None),
         "msm_no_tables_in_flight": generic4,
         "ntt_batched": ntt_batched,
         "msm_generic": {"metric": "G1 MSM pairs/sec, arbitrary points every call (no per-point-set precomputation; 16 bucket sets + window Horner)",
@@ -991,25 +1020,33 @@ def main():
         cb = {"value": sample / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
               "sample": "first 2^11 pairs of the same stream through oracle orc_msm_ref (literal restatement of "
                         "polynomial.rs:156-165: affine double-and-add, one inversion per group op); MSM cost is linear in n"}
-        nn = min(n, 1 << 18)
+        # `cpu_fast`: the oracle's own multi-threaded code -- plain Jacobian-coordinate Pippenger with unsigned windows, a plain
+        # iterative radix-2 NTT on 4x64-bit CIOS Montgomery limbs, OpenMP over the host cores -- written to be read against the
+        # reference, NOT tuned (no signed digits, no endomorphism, no batched affine additions, no assembly): a production CPU
+        # library is one to two orders of magnitude faster per core.  Inputs are generated BEFORE the clock starts.
+        nn = min(n, 1 << 20)
         s2 = orc.synth_vector(orc.FR, SEED, nn, cores)
         p2 = orc.synth_points(SEED + 7, nn, cores)
         t0 = time.perf_counter()
         orc.msm_fast(s2, p2, cores)
         dt2 = time.perf_counter() - t0
-        cb["cpu_fast"] = {"value": nn / dt2, "unit": "pairs/s", "cores": cores, "what": "oracle Pippenger (orc_msm_fast), 2^%d pairs" % (nn.bit_length() - 1)}
+        cb["cpu_fast"] = {"value": nn / dt2, "unit": "pairs/s", "cores": cores, "value_per_core": nn / dt2 / cores,
+                          "what": "oracle Pippenger (orc_msm_fast: windows x slices over the cores), 2^%d pairs, inputs generated before the clock; "
+                                  "the oracle's un-tuned code, not a CPU library -- do not quote a speed-up from it" % (nn.bit_length() - 1)}
         lgs = 14
         v = orc.synth_vector(orc.FR, SEED + 99, 1 << lgs, cores)
         t0 = time.perf_counter()
         orc.ntt_ref(orc.FR, orc.fr_root(lgs), v)
         dt3 = time.perf_counter() - t0
-        t0 = time.perf_counter()
         vv = orc.synth_vector(orc.FR, SEED + 99, n, cores)
+        t0 = time.perf_counter()
         orc.ntt_fast(orc.FR, orc.fr_root(args.log2n), vv, threads=cores)
         dt4 = time.perf_counter() - t0
         cb["ntt"] = {"value": (1 << lgs) / dt3, "unit": "elems/s", "cores": 1, "kind": "port",
                      "sample": "2^14-point oracle orc_ntt_ref (literal ntt.rs:7-48, one pow per output per level; O(n log^2 n), so larger n is slower per element)",
-                     "cpu_fast": {"value": n / dt4, "unit": "elems/s", "cores": cores, "what": "oracle iterative NTT incl. input generation, 2^%d" % args.log2n}}
+                     "cpu_fast": {"value": n / dt4, "unit": "elems/s", "cores": cores, "value_per_core": n / dt4 / cores,
+                                  "what": "oracle iterative radix-2 NTT (orc_ntt_fast), 2^%d points, input generated before the clock; un-tuned "
+                                          "checker code (its stages parallelise poorly beyond a few cores)" % args.log2n}}
         out["cpu_baseline"] = cb
     elif rank == 0:
         out["cpu_baseline"] = None

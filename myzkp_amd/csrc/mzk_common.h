@@ -135,17 +135,27 @@ int kzg_batch_open_dev(const void* d_coef, size_t n, const uint64_t* us_host, si
 
 enum { MSM_PTS_PLAIN = 0, MSM_PTS_MONT = 1, MSM_PTS_TABLES = 2 };
 // Fixed-base window tables: c-bit signed windows, 254 / c + 1 of them.  point_kind carries c in bits 8..15
-// (MSM_PTS_TABLES alone = 16).  The default is 16 bits at every size: wider windows (fewer additions per pair, more
-// buckets) were measured and lose -- 2^24 pairs: c = 16 25.7 ms, 18 28.5, 20 28.2, 22 32.8 (tools/timing/window_sweep.py);
-// the sort grows with the bucket count and the accumulate kernel gains nothing (shorter bucket runs, more flushes).
-// Other widths stay selectable through mzk_srs_from_device_ex for tuning and tests.
+// (MSM_PTS_TABLES alone = 16).  Width by SRS size, from the sweep of round 3 (tools/timing/window_sweep.py,
+// profiles/r03b_window_sweep.txt; one box, ms per commit at c = 16 / 17 / 19 / 20):
+//   2^17  0.54 / 0.57 / 0.89 / 0.80      2^20  1.67 / 1.63 / 2.24 / 1.78      2^22   6.46 /  6.12 /  6.98 / 5.85
+//   2^18  0.73 / 0.74 / 1.00 / 0.93      2^21  3.28 / 2.94 / 3.83 / 3.20      2^24  24.38 / 23.00 / 25.01 /  --
+//   2^19  1.01 / 0.99 / 1.37 / 1.17
+// 17 bits = 15 tables (one accumulation fewer per pair, one table less to hold) with 2^16 buckets wins from 2^19 points on;
+// wider windows lose what they save in the accumulation to the sort and to the bucket reduction (2^19 buckets at c = 20:
+// reduce 0.42 instead of 0.25 ms) except at exactly 2^22.  Widths whose top window is nearly empty are pathological for the
+// merged layout: 254 = 14 * 18 + 2 = 18 * 14 + 2, so at c = 18 (and 14, 21) a quarter of all top-window digits land in each of
+// four buckets, 4096 segment partials apiece at 2^20 -- 0.45 ms of heavy-bucket combine at every size.
+// Other widths stay selectable through mzk_srs_from_device_ex for tuning and tests (BASELINE configs[2] names 16 bits:
+// bench.py reports that width as its own leg).
 static inline int msm_table_windows(int c) { return 254 / c + 1; }
 // Small SRS (the reference's actual sizes: a few thousand powers at most) take the three-launch path of mzk_msm.hip; with
 // tables there is no window Horner either (its ~120 serial doublings are the latency floor of a small generic MSM), so
 // they get narrow windows: 8 bits = 32 tables x 128 buckets up to 1024 points, 10 bits = 26 tables x 512 buckets below 4096.
 // 4096 .. 2^14 points: 13-bit windows (20 tables, 4096 buckets) through the general pipeline: 0.49 ms per commit at 2^12 and
 // 2^13 against 0.74 / 0.83 ms without tables (tools/timing/window_sweep.py 12,13 12,13,14,16).
-static inline int msm_srs_window_bits(size_t n) { return n <= 1024 ? 8 : (n <= 4096 ? 10 : (n < ((size_t)1 << 14) ? 13 : 16)); }
+static inline int msm_srs_window_bits(size_t n) {
+  return n <= 1024 ? 8 : (n <= 4096 ? 10 : (n < ((size_t)1 << 14) ? 13 : (n < ((size_t)1 << 19) ? 16 : 17)));
+}
 static inline bool msm_srs_default_tables(size_t n) { return n > 0; }
 #define MSM_PTS_TABLES_C(c) (MSM_PTS_TABLES | ((c) << 8))
 int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int point_kind, size_t table_stride, void* d_out,

@@ -842,8 +842,11 @@ static void jac_store_affine(const fld_t* f, u64* xy, const jac_t* p) {
   f_mmul(f, y, p->Y, zi2);
   f_frommont(f, xy, x); f_frommont(f, xy + 4, y);
 }
-/* Pippenger bucket MSM, unsigned c-bit windows, threads over windows.  Same function as
- * orc_msm_ref. */
+/* Pippenger bucket MSM, unsigned c-bit windows.  Same function as orc_msm_ref.
+ * Threads: task (w, s) = window w over slice s of the pairs, each with its own bucket array (round 3: threads over windows
+ * alone left all but `nwin` cores of the GPU box idle; this is still the oracle's plain, un-tuned code -- general Jacobian
+ * additions, no signed digits, no endomorphism -- only spread over the cores), then the slices' bucket arrays are summed
+ * per window and each window takes its running sum. */
 int orc_msm_fast(const u64* scalars, const u64* points_xy, size_t n, u64* out_xy, int nthreads) {
   const fld_t* f = fld_of(FID_FQ);
   const fld_t* fr = fld_of(FID_FR);
@@ -852,6 +855,10 @@ int orc_msm_fast(const u64* scalars, const u64* points_xy, size_t n, u64* out_xy
   if (c < 4) c = 4;
   const int nwin = (254 + c - 1) / c;
   const size_t nb = ((size_t)1 << c) - 1;
+  int S = nthreads / nwin;                         /* slices per window */
+  if (S < 1) S = 1;
+  if (S > 16) S = 16;                              /* 16 x 16 bucket arrays of 6 MiB at c = 16 */
+  while (S > 1 && n / (size_t)S < 2 * nb) S--;     /* a slice should at least fill its buckets */
   u64* pm = malloc(64 * (n ? n : 1));
   u64* sc = malloc(32 * (n ? n : 1));
   unsigned char* isinf = malloc(n ? n : 1);
@@ -864,11 +871,14 @@ int orc_msm_fast(const u64* scalars, const u64* points_xy, size_t n, u64* out_xy
     else memcpy(sc + 4 * i, scalars + 4 * i, 32);
   }
   jac_t* wsum = malloc(sizeof(jac_t) * nwin);
+  jac_t* bk_all = malloc(sizeof(jac_t) * nb * (size_t)nwin * (size_t)S);
 #pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
-  for (int w = 0; w < nwin; w++) {
-    jac_t* bk = malloc(sizeof(jac_t) * nb);
+  for (int task = 0; task < nwin * S; task++) {
+    const int w = task / S, sl = task % S;
+    jac_t* bk = bk_all + (size_t)task * nb;
     for (size_t b = 0; b < nb; b++) jac_set_inf(&bk[b]);
-    for (size_t i = 0; i < n; i++) {
+    const size_t lo = n * (size_t)sl / (size_t)S, hi = n * (size_t)(sl + 1) / (size_t)S;
+    for (size_t i = lo; i < hi; i++) {
       if (isinf[i]) continue;
       int bit = w * c;
       u64 d = sc[4 * i + bit / 64] >> (bit % 64);
@@ -879,6 +889,18 @@ int orc_msm_fast(const u64* scalars, const u64* points_xy, size_t n, u64* out_xy
       jac_from_affine(f, &q, pm + 8 * i, pm + 8 * i + 4);
       jac_add(f, &bk[d - 1], &bk[d - 1], &q);
     }
+  }
+  if (S > 1) {                                     /* bucket b of window w: slice 0 += slices 1 .. S-1 */
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (size_t wb = 0; wb < (size_t)nwin * nb; wb++) {
+      const size_t w = wb / nb, b = wb % nb;
+      jac_t* dst = bk_all + (w * (size_t)S) * nb + b;
+      for (int sl = 1; sl < S; sl++) jac_add(f, dst, dst, bk_all + (w * (size_t)S + (size_t)sl) * nb + b);
+    }
+  }
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+  for (int w = 0; w < nwin; w++) {
+    const jac_t* bk = bk_all + ((size_t)w * (size_t)S) * nb;
     jac_t run, acc;
     jac_set_inf(&run); jac_set_inf(&acc);
     for (size_t b = nb; b-- > 0;) {
@@ -886,7 +908,6 @@ int orc_msm_fast(const u64* scalars, const u64* points_xy, size_t n, u64* out_xy
       jac_add(f, &acc, &acc, &run);
     }
     wsum[w] = acc;
-    free(bk);
   }
   jac_t tot;
   jac_set_inf(&tot);
@@ -895,7 +916,7 @@ int orc_msm_fast(const u64* scalars, const u64* points_xy, size_t n, u64* out_xy
     jac_add(f, &tot, &tot, &wsum[w]);
   }
   jac_store_affine(f, out_xy, &tot);
-  free(pm); free(sc); free(isinf); free(wsum);
+  free(pm); free(sc); free(isinf); free(wsum); free(bk_all);
   return 0;
 }
 

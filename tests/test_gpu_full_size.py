@@ -91,6 +91,44 @@ def test_msm_2_24_generic_and_srs_tables_trapdoor_identity(env):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("lg", [20, 24])
+def test_msm_unstructured_points_generic_and_tables_vs_oracle_pippenger(env, lg):
+    """SURVEY 8d configs 3 / 4 on UNSTRUCTURED points: 2^20 and 2^24 try-and-increment hash-to-curve
+    points (mzk_synth_g1_points_dev, the bench's generator; no trapdoor, no closed form), uniform scalars, through the generic
+    GLV layout and through window tables (default width for the size, and BASELINE's 16 bits at 2^20), against the oracle's
+    Pippenger on the same streams regenerated on the CPU."""
+    import os
+    torch, mz, L, dev, st = env
+    n = 1 << lg
+    threads = os.cpu_count() or 8
+    sc = torch.empty(n * 4, dtype=torch.int64, device=dev)
+    pts = torch.empty(n * 8, dtype=torch.int64, device=dev)
+    _ok(L, L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(5200 + lg), ctypes.c_size_t(n), _dp(sc), st))
+    _ok(L, L.mzk_synth_g1_points_dev(ctypes.c_uint64(5300 + lg), ctypes.c_size_t(n), _dp(pts), st))
+    out = torch.zeros(8 * 3, dtype=torch.int64, device=dev)
+    _ok(L, L.mzk_msm_g1_bn254_dev(_dp(sc), _dp(pts), ctypes.c_size_t(n), _dp(out), st))
+    widths = [1] + ([16] if lg == 20 else [])
+    for k, wb in enumerate(widths):
+        h = ctypes.c_void_p()
+        _ok(L, L.mzk_srs_from_device_ex(_dp(pts), ctypes.c_size_t(n), ctypes.c_int(wb), ctypes.byref(h), st))
+        _ok(L, L.mzk_kzg_commit_srs_dev(h, _dp(sc), ctypes.c_size_t(n), _dp(out, 64 * (k + 1)), ctypes.c_int(0), st))
+        torch.cuda.synchronize()
+        L.mzk_srs_free(h)
+        torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    s_cpu = orc.synth_vector(FR, 5200 + lg, n, threads)
+    p_cpu = orc.synth_points(5300 + lg, n, threads)
+    # the device generators are the oracle's streams bit for bit (spot check; the bench checks whole vectors)
+    assert np.array_equal(s_cpu.view(np.int64).reshape(-1)[-4096:], sc[-4096:].cpu().numpy())
+    assert np.array_equal(p_cpu.view(np.int64).reshape(-1)[-4096:], pts[-4096:].cpu().numpy())
+    want = orc.msm_fast(s_cpu, p_cpu, threads)
+    assert _point(mz, out[:8]) == want, "generic MSM on unstructured points != oracle Pippenger"
+    for k, wb in enumerate(widths):
+        assert _point(mz, out[8 * (k + 1):8 * (k + 2)]) == want, "window-table commit (option %d) on unstructured points != oracle Pippenger" % wb
+    del sc, pts
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("fid,nl", [(FR, 4), (M128, 2)])
 def test_ntt_2_24_full_vector_vs_oracle_and_direct_evaluation(env, fid, nl):
     torch, mz, L, dev, st = env

@@ -25,6 +25,21 @@ def test_msm_fast_matches_ref():
         assert orc.msm_fast(s, p) == orc.msm_ref(s, p)
 
 
+def test_msm_fast_sliced_over_many_threads_equals_one_thread_and_trapdoor():
+    """orc_msm_fast splits every window over up to 16 slices of the pairs when it has more threads than windows (the GPU box's
+    256 cores): same point as one thread, and on SRS points [alpha^i]G the closed form [f(alpha)]G (polynomial.rs:156-165)."""
+    n, alpha = 1 << 13, 0x1234567
+    s = orc.synth_vector(FR, 4001, n)
+    powers = orc.to_limbs([pow(alpha, i, orc.P_FR) for i in range(n)], 4)
+    p = orc.fixed_base_batch((1, 2), powers)    # [alpha^i] G (the literal setup_kzg restatement takes a minute at this size)
+    p[77] = 0                                   # a point at infinity in the middle of a slice
+    one = orc.msm_fast(s, p, threads=1)
+    for t in (52, 80, 200):                     # 26 windows at c = 10: 2, 3 and (capped by the slice-size rule) 4 slices each
+        assert orc.msm_fast(s, p, threads=t) == one, t
+    s[77] = 0
+    assert orc.msm_fast(s, p, threads=80) == orc.ec_mul(0, (1, 2), orc.poly_eval(FR, s, alpha))
+
+
 def test_fixed_base_batch_matches_ec_mul():
     s = orc.synth_vector(FR, 5, 16)
     out = orc.arr_to_pts(orc.fixed_base_batch((1, 2), s))

@@ -3,6 +3,7 @@ entry point takes them, ragged batches, empty inputs, special scalars.  A longer
 seeds and sizes): every case prints nothing unless it differs; the summary line counts the cases per entry point.
 
 usage: differential.py [seconds=60] [seed=1]
+tests/test_gpu_fuzz_slice.py runs a 20-second seeded slice of it under `pytest -m gpu` (run(budget, seed)).
 The oracle (tests/orc.py) is the checker, as in tests/."""
 import os, random, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
@@ -12,10 +13,7 @@ import myzkp_amd as mz
 import orc
 from orc import FR, M128
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-rng = random.Random(seed)
-mz.init(0)
+rng = random.Random(1)
 counts, failures = {}, []
 NL = {FR: 4, M128: 2}
 
@@ -231,8 +229,26 @@ def case_coset_divide():
 
 
 CASES = [case_fri_fold, case_kzg_next, case_g2, case_coset_divide, case_ntt, case_ntt_batch, case_lde, case_scale_columns, case_msm, case_merkle, case_poly, case_kzg]
-t0 = time.time()
-while time.time() - t0 < budget:
-    rng.choice(CASES)()
-print("seed %d, %.0f s: %s; %d difference(s)" % (seed, time.time() - t0, ", ".join("%s %d" % kv for kv in sorted(counts.items())), len(failures)), flush=True)
-sys.exit(1 if failures else 0)
+
+
+def run(budget, seed, max_cases=None):
+    """Draw cases for `budget` seconds (or max_cases, whichever comes first) from a generator seeded with `seed`.
+    Returns (counts per entry point, list of differences)."""
+    rng.seed(seed)
+    counts.clear()
+    del failures[:]
+    mz.init(0)
+    t0, done = time.time(), 0
+    while time.time() - t0 < budget and (max_cases is None or done < max_cases):
+        rng.choice(CASES)()
+        done += 1
+    return dict(counts), list(failures)
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0 = time.time()
+    cnt, fails = run(budget, seed)
+    print("seed %d, %.0f s: %s; %d difference(s)" % (seed, time.time() - t0, ", ".join("%s %d" % kv for kv in sorted(cnt.items())), len(fails)), flush=True)
+    sys.exit(1 if fails else 0)
