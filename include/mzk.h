@@ -411,6 +411,12 @@ int mzk_host_field_op(int field_id, int op, const uint64_t* a, const uint64_t* b
  * all-ones, zero and the widest lazy limbs -- and returns the number of differing results (must be 0).
  * field_id may also be MZK_FIELD_FQ. */
 int mzk_selftest_field_asm(int field_id, uint64_t seed, size_t n, uint64_t* mismatches);
+/* Device self-check of the ROW-cooperative group operations behind the MSM tails (myzkp_amd/csrc/mzk_row.h: one point
+ * operation per wave, field elements spread over DPP rows): n pairs of XYZZ points -- independent points, P + P, P + (-P),
+ * infinity on either side -- added and doubled `dbl_reps` times by the row code and by the plain exception-complete formulas
+ * (the group law of curve.rs:44-161), compared as group elements; every record is also checked against the storage bound.
+ * Returns the number of pairs that differ (must be 0). */
+int mzk_selftest_row_ec(uint64_t seed, size_t n, int dbl_reps, uint64_t* mismatches);
 
 /* Deterministic synthetic inputs (bench + tests): bit-identical to the oracle's orc_synth_*. */
 int mzk_synth_field_dev(int field_id, uint64_t seed, size_t n, void* d_out, void* stream);

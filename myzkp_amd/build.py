@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmzk_hip.so")
-SOURCES = ["mzk_api.hip", "mzk_multi.hip", "mzk_io.hip", "mzk_poly.hip", "mzk_ntt.hip", "mzk_msm.hip", "mzk_msm_tail.hip", "mzk_kzg.hip", "mzk_merkle.hip", "mzk_g2.hip", "mzk_selftest.hip"]
+SOURCES = ["mzk_api.hip", "mzk_multi.hip", "mzk_io.hip", "mzk_poly.hip", "mzk_ntt.hip", "mzk_msm.hip", "mzk_msm_tail.hip", "mzk_msm_row.hip", "mzk_kzg.hip", "mzk_merkle.hip", "mzk_g2.hip", "mzk_selftest.hip"]
 import glob
 # every header of csrc/ plus the ABI header: a hand-kept list went stale once (mzk_glv.h)
 HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(ROOT, "include", "mzk.h")]

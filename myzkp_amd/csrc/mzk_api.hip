@@ -1122,6 +1122,12 @@ int mzk_selftest_field_asm(int field_id, uint64_t seed, size_t n, uint64_t* mism
   WsGuard wsg(ctx().stream);
   return selftest_field_asm_impl(field_id, seed, n, mismatches, ctx().stream);
 }
+int mzk_selftest_row_ec(uint64_t seed, size_t n, int dbl_reps, uint64_t* mismatches) {
+  MZK_TRY(ensure_init());
+  if (!mismatches || dbl_reps < 0 || n > ((size_t)1 << 22)) { set_error("selftest_row_ec: bad argument"); return MZK_E_ARG; }
+  WsGuard wsg(ctx().stream);
+  return selftest_row_ec_impl(seed, n, dbl_reps, mismatches, ctx().stream);
+}
 int mzk_synth_g1_points_dev(uint64_t seed, size_t n, void* d_out_xy, void* stream) {
   MZK_TRY(ensure_init());
   WsGuard wsg((hipStream_t)stream);

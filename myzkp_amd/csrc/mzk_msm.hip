@@ -1000,6 +1000,19 @@ __global__ __launch_bounds__(64) void k_small_accumulate(const u32* __restrict__
 // k_window_combine / k_fold_partials live in mzk_msm_tail.hip (compact-code build).
 int launch_window_combine(const u32* wsum, int nwin, int c, int out_xyzz, u32* out, hipStream_t s);
 int launch_fold_partials(const u32* partials, int count, u32* out, hipStream_t s);
+// mzk_msm_row.hip: the same tails on row-cooperative group operations (one point operation per wave)
+int launch_reduce_tail_row(u32* buckets, int lgB, int t_start, int sets, u32* out, int finish_affine, hipStream_t s);
+int launch_window_combine_row(const u32* wsum, int nwin, int c, int out_xyzz, u32* out, hipStream_t s);
+int launch_fold_partials_row(const u32* partials, int count, u32* out, hipStream_t s);
+// MZK_ROW_TAILS=0 selects the DPP-quad tails of round 2 (A/B timing: tools/timing/small_latency.py, time_msm.py)
+static bool row_tails() {
+  static const int v = getenv("MZK_ROW_TAILS") ? atoi(getenv("MZK_ROW_TAILS")) : 1;
+  return v != 0;
+}
+// The single-workgroup tail takes over once a halving step is at most this wide: a dependent launch costs ~6 us whatever runs in
+// it (measured: a step of 1024 additions as one wave each 6.0 us, as DPP quads 6.4 us -- the launch, not the addition), a round
+// of 256 quad additions inside the tail's workgroup 3.6 us, a round of 16 row additions ~1.8 us.
+constexpr size_t ROW_TAIL_MAX_OPS = 256;
 
 // ---- host orchestration -----------------------------------------------------------------------------------
 // d_phi (optional): receives the endomorphism images (beta x, y) of the n points (the generic MSM layout reads them
@@ -1138,14 +1151,17 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     hipLaunchKernelGGL(k_small_accumulate, dim3((unsigned)NB), dim3(64), 0, s, pts, (const u32*)offsets, (const u32*)entries, buckets);
     prof_end(s, MZK_PH_MSM_ACCUMULATE);
     prof_begin(s, MZK_PH_MSM_REDUCE);
+    const bool rows = row_tails();
     if (L.merged) {      // one bucket set: the tail writes the result itself (affine point or the XYZZ partial record)
-      hipLaunchKernelGGL(k_reduce_tail, dim3(1), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, 0, (u32*)d_out, out_partial_xyzz ? 0 : 1);
+      if (rows) MZK_TRY(launch_reduce_tail_row(buckets, sh.lgB, 0, 1, (u32*)d_out, out_partial_xyzz ? 0 : 1, s));
+      else hipLaunchKernelGGL(k_reduce_tail, dim3(1), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, 0, (u32*)d_out, out_partial_xyzz ? 0 : 1);
       prof_end(s, MZK_PH_MSM_REDUCE);
     } else {
-      hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)red_windows), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, 0, wsum, 0);
+      if (rows) MZK_TRY(launch_reduce_tail_row(buckets, sh.lgB, 0, red_windows, wsum, 0, s));
+      else hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)red_windows), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, 0, wsum, 0);
       prof_end(s, MZK_PH_MSM_REDUCE);
       prof_begin(s, MZK_PH_MSM_COMBINE);
-      MZK_TRY(launch_window_combine((const u32*)wsum, red_windows, horner_c, out_partial_xyzz ? 1 : 0, (u32*)d_out, s));
+      MZK_TRY((rows ? launch_window_combine_row : launch_window_combine)((const u32*)wsum, red_windows, horner_c, out_partial_xyzz ? 1 : 0, (u32*)d_out, s));
       prof_end(s, MZK_PH_MSM_COMBINE);
     }
     MZK_HIP(hipGetLastError());
@@ -1262,7 +1278,8 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     hipLaunchKernelGGL(k_seg_accumulate<false>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, pts, offsets, entries, slots, NB, seg);
   prof_end(s, MZK_PH_MSM_ACCUMULATE);
   prof_begin(s, MZK_PH_MSM_SEG_COMBINE);
-  if (NB >= ((size_t)1 << 17))
+  static const int wide_min_log = getenv("MZK_COMBINE_WIDE_MIN_LOG") ? atoi(getenv("MZK_COMBINE_WIDE_MIN_LOG")) : 17;
+  if (NB >= ((size_t)1 << wide_min_log))
     hipLaunchKernelGGL(k_seg_combine_wide, dim3((unsigned)((NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy);
   else
     hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy);
@@ -1274,8 +1291,10 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   // bucket reduction: sum_b (b+1) B_b per bucket set (in-place halving), then the window Horner
   u32* wsum;
   MZK_TRY(ws_get(WS_MSM_OUT, (size_t)MAX_WINDOWS * 128, (void**)&wsum));
+  const bool rows = row_tails();
   int t_start = 0;
-  while (t_start < sh.lgB && ((size_t)(t_start + 1) << (sh.lgB - t_start - 1)) > (size_t)4 * TAIL_QUADS) t_start++;
+  const size_t tail_max = rows ? ROW_TAIL_MAX_OPS : (size_t)4 * TAIL_QUADS;
+  while (t_start < sh.lgB && ((size_t)(t_start + 1) << (sh.lgB - t_start - 1)) > tail_max) t_start++;
   for (int t = 0; t < t_start; t++) {
     const size_t total = (size_t)(t + 1) << (sh.lgB - t - 1);
     if (total * (size_t)red_windows >= ((size_t)1 << 16))
@@ -1284,15 +1303,17 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
       hipLaunchKernelGGL(k_halve_step, dim3((unsigned)((4 * total + 127) / 128), (unsigned)red_windows), dim3(128), 0, s, buckets, sh.lgB, t);
   }
   if (L.merged) {
-    hipLaunchKernelGGL(k_reduce_tail, dim3(1), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, t_start, (u32*)d_out, out_partial_xyzz ? 0 : 1);
+    if (rows) MZK_TRY(launch_reduce_tail_row(buckets, sh.lgB, t_start, 1, (u32*)d_out, out_partial_xyzz ? 0 : 1, s));
+    else hipLaunchKernelGGL(k_reduce_tail, dim3(1), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, t_start, (u32*)d_out, out_partial_xyzz ? 0 : 1);
     MZK_HIP(hipGetLastError());
     prof_end(s, MZK_PH_MSM_REDUCE);
   } else {
-    hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)red_windows), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, t_start, wsum, 0);
+    if (rows) MZK_TRY(launch_reduce_tail_row(buckets, sh.lgB, t_start, red_windows, wsum, 0, s));
+    else hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)red_windows), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, t_start, wsum, 0);
     MZK_HIP(hipGetLastError());
     prof_end(s, MZK_PH_MSM_REDUCE);
     prof_begin(s, MZK_PH_MSM_COMBINE);
-    MZK_TRY(launch_window_combine((const u32*)wsum, red_windows, horner_c, out_partial_xyzz ? 1 : 0, (u32*)d_out, s));
+    MZK_TRY((rows ? launch_window_combine_row : launch_window_combine)((const u32*)wsum, red_windows, horner_c, out_partial_xyzz ? 1 : 0, (u32*)d_out, s));
     prof_end(s, MZK_PH_MSM_COMBINE);
   }
   MZK_HIP(hipGetLastError());
@@ -1301,7 +1322,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
 
 int msm_fold_partials_impl(const void* d_partials, int count, void* d_out_xy, hipStream_t s) {
   if (!d_partials || !d_out_xy || count < 0) { set_error("fold_partials: bad argument"); return MZK_E_ARG; }
-  MZK_TRY(launch_fold_partials((const u32*)d_partials, count, (u32*)d_out_xy, s));
+  MZK_TRY((row_tails() ? launch_fold_partials_row : launch_fold_partials)((const u32*)d_partials, count, (u32*)d_out_xy, s));
   return MZK_OK;
 }
 

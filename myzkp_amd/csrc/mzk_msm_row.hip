@@ -1,0 +1,245 @@
+// mzk_msm_row.hip -- the latency-bound tails of the MSM on ROW-cooperative group operations (mzk_row.h: one point operation
+// per wave, a field element spread over a DPP row): the late halving steps of the bucket reduction, its weighted sum and
+// tree, the window Horner of the generic layout, and the multi-GPU fold of XYZZ partials.  Stands behind the same reference
+// code as mzk_msm.hip (Polynomial::eval_with_powers_on_curve, polynomial.rs:156-165); the early, wide halving steps and
+// everything throughput-bound stay in mzk_msm.hip.  An addition here is ~1.3 us on an idle GPU against ~3.6 us for the DPP-quad
+// form (mzk_coop.h), a doubling ~1.0 against ~2.9 -- and these chains are 30 (merged layout) to 150 (generic) operations long.
+#include "mzk_common.h"
+#include "mzk_ec.h"
+#include "mzk_coop.h"
+#include "mzk_row.h"
+
+namespace mzk {
+
+using rowop::Lane;
+using rowop::Pt;
+
+__device__ __forceinline__ void halve_indices(int lgB, int t, size_t id, size_t* lo, size_t* hi) {
+  const int lgh = lgB - t - 1;
+  const size_t a = id >> lgh, j = id & (((size_t)1 << lgh) - 1);
+  *lo = ((a == 0) ? 0 : ((size_t)1 << (lgB - a))) + j;
+  *hi = *lo + ((size_t)1 << lgh);
+}
+__device__ __forceinline__ void halve_op_row(u32* __restrict__ buf, int lgB, int t, size_t id, const Lane& ln) {
+  size_t lo, hi;
+  halve_indices(lgB, t, id, &lo, &hi);
+  const Pt x = rowop::load(buf + lo * 32, ln), y = rowop::load(buf + hi * 32, ln);
+  rowop::store(buf + lo * 32, rowop::add(x, y, ln), ln);
+}
+__device__ __forceinline__ void halve_op_quad(u32* __restrict__ buf, int lgB, int t, size_t id, int lane) {
+  size_t lo, hi;
+  halve_indices(lgB, t, id, &lo, &hi);
+  const Xyzz x = xyzz_gload_quad(buf, lo, lane), y = xyzz_gload_quad(buf, hi, lane);
+  xyzz_gstore_quad(buf, lo, xyzz_add_quad(x, y, lane), lane);
+}
+
+constexpr int RTAIL_THREADS = 1024;
+constexpr int RTAIL_WAVES = RTAIL_THREADS / 64;
+constexpr int RTAIL_QUADS = RTAIL_THREADS / 4;
+constexpr int RTAIL_ROW_MAX = RTAIL_WAVES;       // a step of at most one round of waves runs on row operations, wider ones on quads
+// Remaining steps t_start .. lgB-1 of a bucket set inside one workgroup, then  buf[0] + sum_j 2^j buf[2^j]  (wave j doubles
+// buf[2^j] j times; tree sum through LDS) and, for a single bucket set, the affine conversion (one safegcd inversion).
+__global__ __launch_bounds__(RTAIL_THREADS) void k_reduce_tail_row(u32* __restrict__ buckets, int lgB, int t_start, u32* __restrict__ out, int finish_affine) {
+  __shared__ __attribute__((aligned(16))) u32 sh[32 * 32];
+  u32* buf = buckets + ((size_t)blockIdx.x << lgB) * 32;
+  const Lane ln = rowop::lane_init();
+  const int wave = threadIdx.x >> 6;
+  for (int t = t_start; t < lgB; t++) {
+    const size_t total = (size_t)(t + 1) << (lgB - t - 1);
+    if (total > RTAIL_ROW_MAX) {
+      for (size_t id = threadIdx.x >> 2; id < total; id += RTAIL_QUADS) halve_op_quad(buf, lgB, t, id, (int)(threadIdx.x & 3));
+    } else {
+      for (size_t id = wave; id < total; id += RTAIL_WAVES) halve_op_row(buf, lgB, t, id, ln);
+    }
+    __syncthreads();
+  }
+  for (int q = wave; q < 32; q += RTAIL_WAVES) {
+    Pt v = rowop::pt_inf();
+    if (q < lgB) {
+      v = rowop::load(buf + ((size_t)1 << q) * 32, ln);
+      for (int d = 0; d < q; d++) v = rowop::dbl(v, ln);
+      if (q == 0) v = rowop::add(v, rowop::load(buf, ln), ln);      // the unweighted sum rides with the term that needs no doubling
+    }
+    rowop::store(sh + q * 32, v, ln);
+  }
+  __syncthreads();
+  for (int off = 16; off >= 1; off >>= 1) {
+    for (int q = wave; q < off; q += RTAIL_WAVES) {
+      const Pt a = rowop::load(sh + q * 32, ln), b = rowop::load(sh + (q + off) * 32, ln);
+      rowop::store(sh + q * 32, rowop::add(a, b, ln), ln);
+    }
+    __syncthreads();
+  }
+  if (finish_affine) {
+    if (threadIdx.x == 0) {
+      u32 wds[16];
+      Affine af;
+      if (xyzz_to_affine<true>(xyzz_load(sh), &af)) affine_store_plain(af, wds);
+      else for (int i = 0; i < 16; i++) wds[i] = 0;
+      for (int i = 0; i < 16; i++) out[i] = wds[i];
+    }
+    return;
+  }
+  if (threadIdx.x < 32) out[(size_t)blockIdx.x * 32 + threadIdx.x] = sh[threadIdx.x];
+}
+
+// total = sum_w 2^(c w) R_w (Horner over the bucket sets of the generic layout: c doublings per window, inherently serial)
+// on ONE wave, then affine or the XYZZ partial record.
+__global__ __launch_bounds__(64) void k_window_combine_row(const u32* __restrict__ wsum, int nwin, int c, int out_xyzz, u32* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) u32 sh[32];
+  const Lane ln = rowop::lane_init();
+  Pt tot = rowop::load(wsum + (size_t)(nwin - 1) * 32, ln);
+  for (int win = nwin - 2; win >= 0; win--) {
+    for (int d = 0; d < c; d++) tot = rowop::dbl(tot, ln);
+    tot = rowop::add(tot, rowop::load(wsum + (size_t)win * 32, ln), ln);
+  }
+  if (out_xyzz) { rowop::store(out, tot, ln); return; }
+  rowop::store(sh, tot, ln);
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  u32 wds[16];
+  Affine af;
+  if (xyzz_to_affine<true>(xyzz_load(sh), &af)) affine_store_plain(af, wds);
+  else for (int i = 0; i < 16; i++) wds[i] = 0;
+  for (int i = 0; i < 16; i++) out[i] = wds[i];
+}
+// fold `count` XYZZ partials (the gathered records of the ranks / contexts) into one affine point
+__global__ __launch_bounds__(64) void k_fold_partials_row(const u32* __restrict__ partials, int count, u32* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) u32 sh[32];
+  const Lane ln = rowop::lane_init();
+  Pt tot = rowop::pt_inf();
+  for (int i = 0; i < count; i++) tot = rowop::add(tot, rowop::load(partials + (size_t)i * 32, ln), ln);
+  rowop::store(sh, tot, ln);
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  u32 wds[16];
+  Affine af;
+  if (xyzz_to_affine<true>(xyzz_load(sh), &af)) affine_store_plain(af, wds);
+  else for (int i = 0; i < 16; i++) wds[i] = 0;
+  for (int i = 0; i < 16; i++) out[i] = wds[i];
+}
+
+int launch_reduce_tail_row(u32* buckets, int lgB, int t_start, int sets, u32* out, int finish_affine, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_tail_row, dim3((unsigned)sets), dim3(RTAIL_THREADS), 0, s, buckets, lgB, t_start, out, finish_affine);
+  return MZK_OK;
+}
+int launch_window_combine_row(const u32* wsum, int nwin, int c, int out_xyzz, u32* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_window_combine_row, dim3(1), dim3(64), 0, s, wsum, nwin, c, out_xyzz, out);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+int launch_fold_partials_row(const u32* partials, int count, u32* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_fold_partials_row, dim3(1), dim3(64), 0, s, partials, count, out);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+
+// ---- self-test: row operations against the plain formulas of mzk_ec.h -----------------------------------------------------
+// Pair i: a = [k_i] of a synthetic point in XYZZ form with a random ZZ, b by case i % 8: an independent point (0..3), the same
+// point in another representation (4: P + P), its negative (5: P + (-P)), infinity on either side (6, 7).  Row kernels write
+// a + b and 2 a as packed records; the checker recomputes both with xyzz_add / xyzz_dbl on one lane and compares as group
+// elements (cross-multiplied coordinates), every record also for the storage bound value < 2.5 p.
+__device__ __forceinline__ u64 st_mix(u64& s) {
+  u64 z = (s += 0x9e3779b97f4a7c15ULL);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ Fq st_rand_fq(u64& s) {
+  u32 w[8];
+  for (int i = 0; i < 4; i++) { const u64 v = st_mix(s); w[2 * i] = (u32)v; w[2 * i + 1] = (u32)(v >> 32); }
+  w[7] &= 0x0fffffffu;                                         // < 2^252 < p
+  return fe_unpack<FqParams>(w);
+}
+__device__ __forceinline__ Xyzz st_rescale(const Affine& p, const Fq& z) {     // (x z^2, y z^3, z^2, z^3)
+  typedef FqParams P;
+  Xyzz r;
+  const Fq z2 = fe_sqr<P>(z), z3 = fe_mul<P>(z2, z);
+  r.X = fe_mul<P>(p.x, z2); r.Y = fe_mul<P>(p.y, z3); r.ZZ = z2; r.ZZZ = z3;
+  return r;
+}
+__global__ __launch_bounds__(128) void k_rowtest_prepare(const u32* __restrict__ pts_mont, size_t n, u64 seed, u32* __restrict__ a_out, u32* __restrict__ b_out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 s = seed ^ (0x51ed27ULL * (i + 1));
+  const Affine p = affine_load_mont(pts_mont + i * 16), q = affine_load_mont(pts_mont + ((i * 7 + 3) % n) * 16);
+  Fq z1 = st_rand_fq(s), z2 = st_rand_fq(s);
+  z1.l[0] |= 1; z2.l[0] |= 1;                                  // non-zero
+  Xyzz a = st_rescale(p, z1), b;
+  switch (i & 7) {
+    case 4: b = st_rescale(p, z2); break;
+    case 5: b = st_rescale(affine_neg(p), z2); break;
+    case 6: b = xyzz_inf(); break;
+    case 7: b = a; a = xyzz_inf(); break;
+    default: b = st_rescale(q, z2); break;
+  }
+  u32 w[32];
+  xyzz_store(a, w);
+  for (int k = 0; k < 32; k++) a_out[i * 32 + k] = w[k];
+  xyzz_store(b, w);
+  for (int k = 0; k < 32; k++) b_out[i * 32 + k] = w[k];
+}
+__global__ __launch_bounds__(256) void k_rowtest_run(const u32* __restrict__ a, const u32* __restrict__ b, size_t n, int dbl_reps, u32* __restrict__ sum_out,
+                                                      u32* __restrict__ dbl_out) {
+  const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const Lane ln = rowop::lane_init();
+  const Pt x = rowop::load(a + i * 32, ln), y = rowop::load(b + i * 32, ln);
+  rowop::store(sum_out + i * 32, rowop::add(x, y, ln), ln);
+  Pt d = x;
+  for (int r = 0; r < dbl_reps; r++) d = rowop::dbl(d, ln);
+  rowop::store(dbl_out + i * 32, d, ln);
+}
+__device__ __forceinline__ bool st_same_point(const Xyzz& u, const Xyzz& v) {
+  typedef FqParams P;
+  const bool ui = xyzz_is_inf(u), vi = xyzz_is_inf(v);
+  if (ui || vi) return ui == vi;
+  return fe_eq_canon<P>(fe_reduce<P>(fe_mul<P>(u.X, v.ZZ)), fe_reduce<P>(fe_mul<P>(v.X, u.ZZ))) &&
+         fe_eq_canon<P>(fe_reduce<P>(fe_mul<P>(u.Y, v.ZZZ)), fe_reduce<P>(fe_mul<P>(v.Y, u.ZZZ)));
+}
+__device__ __forceinline__ bool st_record_ok(const u32* w) {            // every coordinate below 2.5 p (top word of 2.5 p: 0x78fac41e)
+  for (int c = 0; c < 4; c++) if (w[8 * c + 7] >= 0x78fac41eu) return false;
+  return true;
+}
+__global__ __launch_bounds__(128) void k_rowtest_check(const u32* __restrict__ a, const u32* __restrict__ b, size_t n, int dbl_reps, const u32* __restrict__ sum_out,
+                                                        const u32* __restrict__ dbl_out, unsigned long long* __restrict__ mismatches) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 w[32];
+  for (int k = 0; k < 32; k++) w[k] = a[i * 32 + k];
+  const Xyzz x = xyzz_load(w);
+  for (int k = 0; k < 32; k++) w[k] = b[i * 32 + k];
+  const Xyzz y = xyzz_load(w);
+  Xyzz d = x;
+  for (int r = 0; r < dbl_reps; r++) d = xyzz_dbl(d);
+  for (int k = 0; k < 32; k++) w[k] = sum_out[i * 32 + k];
+  bool ok = st_record_ok(w) && st_same_point(xyzz_load(w), xyzz_add(x, y));
+  for (int k = 0; k < 32; k++) w[k] = dbl_out[i * 32 + k];
+  ok = ok && st_record_ok(w) && st_same_point(xyzz_load(w), d);
+  if (!ok) atomicAdd(mismatches, 1ull);
+}
+int synth_g1_impl(uint64_t seed, size_t n, void* d_out, hipStream_t s);
+int selftest_row_ec_impl(uint64_t seed, size_t n, int dbl_reps, uint64_t* mismatches_host, hipStream_t s) {
+  if (n == 0) { *mismatches_host = 0; return MZK_OK; }
+  void *plain, *mont, *a, *b, *so, *dd, *cnt;
+  MZK_TRY(ws_get(WS_MISC_A, n * 64, &plain));
+  MZK_TRY(ws_get(WS_MISC_B, n * 64, &mont));
+  MZK_TRY(ws_get(WS_MISC_C, n * 128, &a));
+  MZK_TRY(ws_get(WS_MISC_D, n * 128, &b));
+  MZK_TRY(ws_get(WS_MISC_E, n * 128, &so));
+  MZK_TRY(ws_get(WS_MISC_F, n * 128 + 64, &dd));
+  cnt = (char*)dd + n * 128;
+  MZK_TRY(synth_g1_impl(seed, n, plain, s));
+  MZK_TRY(msm_prepare_points(plain, n, mont, nullptr, s));
+  MZK_HIP(hipMemsetAsync(cnt, 0, 8, s));
+  hipLaunchKernelGGL(k_rowtest_prepare, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, (const u32*)mont, n, (u64)seed, (u32*)a, (u32*)b);
+  hipLaunchKernelGGL(k_rowtest_run, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, (const u32*)a, (const u32*)b, n, dbl_reps, (u32*)so, (u32*)dd);
+  hipLaunchKernelGGL(k_rowtest_check, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, (const u32*)a, (const u32*)b, n, dbl_reps, (const u32*)so, (const u32*)dd,
+                     (unsigned long long*)cnt);
+  MZK_HIP(hipGetLastError());
+  MZK_HIP(hipMemcpyAsync(mismatches_host, cnt, 8, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  return MZK_OK;
+}
+
+}  // namespace mzk

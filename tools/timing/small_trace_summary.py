@@ -7,7 +7,7 @@ seq=[]; cur=[]
 for r in rows:
     nm = r["Kernel_Name"].replace("mzk::","").replace("void ","").split("(")[0]
     cur.append((nm, int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Grid_Size_X"], r["Workgroup_Size_X"]))
-    if nm == "k_reduce_tail": seq.append(cur); cur=[]
+    if nm in ("k_reduce_tail", "k_reduce_tail_row"): seq.append(cur); cur=[]
 for idx in (15, 35):
     if idx < len(seq):
         c = seq[idx]; t0 = c[0][1]
