@@ -563,6 +563,44 @@ def main():
             res["error"] = str(ex)[:300]
         return res
     ntt_batched = run_ntt_batched()
+
+    def run_pcie_inclusive():
+        """The host-buffer entry points a MyZKP caller binds first (Vec<u64> limbs in, point / vector
+        out), timed with the transfers inside: pageable host memory, plain hipMemcpyAsync (already 56 GB/s either way on this runtime;
+        the points of the generic MSM travel on a side stream under the digit sort -- profiles/r03h_pcie_probe.txt).
+        Reported beside `value`, never as `value` (inputs of `value` are resident in HBM)."""
+        if world != 1 or args.no_two_in_flight:
+            return None
+        res = {}
+        try:
+            hs, hp = scalars.cpu().numpy().view(np.uint64).reshape(-1, 4).copy(), points.cpu().numpy().view(np.uint64).reshape(-1, 8).copy()
+            hv = ntt_in.cpu().numpy().view(np.uint64).reshape(-1, 4).copy()
+            wr = mz.root_of_unity(mz.FIELD_FR, args.log2n)
+            hsrs = mz.Srs.__new__(mz.Srs)
+            hsrs._h, hsrs.n = srs._h, n          # the bench's device-resident handle, host coefficients
+            hout = np.zeros_like(hv)             # the caller's output vector, allocated once (a fresh one per call costs page faults)
+            wl = mz.to_limbs([wr], 4)
+
+            def ntt_host():
+                check(L.mzk_ntt(mz.FIELD_FR, wl.ctypes.data_as(ctypes.c_void_p), hv.ctypes.data_as(ctypes.c_void_p), hout.ctypes.data_as(ctypes.c_void_p),
+                                ctypes.c_size_t(n), 0))
+            legs = (("msm_g1_bn254_host_buffers", lambda: mz.msm_g1(hs, hp), n, "pairs/s", 96 * n),
+                    ("kzg_commit_srs_host_scalars", lambda: hsrs.commit(hs), n, "pairs/s", 32 * n),
+                    ("ntt_host_buffers", ntt_host, n, "elems/s", 64 * n))
+            for name, fn, units, unit, nbytes in legs:
+                fn(); fn()
+                reps = 5
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    r = fn()
+                dtp = (time.perf_counter() - t0) / reps
+                res[name] = {"ms_per_call": dtp * 1e3, "value": units / dtp, "unit": unit, "bytes_over_pcie": nbytes}
+            hsrs._h = None                         # not ours to free
+            res["msm_matches_resident_result"] = bool(mz.msm_g1(hs, hp) == mz.array_to_points(result.cpu().numpy().view(np.uint64))[0]) if world == 1 else None
+        except Exception as ex:
+            res["error"] = str(ex)[:300]
+        return res
+    pcie_inclusive = run_pcie_inclusive()
     progress("timed legs done")
     msm_ms = msm_dt / K * 1e3
     ntt_ms = ntt_dt / K * 1e3
@@ -652,6 +690,7 @@ def main():
         "kzg_commit_16_bit_windows": width16 if width16 is not None else ({"note": "16 bits is the default width at this size: see `value`"} if srs_window_bits == 16 else None),
         "msm_no_tables_in_flight": generic4,
         "ntt_batched": ntt_batched,
+        "pcie_inclusive": pcie_inclusive,
         "msm_generic": {"metric": "G1 MSM pairs/sec, arbitrary points every call (no per-point-set precomputation; 16 bucket sets + window Horner)",
                         "value": msm_rate, "unit": "pairs/s", "ms_per_step": msm_ms, "phases": msm_ph, "roofline": roof},
         "ntt": {"metric": "NTT elems/sec", "value": ntt_rate, "unit": "elems/s", "ms_per_step": ntt_ms, "field": "BN254 Fr",

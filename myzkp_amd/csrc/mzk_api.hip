@@ -454,9 +454,29 @@ int mzk_root_of_unity(int field_id, unsigned log2_n, uint64_t* out) {
 }
 
 // ---- host-buffer NTT family ---------------------------------------------------------------------------
+// host buffer -> workspace slot.  A plain hipMemcpyAsync from pageable memory: on this runtime (ROCm 7.2) it already moves 56 GB/s
+// in either direction, the same as a DMA from pinned memory (tools/timing/pcie_probe.py, profiles/r03h_pcie_probe.txt); a pinned
+// staging ring with copy threads was built in round 3 and measured SLOWER (generic MSM 4.5 vs 3.7 ms, NTT 4.8 vs 3.6 ms), so
+// what the host-buffer entry points can gain is overlap, not a faster copy (see mzk_msm_g1_bn254).
 static int stage_in(WsSlot slot, const void* host, size_t bytes, void** dev, hipStream_t s) {
   MZK_TRY(ws_get(slot, bytes ? bytes : 16, dev));
   if (bytes) MZK_HIP(hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, s));
+  return MZK_OK;
+}
+// device result -> host buffer; returns with the host buffer complete
+static int stage_out(void* host, const void* dev, size_t bytes, hipStream_t s) {
+  if (bytes) MZK_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  return MZK_OK;
+}
+// a second stream of the current context for transfers that should run beside its kernels, with the two events that fork it
+// from / join it to the context's stream (created on first use; shared with mzk_ntt_multi's exchange, which never overlaps a call)
+static int side_stream(hipStream_t* side, hipEvent_t* fork, hipEvent_t* join) {
+  Context& c = ctx();
+  if (!c.xstream[1]) MZK_HIP(hipStreamCreateWithFlags(&c.xstream[1], hipStreamNonBlocking));
+  if (!c.xready) MZK_HIP(hipEventCreateWithFlags(&c.xready, hipEventDisableTiming));
+  if (!c.xdone[1]) MZK_HIP(hipEventCreateWithFlags(&c.xdone[1], hipEventDisableTiming));
+  *side = c.xstream[1]; *fork = c.xready; *join = c.xdone[1];
   return MZK_OK;
 }
 
@@ -472,8 +492,7 @@ int mzk_ntt(int field_id, const uint64_t* root, const uint64_t* in, uint64_t* ou
   MZK_TRY(stage_in(WS_NTT_IO_A, in, bytes, &d_in, s));
   MZK_TRY(ws_get(WS_NTT_IO_B, bytes, &d_out));
   MZK_TRY(ntt_dev_impl(field_id, root, d_in, d_out, n, inverse, nullptr, s));
-  MZK_HIP(hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(stage_out(out, d_out, bytes, s));
   return MZK_OK;
 }
 
@@ -503,8 +522,7 @@ int mzk_coset_lde_batch(int field_id, const uint64_t* coefs, size_t n_coef, cons
   MZK_TRY(stage_in(WS_MISC_A, coefs, batch * n_coef * esz, &d_coef, s));
   MZK_TRY(ws_get(WS_NTT_IO_B, batch * order * esz, &d_out));
   MZK_TRY(coset_lde_dev_impl(field_id, d_coef, n_coef, offset, generator, d_out, order, s, batch));
-  MZK_HIP(hipMemcpyAsync(out, d_out, batch * order * esz, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(stage_out(out, d_out, batch * order * esz, s));
   return MZK_OK;
 }
 int mzk_ntt_batch_dev(int field_id, const uint64_t* root_host, const void* d_in, void* d_out, size_t n, size_t batch, int inverse, void* stream) {
@@ -523,8 +541,7 @@ int mzk_ntt_batch(int field_id, const uint64_t* root, const uint64_t* in, uint64
   void* d;
   MZK_TRY(stage_in(WS_NTT_IO_A, in, bytes, &d, s));
   MZK_TRY(ntt_batch_dev_impl(field_id, root, d, d, n, batch, inverse, s));
-  MZK_HIP(hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(stage_out(out, d, bytes, s));
   return MZK_OK;
 }
 
@@ -542,8 +559,7 @@ int mzk_coset_lde(int field_id, const uint64_t* coef, size_t n_coef, const uint6
   MZK_TRY(stage_in(WS_MISC_A, coef, n_coef * esz, &d_coef, s));
   MZK_TRY(ws_get(WS_NTT_IO_B, order * esz, &d_out));
   MZK_TRY(coset_lde_dev_impl(field_id, d_coef, n_coef, offset, generator, d_out, order, s));
-  MZK_HIP(hipMemcpyAsync(out, d_out, order * esz, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(stage_out(out, d_out, order * esz, s));
   return MZK_OK;
 }
 
@@ -569,8 +585,7 @@ int mzk_poly_scale(int field_id, const uint64_t* coef, size_t n, const uint64_t*
   void* d;
   MZK_TRY(stage_in(WS_MISC_A, coef, n * esz, &d, s));
   MZK_TRY(poly_scale_dev_impl(field_id, d, n, ratio, lead, d, s));
-  MZK_HIP(hipMemcpyAsync(out, d, n * esz, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(stage_out(out, d, n * esz, s));
   return MZK_OK;
 }
 int mzk_poly_scale_dev(int field_id, const void* d_coef, size_t n, const uint64_t* ratio_host, const uint64_t* lead_host, void* d_out, void* stream) {
@@ -760,8 +775,7 @@ int mzk_fast_coset_divide(int field_id, const uint64_t* lhs, size_t ll, const ui
   MZK_TRY(stage_in(WS_MISC_D, rhs, tr * esz, &d_r, s));
   MZK_TRY(ws_get(WS_NTT_IO_B, ql * esz, &d_o));
   MZK_TRY(coset_divide_dev_impl(field_id, d_l, tl, d_r, tr, offset, r, order, d_o, s));
-  MZK_HIP(hipMemcpyAsync(out, d_o, ql * esz, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(stage_out(out, d_o, ql * esz, s));
   *out_len = ql;
   return MZK_OK;
 }
@@ -786,10 +800,24 @@ int mzk_msm_g1_bn254(const uint64_t* scalars, const uint64_t* points_xy, size_t 
   hipStream_t s = ctx().stream;
   WsGuard wsg(s);
   void *d_s, *d_p, *d_o;
+  // The points (64 n bytes) travel on a side stream while the context's stream already sorts the scalars' digits: the side
+  // stream starts behind everything enqueued so far (the previous call may still read the points' slot), the kernels that read
+  // the points wait for it (msm_dev_impl calls points_ready after the sort is enqueued).
+  hipStream_t side;
+  hipEvent_t fork, join;
+  MZK_TRY(side_stream(&side, &fork, &join));
+  MZK_TRY(ws_get(WS_MISC_A, n ? n * 64 : 16, &d_p));
+  MZK_HIP(hipEventRecord(fork, s));
+  MZK_HIP(hipStreamWaitEvent(side, fork, 0));
   MZK_TRY(stage_in(WS_MSM_SCALARS, scalars, n * 32, &d_s, s));
-  MZK_TRY(stage_in(WS_MISC_A, points_xy, n * 64, &d_p, s));
   MZK_TRY(ws_get(WS_MISC_B, 256, &d_o));
-  MZK_TRY(msm_dev_impl(d_s, d_p, n, MSM_PTS_PLAIN, 0, d_o, false, s));
+  const std::function<int()> points_ready = [&]() -> int {
+    if (n) MZK_HIP(hipMemcpyAsync(d_p, points_xy, n * 64, hipMemcpyHostToDevice, side));
+    MZK_HIP(hipEventRecord(join, side));
+    MZK_HIP(hipStreamWaitEvent(s, join, 0));
+    return MZK_OK;
+  };
+  MZK_TRY(msm_dev_impl(d_s, d_p, n, MSM_PTS_PLAIN, 0, d_o, false, s, &points_ready));
   MZK_HIP(hipMemcpyAsync(out_xy, d_o, 64, hipMemcpyDeviceToHost, s));
   MZK_HIP(hipStreamSynchronize(s));
   return MZK_OK;
@@ -1041,8 +1069,7 @@ int mzk_fri_fold(int field_id, const uint64_t* codeword, size_t n, const uint64_
   MZK_TRY(stage_in(WS_NTT_IO_A, codeword, n * esz, &d_in, s));
   MZK_TRY(ws_get(WS_NTT_IO_B, (n / 2) * esz, &d_out));
   MZK_TRY(fri_fold_dev_impl(field_id, d_in, n, alpha, offset, omega, d_out, s));
-  MZK_HIP(hipMemcpyAsync(out, d_out, (n / 2) * esz, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(stage_out(out, d_out, (n / 2) * esz, s));
   return MZK_OK;
 }
 
@@ -1087,8 +1114,7 @@ int mzk_kzg_setup_g1(const uint64_t alpha[4], const uint64_t g1_xy[8], size_t ma
   void* d_p;
   MZK_TRY(ws_get(WS_MSM_POINTS, count * 64, &d_p));
   MZK_TRY(kzg_setup_g1_dev(alpha, g1_xy, 0, count, d_p, s));
-  MZK_HIP(hipMemcpyAsync(powers_xy, d_p, count * 64, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(stage_out(powers_xy, d_p, count * 64, s));
   return MZK_OK;
 }
 

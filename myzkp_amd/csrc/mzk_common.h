@@ -6,6 +6,7 @@
 #include <stddef.h>
 #include <stdio.h>
 #include <string.h>
+#include <functional>
 #include <string>
 #include <vector>
 #include "../../include/mzk.h"
@@ -159,7 +160,8 @@ static inline int msm_srs_window_bits(size_t n) {
 static inline bool msm_srs_default_tables(size_t n) { return n > 0; }
 #define MSM_PTS_TABLES_C(c) (MSM_PTS_TABLES | ((c) << 8))
 int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int point_kind, size_t table_stride, void* d_out,
-                 bool out_partial_xyzz, hipStream_t s);
+                 bool out_partial_xyzz, hipStream_t s, const std::function<int()>* points_ready = nullptr);
+
 int xyzz_batch_to_affine(const void* d_xyzz, size_t count, void* d_out, bool out_mont, hipStream_t s);
 int msm_build_tables(const void* d_points_mont, size_t n, void* d_tables, int window_bits, hipStream_t s);
 int msm_fold_partials_impl(const void* d_partials, int count, void* d_out_xy, hipStream_t s);

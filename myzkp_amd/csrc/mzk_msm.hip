@@ -1103,11 +1103,15 @@ static int sort_records(const SortArgs& a, hipStream_t s) {
 
 // point_kind: 0 = affine canonical (ABI form), 1 = affine Montgomery (prepared), 2 = SRS window tables
 // (SRS_WINDOWS x table_stride affine Montgomery points: all windows share one bucket set, no Horner).
+// points_ready (optional, plain points only): called once, after the digit sort has been enqueued and before the first kernel
+// that reads the points -- the host-buffer entry point stages the points onto the device there, so that the transfer of the
+// 64 n bytes of points runs under the sort of the scalars instead of in front of it.
 int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int point_kind, size_t table_stride, void* d_out,
-                 bool out_partial_xyzz, hipStream_t s) {
+                 bool out_partial_xyzz, hipStream_t s, const std::function<int()>* points_ready) {
   if (!d_out || ((!d_scalars || !d_points) && n)) { set_error("msm: null pointer"); return MZK_E_ARG; }
   if (n > ((size_t)1 << 27)) { set_error("msm: n > 2^27 not supported"); return MZK_E_ARG; }
   if (n == 0) {  // empty polynomial -> point at infinity (polynomial.rs:160)
+    if (points_ready) MZK_TRY((*points_ready)());
     MZK_HIP(hipMemsetAsync(d_out, 0, out_partial_xyzz ? 128 : 64, s));
     return MZK_OK;
   }
@@ -1128,14 +1132,22 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   const int red_windows = L.merged ? 1 : sh.nwin;   // bucket sets to reduce
   const int horner_c = L.merged ? 0 : sh.c;
   const u32* pts = (const u32*)d_points;
+  void* pm = nullptr;
   if (point_kind == 0) {
-    void* pm;
     MZK_TRY(ws_get(WS_MSM_POINTS, 2 * n * 64, &pm));
+    pts = (const u32*)pm;
+  }
+  bool prepared = false;
+  auto prepare = [&]() -> int {          // Montgomery form + endomorphism images of plain points; once, before their first reader
+    if (prepared) return MZK_OK;
+    prepared = true;
+    if (points_ready) MZK_TRY((*points_ready)());
+    if (point_kind != 0) return MZK_OK;
     prof_begin(s, MZK_PH_MSM_PREPARE);
     MZK_TRY(msm_prepare_points(d_points, n, pm, (u32*)pm + n * 16, s));
     prof_end(s, MZK_PH_MSM_PREPARE);
-    pts = (const u32*)pm;
-  }
+    return MZK_OK;
+  };
   const size_t E_max = n * (size_t)(L.glv ? 2 * sh.nwin : sh.nwin);
   // (the generic layout has twice the entries per pair: measured at 4096 pairs it is 5 % slower on this path, the commit 14 % faster)
   if (n < (L.merged ? SMALL_MAX_N : SMALL_MAX_N - 1) && NB <= SMALL_MAX_BUCKETS) {
@@ -1144,6 +1156,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     MZK_TRY(ws_get(WS_MSM_ENTRIES, E_max * 4, (void**)&entries));
     MZK_TRY(ws_get(WS_MSM_BUCKETS, NB * 128, (void**)&buckets));
     MZK_TRY(ws_get(WS_MSM_OUT, (size_t)MAX_WINDOWS * 128, (void**)&wsum));
+    MZK_TRY(prepare());
     prof_begin(s, MZK_PH_MSM_SORT);
     hipLaunchKernelGGL(k_small_sort, dim3(1), dim3(SMALL_SORT_THREADS), (NB + SMALL_SORT_THREADS) * 4, s, (const u32*)d_scalars, n, L, (int)NB, offsets, entries);
     prof_end(s, MZK_PH_MSM_SORT);
@@ -1270,6 +1283,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   }
   MZK_HIP(hipGetLastError());
   prof_end(s, MZK_PH_MSM_SORT);
+  MZK_TRY(prepare());
   prof_begin(s, MZK_PH_MSM_ACCUMULATE);
   // the true entry count lives in offsets[NB] on the device; lanes past it exit (E_max bounds it)
   if (acc_prefetch)
