@@ -275,7 +275,7 @@ def main():
     parity = {}
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
-    threads = max(1, (os.cpu_count() or 1) // world)
+    threads = max(1, orc.usable_threads(64) // world)     # the GPU boxes report 256 CPUs and schedule ~16: more threads are slower
     s_cpu = orc.synth_vector(orc.FR, SEED + 1000003 * rank, n, threads)
     p_cpu = orc.synth_points(SEED + 7 + 1000003 * rank, n, threads)
     ok_inputs = bool(np.array_equal(s_cpu.view(np.int64).reshape(-1), scalars.cpu().numpy()) and
@@ -930,7 +930,7 @@ def main():
             # trapdoor identity: the commitment must be [f(alpha)] G for f = the concatenation of all ranks' scalars
             got2 = mz.array_to_points(res2.cpu().numpy().view(np.uint64))[0]
             if rank == 0:
-                cores = os.cpu_count() or 1
+                cores = orc.usable_threads(64)
                 fa, apow = 0, 1
                 for r in range(world):
                     rlo, rhi = sharded.shard_range(tot, r, world)
@@ -1023,7 +1023,7 @@ def main():
                 mz.ctx_select(r)
                 check(L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(SEED + 7000 + r), ctypes.c_size_t(hi_r - lo_r), dptr(t), None))
                 shards.append(t)
-                sr = orc.synth_vector(orc.FR, SEED + 7000 + r, hi_r - lo_r, os.cpu_count() or 1)
+                sr = orc.synth_vector(orc.FR, SEED + 7000 + r, hi_r - lo_r, orc.usable_threads(64))
                 fa = (fa + orc.poly_eval(orc.FR, sr, alpha) * pow(alpha, lo_r, orc.P_FR)) % orc.P_FR
             mz.ctx_select(0)
             for o in set(ords):
@@ -1049,7 +1049,7 @@ def main():
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only, bounded sample)
     if rank == 0 and world == 1 and not args.skip_cpu:
-        cores = os.cpu_count() or 1
+        cores = orc.usable_threads(64)       # threads the oracle's multi-threaded legs run on (cgroup quota / affinity, capped)
         sample = 1 << 11
         s_cpu = orc.synth_vector(orc.FR, SEED, sample, cores)
         p_cpu = orc.synth_points(SEED + 7, sample, cores)
@@ -1086,6 +1086,7 @@ def main():
                      "cpu_fast": {"value": n / dt4, "unit": "elems/s", "cores": cores, "value_per_core": n / dt4 / cores,
                                   "what": "oracle iterative radix-2 NTT (orc_ntt_fast), 2^%d points, input generated before the clock; un-tuned "
                                           "checker code (its stages parallelise poorly beyond a few cores)" % args.log2n}}
+        cb["host"] = {"os_cpu_count": os.cpu_count(), "threads_used_by_cpu_fast": cores}
         out["cpu_baseline"] = cb
     elif rank == 0:
         out["cpu_baseline"] = None

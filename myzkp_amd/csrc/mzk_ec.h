@@ -122,6 +122,39 @@ template <template <class> class A> MZK_HD Xyzz xyzz_madd_with(const Xyzz& a, co
 }
 MZK_HD Xyzz xyzz_madd(const Xyzz& a, const Affine& q) { return xyzz_madd_with<FeCpp>(a, q); }
 
+// acc + (neg ? -q : q): the signed-digit entries of the bucket method.  The sign is applied to S2 = y2 ZZZ1 after the product
+// (limb-wise 4p - S2 and a select: 18 instructions) instead of to y2 before it (canonical p - y: a carry chain, a zero test
+// and two selects: ~55); y2 enters the formula nowhere else.  Same exception handling as xyzz_madd_with.
+template <template <class> class A> MZK_HD Xyzz xyzz_madd_signed_with(const Xyzz& a, const Affine& q, bool neg) {
+  typedef FqParams P;
+  typedef A<P> F;
+  if (xyzz_is_inf(a)) return xyzz_from_affine(neg ? affine_neg(q) : q);
+  Fq U2 = F::mul(q.x, a.ZZ);                     // < 1.02
+  Fq S2p = F::mul(q.y, a.ZZZ);                   // < 1.02
+  Fq S2n = fe_neg_lazy<P, 4>(S2p);               // 4p - S2 < 4, limbs < 2^30.6
+  Fq S2;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) { const u32 vp = S2p.l[i], vn = S2n.l[i]; S2.l[i] = neg ? vn : vp; }
+  Fq Pd = fe_carry<P>(fe_sub<P, 8>(U2, a.X));    // U2 - X1 (+8p) < 9.02, N
+  Fq Rd = fe_carry<P>(fe_sub<P, 8>(S2, a.Y));    // +-S2 - Y1 (+8p or +12p) < 12, N
+  if (fe_is_zero_mod<P, 10>(Pd)) {               // same x: +-q == +-a   (curve.rs:111-115)
+    if (fe_is_zero_mod<P, 12>(Rd)) return xyzz_dbl_affine(neg ? affine_neg(q) : q);
+    return xyzz_inf();
+  }
+  Xyzz r;
+  Fq PP = F::sqr(Pd);                            // < 1.49
+  Fq PPP = F::mul(Pd, PP);                       // < 1.08
+  Fq Q = F::mul(a.X, PP);                        // < 1.03
+  Fq RR = F::sqr(Rd);                            // < 1.86
+  Fq X3 = fe_weak_reduce<P>(fe_sub<P, 4>(fe_sub<P, 4>(fe_sub<P, 4>(RR, PPP), Q), Q));  // (+12p) < 13.9 -> < 2.01
+  Fq Vd = fe_carry<P>(fe_sub<P, 8>(Q, X3));      // < 9.03
+  r.X = X3;
+  r.Y = F::mul_add2(Rd, Vd, fe_neg_lazy<P, 8>(a.Y), PPP);      // < (12*9.03 + 8*1.08) rho + 1 < 1.7
+  r.ZZ = F::mul(a.ZZ, PP);
+  r.ZZZ = F::mul(a.ZZZ, PPP);
+  return r;
+}
+
 // a + b, both XYZZ   (add-2008-s): 12M + 2S.  Exception-complete.  A as in xyzz_madd_with.
 template <template <class> class A> MZK_HD Xyzz xyzz_add_with(const Xyzz& a, const Xyzz& b) {
   typedef FqParams P;

@@ -372,13 +372,13 @@ template <class P> MZK_HD bool fe_eq_canon(const Fe<P>& a, const Fe<P>& b) {
 // value == 0 (mod p) for a lazily reduced value
 template <class P> MZK_HD bool fe_is_zero(const Fe<P>& a) { return fe_is_zero_canon<P>(fe_reduce<P>(a)); }
 
-// value == 0 (mod p)?  x normalised with value <= KMAX * p.  Cheap filter on limb 0 (x = k p exactly
-// for some k <= KMAX), full reduction only on a hit.
+// value == 0 (mod p)?  x normalised with value <= KMAX * p.  Cheap filter on limb 0: x = k p for some k <= KMAX means
+// x_0 = k p_0 (mod 2^29), i.e. k = x_0 * p_0^-1 mod 2^29 (p_0^-1 = -N0): one multiply and one compare whatever KMAX is
+// (round 2 compared x_0 with every k p_0: 2 KMAX instructions); full reduction only on a hit (a false hit has probability
+// KMAX / 2^29).
 template <class P, int KMAX> MZK_HD bool fe_is_zero_mod(const Fe<P>& x) {
-  bool maybe = false;
-#pragma unroll
-  for (int k = 0; k <= KMAX; k++) maybe |= (x.l[0] == (((u32)k * P::P[0]) & MASK29));
-  if (!maybe) return false;
+  const u32 k = (x.l[0] * ((0u - P::N0) & MASK29)) & MASK29;
+  if (k > (u32)KMAX) return false;
   return fe_is_zero_canon<P>(fe_reduce<P>(x));
 }
 

@@ -748,9 +748,7 @@ __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ 
       do { b++; bend = offsets[b + 1]; } while (e >= bend);
     }
     if (affine_words_is_inf(w)) continue;  // infinity contributes nothing (curve.rs:107-109)
-    Affine p = affine_load_mont(w);
-    if (ent >> 31) p = affine_neg(p);
-    acc = xyzz_madd_with<FeAsm>(acc, p);
+    acc = xyzz_madd_signed_with<FeAsm>(acc, affine_load_mont(w), (ent >> 31) != 0);
   }
   xyzz_gstore_raw(slots, t + b, acc);
 }
@@ -970,9 +968,7 @@ __global__ __launch_bounds__(64) void k_small_accumulate(const u32* __restrict__
     load_words8(points_mont + idx * 16, w);
     load_words8(points_mont + idx * 16 + 8, w + 8);
     if (affine_words_is_inf(w)) continue;
-    Affine p = affine_load_mont(w);
-    if (ent >> 31) p = affine_neg(p);
-    acc = xyzz_madd(acc, p);
+    acc = xyzz_madd_signed_with<FeCpp>(acc, affine_load_mont(w), (ent >> 31) != 0);
   }
   u32 cnt = o1 - o0;
   if (cnt > 64) cnt = 64;

@@ -114,7 +114,7 @@ static void store_pt(const Xyzz& p, u32* w) {
   if (!xyzz_to_affine(p, &a)) { memset(w, 0, 64); return; }
   affine_store_plain(a, w);
 }
-// op 0: madd (p XYZZ-ified + affine q), 1: add, 2: dbl(p), 3: dbl_affine(p)
+// op 0: madd (p XYZZ-ified + affine q), 1: add, 2: dbl(p), 3: dbl_affine(p), 4: signed madd p - q, 5: signed madd p + q
 int hc_g1_op(int op, const u32* p, const u32* q, u32* out) {
   Xyzz P = load_pt(p), R;
   // scramble P's representation so ZZ != 1: P = (2P' - P') style is overkill; scale by lambda = 3:
@@ -131,6 +131,9 @@ int hc_g1_op(int op, const u32* p, const u32* q, u32* out) {
     case 1: R = xyzz_add(P, load_pt(q)); break;
     case 2: R = xyzz_dbl(P); break;
     case 3: R = affine_words_is_inf(p) ? xyzz_inf() : xyzz_dbl_affine(affine_load_plain(p)); break;
+    case 4: case 5:
+      if (affine_words_is_inf(q)) R = P; else R = xyzz_madd_signed_with<FeCpp>(P, affine_load_plain(q), op == 4);
+      break;
     default: return -1;
   }
   store_pt(R, out);

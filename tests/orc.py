@@ -16,6 +16,20 @@ FR_OMEGA28 = 1910321906792171394429139282769207003614565195732928631530564200482
 _lib = None
 
 
+def usable_threads(cap=32):
+    """Threads worth giving the oracle on this box: the cgroup's CPU quota when there is one (the GPU boxes report 256 CPUs
+    but schedule about 16: more threads made every oracle routine SLOWER there, tools/timing/oracle_scaling.py), else the
+    affinity mask, capped."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -97,10 +97,9 @@ def test_msm_unstructured_points_generic_and_tables_vs_oracle_pippenger(env, lg)
     points (mzk_synth_g1_points_dev, the bench's generator; no trapdoor, no closed form), uniform scalars, through the generic
     GLV layout and through window tables (default width for the size, and BASELINE's 16 bits at 2^20), against the oracle's
     Pippenger on the same streams regenerated on the CPU."""
-    import os
     torch, mz, L, dev, st = env
     n = 1 << lg
-    threads = os.cpu_count() or 8
+    threads = orc.usable_threads()
     sc = torch.empty(n * 4, dtype=torch.int64, device=dev)
     pts = torch.empty(n * 8, dtype=torch.int64, device=dev)
     _ok(L, L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(5200 + lg), ctypes.c_size_t(n), _dp(sc), st))
@@ -116,11 +115,16 @@ def test_msm_unstructured_points_generic_and_tables_vs_oracle_pippenger(env, lg)
         L.mzk_srs_free(h)
         torch.cuda.empty_cache()
     torch.cuda.synchronize()
+    # the oracle works on the SAME scalars and points: scalars regenerated on the CPU, points downloaded (1 GiB in 20 ms; the
+    # try-and-increment generator costs a modular square root per point on the CPU -- half a minute at 2^24); the generators
+    # themselves are the oracle's streams bit for bit: whole vectors at 2^20 in bench.py, a 2^14 suffix here
     s_cpu = orc.synth_vector(FR, 5200 + lg, n, threads)
-    p_cpu = orc.synth_points(5300 + lg, n, threads)
-    # the device generators are the oracle's streams bit for bit (spot check; the bench checks whole vectors)
-    assert np.array_equal(s_cpu.view(np.int64).reshape(-1)[-4096:], sc[-4096:].cpu().numpy())
-    assert np.array_equal(p_cpu.view(np.int64).reshape(-1)[-4096:], pts[-4096:].cpu().numpy())
+    p_cpu = pts.cpu().numpy().view(np.uint64).reshape(-1, 8)
+    assert np.array_equal(s_cpu.view(np.int64).reshape(-1), sc.cpu().numpy())
+    tail = 1 << 14
+    p_tail = orc.synth_points(5300 + lg, n, threads)[-tail:] if lg <= 20 else None
+    if p_tail is not None:
+        assert np.array_equal(p_tail, p_cpu[-tail:])
     want = orc.msm_fast(s_cpu, p_cpu, threads)
     assert _point(mz, out[:8]) == want, "generic MSM on unstructured points != oracle Pippenger"
     for k, wb in enumerate(widths):

@@ -106,6 +106,8 @@ def test_group_law_and_exceptions(hc):
         want = orc.ec_add(0, P, Q)
         assert g1op(hc, 0, P, Q) == want, ("madd", P, Q)
         assert g1op(hc, 1, P, Q) == want, ("add", P, Q)
+        assert g1op(hc, 5, P, Q) == want, ("signed madd, +", P, Q)
+        assert g1op(hc, 4, P, neg(Q) if Q != INF else Q) == want, ("signed madd, -", P, Q)      # P - (-Q) through the sign path
     for P in pts[:6] + [(1, 2), INF]:
         want = orc.ec_mul(0, P, 2)
         assert g1op(hc, 2, P) == want
