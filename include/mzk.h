@@ -417,6 +417,11 @@ int mzk_selftest_field_asm(int field_id, uint64_t seed, size_t n, uint64_t* mism
  * (the group law of curve.rs:44-161), compared as group elements; every record is also checked against the storage bound.
  * Returns the number of pairs that differ (must be 0). */
 int mzk_selftest_row_ec(uint64_t seed, size_t n, int dbl_reps, uint64_t* mismatches);
+/* Device self-check of the wave-cooperative Fq inversion that ends every MSM (myzkp_amd/csrc/mzk_inv_wave.h: the safegcd with
+ * the limbs of f, g, d, e spread over the lanes): n values -- 0, 1, 2, 3, 2^29 - 1, 2^28, -1, 1 in Montgomery form, then random
+ * ones -- against the single-lane safegcd (which the host build pins on the oracle) and against a * a^-1 == 1.  Returns the
+ * number of values that differ (must be 0). */
+int mzk_selftest_inv_wave(uint64_t seed, size_t n, uint64_t* mismatches);
 
 /* Deterministic synthetic inputs (bench + tests): bit-identical to the oracle's orc_synth_*. */
 int mzk_synth_field_dev(int field_id, uint64_t seed, size_t n, void* d_out, void* stream);

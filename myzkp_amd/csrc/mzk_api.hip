@@ -1154,6 +1154,12 @@ int mzk_selftest_row_ec(uint64_t seed, size_t n, int dbl_reps, uint64_t* mismatc
   WsGuard wsg(ctx().stream);
   return selftest_row_ec_impl(seed, n, dbl_reps, mismatches, ctx().stream);
 }
+int mzk_selftest_inv_wave(uint64_t seed, size_t n, uint64_t* mismatches) {
+  MZK_TRY(ensure_init());
+  if (!mismatches || n > ((size_t)1 << 22)) { set_error("selftest_inv_wave: bad argument"); return MZK_E_ARG; }
+  WsGuard wsg(ctx().stream);
+  return selftest_inv_wave_impl(seed, n, mismatches, ctx().stream);
+}
 int mzk_synth_g1_points_dev(uint64_t seed, size_t n, void* d_out_xy, void* stream) {
   MZK_TRY(ensure_init());
   WsGuard wsg((hipStream_t)stream);

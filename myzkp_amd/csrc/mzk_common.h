@@ -169,6 +169,7 @@ int msm_prepare_points(const void* d_points_plain, size_t n, void* d_points_mont
 int msm_phi_points(const void* d_points_mont, size_t n, void* d_phi, hipStream_t s);
 int synth_field_impl(int fid, uint64_t seed, size_t n, void* d_out, hipStream_t s);
 int synth_g1_impl(uint64_t seed, size_t n, void* d_out, hipStream_t s);
+int selftest_inv_wave_impl(uint64_t seed, size_t n, uint64_t* mismatches_host, hipStream_t s);
 int selftest_row_ec_impl(uint64_t seed, size_t n, int dbl_reps, uint64_t* mismatches_host, hipStream_t s);
 int selftest_field_asm_impl(int fid, uint64_t seed, size_t n, uint64_t* mismatches_host, hipStream_t s);
 int kzg_setup_g1_dev(const uint64_t* alpha_host, const uint64_t* g1_host, size_t first, size_t count, void* d_powers_xy, hipStream_t s);

@@ -954,14 +954,18 @@ __global__ __launch_bounds__(SMALL_SORT_THREADS) void k_small_sort(const u32* __
     walk_digits(w, L, i, [&](int, u32 key, u32 payload) { entries[atomicAdd(&hist[key], 1u)] = payload; });
   }
 }
-__global__ __launch_bounds__(64) void k_small_accumulate(const u32* __restrict__ points_mont, const u32* __restrict__ offsets,
-                                                          const u32* __restrict__ entries, u32* __restrict__ buckets) {
-  __shared__ __attribute__((aligned(16))) u32 sh[2][64 * 32];
+// T lanes per bucket (64: few entries per bucket -- the generic layout's thousands of buckets; 256: the commit against narrow
+// window tables, ~256 entries per bucket at 2^10 coefficients: one entry per lane, so the per-lane chain of mixed additions
+// (4 x ~4.5 us with 64 lanes) disappears and only the tree remains).  The tree adds partial i + m/2 onto partial i in place.
+template <int T>
+__global__ __launch_bounds__(T) void k_small_accumulate(const u32* __restrict__ points_mont, const u32* __restrict__ offsets,
+                                                         const u32* __restrict__ entries, u32* __restrict__ buckets) {
+  __shared__ __attribute__((aligned(16))) u32 sh[T * 32];
   const size_t b = blockIdx.x;
   const int lane = threadIdx.x;
   const u32 o0 = offsets[b], o1 = offsets[b + 1];
   Xyzz acc = xyzz_inf();
-  for (u32 e = o0 + lane; e < o1; e += 64) {
+  for (u32 e = o0 + lane; e < o1; e += T) {
     const u32 ent = entries[e];
     u32 w[16];
     const size_t idx = ent & 0x7fffffffu;
@@ -971,26 +975,24 @@ __global__ __launch_bounds__(64) void k_small_accumulate(const u32* __restrict__
     acc = xyzz_madd_signed_with<FeCpp>(acc, affine_load_mont(w), (ent >> 31) != 0);
   }
   u32 cnt = o1 - o0;
-  if (cnt > 64) cnt = 64;
-  if (cnt <= 1) {            // wave-uniform
+  if (cnt > T) cnt = T;
+  if (cnt <= 1) {            // workgroup-uniform
     if (lane == 0) xyzz_gstore(buckets, b, acc);
     return;
   }
   u32 width = 2;
   while (width < cnt) width <<= 1;            // partials beyond `cnt` are infinity: sum the first `width` only
-  xyzz_gstore(sh[0], lane, acc);
+  if ((u32)lane < width) xyzz_gstore(sh, lane, acc);
   __syncthreads();
   const int quad = lane >> 2, ql = lane & 3;
-  int cur = 0;
   for (u32 m = width; m > 1; m >>= 1) {
-    for (u32 pair = quad; pair < m / 2; pair += 16) {     // quad-uniform
-      const Xyzz x = xyzz_gload_quad(sh[cur], 2 * pair, ql), y = xyzz_gload_quad(sh[cur], 2 * pair + 1, ql);
-      xyzz_gstore_quad(sh[cur ^ 1], pair, xyzz_add_quad(x, y, ql), ql);
+    for (u32 i = quad; i < m / 2; i += T / 4) {           // quad-uniform
+      const Xyzz x = xyzz_gload_quad(sh, i, ql), y = xyzz_gload_quad(sh, i + m / 2, ql);
+      xyzz_gstore_quad(sh, i, xyzz_add_quad(x, y, ql), ql);
     }
     __syncthreads();
-    cur ^= 1;
   }
-  if (lane < 32) buckets[b * 32 + lane] = sh[cur][lane];
+  if (lane < 32) buckets[b * 32 + lane] = sh[lane];
 }
 
 // k_window_combine / k_fold_partials live in mzk_msm_tail.hip (compact-code build).
@@ -1157,7 +1159,10 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     hipLaunchKernelGGL(k_small_sort, dim3(1), dim3(SMALL_SORT_THREADS), (NB + SMALL_SORT_THREADS) * 4, s, (const u32*)d_scalars, n, L, (int)NB, offsets, entries);
     prof_end(s, MZK_PH_MSM_SORT);
     prof_begin(s, MZK_PH_MSM_ACCUMULATE);
-    hipLaunchKernelGGL(k_small_accumulate, dim3((unsigned)NB), dim3(64), 0, s, pts, (const u32*)offsets, (const u32*)entries, buckets);
+    if (E_max / NB > 64)      // ~256 entries per bucket (commits against narrow tables): a lane per entry
+      hipLaunchKernelGGL(k_small_accumulate<256>, dim3((unsigned)NB), dim3(256), 0, s, pts, (const u32*)offsets, (const u32*)entries, buckets);
+    else
+      hipLaunchKernelGGL(k_small_accumulate<64>, dim3((unsigned)NB), dim3(64), 0, s, pts, (const u32*)offsets, (const u32*)entries, buckets);
     prof_end(s, MZK_PH_MSM_ACCUMULATE);
     prof_begin(s, MZK_PH_MSM_REDUCE);
     const bool rows = row_tails();

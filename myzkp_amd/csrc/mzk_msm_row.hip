@@ -8,11 +8,37 @@
 #include "mzk_ec.h"
 #include "mzk_coop.h"
 #include "mzk_row.h"
+#include "mzk_inv_wave.h"
 
 namespace mzk {
 
 using rowop::Lane;
 using rowop::Pt;
+
+// XYZZ record (packed, in LDS or global memory) -> canonical affine point at the ABI (plain words, all-zero = infinity), by ONE
+// WAVE: the inversion of ZZ ZZZ is spread over the lanes (mzk_inv_wave.h), the six products around it run redundantly in every
+// lane.  All 64 lanes must be active; lane 0 stores.
+__device__ __forceinline__ void wave_store_affine(const u32* rec, u32* __restrict__ out) {
+  typedef FqParams P;
+  u32 w[32];
+#pragma unroll
+  for (int i = 0; i < 32; i++) w[i] = rec[i];
+  const Xyzz p = xyzz_load(w);
+  u32 wds[16];
+  if (xyzz_is_inf(p)) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) wds[i] = 0;
+  } else {
+    const Fq di = invw::inv<P>(fe_mul<P>(p.ZZ, p.ZZZ));          // 1 / (ZZ ZZZ)
+    const Fq izz = fe_mul<P>(di, p.ZZZ), izzz = fe_mul<P>(di, p.ZZ);
+    Affine af;
+    af.x = fe_reduce<P>(fe_mul<P>(p.X, izz));
+    af.y = fe_reduce<P>(fe_mul<P>(p.Y, izzz));
+    affine_store_plain(af, wds);
+  }
+  if ((threadIdx.x & 63) == 0)
+    for (int i = 0; i < 16; i++) out[i] = wds[i];
+}
 
 __device__ __forceinline__ void halve_indices(int lgB, int t, size_t id, size_t* lo, size_t* hi) {
   const int lgh = lgB - t - 1;
@@ -71,13 +97,7 @@ __global__ __launch_bounds__(RTAIL_THREADS) void k_reduce_tail_row(u32* __restri
     __syncthreads();
   }
   if (finish_affine) {
-    if (threadIdx.x == 0) {
-      u32 wds[16];
-      Affine af;
-      if (xyzz_to_affine<true>(xyzz_load(sh), &af)) affine_store_plain(af, wds);
-      else for (int i = 0; i < 16; i++) wds[i] = 0;
-      for (int i = 0; i < 16; i++) out[i] = wds[i];
-    }
+    if (wave == 0) wave_store_affine(sh, out);
     return;
   }
   if (threadIdx.x < 32) out[(size_t)blockIdx.x * 32 + threadIdx.x] = sh[threadIdx.x];
@@ -96,12 +116,7 @@ __global__ __launch_bounds__(64) void k_window_combine_row(const u32* __restrict
   if (out_xyzz) { rowop::store(out, tot, ln); return; }
   rowop::store(sh, tot, ln);
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  u32 wds[16];
-  Affine af;
-  if (xyzz_to_affine<true>(xyzz_load(sh), &af)) affine_store_plain(af, wds);
-  else for (int i = 0; i < 16; i++) wds[i] = 0;
-  for (int i = 0; i < 16; i++) out[i] = wds[i];
+  wave_store_affine(sh, out);
 }
 // fold `count` XYZZ partials (the gathered records of the ranks / contexts) into one affine point
 __global__ __launch_bounds__(64) void k_fold_partials_row(const u32* __restrict__ partials, int count, u32* __restrict__ out) {
@@ -111,12 +126,7 @@ __global__ __launch_bounds__(64) void k_fold_partials_row(const u32* __restrict_
   for (int i = 0; i < count; i++) tot = rowop::add(tot, rowop::load(partials + (size_t)i * 32, ln), ln);
   rowop::store(sh, tot, ln);
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  u32 wds[16];
-  Affine af;
-  if (xyzz_to_affine<true>(xyzz_load(sh), &af)) affine_store_plain(af, wds);
-  else for (int i = 0; i < 16; i++) wds[i] = 0;
-  for (int i = 0; i < 16; i++) out[i] = wds[i];
+  wave_store_affine(sh, out);
 }
 
 int launch_reduce_tail_row(u32* buckets, int lgB, int t_start, int sets, u32* out, int finish_affine, hipStream_t s) {
@@ -217,6 +227,34 @@ __global__ __launch_bounds__(128) void k_rowtest_check(const u32* __restrict__ a
   for (int k = 0; k < 32; k++) w[k] = dbl_out[i * 32 + k];
   ok = ok && st_record_ok(w) && st_same_point(xyzz_load(w), d);
   if (!ok) atomicAdd(mismatches, 1ull);
+}
+// wave inversion against the single-lane safegcd and against a * a^-1 == 1: one value per wave
+__global__ __launch_bounds__(256) void k_invtest(u64 seed, size_t n, unsigned long long* __restrict__ mismatches) {
+  typedef FqParams P;
+  const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  u64 s = seed ^ (0x9e3779b97f4a7c15ULL * (i + 1));
+  Fq a = st_rand_fq(s);
+  const u32 specials[6] = {0u, 1u, 2u, 3u, 0x1fffffffu, 0x10000000u};
+  if (i < 6) { a = fe_zero<P>(); a.l[0] = specials[i]; }
+  if (i == 6) { a = fe_reduce<P>(fe_neg_canon<P>(fe_one<P>())); }             // -R mod p
+  if (i == 7) { a = fe_one<P>(); }
+  const Fq r1 = invw::inv<P>(a), r2 = fe_inv_safegcd<P>(a);
+  bool ok = fe_eq_canon<P>(fe_reduce<P>(r1), fe_reduce<P>(r2));
+  if (!fe_is_zero_canon<P>(fe_reduce<P>(a))) ok = ok && fe_eq_canon<P>(fe_reduce<P>(fe_mul<P>(a, r1)), fe_reduce<P>(fe_one<P>()));
+  if (!ok && (threadIdx.x & 63) == 0) atomicAdd(mismatches, 1ull);
+}
+int selftest_inv_wave_impl(uint64_t seed, size_t n, uint64_t* mismatches_host, hipStream_t s) {
+  unsigned long long* cnt;
+  MZK_TRY(ws_get(WS_MISC_A, 64, (void**)&cnt));
+  MZK_HIP(hipMemsetAsync(cnt, 0, 8, s));
+  if (n) hipLaunchKernelGGL(k_invtest, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, (u64)seed, n, cnt);
+  MZK_HIP(hipGetLastError());
+  unsigned long long h = 0;
+  MZK_HIP(hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  *mismatches_host = (uint64_t)h;
+  return MZK_OK;
 }
 int synth_g1_impl(uint64_t seed, size_t n, void* d_out, hipStream_t s);
 int selftest_row_ec_impl(uint64_t seed, size_t n, int dbl_reps, uint64_t* mismatches_host, hipStream_t s) {

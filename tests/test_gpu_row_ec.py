@@ -20,6 +20,17 @@ def test_row_add_and_dbl_equal_the_plain_formulas(seed, n, reps):
     assert bad.value == 0
 
 
+@pytest.mark.parametrize("seed,n", [(1, 1 << 14), (99, 8), (5, 1)])
+def test_wave_inversion_equals_the_single_lane_safegcd(seed, n):
+    import myzkp_amd as mz
+    mz.init(0)
+    L = mz.lib()
+    bad = ctypes.c_uint64(123)
+    rc = L.mzk_selftest_inv_wave(ctypes.c_uint64(seed), ctypes.c_size_t(n), ctypes.byref(bad))
+    assert rc == 0, L.mzk_last_error()
+    assert bad.value == 0
+
+
 def test_row_and_quad_tails_give_the_same_commitments():
     """MZK_ROW_TAILS=0 keeps the DPP-quad tails selectable; both must give the oracle's point on every path that has a tail:
     small three-launch commits, the general pipeline with tables, the generic layout's window Horner, partial records."""
