@@ -408,7 +408,11 @@ __global__ __launch_bounds__(LDS_SORT_THREADS) void k_digits_scatter_lds(const u
 //           and k_fine_scatter writes the final 4-byte entries -- all inside one bin's region (256 KiB at 2^20),
 //           which stays in L2 while it fills.
 // key = bucket index: |digit| - 1 (merged layout) or window * 2^(c-1) + |digit| - 1.
-constexpr int COARSE_BINS = 256;
+#ifndef MZK_COARSE_LOG
+#define MZK_COARSE_LOG 8
+#endif
+constexpr int COARSE_LOG = MZK_COARSE_LOG;      // 9: A/B build (one more bit for the point reference in the 4-byte sort records)
+constexpr int COARSE_BINS = 1 << COARSE_LOG;
 constexpr int COARSE_PER_WG = 4096;
 constexpr int SORT2_THREADS = 1024;
 __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_count(const u32* __restrict__ scalars, size_t n, DigitLayout L, int key_shift,
@@ -1229,7 +1233,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   if (two_level) {
     int kb = 0;
     while (((size_t)1 << kb) < NBtot) kb++;
-    const int key_shift = kb - 8;
+    const int key_shift = kb - COARSE_LOG;
     const int F = (int)(NBtot / COARSE_BINS);
     const u32 fine_mask = (u32)F - 1u;
     const int nwg = (int)((n + COARSE_PER_WG - 1) / COARSE_PER_WG);
