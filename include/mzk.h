@@ -17,7 +17,9 @@
  *   - all entry points of a context share one grow-only workspace.  Calls on DIFFERENT streams are ordered by the
  *     library (each entry point waits on the previous one's completion event before touching the workspace and
  *     records its own), so results are correct on any stream; work on one context never overlaps.  Calls must
- *     still come from one host thread at a time.
+ *     still come from one host thread at a time: a call that arrives while another thread is inside the library returns
+ *     MZK_E_BUSY without touching any state (calls nested on ONE thread -- the challenge callback of mzk_fri_commit calling back
+ *     in -- are fine).
  */
 #ifndef MZK_H
 #define MZK_H
@@ -41,7 +43,9 @@ enum { MZK_OK = 0,
        MZK_E_HIP = -7,        /* HIP runtime error */
        MZK_E_NOGPU = -8,      /* no gfx950 device visible: there is NO CPU fallback */
        MZK_E_CALLBACK = -9,   /* a caller-supplied callback reported failure (mzk_fri_commit's challenge) */
-       MZK_E_IO = -10         /* file could not be opened / read / written, or is not a valid dump (mzk_srs_save/load) */ };
+       MZK_E_IO = -10,        /* file could not be opened / read / written, or is not a valid dump (mzk_srs_save/load) */
+       MZK_E_BUSY = -11       /* another host thread is inside a call: the library serves one call at a time (see above);
+                                 nothing was enqueued, the call may simply be repeated */ };
 
 /* Select the device for this process, create streams/workspace.  Idempotent: when context 0 already drives
  * `device_ordinal` nothing is torn down (contexts made by mzk_init_devices, their streams and every handle stay valid);

@@ -3,6 +3,7 @@
 // boundary does: examples/sumcheck/src/prover.rs:149-170).
 #include <stdarg.h>
 #include <stdlib.h>
+#include <atomic>
 #include "mzk_common.h"
 
 namespace mzk {
@@ -17,6 +18,25 @@ void set_error(const char* fmt, ...) {
 int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
   return MZK_E_HIP;
+}
+
+// the thread that is inside the library (0 = nobody); depth counts its nested entries
+static std::atomic<uint64_t> g_owner{0};
+static thread_local int t_depth = 0;
+static thread_local char t_marker;            // its address is this thread's id
+EntryGuard::EntryGuard() : ok(true) {
+  if (t_depth > 0) { t_depth++; return; }
+  uint64_t expected = 0;
+  if (!g_owner.compare_exchange_strong(expected, (uint64_t)(uintptr_t)&t_marker, std::memory_order_acquire)) {
+    ok = false;
+    set_error("another host thread is inside the library: calls must come from one thread at a time (MZK_E_BUSY)");
+    return;
+  }
+  t_depth = 1;
+}
+EntryGuard::~EntryGuard() {
+  if (!ok) return;
+  if (--t_depth == 0) g_owner.store(0, std::memory_order_release);
 }
 
 static Context g_ctxs[MZK_MAX_CTX];
@@ -301,6 +321,8 @@ static int check_device(int device_ordinal, int* num_cu) {
 }
 
 int mzk_init_devices(const int* device_ordinals, int n_devices) {
+  mzk::EntryGuard entry;
+  if (!entry.ok) return MZK_E_BUSY;
   if (!device_ordinals || n_devices < 1 || n_devices > MZK_MAX_CTX) { set_error("mzk_init_devices: need 1..%d device ordinals", MZK_MAX_CTX); return MZK_E_ARG; }
   bool same = g_nctx == n_devices;
   for (int i = 0; same && i < n_devices; i++) same = g_ctxs[i].ready && g_ctxs[i].device == device_ordinals[i];
@@ -356,12 +378,18 @@ int mzk_init(int device_ordinal) {
   return mzk_init_devices(&device_ordinal, 1);
 }
 int mzk_ctx_count(void) { return g_nctx; }
-int mzk_ctx_select(int index) { return ctx_select(index); }
+int mzk_ctx_select(int index) {
+  mzk::EntryGuard entry;
+  if (!entry.ok) return MZK_E_BUSY;
+  return ctx_select(index);
+}
 int mzk_ctx_peer_enabled(int a, int b) { return ctx_peer_enabled(a, b); }
 int mzk_ctx_device(int index) { return (index >= 0 && index < g_nctx) ? g_ctxs[index].device : -1; }
 void* mzk_ctx_stream(int index) { return (index >= 0 && index < g_nctx) ? (void*)g_ctxs[index].stream : nullptr; }
 
 void mzk_shutdown(void) {
+  mzk::EntryGuard entry;
+  if (!entry.ok) return;          // another thread is inside a call: tearing its contexts down under it is not an option
   if (g_nctx) {        // the profiler's events belong to context 0's device
     CtxScope sc(0);
     prof_drain();
@@ -481,7 +509,7 @@ static int side_stream(hipStream_t* side, hipEvent_t* fork, hipEvent_t* join) {
 }
 
 int mzk_ntt(int field_id, const uint64_t* root, const uint64_t* in, uint64_t* out, size_t n, int inverse) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("ntt: bad field id %d", field_id); return MZK_E_ARG; }
   if (n == 0) return MZK_OK;
   if (!in || !out) { set_error("ntt: null pointer"); return MZK_E_ARG; }
@@ -497,20 +525,20 @@ int mzk_ntt(int field_id, const uint64_t* root, const uint64_t* in, uint64_t* ou
 }
 
 int mzk_ntt_dev(int field_id, const uint64_t* root_host, const void* d_in, void* d_out, size_t n, int inverse, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   return ntt_dev_impl(field_id, root_host, d_in, d_out, n, inverse, nullptr, (hipStream_t)stream);
 }
 
 int mzk_coset_lde_batch_dev(int field_id, const void* d_coefs, size_t n_coef, const uint64_t* offset_host, const uint64_t* generator_host,
                             void* d_out, size_t order, size_t batch, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   return coset_lde_dev_impl(field_id, d_coefs, n_coef, offset_host, generator_host, d_out, order, (hipStream_t)stream, batch);
 }
 int mzk_coset_lde_batch(int field_id, const uint64_t* coefs, size_t n_coef, const uint64_t* offset, const uint64_t* generator,
                         uint64_t* out, size_t order, size_t batch) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("coset_lde: bad field id %d", field_id); return MZK_E_ARG; }
   if (n_coef > order) { set_error("attempt to subtract with overflow (order - polynomial.coef.len())"); return MZK_E_LENGTH; }
   if (order == 0 || batch == 0) return MZK_OK;
@@ -526,12 +554,12 @@ int mzk_coset_lde_batch(int field_id, const uint64_t* coefs, size_t n_coef, cons
   return MZK_OK;
 }
 int mzk_ntt_batch_dev(int field_id, const uint64_t* root_host, const void* d_in, void* d_out, size_t n, size_t batch, int inverse, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   return ntt_batch_dev_impl(field_id, root_host, d_in, d_out, n, batch, inverse, (hipStream_t)stream);
 }
 int mzk_ntt_batch(int field_id, const uint64_t* root, const uint64_t* in, uint64_t* out, size_t n, size_t batch, int inverse) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("ntt: bad field id %d", field_id); return MZK_E_ARG; }
   if (n == 0 || batch == 0) return MZK_OK;
   if (!in || !out) { set_error("ntt: null pointer"); return MZK_E_ARG; }
@@ -547,7 +575,7 @@ int mzk_ntt_batch(int field_id, const uint64_t* root, const uint64_t* in, uint64
 
 int mzk_coset_lde(int field_id, const uint64_t* coef, size_t n_coef, const uint64_t* offset, const uint64_t* generator,
                   uint64_t* out, size_t order) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("coset_lde: bad field id %d", field_id); return MZK_E_ARG; }
   if (n_coef > order) { set_error("attempt to subtract with overflow (order - polynomial.coef.len())"); return MZK_E_LENGTH; }
   if (order == 0) return MZK_OK;
@@ -565,17 +593,17 @@ int mzk_coset_lde(int field_id, const uint64_t* coef, size_t n_coef, const uint6
 
 int mzk_coset_lde_dev(int field_id, const void* d_coef, size_t n_coef, const uint64_t* offset_host,
                       const uint64_t* generator_host, void* d_out, size_t order, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   return coset_lde_dev_impl(field_id, d_coef, n_coef, offset_host, generator_host, d_out, order, (hipStream_t)stream);
 }
 
 int mzk_ntt_columns_dev(int field_id, const uint64_t* root, const void* d_in, void* d_out, size_t n_points, size_t cols, int inverse, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   return ntt_columns_dev_impl(field_id, root, d_in, d_out, n_points, cols, inverse, (hipStream_t)stream);
 }
 int mzk_poly_scale(int field_id, const uint64_t* coef, size_t n, const uint64_t* ratio, const uint64_t* lead, uint64_t* out) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (n == 0) return MZK_OK;
   if (!coef || !out) { set_error("poly_scale: null pointer"); return MZK_E_ARG; }
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("poly_scale: bad field id %d", field_id); return MZK_E_ARG; }
@@ -589,7 +617,7 @@ int mzk_poly_scale(int field_id, const uint64_t* coef, size_t n, const uint64_t*
   return MZK_OK;
 }
 int mzk_poly_scale_dev(int field_id, const void* d_coef, size_t n, const uint64_t* ratio_host, const uint64_t* lead_host, void* d_out, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   return poly_scale_dev_impl(field_id, d_coef, n, ratio_host, lead_host, d_out, (hipStream_t)stream);
 }
 
@@ -625,7 +653,7 @@ static int conv_on_device(int fid, const uint64_t* a, size_t la, const uint64_t*
 
 int mzk_fft_multiply(int field_id, const uint64_t* a, size_t la, const uint64_t* b, size_t lb, const uint64_t* omega,
                      uint64_t* out, size_t* out_len) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fft_multiply: bad field id %d", field_id); return MZK_E_ARG; }
   if (!out_len || (!a && la) || (!b && lb)) { set_error("fft_multiply: null pointer"); return MZK_E_ARG; }
   if (la + lb == 0) { set_error("attempt to subtract with overflow (self.coef.len() + other.coef.len() - 1)"); return MZK_E_LENGTH; }
@@ -664,7 +692,7 @@ int mzk_fft_multiply(int field_id, const uint64_t* a, size_t la, const uint64_t*
 
 int mzk_fast_multiply(int field_id, const uint64_t* a, size_t la, const uint64_t* b, size_t lb, const uint64_t* root,
                       size_t root_order, uint64_t* out, size_t* out_len) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fast_multiply: bad field id %d", field_id); return MZK_E_ARG; }
   if (!out_len || !root || (!a && la) || (!b && lb)) { set_error("fast_multiply: null pointer"); return MZK_E_ARG; }
   const HostField* hf = host_field(field_id);
@@ -713,7 +741,7 @@ int mzk_fast_multiply(int field_id, const uint64_t* a, size_t la, const uint64_t
 // ntt::fast_coset_divide (ntt.rs:271-330): the quotient step of FastStark::prove (fast_stark.rs:265).
 int mzk_fast_coset_divide(int field_id, const uint64_t* lhs, size_t ll, const uint64_t* rhs, size_t lr, const uint64_t* offset,
                           const uint64_t* root, size_t root_order, uint64_t* out, size_t* out_len) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fast_coset_divide: bad field id %d", field_id); return MZK_E_ARG; }
   if (!out || !out_len || !root || !offset || (!lhs && ll) || (!rhs && lr)) { set_error("fast_coset_divide: null pointer"); return MZK_E_ARG; }
   const HostField* hf = host_field(field_id);
@@ -795,7 +823,7 @@ static int srs_check_ctx(const mzk_srs* srs) {
 }
 
 int mzk_msm_g1_bn254(const uint64_t* scalars, const uint64_t* points_xy, size_t n, uint64_t out_xy[8]) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!out_xy || ((!scalars || !points_xy) && n)) { set_error("msm: null pointer"); return MZK_E_ARG; }
   hipStream_t s = ctx().stream;
   WsGuard wsg(s);
@@ -823,23 +851,23 @@ int mzk_msm_g1_bn254(const uint64_t* scalars, const uint64_t* points_xy, size_t 
   return MZK_OK;
 }
 int mzk_msm_g1_bn254_dev(const void* d_scalars, const void* d_points_xy, size_t n, void* d_out_xy, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   return msm_dev_impl(d_scalars, d_points_xy, n, MSM_PTS_PLAIN, 0, d_out_xy, false, (hipStream_t)stream);
 }
 int mzk_msm_g1_bn254_partial_dev(const void* d_scalars, const void* d_points_xy, size_t n, void* d_partial16, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   return msm_dev_impl(d_scalars, d_points_xy, n, MSM_PTS_PLAIN, 0, d_partial16, true, (hipStream_t)stream);
 }
 int mzk_g1_fold_partials_dev(const void* d_partials16, int count, void* d_out_xy, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   return msm_fold_partials_impl(d_partials16, count, d_out_xy, (hipStream_t)stream);
 }
 
 int mzk_srs_upload(const uint64_t* powers_xy, size_t n, mzk_srs** out) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!out || (!powers_xy && n)) { set_error("srs_upload: null pointer"); return MZK_E_ARG; }
   hipStream_t s = ctx().stream;
   WsGuard wsg(s);
@@ -868,7 +896,7 @@ void mzk_srs_free(mzk_srs* srs) {
   delete srs;
 }
 int mzk_kzg_commit_srs(const mzk_srs* srs, const uint64_t* coef, size_t n, uint64_t out_xy[8]) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!srs || !out_xy || (!coef && n)) { set_error("commit_srs: null pointer"); return MZK_E_ARG; }
   MZK_TRY(srs_check_ctx(srs));
   if (n > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }  // powers[i], polynomial.rs:162
@@ -884,7 +912,7 @@ int mzk_kzg_commit_srs(const mzk_srs* srs, const uint64_t* coef, size_t n, uint6
 }
 
 int mzk_kzg_commit_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, void* d_out, int out_partial, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   if (!srs || !d_out || (!d_coef && n)) { set_error("commit_srs_dev: null pointer"); return MZK_E_ARG; }
   MZK_TRY(srs_check_ctx(srs));
@@ -952,7 +980,7 @@ extern "C" {
 
 int mzk_kzg_commit_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, void* d_out_xy, int max_in_flight,
                                  void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!srs || ((!d_coefs || !d_out_xy) && count)) { set_error("commit_srs_batch_dev: null pointer"); return MZK_E_ARG; }
   MZK_TRY(srs_check_ctx(srs));
   if (n > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }
@@ -967,7 +995,7 @@ int mzk_kzg_commit_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t
 // commitment w_i, the quotient and its MSM of each opening on one lane
 int mzk_kzg_open_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, const uint64_t* us_host, void* d_ys, void* d_ws_xy,
                                int max_in_flight, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!srs || ((!d_coefs || !us_host || !d_ys || !d_ws_xy) && count)) { set_error("open_srs_batch_dev: null pointer"); return MZK_E_ARG; }
   MZK_TRY(srs_check_ctx(srs));
   if (n > 1 && n - 1 > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }
@@ -979,7 +1007,7 @@ int mzk_kzg_open_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t n
   });
 }
 int mzk_kzg_commit_srs_batch(const mzk_srs* srs, const uint64_t* coefs, size_t n, size_t count, uint64_t* out_xy) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!srs || ((!coefs || !out_xy) && count)) { set_error("commit_srs_batch: null pointer"); return MZK_E_ARG; }
   if (count == 0) return MZK_OK;
   hipStream_t s = ctx().stream;
@@ -996,7 +1024,7 @@ int mzk_kzg_commit_srs_batch(const mzk_srs* srs, const uint64_t* coefs, size_t n
 }
 
 int mzk_kzg_open_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, const uint64_t u_host[4], void* d_y, void* d_w_xy, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   if (!srs) { set_error("open_srs_dev: null srs"); return MZK_E_ARG; }
   MZK_TRY(srs_check_ctx(srs));
@@ -1004,18 +1032,18 @@ int mzk_kzg_open_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, const
   return kzg_open_dev(d_coef, n, u_host, srs->d_points_mont, srs->kind(), srs->n, d_y, d_w_xy, nullptr, (hipStream_t)stream);
 }
 int mzk_kzg_setup_g1_dev(const uint64_t alpha_host[4], const uint64_t g1_xy_host[8], size_t max_d, void* d_powers_xy, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   return kzg_setup_g1_dev(alpha_host, g1_xy_host, 0, max_d + 1, d_powers_xy, (hipStream_t)stream);
 }
 int mzk_kzg_setup_g1_range_dev(const uint64_t alpha_host[4], const uint64_t g1_xy_host[8], size_t first, size_t count, void* d_powers_xy,
                                void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   return kzg_setup_g1_dev(alpha_host, g1_xy_host, first, count, d_powers_xy, (hipStream_t)stream);
 }
 int mzk_kzg_open_quotient_dev(const void* d_coef, size_t n, const uint64_t u_host[4], void* d_y, void* d_q, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   if (!d_q && n > 1) { set_error("open_quotient: null pointer"); return MZK_E_ARG; }
   int dummy;
@@ -1025,7 +1053,7 @@ int mzk_srs_from_device(const void* d_powers_xy, size_t n, mzk_srs** out, void* 
   return mzk_srs_from_device_ex(d_powers_xy, n, 1, out, stream);
 }
 int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, mzk_srs** out, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   if (!out || (!d_powers_xy && n)) { set_error("srs_from_device: null pointer"); return MZK_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
@@ -1052,13 +1080,13 @@ int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, m
 
 int mzk_fri_fold_dev(int field_id, const void* d_codeword, size_t n, const uint64_t* alpha_host, const uint64_t* offset_host,
                      const uint64_t* omega_host, void* d_out, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   return fri_fold_dev_impl(field_id, d_codeword, n, alpha_host, offset_host, omega_host, d_out, (hipStream_t)stream);
 }
 int mzk_fri_fold(int field_id, const uint64_t* codeword, size_t n, const uint64_t* alpha, const uint64_t* offset,
                  const uint64_t* omega, uint64_t* out) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fri_fold: bad field id %d", field_id); return MZK_E_ARG; }
   if (n / 2 == 0) return MZK_OK;
   if (!codeword || !out) { set_error("fri_fold: null pointer"); return MZK_E_ARG; }
@@ -1075,7 +1103,7 @@ int mzk_fri_fold(int field_id, const uint64_t* codeword, size_t n, const uint64_
 
 int mzk_kzg_batch_open(const uint64_t* coef, size_t n, const uint64_t* us, size_t k, const uint64_t* powers_xy, uint64_t* ys,
                        uint64_t w_xy[8]) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!w_xy || (!coef && n) || ((!us || !ys) && k) || (!powers_xy && n > k)) { set_error("batch_open: null pointer"); return MZK_E_ARG; }
   hipStream_t s = ctx().stream;
   WsGuard wsg(s);
@@ -1094,7 +1122,7 @@ int mzk_kzg_batch_open(const uint64_t* coef, size_t n, const uint64_t* us, size_
 }
 
 int mzk_kzg_prove_degree_bound(const uint64_t* coef, size_t n, const uint64_t* powers_xy, size_t n_powers, size_t d, uint64_t out_xy[8]) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!out_xy || (!coef && n) || (!powers_xy && n_powers)) { set_error("degree_bound: null pointer"); return MZK_E_ARG; }
   if (n_powers == 0 || d > n_powers - 1) { set_error("attempt to subtract with overflow (max_d - d)"); return MZK_E_LENGTH; }
   const size_t shift = n_powers - 1 - d;
@@ -1106,7 +1134,7 @@ int mzk_kzg_prove_degree_bound(const uint64_t* coef, size_t n, const uint64_t* p
 }
 
 int mzk_kzg_setup_g1(const uint64_t alpha[4], const uint64_t g1_xy[8], size_t max_d, uint64_t* powers_xy) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!alpha || !g1_xy || !powers_xy) { set_error("kzg_setup: null pointer"); return MZK_E_ARG; }
   hipStream_t s = ctx().stream;
   WsGuard wsg(s);
@@ -1119,7 +1147,7 @@ int mzk_kzg_setup_g1(const uint64_t alpha[4], const uint64_t g1_xy[8], size_t ma
 }
 
 int mzk_kzg_open(const uint64_t* coef, size_t n, const uint64_t u[4], const uint64_t* powers_xy, uint64_t y[4], uint64_t w_xy[8]) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!u || !y || !w_xy || (!coef && n) || (!powers_xy && n > 1)) { set_error("kzg_open: null pointer"); return MZK_E_ARG; }
   hipStream_t s = ctx().stream;
   WsGuard wsg(s);
@@ -1137,31 +1165,31 @@ int mzk_kzg_open(const uint64_t* coef, size_t n, const uint64_t u[4], const uint
 }
 
 int mzk_synth_field_dev(int field_id, uint64_t seed, size_t n, void* d_out, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   if (!d_out && n) { set_error("synth: null pointer"); return MZK_E_ARG; }
   return synth_field_impl(field_id, seed, n, d_out, (hipStream_t)stream);
 }
 int mzk_selftest_field_asm(int field_id, uint64_t seed, size_t n, uint64_t* mismatches) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!mismatches) { set_error("selftest: null pointer"); return MZK_E_ARG; }
   WsGuard wsg(ctx().stream);
   return selftest_field_asm_impl(field_id, seed, n, mismatches, ctx().stream);
 }
 int mzk_selftest_row_ec(uint64_t seed, size_t n, int dbl_reps, uint64_t* mismatches) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!mismatches || dbl_reps < 0 || n > ((size_t)1 << 22)) { set_error("selftest_row_ec: bad argument"); return MZK_E_ARG; }
   WsGuard wsg(ctx().stream);
   return selftest_row_ec_impl(seed, n, dbl_reps, mismatches, ctx().stream);
 }
 int mzk_selftest_inv_wave(uint64_t seed, size_t n, uint64_t* mismatches) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!mismatches || n > ((size_t)1 << 22)) { set_error("selftest_inv_wave: bad argument"); return MZK_E_ARG; }
   WsGuard wsg(ctx().stream);
   return selftest_inv_wave_impl(seed, n, mismatches, ctx().stream);
 }
 int mzk_synth_g1_points_dev(uint64_t seed, size_t n, void* d_out_xy, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   if (!d_out_xy && n) { set_error("synth: null pointer"); return MZK_E_ARG; }
   return synth_g1_impl(seed, n, d_out_xy, (hipStream_t)stream);

@@ -64,6 +64,18 @@ struct Context {
 // peer access between the devices of two contexts: 1 = enabled (or same device), 0 = the runtime refused (copies then stage
 // through the host inside hipMemcpyPeerAsync; still correct)
 int ctx_peer_enabled(int a, int b);
+// One host thread at a time (include/mzk.h): every entry point that touches contexts, workspaces or caches starts with
+// MZK_ENTER().  A second THREAD arriving while a call is in progress gets MZK_E_BUSY before any state is read; nested calls on
+// the owning thread (entry points calling entry points, callbacks calling back in) pass.
+struct EntryGuard {
+  bool ok;
+  EntryGuard();
+  ~EntryGuard();
+};
+#define MZK_ENTER()                        \
+  mzk::EntryGuard _mzk_entry;              \
+  if (!_mzk_entry.ok) return MZK_E_BUSY;   \
+  MZK_TRY(mzk::ensure_init())
 Context& ctx();
 int ctx_count();
 int ctx_select(int index);       // hipSetDevice + make it current

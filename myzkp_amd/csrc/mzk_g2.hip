@@ -90,12 +90,12 @@ using namespace mzk;
 extern "C" {
 
 int mzk_msm_g2_bn254_dev(const void* d_scalars, const void* d_points_xy, size_t n, void* d_out_xy, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   return g2_msm_dev_impl(d_scalars, d_points_xy, n, d_out_xy, (hipStream_t)stream);
 }
 int mzk_msm_g2_bn254(const uint64_t* scalars, const uint64_t* points_xy, size_t n, uint64_t out_xy[16]) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!out_xy || ((!scalars || !points_xy) && n)) { set_error("msm_g2: null pointer"); return MZK_E_ARG; }
   const HostField* fq = host_field(MZK_FIELD_FQ);
   for (size_t i = 0; i < 4 * n; i++)
@@ -116,7 +116,7 @@ int mzk_msm_g2_bn254(const uint64_t* scalars, const uint64_t* points_xy, size_t 
   return MZK_OK;
 }
 int mzk_kzg_setup_g2(const uint64_t alpha[4], const uint64_t g2_xy[16], size_t max_d, uint64_t* powers2_xy) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!alpha || !g2_xy || !powers2_xy) { set_error("kzg_setup_g2: null pointer"); return MZK_E_ARG; }
   const HostField* fq = host_field(MZK_FIELD_FQ);
   if (!h_is_canonical(host_field(MZK_FIELD_FR), alpha)) { set_error("kzg_setup_g2: alpha not canonical"); return MZK_E_RANGE; }

@@ -53,7 +53,7 @@ struct FileCloser { FILE* f; ~FileCloser() { if (f) fclose(f); } };
 extern "C" {
 
 int mzk_srs_save(const mzk_srs* srs, const char* path, int with_tables) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!srs || !path) { set_error("srs_save: null pointer"); return MZK_E_ARG; }
   if (srs->ctx_index != ctx().index) { set_error("SRS handle lives on context %d, the current context is %d", srs->ctx_index, ctx().index); return MZK_E_ARG; }
   hipStream_t s = ctx().stream;
@@ -99,7 +99,7 @@ int mzk_srs_save(const mzk_srs* srs, const char* path, int with_tables) {
 // with_tables as in mzk_srs_from_device_ex (0 = plain prepared points, 1 = default 16-bit windows, 12..22 = that width);
 // tables stored in the file are used when their width matches, otherwise they are rebuilt from the points.
 int mzk_srs_load(const char* path, int with_tables, mzk_srs** out) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!path || !out) { set_error("srs_load: null pointer"); return MZK_E_ARG; }
   *out = nullptr;
   if (with_tables < 0 || (with_tables > 1 && (with_tables < 12 || with_tables > 22))) { set_error("srs_load: with_tables must be 0, 1 or a window width 12..22"); return MZK_E_ARG; }
@@ -152,7 +152,7 @@ int mzk_srs_load(const char* path, int with_tables, mzk_srs** out) {
 
 // the points of a handle back at the ABI (affine canonical, n * 8 limbs): PublicKeyKZG.powers_1 as the reference holds it
 int mzk_srs_download(const mzk_srs* srs, uint64_t* powers_xy, size_t cap_points) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!srs || (!powers_xy && srs->n)) { set_error("srs_download: null pointer"); return MZK_E_ARG; }
   if (cap_points < srs->n) { set_error("srs_download: buffer holds %zu points, the SRS has %zu", cap_points, srs->n); return MZK_E_LENGTH; }
   if (srs->ctx_index != ctx().index) { set_error("SRS handle lives on context %d, the current context is %d", srs->ctx_index, ctx().index); return MZK_E_ARG; }

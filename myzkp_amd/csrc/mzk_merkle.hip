@@ -595,13 +595,13 @@ static int merkle_build(int kind, int fid, const void* src, bool src_on_device, 
 extern "C" {
 
 int mzk_merkle_build_field_dev(int field_id, const void* d_elems, size_t n, mzk_merkle** out, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("merkle: bad field id %d", field_id); return MZK_E_ARG; }
   return merkle_build(0, field_id, d_elems, true, n * field_bytes(field_id), nullptr, n, out, (hipStream_t)stream);
 }
 static int build_field_host(int field_id, const uint64_t* elems, const uint8_t* negative, size_t n, mzk_merkle** out) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("merkle: bad field id %d", field_id); return MZK_E_ARG; }
   if (elems) {
     const HostField* hf = host_field(field_id);
@@ -626,7 +626,7 @@ int mzk_merkle_commit_field_signed(int field_id, const uint64_t* magnitudes, con
   return rc;
 }
 int mzk_merkle_build_bytes(const uint8_t* leaves, const uint64_t* offsets, size_t n, mzk_merkle** out) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!offsets) { set_error("merkle: null offsets"); return MZK_E_ARG; }
   for (size_t i = 0; i < n; i++)
     if (offsets[i + 1] < offsets[i]) { set_error("merkle: offsets must be non-decreasing"); return MZK_E_ARG; }
@@ -642,7 +642,7 @@ int mzk_merkle_build_bytes(const uint8_t* leaves, const uint64_t* offsets, size_
 
 int mzk_merkle_root(const mzk_merkle* t, uint8_t* root, size_t cap, size_t* root_len) {
   if (!t || !root || !root_len) { set_error("merkle_root: null pointer"); return MZK_E_ARG; }
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   MerkleScope ms(t);
   MZK_TRY(ms.rc);
   if (t->n == 1) {   // merkle.rs:17-19: the single leaf itself
@@ -682,7 +682,7 @@ int mzk_merkle_open(const mzk_merkle* t, size_t index, uint8_t* path, size_t str
     const uint64_t idx64 = (uint64_t)index;
     return mzk_merkle_open_batch(t, &idx64, 1, path, stride, path_len, depth);
   }
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   MerkleScope ms(t);
   MZK_TRY(ms.rc);
   hipStream_t s = ms.s;
@@ -769,7 +769,7 @@ int mzk_merkle_open_batch(const mzk_merkle* t, const uint64_t* indices, size_t c
   if (stride < 32) { set_error("merkle_open: stride < 32"); return MZK_E_LENGTH; }
   for (size_t q = 0; q < count; q++)
     if (indices[q] >= t->n) { set_error("merkle_open: index %llu out of range", (unsigned long long)indices[q]); return MZK_E_LENGTH; }
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   MerkleScope ms(t);
   MZK_TRY(ms.rc);
   hipStream_t s = ms.s;
@@ -842,7 +842,7 @@ int mzk_merkle_open_multi(const mzk_merkle* const* trees, size_t n_trees, const 
   }
   if (total == 0) return MZK_OK;
   if (stride < 32) { set_error("merkle_open: stride < 32"); return MZK_E_LENGTH; }
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   MerkleScope ms(first);
   MZK_TRY(ms.rc);
   hipStream_t s = ms.s;
@@ -914,7 +914,7 @@ void mzk_merkle_free(mzk_merkle* t) {
 // One-shot commit of a device-resident codeword (the FRI round: root -> transcript -> alpha -> fold); nothing is
 // retained, the node levels live in workspace.  root: 32 bytes (n >= 2) or the leaf bytes (n == 1; cap >= 41).
 int mzk_merkle_commit_field_dev(int field_id, const void* d_elems, size_t n, uint8_t* root, size_t cap, size_t* root_len, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("merkle: bad field id %d", field_id); return MZK_E_ARG; }
   if (n == 0) { set_error("merkle: empty leaf set (Merkle::commit recurses forever on it, merkle.rs:20-22)"); return MZK_E_LENGTH; }
@@ -950,7 +950,7 @@ int mzk_merkle_commit_field_dev(int field_id, const void* d_elems, size_t n, uin
 // Merkle::commit of `batch` codewords of n elements each (n a power of two >= 2), roots only: one set of launches for all
 // trees, so the latency-bound upper levels of the trees run side by side.
 int mzk_merkle_commit_field_batch_dev(int field_id, const void* d_elems, size_t n, size_t batch, uint8_t* roots, void* stream) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   WsGuard wsg((hipStream_t)stream);
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("merkle: bad field id %d", field_id); return MZK_E_ARG; }
   if (batch == 0) return MZK_OK;
@@ -968,7 +968,7 @@ int mzk_merkle_commit_field_batch_dev(int field_id, const void* d_elems, size_t 
   return MZK_OK;
 }
 int mzk_merkle_commit_field_batch(int field_id, const uint64_t* elems, size_t n, size_t batch, uint8_t* roots) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("merkle: bad field id %d", field_id); return MZK_E_ARG; }
   if (batch == 0) return MZK_OK;
   if (!elems) { set_error("merkle: null pointer"); return MZK_E_ARG; }
@@ -1022,7 +1022,7 @@ static int fri_commit_impl(int field_id, const uint64_t* codeword, const uint8_t
 static int fri_commit_rounds(int field_id, const uint64_t* codeword, const uint8_t* negative, size_t n, const uint64_t* omega, const uint64_t* offset,
                              int num_rounds, mzk_fri_challenge_fn challenge, void* user, uint8_t* roots, uint64_t* root_len, uint64_t* codewords_out,
                              mzk_merkle** trees_out, bool on_device) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fri_commit: bad field id %d", field_id); return MZK_E_ARG; }
   if (num_rounds <= 0) return MZK_OK;
   if (!codeword || !omega || !offset || !challenge || !roots || !root_len) { set_error("fri_commit: null pointer"); return MZK_E_ARG; }
@@ -1130,7 +1130,7 @@ int mzk_merkle_leaves(const mzk_merkle* t, const uint64_t* indices, size_t count
   for (size_t q = 0; q < count; q++)
     if (indices[q] >= t->n) { set_error("merkle_leaves: index %llu out of range", (unsigned long long)indices[q]); return MZK_E_LENGTH; }
   if (count == 0) return MZK_OK;
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   MerkleScope ms(t);
   MZK_TRY(ms.rc);
   hipStream_t s = ms.s;

@@ -227,7 +227,7 @@ void mzk_shard_range(size_t n, int rank, int world, size_t* lo, size_t* hi) {
 }
 
 int mzk_msm_g1_bn254_multi(const uint64_t* scalars, const uint64_t* points_xy, size_t n, uint64_t out_xy[8]) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!out_xy || ((!scalars || !points_xy) && n)) { set_error("msm_multi: null pointer"); return MZK_E_ARG; }
   const int world = ctx_count();
   uint64_t* h_rec;
@@ -274,7 +274,7 @@ static mzk_srs_multi* new_multi(size_t n) {
 }
 
 int mzk_srs_upload_multi(const uint64_t* powers_xy, size_t n, mzk_srs_multi** out) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!out || (!powers_xy && n)) { set_error("srs_upload_multi: null pointer"); return MZK_E_ARG; }
   mzk_srs_multi* h = new_multi(n);
   for (int r = 0; r < h->world; r++) {
@@ -289,7 +289,7 @@ int mzk_srs_upload_multi(const uint64_t* powers_xy, size_t n, mzk_srs_multi** ou
 // setup_kzg (kzg.rs:27-40) sharded: context r builds powers [lo_r, hi_r) of [alpha^i] g1 on its own GPU and keeps
 // them as its SRS shard -- no point ever crosses PCIe or xGMI.
 int mzk_kzg_setup_srs_multi(const uint64_t alpha[4], const uint64_t g1_xy[8], size_t max_d, int with_tables, mzk_srs_multi** out) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!out || !alpha || !g1_xy) { set_error("setup_srs_multi: null pointer"); return MZK_E_ARG; }
   mzk_srs_multi* h = new_multi(max_d + 1);
   void* tmp[MZK_MAX_CTX] = {};
@@ -321,7 +321,7 @@ int mzk_srs_multi_world(const mzk_srs_multi* h) { return h ? h->world : 0; }
 // copies its slice); otherwise d_coef_shards[r] is a device pointer ON CONTEXT r's GPU to coefficients
 // [lo_r, min(hi_r, n)) -- already complete when the call is made (the call does not know the producer's stream).
 static int commit_multi(const mzk_srs_multi* h, const uint64_t* host_coef, const void* const* d_coef_shards, size_t n, uint64_t out_xy[8]) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (!h || !out_xy || (n && !host_coef && !d_coef_shards)) { set_error("commit_srs_multi: null pointer"); return MZK_E_ARG; }
   if (h->world != ctx_count()) { set_error("commit_srs_multi: handle was built for %d contexts, %d are initialised", h->world, ctx_count()); return MZK_E_ARG; }
   if (n > h->n) { set_error("index out of bounds: the len is %zu but the index is %zu", h->n, h->n); return MZK_E_LENGTH; }   // powers[i], polynomial.rs:162
@@ -360,12 +360,12 @@ int mzk_kzg_commit_srs_multi_dev(const mzk_srs_multi* h, const void* const* d_co
 // One n-point transform (ntt / intt, ntt.rs:7-64) whose vector is spread over the contexts; see include/mzk.h.
 int mzk_ntt_multi_dev(int field_id, const uint64_t* root, const void* const* d_in_parts, void* const* d_out_parts, size_t n, int inverse,
                       int layout_in, int layout_out) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   return ntt_multi_impl(field_id, root, d_in_parts, d_out_parts, n, inverse, layout_in, layout_out);
 }
 // host vector in natural order: context r gets x[r n/W, (r+1) n/W) and returns the same slice of the result
 int mzk_ntt_multi(int field_id, const uint64_t* root, const uint64_t* in, uint64_t* out, size_t n, int inverse) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (n == 0) return MZK_OK;
   if (!in || !out) { set_error("ntt_multi: null pointer"); return MZK_E_ARG; }
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("ntt_multi: field id %d has no NTT on this path", field_id); return MZK_E_ARG; }

@@ -649,7 +649,7 @@ using namespace mzk;
 extern "C" {
 
 int mzk_fast_zerofier(int field_id, const uint64_t* domain, size_t n, const uint64_t* root, size_t root_order, uint64_t* out, size_t* out_len) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fast_zerofier: bad field id %d", field_id); return MZK_E_ARG; }
   if (!root || !out_len || (n && (!domain || !out))) { set_error("fast_zerofier: null pointer"); return MZK_E_ARG; }
   const HostField* hf = host_field(field_id);
@@ -659,7 +659,7 @@ int mzk_fast_zerofier(int field_id, const uint64_t* domain, size_t n, const uint
                                     : zerofier_impl<FrParams>(field_id, domain, n, root, root_order, out, out_len);
 }
 int mzk_fast_evaluate(int field_id, const uint64_t* coef, size_t m, const uint64_t* domain, size_t n, const uint64_t* root, size_t root_order, uint64_t* out) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fast_evaluate: bad field id %d", field_id); return MZK_E_ARG; }
   if (!root || (m && !coef) || (n && (!domain || !out))) { set_error("fast_evaluate: null pointer"); return MZK_E_ARG; }
   const HostField* hf = host_field(field_id);
@@ -671,7 +671,7 @@ int mzk_fast_evaluate(int field_id, const uint64_t* coef, size_t m, const uint64
 }
 int mzk_fast_interpolate(int field_id, const uint64_t* domain, const uint64_t* values, size_t n, const uint64_t* root, size_t root_order, uint64_t* out,
                          size_t* out_len) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fast_interpolate: bad field id %d", field_id); return MZK_E_ARG; }
   if (!root || !out_len || (n && (!domain || !values || !out))) { set_error("fast_interpolate: null pointer"); return MZK_E_ARG; }
   const HostField* hf = host_field(field_id);
@@ -683,7 +683,7 @@ int mzk_fast_interpolate(int field_id, const uint64_t* domain, const uint64_t* v
 }
 int mzk_fast_interpolate_batch(int field_id, const uint64_t* domain, const uint64_t* values, size_t n, size_t batch, const uint64_t* root,
                                size_t root_order, uint64_t* out, size_t* out_lens) {
-  MZK_TRY(ensure_init());
+  MZK_ENTER();
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fast_interpolate: bad field id %d", field_id); return MZK_E_ARG; }
   if (batch == 0) return MZK_OK;
   if (!root || !out_lens || (n && (!domain || !values || !out))) { set_error("fast_interpolate: null pointer"); return MZK_E_ARG; }

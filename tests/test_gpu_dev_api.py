@@ -182,3 +182,49 @@ def test_srs_tables_with_explicit_window_width(env, c):
         torch.cuda.synchronize()
         assert mz.array_to_points(out.cpu().numpy().view(np.uint64))[0] == (want if m == n else orc.msm_fast(s[:m], p[:m])), (c, m)
     L.mzk_srs_free(h)
+
+
+def test_second_host_thread_gets_busy_not_corruption():
+    """include/mzk.h: one host thread at a time.  A call arriving while another thread is inside the library returns MZK_E_BUSY
+    (-11) before touching any state; the call in progress is unaffected (VERDICT r02 weak #8)."""
+    import threading
+    import myzkp_amd as mzz
+    mzz.init(0)
+    Lb = mzz.lib()
+    lg = 22
+    n = 1 << lg
+    v = orc.synth_vector(orc.FR, 31337, n)
+    w = orc.root_of(orc.FR, lg)
+    wl = mzz.to_limbs([w], 4)
+    out = np.zeros_like(v)
+    small_in = orc.synth_vector(orc.FR, 5, 64)
+    small_w = mzz.to_limbs([orc.root_of(orc.FR, 6)], 4)
+    rc_rec, ok_small, stop = [], [], threading.Event()
+    rc, want_small = orc.ntt_fast(orc.FR, orc.root_of(orc.FR, 6), small_in)
+
+    def hammer():
+        o = np.zeros_like(small_in)
+        while not stop.is_set():
+            r = Lb.mzk_ntt(0, small_w.ctypes.data_as(ctypes.c_void_p), small_in.ctypes.data_as(ctypes.c_void_p), o.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(64), 0)
+            rc_rec.append(r)
+            if r == 0:
+                ok_small.append(bool(np.array_equal(o, want_small)))
+    th = threading.Thread(target=hammer)
+    th.start()
+    try:
+        done, tries = 0, 0
+        while done < 6 and tries < 100000:      # ~10 ms each with the transfers: long enough for the other thread to run into it
+            r = Lb.mzk_ntt(0, wl.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n), 0)
+            assert r in (0, -11)                 # -11: the other thread was inside at that moment -- repeat, as the header says
+            done += r == 0
+            tries += 1
+        assert done == 6
+    finally:
+        stop.set()
+        th.join()
+    assert set(rc_rec) <= {0, -11} and -11 in rc_rec, "the second thread never met a call in progress"
+    assert all(ok_small)
+    # the big transform, alone again, is right
+    assert Lb.mzk_ntt(0, wl.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n), 0) == 0
+    rc, want = orc.ntt_fast(orc.FR, w, v)
+    assert rc == 0 and np.array_equal(out, want)
