@@ -1194,10 +1194,12 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
       return MZK_E_ARG;
     }
   }
-  // Segment length: one lane per segment, and the grid should be ONE full round of resident waves -- the kernel is a
-  // long dependent loop, so the waves of a partial second round would run alone on their SIMDs.  k_seg_accumulate
-  // <PREFETCH = false> needs 123 VGPRs = 4 waves per SIMD, <true> 139 = 3 (tools/timing/acc_sweep.py sweeps both and
-  // the segment length through MZK_ACC_PREFETCH / MZK_ACC_SEG).
+  // Segment length: one lane per segment, sized as if four waves per SIMD were resident (E / (CUs * 4 * 4 * 64), >= 16).  Round 2's
+  // kernel had 123 VGPRs and the grid was exactly one round of resident waves; with the signed mixed addition of round 3 the
+  // compiler takes 140 VGPRs (three waves per SIMD), and the same segment length is still the fastest of the variants measured
+  // (profiles/r03o_accumulate_occupancy_ab.txt: shipped 1.05-1.06 ms at 2^20; __launch_bounds__(256, 4) = 128 VGPRs + 64 B of
+  // scratch 1.07-1.10; segments sized for three waves 1.07 with a cheaper segment combine: equal in total).
+  // (tools/timing/acc_sweep.py sweeps MZK_ACC_PREFETCH / MZK_ACC_SEG.)
   static const int env_prefetch = getenv("MZK_ACC_PREFETCH") ? atoi(getenv("MZK_ACC_PREFETCH")) : -1;
   static const int env_seg = getenv("MZK_ACC_SEG") ? atoi(getenv("MZK_ACC_SEG")) : 0;
   const bool acc_prefetch = env_prefetch >= 0 ? env_prefetch != 0 : false;
