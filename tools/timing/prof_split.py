@@ -1,5 +1,5 @@
 """Kernel time per MSM from a rocprofv3 kernel trace: python tools/timing/prof_split.py <..._kernel_trace.csv>
-An MSM ends at its k_reduce_tail when that runs ONE workgroup (merged layout: the tail writes the result itself), or
+An MSM ends at its k_reduce_tail[_row] when that runs ONE workgroup (merged layout: the tail writes the result itself), or
 at the k_window_combine that follows a multi-workgroup k_reduce_tail (generic layout: one bucket set per window).
 Kernels outside any MSM (NTT, Merkle, table building, synthetic inputs) are skipped."""
 import csv, sys, collections
@@ -13,12 +13,12 @@ for r in rows:
         continue
     cur.append((nm, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
     kind = None
-    if nm == "k_reduce_tail":
-        if int(r["Grid_Size_X"]) <= 512:
+    if nm in ("k_reduce_tail", "k_reduce_tail_row"):
+        if int(r["Grid_Size_X"]) <= (1024 if nm.endswith("_row") else 512):      # one workgroup
             kind = "merged (KZG commit against SRS tables)"
         else:
             pending_generic = True
-    elif nm == "k_window_combine" and pending_generic:
+    elif nm in ("k_window_combine", "k_window_combine_row") and pending_generic:
         kind, pending_generic = "generic (arbitrary points, GLV)", False
     if kind:
         agg = collections.defaultdict(float)
