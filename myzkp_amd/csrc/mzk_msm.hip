@@ -22,6 +22,7 @@
 #include "mzk_common.h"
 #include "mzk_ec.h"
 #include "mzk_coop.h"
+#include "mzk_row.h"
 #include "mzk_glv.h"
 
 namespace mzk {
@@ -989,10 +990,18 @@ __global__ __launch_bounds__(T) void k_small_accumulate(const u32* __restrict__ 
   if ((u32)lane < width) xyzz_gstore(sh, lane, acc);
   __syncthreads();
   const int quad = lane >> 2, ql = lane & 3;
+  const rowop::Lane ln = rowop::lane_init();
   for (u32 m = width; m > 1; m >>= 1) {
-    for (u32 i = quad; i < m / 2; i += T / 4) {           // quad-uniform
-      const Xyzz x = xyzz_gload_quad(sh, i, ql), y = xyzz_gload_quad(sh, i + m / 2, ql);
-      xyzz_gstore_quad(sh, i, xyzz_add_quad(x, y, ql), ql);
+    if (m / 2 <= (u32)(T / 64)) {                         // the last levels: one row-cooperative addition per wave (1.3 us, not 3.6)
+      for (u32 i = (u32)(lane >> 6); i < m / 2; i += T / 64) {
+        const rowop::Pt x = rowop::load(sh + i * 32, ln), y = rowop::load(sh + (i + m / 2) * 32, ln);
+        rowop::store(sh + i * 32, rowop::add(x, y, ln), ln);
+      }
+    } else {
+      for (u32 i = quad; i < m / 2; i += T / 4) {         // quad-uniform
+        const Xyzz x = xyzz_gload_quad(sh, i, ql), y = xyzz_gload_quad(sh, i + m / 2, ql);
+        xyzz_gstore_quad(sh, i, xyzz_add_quad(x, y, ql), ql);
+      }
     }
     __syncthreads();
   }
@@ -1014,7 +1023,43 @@ static bool row_tails() {
 // The single-workgroup tail takes over once a halving step is at most this wide: a dependent launch costs ~6 us whatever runs in
 // it (measured: a step of 1024 additions as one wave each 6.0 us, as DPP quads 6.4 us -- the launch, not the addition), a round
 // of 256 quad additions inside the tail's workgroup 3.6 us, a round of 16 row additions ~1.8 us.
-constexpr size_t ROW_TAIL_MAX_OPS = 256;
+static size_t row_tail_max_ops() {
+  static const size_t v = getenv("MZK_TAIL_MAX_OPS") ? (size_t)atoi(getenv("MZK_TAIL_MAX_OPS")) : 64;
+  return v < 1 ? 1 : v;
+}
+
+// Bucket reduction of `sets` bucket sets of 2^lgB buckets each: sum_b (b+1) B_b by in-place halving -- wide steps as launches,
+// the late ones inside one workgroup per set -- then, for the generic layout, the Horner over the windows.  merged: one set, the
+// tail writes the result itself (affine point, or the XYZZ partial record).
+static int reduce_bucket_sets(u32* buckets, int lgB, int sets, bool merged, int horner_c, u32* wsum, u32* d_out, bool out_partial_xyzz, hipStream_t s) {
+  prof_begin(s, MZK_PH_MSM_REDUCE);
+  const bool rows = row_tails();
+  int t_start = 0;
+  const size_t tail_max = rows ? row_tail_max_ops() : (size_t)4 * TAIL_QUADS;
+  while (t_start < lgB && ((size_t)(t_start + 1) << (lgB - t_start - 1)) > tail_max) t_start++;
+  for (int t = 0; t < t_start; t++) {
+    const size_t total = (size_t)(t + 1) << (lgB - t - 1);
+    if (total * (size_t)sets >= ((size_t)1 << 16))
+      hipLaunchKernelGGL(k_halve_step_wide, dim3((unsigned)((total + 127) / 128), (unsigned)sets), dim3(128), 0, s, buckets, lgB, t);
+    else
+      hipLaunchKernelGGL(k_halve_step, dim3((unsigned)((4 * total + 127) / 128), (unsigned)sets), dim3(128), 0, s, buckets, lgB, t);
+  }
+  if (merged) {
+    if (rows) MZK_TRY(launch_reduce_tail_row(buckets, lgB, t_start, 1, d_out, out_partial_xyzz ? 0 : 1, s));
+    else hipLaunchKernelGGL(k_reduce_tail, dim3(1), dim3(TAIL_THREADS), 0, s, buckets, lgB, t_start, d_out, out_partial_xyzz ? 0 : 1);
+    MZK_HIP(hipGetLastError());
+    prof_end(s, MZK_PH_MSM_REDUCE);
+    return MZK_OK;
+  }
+  if (rows) MZK_TRY(launch_reduce_tail_row(buckets, lgB, t_start, sets, wsum, 0, s));
+  else hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)sets), dim3(TAIL_THREADS), 0, s, buckets, lgB, t_start, wsum, 0);
+  MZK_HIP(hipGetLastError());
+  prof_end(s, MZK_PH_MSM_REDUCE);
+  prof_begin(s, MZK_PH_MSM_COMBINE);
+  MZK_TRY((rows ? launch_window_combine_row : launch_window_combine)((const u32*)wsum, sets, horner_c, out_partial_xyzz ? 1 : 0, d_out, s));
+  prof_end(s, MZK_PH_MSM_COMBINE);
+  return MZK_OK;
+}
 
 // ---- host orchestration -----------------------------------------------------------------------------------
 // d_phi (optional): receives the endomorphism images (beta x, y) of the n points (the generic MSM layout reads them
@@ -1168,20 +1213,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     else
       hipLaunchKernelGGL(k_small_accumulate<64>, dim3((unsigned)NB), dim3(64), 0, s, pts, (const u32*)offsets, (const u32*)entries, buckets);
     prof_end(s, MZK_PH_MSM_ACCUMULATE);
-    prof_begin(s, MZK_PH_MSM_REDUCE);
-    const bool rows = row_tails();
-    if (L.merged) {      // one bucket set: the tail writes the result itself (affine point or the XYZZ partial record)
-      if (rows) MZK_TRY(launch_reduce_tail_row(buckets, sh.lgB, 0, 1, (u32*)d_out, out_partial_xyzz ? 0 : 1, s));
-      else hipLaunchKernelGGL(k_reduce_tail, dim3(1), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, 0, (u32*)d_out, out_partial_xyzz ? 0 : 1);
-      prof_end(s, MZK_PH_MSM_REDUCE);
-    } else {
-      if (rows) MZK_TRY(launch_reduce_tail_row(buckets, sh.lgB, 0, red_windows, wsum, 0, s));
-      else hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)red_windows), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, 0, wsum, 0);
-      prof_end(s, MZK_PH_MSM_REDUCE);
-      prof_begin(s, MZK_PH_MSM_COMBINE);
-      MZK_TRY((rows ? launch_window_combine_row : launch_window_combine)((const u32*)wsum, red_windows, horner_c, out_partial_xyzz ? 1 : 0, (u32*)d_out, s));
-      prof_end(s, MZK_PH_MSM_COMBINE);
-    }
+    MZK_TRY(reduce_bucket_sets(buckets, sh.lgB, red_windows, L.merged != 0, horner_c, wsum, (u32*)d_out, out_partial_xyzz, s));
     MZK_HIP(hipGetLastError());
     return MZK_OK;
   }
@@ -1307,36 +1339,10 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   hipLaunchKernelGGL(k_seg_combine_heavy, dim3(512), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)offsets, buckets, seg, (const u32*)heavy);
   MZK_HIP(hipGetLastError());
   prof_end(s, MZK_PH_MSM_SEG_COMBINE);
-  prof_begin(s, MZK_PH_MSM_REDUCE);
 
-  // bucket reduction: sum_b (b+1) B_b per bucket set (in-place halving), then the window Horner
   u32* wsum;
   MZK_TRY(ws_get(WS_MSM_OUT, (size_t)MAX_WINDOWS * 128, (void**)&wsum));
-  const bool rows = row_tails();
-  int t_start = 0;
-  const size_t tail_max = rows ? ROW_TAIL_MAX_OPS : (size_t)4 * TAIL_QUADS;
-  while (t_start < sh.lgB && ((size_t)(t_start + 1) << (sh.lgB - t_start - 1)) > tail_max) t_start++;
-  for (int t = 0; t < t_start; t++) {
-    const size_t total = (size_t)(t + 1) << (sh.lgB - t - 1);
-    if (total * (size_t)red_windows >= ((size_t)1 << 16))
-      hipLaunchKernelGGL(k_halve_step_wide, dim3((unsigned)((total + 127) / 128), (unsigned)red_windows), dim3(128), 0, s, buckets, sh.lgB, t);
-    else
-      hipLaunchKernelGGL(k_halve_step, dim3((unsigned)((4 * total + 127) / 128), (unsigned)red_windows), dim3(128), 0, s, buckets, sh.lgB, t);
-  }
-  if (L.merged) {
-    if (rows) MZK_TRY(launch_reduce_tail_row(buckets, sh.lgB, t_start, 1, (u32*)d_out, out_partial_xyzz ? 0 : 1, s));
-    else hipLaunchKernelGGL(k_reduce_tail, dim3(1), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, t_start, (u32*)d_out, out_partial_xyzz ? 0 : 1);
-    MZK_HIP(hipGetLastError());
-    prof_end(s, MZK_PH_MSM_REDUCE);
-  } else {
-    if (rows) MZK_TRY(launch_reduce_tail_row(buckets, sh.lgB, t_start, red_windows, wsum, 0, s));
-    else hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)red_windows), dim3(TAIL_THREADS), 0, s, buckets, sh.lgB, t_start, wsum, 0);
-    MZK_HIP(hipGetLastError());
-    prof_end(s, MZK_PH_MSM_REDUCE);
-    prof_begin(s, MZK_PH_MSM_COMBINE);
-    MZK_TRY((rows ? launch_window_combine_row : launch_window_combine)((const u32*)wsum, red_windows, horner_c, out_partial_xyzz ? 1 : 0, (u32*)d_out, s));
-    prof_end(s, MZK_PH_MSM_COMBINE);
-  }
+  MZK_TRY(reduce_bucket_sets(buckets, sh.lgB, red_windows, L.merged != 0, horner_c, wsum, (u32*)d_out, out_partial_xyzz, s));
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }

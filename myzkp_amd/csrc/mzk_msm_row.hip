@@ -46,61 +46,134 @@ __device__ __forceinline__ void halve_indices(int lgB, int t, size_t id, size_t*
   *lo = ((a == 0) ? 0 : ((size_t)1 << (lgB - a))) + j;
   *hi = *lo + ((size_t)1 << lgh);
 }
-__device__ __forceinline__ void halve_op_row(u32* __restrict__ buf, int lgB, int t, size_t id, const Lane& ln) {
-  size_t lo, hi;
-  halve_indices(lgB, t, id, &lo, &hi);
-  const Pt x = rowop::load(buf + lo * 32, ln), y = rowop::load(buf + hi * 32, ln);
-  rowop::store(buf + lo * 32, rowop::add(x, y, ln), ln);
-}
-__device__ __forceinline__ void halve_op_quad(u32* __restrict__ buf, int lgB, int t, size_t id, int lane) {
+__device__ __noinline__ void halve_op_quad(u32* __restrict__ buf, int lgB, int t, size_t id, int lane) {
   size_t lo, hi;
   halve_indices(lgB, t, id, &lo, &hi);
   const Xyzz x = xyzz_gload_quad(buf, lo, lane), y = xyzz_gload_quad(buf, hi, lane);
   xyzz_gstore_quad(buf, lo, xyzz_add_quad(x, y, lane), lane);
 }
 
-constexpr int RTAIL_THREADS = 1024;
+// -DMZK_TAIL_TRACE (what-if builds only, tools/timing/tail_trace.py): 100-MHz timestamps of the tail's phases
+#ifdef MZK_TAIL_TRACE
+__device__ unsigned long long g_tail_trace[64];
+#define MZK_TT(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { g_tail_trace[(i)] = wall_clock64(); if ((i) == 0 || (i) == 60) g_tail_trace[(i) + 1 + ((i) == 0 ? 61 : 0)] = clock64(); } } while (0)
+extern "C" int mzk_debug_tail_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_trace), sizeof(g_tail_trace)) == hipSuccess ? 0 : -1;
+}
+#else
+#define MZK_TT(i)
+#endif
+
+constexpr int RTAIL_THREADS = 256;               // four waves = one per SIMD: see below
 constexpr int RTAIL_WAVES = RTAIL_THREADS / 64;
 constexpr int RTAIL_QUADS = RTAIL_THREADS / 4;
-constexpr int RTAIL_ROW_MAX = RTAIL_WAVES;       // a step of at most one round of waves runs on row operations, wider ones on quads
-// Remaining steps t_start .. lgB-1 of a bucket set inside one workgroup, then  buf[0] + sum_j 2^j buf[2^j]  (wave j doubles
-// buf[2^j] j times; tree sum through LDS) and, for a single bucket set, the affine conversion (one safegcd inversion).
-__global__ __launch_bounds__(RTAIL_THREADS) void k_reduce_tail_row(u32* __restrict__ buckets, int lgB, int t_start, u32* __restrict__ out, int finish_affine) {
-  __shared__ __attribute__((aligned(16))) u32 sh[32 * 32];
+constexpr int RTAIL_LDS_SLOTS = 512;             // live entries the workgroup keeps in LDS (64 KiB) once they fit
+constexpr int RTAIL_GROUPS = 4;                  // Horner groups of the weighted sum: one wave per SIMD
+struct TailPlan { int b[RTAIL_GROUPS + 1]; };    // wave g sums the terms q in [b[g], b[g + 1])
+
+// ONE copy of the group operations that the tail runs once here and once there: what such code waits for is its own
+// instruction fetch as much as the arithmetic (the fully inlined kernel was 142 KB against a 64-KB instruction cache;
+// tools/timing/tail_trace.py).  Loops keep their operations inlined: a call costs ~0.25 us of register saves and restores.
+__device__ __noinline__ Pt row_add_shared(Pt a, Pt b, Lane ln) { return rowop::add(a, b, ln); }
+// buf[lo] += buf[hi] by a DPP quad; buf in LDS or global memory
+__device__ __noinline__ void quad_add_lds(int lo, int hi, int ql) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  const Xyzz x = xyzz_gload_quad(lds, (size_t)lo, ql), y = xyzz_gload_quad(lds, (size_t)hi, ql);
+  xyzz_gstore_quad(lds, (size_t)lo, xyzz_add_quad(x, y, ql), ql);
+}
+
+// Remaining steps t_start .. lgB-1 of a bucket set inside one workgroup, then  buf[0] + sum_q 2^q buf[2^q]  and, for a single
+// bucket set, the affine conversion (one safegcd inversion).
+// One CU's issue rate bounds this kernel, not only the chain (tools/timing/tail_trace.py: a row operation keeps its SIMD
+// ~85 % busy -- four waves of a SIMD doubling at once took 1.9 us per doubling each, not 1.0 -- and 1024 lanes of quad
+// additions were capped at 128 VGPRs and spilled).  Hence
+//  * four waves, one per SIMD, 256 VGPRs each; the host hands over at steps of <= 64 additions (one round of 64 quads);
+//  * the live entries move into LDS as soon as they fit (no global round trip per step);
+//  * a step runs on row operations only when it has at most `row_max` (<= 4) additions, on DPP quads above;
+//  * the weighted sum is FOUR Horner chains (terms split by the host so that the chains are equally long: max(G) doublings +
+//    |G| - 1 additions each) and a two-level tree -- 44 doublings for 16 terms where "wave q doubles q times" needed 120.
+__global__ __launch_bounds__(RTAIL_THREADS) void k_reduce_tail_row(u32* __restrict__ buckets, int lgB, int t_start, u32* __restrict__ out, int finish_affine,
+                                                                   int row_max, TailPlan plan) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds[];
+  u32* res = lds + RTAIL_LDS_SLOTS * 32;
   u32* buf = buckets + ((size_t)blockIdx.x << lgB) * 32;
   const Lane ln = rowop::lane_init();
   const int wave = threadIdx.x >> 6;
-  for (int t = t_start; t < lgB; t++) {
+  MZK_TT(0);
+  int t = t_start;
+  for (; t < lgB && ((size_t)(t + 1) << (lgB - t)) > (size_t)RTAIL_LDS_SLOTS; t++) {      // too many live entries for LDS: in place
     const size_t total = (size_t)(t + 1) << (lgB - t - 1);
-    if (total > RTAIL_ROW_MAX) {
-      for (size_t id = threadIdx.x >> 2; id < total; id += RTAIL_QUADS) halve_op_quad(buf, lgB, t, id, (int)(threadIdx.x & 3));
-    } else {
-      for (size_t id = wave; id < total; id += RTAIL_WAVES) halve_op_row(buf, lgB, t, id, ln);
-    }
+    for (size_t id = threadIdx.x >> 2; id < total; id += RTAIL_QUADS) halve_op_quad(buf, lgB, t, id, (int)(threadIdx.x & 3));
     __syncthreads();
+    MZK_TT(1 + t);
   }
-  for (int q = wave; q < 32; q += RTAIL_WAVES) {
-    Pt v = rowop::pt_inf();
-    if (q < lgB) {
-      v = rowop::load(buf + ((size_t)1 << q) * 32, ln);
-      for (int d = 0; d < q; d++) v = rowop::dbl(v, ln);
-      if (q == 0) v = rowop::add(v, rowop::load(buf, ln), ln);      // the unweighted sum rides with the term that needs no doubling
+  // live now: region 0 = [0, W) and regions a = 1 .. t0 = [2^(lgB - a), + W), W = 2^(lgB - t0); region a -> LDS slots [a W, + W).
+  // The regions the later steps create (a > t0) lie inside region 0's slots, at their global index.
+  const int t0 = t, lgW = lgB - t0;
+  {
+    const int n16 = ((t0 + 1) << lgW) * 8;
+    for (int k = threadIdx.x; k < n16; k += RTAIL_THREADS) {
+      const int e = k >> 3, a = e >> lgW, j = e & ((1 << lgW) - 1);
+      const size_t src = (a ? ((size_t)1 << (lgB - a)) : 0) + (size_t)j;
+      reinterpret_cast<uint4*>(lds)[k] = reinterpret_cast<const uint4*>(buf + src * 32)[k & 7];
     }
-    rowop::store(sh + q * 32, v, ln);
   }
   __syncthreads();
-  for (int off = 16; off >= 1; off >>= 1) {
-    for (int q = wave; q < off; q += RTAIL_WAVES) {
-      const Pt a = rowop::load(sh + q * 32, ln), b = rowop::load(sh + (q + off) * 32, ln);
-      rowop::store(sh + q * 32, rowop::add(a, b, ln), ln);
+  MZK_TT(39);
+  for (; t < lgB; t++) {
+    const int lgh = lgB - t - 1;
+    const int total = (t + 1) << lgh;
+    if (total > row_max) {
+      for (int id = threadIdx.x >> 2; id < total; id += RTAIL_QUADS) {
+        const int a = id >> lgh, j = id & ((1 << lgh) - 1);
+        const int lo = ((a == 0) ? 0 : (a > t0) ? (1 << (lgB - a)) : (a << lgW)) + j;
+        quad_add_lds(lo, lo + (1 << lgh), (int)(threadIdx.x & 3));
+      }
+    } else {
+      for (int id = wave; id < total; id += RTAIL_WAVES) {
+        const int a = id >> lgh, j = id & ((1 << lgh) - 1);
+        const int lo = ((a == 0) ? 0 : (a > t0) ? (1 << (lgB - a)) : (a << lgW)) + j;
+        const Pt x = rowop::load(lds + lo * 32, ln), y = rowop::load(lds + (lo + (1 << lgh)) * 32, ln);
+        rowop::store(lds + lo * 32, row_add_shared(x, y, ln), ln);
+      }
     }
     __syncthreads();
+    MZK_TT(1 + t);
   }
+  {
+    // term q = 2^q buf[2^q]; buf[2^q] is the start of region lgB - q
+    auto term = [&](int q) { const int a = lgB - q; return rowop::load(lds + ((a > t0) ? (1 << q) : (a << lgW)) * 32, ln); };
+    const int lo = plan.b[wave], hi = plan.b[wave + 1];
+    // one chain: v = term(hi-1); then for k = hi-2 .. 0: v = 2 v (+ term(k) while k >= lo); wave 0 ends with + buf[0].
+    // ONE inlined doubling and ONE inlined addition in a loop (hot after the first trip; a call costs ~0.25 us in saves / restores)
+    Pt v = (hi > lo) ? term(hi - 1) : rowop::pt_inf();
+#pragma unroll 1
+    for (int k = (hi > lo) ? hi - 2 : -1; k >= -1; k--) {
+      if (k >= 0) v = rowop::dbl(v, ln);
+      if (k >= lo || (k < 0 && wave == 0)) v = rowop::add(v, (k >= 0) ? term(k) : rowop::load(lds, ln), ln);
+    }
+    rowop::store(res + wave * 32, v, ln);
+  }
+  __syncthreads();
+  MZK_TT(40);
+  if (wave < 2) {
+    const Pt x = rowop::load(res + wave * 32, ln), y = rowop::load(res + (wave + 2) * 32, ln);
+    rowop::store(res + wave * 32, row_add_shared(x, y, ln), ln);
+  }
+  __syncthreads();
+  MZK_TT(41);
+  if (wave != 0) return;
+  {
+    const Pt x = rowop::load(res, ln), y = rowop::load(res + 32, ln);
+    rowop::store(res, row_add_shared(x, y, ln), ln);
+  }
+  MZK_TT(42);
   if (finish_affine) {
-    if (wave == 0) wave_store_affine(sh, out);
+    wave_store_affine(res, out);
+    MZK_TT(60);
     return;
   }
-  if (threadIdx.x < 32) out[(size_t)blockIdx.x * 32 + threadIdx.x] = sh[threadIdx.x];
+  if (threadIdx.x < 32) out[(size_t)blockIdx.x * 32 + threadIdx.x] = res[threadIdx.x];
 }
 
 // total = sum_w 2^(c w) R_w (Horner over the bucket sets of the generic layout: c doublings per window, inherently serial)
@@ -129,8 +202,43 @@ __global__ __launch_bounds__(64) void k_fold_partials_row(const u32* __restrict_
   wave_store_affine(sh, out);
 }
 
+// Horner groups for lgB terms: contiguous ranges [b[g], b[g + 1]), g = 0 .. 3, minimising the longest chain --
+// (top term) doublings + (terms - 1) additions, group 0 one addition more (the unweighted sum); 1.0 / 1.4 us each.
+static TailPlan tail_plan(int lgB) {
+  static TailPlan cache[32];
+  static bool have[32];
+  if (lgB < 0 || lgB >= 32) lgB = 31;
+  if (have[lgB]) return cache[lgB];
+  auto cost = [](int g, int lo, int hi) { return hi > lo ? 10 * (hi - 1) + 14 * (hi - lo - 1) + (g == 0 ? 14 : 0) : 0; };
+  TailPlan best{};
+  int best_max = 1 << 30, best_sum = 1 << 30;
+  for (int b1 = 0; b1 <= lgB; b1++)
+    for (int b2 = b1; b2 <= lgB; b2++)
+      for (int b3 = b2; b3 <= lgB; b3++) {
+        const int b[5] = {0, b1, b2, b3, lgB};
+        int mx = 0, sum = 0;
+        for (int g = 0; g < 4; g++) { const int c = cost(g, b[g], b[g + 1]); mx = c > mx ? c : mx; sum += c; }
+        if (mx < best_max || (mx == best_max && sum < best_sum)) {
+          best_max = mx; best_sum = sum;
+          for (int g = 0; g < 5; g++) best.b[g] = b[g];
+        }
+      }
+  cache[lgB] = best; have[lgB] = true;
+  return best;
+}
+static int tail_row_max() {      // widest step that still runs as row operations (A/B: tools/timing/small_latency.py)
+  static const int v = getenv("MZK_TAIL_ROW_MAX") ? atoi(getenv("MZK_TAIL_ROW_MAX")) : 4;
+  return v;
+}
 int launch_reduce_tail_row(u32* buckets, int lgB, int t_start, int sets, u32* out, int finish_affine, hipStream_t s) {
-  hipLaunchKernelGGL(k_reduce_tail_row, dim3((unsigned)sets), dim3(RTAIL_THREADS), 0, s, buckets, lgB, t_start, out, finish_affine);
+  constexpr size_t LDS_BYTES = (size_t)(RTAIL_LDS_SLOTS + RTAIL_GROUPS) * 128;
+  bool& configured = ctx().attr_done[ATTR_TAIL_ROW];
+  if (!configured) {
+    MZK_HIP(hipFuncSetAttribute((const void*)k_reduce_tail_row, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    configured = true;
+  }
+  hipLaunchKernelGGL(k_reduce_tail_row, dim3((unsigned)sets), dim3(RTAIL_THREADS), LDS_BYTES, s, buckets, lgB, t_start, out, finish_affine, tail_row_max(),
+                     tail_plan(lgB));
   return MZK_OK;
 }
 int launch_window_combine_row(const u32* wsum, int nwin, int c, int out_xyzz, u32* out, hipStream_t s) {
