@@ -3,10 +3,12 @@
 //
 // Every MSM, fold and small commit ends in one Fq inversion (XYZZ -> affine), a ~9000-instruction dependent chain on a single
 // lane: 35 us of the ~46 us conversion (profiles/r03l_*).  Half of those instructions are the per-batch updates of f, g, d, e
-// (9 limbs each, limb-serial carries).  Here limb i of each of the four numbers lives in lane i, so an update is four
-// v_mad_i64_i32 per lane and a re-cut of the 64-bit lane values at 30-bit boundaries (low piece one lane down, top piece one lane
-// up, DPP), followed by an exact carry resolution from generate / propagate ballots (the sign of d, e and the zero test of g
-// need canonical limbs); the 30 divsteps of a batch run on wave-uniform values (f_0, g_0 by v_readlane), i.e. on the scalar unit.
+// (9 limbs each, limb-serial carries).  Here the four numbers live in the four 16-lane rows of the wave, limb i in lane i of
+// the row, so the whole update of a batch is three v_mad_i64_i32 per lane (the partner number arrives by v_permlane16_swap)
+// and ONE re-cut of the 64-bit lane values at 30-bit boundaries (low piece one lane down, top piece one lane up, DPP),
+// followed by an exact carry resolution from generate / propagate ballots (the sign of d, e and the zero test of g need
+// canonical limbs; lanes 9..15 of a row hold zeros, so no carry crosses a row); the 30 divsteps of a batch run on wave-uniform
+// values (f_0, g_0 by v_readlane), i.e. on the scalar unit.
 // Same algorithm, same batches, same result as fe_inv_safegcd (checked by mzk_selftest_inv_wave).
 //
 // Call with all 64 lanes of a wave active and the SAME argument in every lane; every lane returns the result.
@@ -59,7 +61,7 @@ template <class P> __device__ __forceinline__ Fe<P> inv(const Fe<P>& a) {
   constexpr int NW = P::NW;
   constexpr int NL = (32 * NW + 29) / 30;
   static_assert(NL <= 9, "one row of 16 lanes holds the limbs");
-  const int j = (int)(threadIdx.x & 15);
+  const int lane = (int)(threadIdx.x & 63), j = lane & 15, row = lane >> 4;
   u32 xw[NW], pw[NW];
   {
     Fe<P> c = fe_reduce<P>(a);
@@ -71,11 +73,13 @@ template <class P> __device__ __forceinline__ Fe<P> inv(const Fe<P>& a) {
   Sgn30<NL> mod, x0;
   sg_from_words<NW, NL>(pw, &mod);
   sg_from_words<NW, NL>(xw, &x0);
-  // distribute: lane i takes limb i (every row of the wave holds the same copy)
-  i32 modl = 0, f = 0, g = 0, d = 0, e = (j == 0) ? 1 : 0;
+  // the four numbers of the algorithm in the four rows of the wave, limb i in lane i of the row:
+  // row 0 = f (= p), row 1 = g (= x), row 2 = d (= 0), row 3 = e (= 1)
+  i32 modl = 0, xl = 0;
 #pragma unroll
-  for (int i = 0; i < NL; i++) { modl = (j == i) ? mod.v[i] : modl; g = (j == i) ? x0.v[i] : g; }
-  f = modl;
+  for (int i = 0; i < NL; i++) { modl = (j == i) ? mod.v[i] : modl; xl = (j == i) ? x0.v[i] : xl; }
+  i32 x = (row == 0) ? modl : (row == 1) ? xl : (row == 3 && j == 0) ? 1 : 0;
+  const bool odd = (row & 1) != 0, de = (row & 2) != 0;
   u32 pinv = (u32)mod.v[0];
 #pragma unroll
   for (int it = 0; it < 4; it++) pinv *= 2 - (u32)mod.v[0] * pinv;
@@ -85,26 +89,28 @@ template <class P> __device__ __forceinline__ Fe<P> inv(const Fe<P>& a) {
   for (int batch = 0; batch < 32; batch++) {
     // 30 divsteps on the low limbs: wave-uniform, scalar unit
     DivMat t;
-    const u32 f0 = (u32)__builtin_amdgcn_readlane(f, 0), g0 = (u32)__builtin_amdgcn_readlane(g, 0);
+    const u32 f0 = (u32)__builtin_amdgcn_readlane(x, 0), g0 = (u32)__builtin_amdgcn_readlane(x, 16);
     eta = sg_divsteps_30(eta, f0, g0, &t);
-    const i32 d0 = __builtin_amdgcn_readlane(d, 0), e0 = __builtin_amdgcn_readlane(e, 0);
-    const i32 sd = __builtin_amdgcn_readlane(d, NL - 1) >> 31, se = __builtin_amdgcn_readlane(e, NL - 1) >> 31;
+    const i32 d0 = __builtin_amdgcn_readlane(x, 32), e0 = __builtin_amdgcn_readlane(x, 48);
+    const i32 sd = __builtin_amdgcn_readlane(x, 32 + NL - 1) >> 31, se = __builtin_amdgcn_readlane(x, 48 + NL - 1) >> 31;
     i32 md = (t.u & sd) + (t.v & se), me = (t.q & sd) + (t.r & se);
     md -= (i32)((pinv * (u32)((int64_t)t.u * d0 + (int64_t)t.v * e0) + (u32)md) & M30);
     me -= (i32)((pinv * (u32)((int64_t)t.q * d0 + (int64_t)t.r * e0) + (u32)me) & M30);
-    // every lane: its limb of t (f, g) and of t (d, e) + (md, me) mod -- exact multiples of 2^30 -- then the division by 2^30
-    const int64_t tf = (int64_t)t.u * f + (int64_t)t.v * g, tg = (int64_t)t.q * f + (int64_t)t.r * g;
-    const int64_t td = (int64_t)t.u * d + (int64_t)t.v * e + (int64_t)modl * md;
-    const int64_t te = (int64_t)t.q * d + (int64_t)t.r * e + (int64_t)modl * me;
-    f = recut_div30(tf, j, bias); g = recut_div30(tg, j, bias);
-    d = recut_div30(td, j, bias); e = recut_div30(te, j, bias);
-    if (__builtin_amdgcn_ballot_w64(g != 0) == 0) break;
+    // rows 0, 1: t (f, g); rows 2, 3: t (d, e) + (md, me) p -- each lane its limb of its row's number (exact multiples of
+    // 2^30), then ONE re-cut divides all four by 2^30.  The partner number comes by v_permlane16_swap:
+    // [f g d e] -> [f f d d], [g g e e].
+    const auto sw = __builtin_amdgcn_permlane16_swap((u32)x, (u32)x, false, false);
+    const i32 first = (i32)sw[0], second = (i32)sw[1];
+    const i32 ca = odd ? t.q : t.u, cb = odd ? t.r : t.v, cm = de ? (odd ? me : md) : 0;
+    const int64_t tt = (int64_t)ca * first + (int64_t)cb * second + (int64_t)cm * modl;
+    x = recut_div30(tt, j, bias);
+    if ((__builtin_amdgcn_ballot_w64(x != 0) & 0x00000000ffff0000ull) == 0) break;       // g == 0
   }
   // f = +-1, d = +-x^-1 in (-2p, p): the few remaining steps on wave-uniform scalars, as fe_inv_safegcd
   Sgn30<NL> dd;
 #pragma unroll
-  for (int i = 0; i < NL; i++) dd.v[i] = __builtin_amdgcn_readlane(d, i);
-  sg_normalize<NL>(&dd, __builtin_amdgcn_readlane(f, NL - 1), &mod);
+  for (int i = 0; i < NL; i++) dd.v[i] = __builtin_amdgcn_readlane(x, 32 + i);
+  sg_normalize<NL>(&dd, __builtin_amdgcn_readlane(x, NL - 1), &mod);
   u32 rw[NW];
   sg_to_words<NW, NL>(&dd, rw);
   Fe<P> r3;

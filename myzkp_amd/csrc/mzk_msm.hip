@@ -959,27 +959,11 @@ __global__ __launch_bounds__(SMALL_SORT_THREADS) void k_small_sort(const u32* __
     walk_digits(w, L, i, [&](int, u32 key, u32 payload) { entries[atomicAdd(&hist[key], 1u)] = payload; });
   }
 }
-// T lanes per bucket (64: few entries per bucket -- the generic layout's thousands of buckets; 256: the commit against narrow
-// window tables, ~256 entries per bucket at 2^10 coefficients: one entry per lane, so the per-lane chain of mixed additions
-// (4 x ~4.5 us with 64 lanes) disappears and only the tree remains).  The tree adds partial i + m/2 onto partial i in place.
+// The T per-lane partials of a bucket (the first min(cnt, T) can be non-trivial) -> their sum in buckets[b]: a tree in place
+// through LDS, DPP quads while a level has more pairs than waves, one row-cooperative addition per wave below.
 template <int T>
-__global__ __launch_bounds__(T) void k_small_accumulate(const u32* __restrict__ points_mont, const u32* __restrict__ offsets,
-                                                         const u32* __restrict__ entries, u32* __restrict__ buckets) {
-  __shared__ __attribute__((aligned(16))) u32 sh[T * 32];
-  const size_t b = blockIdx.x;
+__device__ __forceinline__ void small_tree_store(u32* sh, const Xyzz& acc, u32 cnt, size_t b, u32* __restrict__ buckets) {
   const int lane = threadIdx.x;
-  const u32 o0 = offsets[b], o1 = offsets[b + 1];
-  Xyzz acc = xyzz_inf();
-  for (u32 e = o0 + lane; e < o1; e += T) {
-    const u32 ent = entries[e];
-    u32 w[16];
-    const size_t idx = ent & 0x7fffffffu;
-    load_words8(points_mont + idx * 16, w);
-    load_words8(points_mont + idx * 16 + 8, w + 8);
-    if (affine_words_is_inf(w)) continue;
-    acc = xyzz_madd_signed_with<FeCpp>(acc, affine_load_mont(w), (ent >> 31) != 0);
-  }
-  u32 cnt = o1 - o0;
   if (cnt > T) cnt = T;
   if (cnt <= 1) {            // workgroup-uniform
     if (lane == 0) xyzz_gstore(buckets, b, acc);
@@ -1007,6 +991,105 @@ __global__ __launch_bounds__(T) void k_small_accumulate(const u32* __restrict__ 
   }
   if (lane < 32) buckets[b * 32 + lane] = sh[lane];
 }
+
+// T lanes per bucket (64: few entries per bucket -- the generic layout's thousands of buckets; 256: the commit against narrow
+// window tables, ~256 entries per bucket at 2^10 coefficients: one entry per lane, so the per-lane chain of mixed additions
+// (4 x ~4.5 us with 64 lanes) disappears and only the tree remains).  The tree adds partial i + m/2 onto partial i in place.
+template <int T>
+__global__ __launch_bounds__(T) void k_small_accumulate(const u32* __restrict__ points_mont, const u32* __restrict__ offsets,
+                                                         const u32* __restrict__ entries, u32* __restrict__ buckets) {
+  __shared__ __attribute__((aligned(16))) u32 sh[T * 32];
+  const size_t b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const u32 o0 = offsets[b], o1 = offsets[b + 1];
+  Xyzz acc = xyzz_inf();
+  for (u32 e = o0 + lane; e < o1; e += T) {
+    const u32 ent = entries[e];
+    u32 w[16];
+    const size_t idx = ent & 0x7fffffffu;
+    load_words8(points_mont + idx * 16, w);
+    load_words8(points_mont + idx * 16 + 8, w + 8);
+    if (affine_words_is_inf(w)) continue;
+    acc = xyzz_madd_signed_with<FeCpp>(acc, affine_load_mont(w), (ent >> 31) != 0);
+  }
+  small_tree_store<T>(sh, acc, o1 - o0, b, buckets);
+}
+// The same for a commit against window tables WITHOUT the sort launch: every workgroup walks all n scalars itself (n <= 4096:
+// n / T scalars per lane, ~10 instructions per digit -- a few microseconds against the ~30 of k_small_sort's launch) and
+// collects the entries of ITS bucket in an LDS list; entries beyond the list's capacity (degenerate inputs: all scalars equal)
+// are added on the spot by the lane that found them.  Merged layout only: the generic one would repeat the GLV split of
+// every scalar in every workgroup.
+constexpr int SMALL_LIST_CAP = 2048;
+// Signed c-bit digits without the serial carry walk: with t = k + sum_w (2^(c-1) - 1) 2^(c w) the digit of window w is
+// window_w(t) - (2^(c-1) - 1) (the carries of that ONE long addition are exactly the recoding's carries: window w overflows iff
+// raw_w + carry > 2^(c-1)), same digits as walk_digits.  Word k of the constant, C a compile-time width:
+constexpr u32 digit_bias_word(int C, int k) {
+  const int nwin = 254 / C + 1;
+  const unsigned long long hm1 = (1ull << (C - 1)) - 1;
+  unsigned long long acc = 0;
+  for (int w = 0; w < nwin; w++) {
+    const int sh = w * C - 32 * k;
+    if (sh >= 0 && sh < 32) acc |= (hm1 << sh) & 0xffffffffull;
+    else if (sh < 0 && sh > -32) acc |= hm1 >> (-sh);
+  }
+  return (u32)acc;
+}
+template <int T, int C>
+__global__ __launch_bounds__(T) void k_small_accumulate_scan(const u32* __restrict__ scalars, size_t n, size_t table_stride, const u32* __restrict__ points_mont,
+                                                              u32* __restrict__ buckets) {
+  constexpr int NWIN = 254 / C + 1;
+  constexpr u32 HALF = 1u << (C - 1), MASKC = (1u << C) - 1u;
+  __shared__ __attribute__((aligned(16))) u32 sh[T * 32];
+  __shared__ u32 list[SMALL_LIST_CAP];
+  __shared__ u32 count;
+  const size_t b = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (lane == 0) count = 0;
+  __syncthreads();
+  Xyzz acc = xyzz_inf();
+  auto add_entry = [&](u32 ent) {
+    u32 w[16];
+    const size_t idx = ent & 0x7fffffffu;
+    load_words8(points_mont + idx * 16, w);
+    load_words8(points_mont + idx * 16 + 8, w + 8);
+    if (affine_words_is_inf(w)) return;
+    acc = xyzz_madd_signed_with<FeCpp>(acc, affine_load_mont(w), (ent >> 31) != 0);
+  };
+  // window values of this bucket: digit +(b + 1) and -(b + 1)
+  const u32 vpos = (u32)b + HALF, vneg = HALF - 2u - (u32)b;
+  for (size_t i = lane; i < n; i += T) {
+    u32 w[8], t[9];
+    load_scalar_canonical(scalars, i, w);
+    u64 cy = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { cy += (u64)w[k] + digit_bias_word(C, k); t[k] = (u32)cy; cy >>= 32; }
+    t[8] = (u32)cy + digit_bias_word(C, 8);
+    u32 hits = 0;          // bit w: window w belongs to this bucket (NWIN <= 32)
+    u32 negs = 0;
+#pragma unroll
+    for (int win = 0; win < NWIN; win++) {
+      const int bit = win * C, k = bit >> 5, sft = bit & 31;
+      const u64 pair = (u64)t[k] | ((k + 1 < 9) ? ((u64)t[k + 1] << 32) : 0ull);
+      const u32 v = (u32)(pair >> sft) & MASKC;
+      hits |= (v == vpos || v == vneg) ? (1u << win) : 0u;
+      negs |= (v == vneg) ? (1u << win) : 0u;
+    }
+    while (hits) {
+      const int win = __builtin_ctz(hits);
+      hits &= hits - 1;
+      const u32 payload = (u32)((size_t)win * table_stride + i) | (((negs >> win) & 1u) << 31);
+      const u32 pos = atomicAdd(&count, 1u);
+      if (pos < (u32)SMALL_LIST_CAP) list[pos] = payload;
+      else add_entry(payload);
+    }
+  }
+  __syncthreads();
+  const u32 total = count;
+  const u32 listed = total < (u32)SMALL_LIST_CAP ? total : (u32)SMALL_LIST_CAP;
+  for (u32 e = lane; e < listed; e += T) add_entry(list[e]);
+  small_tree_store<T>(sh, acc, total > (u32)SMALL_LIST_CAP ? (u32)T : total, b, buckets);
+}
+static_assert(254 / 8 + 1 <= 32, "window hit masks are 32 bits");
 
 // k_window_combine / k_fold_partials live in mzk_msm_tail.hip (compact-code build).
 int launch_window_combine(const u32* wsum, int nwin, int c, int out_xyzz, u32* out, hipStream_t s);
@@ -1204,6 +1287,20 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     MZK_TRY(ws_get(WS_MSM_BUCKETS, NB * 128, (void**)&buckets));
     MZK_TRY(ws_get(WS_MSM_OUT, (size_t)MAX_WINDOWS * 128, (void**)&wsum));
     MZK_TRY(prepare());
+    static const int env_scan = getenv("MZK_SMALL_SCAN") ? atoi(getenv("MZK_SMALL_SCAN")) : 1;     // 0: A/B against the sorted path
+    if (L.merged && env_scan && (L.c == 8 || L.c == 10 || L.c == 13)) {      // two launches: every bucket's workgroup finds its own entries
+      prof_begin(s, MZK_PH_MSM_ACCUMULATE);
+      if (L.c == 8)
+        hipLaunchKernelGGL((k_small_accumulate_scan<256, 8>), dim3((unsigned)NB), dim3(256), 0, s, (const u32*)d_scalars, n, L.table_stride, pts, buckets);
+      else if (L.c == 10)
+        hipLaunchKernelGGL((k_small_accumulate_scan<256, 10>), dim3((unsigned)NB), dim3(256), 0, s, (const u32*)d_scalars, n, L.table_stride, pts, buckets);
+      else
+        hipLaunchKernelGGL((k_small_accumulate_scan<256, 13>), dim3((unsigned)NB), dim3(256), 0, s, (const u32*)d_scalars, n, L.table_stride, pts, buckets);
+      prof_end(s, MZK_PH_MSM_ACCUMULATE);
+      MZK_TRY(reduce_bucket_sets(buckets, sh.lgB, red_windows, true, horner_c, wsum, (u32*)d_out, out_partial_xyzz, s));
+      MZK_HIP(hipGetLastError());
+      return MZK_OK;
+    }
     prof_begin(s, MZK_PH_MSM_SORT);
     hipLaunchKernelGGL(k_small_sort, dim3(1), dim3(SMALL_SORT_THREADS), (NB + SMALL_SORT_THREADS) * 4, s, (const u32*)d_scalars, n, L, (int)NB, offsets, entries);
     prof_end(s, MZK_PH_MSM_SORT);

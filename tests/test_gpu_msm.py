@@ -158,6 +158,24 @@ def test_skewed_scalars_merged_two_level_sort(mz):
     h.close()
 
 
+@pytest.mark.parametrize("n", [5, 700, 1024, 3000, 4096])
+def test_small_commit_without_sort_launch_skewed_scalars(mz, n):
+    """Commits of at most 4096 coefficients against narrow window tables (8 / 10 bits) find every bucket's entries by
+    walking the scalars inside the accumulate kernel (k_small_accumulate_scan, no sort launch): uniform scalars, and
+    the skew patterns that overflow the per-bucket LDS list (all scalars equal: one bucket per window gets n entries,
+    'ones': one bucket gets all of them), infinity entries in the SRS included."""
+    p = orc.synth_points(4242 + n, n)
+    if n > 100:
+        p[7:9] = 0
+    h = mz.Srs(p)
+    sets = _skewed_scalar_sets(n, 77 + n)
+    sets["uniform"] = orc.synth_vector(FR, 78 + n, n)
+    sets["same_digit_everywhere"] = np.tile(orc.to_limbs([sum(5 << (8 * w) for w in range(31))], 4), (n, 1))
+    for name, s in sets.items():
+        assert h.commit(s) == orc.msm_fast(s, p), name
+    h.close()
+
+
 def test_skewed_scalars_generic_two_level_sort(mz):
     """generic layout takes the two-level sort from n = 2^19 (c = 16); heavy buckets there go through
     k_seg_combine_wide's deferral"""
