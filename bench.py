@@ -226,7 +226,7 @@ def main():
             L.mzk_srs_free(hh)
     srs._h = hh
     # msm_srs_window_bits (mzk_common.h): the default window width of an SRS handle by its size
-    srs_window_bits = 8 if n <= 1024 else (10 if n <= 4096 else (13 if n < (1 << 14) else (16 if n < (1 << 19) else 17)))
+    srs_window_bits = 8 if n <= 1024 else (10 if n <= (1 << 14) else (16 if n < (1 << 19) else 17))
     srs_table_windows = 254 // srs_window_bits + 1
     progress("SRS handle built")
     # The HIP runtime stalls once for 35-45 ms a few thousand dispatches into a process (measured: one stall in 120 000

@@ -397,11 +397,11 @@ int mzk_kzg_open_quotient_dev(const void* d_coef, size_t n, const uint64_t u_hos
 /* Build an SRS handle from points already in HBM (affine canonical, n * 8 limbs).  The _ex form chooses
  * whether the window tables are built (worth it from ~30 commits per SRS on at 2^20 points; a one-shot pipeline keeps
  * the plain prepared points and pays the window Horner instead).  Default widths by size: 8 bits up to 1024 points,
- * 10 up to 4096, 13 below 2^14, 16 below 2^19, 17 from there on (254 / c + 1 tables of n points each: 15 at 17 bits;
+ * 10 up to 2^14, 16 below 2^19, 17 from there on (254 / c + 1 tables of n points each: 15 at 17 bits;
  * measured per size, profiles/r03b_window_sweep.txt). */
 int mzk_srs_from_device(const void* d_powers_xy, size_t n, mzk_srs** out, void* stream);
 int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, mzk_srs** out, void* stream);
-/* with_tables: 0 = plain prepared points, 1 = tables with the default window width for n (above), 12..22 = that window width
+/* with_tables: 0 = plain prepared points, 1 = tables with the default window width for n (above), 8..22 = that window width
  * (tuning / tests, and BASELINE configs[2]'s 16 bits at any size; wider windows than the default were measured and do not
  * pay). */
 

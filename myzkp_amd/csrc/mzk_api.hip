@@ -1057,7 +1057,7 @@ int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, m
   WsGuard wsg((hipStream_t)stream);
   if (!out || (!d_powers_xy && n)) { set_error("srs_from_device: null pointer"); return MZK_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
-  if (with_tables < 0 || (with_tables > 1 && (with_tables < 12 || with_tables > 22))) { set_error("srs_from_device: with_tables must be 0, 1 or a window width 12..22"); return MZK_E_ARG; }
+  if (with_tables < 0 || (with_tables > 1 && (with_tables < 8 || with_tables > 22))) { set_error("srs_from_device: with_tables must be 0, 1 or a window width 8..22"); return MZK_E_ARG; }
   mzk_srs* h = new mzk_srs{nullptr, n, with_tables > 1 || (with_tables && msm_srs_default_tables(n)), with_tables > 1 ? with_tables : msm_srs_window_bits(n), ctx().index};
   if (n) {
     void* d_mont;

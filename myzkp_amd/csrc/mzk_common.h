@@ -161,13 +161,13 @@ enum { MSM_PTS_PLAIN = 0, MSM_PTS_MONT = 1, MSM_PTS_TABLES = 2 };
 // Other widths stay selectable through mzk_srs_from_device_ex for tuning and tests (BASELINE configs[2] names 16 bits:
 // bench.py reports that width as its own leg).
 static inline int msm_table_windows(int c) { return 254 / c + 1; }
-// Small SRS (the reference's actual sizes: a few thousand powers at most) take the three-launch path of mzk_msm.hip; with
-// tables there is no window Horner either (its ~120 serial doublings are the latency floor of a small generic MSM), so
-// they get narrow windows: 8 bits = 32 tables x 128 buckets up to 1024 points, 10 bits = 26 tables x 512 buckets below 4096.
-// 4096 .. 2^14 points: 13-bit windows (20 tables, 4096 buckets) through the general pipeline: 0.49 ms per commit at 2^12 and
-// 2^13 against 0.74 / 0.83 ms without tables (tools/timing/window_sweep.py 12,13 12,13,14,16).
+// Small SRS (the reference's actual sizes: a few thousand powers at most) take the short paths of mzk_msm.hip (two launches:
+// k_small_accumulate_scan + the tail); with tables there is no window Horner either (its ~120 serial doublings are the latency
+// floor of a small generic MSM), so they get narrow windows: 8 bits = 32 tables x 128 buckets up to 1024 points, 10 bits =
+// 26 tables x 512 buckets up to 2^14 (where the sortless path still beats the general pipeline: profiles/r03v_*), then 16 and,
+// from 2^19 points on, 17 bits through the general pipeline (tools/timing/window_sweep.py).
 static inline int msm_srs_window_bits(size_t n) {
-  return n <= 1024 ? 8 : (n <= 4096 ? 10 : (n < ((size_t)1 << 14) ? 13 : (n < ((size_t)1 << 19) ? 16 : 17)));
+  return n <= 1024 ? 8 : (n <= ((size_t)1 << 14) ? 10 : (n < ((size_t)1 << 19) ? 16 : 17));
 }
 static inline bool msm_srs_default_tables(size_t n) { return n > 0; }
 #define MSM_PTS_TABLES_C(c) (MSM_PTS_TABLES | ((c) << 8))

@@ -96,13 +96,13 @@ int mzk_srs_save(const mzk_srs* srs, const char* path, int with_tables) {
   return MZK_OK;
 }
 
-// with_tables as in mzk_srs_from_device_ex (0 = plain prepared points, 1 = default 16-bit windows, 12..22 = that width);
+// with_tables as in mzk_srs_from_device_ex (0 = plain prepared points, 1 = default 16-bit windows, 8..22 = that width);
 // tables stored in the file are used when their width matches, otherwise they are rebuilt from the points.
 int mzk_srs_load(const char* path, int with_tables, mzk_srs** out) {
   MZK_ENTER();
   if (!path || !out) { set_error("srs_load: null pointer"); return MZK_E_ARG; }
   *out = nullptr;
-  if (with_tables < 0 || (with_tables > 1 && (with_tables < 12 || with_tables > 22))) { set_error("srs_load: with_tables must be 0, 1 or a window width 12..22"); return MZK_E_ARG; }
+  if (with_tables < 0 || (with_tables > 1 && (with_tables < 8 || with_tables > 22))) { set_error("srs_load: with_tables must be 0, 1 or a window width 8..22"); return MZK_E_ARG; }
   hipStream_t s = ctx().stream;
   FileCloser fc{fopen(path, "rb")};
   if (!fc.f) { set_error("srs_load: cannot open %s", path); return MZK_E_IO; }

@@ -1014,12 +1014,14 @@ __global__ __launch_bounds__(T) void k_small_accumulate(const u32* __restrict__ 
   }
   small_tree_store<T>(sh, acc, o1 - o0, b, buckets);
 }
-// The same for a commit against window tables WITHOUT the sort launch: every workgroup walks all n scalars itself (n <= 4096:
-// n / T scalars per lane, ~10 instructions per digit -- a few microseconds against the ~30 of k_small_sort's launch) and
-// collects the entries of ITS bucket in an LDS list; entries beyond the list's capacity (degenerate inputs: all scalars equal)
-// are added on the spot by the lane that found them.  Merged layout only: the generic one would repeat the GLV split of
-// every scalar in every workgroup.
-constexpr int SMALL_LIST_CAP = 2048;
+// The same for a commit against window tables WITHOUT the sort launch: every workgroup walks all n scalars itself (n / T
+// scalars per lane, ~8 instructions per digit: a few microseconds at n <= 4096 against the ~30 of k_small_sort's launch) and
+// collects the entries of ITS bucket in an LDS list; entries beyond the list's capacity (skewed inputs: bit vectors, all
+// scalars equal) are added on the spot by the lane that found them.  Merged layout only: the generic one would repeat the GLV
+// split of every scalar in every workgroup.  The redundant walks grow with n * buckets: measured against the general pipeline
+// (profiles/r03v_scan_path_size_sweep.txt) this path wins up to 2^14 coefficients at 10-bit windows (0.24 vs 0.38 ms at 2^13,
+// 0.32 vs 0.39 at 2^14) and loses from 2^15 on (0.93 vs 0.39).
+constexpr int SMALL_LIST_CAP = 4096;
 // Signed c-bit digits without the serial carry walk: with t = k + sum_w (2^(c-1) - 1) 2^(c w) the digit of window w is
 // window_w(t) - (2^(c-1) - 1) (the carries of that ONE long addition are exactly the recoding's carries: window w overflows iff
 // raw_w + carry > 2^(c-1)), same digits as walk_digits.  Word k of the constant, C a compile-time width:
@@ -1280,22 +1282,21 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   };
   const size_t E_max = n * (size_t)(L.glv ? 2 * sh.nwin : sh.nwin);
   // (the generic layout has twice the entries per pair: measured at 4096 pairs it is 5 % slower on this path, the commit 14 % faster)
-  if (n < (L.merged ? SMALL_MAX_N : SMALL_MAX_N - 1) && NB <= SMALL_MAX_BUCKETS) {
+  static const int env_scan = getenv("MZK_SMALL_SCAN") ? atoi(getenv("MZK_SMALL_SCAN")) : 1;     // 0: A/B against the sorted path
+  static const int env_scan_log = getenv("MZK_SCAN_MAX_LOG") ? atoi(getenv("MZK_SCAN_MAX_LOG")) : 14;
+  const bool scan_ok = L.merged && env_scan && n <= ((size_t)1 << env_scan_log) && (L.c == 8 || (L.c >= 10 && L.c <= 13));
+  if ((scan_ok || n < (L.merged ? SMALL_MAX_N : SMALL_MAX_N - 1)) && NB <= SMALL_MAX_BUCKETS) {
     u32 *offsets, *entries, *buckets, *wsum;
     MZK_TRY(ws_get(WS_MSM_OFFSETS, (NB + 1) * 4, (void**)&offsets));
     MZK_TRY(ws_get(WS_MSM_ENTRIES, E_max * 4, (void**)&entries));
     MZK_TRY(ws_get(WS_MSM_BUCKETS, NB * 128, (void**)&buckets));
     MZK_TRY(ws_get(WS_MSM_OUT, (size_t)MAX_WINDOWS * 128, (void**)&wsum));
     MZK_TRY(prepare());
-    static const int env_scan = getenv("MZK_SMALL_SCAN") ? atoi(getenv("MZK_SMALL_SCAN")) : 1;     // 0: A/B against the sorted path
-    if (L.merged && env_scan && (L.c == 8 || L.c == 10 || L.c == 13)) {      // two launches: every bucket's workgroup finds its own entries
+    if (scan_ok) {      // two launches: every bucket's workgroup finds its own entries
       prof_begin(s, MZK_PH_MSM_ACCUMULATE);
-      if (L.c == 8)
-        hipLaunchKernelGGL((k_small_accumulate_scan<256, 8>), dim3((unsigned)NB), dim3(256), 0, s, (const u32*)d_scalars, n, L.table_stride, pts, buckets);
-      else if (L.c == 10)
-        hipLaunchKernelGGL((k_small_accumulate_scan<256, 10>), dim3((unsigned)NB), dim3(256), 0, s, (const u32*)d_scalars, n, L.table_stride, pts, buckets);
-      else
-        hipLaunchKernelGGL((k_small_accumulate_scan<256, 13>), dim3((unsigned)NB), dim3(256), 0, s, (const u32*)d_scalars, n, L.table_stride, pts, buckets);
+#define MZK_SCAN_CASE(C) case C: hipLaunchKernelGGL((k_small_accumulate_scan<256, C>), dim3((unsigned)NB), dim3(256), 0, s, (const u32*)d_scalars, n, L.table_stride, pts, buckets); break;
+      switch (L.c) { MZK_SCAN_CASE(8) MZK_SCAN_CASE(10) MZK_SCAN_CASE(11) MZK_SCAN_CASE(12) MZK_SCAN_CASE(13) }
+#undef MZK_SCAN_CASE
       prof_end(s, MZK_PH_MSM_ACCUMULATE);
       MZK_TRY(reduce_bucket_sets(buckets, sh.lgB, red_windows, true, horner_c, wsum, (u32*)d_out, out_partial_xyzz, s));
       MZK_HIP(hipGetLastError());

@@ -158,9 +158,9 @@ def test_skewed_scalars_merged_two_level_sort(mz):
     h.close()
 
 
-@pytest.mark.parametrize("n", [5, 700, 1024, 3000, 4096])
+@pytest.mark.parametrize("n", [5, 700, 1024, 3000, 4096, 8191, 16384])
 def test_small_commit_without_sort_launch_skewed_scalars(mz, n):
-    """Commits of at most 4096 coefficients against narrow window tables (8 / 10 bits) find every bucket's entries by
+    """Commits of at most 2^14 coefficients against narrow window tables (8 / 10 bits) find every bucket's entries by
     walking the scalars inside the accumulate kernel (k_small_accumulate_scan, no sort launch): uniform scalars, and
     the skew patterns that overflow the per-bucket LDS list (all scalars equal: one bucket per window gets n entries,
     'ones': one bucket gets all of them), infinity entries in the SRS included."""

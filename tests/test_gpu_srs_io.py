@@ -17,7 +17,7 @@ def mz():
     return myzkp_amd
 
 
-@pytest.mark.parametrize("n", [0, 1, 300, 3000, 5000, (1 << 14) + 7])      # 8-, 10-, 13- and 16-bit window tables
+@pytest.mark.parametrize("n", [0, 1, 300, 3000, 5000, (1 << 14) + 7])      # 8-, 10- and 16-bit window tables
 @pytest.mark.parametrize("with_tables", [False, True])
 def test_save_load_round_trip(mz, tmp_path, n, with_tables):
     p = orc.synth_points(1200 + n, n)
@@ -33,7 +33,7 @@ def test_save_load_round_trip(mz, tmp_path, n, with_tables):
     raw = open(path, "rb").read()
     assert raw[:8] == b"MZKSRS\0\0" and struct.unpack_from("<Q", raw, 16)[0] == n
     assert raw[64:64 + 64 * n] == p.tobytes()                        # the ABI wire format, verbatim
-    c = 8 if n <= 1024 else (10 if n < 4096 else (13 if n < (1 << 14) else 16))
+    c = 8 if n <= 1024 else (10 if n <= (1 << 14) else 16)             # msm_srs_window_bits (mzk_common.h)
     has_tables = with_tables and n > 0
     assert len(raw) == 64 + 64 * n * ((254 // c + 1) if has_tables else 1)
     for mode in (1, 0, 13):                                          # stored tables / plain points / rebuilt at another width
