@@ -117,6 +117,47 @@ template <class P> MZK_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
   return r;
 }
 
+// Precomputed-quotient (Shoup) product for a CONSTANT factor: x * w mod p with plain w (limbs w[L]) and
+// wq = floor(w 2^(29 L) / p) (limbs wq[L]) -- no Montgomery form anywhere.  q = columns L .. 2L-1 of x * wq (columns L-2, L-1
+// computed as guards, the lower ones dropped: |q - floor(x w / p)| <= 2), r = low L columns of x * w + q (2^(29 L) - p).
+// r == x w (mod p), r < 4 p (measured: < 1.3 p), limbs normalised.  x may be lazy: limbs up to 3 * 2^30, value < 2^(29 L).
+// 143 multiply-adds against the Montgomery product's 162 for L = 9 (tools/shoup_model.py is the integer model; the NTT uses
+// it where a whole wave shares a twiddle and w, wq sit in scalar registers).
+template <class P> MZK_HD Fe<P> fe_shoup_mul(const Fe<P>& x, const u32* w, const u32* wq) {
+  constexpr int L = P::L;
+  u32 q[L];
+  Fe<P> r;
+  u64 col = 0;
+#if defined(MZK_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+  {
+    u64 mx = 0;
+    for (int i = 0; i < L; i++) { if (x.l[i] > mx) mx = x.l[i]; assert(w[i] <= MASK29 && wq[i] <= MASK29); }
+    const unsigned __int128 worst = (unsigned __int128)mx * MASK29 * L + (unsigned __int128)L * ((u64)MASK29 * MASK29) + ((u64)1 << 36);
+    assert(worst < ((unsigned __int128)1 << 64));
+  }
+#endif
+#pragma unroll
+  for (int k = L - 2; k < 2 * L - 1; k++) {
+#pragma unroll
+    for (int i = (k - L + 1 > 0 ? k - L + 1 : 0); i <= (k < L - 1 ? k : L - 1); i++) col = mzk_mad(x.l[i], wq[k - i], col);
+    if (k >= L) q[k - L] = (u32)col & MASK29;
+    col >>= W29;
+  }
+  MZK_ASSERT(col < ((u64)1 << 32));
+  q[L - 1] = (u32)col;
+  col = 0;
+#pragma unroll
+  for (int k = 0; k < L; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) col = mzk_mad(x.l[i], w[k - i], col);
+#pragma unroll
+    for (int i = 0; i <= k; i++) col = mzk_mad(q[i], P::RMP[k - i], col);
+    r.l[k] = (u32)col & MASK29;
+    col >>= W29;
+  }
+  return r;
+}
+
 // a*b + c*d with ONE Montgomery reduction (the two double-width products share the 64-bit columns):
 // (a b + c d)/R mod p, normalised, < (a b + c d)/R + p.  Saves a whole reduction (81 MADs + 9 v_mul_lo)
 // wherever a formula adds or subtracts two products.  Needs

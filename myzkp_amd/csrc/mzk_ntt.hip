@@ -193,13 +193,101 @@ __device__ __forceinline__ void bfly(Fe<P>& lo, Fe<P>& hi, const u32* twl, int t
 // arithmetic and barriers of one-stage-at-a-time); an odd lgn starts with one radix-2 stage.  Groups are
 // enumerated twiddle-major (all groups with twiddle index 0 first), so whole waves skip the products by
 // w^0 = 1: about one stage's worth of products per level.
+// One radix-4 group in registers: the two butterfly stages s, s + 1 on the four elements at k-distance 2^(s-1), 2^s
+// (x0, x1 = first stage pair; x2, x3 the second); j1 = the group's index inside the first stage's half.
 template <class P, class G>
-__device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, int lgc) {
+__device__ __forceinline__ void radix4_regs(Fe<P>& x0, Fe<P>& x1, Fe<P>& x2, Fe<P>& x3, const u32* twl, int tws, int lgn, int s, int j1) {
+  const int lgh = s - 1;
+  const bool triv = (j1 == 0);
+  const bool raw = (s == 1);
+  const int t1 = j1 << (lgn - s);
+  bfly<P, G, NTT_LAZY_FIRST>(x0, x1, twl, tws, t1, triv, raw);
+  bfly<P, G, NTT_LAZY_FIRST>(x2, x3, twl, tws, t1, triv, raw);
+  bfly<P, G>(x0, x2, twl, tws, j1 << (lgn - s - 1), triv, false);
+  bfly<P, G>(x1, x3, twl, tws, (j1 + (1 << lgh)) << (lgn - s - 1), false, false);
+}
+// Stage pairs whose twiddles are the same for a whole wave (groups are enumerated twiddle-major: 2^lgrest consecutive groups
+// share j1, so from lgrest >= 6 on a wave has ONE j1) take them from the plan's Shoup table by scalar loads -- entry ti =
+// 32 words: limbs of the plain w^ti at [0, 9), of floor(w^ti 2^261 / p) at [16, 25) -- and multiply by the precomputed-quotient
+// product (fe_shoup_mul: 143 multiply-adds, the constant in scalar registers) instead of the Montgomery one (162 + the twiddle's
+// eight LDS reads and its unpacking).  BN254 Fr only (M128's sparse modulus makes its Montgomery reduction cheaper than that).
+constexpr int SHOUP_ENTRY_WORDS = 32;
+template <class P> struct HasShoup { static constexpr bool value = false; };
+template <> struct HasShoup<FrParams> { static constexpr bool value = true; };
+template <class P, bool LAZY>
+__device__ __forceinline__ void bfly_shoup(Fe<P>& lo, Fe<P>& hi, const u32* __restrict__ entry, bool trivial, bool raw) {
+  Fe<P> t = hi;
+  if (!trivial) {
+    u32 w[P::L], wq[P::L];
+#pragma unroll
+    for (int i = 0; i < P::L; i++) { w[i] = entry[i]; wq[i] = entry[16 + i]; }
+    t = FeAsm<P>::shoup_mul(t, w, wq);
+  } else if (!raw) {
+    t = fe_weak_reduce<P>(t);
+  }
+  if constexpr (LAZY) {
+    hi = fe_sub<P, 8>(lo, t);
+    lo = fe_add<P>(lo, t);
+  } else {
+    hi = fe_sub_carry<P, 8>(lo, t);
+    lo = fe_add_carry<P>(lo, t);
+  }
+}
+// radix4_regs with a wave-uniform j1 (an SGPR: the table addresses are scalar)
+template <class P>
+__device__ __forceinline__ void radix4_shoup(Fe<P>& x0, Fe<P>& x1, Fe<P>& x2, Fe<P>& x3, const u32* __restrict__ tab, int lgn, int s, int j1) {
+  const int lgh = s - 1;
+  const bool triv = (j1 == 0);
+  const bool raw = (s == 1);
+  const u32* e1 = tab + (size_t)(j1 << (lgn - s)) * SHOUP_ENTRY_WORDS;
+  const u32* e2 = tab + (size_t)(j1 << (lgn - s - 1)) * SHOUP_ENTRY_WORDS;
+  const u32* e3 = tab + (size_t)((j1 + (1 << lgh)) << (lgn - s - 1)) * SHOUP_ENTRY_WORDS;
+  bfly_shoup<P, NTT_LAZY_FIRST>(x0, x1, e1, triv, raw);
+  bfly_shoup<P, NTT_LAZY_FIRST>(x2, x3, e1, triv, raw);
+  bfly_shoup<P, false>(x0, x2, e2, triv, false);
+  bfly_shoup<P, false>(x1, x3, e3, false, false);
+}
+
+// The first stage pair (s = 1) of a tile with an even number of levels on elements that never went through LDS: a lane's four
+// loads ARE a radix-4 group (rows r + u 2^(lgn-2) land on bit-reversed rows 4 brev(r) + brev2(u)).  All twiddles are 1 except
+// w^(n/4), taken from the global table (the LDS copy is not staged yet: no barrier in front of this).
+template <class P, class G>
+__device__ __forceinline__ void first_pair_regs(Fe<P>& x0, Fe<P>& x1, Fe<P>& x2, Fe<P>& x3, const u32* __restrict__ tw_tile, const u32* __restrict__ tw_shoup,
+                                                int lgn) {
+  if (lgn & 1) {        // odd level count: the lone radix-2 stage (all twiddles 1) -- the lane holds two of its butterflies
+    bfly<P, G>(x0, x1, nullptr, 0, 0, true, true);
+    bfly<P, G>(x2, x3, nullptr, 0, 0, true, true);
+    return;
+  }
+  if constexpr (HasShoup<P>::value) {
+    if (tw_shoup) { radix4_shoup<P>(x0, x1, x2, x3, tw_shoup, lgn, 1, 0); return; }
+  }
+  const Fe<P> zeta = gload<P>(tw_tile, (size_t)1 << (lgn - 2));
+  bfly<P, G, NTT_LAZY_FIRST>(x0, x1, nullptr, 0, 0, true, true);
+  bfly<P, G, NTT_LAZY_FIRST>(x2, x3, nullptr, 0, 0, true, true);
+  bfly<P, G>(x0, x2, nullptr, 0, 0, true, false);
+  const Fe<P> t = FeAsm<P>::mul(x3, zeta);
+  x3 = fe_sub_carry<P, 8>(x1, t);
+  x1 = fe_add_carry<P>(x1, t);
+}
+// fused first / last stage pairs need one radix-4 group per lane (a full tile) and at least one stage pair after the first stage(s)
+template <class G> __device__ __forceinline__ bool fuse_edges(int lgn, int lgc, int enable) { return enable && lgn >= 4 && (lgn + lgc) == G::TL; }
+
+// In-LDS radix-2/radix-4 DIT over the k-dimension of a [2^lgn][2^lgc] tile whose rows were stored
+// bit-reversed; leaves natural order.  Stages run in pairs: a lane loads the four elements of a radix-4
+// group once, does two butterfly stages in registers and stores them (half the LDS traffic, address
+// arithmetic and barriers of one-stage-at-a-time); an odd lgn starts with one radix-2 stage.  Groups are
+// enumerated twiddle-major (all groups with twiddle index 0 first), so whole waves skip the products by
+// w^0 = 1: about one stage's worth of products per level.
+// Stages s_from .. s_to only (pairs; s_from = 3 / s_to = lgn - 2 when the kernel runs the first / last pair itself on
+// registers next to its global loads / stores).
+template <class P, class G>
+__device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, int lgc, int s_from, int s_to, const u32* __restrict__ tw_shoup = nullptr) {
   const int tid = threadIdx.x;
   const int cmask = (1 << lgc) - 1;
   const int tws = (lgn >= 2) ? (1 << (lgn - 1)) : 1;   // twiddle table stride (entries per limb row)
-  int s = 1;
-  if (lgn & 1) {  // stage 1 alone: every twiddle is 1
+  int s = s_from;
+  if (s == 1 && (lgn & 1)) {  // stage 1 alone: every twiddle is 1
     const int nbf = 1 << (lgn + lgc - 1);
     for (int b = tid; b < nbf; b += G::NT) {
       const int c = b & cmask, grp = b >> lgc;
@@ -213,7 +301,7 @@ __device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, i
     s = 2;
   }
   const int lgg = lgn + lgc - 2;   // log2(radix-4 groups per stage pair)
-  for (; s + 1 <= lgn; s += 2) {
+  for (; s + 1 <= s_to; s += 2) {
     const int lgh = s - 1;                 // log2 of the first stage's half-distance (in k)
     const int lgrest = lgg - lgh;
     for (int g = tid; g < (1 << lgg); g += G::NT) {
@@ -225,13 +313,14 @@ __device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, i
       const int d1 = 1 << (lgh + lgc), d2 = d1 << 1;
       Fe<P> x0 = lds_load<P, G>(lds, p0), x1 = lds_load<P, G>(lds, p0 + d1);
       Fe<P> x2 = lds_load<P, G>(lds, p0 + d2), x3 = lds_load<P, G>(lds, p0 + d2 + d1);
-      const bool triv = (j1 == 0);
-      const bool raw = (s == 1);
-      const int t1 = j1 << (lgn - s);
-      bfly<P, G, NTT_LAZY_FIRST>(x0, x1, twl, tws, t1, triv, raw);
-      bfly<P, G, NTT_LAZY_FIRST>(x2, x3, twl, tws, t1, triv, raw);
-      bfly<P, G>(x0, x2, twl, tws, j1 << (lgn - s - 1), triv, false);
-      bfly<P, G>(x1, x3, twl, tws, (j1 + (1 << lgh)) << (lgn - s - 1), false, false);
+      bool done = false;
+      if constexpr (HasShoup<P>::value) {
+        if (tw_shoup && lgrest >= 6) {       // one j1 per wave: scalar twiddles
+          radix4_shoup<P>(x0, x1, x2, x3, tw_shoup, lgn, s, __builtin_amdgcn_readfirstlane(j1));
+          done = true;
+        }
+      }
+      if (!done) radix4_regs<P, G>(x0, x1, x2, x3, twl, tws, lgn, s, j1);
       lds_store<P, G>(lds, p0, x0);
       lds_store<P, G>(lds, p0 + d1, x1);
       lds_store<P, G>(lds, p0 + d2, x2);
@@ -240,6 +329,8 @@ __device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, i
     __syncthreads();
   }
 }
+template <class P, class G>
+__device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, int lgc) { tile_stages<P, G>(lds, twl, lgn, lgc, 1, lgn); }
 
 // Pass t < K: in-place strided columns + inter-pass twiddle.
 // PRE (first pass of a coset LDE, ntt.rs:254-269): the input is the coefficient vector itself -- element idx is
@@ -250,7 +341,7 @@ struct PreArgs { const u32* coef; size_t n_coef; const u32* pre_row; const u32* 
 template <class P, bool PRE, class G>
 __global__ __launch_bounds__(G::NT) void k_ntt_strided(const u32* __restrict__ in, u32* __restrict__ out,
                                                            const u32* __restrict__ tw_tile,
-                                                           const u32* __restrict__ tw_inter, int lgn, int lgM, int lgc, PreArgs pre) {
+                                                           const u32* __restrict__ tw_inter, int lgn, int lgM, int lgc, PreArgs pre, int fuse, const u32* __restrict__ tw_shoup) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   const int tid = threadIdx.x;
   const int lg_tiles = lgM - lgc;
@@ -262,6 +353,7 @@ __global__ __launch_bounds__(G::NT) void k_ntt_strided(const u32* __restrict__ i
   u32* twl = lds + P::L * G::TILE;
   stage_twiddles<P, G>(twl, tw_tile, lgn);
   constexpr int UNR = G::TILE / G::NT;          // elements per lane and tile (tile_elems == G::TILE here)
+  const bool fused = fuse_edges<G>(lgn, lgc, fuse);   // first (plain loads only) and last stage pair on registers, next to the global accesses
   if constexpr (!PRE) {
     u32 w[UNR][P::NW];
 #pragma unroll
@@ -269,6 +361,18 @@ __global__ __launch_bounds__(G::NT) void k_ntt_strided(const u32* __restrict__ i
       const int e = tid + u * G::NT;
       gload_words<P>(in, base + ((size_t)(e >> lgc) << lgM) + (e & cmask), w[u]);
     }
+    if (fused) {       // first stage pair next to the loads: the data of a wave starts computing when IT has arrived
+      static_assert(UNR == 4, "one radix-4 group per lane");
+      Fe<P> x0 = fe_unpack<P>(w[0]), x2 = fe_unpack<P>(w[1]), x1 = fe_unpack<P>(w[2]), x3 = fe_unpack<P>(w[3]);
+      first_pair_regs<P, G>(x0, x1, x2, x3, tw_tile, tw_shoup, lgn);
+      const int r = tid >> lgc, c = tid & cmask;
+      const int k0 = (int)(__brev((unsigned)r) >> (32 - (lgn - 2))) << 2;
+      const int p0 = (k0 << lgc) | c, d1 = 1 << lgc;
+      lds_store<P, G>(lds, p0, x0);
+      lds_store<P, G>(lds, p0 + d1, x1);
+      lds_store<P, G>(lds, p0 + 2 * d1, x2);
+      lds_store<P, G>(lds, p0 + 3 * d1, x3);
+    } else
 #pragma unroll
     for (int u = 0; u < UNR; u++) {
       const int e = tid + u * G::NT;
@@ -298,13 +402,27 @@ __global__ __launch_bounds__(G::NT) void k_ntt_strided(const u32* __restrict__ i
     lds_store<P, G>(lds, (k << lgc) | c, v);
   }
   __syncthreads();
-  tile_stages<P, G>(lds, twl, lgn, lgc);
+  tile_stages<P, G>(lds, twl, lgn, lgc, (fused && !PRE) ? 3 - (lgn & 1) : 1, fused ? lgn - 2 : lgn, tw_shoup);
   {
     u32 tw[UNR][P::NW];               // the inter-pass twiddles of all the lane's elements, requested before the first product
 #pragma unroll
     for (int u = 0; u < UNR; u++) {
       const int e = tid + u * G::NT;
       gload_words<P>(tw_inter, ((size_t)(e >> lgc) << lgM) + (ct << lgc) + (e & cmask), tw[u]);
+    }
+    if (fused) {       // last stage pair on registers: the lane's group is rows j1 + u 2^(lgn-2), exactly the elements it stores
+      const int j1 = tid >> lgc, c = tid & cmask;
+      const int p0 = (j1 << lgc) | c, d1 = 1 << (lgn - 2 + lgc);
+      Fe<P> x[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) x[u] = lds_load<P, G>(lds, p0 + u * d1);
+      radix4_regs<P, G>(x[0], x[1], x[2], x[3], twl, 1 << (lgn - 1), lgn, lgn - 1, j1);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const size_t off = ((size_t)(j1 + (u << (lgn - 2))) << lgM) + (ct << lgc) + c;
+        gstore<P>(out, (o << (lgn + lgM)) + off, fe_fit<P>(FeAsm<P>::mul(x[u], fe_unpack<P>(tw[u]))));
+      }
+      return;
     }
 #pragma unroll
     for (int u = 0; u < UNR; u++) {
@@ -324,7 +442,7 @@ __global__ __launch_bounds__(G::NT) void k_ntt_strided(const u32* __restrict__ i
 template <class P, class G>
 __global__ __launch_bounds__(G::NT) void k_ntt_last(const u32* __restrict__ in, u32* __restrict__ out,
                                                         const u32* __restrict__ tw_tile, LevelInfo li, int lgn, int lgr,
-                                                        int lg_rows, Words8 scale, int has_scale, size_t total_rows) {
+                                                        int lg_rows, Words8 scale, int has_scale, size_t total_rows, int fuse, const u32* __restrict__ tw_shoup) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
   const int tid = threadIdx.x;
   const size_t p0 = (size_t)blockIdx.x << lgr;
@@ -335,6 +453,37 @@ __global__ __launch_bounds__(G::NT) void k_ntt_last(const u32* __restrict__ in, 
   u32* twl = lds + P::L * G::TILE;
   stage_twiddles<P, G>(twl, tw_tile, lgn);
   constexpr int UNR = G::TILE / G::NT;
+  const bool fused = fuse_edges<G>(lgn, lgr, fuse);      // full tile, even number of levels: first and last stage pair on registers
+  auto row_base = [&](size_t r) -> size_t {        // first element of logical row r in the previous pass's layout
+    size_t rem = r & rowmask, row = 0;
+    for (int i = 0; i < li.nlev - 1; i++) {
+      row = (row << li.lg[i]) | (rem & (((size_t)1 << li.lg[i]) - 1));
+      rem >>= li.lg[i];
+    }
+    return ((r >> lg_rows) << logn) + (row << lgn);
+  };
+  if (fused) {
+    // lane = (row rr, r): its loads j = r + u 2^(lgn-2) are one radix-4 group of the first stage pair (bit-reversed rows
+    // 4 brev(r) + brev2(u)); consecutive lanes read consecutive elements of a row
+    static_assert(UNR == 4, "one radix-4 group per lane");
+    const int rr = tid >> (lgn - 2), r4 = tid & ((1 << (lgn - 2)) - 1);
+    const size_t r = p0 + rr;
+    u32 w[4][P::NW];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+#pragma unroll
+      for (int q = 0; q < P::NW; q++) w[u][q] = 0;
+      if (r < total_rows) gload_words<P>(in, row_base(r) + r4 + ((size_t)u << (lgn - 2)), w[u]);
+    }
+    Fe<P> x0 = fe_unpack<P>(w[0]), x2 = fe_unpack<P>(w[1]), x1 = fe_unpack<P>(w[2]), x3 = fe_unpack<P>(w[3]);
+    first_pair_regs<P, G>(x0, x1, x2, x3, tw_tile, tw_shoup, lgn);
+    const int k0 = (int)(__brev((unsigned)r4) >> (32 - (lgn - 2))) << 2;
+    const int q0 = (k0 << lgr) | rr, d1 = 1 << lgr;
+    lds_store<P, G>(lds, q0, x0);
+    lds_store<P, G>(lds, q0 + d1, x1);
+    lds_store<P, G>(lds, q0 + 2 * d1, x2);
+    lds_store<P, G>(lds, q0 + 3 * d1, x3);
+  } else
   for (int e0 = tid; e0 < tile_elems; e0 += UNR * G::NT) {       // one trip for a full tile: all loads first, then the LDS stores
     u32 w[UNR][P::NW];
 #pragma unroll
@@ -344,14 +493,7 @@ __global__ __launch_bounds__(G::NT) void k_ntt_last(const u32* __restrict__ in, 
       const size_t r = p0 + rr;
 #pragma unroll
       for (int q = 0; q < P::NW; q++) w[u][q] = 0;
-      if (e < tile_elems && r < total_rows) {
-        size_t rem = r & rowmask, row = 0;
-        for (int i = 0; i < li.nlev - 1; i++) {
-          row = (row << li.lg[i]) | (rem & (((size_t)1 << li.lg[i]) - 1));
-          rem >>= li.lg[i];
-        }
-        gload_words<P>(in, ((r >> lg_rows) << logn) + (row << lgn) + j, w[u]);
-      }
+      if (e < tile_elems && r < total_rows) gload_words<P>(in, row_base(r) + j, w[u]);
     }
 #pragma unroll
     for (int u = 0; u < UNR; u++) {
@@ -363,9 +505,26 @@ __global__ __launch_bounds__(G::NT) void k_ntt_last(const u32* __restrict__ in, 
     }
   }
   __syncthreads();
-  tile_stages<P, G>(lds, twl, lgn, lgr);
+  tile_stages<P, G>(lds, twl, lgn, lgr, fused ? 3 - (lgn & 1) : 1, fused ? lgn - 2 : lgn, tw_shoup);
   Fe<P> sc;
   if (has_scale) sc = fe_unpack<P>(scale.w);
+  if (fused) {         // last stage pair on registers: the group of lane (j1, rr) is rows j1 + u 2^(lgn-2), the elements it stores
+    const int j1 = tid >> lgr, rr = tid & rmask;
+    const size_t r = p0 + rr;
+    const int q0 = (j1 << lgr) | rr, d1 = 1 << (lgn - 2 + lgr);
+    Fe<P> x[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) x[u] = lds_load<P, G>(lds, q0 + u * d1);
+    radix4_regs<P, G>(x[0], x[1], x[2], x[3], twl, 1 << (lgn - 1), lgn, lgn - 1, j1);
+    if (r >= total_rows) return;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      Fe<P> v = x[u];
+      if (has_scale) v = FeAsm<P>::mul(v, sc);
+      gstore<P>(out, ((r >> lg_rows) << logn) + (r & rowmask) + ((size_t)(j1 + (u << (lgn - 2))) << lg_rows), fe_reduce<P>(v));
+    }
+    return;
+  }
   for (int e = tid; e < tile_elems; e += G::NT) {
     const int rr = e & rmask, k = e >> lgr;
     const size_t r = p0 + rr;
@@ -524,6 +683,7 @@ struct NttPlan {
   LevelInfo li{};
   u32* tw_tile[4] = {nullptr, nullptr, nullptr, nullptr};
   u32* tw_inter[3] = {nullptr, nullptr, nullptr};
+  u32* tw_shoup[4] = {nullptr, nullptr, nullptr, nullptr};   // Fr: per level, the in-tile twiddles again as (plain w, floor(w 2^261 / p)) limb entries
   Words8 last_scale{};                 // single-pass inverse: n^-1 (* scale), Montgomery
   int has_last_scale = 0;
   uint64_t stamp = 0;
@@ -536,6 +696,7 @@ constexpr size_t MAX_PLANS = 96;      // the polynomial trees of mzk_poly.hip us
 static void free_plan(NttPlan* p) {
   for (auto& t : p->tw_tile) if (t) (void)hipFree(t);
   for (auto& t : p->tw_inter) if (t) (void)hipFree(t);
+  for (auto& t : p->tw_shoup) if (t) (void)hipFree(t);
   delete p;
 }
 // offset-power tables of the fused coset LDE, per (context, field); see coset_lde_dev_impl
@@ -572,6 +733,51 @@ static void to_words(const uint64_t* limbs, int nl, Words8* w) {
   }
 }
 
+// Shoup entries of the in-tile twiddles w^j, j < cnt, w = root^emul: limbs (29 bits) of w^j at words [0, 9), of
+// floor(w^j 2^261 / p) at [16, 25) of a 32-word entry.  Host arithmetic (a few hundred 256-bit products and divisions per plan).
+static int build_shoup_table(const HostField* hf, const uint64_t* root, uint64_t emul, size_t cnt, u32** out, hipStream_t s) {
+  std::vector<u32> tab(cnt * SHOUP_ENTRY_WORDS, 0u);
+  uint64_t w[4], cur[4] = {1, 0, 0, 0};
+  h_powmod_u64(hf, w, root, emul);
+  auto limbs_of = [](const uint64_t* v5, u32* dst) {      // 9 limbs of 29 bits from a 5 x 64-bit number
+    for (int i = 0; i < 9; i++) {
+      const int bit = 29 * i, k = bit >> 6, sft = bit & 63;
+      uint64_t x = v5[k] >> sft;
+      if (sft > 35 && k + 1 < 5) x |= v5[k + 1] << (64 - sft);
+      dst[i] = (u32)(x & 0x1fffffffu);
+    }
+  };
+  for (size_t j = 0; j < cnt; j++) {
+    uint64_t v5[5] = {cur[0], cur[1], cur[2], cur[3], 0};
+    limbs_of(v5, &tab[j * SHOUP_ENTRY_WORDS]);
+    // q = floor(cur 2^261 / p): restoring division, one quotient bit per step (cur < p < 2^254, so the remainder stays below 2^255)
+    uint64_t rem[4] = {cur[0], cur[1], cur[2], cur[3]}, q[5] = {0, 0, 0, 0, 0};
+    for (int step = 0; step < 261; step++) {
+      for (int i = 4; i > 0; i--) q[i] = (q[i] << 1) | (q[i - 1] >> 63);
+      q[0] <<= 1;
+      for (int i = 3; i > 0; i--) rem[i] = (rem[i] << 1) | (rem[i - 1] >> 63);
+      rem[0] <<= 1;
+      bool ge = true;
+      for (int i = 3; i >= 0; i--) if (rem[i] != hf->p[i]) { ge = rem[i] > hf->p[i]; break; }
+      if (ge) {
+        unsigned __int128 br = 0;
+        for (int i = 0; i < 4; i++) {
+          const unsigned __int128 d = (unsigned __int128)rem[i] - hf->p[i] - (uint64_t)br;
+          rem[i] = (uint64_t)d;
+          br = (d >> 64) & 1;
+        }
+        q[0] |= 1;
+      }
+    }
+    limbs_of(q, &tab[j * SHOUP_ENTRY_WORDS + 16]);
+    h_mulmod(hf, cur, cur, w);
+  }
+  MZK_HIP(hipMalloc((void**)out, tab.size() * sizeof(u32)));
+  MZK_HIP(hipMemcpyAsync(*out, tab.data(), tab.size() * sizeof(u32), hipMemcpyHostToDevice, s));
+  MZK_HIP(hipStreamSynchronize(s));          // `tab` is a local
+  return MZK_OK;
+}
+
 template <class P>
 static int build_tables(NttPlan* pl, const uint64_t* eff_root, const uint64_t* fold_scale, hipStream_t s) {
   const HostField* hf = host_field(pl->fid);
@@ -594,6 +800,7 @@ static int build_tables(NttPlan* pl, const uint64_t* eff_root, const uint64_t* f
       unsigned blocks = (unsigned)((cnt + GEN_CHUNK * 64 - 1) / (GEN_CHUNK * 64));
       hipLaunchKernelGGL((k_gen_pow_table<P>), dim3(blocks), dim3(64), 0, s, rootw, (uint64_t)1 << (pl->logn - lgn), cnt,
                          pl->tw_tile[t]);
+      if (HasShoup<P>::value) MZK_TRY(build_shoup_table(hf, eff_root, (uint64_t)1 << (pl->logn - lgn), cnt, &pl->tw_shoup[t], s));
     }
     if (t < li.nlev - 1) {
       // inter-pass twiddles for the block of size n_t * M_t: primitive root = root^(n / (n_t M_t))
@@ -682,6 +889,8 @@ static int run_plan_geo(const NttPlan* pl, const u32* d_in, u32* d_out, hipStrea
   const unsigned logn = pl->logn;
 
   ProfScope whole(s, MZK_PH_NTT_TOTAL);
+  static const int fuse = getenv("MZK_NTT_FUSE_EDGES") ? atoi(getenv("MZK_NTT_FUSE_EDGES")) : 1;     // 0: A/B (tools/timing/time_ntt.py)
+  static const int shoup = getenv("MZK_NTT_SHOUP") ? atoi(getenv("MZK_NTT_SHOUP")) : 1;
   if (G::TL != TILE_LOG) {        // tiles above 64 KiB of LDS need the attribute, once per context and instantiation
     bool& done = ctx().attr_done[P::NW == 4 ? ATTR_NTT_LARGE_M128 : ATTR_NTT_LARGE_FR];
     if (!done) {
@@ -703,10 +912,10 @@ static int run_plan_geo(const NttPlan* pl, const u32* d_in, u32* d_out, hipStrea
       ProfScope ps(s, MZK_PH_NTT_PASS0 + t);
       if (t == 0 && pre)
         hipLaunchKernelGGL((k_ntt_strided<P, true, G>), dim3(blocks), dim3(G::NT), G::template lds_bytes<P>(lgn), s, src, tmp, pl->tw_tile[t],
-                           pl->tw_inter[t], lgn, lgM, lgc, *pre);
+                           pl->tw_inter[t], lgn, lgM, lgc, *pre, fuse, shoup ? pl->tw_shoup[t] : nullptr);
       else
         hipLaunchKernelGGL((k_ntt_strided<P, false, G>), dim3(blocks), dim3(G::NT), G::template lds_bytes<P>(lgn), s, src, tmp, pl->tw_tile[t],
-                           pl->tw_inter[t], lgn, lgM, lgc, PreArgs{nullptr, 0, nullptr, nullptr});
+                           pl->tw_inter[t], lgn, lgM, lgc, PreArgs{nullptr, 0, nullptr, nullptr}, fuse, shoup ? pl->tw_shoup[t] : nullptr);
     }
     src = tmp;
     lg_after = lgM;
@@ -720,7 +929,8 @@ static int run_plan_geo(const NttPlan* pl, const u32* d_in, u32* d_out, hipStrea
     const unsigned blocks = (unsigned)((total_rows + ((size_t)1 << lgr) - 1) >> lgr);
     ProfScope ps(s, MZK_PH_NTT_PASS0 + li.nlev - 1);
     hipLaunchKernelGGL((k_ntt_last<P, G>), dim3(blocks), dim3(G::NT), G::template lds_bytes<P>(lgn), s, src, d_out,
-                       pl->tw_tile[li.nlev - 1], li, lgn, lgr, lg_rows, pl->last_scale, pl->has_last_scale, total_rows);
+                       pl->tw_tile[li.nlev - 1], li, lgn, lgr, lg_rows, pl->last_scale, pl->has_last_scale, total_rows, fuse,
+                       shoup ? pl->tw_shoup[li.nlev - 1] : nullptr);
   }
   MZK_HIP(hipGetLastError());
   return MZK_OK;

@@ -3,6 +3,7 @@
 // (tests/hostcheck) cannot reach them; this kernel feeds both forms the same operands -- random limbs, all-ones limbs,
 // zeros, and the widest lazy operands the callers produce (limbs up to 2^30.6 against normalised ones) -- and counts
 // the lanes whose results differ in any limb.  Called by tests/test_gpu_field_asm.py through mzk_selftest_field_asm.
+#include <type_traits>
 #include "mzk_common.h"
 #include "mzk_field_asm.h"
 
@@ -51,6 +52,19 @@ __global__ void k_selftest_field_asm(u64 seed, size_t n, unsigned long long* __r
   bad += !st_same<P>(fe_sqr<P>(q), FeAsm<P>::sqr(q));
   // the fused pair needs L (|a||b| + |c||d|) + L 2^58 < 2^64: both lazy operands at 2^30.6 fit against normalised ones
   bad += !st_same<P>(fe_mul_add2<P>(a, b, c, d), FeAsm<P>::mul_add2(a, b, c, d));
+  if constexpr (std::is_same<P, FrParams>::value) {
+    // the precomputed-quotient product of the NTT's wave-uniform twiddles: constants in scalar registers (one pair per wave),
+    // x any of the operand kinds incl. the lazy one; both forms compute the same columns whatever the constants are
+    u64 sw = seed ^ (0x2545f4914f6cdd1dULL * ((i >> 6) + 1));
+    u32 w[P::L], wq[P::L];
+    for (int k = 0; k < P::L; k++) {
+      w[k] = (u32)__builtin_amdgcn_readfirstlane((int)((u32)st_mix(sw) & MASK29));
+      wq[k] = (u32)__builtin_amdgcn_readfirstlane((int)((u32)st_mix(sw) & MASK29));
+    }
+    Fe<P> x = a;
+    x.l[P::L - 1] &= 0x07ffffffu;            // value below 2^261: the quotient must fit its nine limbs
+    bad += !st_same<P>(fe_shoup_mul<P>(x, w, wq), FeAsm<P>::shoup_mul(x, w, wq));
+  }
   if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
 

@@ -46,7 +46,10 @@ template <class P> static void run_field(int op, const u32* a, const u32* b, u32
 // propagation), the second normalises (fe_add_carry / fe_sub_carry<8>); a twiddle of 1 skips the product (weak reduction
 // instead, except on raw stage-1 inputs); an odd level count starts with one carrying stage.  Data plain, twiddles
 // Montgomery, like the kernels.  words: n x NW in, n x NW out (reduced, natural order); tw: n/2 twiddles w^j, plain words.
-template <class P> static void run_ntt_tile(const u32* words, int lgn, const u32* tw_words, u32* out) {
+// shoup (Fr only, may be null): 18 words per twiddle -- the 29-bit limbs of the plain w^j and of floor(w^j 2^261 / p); stage
+// pairs in which a whole wave of the kernel shares a twiddle (2^(lgn + lgc - 2 - (s - 1)) >= 64 groups per j1; lgc = log2 of the
+// tile's columns) then multiply by fe_shoup_mul instead of the Montgomery product, as tile_stages / radix4_shoup do.
+template <class P> static void run_ntt_tile(const u32* words, int lgn, const u32* tw_words, u32* out, const u32* shoup = nullptr, int lgc = 0) {
   const int n = 1 << lgn;
   std::vector<Fe<P>> x(n), tw(n / 2 > 0 ? n / 2 : 1);
   for (int j = 0; j < n / 2; j++) tw[j] = fe_reduce<P>(fe_to_mont<P>(fe_unpack<P>(tw_words + (size_t)j * P::NW)));
@@ -55,9 +58,11 @@ template <class P> static void run_ntt_tile(const u32* words, int lgn, const u32
     for (int b = 0; b < lgn; b++) if (j & (1 << b)) k |= 1 << (lgn - 1 - b);
     x[k] = fe_unpack<P>(words + (size_t)j * P::NW);
   }
+  bool use_shoup = false;
   auto bfly = [&](Fe<P>& lo, Fe<P>& hi, int ti, bool trivial, bool raw, bool lazy) {
     Fe<P> t = hi;
-    if (!trivial) t = fe_mul<P>(t, tw[ti]);
+    if (!trivial && use_shoup) t = fe_shoup_mul<P>(t, shoup + (size_t)ti * 18, shoup + (size_t)ti * 18 + 9);
+    else if (!trivial) t = fe_mul<P>(t, tw[ti]);
     else if (!raw) t = fe_weak_reduce<P>(t);
     if (lazy) { hi = fe_sub<P, 8>(lo, t); lo = fe_add<P>(lo, t); }
     else { hi = fe_sub_carry<P, 8>(lo, t); lo = fe_add_carry<P>(lo, t); }
@@ -69,6 +74,7 @@ template <class P> static void run_ntt_tile(const u32* words, int lgn, const u32
   }
   for (; s + 1 <= lgn; s += 2) {
     const int lgh = s - 1, half = 1 << lgh;
+    use_shoup = shoup != nullptr && (lgn + lgc - 2 - lgh) >= 6;
     for (int grp = 0; grp < (n >> (s + 1)); grp++)
       for (int j1 = 0; j1 < half; j1++) {
         const int p0 = (grp << (s + 1)) | j1, d1 = half, d2 = half << 1;
@@ -97,6 +103,19 @@ int hc_ntt_tile(int fid, const u32* words, int lgn, const u32* tw_words, u32* ou
   if (fid == 0) run_ntt_tile<FrParams>(words, lgn, tw_words, out);
   else if (fid == 1) run_ntt_tile<M128Params>(words, lgn, tw_words, out);
   else return -1;
+  return 0;
+}
+// the same with the Shoup products of the wave-uniform stage pairs (BN254 Fr; lgc: log2 of the tile's columns in the kernel)
+int hc_ntt_tile_shoup(const u32* words, int lgn, int lgc, const u32* tw_words, const u32* shoup, u32* out) {
+  run_ntt_tile<FrParams>(words, lgn, tw_words, out, shoup, lgc);
+  return 0;
+}
+// x * w mod p by fe_shoup_mul: x as 9 raw limbs (lazy forms allowed), w / wq as 9 limbs each; out = 9 limbs of the result
+int hc_shoup_mul(const u32* x_limbs, const u32* w_limbs, const u32* wq_limbs, u32* out_limbs) {
+  Fe<FrParams> x;
+  for (int i = 0; i < 9; i++) x.l[i] = x_limbs[i];
+  const Fe<FrParams> r = fe_shoup_mul<FrParams>(x, w_limbs, wq_limbs);
+  for (int i = 0; i < 9; i++) out_limbs[i] = r.l[i];
   return 0;
 }
 // pack(unpack(w)) round trip

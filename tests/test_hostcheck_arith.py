@@ -215,3 +215,52 @@ def test_ntt_stage_schedule_with_lazy_first_stages_holds_its_bounds(hc):
             raw = np.full(n * nw, 0xFFFFFFFF, dtype=np.uint32)          # bounds only: the asserts inside must hold
             out = np.zeros(n * nw, dtype=np.uint32)
             assert hc.hc_ntt_tile(fid, orc.ptr(raw), lgn, orc.ptr(tw), orc.ptr(out)) == 0
+
+
+def _limbs29(v, n=9):
+    return [(v >> (29 * i)) & 0x1fffffff for i in range(n)]
+
+
+def test_shoup_product_matches_its_integer_model_and_bounds(hc):
+    """fe_shoup_mul (mzk_field.h; the asm form of the NTT's wave-uniform twiddles computes the same columns): x * w mod p
+    for constant w with wq = floor(w 2^261 / p) -- result congruent, below 4 p, limbs normalised, for normalised and for the
+    widest lazy x (limbs up to 3 * 2^30), with the column-overflow assertion of the host build on."""
+    import random
+    rng = random.Random(21)
+    p = P_FR
+    beta = 1 << 261
+    for case in range(3000):
+        wv = rng.randrange(p) if case % 6 else [0, 1, p - 1, 2, p // 2, (1 << 253)][(case // 6) % 6]
+        lim = [0x1fffffff, 3 << 30, (1 << 30) + (1 << 29)][case % 3]
+        x = [rng.randrange(lim + 1) for _ in range(9)]
+        if case % 40 == 0:
+            x = [lim] * 9
+        x[8] = rng.randrange(1 << 27)
+        xv = sum(v << (29 * i) for i, v in enumerate(x))
+        out = np.zeros(9, dtype=np.uint32)
+        assert hc.hc_shoup_mul(orc.ptr(np.array(x, dtype=np.uint32)), orc.ptr(np.array(_limbs29(wv), dtype=np.uint32)),
+                               orc.ptr(np.array(_limbs29(wv * beta // p), dtype=np.uint32)), orc.ptr(out)) == 0
+        rv = sum(int(v) << (29 * i) for i, v in enumerate(out))
+        assert rv % p == xv * wv % p and rv < 4 * p and all(int(v) <= 0x1fffffff for v in out), case
+
+
+def test_ntt_stage_schedule_with_shoup_products_holds_its_bounds(hc):
+    """The stage schedule again with the precomputed-quotient products in the stage pairs whose twiddles a whole wave shares
+    (tile of 2^lgn rows x 2^lgc columns as the kernels cut it: 2^10 x 4 and 2^8 x 4), bounds assertions on, results against
+    the oracle's transform."""
+    p = P_FR
+    for lgn, lgc in ((10, 2), (8, 2), (7, 3), (6, 4), (4, 6)):
+        n = 1 << lgn
+        w = orc.root_of(FR, lgn)
+        pw = [pow(w, j, p) for j in range(n // 2)]
+        tw = orc.to_limbs(pw, 4).view(np.uint32).reshape(-1)
+        sh = np.array([_limbs29(v) + _limbs29(v * (1 << 261) // p) for v in pw], dtype=np.uint32).reshape(-1)
+        cases = [orc.synth_vector(FR, 140 + lgn, n, 1), orc.to_limbs([p - 1] * n, 4), orc.to_limbs([1] + [0] * (n - 1), 4)]
+        for x in cases:
+            out = np.zeros(n * 8, dtype=np.uint32)
+            assert hc.hc_ntt_tile_shoup(orc.ptr(np.ascontiguousarray(x).view(np.uint32).reshape(-1)), lgn, lgc, orc.ptr(tw), orc.ptr(sh), orc.ptr(out)) == 0
+            rc, want = orc.ntt_fast(FR, w, np.ascontiguousarray(x), False, 1)
+            assert rc == 0 and np.array_equal(out.view(np.uint64).reshape(n, 4), want), (lgn, lgc)
+        raw = np.full(n * 8, 0xFFFFFFFF, dtype=np.uint32)
+        out = np.zeros(n * 8, dtype=np.uint32)
+        assert hc.hc_ntt_tile_shoup(orc.ptr(raw), lgn, lgc, orc.ptr(tw), orc.ptr(sh), orc.ptr(out)) == 0

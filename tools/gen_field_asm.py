@@ -118,6 +118,44 @@ def gen(kind, name, L, P):
     return "  static __device__ __forceinline__ %s %s {\n    %s r;\n%s%s\n    return r;\n  }\n" % (T, sig, T, pre, A.render())
 
 
+def gen_shoup(name, L, p):
+    """x * w mod p, w and wq = floor(w 2^(29 L) / p) as SCALAR operands (a wave-uniform twiddle): same columns as fe_shoup_mul."""
+    A = Asm()
+    r = [A.out("r.l[%d]" % i) for i in range(L)]
+    q = [A.out("q[%d]" % i) for i in range(L)]
+    A.fix()
+    x = [A.inp("v", "x.l[%d]" % i) for i in range(L)]
+    w = [A.inp("s", "w[%d]" % i) for i in range(L)]
+    wq = [A.inp("s", "wq[%d]" % i) for i in range(L)]
+    pc = [A.inp("s", "%sParams::RMP[%d]" % (name, i)) for i in range(L)]
+    mask = "0x1fffffff"
+    first = [True]
+
+    def mad(a, b):
+        A.emit("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (COL, a, b, "0" if first[0] else COL))
+        first[0] = False
+
+    for k in range(L - 2, 2 * L - 1):
+        for i in range(max(0, k - L + 1), min(k, L - 1) + 1):
+            mad(x[i], wq[k - i])
+        if k >= L:
+            A.emit("v_and_b32 %s, %s, %s" % (q[k - L], mask, CLO))
+        A.emit("v_lshrrev_b64 %s, 29, %s" % (COL, COL))
+    A.emit("v_mov_b32 %s, %s" % (q[L - 1], CLO))
+    first[0] = True
+    for k in range(L):
+        for i in range(k + 1):
+            mad(x[i], w[k - i])
+        for i in range(k + 1):
+            mad(q[i], pc[k - i])
+        A.emit("v_and_b32 %s, %s, %s" % (r[k], mask, CLO))
+        if k < L - 1:
+            A.emit("v_lshrrev_b64 %s, 29, %s" % (COL, COL))
+    T = "Fe<%sParams>" % name
+    head = "  // w, wq: wave-uniform (the asm takes them as scalar registers)\n  static __device__ __forceinline__ %s shoup_mul(const %s& x, const u32* w, const u32* wq) {\n" % (T, T)
+    return head + "    %s r;\n    u32 q[%d];\n%s\n    return r;\n  }\n" % (T, L, A.render())
+
+
 def check_slot_reuse(L):
     # m[j] last read: column j + L - 1 ; r[j] written at column j + L (k >= L) -- and in column k >= L the reads of
     # m[i] are for i >= k - L + 1, i.e. never m[k-L].
@@ -141,6 +179,8 @@ def main(out):
         S.append("template <> struct FeAsm<%sParams> {" % name)
         for kind in ("mul", "sqr", "mul_add2"):
             S.append(gen(kind, name, L, P))
+        if name == "Fr":
+            S.append(gen_shoup(name, L, p))
         S.append("};")
     S.append("}  // namespace mzk")
     S.append("#else   // host pass of hipcc / g++ host builds: the portable form (never executed for device work)")
@@ -149,6 +189,7 @@ def main(out):
     S.append("  static MZK_HD Fe<P> mul(const Fe<P>& a, const Fe<P>& b) { return fe_mul<P>(a, b); }")
     S.append("  static MZK_HD Fe<P> sqr(const Fe<P>& a) { return fe_sqr<P>(a); }")
     S.append("  static MZK_HD Fe<P> mul_add2(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) { return fe_mul_add2<P>(a, b, c, d); }")
+    S.append("  static MZK_HD Fe<P> shoup_mul(const Fe<P>& x, const u32* w, const u32* wq) { return fe_shoup_mul<P>(x, w, wq); }")
     S.append("};")
     S.append("}  // namespace mzk")
     S.append("#endif")
