@@ -44,7 +44,7 @@ def check(name, ok, info):
 
 def case_ntt():
     fid = rng.choice((FR, M128))
-    lg = rng.choice([0, 1, 2, 3, 5, 8, 10, 11, 12, 13, 14, 15, 16, 17])
+    lg = rng.choice([0, 1, 2, 3, 5, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21])      # 2^20: the large-tile geometry; odd and even level counts
     n = 1 << lg
     w = orc.root_of(fid, lg) if lg else 1
     x = vec(fid, n)
