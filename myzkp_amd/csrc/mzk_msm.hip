@@ -277,6 +277,44 @@ __device__ __forceinline__ void walk_digits(const u32* w, const DigitLayout& L, 
   }
 }
 
+// Signed c-bit digits without the serial carry walk: with t = k + sum_w (2^(c-1) - 1) 2^(c w) the digit of window w is
+// window_w(t) - (2^(c-1) - 1) (the carries of that ONE long addition are exactly the recoding's carries: window w overflows iff
+// raw_w + carry > 2^(c-1)), same digits as walk_digits.  Word k of the constant, C a compile-time width:
+constexpr u32 digit_bias_word(int C, int k) {
+  const int nwin = 254 / C + 1;
+  const unsigned long long hm1 = (1ull << (C - 1)) - 1;
+  unsigned long long acc = 0;
+  for (int w = 0; w < nwin; w++) {
+    const int sh = w * C - 32 * k;
+    if (sh >= 0 && sh < 32) acc |= (hm1 << sh) & 0xffffffffull;
+    else if (sh < 0 && sh > -32) acc |= hm1 >> (-sh);
+  }
+  return (u32)acc;
+}
+// walk_digits for the merged layout with a compile-time window width: the same (window, key, payload) triples in the same order,
+// from ONE long addition and NWIN independent extractions with static word indices (walk_digits' runtime window index makes
+// every word access a select chain).  Used by the coarse passes of the two-level sort and by the sortless small path.
+template <int C, class Emit>
+__device__ __forceinline__ void walk_digits_merged(const u32* w, size_t table_stride, size_t i, Emit emit) {
+  constexpr int NWIN = 254 / C + 1;
+  constexpr u32 HALF = 1u << (C - 1), MASKC = (1u << C) - 1u;
+  u32 t[9];
+  u64 cy = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { cy += (u64)w[k] + digit_bias_word(C, k); t[k] = (u32)cy; cy >>= 32; }
+  t[8] = (u32)cy + digit_bias_word(C, 8);
+#pragma unroll
+  for (int win = 0; win < NWIN; win++) {
+    const int bit = win * C, k = bit >> 5, sft = bit & 31;
+    const u64 pair = (u64)t[k] | ((k + 1 < 9) ? ((u64)t[k + 1] << 32) : 0ull);
+    const u32 v = (u32)(pair >> sft) & MASKC;            // digit + HALF - 1
+    if (v == HALF - 1u) continue;                        // digit 0
+    const bool neg = v < HALF - 1u;
+    const u32 mag = neg ? (HALF - 1u) - v : v - (HALF - 1u);
+    emit(win, mag - 1u, (u32)((size_t)win * table_stride + i) | ((u32)neg << 31));
+  }
+}
+
 // Counter increment (LDS or global) that stays fast when most of a wave hits ONE counter (bit-vector or repeated
 // scalars, the sparsely populated top window of a GLV half):
 // the lanes sharing the first active lane's key take a single atomic together.  Returns the lane's rank.
@@ -416,6 +454,8 @@ constexpr int COARSE_LOG = MZK_COARSE_LOG;      // 9: A/B build (one more bit fo
 constexpr int COARSE_BINS = 1 << COARSE_LOG;
 constexpr int COARSE_PER_WG = 4096;
 constexpr int SORT2_THREADS = 1024;
+// C: compile-time window width of the merged layout (walk_digits_merged), 0 = any layout by walk_digits
+template <int C>
 __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_count(const u32* __restrict__ scalars, size_t n, DigitLayout L, int key_shift,
                                                                  u32* __restrict__ binhist, int nwg) {
   __shared__ u32 hist[COARSE_BINS];
@@ -432,7 +472,11 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_count(const u32* __res
 #pragma unroll
   for (int k = 0; k < COARSE_PER_WG / SORT2_THREADS; k++) {
     const size_t i = lo + threadIdx.x + (size_t)k * SORT2_THREADS;
-    if (i < hi) walk_digits(w[k], L, i, [&](int, u32 key, u32) { counter_inc_agg(hist, key >> key_shift); });
+    if (i < hi) {
+      auto emit = [&](int, u32 key, u32) { counter_inc_agg(hist, key >> key_shift); };
+      if constexpr (C != 0) walk_digits_merged<C>(w[k], L.table_stride, i, emit);
+      else walk_digits(w[k], L, i, emit);
+    }
   }
   __syncthreads();
   if (threadIdx.x < COARSE_BINS) binhist[(size_t)threadIdx.x * nwg + blockIdx.x] = hist[threadIdx.x];
@@ -452,7 +496,7 @@ struct Rec4 {   // ref << (fb + 1) | fine << 1 | sign;  needs ref < 2^(31 - fb)
   static __device__ __forceinline__ u32 fine(const T& r, u32 fmask, int) { return (r >> 1) & fmask; }
   static __device__ __forceinline__ u32 payload(const T& r, int fb) { return (r >> (fb + 1)) | ((r & 1u) << 31); }
 };
-template <class REC>
+template <class REC, int C>
 __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter(const u32* __restrict__ scalars, size_t n, DigitLayout L, int key_shift,
                                                                    u32 fine_mask, int fb, const u32* __restrict__ binbase, int nwg,
                                                                    typename REC::T* __restrict__ tmp) {
@@ -470,10 +514,14 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter(const u32* __r
 #pragma unroll
   for (int k = 0; k < COARSE_PER_WG / SORT2_THREADS; k++) {
     const size_t i = lo + threadIdx.x + (size_t)k * SORT2_THREADS;
-    if (i < hi) walk_digits(w[k], L, i, [&](int, u32 key, u32 payload) {
-      const u32 pos = counter_inc_agg(cursor, key >> key_shift);
-      tmp[pos] = REC::make(payload, key & fine_mask, fb);
-    });
+    if (i < hi) {
+      auto emit = [&](int, u32 key, u32 payload) {
+        const u32 pos = counter_inc_agg(cursor, key >> key_shift);
+        tmp[pos] = REC::make(payload, key & fine_mask, fb);
+      };
+      if constexpr (C != 0) walk_digits_merged<C>(w[k], L.table_stride, i, emit);
+      else walk_digits(w[k], L, i, emit);
+    }
   }
 }
 // slice of bin b handled by sub-workgroup s of S: bins are the runs [binbase[b * nwg], binbase[(b+1) * nwg])
@@ -1022,20 +1070,6 @@ __global__ __launch_bounds__(T) void k_small_accumulate(const u32* __restrict__ 
 // (profiles/r03v_scan_path_size_sweep.txt) this path wins up to 2^14 coefficients at 10-bit windows (0.24 vs 0.38 ms at 2^13,
 // 0.32 vs 0.39 at 2^14) and loses from 2^15 on (0.93 vs 0.39).
 constexpr int SMALL_LIST_CAP = 4096;
-// Signed c-bit digits without the serial carry walk: with t = k + sum_w (2^(c-1) - 1) 2^(c w) the digit of window w is
-// window_w(t) - (2^(c-1) - 1) (the carries of that ONE long addition are exactly the recoding's carries: window w overflows iff
-// raw_w + carry > 2^(c-1)), same digits as walk_digits.  Word k of the constant, C a compile-time width:
-constexpr u32 digit_bias_word(int C, int k) {
-  const int nwin = 254 / C + 1;
-  const unsigned long long hm1 = (1ull << (C - 1)) - 1;
-  unsigned long long acc = 0;
-  for (int w = 0; w < nwin; w++) {
-    const int sh = w * C - 32 * k;
-    if (sh >= 0 && sh < 32) acc |= (hm1 << sh) & 0xffffffffull;
-    else if (sh < 0 && sh > -32) acc |= hm1 >> (-sh);
-  }
-  return (u32)acc;
-}
 template <int T, int C>
 __global__ __launch_bounds__(T) void k_small_accumulate_scan(const u32* __restrict__ scalars, size_t n, size_t table_stride, const u32* __restrict__ points_mont,
                                                               u32* __restrict__ buckets) {
@@ -1211,8 +1245,16 @@ struct SortArgs {
 template <class REC>
 static int sort_records(const SortArgs& a, hipStream_t s) {
   typedef typename REC::T R;
-  hipLaunchKernelGGL((k_coarse_scatter<REC>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb,
-                     (const u32*)a.binhist, a.nwg, (R*)a.tmp);
+  const int cw = (a.L.merged && !a.L.glv && (a.L.c == 16 || a.L.c == 17)) ? a.L.c : 0;
+  if (cw == 17)
+    hipLaunchKernelGGL((k_coarse_scatter<REC, 17>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb,
+                       (const u32*)a.binhist, a.nwg, (R*)a.tmp);
+  else if (cw == 16)
+    hipLaunchKernelGGL((k_coarse_scatter<REC, 16>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb,
+                       (const u32*)a.binhist, a.nwg, (R*)a.tmp);
+  else
+    hipLaunchKernelGGL((k_coarse_scatter<REC, 0>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb,
+                       (const u32*)a.binhist, a.nwg, (R*)a.tmp);
   hipLaunchKernelGGL((k_fine_count<REC>), dim3(COARSE_BINS, a.S), dim3(SORT2_THREADS), 0, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg, a.F, a.S,
                      a.fb, a.finehist);
   MZK_TRY(launch_exclusive_scan((const u32*)a.finehist, a.finehist, a.n_fine, a.scan3, s));
@@ -1382,7 +1424,12 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     const size_t sb_c = (n_coarse + SCAN_BLOCK - 1) / SCAN_BLOCK, sb_f = (n_fine + SCAN_BLOCK - 1) / SCAN_BLOCK;
     u32* scan2;
     MZK_TRY(ws_get(WS_MSM_SCAN, (sb_c + sb_f + 4) * 4, (void**)&scan2));
-    hipLaunchKernelGGL(k_coarse_count, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
+    if (L.merged && !L.glv && L.c == 17)
+      hipLaunchKernelGGL(k_coarse_count<17>, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
+    else if (L.merged && !L.glv && L.c == 16)
+      hipLaunchKernelGGL(k_coarse_count<16>, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
+    else
+      hipLaunchKernelGGL(k_coarse_count<0>, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
     MZK_TRY(launch_exclusive_scan((const u32*)binhist, binhist, n_coarse, scan2, s));
     int fb = 0;
     while ((1 << fb) < F) fb++;

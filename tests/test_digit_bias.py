@@ -33,7 +33,7 @@ def biased_digits(k, c):
 
 def test_biased_windows_equal_the_carry_walk():
     rng = random.Random(5)
-    for c in (8, 10, 13):
+    for c in (8, 10, 11, 12, 13, 16, 17):           # the widths with a compile-time walker (mzk_msm.hip)
         half = 1 << (c - 1)
         special = [0, 1, R - 1, R - 2, half, half + 1, half - 1, (1 << 254) - 1 if (1 << 254) - 1 < R else R - 1]
         special += [sum(half << (c * w) for w in range(254 // c)) % R, sum((half + 1) << (c * w) for w in range(254 // c)) % R]
