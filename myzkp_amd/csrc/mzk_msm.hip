@@ -524,6 +524,77 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter(const u32* __r
     }
   }
 }
+// The same with the records of 1024 scalars (one per lane, <= 15360 records) sorted by bin INSIDE LDS first and copied out as
+// contiguous runs (~60 records = 480 bytes per bin and chunk): a what-if build with perfectly coalesced stores ran in 32 us
+// against the 72 us of the isolated 8-byte stores above (profiles/r04g_*) -- the scatter, not the digits, is what that kernel
+// waits for.  Per chunk: histogram by LDS atomics, one-wave exclusive scan, placement through LDS cursors, copy-out.
+// Merged layout with a compile-time window width only (the digits are walked twice).
+constexpr int STAGE_RECORDS = 16 * SORT2_THREADS;       // per chunk: NWIN <= 16 records per scalar
+template <class REC, int C>
+__global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter_staged(const u32* __restrict__ scalars, size_t n, size_t table_stride, int key_shift,
+                                                                          u32 fine_mask, int fb, const u32* __restrict__ binbase, int nwg,
+                                                                          typename REC::T* __restrict__ tmp) {
+  typedef typename REC::T R;
+  extern __shared__ __attribute__((aligned(16))) u32 lds_stage[];
+  R* stage = reinterpret_cast<R*>(lds_stage);                                   // [STAGE_RECORDS]
+  unsigned char* stage_bin = reinterpret_cast<unsigned char*>(stage + STAGE_RECORDS);   // [STAGE_RECORDS]
+  u32* cursor = reinterpret_cast<u32*>(stage_bin + STAGE_RECORDS);              // [COARSE_BINS] running position of (bin, this workgroup) in tmp
+  u32* hist = cursor + COARSE_BINS;                                             // [COARSE_BINS] records of the chunk per bin, then placement cursors
+  u32* loff = hist + COARSE_BINS;                                               // [COARSE_BINS + 1] chunk-local exclusive offsets
+  u32* gpos = loff + COARSE_BINS + 1;                                           // [COARSE_BINS] destination of the chunk's run of each bin
+  static_assert(COARSE_BINS == 256, "one wave scans four bins per lane");
+  const int tid = threadIdx.x;
+  if (tid < COARSE_BINS) cursor[tid] = binbase[(size_t)tid * nwg + blockIdx.x];
+  const size_t lo = (size_t)blockIdx.x * COARSE_PER_WG;
+  const size_t hi = (lo + COARSE_PER_WG < n) ? lo + COARSE_PER_WG : n;
+  u32 w[COARSE_PER_WG / SORT2_THREADS][8];
+#pragma unroll
+  for (int k = 0; k < COARSE_PER_WG / SORT2_THREADS; k++) {
+    const size_t i = lo + tid + (size_t)k * SORT2_THREADS;
+    if (i < hi) load_scalar_canonical(scalars, i, w[k]);
+  }
+#pragma unroll 1
+  for (int k = 0; k < COARSE_PER_WG / SORT2_THREADS; k++) {
+    const size_t i = lo + tid + (size_t)k * SORT2_THREADS;
+    if (tid < COARSE_BINS) hist[tid] = 0;
+    __syncthreads();
+    if (i < hi) walk_digits_merged<C>(w[k], table_stride, i, [&](int, u32 key, u32) { counter_inc_agg(hist, key >> key_shift); });
+    __syncthreads();
+    if (tid < 64) {                      // exclusive scan of the 256 counts by one wave: four bins per lane
+      const u32 c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+      u32 incl = c0 + c1 + c2 + c3;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const u32 up = (u32)__shfl_up((int)incl, d, 64);
+        if (tid >= d) incl += up;
+      }
+      const u32 base = incl - (c0 + c1 + c2 + c3);
+      loff[4 * tid] = base; loff[4 * tid + 1] = base + c0; loff[4 * tid + 2] = base + c0 + c1; loff[4 * tid + 3] = base + c0 + c1 + c2;
+      if (tid == 63) loff[COARSE_BINS] = incl;
+    }
+    __syncthreads();
+    if (tid < COARSE_BINS) {
+      const u32 cnt = hist[tid];
+      gpos[tid] = cursor[tid];
+      cursor[tid] += cnt;
+      hist[tid] = loff[tid];             // placement cursor
+    }
+    __syncthreads();
+    if (i < hi) walk_digits_merged<C>(w[k], table_stride, i, [&](int, u32 key, u32 payload) {
+      const u32 bin = key >> key_shift;
+      const u32 pos = counter_inc_agg(hist, bin);
+      stage[pos] = REC::make(payload, key & fine_mask, fb);
+      stage_bin[pos] = (unsigned char)bin;
+    });
+    __syncthreads();
+    const u32 total = loff[COARSE_BINS];
+    for (u32 p = tid; p < total; p += SORT2_THREADS) {
+      const u32 b = stage_bin[p];
+      tmp[gpos[b] + (p - loff[b])] = stage[p];
+    }
+    __syncthreads();
+  }
+}
 // slice of bin b handled by sub-workgroup s of S: bins are the runs [binbase[b * nwg], binbase[(b+1) * nwg])
 __device__ __forceinline__ void fine_slice(const u32* __restrict__ binbase, int nwg, int b, int s, int S, u32* lo, u32* hi) {
   const u32 start = binbase[(size_t)b * nwg], end = binbase[(size_t)(b + 1) * nwg];   // binbase has 256 * nwg + 1 entries
@@ -1246,7 +1317,22 @@ template <class REC>
 static int sort_records(const SortArgs& a, hipStream_t s) {
   typedef typename REC::T R;
   const int cw = (a.L.merged && !a.L.glv && (a.L.c == 16 || a.L.c == 17)) ? a.L.c : 0;
-  if (cw == 17)
+  static const int env_staged = getenv("MZK_COARSE_STAGED") ? atoi(getenv("MZK_COARSE_STAGED")) : 1;      // 0: A/B against the direct stores
+  if (cw && env_staged) {
+    const size_t lds = (size_t)STAGE_RECORDS * (sizeof(R) + 1) + (size_t)(4 * COARSE_BINS + 1) * 4;
+    bool& attr = ctx().attr_done[sizeof(R) == 4 ? ATTR_COARSE_STAGED4 : ATTR_COARSE_STAGED8];
+    if (!attr) {
+      MZK_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<REC, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      MZK_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<REC, 17>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr = true;
+    }
+    if (cw == 17)
+      hipLaunchKernelGGL((k_coarse_scatter_staged<REC, 17>), dim3(a.nwg), dim3(SORT2_THREADS), lds, s, a.scalars, a.n, a.L.table_stride, a.key_shift, a.fine_mask,
+                         a.fb, (const u32*)a.binhist, a.nwg, (R*)a.tmp);
+    else
+      hipLaunchKernelGGL((k_coarse_scatter_staged<REC, 16>), dim3(a.nwg), dim3(SORT2_THREADS), lds, s, a.scalars, a.n, a.L.table_stride, a.key_shift, a.fine_mask,
+                         a.fb, (const u32*)a.binhist, a.nwg, (R*)a.tmp);
+  } else if (cw == 17)
     hipLaunchKernelGGL((k_coarse_scatter<REC, 17>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb,
                        (const u32*)a.binhist, a.nwg, (R*)a.tmp);
   else if (cw == 16)
