@@ -760,48 +760,34 @@ __global__ __launch_bounds__(256) void k_scan_local(const u32* __restrict__ in, 
     excl += v[k];
   }
 }
-__global__ __launch_bounds__(256) void k_scan_blocksums(u32* __restrict__ block_sums, size_t nblocks, u32* __restrict__ total_out) {
-  __shared__ u32 sh[256];
-  __shared__ u32 running;
-  if (threadIdx.x == 0) running = 0;
-  __syncthreads();
-  for (size_t base = 0; base < nblocks; base += 256) {
-    const size_t i = base + threadIdx.x;
-    const u32 v = (i < nblocks) ? block_sums[i] : 0u;
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-      u32 t = (threadIdx.x >= (unsigned)off) ? sh[threadIdx.x - off] : 0u;
-      __syncthreads();
-      sh[threadIdx.x] += t;
-      __syncthreads();
-    }
-    if (i < nblocks) block_sums[i] = running + sh[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == 255) running += sh[255];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *total_out = running;
-}
-// offsets[i] += block_sums[block(i)]; offsets[n] = total
-__global__ __launch_bounds__(256) void k_scan_finish(u32* __restrict__ offsets, const u32* __restrict__ block_sums,
-                                                      const u32* __restrict__ total, size_t n) {
+// offsets[i] += sum of the block totals in front of block(i); offsets[n] = total.  Every workgroup (256 consecutive i: ONE block)
+// sums the totals in front of its block itself -- a few dozen values -- instead of a launch of its own for their scan.
+__global__ __launch_bounds__(256) void k_scan_finish(u32* __restrict__ offsets, const u32* __restrict__ block_sums, size_t nblocks, size_t n) {
+  __shared__ u32 part[4];
+  static_assert(SCAN_BLOCK % 256 == 0, "one block index per workgroup");
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    offsets[i] = offsets[i] + block_sums[i / SCAN_BLOCK];
-  } else if (i == n) {
-    offsets[n] = *total;
-  }
+  const size_t first = (size_t)blockIdx.x * blockDim.x;
+  const bool total_wg = first >= n;                                   // the one workgroup past the data writes offsets[n]
+  const size_t blk = total_wg ? nblocks : first / SCAN_BLOCK;
+  u32 acc = 0;
+  for (size_t j = threadIdx.x; j < blk; j += 256) acc += block_sums[j];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += (u32)__shfl_xor((int)acc, d, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  const u32 pre = part[0] + part[1] + part[2] + part[3];
+  if (total_wg) { if (threadIdx.x == 0) offsets[n] = pre; }
+  else if (i < n) offsets[i] = offsets[i] + pre;
 }
 
 // out[i] = sum_{j<i} in[j] for i <= n (out[n] = total); in == out allowed; scratch: (ceil(n / SCAN_BLOCK) + 2) words
-// (A single-workgroup scan of the 65536 counters was measured: 40 us SLOWER per scan than these three launches -- one CU
+// Two launches: block-local scans, then every workgroup adds the totals in front of its block.
+// (A single-workgroup scan of the 65536 counters was measured: 40 us SLOWER per scan than the launches -- one CU
 // cannot stream and shuffle-scan 256 KiB as fast as 32 workgroups do, launch latency included.)
 static int launch_exclusive_scan(const u32* in, u32* out, size_t n, u32* scratch, hipStream_t s) {
   const size_t sb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
   hipLaunchKernelGGL(k_scan_local, dim3((unsigned)sb), dim3(256), 0, s, in, out, scratch, n);
-  hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(256), 0, s, scratch, sb, scratch + sb);
-  hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s, out, (const u32*)scratch, (const u32*)(scratch + sb), n);
+  hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((n + 255) / 256 + 1)), dim3(256), 0, s, out, (const u32*)scratch, sb, n);
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }
