@@ -658,8 +658,13 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter_direct(const typ
 // Staged form: the workgroup sorts up to STAGE_CAP records of its slice by bucket INSIDE LDS (count, prefix, place),
 // then copies the staged run out with consecutive lanes writing consecutive entries -- bucket runs leave as
 // contiguous stores instead of one dirty sector per record (HBM write traffic of this kernel 3.5x -> ~1x payload).
-constexpr int STAGE_CAP = 16384;
-constexpr int STAGE_PER_LANE = STAGE_CAP / SORT2_THREADS;     // 16 records per lane per round
+#ifndef MZK_STAGE_CAP
+#define MZK_STAGE_CAP 8192
+#endif
+// 8192 records per round = 56 KB of LDS and 8 records in registers per lane: two workgroups per CU, whose phases overlap (16384 =
+// one workgroup per CU: sort 0.170 -> 0.163 ms at 2^20, 0.726 -> 0.668 at 2^22; 4096 loses on the generic layout: profiles/r04l_*)
+constexpr int STAGE_CAP = MZK_STAGE_CAP;
+constexpr int STAGE_PER_LANE = STAGE_CAP / SORT2_THREADS;     // records per lane per round
 constexpr int STAGE_F_MAX = 2048;
 template <class REC>
 __global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter(const typename REC::T* __restrict__ tmp, const u32* __restrict__ binbase, int nwg, int F,
