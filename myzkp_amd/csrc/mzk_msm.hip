@@ -1488,9 +1488,11 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     const int F = (int)(NBtot / COARSE_BINS);
     const u32 fine_mask = (u32)F - 1u;
     const int nwg = (int)((n + COARSE_PER_WG - 1) / COARSE_PER_WG);
-    // records per fine workgroup: 32 Ki (>= 2 workgroups per CU at 2^20), 128 Ki when a bin has thousands of buckets
+    // records per fine workgroup: 32 Ki for the merged layout, 16 Ki for the generic one (measured: generic sort 0.250 -> 0.230 ms
+    // at 2^20, merged equal within noise from 16 Ki to 64 Ki: profiles/r04m_*), 128 Ki when a bin has thousands of buckets
     // (the [bucket][sub] histogram that is scanned afterwards has NB * S entries)
-    const size_t per_fine = (NBtot / COARSE_BINS >= 4096) ? 131072 : 32768;
+    static const int env_per_fine = getenv("MZK_PER_FINE") ? atoi(getenv("MZK_PER_FINE")) : 0;      // tuning: tools/timing/window_sweep.py
+    const size_t per_fine = env_per_fine > 0 ? (size_t)env_per_fine : ((NBtot / COARSE_BINS >= 4096) ? 131072 : (L.glv ? 16384 : 32768));
     int S = (int)((E_max / COARSE_BINS + per_fine - 1) / per_fine);
     if (S < 2) S = 2;
     if (S > 64) S = 64;
