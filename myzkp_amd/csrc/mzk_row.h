@@ -89,30 +89,20 @@ __device__ __forceinline__ Rep rep(u32 d) {
 }
 
 __device__ __forceinline__ u64 mad64(u32 a, u32 b, u64 c) { return c + (u64)a * b; }
+// Three independent chains of three multiply-adds (a single wave waits ~8 cycles for every DEPENDENT v_mad_u64_u32; the row
+// operations run alone on their SIMD), summed at the end -- same column sum.
 __device__ __forceinline__ u64 col_ab(const Rep& a, u32 b, u64 acc) {      // lane j: acc += sum_i a_i b_(j - i)
-  acc = mad64(a.l[0], b, acc);
-  acc = mad64(a.l[1], row_shr<1>(b), acc);
-  acc = mad64(a.l[2], row_shr<2>(b), acc);
-  acc = mad64(a.l[3], row_shr<3>(b), acc);
-  acc = mad64(a.l[4], row_shr<4>(b), acc);
-  acc = mad64(a.l[5], row_shr<5>(b), acc);
-  acc = mad64(a.l[6], row_shr<6>(b), acc);
-  acc = mad64(a.l[7], row_shr<7>(b), acc);
-  acc = mad64(a.l[8], row_shr<8>(b), acc);
-  return acc;
+  u64 s0 = mad64(a.l[0], b, acc), s1 = mad64(a.l[3], row_shr<3>(b), 0), s2 = mad64(a.l[6], row_shr<6>(b), 0);
+  s0 = mad64(a.l[1], row_shr<1>(b), s0); s1 = mad64(a.l[4], row_shr<4>(b), s1); s2 = mad64(a.l[7], row_shr<7>(b), s2);
+  s0 = mad64(a.l[2], row_shr<2>(b), s0); s1 = mad64(a.l[5], row_shr<5>(b), s1); s2 = mad64(a.l[8], row_shr<8>(b), s2);
+  return s0 + s1 + s2;
 }
 // lane j: sum_i C[i] v_(j - i) for a compile-time constant C (N' or p)
 template <const u32 (&C)[9]> __device__ __forceinline__ u64 col_const(u32 v, u64 acc) {
-  acc = mad64(C[0], v, acc);
-  acc = mad64(C[1], row_shr<1>(v), acc);
-  acc = mad64(C[2], row_shr<2>(v), acc);
-  acc = mad64(C[3], row_shr<3>(v), acc);
-  acc = mad64(C[4], row_shr<4>(v), acc);
-  acc = mad64(C[5], row_shr<5>(v), acc);
-  acc = mad64(C[6], row_shr<6>(v), acc);
-  acc = mad64(C[7], row_shr<7>(v), acc);
-  acc = mad64(C[8], row_shr<8>(v), acc);
-  return acc;
+  u64 s0 = mad64(C[0], v, acc), s1 = mad64(C[3], row_shr<3>(v), 0), s2 = mad64(C[6], row_shr<6>(v), 0);
+  s0 = mad64(C[1], row_shr<1>(v), s0); s1 = mad64(C[4], row_shr<4>(v), s1); s2 = mad64(C[7], row_shr<7>(v), s2);
+  s0 = mad64(C[2], row_shr<2>(v), s0); s1 = mad64(C[5], row_shr<5>(v), s1); s2 = mad64(C[8], row_shr<8>(v), s2);
+  return s0 + s1 + s2;
 }
 // n_j = lo(acc_j) + mid(acc_(j-1)) + hi(acc_(j-2)): the column sums re-cut at 29-bit boundaries without a ripple
 __device__ __forceinline__ u32 recut(u64 acc) {
