@@ -140,9 +140,11 @@ __device__ __forceinline__ Xyzz xyzz_add_quad(const Xyzz& a, const Xyzz& b, int 
     const Xyzz d = xyzz_dbl(a);                           // plain (non-cooperative) doubling, no cross-lane traffic
     o = xyzz_select(need_dbl, d, o);
   }
-  o = xyzz_select(generic && p_zero && !r_zero, xyzz_inf(), o);
-  o = xyzz_select(b_inf, a, o);
-  o = xyzz_select(a_inf, b, o);
+  if (__builtin_amdgcn_ballot_w64(a_inf || b_inf || p_zero) != 0) {       // wave-uniform: the three select chains only where some quad needs one
+    o = xyzz_select(generic && p_zero && !r_zero, xyzz_inf(), o);
+    o = xyzz_select(b_inf, a, o);
+    o = xyzz_select(a_inf, b, o);
+  }
   return o;
 }
 
