@@ -44,7 +44,7 @@ def recorded_traffic(kernel_prefix):
             m = re.match(r"(.*?)\s+launches=.*FETCH_SIZE avg=\s*([0-9.]+) KiB\s+WRITE_SIZE avg=\s*([0-9.]+) KiB", line)
             if m and kernel_prefix in m.group(1):
                 best = {"bytes": int((float(m.group(2)) + float(m.group(3))) * 1024),
-                        "source": "profiles/%s (recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, raw counters; not collected by this run)" % os.path.basename(path)}
+                        "source": "profiles/%s (recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, separate runs, raw counters; not collected by this run).  Calibration as the microarchitecture guide asks: for this library's 16-byte-per-lane loads the same counters read 33 + 32 MB for an NTT pass that streams exactly 32 MB of data + 1 MB of twiddles in and 32 MB out (profiles/r02o_hbm_traffic_pmc.txt), so the guide's x2 correction for FETCH_SIZE does not apply here" % os.path.basename(path)}
                 break       # first match per file = the KZG-commit section
     return best
 
