@@ -44,7 +44,7 @@ def recorded_traffic(kernel_prefix):
             m = re.match(r"(.*?)\s+launches=.*FETCH_SIZE avg=\s*([0-9.]+) KiB\s+WRITE_SIZE avg=\s*([0-9.]+) KiB", line)
             if m and kernel_prefix in m.group(1):
                 best = {"bytes": int((float(m.group(2)) + float(m.group(3))) * 1024),
-                        "source": "profiles/%s (recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, separate runs, raw counters; not collected by this run).  Calibration as the microarchitecture guide asks: for this library's 16-byte-per-lane loads the same counters read 33 + 32 MB for an NTT pass that streams exactly 32 MB of data + 1 MB of twiddles in and 32 MB out (profiles/r02o_hbm_traffic_pmc.txt), so the guide's x2 correction for FETCH_SIZE does not apply here" % os.path.basename(path)}
+                        "source": "profiles/%s (recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, separate runs, raw counters; not collected by this run).  Calibration as the microarchitecture guide asks (profiles/r02o_hbm_traffic_pmc.txt, known byte counts): requests of 128 contiguous bytes are tallied at 64 (BN254 NTT passes: 32 MB of data + 32 MB of twiddles read -> FETCH_SIZE 33.0 MB, the guide's x2), reads in 64-byte runs are counted 1:1 (M128 strided pass: 16 + 16 MB read -> 32.9 MB); k_seg_accumulate gathers 64-byte table rows, so its raw figure stands" % os.path.basename(path)}
                 break       # first match per file = the KZG-commit section
     return best
 
