@@ -381,6 +381,33 @@ int mzk_kzg_commit_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t
  * lanes as the batch commit; every (y_i, w_i) bit-identical to mzk_kzg_open_srs_dev. */
 int mzk_kzg_open_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, const uint64_t* us, void* d_ys, void* d_ws_xy,
                                int max_in_flight, void* stream);
+/* The reference's actual call pattern -- hundreds of SHORT polynomials against one `pk`: one commit_kzg per row
+ * (das/avail.rs:88-98), per chunk (das/eigenda.rs:92-101), per folded polynomial (algebra/gemini.rs:112-114), one open_kzg
+ * per cell (das/avail.rs:132).  When the handle holds narrow window tables (8- or 10..13-bit: the default up to 2^14 points)
+ * and count > 1, the whole batch runs as ONE bucket problem over (polynomial x bucket) -- digit sort, accumulation, bucket
+ * reduction and one tail workgroup PER POLYNOMIAL, the same handful of launches whatever `count` is -- instead of one commit
+ * per lane: 256 commitments of 2^10 coefficients take about what six single calls took (0.76 ms; 0.52 - 0.59 ms over the
+ * direct tables below).  Arguments and results exactly as the _batch_dev forms, which route here themselves from four
+ * polynomials on; handles without narrow tables take the lanes of the _batch forms.  Every point bit-identical to the single
+ * call.  Work enqueued on `stream` only: no fork, no extra contexts needed. */
+int mzk_kzg_commit_srs_many_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, void* d_out_xy, void* stream);
+/* Optional second table set of a SHORT SRS (at most 2^14 points) for those batches: every multiple a signed window digit can
+ * ask for, D[w][i][m] = (m + 1) 2^(c w) P_i -- (254 / c + 1) n 2^(c-1) affine points: 0.85 GiB for 1024 powers at c = 10.  With
+ * it a batch needs no buckets at all: one gathered row and one mixed addition per (coefficient, window), a tree per 256
+ * coefficients and one fold per polynomial -- two launches, no digit sort, no bucket reduction (the large HBM is what makes
+ * this affordable; build once per SRS like the window tables).  window_bits: 8..12, or 0 = the widest that fits max_bytes
+ * (0 = a quarter of the free device memory, at most 4 GiB).  Blocking (the tables are complete on return); calling it again with
+ * another width replaces them; mzk_srs_drop_direct releases them (mzk_srs_free does too).  Results are bit-identical with and
+ * without: the same group element, converted to the same canonical affine point. */
+int mzk_srs_build_direct(mzk_srs* srs, int window_bits, size_t max_bytes, void* stream);
+void mzk_srs_drop_direct(mzk_srs* srs);
+/* What a handle holds: window width of its tables (0 = none: prepared points only), of its direct tables (0 = none), and the
+ * device bytes of both together. */
+int mzk_srs_window_bits(const mzk_srs* srs);
+int mzk_srs_direct_bits(const mzk_srs* srs);
+size_t mzk_srs_table_bytes(const mzk_srs* srs);
+int mzk_kzg_open_srs_many_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, const uint64_t* us, void* d_ys, void* d_ws_xy,
+                              void* stream);
 
 /* open_kzg / setup_kzg with everything device-resident (end-to-end pipelines: iNTT -> commit -> open).
  * d_y: 4 limbs, d_w_xy: 8 limbs on the device; u / alpha / g1 are host parameters. */

@@ -893,6 +893,7 @@ int mzk_srs_upload(const uint64_t* powers_xy, size_t n, mzk_srs** out) {
 void mzk_srs_free(mzk_srs* srs) {
   if (!srs) return;
   if (srs->d_points_mont) (void)hipFree(srs->d_points_mont);
+  if (srs->d_direct) (void)hipFree(srs->d_direct);
   delete srs;
 }
 int mzk_kzg_commit_srs(const mzk_srs* srs, const uint64_t* coef, size_t n, uint64_t out_xy[8]) {
@@ -978,33 +979,108 @@ static int run_in_flight(size_t count, int max_in_flight, hipStream_t caller, JO
 
 extern "C" {
 
-int mzk_kzg_commit_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, void* d_out_xy, int max_in_flight,
-                                 void* stream) {
+// Short polynomials against narrow window tables: the whole batch as ONE bucket problem (msm_many_dev_impl) instead of one
+// commit per lane -- every kernel of it runs over (polynomial x bucket), one tail workgroup per polynomial.
+
+// Direct tables (every multiple of every window-table row) for the grid-batched commitments of short polynomials.
+int mzk_srs_build_direct(mzk_srs* srs, int window_bits, size_t max_bytes, void* stream) {
   MZK_ENTER();
+  WsGuard wsg((hipStream_t)stream);
+  if (!srs) { set_error("srs_build_direct: null handle"); return MZK_E_ARG; }
+  MZK_TRY(srs_check_ctx(srs));
+  if (srs->n == 0) return MZK_OK;
+  if (srs->n > MSM_DIRECT_MAX_N) { set_error("srs_build_direct: direct tables are for SRS of at most %zu points (this one has %zu)", MSM_DIRECT_MAX_N, srs->n); return MZK_E_ARG; }
+  if (window_bits != 0 && (window_bits < 8 || window_bits > 12)) { set_error("srs_build_direct: window_bits must be 0 (by budget) or 8..12"); return MZK_E_ARG; }
+  size_t budget = max_bytes;
+  if (budget == 0) {                       // default: a quarter of what is free now, at most 4 GiB
+    size_t free_b = 0, total_b = 0;
+    MZK_HIP(hipMemGetInfo(&free_b, &total_b));
+    budget = free_b / 4;
+    if (budget > ((size_t)4 << 30)) budget = (size_t)4 << 30;
+  }
+  int c = window_bits;
+  if (c == 0) {                            // the widest windows (fewest additions per coefficient) that fit
+    for (c = 12; c > 8 && msm_direct_bytes(srs->n, c) > budget; c--) {}
+  }
+  const size_t bytes = msm_direct_bytes(srs->n, c);
+  if (bytes > budget) { set_error("srs_build_direct: %d-bit direct tables of %zu points take %zu bytes, the budget is %zu", c, srs->n, bytes, budget); return MZK_E_ARG; }
+  if (srs->d_direct && srs->direct_bits == c) return MZK_OK;
+  void* d = nullptr;
+  if (hipMalloc(&d, bytes) != hipSuccess) { (void)hipGetLastError(); set_error("srs_build_direct: hipMalloc of %zu bytes failed", bytes); return MZK_E_HIP; }
+  int rc = msm_build_direct(srs->d_points_mont, srs->n, c, d, (hipStream_t)stream);
+  if (rc == MZK_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = MZK_E_HIP;
+  if (rc != MZK_OK) { (void)hipFree(d); return rc; }
+  if (srs->d_direct) (void)hipFree(srs->d_direct);       // (the stream is idle: nothing reads the old tables any more)
+  srs->d_direct = d; srs->direct_bits = c; srs->direct_bytes = bytes;
+  return MZK_OK;
+}
+void mzk_srs_drop_direct(mzk_srs* srs) {
+  if (!srs || !srs->d_direct) return;
+  (void)hipDeviceSynchronize();
+  (void)hipFree(srs->d_direct);
+  srs->d_direct = nullptr; srs->direct_bits = 0; srs->direct_bytes = 0;
+}
+int mzk_srs_window_bits(const mzk_srs* srs) { return (srs && srs->has_tables) ? srs->window_bits : 0; }
+int mzk_srs_direct_bits(const mzk_srs* srs) { return (srs && srs->d_direct) ? srs->direct_bits : 0; }
+size_t mzk_srs_table_bytes(const mzk_srs* srs) {
+  if (!srs) return 0;
+  return srs->n * 64 * (srs->has_tables ? (size_t)msm_table_windows(srs->window_bits) : 2) + srs->direct_bytes;
+}
+
+// The _many forms take the grid pass whenever the handle can (any count >= 1); the _batch forms from MANY_MIN_COUNT polynomials
+// on (two or three are served as well by the lanes: the pass has ~10 launches and an 80-us tail of its own).
+constexpr size_t MANY_MIN_COUNT = 4;
+static int commit_batch_route(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, void* d_out_xy, int max_in_flight, size_t many_from, hipStream_t stream) {
   if (!srs || ((!d_coefs || !d_out_xy) && count)) { set_error("commit_srs_batch_dev: null pointer"); return MZK_E_ARG; }
   MZK_TRY(srs_check_ctx(srs));
   if (n > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }
   if (count == 0) return MZK_OK;
+  if (count >= many_from && srs_many_capable(srs)) {
+    WsGuard wsg(stream);
+    return msm_many_srs(srs, d_coefs, n, n, count, d_out_xy, stream);
+  }
   const char* coefs = (const char*)d_coefs;
   char* outs = (char*)d_out_xy;
-  return run_in_flight(count, max_in_flight, (hipStream_t)stream, [&](size_t i, hipStream_t ls) {
+  return run_in_flight(count, max_in_flight, stream, [&](size_t i, hipStream_t ls) {
     return msm_dev_impl(coefs + i * n * 32, srs->d_points_mont, n, srs->kind(), srs->n, outs + i * 64, false, ls);
   });
 }
 // open_kzg (kzg.rs:61-72) of `count` polynomials, polynomial i at the point us[i]: y_i = f_i(u_i) and the witness
 // commitment w_i, the quotient and its MSM of each opening on one lane
-int mzk_kzg_open_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, const uint64_t* us_host, void* d_ys, void* d_ws_xy,
-                               int max_in_flight, void* stream) {
-  MZK_ENTER();
+static int open_batch_route(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, const uint64_t* us_host, void* d_ys, void* d_ws_xy, int max_in_flight,
+                            size_t many_from, hipStream_t stream) {
   if (!srs || ((!d_coefs || !us_host || !d_ys || !d_ws_xy) && count)) { set_error("open_srs_batch_dev: null pointer"); return MZK_E_ARG; }
   MZK_TRY(srs_check_ctx(srs));
   if (n > 1 && n - 1 > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }
   if (count == 0) return MZK_OK;
+  if (count >= many_from && kzg_open_many_supported(srs, n)) {
+    WsGuard wsg(stream);
+    return kzg_open_many_dev(srs, d_coefs, n, count, us_host, d_ys, d_ws_xy, stream);
+  }
   const char* coefs = (const char*)d_coefs;
   char *ys = (char*)d_ys, *ws = (char*)d_ws_xy;
-  return run_in_flight(count, max_in_flight, (hipStream_t)stream, [&](size_t i, hipStream_t ls) {
+  return run_in_flight(count, max_in_flight, stream, [&](size_t i, hipStream_t ls) {
     return kzg_open_dev(coefs + i * n * 32, n, us_host + 4 * i, srs->d_points_mont, srs->kind(), srs->n, ys + i * 32, ws + i * 64, nullptr, ls);
   });
+}
+int mzk_kzg_commit_srs_many_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, void* d_out_xy, void* stream) {
+  MZK_ENTER();
+  return commit_batch_route(srs, d_coefs, n, count, d_out_xy, 0, 1, (hipStream_t)stream);
+}
+int mzk_kzg_open_srs_many_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, const uint64_t* us_host, void* d_ys, void* d_ws_xy,
+                              void* stream) {
+  MZK_ENTER();
+  return open_batch_route(srs, d_coefs, n, count, us_host, d_ys, d_ws_xy, 0, 1, (hipStream_t)stream);
+}
+int mzk_kzg_commit_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, void* d_out_xy, int max_in_flight,
+                                 void* stream) {
+  MZK_ENTER();
+  return commit_batch_route(srs, d_coefs, n, count, d_out_xy, max_in_flight, MANY_MIN_COUNT, (hipStream_t)stream);
+}
+int mzk_kzg_open_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, const uint64_t* us_host, void* d_ys, void* d_ws_xy,
+                               int max_in_flight, void* stream) {
+  MZK_ENTER();
+  return open_batch_route(srs, d_coefs, n, count, us_host, d_ys, d_ws_xy, max_in_flight, MANY_MIN_COUNT, (hipStream_t)stream);
 }
 int mzk_kzg_commit_srs_batch(const mzk_srs* srs, const uint64_t* coefs, size_t n, size_t count, uint64_t* out_xy) {
   MZK_ENTER();

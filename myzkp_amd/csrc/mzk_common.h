@@ -174,6 +174,16 @@ static inline bool msm_srs_default_tables(size_t n) { return n > 0; }
 int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int point_kind, size_t table_stride, void* d_out,
                  bool out_partial_xyzz, hipStream_t s, const std::function<int()>* points_ready = nullptr);
 
+// Grid-batched form for many short polynomials against one set of narrow window tables (mzk_msm.hip, mzk_kzg.hip)
+bool msm_many_supported(int window_bits);
+int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size_t count, const void* d_tables, int c, size_t table_stride, void* d_out,
+                      hipStream_t s);
+constexpr size_t MSM_DIRECT_MAX_N = (size_t)1 << 14;
+size_t msm_direct_bytes(size_t n, int c);
+int msm_build_direct(const void* d_points_mont, size_t n, int c, void* d_direct, hipStream_t s);
+int msm_direct_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size_t count, const void* d_direct, int c, size_t table_stride, void* d_out,
+                             hipStream_t s);
+
 int xyzz_batch_to_affine(const void* d_xyzz, size_t count, void* d_out, bool out_mont, hipStream_t s);
 int msm_build_tables(const void* d_points_mont, size_t n, void* d_tables, int window_bits, hipStream_t s);
 int msm_fold_partials_impl(const void* d_partials, int count, void* d_out_xy, hipStream_t s);
@@ -197,5 +207,19 @@ struct mzk_srs {
   bool has_tables;
   int window_bits;
   int ctx_index;         // the context (device) that owns d_points_mont
+  // optional (mzk_srs_build_direct): every multiple a window digit can ask for, D[(w n + i) 2^(direct_bits-1) + m] = (m + 1) 2^(direct_bits w) P_i,
+  // affine Montgomery -- commitments of many short polynomials then need no buckets at all (msm_many_srs)
+  void* d_direct = nullptr;
+  int direct_bits = 0;
+  size_t direct_bytes = 0;
   int kind() const { return has_tables ? (mzk::MSM_PTS_TABLES | (window_bits << 8)) : (int)mzk::MSM_PTS_MONT; }
 };
+
+namespace mzk {
+// `count` commitments of n coefficients each (polynomial j at d_scalars + j * stride_elems * 32 bytes) against one handle, as ONE
+// pass: over the direct tables when the handle has them, over its narrow window tables otherwise (srs_many_capable)
+bool srs_many_capable(const mzk_srs* srs);
+int msm_many_srs(const mzk_srs* srs, const void* d_scalars, size_t n, size_t stride_elems, size_t count, void* d_out, hipStream_t s);
+bool kzg_open_many_supported(const mzk_srs* srs, size_t n);
+int kzg_open_many_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, const uint64_t* us_host, void* d_ys, void* d_ws_xy, hipStream_t s);
+}  // namespace mzk

@@ -453,4 +453,110 @@ int kzg_open_dev(const void* d_coef, size_t n, const uint64_t* u_host, const voi
   return msm_dev_impl(bbuf + 8, d_points, n - 1, point_kind, table_stride, d_w_xy, false, s);
 }
 
+// ---- open_kzg of MANY short polynomials, polynomial j at its own point u_j (kzg.rs:61-72 once per polynomial, as
+// das/avail.rs:132 does per cell): ONE workgroup per polynomial solves the suffix recurrence b_i = c_i + u b_{i+1} --
+// lane L owns the K = ceil(n / 256) coefficients [L K, (L + 1) K): chunk value at u by Horner, a log-step suffix scan of
+// the 256 chunk values with u^K, u^2K, ... through LDS, then the chunk is filled from its successor's carry.  y_j = b_0,
+// q_j = b_1 .. b_{n-1} (row j of `q`, rows q_stride_words apart); the witness MSMs then run as one grid-batched pass
+// (msm_many_dev_impl).  Field arithmetic is exact, so the canonical outputs equal the chunked single-opening path bit for bit.
+constexpr int OPENM_THREADS = 256;
+constexpr size_t OPENM_MAX_N = (size_t)1 << 14;
+constexpr int PUT_WORDS_MAX = 112;                 // 32-byte values per launch through the kernel-argument buffer (3.5 KiB)
+struct PutBatch { u32 w[PUT_WORDS_MAX][8]; };
+__global__ void k_put_words8(PutBatch b, int count, u32* __restrict__ dst) {
+  const int i = threadIdx.x;
+  if (i < count) st8(dst + 8 * i, b.w[i]);
+}
+__global__ __launch_bounds__(OPENM_THREADS) void k_open_many(const u32* __restrict__ coefs, size_t n, size_t stride_words, const u32* __restrict__ us,
+                                                              u32* __restrict__ q, size_t q_stride_words, u32* __restrict__ ys) {
+  typedef FrParams P;
+  __shared__ u32 S[OPENM_THREADS][P::L];
+  const size_t j = blockIdx.x;
+  const int L = threadIdx.x;
+  const u32* c = coefs + j * stride_words;
+  u32 uw[8];
+  ld8(us + 8 * j, uw);
+  const FrE u = fe_to_mont<P>(fe_unpack<P>(uw));            // u R: fe_mul(x, u) = x u for plain x
+  const size_t K = (n + OPENM_THREADS - 1) / OPENM_THREADS;
+  const size_t lo = (size_t)L * K;
+  const size_t hi = (lo + K < n) ? lo + K : n;
+  FrE mine = fe_zero<P>();
+  if (lo < n) {
+    mine = fr_gload(c, hi - 1);
+    for (size_t t = hi - 1; t-- > lo;) mine = fe_add<P>(fe_mul<P>(mine, u), fr_gload(c, t));
+    mine = fe_reduce<P>(mine);
+  }
+  FrE pw = fe_one<P>(), base = u;                           // u^K in Montgomery form
+  for (size_t k = K; k; k >>= 1) {
+    if (k & 1) pw = fe_mul<P>(pw, base);
+    base = fe_sqr<P>(base);
+  }
+#pragma unroll
+  for (int i = 0; i < P::L; i++) S[L][i] = mine.l[i];
+  for (int d = 1; d < OPENM_THREADS; d <<= 1) {
+    __syncthreads();
+    FrE other = fe_zero<P>();
+    if (L + d < OPENM_THREADS) {
+#pragma unroll
+      for (int i = 0; i < P::L; i++) other.l[i] = S[L + d][i];
+    }
+    __syncthreads();
+    mine = fe_reduce<P>(fe_add<P>(mine, fe_mul<P>(other, pw)));
+#pragma unroll
+    for (int i = 0; i < P::L; i++) S[L][i] = mine.l[i];
+    pw = fe_sqr<P>(pw);
+  }
+  __syncthreads();
+  if (lo >= n) return;
+  FrE acc = fe_zero<P>();                                   // b at index (L + 1) K
+  if (L + 1 < OPENM_THREADS) {
+#pragma unroll
+    for (int i = 0; i < P::L; i++) acc.l[i] = S[L + 1][i];
+  }
+  u32* qj = q + j * q_stride_words;
+  for (size_t t = hi; t-- > lo;) {
+    acc = fe_reduce<P>(fe_add<P>(fe_mul<P>(acc, u), fr_gload(c, t)));
+    if (t > 0) fr_gstore(qj, t - 1, acc);
+    else fr_gstore(ys, j, acc);
+  }
+}
+
+bool kzg_open_many_supported(const mzk_srs* srs, size_t n) { return n <= OPENM_MAX_N && srs_many_capable(srs); }
+// d_ys: count * 8 words, d_ws_xy: count * 16 words.
+int kzg_open_many_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, const uint64_t* us_host, void* d_ys, void* d_ws_xy, hipStream_t s) {
+  if (count == 0) return MZK_OK;
+  if (!srs || !us_host || !d_ys || !d_ws_xy || (!d_coefs && n)) { set_error("kzg_open_many: null pointer"); return MZK_E_ARG; }
+  const HostField* fr = host_field(MZK_FIELD_FR);
+  for (size_t i = 0; i < count; i++) if (!h_is_canonical(fr, us_host + 4 * i)) { set_error("kzg_open: u not canonical"); return MZK_E_RANGE; }
+  if (n == 0) {  // empty polynomials: y = 0, quotient empty -> infinity
+    MZK_HIP(hipMemsetAsync(d_ys, 0, count * 32, s));
+    MZK_HIP(hipMemsetAsync(d_ws_xy, 0, count * 64, s));
+    return MZK_OK;
+  }
+  size_t per_pass = (((size_t)1 << 22) + n - 1) / n;
+  u32 *d_us, *d_q;
+  const size_t first_cnt = count < per_pass ? count : per_pass;
+  MZK_TRY(ws_get(WS_MISC_B, first_cnt * 32, (void**)&d_us));
+  MZK_TRY(ws_get(WS_MISC_A, first_cnt * n * 32, (void**)&d_q));
+  for (size_t first = 0; first < count; first += per_pass) {
+    const size_t cnt = (count - first < per_pass) ? count - first : per_pass;
+    for (size_t k = 0; k < cnt; k += PUT_WORDS_MAX) {
+      PutBatch b;
+      const int m = (int)((cnt - k < (size_t)PUT_WORDS_MAX) ? cnt - k : (size_t)PUT_WORDS_MAX);
+      for (int i = 0; i < m; i++)
+        for (int l = 0; l < 4; l++) {
+          const uint64_t v = us_host[4 * (first + k + i) + l];
+          b.w[i][2 * l] = (u32)v; b.w[i][2 * l + 1] = (u32)(v >> 32);
+        }
+      hipLaunchKernelGGL(k_put_words8, dim3(1), dim3(128), 0, s, b, m, d_us + 8 * k);
+    }
+    hipLaunchKernelGGL(k_open_many, dim3((unsigned)cnt), dim3(OPENM_THREADS), 0, s, (const u32*)d_coefs + first * n * 8, n, n * 8, (const u32*)d_us, d_q, n * 8,
+                       (u32*)d_ys + first * 8);
+    MZK_HIP(hipGetLastError());
+    // w_j = MSM(q_j, powers), q_j of n - 1 coefficients     (kzg.rs:70)
+    MZK_TRY(msm_many_srs(srs, d_q, n - 1, n, cnt, (u32*)d_ws_xy + first * 16, s));
+  }
+  return MZK_OK;
+}
+
 }  // namespace mzk

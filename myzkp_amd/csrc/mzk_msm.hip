@@ -24,6 +24,7 @@
 #include "mzk_coop.h"
 #include "mzk_row.h"
 #include "mzk_glv.h"
+#include "mzk_affine_wave.h"
 
 namespace mzk {
 
@@ -1569,6 +1570,348 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   MZK_TRY(reduce_bucket_sets(buckets, sh.lgB, red_windows, L.merged != 0, horner_c, wsum, (u32*)d_out, out_partial_xyzz, s));
   MZK_HIP(hipGetLastError());
   return MZK_OK;
+}
+
+// ---- many small commitments against ONE SRS in one pass (grid-batched) ---------------------------------------------------
+// The reference's callers commit to hundreds of short polynomials against one `pk` in a loop: one commit_kzg per row
+// (das/avail.rs:88-98), per chunk (das/eigenda.rs:92-101), per folded polynomial (algebra/gemini.rs:112-114), and open per
+// cell (avail.rs:132).  One such commitment is nothing but latency on this machine (0.135 ms at 2^10 coefficients: two
+// launches, 250 CUs idle under a 75-us single-workgroup tail), so the batch is laid out as ONE large bucket problem:
+// bucket (j, b) = bucket b of polynomial j, count * 2^(c-1) buckets in all, entries = (window table row, sign) exactly as
+// in the single commit.  Then the general pipeline's throughput kernels apply unchanged:
+//   k_many_count     workgroup (j, chunk of 1024 coefficients): digits -> LDS histogram -> cnt[j][b][chunk]
+//   exclusive scan   over [j][b][chunk]: bucket (j, b) is the concatenation of its chunks' runs
+//   k_many_scatter   the same walk again, LDS cursors, entries to their final place
+//   k_seg_accumulate / k_seg_combine[_heavy]   one lane per fixed-size segment of the sorted entries (mixed additions)
+//   k_halve_step*    the wide halving steps, grid.y = polynomial
+//   k_reduce_tail_row  one workgroup PER POLYNOMIAL: late steps, weighted sum, affine conversion (wave inversion)
+// Every output is the canonical affine point of the same group element the single call returns, hence bit-identical.
+constexpr int MANY_CHUNK = 1024;
+constexpr int MANY_THREADS = 256;
+constexpr int MANY_PER_LANE = MANY_CHUNK / MANY_THREADS;
+template <int C>
+__global__ __launch_bounds__(MANY_THREADS) void k_many_count(const u32* __restrict__ scalars, size_t n, size_t stride_words, int nch, u32* __restrict__ cnt) {
+  constexpr int NB = 1 << (C - 1);
+  __shared__ u32 hist[NB];
+  const size_t j = blockIdx.x / (unsigned)nch;
+  const int ch = (int)(blockIdx.x % (unsigned)nch);
+  for (int b = threadIdx.x; b < NB; b += MANY_THREADS) hist[b] = 0;
+  __syncthreads();
+  const u32* sc = scalars + j * stride_words;
+  const size_t lo = (size_t)ch * MANY_CHUNK;
+  const size_t hi = (lo + MANY_CHUNK < n) ? lo + MANY_CHUNK : n;
+  u32 w[MANY_PER_LANE][8];
+#pragma unroll
+  for (int k = 0; k < MANY_PER_LANE; k++) {
+    const size_t i = lo + threadIdx.x + (size_t)k * MANY_THREADS;
+    if (i < hi) load_scalar_canonical(sc, i, w[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < MANY_PER_LANE; k++) {
+    const size_t i = lo + threadIdx.x + (size_t)k * MANY_THREADS;
+    if (i < hi) walk_digits_merged<C>(w[k], 0, i, [&](int, u32 key, u32) { counter_inc_agg(hist, key); });
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < NB; b += MANY_THREADS) cnt[(j * NB + b) * (size_t)nch + ch] = hist[b];
+}
+// offs = exclusive scan of cnt (offs[total count] = number of entries).  compact (nch > 1 only): the bucket offsets
+// offs[j][b][0] gathered into the dense array k_seg_accumulate reads, compact[nbuckets] = total.
+template <int C>
+__global__ __launch_bounds__(MANY_THREADS) void k_many_scatter(const u32* __restrict__ scalars, size_t n, size_t stride_words, int nch, size_t table_stride,
+                                                                const u32* __restrict__ offs, u32* __restrict__ compact, size_t nbuckets,
+                                                                u32* __restrict__ entries) {
+  constexpr int NB = 1 << (C - 1);
+  __shared__ u32 cursor[NB];
+  const size_t j = blockIdx.x / (unsigned)nch;
+  const int ch = (int)(blockIdx.x % (unsigned)nch);
+  for (int b = threadIdx.x; b < NB; b += MANY_THREADS) {
+    const u32 o = offs[(j * NB + b) * (size_t)nch + ch];
+    cursor[b] = o;
+    if (compact != nullptr && ch == 0) compact[j * NB + b] = o;
+  }
+  if (compact != nullptr && blockIdx.x == 0 && threadIdx.x == 0) compact[nbuckets] = offs[nbuckets * (size_t)nch];
+  __syncthreads();
+  const u32* sc = scalars + j * stride_words;
+  const size_t lo = (size_t)ch * MANY_CHUNK;
+  const size_t hi = (lo + MANY_CHUNK < n) ? lo + MANY_CHUNK : n;
+  u32 w[MANY_PER_LANE][8];
+#pragma unroll
+  for (int k = 0; k < MANY_PER_LANE; k++) {
+    const size_t i = lo + threadIdx.x + (size_t)k * MANY_THREADS;
+    if (i < hi) load_scalar_canonical(sc, i, w[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < MANY_PER_LANE; k++) {
+    const size_t i = lo + threadIdx.x + (size_t)k * MANY_THREADS;
+    if (i < hi) walk_digits_merged<C>(w[k], table_stride, i, [&](int, u32 key, u32 payload) { entries[counter_inc_agg(cursor, key)] = payload; });
+  }
+}
+
+bool msm_many_supported(int window_bits) { return window_bits == 8 || (window_bits >= 10 && window_bits <= 13); }
+
+// `count` MSMs of n scalars each (polynomial j at d_scalars + j * stride_elems * 32 bytes) against the window tables of one SRS
+// handle (c-bit windows, msm_many_supported(c)); d_out: count affine points (ABI form), 64 bytes apart.
+int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size_t count, const void* d_tables, int c, size_t table_stride, void* d_out,
+                      hipStream_t s) {
+  if (count == 0) return MZK_OK;
+  if (!d_out || ((!d_scalars || !d_tables) && n)) { set_error("msm_many: null pointer"); return MZK_E_ARG; }
+  if (!msm_many_supported(c)) { set_error("msm_many: window width %d has no grid-batched path", c); return MZK_E_ARG; }
+  if (n == 0) {  // empty polynomials -> points at infinity (polynomial.rs:160)
+    MZK_HIP(hipMemsetAsync(d_out, 0, count * 64, s));
+    return MZK_OK;
+  }
+  const int nwin = msm_table_windows(c), lgB = c - 1;
+  const size_t NB = (size_t)1 << lgB;
+  if ((size_t)nwin * table_stride > ((size_t)1 << 31)) { set_error("msm_many: table rows exceed the 31-bit point references"); return MZK_E_ARG; }
+  const int nch = (int)((n + MANY_CHUNK - 1) / MANY_CHUNK);
+  // one pass handles at most 2^21 buckets and 2^22 coefficients (entries, partial slots and buckets stay below ~1.5 GiB of workspace)
+  size_t per_pass = ((size_t)1 << 21) / NB;
+  const size_t by_coefs = (((size_t)1 << 22) + n - 1) / n;
+  if (by_coefs < per_pass) per_pass = by_coefs;
+  if (per_pass < 1) per_pass = 1;
+  for (size_t first = 0; first < count; first += per_pass) {
+    const size_t cnt = (count - first < per_pass) ? count - first : per_pass;
+    const u32* sc = (const u32*)d_scalars + first * stride_elems * 8;
+    u32* out = (u32*)d_out + first * 16;
+    const size_t NBtot = cnt * NB, ncnt = NBtot * (size_t)nch;
+    const size_t E_max = cnt * n * (size_t)nwin;
+    const size_t resident_lanes = (size_t)ctx().num_cu * 4 * 4 * 64;
+    size_t seg_sz = (E_max + resident_lanes - 1) / resident_lanes;
+    if (seg_sz < 16) seg_sz = 16;
+    const u32 seg = (u32)seg_sz;
+    const size_t T = (E_max + seg_sz - 1) / seg_sz;
+    const size_t nslots = T + NBtot + 1;
+    const size_t heavy_words = 4 + (T + NBtot) / HEAVY_SLOTS;
+    const size_t sb = (ncnt + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    u32 *offs, *compact, *entries, *scan_tmp, *buckets, *slots;
+    MZK_TRY(ws_get(WS_MSM_COUNTS, (ncnt + 1) * 4, (void**)&offs));
+    MZK_TRY(ws_get(WS_MSM_ENTRIES, E_max * 4, (void**)&entries));
+    MZK_TRY(ws_get(WS_MSM_SCAN, (sb + 2) * 4, (void**)&scan_tmp));
+    MZK_TRY(ws_get(WS_MSM_BUCKETS, NBtot * 128, (void**)&buckets));
+    MZK_TRY(ws_get(WS_MSM_SLOTS, nslots * SLOT_WORDS * 4 + heavy_words * 4, (void**)&slots));
+    compact = offs;
+    if (nch > 1) MZK_TRY(ws_get(WS_MSM_OFFSETS, (NBtot + 1) * 4, (void**)&compact));
+    u32* heavy = slots + nslots * SLOT_WORDS;
+    prof_begin(s, MZK_PH_MSM_SORT);
+    MZK_HIP(hipMemsetAsync(heavy, 0, 8, s));
+    const unsigned nwg = (unsigned)(cnt * (size_t)nch);
+#define MZK_MANY_CASE(C) case C:                                                                                                                    \
+      hipLaunchKernelGGL((k_many_count<C>), dim3(nwg), dim3(MANY_THREADS), 0, s, sc, n, stride_elems * 8, nch, offs);                                \
+      MZK_TRY(launch_exclusive_scan((const u32*)offs, offs, ncnt, scan_tmp, s));                                                                     \
+      hipLaunchKernelGGL((k_many_scatter<C>), dim3(nwg), dim3(MANY_THREADS), 0, s, sc, n, stride_elems * 8, nch, table_stride, (const u32*)offs,     \
+                         nch > 1 ? compact : (u32*)nullptr, NBtot, entries);                                                                         \
+      break;
+    switch (c) { MZK_MANY_CASE(8) MZK_MANY_CASE(10) MZK_MANY_CASE(11) MZK_MANY_CASE(12) MZK_MANY_CASE(13) }
+#undef MZK_MANY_CASE
+    MZK_HIP(hipGetLastError());
+    prof_end(s, MZK_PH_MSM_SORT);
+    prof_begin(s, MZK_PH_MSM_ACCUMULATE);
+    hipLaunchKernelGGL(k_seg_accumulate<false>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, (const u32*)d_tables, (const u32*)compact, (const u32*)entries,
+                       slots, NBtot, seg);
+    prof_end(s, MZK_PH_MSM_ACCUMULATE);
+    prof_begin(s, MZK_PH_MSM_SEG_COMBINE);
+    hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NBtot + 127) / 128)), dim3(128), 0, s, slots, (const u32*)compact, buckets, NBtot, seg, heavy);
+    hipLaunchKernelGGL(k_seg_combine_heavy, dim3(512), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)compact, buckets, seg, (const u32*)heavy);
+    MZK_HIP(hipGetLastError());
+    prof_end(s, MZK_PH_MSM_SEG_COMBINE);
+    prof_begin(s, MZK_PH_MSM_REDUCE);
+    int t_start = 0;
+    const size_t tail_max = row_tail_max_ops();
+    while (t_start < lgB && ((size_t)(t_start + 1) << (lgB - t_start - 1)) > tail_max) t_start++;
+    for (int t = 0; t < t_start; t++) {
+      const size_t total = (size_t)(t + 1) << (lgB - t - 1);
+      if (total * cnt >= ((size_t)1 << 16))
+        hipLaunchKernelGGL(k_halve_step_wide, dim3((unsigned)((total + 127) / 128), (unsigned)cnt), dim3(128), 0, s, buckets, lgB, t);
+      else
+        hipLaunchKernelGGL(k_halve_step, dim3((unsigned)((4 * total + 127) / 128), (unsigned)cnt), dim3(128), 0, s, buckets, lgB, t);
+    }
+    MZK_TRY(launch_reduce_tail_row(buckets, lgB, t_start, (int)cnt, out, 1, s));
+    MZK_HIP(hipGetLastError());
+    prof_end(s, MZK_PH_MSM_REDUCE);
+  }
+  return MZK_OK;
+}
+
+// ---- the same batch over DIRECT tables: no buckets at all ------------------------------------------------------------------
+// D[(w n + i) M + m] = (m + 1) 2^(c w) P_i for every magnitude a signed c-bit digit can take (M = 2^(c-1)): a commitment is then
+// sum over (i, w) of +-D[w][i][|d| - 1] -- n (254 / c + 1) mixed additions in ANY order, so there is no digit sort, no bucket
+// accumulation by segments, no segment combine, no bucket reduction.  Affordable only because the polynomials are short and the
+// HBM is large: 0.85 GiB for a 1024-power SRS at 10-bit windows (26 x 1024 x 512 points), built once per handle on request
+// (mzk_srs_build_direct).  Two launches for the whole batch:
+//   k_direct_accumulate  workgroup = 256 coefficients of one polynomial, one coefficient per lane: its digits (the long addition
+//                        of walk_digits_merged, then one window per trip), one gathered row and one mixed addition per window,
+//                        then the 256 partials -> one by the tree of the small-commit path (quads, the last levels row additions)
+//   k_fold_partials_row  one wave per polynomial: its ceil(n / 256) partials, then the affine conversion (wave inversion)
+constexpr int DIRECT_THREADS = 256;
+size_t msm_direct_bytes(size_t n, int c) { return (size_t)msm_table_windows(c) * n * ((size_t)1 << (c - 1)) * 64; }
+// multiples 1 .. M of `rows` table rows (affine Montgomery) as XYZZ records, row-major: out[(r M + m)] = (m + 1) T[r]
+__global__ __launch_bounds__(64) void k_direct_chain(const u32* __restrict__ rows_mont, size_t rows, int M, u32* __restrict__ out_xyzz) {
+  const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  u32 w[16];
+  load_words8(rows_mont + r * 16, w);
+  load_words8(rows_mont + r * 16 + 8, w + 8);
+  const bool inf = affine_words_is_inf(w);
+  const Affine a = affine_load_mont(w);
+  Xyzz acc = xyzz_inf();
+  for (int m = 0; m < M; m++) {
+    if (!inf) acc = xyzz_madd_signed_with<FeCpp>(acc, a, false);
+    xyzz_gstore(out_xyzz, r * (size_t)M + m, acc);
+  }
+}
+int msm_build_direct(const void* d_points_mont, size_t n, int c, void* d_direct, hipStream_t s) {
+  if (n == 0) return MZK_OK;
+  const int nwin = msm_table_windows(c), M = 1 << (c - 1);
+  const size_t rows = (size_t)nwin * n;
+  // window tables T[w][i] = 2^(c w) P_i of this width (scratch), then the multiples of every row in slices of <= 2^21 records
+  u32 *tables, *tmp;
+  MZK_TRY(ws_get(WS_MISC_C, rows * 64, (void**)&tables));
+  MZK_TRY(msm_build_tables(d_points_mont, n, tables, c, s));
+  size_t slice = ((size_t)1 << 21) / (size_t)M;
+  if (slice < 64) slice = 64;
+  if (slice > rows) slice = rows;
+  MZK_TRY(ws_get(WS_MISC_D, slice * (size_t)M * 128, (void**)&tmp));
+  for (size_t r0 = 0; r0 < rows; r0 += slice) {
+    const size_t cnt = (rows - r0 < slice) ? rows - r0 : slice;
+    hipLaunchKernelGGL(k_direct_chain, dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, s, (const u32*)tables + r0 * 16, cnt, M, tmp);
+    MZK_HIP(hipGetLastError());
+    MZK_TRY(xyzz_batch_to_affine(tmp, cnt * (size_t)M, (u32*)d_direct + r0 * (size_t)M * 16, true, s));
+  }
+  return MZK_OK;
+}
+// Work item t of a polynomial = (coefficient t / NWIN, window t % NWIN).  A polynomial's n NWIN items are cut into `parts`
+// contiguous ranges, one workgroup each, lane l taking items first + l, first + l + 256, ...: the host picks `parts` so that the
+// grid is about ONE round of resident workgroups whatever count and n are (a lane per coefficient would be 26 additions long
+// and, at 256 x 2^10, 1.33 rounds: measured 0.60 ms where the additions themselves are 0.48).  Every item recomputes the
+// biased scalar of its coefficient (one 256-bit addition: ~1 % of the mixed addition it feeds; consecutive lanes mostly share
+// the coefficient, so the loads are broadcasts), requests the NEXT item's row before adding the current one, and the 256
+// partials end in the tree of the small-commit path.
+template <int C>
+__device__ __forceinline__ bool direct_item(const u32* __restrict__ sc, size_t t, size_t table_stride, const u32* __restrict__ direct, const u32** rec, bool* neg) {
+  constexpr int NWIN = 254 / C + 1;
+  constexpr u32 HALF = 1u << (C - 1), MASKC = (1u << C) - 1u;
+  const size_t i = t / NWIN;
+  const int win = (int)(t - i * NWIN);
+  u32 w[8], tw[10];
+  load_scalar_canonical(sc, i, w);
+  u64 cy = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { cy += (u64)w[k] + digit_bias_word(C, k); tw[k] = (u32)cy; cy >>= 32; }
+  tw[8] = (u32)cy + digit_bias_word(C, 8);
+  tw[9] = 0;
+  const int bit = win * C, k = bit >> 5, sft = bit & 31;
+  u32 lo = tw[0], hi = tw[1];
+#pragma unroll
+  for (int q = 1; q < 9; q++) { lo = (k == q) ? tw[q] : lo; hi = (k == q) ? tw[q + 1] : hi; }
+  const u32 v = (u32)((((u64)hi << 32) | lo) >> sft) & MASKC;       // digit + HALF - 1
+  if (v == HALF - 1u) return false;                                  // digit 0
+  *neg = v < HALF - 1u;
+  const u32 mag = *neg ? (HALF - 1u) - v : v - (HALF - 1u);
+  *rec = direct + (((size_t)win * table_stride + i) * HALF + (mag - 1u)) * 16;
+  return true;
+}
+template <int C>
+__global__ __launch_bounds__(DIRECT_THREADS) void k_direct_accumulate(const u32* __restrict__ scalars, size_t n, size_t stride_words, int parts, size_t table_stride,
+                                                                       const u32* __restrict__ direct, u32* __restrict__ slots) {
+  constexpr int NWIN = 254 / C + 1;
+  const size_t j = blockIdx.x / (unsigned)parts;
+  const int part = (int)(blockIdx.x % (unsigned)parts);
+  const u32* sc = scalars + j * stride_words;
+  const size_t items = n * NWIN;
+  const size_t per = (items + parts - 1) / parts;
+  const size_t first = (size_t)part * per;
+  const size_t last = (first + per < items) ? first + per : items;
+  Xyzz acc = xyzz_inf();
+  u32 pw[16];
+  const u32* rec = nullptr;
+  bool neg = false;
+  size_t t = first + threadIdx.x;
+  bool have = (t < last) && direct_item<C>(sc, t, table_stride, direct, &rec, &neg);
+  if (have) { load_words8(rec, pw); load_words8(rec + 8, pw + 8); }
+  while (t < last) {
+    const bool cur_have = have, cur_neg = neg;
+    u32 cw[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) cw[q] = pw[q];
+    t += DIRECT_THREADS;
+    have = (t < last) && direct_item<C>(sc, t, table_stride, direct, &rec, &neg);
+    if (have) { load_words8(rec, pw); load_words8(rec + 8, pw + 8); }
+    if (cur_have && !affine_words_is_inf(cw)) acc = xyzz_madd_signed_with<FeAsm>(acc, affine_load_mont(cw), cur_neg);
+  }
+  xyzz_gstore_raw(slots, (size_t)blockIdx.x * DIRECT_THREADS + threadIdx.x, acc);
+}
+// one workgroup per polynomial: lane l sums the partials of lane l of its `parts` accumulate workgroups, the 256 sums go through
+// the tree of the small-commit path, and wave 0 converts the result to the affine point
+__global__ __launch_bounds__(DIRECT_THREADS) void k_direct_finish(const u32* __restrict__ slots, int parts, u32* __restrict__ scratch, u32* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) u32 sh[DIRECT_THREADS * 32];
+  const size_t j = blockIdx.x;
+  Xyzz acc = xyzz_gload_raw(slots, (j * parts) * DIRECT_THREADS + threadIdx.x);
+  for (int p = 1; p < parts; p++) acc = xyzz_add_with<FeAsm>(acc, xyzz_gload_raw(slots, (j * parts + p) * DIRECT_THREADS + threadIdx.x));
+  small_tree_store<DIRECT_THREADS>(sh, acc, DIRECT_THREADS, j, scratch);          // leaves the sum in sh[0 .. 32) as well
+  __syncthreads();
+  if (threadIdx.x < 64) wave_store_affine(sh, out + j * 16);
+}
+// more than DIRECT_FINISH_PARTS partial sets per polynomial (few, long polynomials): workgroup (j, g) of `groups` per polynomial
+// sums the sets g, g + groups, ... lane by lane first, so that no lane ever chains more than ~sqrt(parts) additions
+constexpr int DIRECT_FINISH_PARTS = 8;
+__global__ __launch_bounds__(DIRECT_THREADS) void k_direct_fold(const u32* __restrict__ slots, int parts, int groups, u32* __restrict__ folded) {
+  const size_t j = blockIdx.x / (unsigned)groups;
+  const int g = (int)(blockIdx.x % (unsigned)groups);
+  Xyzz acc = xyzz_gload_raw(slots, (j * parts + g) * DIRECT_THREADS + threadIdx.x);
+  for (int p = g + groups; p < parts; p += groups) acc = xyzz_add_with<FeAsm>(acc, xyzz_gload_raw(slots, (j * parts + p) * DIRECT_THREADS + threadIdx.x));
+  xyzz_gstore_raw(folded, (size_t)blockIdx.x * DIRECT_THREADS + threadIdx.x, acc);
+}
+int msm_direct_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size_t count, const void* d_direct, int c, size_t table_stride, void* d_out,
+                             hipStream_t s) {
+  if (count == 0) return MZK_OK;
+  if (!d_out || ((!d_scalars || !d_direct) && n)) { set_error("msm_direct_many: null pointer"); return MZK_E_ARG; }
+  if (n == 0) {
+    MZK_HIP(hipMemsetAsync(d_out, 0, count * 64, s));
+    return MZK_OK;
+  }
+  const size_t items = n * (size_t)msm_table_windows(c);
+  const size_t per_pass = (size_t)1 << 14;                           // polynomials per pass (lane partials: <= 64 x 256 x 144 bytes each)
+  for (size_t first = 0; first < count; first += per_pass) {
+    const size_t cnt = (count - first < per_pass) ? count - first : per_pass;
+    // workgroups per polynomial: one round of resident workgroups over the batch (three 256-lane workgroups per CU at the
+    // kernel's VGPR count), at least one, at most one per 256 items, and at most 64 (k_direct_fold / k_direct_finish add them)
+    const size_t resident = (size_t)ctx().num_cu * 3;
+    size_t parts = (resident + cnt / 2) / cnt;
+    const size_t max_parts = (items + DIRECT_THREADS - 1) / DIRECT_THREADS;
+    if (parts > max_parts) parts = max_parts;
+    if (parts > 64) parts = 64;
+    if (parts < 1) parts = 1;
+    size_t groups = 0;
+    if (parts > (size_t)DIRECT_FINISH_PARTS) for (groups = 2; groups * groups < parts; groups++) {}
+    u32 *slots, *scratch;
+    MZK_TRY(ws_get(WS_MSM_SLOTS, cnt * (parts + groups) * DIRECT_THREADS * SLOT_WORDS * 4, (void**)&slots));
+    MZK_TRY(ws_get(WS_MSM_BUCKETS, cnt * 128, (void**)&scratch));
+    const u32* sc = (const u32*)d_scalars + first * stride_elems * 8;
+    const unsigned nwg = (unsigned)(cnt * parts);
+    prof_begin(s, MZK_PH_MSM_ACCUMULATE);
+#define MZK_DIRECT_CASE(C) case C: hipLaunchKernelGGL((k_direct_accumulate<C>), dim3(nwg), dim3(DIRECT_THREADS), 0, s, sc, n, stride_elems * 8, (int)parts, table_stride, (const u32*)d_direct, slots); break;
+    switch (c) { MZK_DIRECT_CASE(8) MZK_DIRECT_CASE(9) MZK_DIRECT_CASE(10) MZK_DIRECT_CASE(11) MZK_DIRECT_CASE(12)
+      default: set_error("msm_direct_many: no kernel for %d-bit direct tables", c); return MZK_E_ARG; }
+#undef MZK_DIRECT_CASE
+    MZK_HIP(hipGetLastError());
+    prof_end(s, MZK_PH_MSM_ACCUMULATE);
+    prof_begin(s, MZK_PH_MSM_REDUCE);
+    if (groups) {
+      u32* folded = slots + cnt * parts * DIRECT_THREADS * SLOT_WORDS;
+      hipLaunchKernelGGL(k_direct_fold, dim3((unsigned)(cnt * groups)), dim3(DIRECT_THREADS), 0, s, (const u32*)slots, (int)parts, (int)groups, folded);
+      hipLaunchKernelGGL(k_direct_finish, dim3((unsigned)cnt), dim3(DIRECT_THREADS), 0, s, (const u32*)folded, (int)groups, scratch, (u32*)d_out + first * 16);
+    } else {
+      hipLaunchKernelGGL(k_direct_finish, dim3((unsigned)cnt), dim3(DIRECT_THREADS), 0, s, (const u32*)slots, (int)parts, scratch, (u32*)d_out + first * 16);
+    }
+    MZK_HIP(hipGetLastError());
+    prof_end(s, MZK_PH_MSM_REDUCE);
+  }
+  return MZK_OK;
+}
+bool srs_many_capable(const mzk_srs* srs) { return srs->d_direct != nullptr || (srs->has_tables && msm_many_supported(srs->window_bits)); }
+int msm_many_srs(const mzk_srs* srs, const void* d_scalars, size_t n, size_t stride_elems, size_t count, void* d_out, hipStream_t s) {
+  if (srs->d_direct) return msm_direct_many_dev_impl(d_scalars, n, stride_elems, count, srs->d_direct, srs->direct_bits, srs->n, d_out, s);
+  return msm_many_dev_impl(d_scalars, n, stride_elems, count, srs->d_points_mont, srs->window_bits, srs->n, d_out, s);
 }
 
 int msm_fold_partials_impl(const void* d_partials, int count, void* d_out_xy, hipStream_t s) {

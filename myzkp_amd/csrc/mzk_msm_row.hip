@@ -9,36 +9,12 @@
 #include "mzk_coop.h"
 #include "mzk_row.h"
 #include "mzk_inv_wave.h"
+#include "mzk_affine_wave.h"
 
 namespace mzk {
 
 using rowop::Lane;
 using rowop::Pt;
-
-// XYZZ record (packed, in LDS or global memory) -> canonical affine point at the ABI (plain words, all-zero = infinity), by ONE
-// WAVE: the inversion of ZZ ZZZ is spread over the lanes (mzk_inv_wave.h), the six products around it run redundantly in every
-// lane.  All 64 lanes must be active; lane 0 stores.
-__device__ __forceinline__ void wave_store_affine(const u32* rec, u32* __restrict__ out) {
-  typedef FqParams P;
-  u32 w[32];
-#pragma unroll
-  for (int i = 0; i < 32; i++) w[i] = rec[i];
-  const Xyzz p = xyzz_load(w);
-  u32 wds[16];
-  if (xyzz_is_inf(p)) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) wds[i] = 0;
-  } else {
-    const Fq di = invw::inv<P>(fe_mul<P>(p.ZZ, p.ZZZ));          // 1 / (ZZ ZZZ)
-    const Fq izz = fe_mul<P>(di, p.ZZZ), izzz = fe_mul<P>(di, p.ZZ);
-    Affine af;
-    af.x = fe_reduce<P>(fe_mul<P>(p.X, izz));
-    af.y = fe_reduce<P>(fe_mul<P>(p.Y, izzz));
-    affine_store_plain(af, wds);
-  }
-  if ((threadIdx.x & 63) == 0)
-    for (int i = 0; i < 16; i++) out[i] = wds[i];
-}
 
 __device__ __forceinline__ void halve_indices(int lgB, int t, size_t id, size_t* lo, size_t* hi) {
   const int lgh = lgB - t - 1;
@@ -168,8 +144,8 @@ __global__ __launch_bounds__(RTAIL_THREADS) void k_reduce_tail_row(u32* __restri
     rowop::store(res, row_add_shared(x, y, ln), ln);
   }
   MZK_TT(42);
-  if (finish_affine) {
-    wave_store_affine(res, out);
+  if (finish_affine) {          // one affine point per bucket set (a single set for one commit; one per polynomial for mzk_*_many)
+    wave_store_affine(res, out + (size_t)blockIdx.x * 16);
     MZK_TT(60);
     return;
   }
@@ -192,14 +168,16 @@ __global__ __launch_bounds__(64) void k_window_combine_row(const u32* __restrict
   wave_store_affine(sh, out);
 }
 // fold `count` XYZZ partials (the gathered records of the ranks / contexts) into one affine point
+// (grid: one wave per result -- workgroup g folds partials [g count, (g + 1) count) into out[g]; one workgroup for the ranks' fold)
 __global__ __launch_bounds__(64) void k_fold_partials_row(const u32* __restrict__ partials, int count, u32* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) u32 sh[32];
   const Lane ln = rowop::lane_init();
+  partials += (size_t)blockIdx.x * (size_t)count * 32;
   Pt tot = rowop::pt_inf();
   for (int i = 0; i < count; i++) tot = rowop::add(tot, rowop::load(partials + (size_t)i * 32, ln), ln);
   rowop::store(sh, tot, ln);
   __syncthreads();
-  wave_store_affine(sh, out);
+  wave_store_affine(sh, out + (size_t)blockIdx.x * 16);
 }
 
 // Horner groups for lgB terms: contiguous ranges [b[g], b[g + 1]), g = 0 .. 3, minimising the longest chain --
@@ -248,6 +226,13 @@ int launch_window_combine_row(const u32* wsum, int nwin, int c, int out_xyzz, u3
 }
 int launch_fold_partials_row(const u32* partials, int count, u32* out, hipStream_t s) {
   hipLaunchKernelGGL(k_fold_partials_row, dim3(1), dim3(64), 0, s, partials, count, out);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+// `groups` independent folds of `count` consecutive partials each -> groups affine points
+int launch_fold_partial_groups_row(const u32* partials, int count, size_t groups, u32* out, hipStream_t s) {
+  if (groups == 0) return MZK_OK;
+  hipLaunchKernelGGL(k_fold_partials_row, dim3((unsigned)groups), dim3(64), 0, s, partials, count, out);
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }
