@@ -225,8 +225,7 @@ def main():
         if attempt == 0:
             L.mzk_srs_free(hh)
     srs._h = hh
-    # msm_srs_window_bits (mzk_common.h): the default window width of an SRS handle by its size
-    srs_window_bits = 8 if n <= 1024 else (10 if n <= (1 << 14) else (16 if n < (1 << 19) else 17))
+    srs_window_bits = int(L.mzk_srs_window_bits(srs._h))       # the library's default width for an SRS of this size (msm_srs_window_bits)
     srs_table_windows = 254 // srs_window_bits + 1
     progress("SRS handle built")
     # The HIP runtime stalls once for 35-45 ms a few thousand dispatches into a process (measured: one stall in 120 000
@@ -496,6 +495,78 @@ def main():
             torch.cuda.empty_cache()
     width16 = run_other_width(16) if srs_window_bits != 16 else None
 
+    def run_small_batch():
+        """The reference's actual call pattern: hundreds of SHORT polynomials committed against one pk in a loop (das/avail.rs:88-98
+        per row, das/eigenda.rs:92-101 per chunk, algebra/gemini.rs:112-114).  One call for the batch (mzk_kzg_commit_srs_many_dev:
+        the whole batch as one bucket problem; with mzk_srs_build_direct no buckets at all) against the same batch one commit at a
+        time; first and last point of every batch checked against the oracle's Pippenger, all of them against the single calls."""
+        if world != 1 or args.no_two_in_flight:
+            return None
+        res = {}
+        L.mzk_srs_table_bytes.restype = ctypes.c_size_t
+        for lg, count in ((10, 256), (12, 64)):
+            nn = 1 << lg
+            key = "%d_x_2^%d" % (count, lg)
+            hs = ctypes.c_void_p()
+            try:
+                pt = torch.empty(nn * 8, dtype=torch.int64, device=dev)
+                cf = torch.empty(count * nn * 4, dtype=torch.int64, device=dev)
+                check(L.mzk_synth_g1_points_dev(ctypes.c_uint64(SEED + 31), ctypes.c_size_t(nn), dptr(pt), stream))
+                check(L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(SEED + 32), ctypes.c_size_t(count * nn), dptr(cf), stream))
+                check(L.mzk_srs_from_device(dptr(pt), ctypes.c_size_t(nn), ctypes.byref(hs), stream))
+                o_many = torch.zeros(count * 8, dtype=torch.int64, device=dev)
+                o_one = torch.zeros(count * 8, dtype=torch.int64, device=dev)
+
+                def many():
+                    check(L.mzk_kzg_commit_srs_many_dev(hs, dptr(cf), ctypes.c_size_t(nn), ctypes.c_size_t(count), dptr(o_many), stream))
+
+                def loop():
+                    for k in range(count):
+                        check(L.mzk_kzg_commit_srs_dev(hs, ctypes.c_void_p(cf.data_ptr() + k * nn * 32), ctypes.c_size_t(nn),
+                                                       ctypes.c_void_p(o_one.data_ptr() + k * 64), ctypes.c_int(0), stream))
+
+                def clock(fn, reps):
+                    for _ in range(2):
+                        fn()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        fn()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t0) / reps * 1e3
+                e = {"polynomials": count, "coefficients_each": nn, "window_bits": int(L.mzk_srs_window_bits(hs))}
+                e["one_at_a_time_ms"] = clock(loop, 2)
+                e["one_call_ms"] = clock(many, max(K, 10))
+                e["same_points_as_single_calls"] = bool(torch.equal(o_many, o_one))
+                pts_h = pt.cpu().numpy().view(np.uint64).reshape(nn, 8)
+                cf_h = cf.cpu().numpy().view(np.uint64).reshape(count, nn, 4)
+                got = mz.array_to_points(o_many.cpu().numpy().view(np.uint64).reshape(count, 8))
+                e["first_and_last_equal_oracle"] = bool(got[0] == orc.msm_fast(cf_h[0], pts_h) and got[-1] == orc.msm_fast(cf_h[-1], pts_h))
+                for bits in (10, 12):
+                    b0 = L.mzk_srs_table_bytes(hs)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    check(L.mzk_srs_build_direct(hs, ctypes.c_int(bits), ctypes.c_size_t(16 << 30), stream))
+                    build_ms = (time.perf_counter() - t0) * 1e3
+                    o_many.zero_()
+                    d = {"table_bytes": int(L.mzk_srs_table_bytes(hs) - b0), "table_build_ms": build_ms, "one_call_ms": clock(many, max(K, 10))}
+                    d["same_points_as_single_calls"] = bool(torch.equal(o_many, o_one))
+                    d["us_per_commit"] = d["one_call_ms"] / count * 1e3
+                    e["direct_tables_%d_bit" % bits] = d
+                e["us_per_commit"] = e["one_call_ms"] / count * 1e3
+                e["speedup_over_one_at_a_time"] = e["one_at_a_time_ms"] / e["one_call_ms"]
+                res[key] = e
+            except Exception as ex:
+                res[key] = {"error": str(ex)[:300]}
+            finally:
+                if hs:
+                    L.mzk_srs_free(hs)
+                torch.cuda.empty_cache()
+        res["metric"] = ("ms per batch of KZG commitments of short polynomials against one SRS: mzk_kzg_commit_srs_many_dev (one call, default narrow "
+                         "window tables; direct_tables_*: after mzk_srs_build_direct) vs one mzk_kzg_commit_srs_dev per polynomial")
+        return res
+    small_batch = run_small_batch()
+
     def run_ntt_batched():
         """Many transforms per call (mzk_ntt_batch_dev): a prover interpolates / extends every column of a trace, and a batch
         gives the kernels several rounds of workgroups per CU, i.e. loads and stores under other tiles' butterflies."""
@@ -576,8 +647,10 @@ def main():
             hs, hp = scalars.cpu().numpy().view(np.uint64).reshape(-1, 4).copy(), points.cpu().numpy().view(np.uint64).reshape(-1, 8).copy()
             hv = ntt_in.cpu().numpy().view(np.uint64).reshape(-1, 4).copy()
             wr = mz.root_of_unity(mz.FIELD_FR, args.log2n)
-            hsrs = mz.Srs.__new__(mz.Srs)
-            hsrs._h, hsrs.n = srs._h, n          # the bench's device-resident handle, host coefficients
+            hcommit_out = np.zeros((1, 8), dtype=np.uint64)
+
+            def commit_host():                    # the bench's device-resident handle, host coefficients (no wrapper object that could free it)
+                check(L.mzk_kzg_commit_srs(srs._h, hs.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n), hcommit_out.ctypes.data_as(ctypes.c_void_p)))
             hout = np.zeros_like(hv)             # the caller's output vector, allocated once (a fresh one per call costs page faults)
             wl = mz.to_limbs([wr], 4)
 
@@ -585,7 +658,7 @@ def main():
                 check(L.mzk_ntt(mz.FIELD_FR, wl.ctypes.data_as(ctypes.c_void_p), hv.ctypes.data_as(ctypes.c_void_p), hout.ctypes.data_as(ctypes.c_void_p),
                                 ctypes.c_size_t(n), 0))
             legs = (("msm_g1_bn254_host_buffers", lambda: mz.msm_g1(hs, hp), n, "pairs/s", 96 * n),
-                    ("kzg_commit_srs_host_scalars", lambda: hsrs.commit(hs), n, "pairs/s", 32 * n),
+                    ("kzg_commit_srs_host_scalars", commit_host, n, "pairs/s", 32 * n),
                     ("ntt_host_buffers", ntt_host, n, "elems/s", 64 * n))
             for name, fn, units, unit, nbytes in legs:
                 fn(); fn()
@@ -595,7 +668,6 @@ def main():
                     r = fn()
                 dtp = (time.perf_counter() - t0) / reps
                 res[name] = {"ms_per_call": dtp * 1e3, "value": units / dtp, "unit": unit, "bytes_over_pcie": nbytes}
-            hsrs._h = None                         # not ours to free
             res["msm_matches_resident_result"] = bool(mz.msm_g1(hs, hp) == mz.array_to_points(result.cpu().numpy().view(np.uint64))[0]) if world == 1 else None
         except Exception as ex:
             res["error"] = str(ex)[:300]
@@ -688,6 +760,7 @@ def main():
         "kzg_commit_two_in_flight": pipelined,
         "kzg_commit_four_in_flight": pipelined4,
         "kzg_commit_16_bit_windows": width16 if width16 is not None else ({"note": "16 bits is the default width at this size: see `value`"} if srs_window_bits == 16 else None),
+        "kzg_commit_small_batch": small_batch,
         "msm_no_tables_in_flight": generic4,
         "ntt_batched": ntt_batched,
         "pcie_inclusive": pcie_inclusive,

@@ -381,6 +381,8 @@ int mzk_kzg_commit_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t
  * lanes as the batch commit; every (y_i, w_i) bit-identical to mzk_kzg_open_srs_dev. */
 int mzk_kzg_open_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t n, size_t count, const uint64_t* us, void* d_ys, void* d_ws_xy,
                                int max_in_flight, void* stream);
+/* the same with coefficients and results in host memory (blocking): ys = count * 4 limbs, ws_xy = count * 8 limbs */
+int mzk_kzg_open_srs_batch(const mzk_srs* srs, const uint64_t* coefs, size_t n, size_t count, const uint64_t* us, uint64_t* ys, uint64_t* ws_xy);
 /* The reference's actual call pattern -- hundreds of SHORT polynomials against one `pk`: one commit_kzg per row
  * (das/avail.rs:88-98), per chunk (das/eigenda.rs:92-101), per folded polynomial (algebra/gemini.rs:112-114), one open_kzg
  * per cell (das/avail.rs:132).  When the handle holds narrow window tables (8- or 10..13-bit: the default up to 2^14 points)

@@ -397,6 +397,31 @@ class Srs:
         _check(lib().mzk_kzg_commit_srs_batch(self._h, _p(c), ctypes.c_size_t(c.shape[1]), ctypes.c_size_t(count), _p(out)))
         return array_to_points(out[:count])
 
+    def commit_many(self, coefs):
+        """commit_kzg of every row of `coefs` as ONE grid-batched pass (mzk_kzg_commit_srs_many_dev): the reference's per-row /
+        per-chunk loops (das/avail.rs:88-98, das/eigenda.rs:92-101, algebra/gemini.rs:112-114)."""
+        import torch
+        c = np.ascontiguousarray(coefs, dtype=np.uint64)
+        count = c.shape[0]
+        if count == 0:
+            return []
+        c = c.reshape(count, -1, 4)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        d_c = torch.from_numpy(c.view(np.int64).reshape(-1).copy()).cuda() if c.size else torch.zeros(4, dtype=torch.int64, device="cuda")
+        d_o = torch.zeros(count * 8, dtype=torch.int64, device="cuda")
+        _check(lib().mzk_kzg_commit_srs_many_dev(self._h, ctypes.c_void_p(d_c.data_ptr()), ctypes.c_size_t(c.shape[1]), ctypes.c_size_t(count),
+                                                 ctypes.c_void_p(d_o.data_ptr()), st))
+        torch.cuda.synchronize()
+        return array_to_points(d_o.cpu().numpy().view(np.uint64).reshape(count, 8))
+
+    def build_direct(self, window_bits=0, max_bytes=0):
+        """Direct tables for batches of short polynomials (mzk_srs_build_direct); returns the width built."""
+        _check(lib().mzk_srs_build_direct(self._h, int(window_bits), ctypes.c_size_t(max_bytes), None))
+        return int(lib().mzk_srs_direct_bits(self._h))
+
+    def drop_direct(self):
+        lib().mzk_srs_drop_direct(self._h)
+
     def save(self, path, with_tables=False):
         """Raw little-endian dump of powers_1 (+ optionally the window tables): mzk_srs_save."""
         _check(lib().mzk_srs_save(self._h, os.fsencode(path), int(bool(with_tables))))

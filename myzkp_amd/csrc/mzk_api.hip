@@ -24,8 +24,8 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 static std::atomic<uint64_t> g_owner{0};
 static thread_local int t_depth = 0;
 static thread_local char t_marker;            // its address is this thread's id
-EntryGuard::EntryGuard() : ok(true) {
-  if (t_depth > 0) { t_depth++; return; }
+EntryGuard::EntryGuard() : ok(true), nested(false) {
+  if (t_depth > 0) { t_depth++; nested = true; return; }
   uint64_t expected = 0;
   if (!g_owner.compare_exchange_strong(expected, (uint64_t)(uintptr_t)&t_marker, std::memory_order_acquire)) {
     ok = false;
@@ -373,8 +373,14 @@ int mzk_init_devices(const int* device_ordinals, int n_devices) {
 }
 // Idempotent: when context 0 already drives this ordinal nothing is torn down (further contexts made by mzk_init_devices,
 // their streams, workspaces and the handles that live on them all stay valid).
+// It takes the entry guard like every other entry point: wrappers call it once per thread, and a second thread arriving while
+// a call is in progress must get MZK_E_BUSY instead of flipping the current context (ctx_select below) under that call's
+// CtxScope switches.  Called from inside a call on the owning thread (a callback), the fast path leaves the current context
+// and the device alone -- the enclosing call owns them.
 int mzk_init(int device_ordinal) {
-  if (g_nctx > 0 && g_ctxs[0].ready && g_ctxs[0].device == device_ordinal) return ctx_select(0);
+  mzk::EntryGuard entry;
+  if (!entry.ok) return MZK_E_BUSY;
+  if (g_nctx > 0 && g_ctxs[0].ready && g_ctxs[0].device == device_ordinal) return entry.nested ? MZK_OK : ctx_select(0);
   return mzk_init_devices(&device_ordinal, 1);
 }
 int mzk_ctx_count(void) { return g_nctx; }
@@ -1081,6 +1087,26 @@ int mzk_kzg_open_srs_batch_dev(const mzk_srs* srs, const void* d_coefs, size_t n
                                int max_in_flight, void* stream) {
   MZK_ENTER();
   return open_batch_route(srs, d_coefs, n, count, us_host, d_ys, d_ws_xy, max_in_flight, MANY_MIN_COUNT, (hipStream_t)stream);
+}
+// open_kzg of `count` polynomials with everything in host memory: ys = count * 4 limbs, ws_xy = count * 8 limbs
+int mzk_kzg_open_srs_batch(const mzk_srs* srs, const uint64_t* coefs, size_t n, size_t count, const uint64_t* us, uint64_t* ys, uint64_t* ws_xy) {
+  MZK_ENTER();
+  if (!srs || ((!coefs || !us || !ys || !ws_xy) && count)) { set_error("open_srs_batch: null pointer"); return MZK_E_ARG; }
+  if (count == 0) return MZK_OK;
+  hipStream_t s = ctx().stream;
+  void *d_c, *d_o;
+  {
+    WsGuard wsg(s);
+    MZK_TRY(stage_in(WS_MISC_E, coefs, count * n * 32, &d_c, s));
+    MZK_TRY(ws_get(WS_MISC_F, count * 96, &d_o));
+  }
+  char* d_y = (char*)d_o;
+  char* d_w = d_y + count * 32;
+  MZK_TRY(open_batch_route(srs, d_c, n, count, us, d_y, d_w, 0, MANY_MIN_COUNT, s));
+  MZK_HIP(hipMemcpyAsync(ys, d_y, count * 32, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipMemcpyAsync(ws_xy, d_w, count * 64, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  return MZK_OK;
 }
 int mzk_kzg_commit_srs_batch(const mzk_srs* srs, const uint64_t* coefs, size_t n, size_t count, uint64_t* out_xy) {
   MZK_ENTER();

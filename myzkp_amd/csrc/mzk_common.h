@@ -69,6 +69,7 @@ int ctx_peer_enabled(int a, int b);
 // the owning thread (entry points calling entry points, callbacks calling back in) pass.
 struct EntryGuard {
   bool ok;
+  bool nested;      // this thread was already inside a call (an entry point calling an entry point, a callback calling back in)
   EntryGuard();
   ~EntryGuard();
 };

@@ -425,6 +425,11 @@ struct SrsHandle {
     auto p = points_to_wire(pk.powers_1);
     expect(mzk_srs_upload(p.data(), pk.powers_1.size(), &h));
   }
+  // every multiple of every window-table row, for batches of short polynomials (mzk_srs_build_direct); returns the width built
+  int build_direct(int window_bits = 0, size_t max_bytes = 0) {
+    expect(mzk_srs_build_direct(h, window_bits, max_bytes, nullptr));
+    return mzk_srs_direct_bits(h);
+  }
   SrsHandle(const SrsHandle&) = delete;
   SrsHandle& operator=(const SrsHandle&) = delete;
   ~SrsHandle() { mzk_srs_free(h); }
@@ -440,6 +445,25 @@ inline std::vector<CommitmentKZG> commit_kzg(const std::vector<Polynomial<FqOrde
     for (size_t j = 0; j < fs[i].coef.size(); j++) std::memcpy(&c[(i * n + j) * 4], fs[i].coef[j].value.data(), 32);
   expect(mzk_kzg_commit_srs_batch(srs.h, c.data(), n, fs.size(), xy.data()));
   for (size_t i = 0; i < fs.size(); i++) out[i] = G1Point::from_wire(&xy[8 * i]);
+  return out;
+}
+
+// for (f, u) in zip(fs, us) { open_kzg(f, u, pk) }   (kzg.rs:61-72; das/avail.rs:132 opens per cell); polynomials padded with zero
+// coefficients to the longest -- the quotient of a padded polynomial has zero leading coefficients, the witness is the same point
+inline std::vector<ProofKZG> open_kzg(const std::vector<Polynomial<FqOrder>>& fs, const std::vector<FqOrder>& us, const SrsHandle& srs) {
+  if (fs.size() != us.size()) throw Panic(MZK_E_ARG, "batch::open_kzg: one point per polynomial");
+  size_t n = 0;
+  for (auto& f : fs) n = f.coef.size() > n ? f.coef.size() : n;
+  std::vector<ProofKZG> out(fs.size());
+  if (fs.empty()) return out;
+  std::vector<uint64_t> c(fs.size() * n * 4 + 4, 0), u = to_wire(us), ys(fs.size() * 4), ws(fs.size() * 8);
+  for (size_t i = 0; i < fs.size(); i++)
+    for (size_t j = 0; j < fs[i].coef.size(); j++) std::memcpy(&c[(i * n + j) * 4], fs[i].coef[j].value.data(), 32);
+  expect(mzk_kzg_open_srs_batch(srs.h, c.data(), n, fs.size(), u.data(), ys.data(), ws.data()));
+  for (size_t i = 0; i < fs.size(); i++) {
+    std::memcpy(out[i].y.value.data(), &ys[4 * i], 32);
+    out[i].w = G1Point::from_wire(&ws[8 * i]);
+  }
   return out;
 }
 

@@ -366,6 +366,26 @@ static void test_batch_extensions() {
     CHECK(cs.size() == 3);
     for (size_t k = 0; k < 3; k++) CHECK(cs[k] == commit_kzg(fs[k], pk));
     CHECK(batch::commit_kzg({}, srs).empty());
+    // six polynomials: the grid-batched pass (mzk_kzg_commit_srs_batch routes there from four on), over the window tables and
+    // over direct tables (mzk_srs_build_direct); openings per polynomial at its own point (das/avail.rs:132) the same way
+    std::vector<Polynomial<FqOrder>> gs(6);
+    std::vector<FqOrder> us;
+    for (size_t k = 0; k < 6; k++) {
+      const size_t len = k == 5 ? 1 : deg + 1 - 13 * k;
+      for (size_t i = 0; i < len; i++) gs[k].coef.push_back(FqOrder::from_limbs(&sc[4 * ((k % 3) * (deg + 1) + i + k)]));
+      us.push_back(FqOrder::from_value(1000 + 7 * k));
+    }
+    for (int pass = 0; pass < 2; pass++) {
+      if (pass == 1) CHECK(srs.build_direct(9) == 9);
+      auto ds = batch::commit_kzg(gs, srs);
+      auto ps = batch::open_kzg(gs, us, srs);
+      CHECK(ds.size() == 6 && ps.size() == 6);
+      for (size_t k = 0; k < 6; k++) {
+        CHECK(ds[k] == commit_kzg(gs[k], pk));
+        auto pr = open_kzg(gs[k], us[k], pk);
+        CHECK(ps[k].y == pr.y && ps[k].w == pr.w);
+      }
+    }
   }
 }
 

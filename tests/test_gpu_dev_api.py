@@ -228,3 +228,43 @@ def test_second_host_thread_gets_busy_not_corruption():
     assert Lb.mzk_ntt(0, wl.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n), 0) == 0
     rc, want = orc.ntt_fast(orc.FR, w, v)
     assert rc == 0 and np.array_equal(out, want)
+
+
+def test_init_and_ctx_select_from_a_second_thread_cannot_flip_the_context_under_a_batch_call():
+    """mzk_init's idempotent fast path used to run outside the entry guard and re-select context 0 -- a second
+    thread calling it (wrappers init per thread) could switch the current context under the CtxScope switches of a batch call
+    in progress.  Now it gets MZK_E_BUSY like every other entry point; the batch's points stay right."""
+    import threading
+    import myzkp_amd as mzz
+    mzz.init_devices([0, 0, 0])
+    Lb = mzz.lib()
+    n, count = 1 << 15, 6                       # 2^15 coefficients: wide tables -> one commit per lane (three contexts)
+    p = orc.synth_points(4711, n)
+    h = mzz.Srs(p)
+    coefs = np.stack([orc.synth_vector(orc.FR, 900 + k, n) for k in range(count)])
+    want = [orc.msm_fast(coefs[k], p) for k in range(count)]
+    rcs, stop = [], threading.Event()
+
+    def hammer():
+        while not stop.is_set():
+            rcs.append(Lb.mzk_init(0))
+            rcs.append(Lb.mzk_ctx_select(2))
+    th = threading.Thread(target=hammer)
+    th.start()
+    try:
+        done, tries = 0, 0
+        out = np.zeros((count, 8), dtype=np.uint64)
+        while done < 8 and tries < 100000:
+            r = Lb.mzk_kzg_commit_srs_batch(h._h, coefs.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n), ctypes.c_size_t(count), out.ctypes.data_as(ctypes.c_void_p))
+            assert r in (0, -11), Lb.mzk_last_error()
+            if r == 0:
+                assert mzz.array_to_points(out) == want
+                done += 1
+            tries += 1
+        assert done == 8
+    finally:
+        stop.set()
+        th.join()
+    assert set(rcs) <= {0, -11} and -11 in rcs, "the second thread never met a call in progress"
+    h.close()
+    mzz.init_devices([0])
