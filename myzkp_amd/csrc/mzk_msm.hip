@@ -975,6 +975,7 @@ __global__ __launch_bounds__(128) void k_halve_step(u32* __restrict__ buckets, i
   if (id >= total) return;                        // quad-uniform
   halve_op(buckets + ((size_t)blockIdx.y << lgB) * 32, lgB, t, id, (int)(tid & 3));
 }
+#ifdef MZK_TUNING      // the DPP-quad tail of round 2: reachable only through MZK_ROW_TAILS=0 (A/B timing), not in the shipped library
 constexpr int TAIL_THREADS = 512;
 constexpr int TAIL_QUADS = TAIL_THREADS / 4;
 // Remaining steps t_start..lgB-1 inside one workgroup per bucket set, then the weighted sum
@@ -1020,6 +1021,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_reduce_tail(u32* __restrict__ 
   }
   if (threadIdx.x < 32) out[(size_t)blockIdx.x * 32 + threadIdx.x] = sh[threadIdx.x];
 }
+#endif
 
 // ---- small inputs (n < 4096): three launches instead of twenty-five ---------------------------------------------
 // The reference's real callers commit to polynomials of at most a few thousand coefficients (das/avail.rs:96,
@@ -1190,23 +1192,29 @@ __global__ __launch_bounds__(T) void k_small_accumulate_scan(const u32* __restri
 }
 static_assert(254 / 8 + 1 <= 32, "window hit masks are 32 bits");
 
-// k_window_combine / k_fold_partials live in mzk_msm_tail.hip (compact-code build).
+#ifdef MZK_TUNING
+// k_window_combine / k_fold_partials (DPP-quad forms, round 2) live in mzk_msm_tail.hip: tuning build only
 int launch_window_combine(const u32* wsum, int nwin, int c, int out_xyzz, u32* out, hipStream_t s);
 int launch_fold_partials(const u32* partials, int count, u32* out, hipStream_t s);
+#endif
 // mzk_msm_row.hip: the same tails on row-cooperative group operations (one point operation per wave)
 int launch_reduce_tail_row(u32* buckets, int lgB, int t_start, int sets, u32* out, int finish_affine, hipStream_t s);
 int launch_window_combine_row(const u32* wsum, int nwin, int c, int out_xyzz, u32* out, hipStream_t s);
 int launch_fold_partials_row(const u32* partials, int count, u32* out, hipStream_t s);
-// MZK_ROW_TAILS=0 selects the DPP-quad tails of round 2 (A/B timing: tools/timing/small_latency.py, time_msm.py)
+// tuning build: MZK_ROW_TAILS=0 selects the DPP-quad tails of round 2 (A/B timing: tools/timing/small_latency.py, time_msm.py)
+#ifdef MZK_TUNING
 static bool row_tails() {
-  static const int v = getenv("MZK_ROW_TAILS") ? atoi(getenv("MZK_ROW_TAILS")) : 1;
+  static const int v = tune_int("MZK_ROW_TAILS", 1);
   return v != 0;
 }
+#else
+static constexpr bool row_tails() { return true; }
+#endif
 // The single-workgroup tail takes over once a halving step is at most this wide: a dependent launch costs ~6 us whatever runs in
 // it (measured: a step of 1024 additions as one wave each 6.0 us, as DPP quads 6.4 us -- the launch, not the addition), a round
 // of 256 quad additions inside the tail's workgroup 3.6 us, a round of 16 row additions ~1.8 us.
 static size_t row_tail_max_ops() {
-  static const size_t v = getenv("MZK_TAIL_MAX_OPS") ? (size_t)atoi(getenv("MZK_TAIL_MAX_OPS")) : 64;
+  static const size_t v = (size_t)tune_int("MZK_TAIL_MAX_OPS", 64);
   return v < 1 ? 1 : v;
 }
 
@@ -1216,8 +1224,13 @@ static size_t row_tail_max_ops() {
 static int reduce_bucket_sets(u32* buckets, int lgB, int sets, bool merged, int horner_c, u32* wsum, u32* d_out, bool out_partial_xyzz, hipStream_t s) {
   prof_begin(s, MZK_PH_MSM_REDUCE);
   const bool rows = row_tails();
+  (void)rows;
   int t_start = 0;
+#ifdef MZK_TUNING
   const size_t tail_max = rows ? row_tail_max_ops() : (size_t)4 * TAIL_QUADS;
+#else
+  const size_t tail_max = row_tail_max_ops();
+#endif
   while (t_start < lgB && ((size_t)(t_start + 1) << (lgB - t_start - 1)) > tail_max) t_start++;
   for (int t = 0; t < t_start; t++) {
     const size_t total = (size_t)(t + 1) << (lgB - t - 1);
@@ -1227,18 +1240,28 @@ static int reduce_bucket_sets(u32* buckets, int lgB, int sets, bool merged, int 
       hipLaunchKernelGGL(k_halve_step, dim3((unsigned)((4 * total + 127) / 128), (unsigned)sets), dim3(128), 0, s, buckets, lgB, t);
   }
   if (merged) {
-    if (rows) MZK_TRY(launch_reduce_tail_row(buckets, lgB, t_start, 1, d_out, out_partial_xyzz ? 0 : 1, s));
-    else hipLaunchKernelGGL(k_reduce_tail, dim3(1), dim3(TAIL_THREADS), 0, s, buckets, lgB, t_start, d_out, out_partial_xyzz ? 0 : 1);
+#ifdef MZK_TUNING
+    if (!rows) hipLaunchKernelGGL(k_reduce_tail, dim3(1), dim3(TAIL_THREADS), 0, s, buckets, lgB, t_start, d_out, out_partial_xyzz ? 0 : 1);
+    else
+#endif
+    MZK_TRY(launch_reduce_tail_row(buckets, lgB, t_start, 1, d_out, out_partial_xyzz ? 0 : 1, s));
     MZK_HIP(hipGetLastError());
     prof_end(s, MZK_PH_MSM_REDUCE);
     return MZK_OK;
   }
-  if (rows) MZK_TRY(launch_reduce_tail_row(buckets, lgB, t_start, sets, wsum, 0, s));
-  else hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)sets), dim3(TAIL_THREADS), 0, s, buckets, lgB, t_start, wsum, 0);
+#ifdef MZK_TUNING
+  if (!rows) hipLaunchKernelGGL(k_reduce_tail, dim3((unsigned)sets), dim3(TAIL_THREADS), 0, s, buckets, lgB, t_start, wsum, 0);
+  else
+#endif
+  MZK_TRY(launch_reduce_tail_row(buckets, lgB, t_start, sets, wsum, 0, s));
   MZK_HIP(hipGetLastError());
   prof_end(s, MZK_PH_MSM_REDUCE);
   prof_begin(s, MZK_PH_MSM_COMBINE);
-  MZK_TRY((rows ? launch_window_combine_row : launch_window_combine)((const u32*)wsum, sets, horner_c, out_partial_xyzz ? 1 : 0, d_out, s));
+#ifdef MZK_TUNING
+  if (!rows) MZK_TRY(launch_window_combine((const u32*)wsum, sets, horner_c, out_partial_xyzz ? 1 : 0, d_out, s));
+  else
+#endif
+  MZK_TRY(launch_window_combine_row((const u32*)wsum, sets, horner_c, out_partial_xyzz ? 1 : 0, d_out, s));
   prof_end(s, MZK_PH_MSM_COMBINE);
   return MZK_OK;
 }
@@ -1309,8 +1332,8 @@ template <class REC>
 static int sort_records(const SortArgs& a, hipStream_t s) {
   typedef typename REC::T R;
   const int cw = (a.L.merged && !a.L.glv && (a.L.c == 16 || a.L.c == 17)) ? a.L.c : 0;
-  static const int env_staged = getenv("MZK_COARSE_STAGED") ? atoi(getenv("MZK_COARSE_STAGED")) : 1;      // 0: A/B against the direct stores
-  if (cw && env_staged) {
+  static const int env_staged = tune_int("MZK_COARSE_STAGED", 1);      // 0: A/B against the direct stores
+  if (cw != 0 && env_staged != 0) {
     const size_t lds = (size_t)STAGE_RECORDS * (sizeof(R) + 1) + (size_t)(4 * COARSE_BINS + 1) * 4;
     bool& attr = ctx().attr_done[sizeof(R) == 4 ? ATTR_COARSE_STAGED4 : ATTR_COARSE_STAGED8];
     if (!attr) {
@@ -1324,12 +1347,15 @@ static int sort_records(const SortArgs& a, hipStream_t s) {
     else
       hipLaunchKernelGGL((k_coarse_scatter_staged<REC, 16>), dim3(a.nwg), dim3(SORT2_THREADS), lds, s, a.scalars, a.n, a.L.table_stride, a.key_shift, a.fine_mask,
                          a.fb, (const u32*)a.binhist, a.nwg, (R*)a.tmp);
-  } else if (cw == 17)
+  }
+#ifdef MZK_TUNING
+  else if (cw == 17)
     hipLaunchKernelGGL((k_coarse_scatter<REC, 17>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb,
                        (const u32*)a.binhist, a.nwg, (R*)a.tmp);
   else if (cw == 16)
     hipLaunchKernelGGL((k_coarse_scatter<REC, 16>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb,
                        (const u32*)a.binhist, a.nwg, (R*)a.tmp);
+#endif
   else
     hipLaunchKernelGGL((k_coarse_scatter<REC, 0>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb,
                        (const u32*)a.binhist, a.nwg, (R*)a.tmp);
@@ -1402,9 +1428,9 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   };
   const size_t E_max = n * (size_t)(L.glv ? 2 * sh.nwin : sh.nwin);
   // (the generic layout has twice the entries per pair: measured at 4096 pairs it is 5 % slower on this path, the commit 14 % faster)
-  static const int env_scan = getenv("MZK_SMALL_SCAN") ? atoi(getenv("MZK_SMALL_SCAN")) : 1;     // 0: A/B against the sorted path
-  static const int env_scan_log = getenv("MZK_SCAN_MAX_LOG") ? atoi(getenv("MZK_SCAN_MAX_LOG")) : 14;
-  const bool scan_ok = L.merged && env_scan && n <= ((size_t)1 << env_scan_log) && (L.c == 8 || (L.c >= 10 && L.c <= 13));
+  static const int env_scan = tune_int("MZK_SMALL_SCAN", 1);     // 0: A/B against the sorted path
+  static const int env_scan_log = tune_int("MZK_SCAN_MAX_LOG", 14);
+  const bool scan_ok = L.merged && env_scan != 0 && n <= ((size_t)1 << env_scan_log) && (L.c == 8 || (L.c >= 10 && L.c <= 13));
   if ((scan_ok || n < (L.merged ? SMALL_MAX_N : SMALL_MAX_N - 1)) && NB <= SMALL_MAX_BUCKETS) {
     u32 *offsets, *entries, *buckets, *wsum;
     MZK_TRY(ws_get(WS_MSM_OFFSETS, (NB + 1) * 4, (void**)&offsets));
@@ -1450,8 +1476,8 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   // (profiles/r03o_accumulate_occupancy_ab.txt: shipped 1.05-1.06 ms at 2^20; __launch_bounds__(256, 4) = 128 VGPRs + 64 B of
   // scratch 1.07-1.10; segments sized for three waves 1.07 with a cheaper segment combine: equal in total).
   // (tools/timing/acc_sweep.py sweeps MZK_ACC_PREFETCH / MZK_ACC_SEG.)
-  static const int env_prefetch = getenv("MZK_ACC_PREFETCH") ? atoi(getenv("MZK_ACC_PREFETCH")) : -1;
-  static const int env_seg = getenv("MZK_ACC_SEG") ? atoi(getenv("MZK_ACC_SEG")) : 0;
+  static const int env_prefetch = tune_int("MZK_ACC_PREFETCH", -1);
+  static const int env_seg = tune_int("MZK_ACC_SEG", 0);
   const bool acc_prefetch = env_prefetch >= 0 ? env_prefetch != 0 : false;
   const size_t resident_lanes = (size_t)ctx().num_cu * 4 * (acc_prefetch ? 3 : 4) * 64;
   size_t seg_sz = (E_max + resident_lanes - 1) / resident_lanes;
@@ -1492,7 +1518,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     // records per fine workgroup: 32 Ki for the merged layout, 16 Ki for the generic one (measured: generic sort 0.250 -> 0.230 ms
     // at 2^20, merged equal within noise from 16 Ki to 64 Ki: profiles/r04m_*), 128 Ki when a bin has thousands of buckets
     // (the [bucket][sub] histogram that is scanned afterwards has NB * S entries)
-    static const int env_per_fine = getenv("MZK_PER_FINE") ? atoi(getenv("MZK_PER_FINE")) : 0;      // tuning: tools/timing/window_sweep.py
+    static const int env_per_fine = tune_int("MZK_PER_FINE", 0);      // tuning: tools/timing/window_sweep.py
     const size_t per_fine = env_per_fine > 0 ? (size_t)env_per_fine : ((NBtot / COARSE_BINS >= 4096) ? 131072 : (L.glv ? 16384 : 32768));
     int S = (int)((E_max / COARSE_BINS + per_fine - 1) / per_fine);
     if (S < 2) S = 2;
@@ -1550,13 +1576,15 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   MZK_TRY(prepare());
   prof_begin(s, MZK_PH_MSM_ACCUMULATE);
   // the true entry count lives in offsets[NB] on the device; lanes past it exit (E_max bounds it)
+#ifdef MZK_TUNING
   if (acc_prefetch)
     hipLaunchKernelGGL(k_seg_accumulate<true>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, pts, offsets, entries, slots, NB, seg);
   else
+#endif
     hipLaunchKernelGGL(k_seg_accumulate<false>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, pts, offsets, entries, slots, NB, seg);
   prof_end(s, MZK_PH_MSM_ACCUMULATE);
   prof_begin(s, MZK_PH_MSM_SEG_COMBINE);
-  static const int wide_min_log = getenv("MZK_COMBINE_WIDE_MIN_LOG") ? atoi(getenv("MZK_COMBINE_WIDE_MIN_LOG")) : 17;
+  static const int wide_min_log = tune_int("MZK_COMBINE_WIDE_MIN_LOG", 17);
   if (NB >= ((size_t)1 << wide_min_log))
     hipLaunchKernelGGL(k_seg_combine_wide, dim3((unsigned)((NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy);
   else
@@ -1916,7 +1944,10 @@ int msm_many_srs(const mzk_srs* srs, const void* d_scalars, size_t n, size_t str
 
 int msm_fold_partials_impl(const void* d_partials, int count, void* d_out_xy, hipStream_t s) {
   if (!d_partials || !d_out_xy || count < 0) { set_error("fold_partials: bad argument"); return MZK_E_ARG; }
-  MZK_TRY((row_tails() ? launch_fold_partials_row : launch_fold_partials)((const u32*)d_partials, count, (u32*)d_out_xy, s));
+#ifdef MZK_TUNING
+  if (!row_tails()) return launch_fold_partials((const u32*)d_partials, count, (u32*)d_out_xy, s);
+#endif
+  MZK_TRY(launch_fold_partials_row((const u32*)d_partials, count, (u32*)d_out_xy, s));
   return MZK_OK;
 }
 

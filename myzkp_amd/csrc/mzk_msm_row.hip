@@ -205,7 +205,7 @@ static TailPlan tail_plan(int lgB) {
   return best;
 }
 static int tail_row_max() {      // widest step that still runs as row operations (A/B: tools/timing/small_latency.py)
-  static const int v = getenv("MZK_TAIL_ROW_MAX") ? atoi(getenv("MZK_TAIL_ROW_MAX")) : 4;
+  static const int v = tune_int("MZK_TAIL_ROW_MAX", 4);
   return v;
 }
 int launch_reduce_tail_row(u32* buckets, int lgB, int t_start, int sets, u32* out, int finish_affine, hipStream_t s) {

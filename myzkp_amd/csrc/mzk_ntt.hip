@@ -45,8 +45,15 @@ constexpr bool NTT_LAZY_FIRST = MZK_NTT_LAZY_FIRST != 0;
 // transform is TWO passes of 2^10 levels instead of three (one global round trip and one inter-pass twiddle product
 // per element less), each tile still 4+ adjacent columns wide (>= 128-byte runs).  The Fr tile is 144 KiB of limbs, so
 // its in-tile twiddles are staged as packed words (16 KiB: 160 KiB exactly) and unpacked at use.
-template <int TL_, int NT_, int MAXLV_> struct Geo {
-  static constexpr int TL = TL_, TILE = 1 << TL_, NT = NT_, MAXLV = MAXLV_;
+// TWG_ (M128 large tiles): the in-tile twiddles are NOT staged in LDS -- a 4096-element M128 tile is 80 KiB, so without its
+// 10 KiB of twiddles TWO workgroups of 512 lanes share a CU and one's loads / stores run under the other's butterflies (the
+// single 1024-lane workgroup per CU had nothing to overlap its ~22 us of global traffic with).  A twiddle is 16 packed bytes:
+// stage pairs in which a wave shares its twiddles read them by scalar loads, the others by one dwordx4 per twiddle from L1.
+// WPE_: waves per SIMD the register budget must allow (4 = two 512-lane workgroups per CU).
+template <int TL_, int NT_, int MAXLV_, bool TWG_ = false, int WPE_ = 1> struct Geo {
+  static constexpr int TL = TL_, TILE = 1 << TL_, NT = NT_, MAXLV = MAXLV_, WPE = WPE_;
+  static constexpr bool TWG = TWG_;
+  static constexpr int GQ = TILE / NT_ / 4;            // radix-4 groups per lane and stage pair (fused first / last pairs)
   // Logical tile position -> LDS word index inside a limb row.  The low five bits (the bank) are XORed with a GF(2)-linear
   // function of the upper bits, chosen by simulating every wave-level access of the kernels (bit-reversed scatter of
   // the load phase, the four loads and stores of every radix-4 stage pair, all level sizes the geometry runs;
@@ -59,13 +66,17 @@ template <int TL_, int NT_, int MAXLV_> struct Geo {
     const int x = (TL_ == 10) ? (h ^ (h << 2) ^ (h << 3)) : ((h >> 2) ^ (h << 1) ^ (h << 3));
     return pos ^ (x & 31);
   }
-  template <class P> static constexpr bool twpack() { return (size_t)4 * P::L * (TILE + (1 << (MAXLV_ - 1))) > (size_t)160 * 1024; }
+  template <class P> static constexpr bool twpack() { return !TWG_ && (size_t)4 * P::L * (TILE + (1 << (MAXLV_ - 1))) > (size_t)160 * 1024; }
   template <class P> static constexpr size_t lds_bytes(int lgn) {
+    if (TWG_) return sizeof(u32) * (size_t)P::L * TILE;
     return sizeof(u32) * ((size_t)P::L * TILE + (size_t)(twpack<P>() ? P::NW : P::L) * (lgn >= 2 ? ((size_t)1 << (lgn - 1)) : 1));
   }
 };
 typedef Geo<TILE_LOG, NTHREADS, MAX_LEVEL_LOG> GeoS;
 typedef Geo<12, 1024, 10> GeoL;
+typedef Geo<12, 512, 10, true, 4> GeoM;        // M128 large tiles: two workgroups per CU
+template <class P> struct LargeGeo { typedef GeoL type; };
+template <> struct LargeGeo<M128Params> { typedef GeoM type; };
 // The large geometry is used exactly where it saves a whole pass: 2^20 (two passes of 2^10 instead of 7/7/6: measured
 // Fr 0.147 -> 0.137 ms, M128 0.063 -> 0.056 ms) and 2^25 .. 2^30.  Where both geometries need three passes the small
 // tiles win (2^21 .. 2^24: Fr +8 %, M128 +16 % with large tiles; tools/timing/time_ntt.py with MZK_NTT_LARGE_FR /
@@ -75,8 +86,8 @@ typedef Geo<12, 1024, 10> GeoL;
 // CU; the large tile owns it) -- from three Fr / two M128 transforms of 2^20 on, three overlapped passes beat two
 // exposed ones (tools/timing/ntt_batch.py: Fr 0.1045 vs 0.1131 ms per transform at batch 16, M128 0.041 vs 0.048).
 static bool large_geo(int fid, unsigned logn, size_t batch = 1) {
-  static const int env_fr = getenv("MZK_NTT_LARGE_FR") ? atoi(getenv("MZK_NTT_LARGE_FR")) : -1;
-  static const int env_m = getenv("MZK_NTT_LARGE_M128") ? atoi(getenv("MZK_NTT_LARGE_M128")) : -1;
+  static const int env_fr = tune_int("MZK_NTT_LARGE_FR", -1);
+  static const int env_m = tune_int("MZK_NTT_LARGE_M128", -1);
   const int env = fid == MZK_FIELD_M128 ? env_m : env_fr;
   if (env >= 0) return logn >= (unsigned)env && logn >= 14;
   if (logn < 20) return false;
@@ -142,6 +153,7 @@ template <class P, class G> __device__ __forceinline__ void lds_store(u32* lds, 
 // twiddle with L ds_read_b32 and no unpacking.
 template <class P, class G>
 __device__ __forceinline__ void stage_twiddles(u32* twl, const u32* __restrict__ tw, int lgn) {
+  if constexpr (G::TWG) return;            // read from global memory at use (bfly)
   const int cnt = (lgn >= 2) ? (1 << (lgn - 1)) : 0;
   for (int j = threadIdx.x; j < cnt; j += G::NT) {
     if constexpr (G::template twpack<P>()) {      // packed words, word-major
@@ -166,7 +178,9 @@ __device__ __forceinline__ void bfly(Fe<P>& lo, Fe<P>& hi, const u32* twl, int t
   Fe<P> t = hi;
   if (!trivial) {
     Fe<P> w;
-    if constexpr (G::template twpack<P>()) {
+    if constexpr (G::TWG) {
+      w = gload<P>(twl, (size_t)ti);         // twl = the plan's table in global memory (16 bytes per M128 twiddle; L1 / scalar cache)
+    } else if constexpr (G::template twpack<P>()) {
       u32 ww[P::NW];
 #pragma unroll
       for (int i = 0; i < P::NW; i++) ww[i] = twl[i * tws + ti];
@@ -320,7 +334,10 @@ __device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, i
           done = true;
         }
       }
-      if (!done) radix4_regs<P, G>(x0, x1, x2, x3, twl, tws, lgn, s, j1);
+      if (!done) {
+        if (G::TWG && lgrest >= 6) radix4_regs<P, G>(x0, x1, x2, x3, twl, tws, lgn, s, __builtin_amdgcn_readfirstlane(j1));   // scalar loads
+        else radix4_regs<P, G>(x0, x1, x2, x3, twl, tws, lgn, s, j1);
+      }
       lds_store<P, G>(lds, p0, x0);
       lds_store<P, G>(lds, p0 + d1, x1);
       lds_store<P, G>(lds, p0 + d2, x2);
@@ -339,7 +356,7 @@ __device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, i
 // entries, pre_col: M entries, Montgomery form).
 struct PreArgs { const u32* coef; size_t n_coef; const u32* pre_row; const u32* pre_col; };
 template <class P, bool PRE, class G>
-__global__ __launch_bounds__(G::NT) void k_ntt_strided(const u32* __restrict__ in, u32* __restrict__ out,
+__global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_strided(const u32* __restrict__ in, u32* __restrict__ out,
                                                            const u32* __restrict__ tw_tile,
                                                            const u32* __restrict__ tw_inter, int lgn, int lgM, int lgc, PreArgs pre, int fuse, const u32* __restrict__ tw_shoup) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -350,9 +367,11 @@ __global__ __launch_bounds__(G::NT) void k_ntt_strided(const u32* __restrict__ i
   const size_t base = (o << (lgn + lgM)) + (ct << lgc);
   const int cmask = (1 << lgc) - 1;
   const int tile_elems = 1 << (lgn + lgc);
-  u32* twl = lds + P::L * G::TILE;
-  stage_twiddles<P, G>(twl, tw_tile, lgn);
+  const u32* twl = G::TWG ? tw_tile : lds + P::L * G::TILE;
+  stage_twiddles<P, G>(lds + P::L * G::TILE, tw_tile, lgn);
   constexpr int UNR = G::TILE / G::NT;          // elements per lane and tile (tile_elems == G::TILE here)
+  constexpr int GQ = G::GQ;                     // radix-4 groups per lane: element u = q + GQ v is member v of group q
+  static_assert(UNR == 4 * GQ, "whole radix-4 groups per lane");
   const bool fused = fuse_edges<G>(lgn, lgc, fuse);   // first (plain loads only) and last stage pair on registers, next to the global accesses
   if constexpr (!PRE) {
     u32 w[UNR][P::NW];
@@ -362,16 +381,18 @@ __global__ __launch_bounds__(G::NT) void k_ntt_strided(const u32* __restrict__ i
       gload_words<P>(in, base + ((size_t)(e >> lgc) << lgM) + (e & cmask), w[u]);
     }
     if (fused) {       // first stage pair next to the loads: the data of a wave starts computing when IT has arrived
-      static_assert(UNR == 4, "one radix-4 group per lane");
-      Fe<P> x0 = fe_unpack<P>(w[0]), x2 = fe_unpack<P>(w[1]), x1 = fe_unpack<P>(w[2]), x3 = fe_unpack<P>(w[3]);
-      first_pair_regs<P, G>(x0, x1, x2, x3, tw_tile, tw_shoup, lgn);
-      const int r = tid >> lgc, c = tid & cmask;
-      const int k0 = (int)(__brev((unsigned)r) >> (32 - (lgn - 2))) << 2;
-      const int p0 = (k0 << lgc) | c, d1 = 1 << lgc;
-      lds_store<P, G>(lds, p0, x0);
-      lds_store<P, G>(lds, p0 + d1, x1);
-      lds_store<P, G>(lds, p0 + 2 * d1, x2);
-      lds_store<P, G>(lds, p0 + 3 * d1, x3);
+#pragma unroll
+      for (int q = 0; q < GQ; q++) {
+        Fe<P> x0 = fe_unpack<P>(w[q]), x2 = fe_unpack<P>(w[q + GQ]), x1 = fe_unpack<P>(w[q + 2 * GQ]), x3 = fe_unpack<P>(w[q + 3 * GQ]);
+        first_pair_regs<P, G>(x0, x1, x2, x3, tw_tile, tw_shoup, lgn);
+        const int r = (tid >> lgc) + q * (G::NT >> lgc), c = tid & cmask;
+        const int k0 = (int)(__brev((unsigned)r) >> (32 - (lgn - 2))) << 2;
+        const int p0 = (k0 << lgc) | c, d1 = 1 << lgc;
+        lds_store<P, G>(lds, p0, x0);
+        lds_store<P, G>(lds, p0 + d1, x1);
+        lds_store<P, G>(lds, p0 + 2 * d1, x2);
+        lds_store<P, G>(lds, p0 + 3 * d1, x3);
+      }
     } else
 #pragma unroll
     for (int u = 0; u < UNR; u++) {
@@ -404,23 +425,33 @@ __global__ __launch_bounds__(G::NT) void k_ntt_strided(const u32* __restrict__ i
   __syncthreads();
   tile_stages<P, G>(lds, twl, lgn, lgc, (fused && !PRE) ? 3 - (lgn & 1) : 1, fused ? lgn - 2 : lgn, tw_shoup);
   {
-    u32 tw[UNR][P::NW];               // the inter-pass twiddles of all the lane's elements, requested before the first product
-#pragma unroll
-    for (int u = 0; u < UNR; u++) {
+    // The inter-pass twiddles of all the lane's elements, requested before the first product.  The epilogue's addresses are
+    // recomputed from an OPAQUE copy of the lane id: hoisted above the stage loop they were 22 more registers live across it,
+    // and the 1024-lane BN254 tile (128 VGPRs per lane) spilled exactly those (vgpr_spill_count 32 -> 0; tests/test_abi_load.py
+    // keeps every hot kernel at zero).
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    u32 tw[UNR][P::NW];
+    auto tw_load = [&](int u) {
       const int e = tid + u * G::NT;
       gload_words<P>(tw_inter, ((size_t)(e >> lgc) << lgM) + (ct << lgc) + (e & cmask), tw[u]);
-    }
-    if (fused) {       // last stage pair on registers: the lane's group is rows j1 + u 2^(lgn-2), exactly the elements it stores
-      const int j1 = tid >> lgc, c = tid & cmask;
-      const int p0 = (j1 << lgc) | c, d1 = 1 << (lgn - 2 + lgc);
-      Fe<P> x[4];
+    };
 #pragma unroll
-      for (int u = 0; u < 4; u++) x[u] = lds_load<P, G>(lds, p0 + u * d1);
-      radix4_regs<P, G>(x[0], x[1], x[2], x[3], twl, 1 << (lgn - 1), lgn, lgn - 1, j1);
+    for (int u = 0; u < UNR; u++) tw_load(u);
+    if (fused) {       // last stage pair on registers: the lane's group q is rows j1 + v 2^(lgn-2), exactly the elements it stores
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const size_t off = ((size_t)(j1 + (u << (lgn - 2))) << lgM) + (ct << lgc) + c;
-        gstore<P>(out, (o << (lgn + lgM)) + off, fe_fit<P>(FeAsm<P>::mul(x[u], fe_unpack<P>(tw[u]))));
+      for (int q = 0; q < GQ; q++) {
+        const int j1 = (tid >> lgc) + q * (G::NT >> lgc), c = tid & cmask;
+        const int p0 = (j1 << lgc) | c, d1 = 1 << (lgn - 2 + lgc);
+        Fe<P> x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) x[u] = lds_load<P, G>(lds, p0 + u * d1);
+        radix4_regs<P, G>(x[0], x[1], x[2], x[3], twl, 1 << (lgn - 1), lgn, lgn - 1, j1);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const size_t off = ((size_t)(j1 + (u << (lgn - 2))) << lgM) + (ct << lgc) + c;
+          gstore<P>(out, (o << (lgn + lgM)) + off, fe_fit<P>(FeAsm<P>::mul(x[u], fe_unpack<P>(tw[q + GQ * u]))));
+        }
       }
       return;
     }
@@ -440,7 +471,7 @@ __global__ __launch_bounds__(G::NT) void k_ntt_strided(const u32* __restrict__ i
 // r = blockIdx * 2^lgr + rr belongs to transform r >> lg_rows): the product trees of mzk_poly.hip transform hundreds
 // of small polynomials per launch.
 template <class P, class G>
-__global__ __launch_bounds__(G::NT) void k_ntt_last(const u32* __restrict__ in, u32* __restrict__ out,
+__global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_last(const u32* __restrict__ in, u32* __restrict__ out,
                                                         const u32* __restrict__ tw_tile, LevelInfo li, int lgn, int lgr,
                                                         int lg_rows, Words8 scale, int has_scale, size_t total_rows, int fuse, const u32* __restrict__ tw_shoup) {
   extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -450,9 +481,11 @@ __global__ __launch_bounds__(G::NT) void k_ntt_last(const u32* __restrict__ in, 
   const int tile_elems = 1 << (lgn + lgr);
   const size_t rowmask = ((size_t)1 << lg_rows) - 1;
   const int logn = lg_rows + lgn;
-  u32* twl = lds + P::L * G::TILE;
-  stage_twiddles<P, G>(twl, tw_tile, lgn);
+  const u32* twl = G::TWG ? tw_tile : lds + P::L * G::TILE;
+  stage_twiddles<P, G>(lds + P::L * G::TILE, tw_tile, lgn);
   constexpr int UNR = G::TILE / G::NT;
+  constexpr int GQ = G::GQ;
+  static_assert(UNR == 4 * GQ, "whole radix-4 groups per lane");
   const bool fused = fuse_edges<G>(lgn, lgr, fuse);      // full tile, even number of levels: first and last stage pair on registers
   auto row_base = [&](size_t r) -> size_t {        // first element of logical row r in the previous pass's layout
     size_t rem = r & rowmask, row = 0;
@@ -465,24 +498,30 @@ __global__ __launch_bounds__(G::NT) void k_ntt_last(const u32* __restrict__ in, 
   if (fused) {
     // lane = (row rr, r): its loads j = r + u 2^(lgn-2) are one radix-4 group of the first stage pair (bit-reversed rows
     // 4 brev(r) + brev2(u)); consecutive lanes read consecutive elements of a row
-    static_assert(UNR == 4, "one radix-4 group per lane");
-    const int rr = tid >> (lgn - 2), r4 = tid & ((1 << (lgn - 2)) - 1);
-    const size_t r = p0 + rr;
-    u32 w[4][P::NW];
+    const int r4 = tid & ((1 << (lgn - 2)) - 1);
+    u32 w[GQ][4][P::NW];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int g = 0; g < GQ; g++) {           // group g of the lane: row rr + g (NT >> (lgn - 2)) of the tile
+      const size_t r = p0 + (tid >> (lgn - 2)) + g * (G::NT >> (lgn - 2));
 #pragma unroll
-      for (int q = 0; q < P::NW; q++) w[u][q] = 0;
-      if (r < total_rows) gload_words<P>(in, row_base(r) + r4 + ((size_t)u << (lgn - 2)), w[u]);
+      for (int u = 0; u < 4; u++) {
+#pragma unroll
+        for (int q = 0; q < P::NW; q++) w[g][u][q] = 0;
+        if (r < total_rows) gload_words<P>(in, row_base(r) + r4 + ((size_t)u << (lgn - 2)), w[g][u]);
+      }
     }
-    Fe<P> x0 = fe_unpack<P>(w[0]), x2 = fe_unpack<P>(w[1]), x1 = fe_unpack<P>(w[2]), x3 = fe_unpack<P>(w[3]);
-    first_pair_regs<P, G>(x0, x1, x2, x3, tw_tile, tw_shoup, lgn);
-    const int k0 = (int)(__brev((unsigned)r4) >> (32 - (lgn - 2))) << 2;
-    const int q0 = (k0 << lgr) | rr, d1 = 1 << lgr;
-    lds_store<P, G>(lds, q0, x0);
-    lds_store<P, G>(lds, q0 + d1, x1);
-    lds_store<P, G>(lds, q0 + 2 * d1, x2);
-    lds_store<P, G>(lds, q0 + 3 * d1, x3);
+#pragma unroll
+    for (int g = 0; g < GQ; g++) {
+      const int rr = (tid >> (lgn - 2)) + g * (G::NT >> (lgn - 2));
+      Fe<P> x0 = fe_unpack<P>(w[g][0]), x2 = fe_unpack<P>(w[g][1]), x1 = fe_unpack<P>(w[g][2]), x3 = fe_unpack<P>(w[g][3]);
+      first_pair_regs<P, G>(x0, x1, x2, x3, tw_tile, tw_shoup, lgn);
+      const int k0 = (int)(__brev((unsigned)r4) >> (32 - (lgn - 2))) << 2;
+      const int q0 = (k0 << lgr) | rr, d1 = 1 << lgr;
+      lds_store<P, G>(lds, q0, x0);
+      lds_store<P, G>(lds, q0 + d1, x1);
+      lds_store<P, G>(lds, q0 + 2 * d1, x2);
+      lds_store<P, G>(lds, q0 + 3 * d1, x3);
+    }
   } else
   for (int e0 = tid; e0 < tile_elems; e0 += UNR * G::NT) {       // one trip for a full tile: all loads first, then the LDS stores
     u32 w[UNR][P::NW];
@@ -509,19 +548,23 @@ __global__ __launch_bounds__(G::NT) void k_ntt_last(const u32* __restrict__ in, 
   Fe<P> sc;
   if (has_scale) sc = fe_unpack<P>(scale.w);
   if (fused) {         // last stage pair on registers: the group of lane (j1, rr) is rows j1 + u 2^(lgn-2), the elements it stores
-    const int j1 = tid >> lgr, rr = tid & rmask;
+    const int rr = tid & rmask;
     const size_t r = p0 + rr;
-    const int q0 = (j1 << lgr) | rr, d1 = 1 << (lgn - 2 + lgr);
-    Fe<P> x[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) x[u] = lds_load<P, G>(lds, q0 + u * d1);
-    radix4_regs<P, G>(x[0], x[1], x[2], x[3], twl, 1 << (lgn - 1), lgn, lgn - 1, j1);
-    if (r >= total_rows) return;
+    for (int g = 0; g < GQ; g++) {
+      const int j1 = (tid >> lgr) + g * (G::NT >> lgr);
+      const int q0 = (j1 << lgr) | rr, d1 = 1 << (lgn - 2 + lgr);
+      Fe<P> x[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      Fe<P> v = x[u];
-      if (has_scale) v = FeAsm<P>::mul(v, sc);
-      gstore<P>(out, ((r >> lg_rows) << logn) + (r & rowmask) + ((size_t)(j1 + (u << (lgn - 2))) << lg_rows), fe_reduce<P>(v));
+      for (int u = 0; u < 4; u++) x[u] = lds_load<P, G>(lds, q0 + u * d1);
+      radix4_regs<P, G>(x[0], x[1], x[2], x[3], twl, 1 << (lgn - 1), lgn, lgn - 1, j1);
+      if (r >= total_rows) continue;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        Fe<P> v = x[u];
+        if (has_scale) v = FeAsm<P>::mul(v, sc);
+        gstore<P>(out, ((r >> lg_rows) << logn) + (r & rowmask) + ((size_t)(j1 + (u << (lgn - 2))) << lg_rows), fe_reduce<P>(v));
+      }
     }
     return;
   }
@@ -889,10 +932,10 @@ static int run_plan_geo(const NttPlan* pl, const u32* d_in, u32* d_out, hipStrea
   const unsigned logn = pl->logn;
 
   ProfScope whole(s, MZK_PH_NTT_TOTAL);
-  static const int fuse = getenv("MZK_NTT_FUSE_EDGES") ? atoi(getenv("MZK_NTT_FUSE_EDGES")) : 1;     // 0: A/B (tools/timing/time_ntt.py)
-  static const int shoup = getenv("MZK_NTT_SHOUP") ? atoi(getenv("MZK_NTT_SHOUP")) : 1;
+  static const int fuse = tune_int("MZK_NTT_FUSE_EDGES", 1);     // 0: A/B (tools/timing/time_ntt.py)
+  static const int shoup = tune_int("MZK_NTT_SHOUP", 1);
   if (G::TL != TILE_LOG) {        // tiles above 64 KiB of LDS need the attribute, once per context and instantiation
-    bool& done = ctx().attr_done[P::NW == 4 ? ATTR_NTT_LARGE_M128 : ATTR_NTT_LARGE_FR];
+    bool& done = ctx().attr_done[P::NW == 4 ? (G::TWG ? ATTR_NTT_LARGE_M128_2WG : ATTR_NTT_LARGE_M128) : ATTR_NTT_LARGE_FR];
     if (!done) {
       MZK_HIP(hipFuncSetAttribute((const void*)k_ntt_strided<P, true, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       MZK_HIP(hipFuncSetAttribute((const void*)k_ntt_strided<P, false, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -937,6 +980,12 @@ static int run_plan_geo(const NttPlan* pl, const u32* d_in, u32* d_out, hipStrea
 }
 template <class P>
 static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t s, const PreArgs* pre = nullptr, size_t batch = 1) {
+  // M128 large tiles: two 512-lane workgroups per CU (GeoM) once there are at least two tiles per CU -- 2^25 and up: 1.69 instead of
+  // 1.83 - 1.85 ms at 2^25 (same box A/B, profiles/r04b_*).  A 2^20 transform is exactly 256 tiles, ONE per CU whatever the
+  // workgroup size, and the 512-lane form only halves the lanes working on it (0.057 against 0.047 ms): it keeps round 3's
+  // single 1024-lane workgroup.  Tuning build: MZK_NTT_M128_TWO_WG = smallest log2 size on GeoM (99 = never).
+  static const int two_wg_from = tune_int("MZK_NTT_M128_TWO_WG", 21);
+  if (pl->large && P::NW == 4 && (int)pl->logn >= two_wg_from) return run_plan_geo<P, typename LargeGeo<P>::type>(pl, d_in, d_out, s, pre, batch);
   if (pl->large) return run_plan_geo<P, GeoL>(pl, d_in, d_out, s, pre, batch);
   return run_plan_geo<P, GeoS>(pl, d_in, d_out, s, pre, batch);
 }

@@ -74,3 +74,45 @@ def test_host_parameter_arithmetic_without_a_gpu(mz):
                 assert op(fid, 1, a) == (pow(a, -1, p) if a else 0)
                 e = rnd.getrandbits(64)
                 assert op(fid, 2, a, e) == pow(a, e, p)
+
+
+def test_shipped_library_reads_no_environment_variable():
+    """a caller's environment must not be able to change the code path.  The shipped .so does not import
+    getenv at all, and the sources mention it only inside the MZK_TUNING helper of mzk_common.h."""
+    import glob, os, subprocess
+    import myzkp_amd.build as b
+    so = b.build()
+    und = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+    hits = []
+    for f in glob.glob(os.path.join(os.path.dirname(so), "csrc", "*")):
+        for i, line in enumerate(open(f), 1):
+            if "getenv" in line and not line.lstrip().startswith("//"):
+                hits.append((os.path.basename(f), i))
+    assert [h[0] for h in hits] == ["mzk_common.h"], hits
+
+
+def test_no_hot_kernel_spills_registers():
+    """the 1024-lane BN254 NTT pass shipped with vgpr_spill_count 32 and nobody had noticed.  Read the kernel
+    metadata out of the shipped .so (tools/kernel_resources.py): no kernel may spill vector registers unless it is listed here
+    with its reason; scratch (private segment) is allowed only where a kernel indexes a local array dynamically or calls a
+    non-inlined function."""
+    import os, sys
+    import myzkp_amd.build as b
+    so = b.build()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kernel_resources
+    res = kernel_resources.kernel_resources(so)
+    assert len(res) > 100, "kernel metadata not found in the library"
+    allowed = {
+        "k_fb_table": "one-time fixed-base table of setup_kzg (built once per generator, 32 x 256 entries): launch-bound 128 VGPRs, off the timed paths",
+        "k_selftest_field_asm": "device self-test, not a product path",
+    }
+    spilled = {k: v["vgpr_spill"] for k, v in res.items() if v["vgpr_spill"] > 0}
+    bad = {k: n for k, n in spilled.items() if not any(a in k for a in allowed)}
+    assert not bad, "kernels spilling VGPRs: %s" % bad
+    # the kernels the bench prices, by name: present and spill-free
+    for must in ("k_seg_accumulate", "k_ntt_strided", "k_ntt_last", "k_direct_accumulate", "k_many_scatter", "k_fine_scatter", "k_merkle"):
+        hits = [k for k in res if must in k]
+        assert hits, must
+        assert all(res[k]["vgpr_spill"] == 0 for k in hits), must
