@@ -426,13 +426,21 @@ int mzk_kzg_open_quotient_dev(const void* d_coef, size_t n, const uint64_t u_hos
 /* Build an SRS handle from points already in HBM (affine canonical, n * 8 limbs).  The _ex form chooses
  * whether the window tables are built (worth it from ~30 commits per SRS on at 2^20 points; a one-shot pipeline keeps
  * the plain prepared points and pays the window Horner instead).  Default widths by size: 8 bits up to 1024 points,
- * 10 up to 2^14, 16 below 2^19, 17 from there on (254 / c + 1 tables of n points each: 15 at 17 bits;
- * measured per size, profiles/r03b_window_sweep.txt). */
+ * 10 up to 2^14, 16 below 2^19, 17 below 2^22, 20 from there on (254 / c + 1 tables of n points each: 15 at 17 bits, 13 at 20;
+ * measured per size, profiles/r03b_window_sweep.txt, profiles/r04c_window_sweep.txt). */
 int mzk_srs_from_device(const void* d_powers_xy, size_t n, mzk_srs** out, void* stream);
 int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, mzk_srs** out, void* stream);
 /* with_tables: 0 = plain prepared points, 1 = tables with the default window width for n (above), 8..22 = that window width
- * (tuning / tests, and BASELINE configs[2]'s 16 bits at any size; wider windows than the default were measured and do not
- * pay). */
+ * (tuning / tests, and BASELINE configs[2]'s 16 bits at any size).
+ * A handle never fails for lack of TABLE memory (commit_kzg(&poly, &pk) does not either): when the wanted tables exceed the
+ * budget set by mzk_set_table_budget (bytes per handle; 0 = no limit, the default) or the device refuses the allocation, the
+ * handle degrades -- every 2nd table with two bucket sets, every 4th with four (from 2^15 points on; 1/2 and 1/4 of the
+ * memory, the same additions, 2 - 4 times the bucket reduction and a few dozen doublings at the end), finally the prepared
+ * points alone (the generic layout: 128 bytes per point, ~25 % slower commits) -- and every commitment stays bit-identical.
+ * mzk_srs_window_bits / mzk_srs_bucket_sets / mzk_srs_table_bytes tell what a handle got (bucket sets: 1 = full tables,
+ * 2 / 4 = degraded, 0 = no tables).  Applies to mzk_srs_upload, mzk_srs_from_device[_ex], mzk_srs_load and the sharded forms. */
+int mzk_set_table_budget(size_t bytes);
+int mzk_srs_bucket_sets(const mzk_srs* srs);
 
 /* Host-side parameter arithmetic of the library (roots, inverses, offsets: O(log n) scalar work per call, never on the
  * data path), exposed for checking without a GPU: op 0 = a * b, 1 = a^-1 (0 -> 0), 2 = a^(b[0]), 3 = a * b by the

@@ -872,24 +872,79 @@ int mzk_g1_fold_partials_dev(const void* d_partials16, int count, void* d_out_xy
   return msm_fold_partials_impl(d_partials16, count, d_out_xy, (hipStream_t)stream);
 }
 
+}  // extern "C"
+
+// ---- layout of a new handle: what fits -------------------------------------------------------------------------------------
+// commit_kzg(&poly, &pk) never fails for lack of memory, so neither may the seam: the window tables are an accelerator, and a
+// handle takes the richest layout that fits the caller's budget (mzk_set_table_budget; 0 = no limit) AND the device --
+//   all tables of the wanted width (15 x n points at 17 bits: 0.94 GiB at 2^20, 13 x n at 20 bits: 13 GiB at 2^24)
+//   -> every 2nd table with two bucket sets -> every 4th with four (from 2^15 points on; at most 17-bit windows: the bucket
+//      sets multiply the bucket count, and beyond 2^19 buckets the sort leaves its staged path)
+//   -> the prepared points and their endomorphism images only (the generic GLV layout: 128 bytes per point).
+// The last step ignores the budget (it is what the library needs to work at all); only when even that allocation fails is
+// the error MZK_E_HIP.  mzk_srs_window_bits / mzk_srs_bucket_sets / mzk_srs_table_bytes report what a handle got.
+static size_t g_table_budget = 0;
+namespace mzk {
+int srs_alloc_layout(mzk_srs* h, int with_tables) {
+  const size_t n = h->n;
+  struct Cand { bool tables; int bits, sets; };
+  Cand cand[4];
+  int nc = 0;
+  const bool want = with_tables > 1 || (with_tables && msm_srs_default_tables(n));
+  const int bits = with_tables > 1 ? with_tables : msm_srs_window_bits(n);
+  if (want) {
+    cand[nc++] = {true, bits, 1};
+    if (n >= ((size_t)1 << 15) && bits >= 14) {
+      const int b2 = bits > 17 ? 17 : bits;
+      cand[nc++] = {true, b2, 2};
+      cand[nc++] = {true, b2, 4};
+    }
+  }
+  cand[nc++] = {false, bits, 1};
+  for (int k = 0; k < nc; k++) {
+    const size_t rows = cand[k].tables ? (size_t)msm_table_rows(cand[k].bits, cand[k].sets) : 2;
+    const size_t bytes = n * 64 * rows;
+    const bool last = k == nc - 1;
+    if (!last && g_table_budget && bytes > g_table_budget) continue;
+    void* p = nullptr;
+    if (n == 0 || hipMalloc(&p, bytes) == hipSuccess) {
+      h->d_points_mont = p; h->has_tables = cand[k].tables; h->window_bits = cand[k].bits; h->sets = cand[k].sets;
+      return MZK_OK;
+    }
+    (void)hipGetLastError();
+  }
+  set_error("SRS handle: hipMalloc of %zu bytes (the prepared points alone) failed", n * 128);
+  return MZK_E_HIP;
+}
+// fills a freshly laid-out handle from n affine canonical points in device memory
+int srs_fill(mzk_srs* h, const void* d_plain, hipStream_t s) {
+  const size_t n = h->n;
+  if (n == 0) return MZK_OK;
+  if (!h->has_tables) return msm_prepare_points(d_plain, n, h->d_points_mont, (uint8_t*)h->d_points_mont + n * 64, s);
+  void* d_mont;
+  MZK_TRY(ws_get(WS_MSM_POINTS, n * 64, &d_mont));
+  MZK_TRY(msm_prepare_points(d_plain, n, d_mont, nullptr, s));
+  return msm_build_tables(d_mont, n, h->d_points_mont, h->window_bits * h->sets, s);     // every sets-th window: rows 2^(c sets q) P_i
+}
+}  // namespace mzk
+
+extern "C" {
+
+int mzk_set_table_budget(size_t bytes) { g_table_budget = bytes; return MZK_OK; }
+int mzk_srs_bucket_sets(const mzk_srs* srs) { return (srs && srs->has_tables) ? srs->sets : 0; }
+
 int mzk_srs_upload(const uint64_t* powers_xy, size_t n, mzk_srs** out) {
   MZK_ENTER();
   if (!out || (!powers_xy && n)) { set_error("srs_upload: null pointer"); return MZK_E_ARG; }
   hipStream_t s = ctx().stream;
   WsGuard wsg(s);
-  mzk_srs* h = new mzk_srs{nullptr, n, msm_srs_default_tables(n), msm_srs_window_bits(n), ctx().index};
+  mzk_srs* h = new mzk_srs{nullptr, n, false, 0, ctx().index};
+  int rc = srs_alloc_layout(h, 1);
+  if (rc != MZK_OK) { delete h; return rc; }
   if (n) {
-    void *d_plain, *d_mont;
-    const size_t copies = h->has_tables ? (size_t)msm_table_windows(h->window_bits) : 2;   // no tables: P_i, then phi(P_i) (GLV layout)
-    if (hipMalloc(&h->d_points_mont, n * 64 * copies) != hipSuccess) { delete h; set_error("srs_upload: hipMalloc failed"); return MZK_E_HIP; }
-    int rc = stage_in(WS_MISC_A, powers_xy, n * 64, &d_plain, s);
-    if (rc == MZK_OK && h->has_tables) {
-      rc = ws_get(WS_MSM_POINTS, n * 64, &d_mont);
-      if (rc == MZK_OK) rc = msm_prepare_points(d_plain, n, d_mont, nullptr, s);
-      if (rc == MZK_OK) rc = msm_build_tables(d_mont, n, h->d_points_mont, h->window_bits, s);
-    } else if (rc == MZK_OK) {
-      rc = msm_prepare_points(d_plain, n, h->d_points_mont, (uint8_t*)h->d_points_mont + n * 64, s);
-    }
+    void* d_plain;
+    rc = stage_in(WS_MISC_A, powers_xy, n * 64, &d_plain, s);
+    if (rc == MZK_OK) rc = srs_fill(h, d_plain, s);
     if (rc == MZK_OK && hipStreamSynchronize(s) != hipSuccess) rc = MZK_E_HIP;
     if (rc != MZK_OK) { (void)hipFree(h->d_points_mont); delete h; return rc; }
   }
@@ -1030,7 +1085,7 @@ int mzk_srs_window_bits(const mzk_srs* srs) { return (srs && srs->has_tables) ? 
 int mzk_srs_direct_bits(const mzk_srs* srs) { return (srs && srs->d_direct) ? srs->direct_bits : 0; }
 size_t mzk_srs_table_bytes(const mzk_srs* srs) {
   if (!srs) return 0;
-  return srs->n * 64 * (srs->has_tables ? (size_t)msm_table_windows(srs->window_bits) : 2) + srs->direct_bytes;
+  return srs->n * 64 * srs->table_rows() + srs->direct_bytes;
 }
 
 // The _many forms take the grid pass whenever the handle can (any count >= 1); the _batch forms from MANY_MIN_COUNT polynomials
@@ -1160,19 +1215,11 @@ int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, m
   if (!out || (!d_powers_xy && n)) { set_error("srs_from_device: null pointer"); return MZK_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
   if (with_tables < 0 || (with_tables > 1 && (with_tables < 8 || with_tables > 22))) { set_error("srs_from_device: with_tables must be 0, 1 or a window width 8..22"); return MZK_E_ARG; }
-  mzk_srs* h = new mzk_srs{nullptr, n, with_tables > 1 || (with_tables && msm_srs_default_tables(n)), with_tables > 1 ? with_tables : msm_srs_window_bits(n), ctx().index};
+  mzk_srs* h = new mzk_srs{nullptr, n, false, 0, ctx().index};
+  int rc = srs_alloc_layout(h, with_tables);
+  if (rc != MZK_OK) { delete h; return rc; }
   if (n) {
-    void* d_mont;
-    const size_t copies = h->has_tables ? (size_t)msm_table_windows(h->window_bits) : 2;   // no tables: P_i, then phi(P_i) (GLV layout)
-    if (hipMalloc(&h->d_points_mont, n * 64 * copies) != hipSuccess) { delete h; set_error("srs_from_device: hipMalloc failed"); return MZK_E_HIP; }
-    int rc = MZK_OK;
-    if (h->has_tables) {
-      rc = ws_get(WS_MSM_POINTS, n * 64, &d_mont);
-      if (rc == MZK_OK) rc = msm_prepare_points(d_powers_xy, n, d_mont, nullptr, s);
-      if (rc == MZK_OK) rc = msm_build_tables(d_mont, n, h->d_points_mont, h->window_bits, s);
-    } else {
-      rc = msm_prepare_points(d_powers_xy, n, h->d_points_mont, (uint8_t*)h->d_points_mont + n * 64, s);
-    }
+    rc = srs_fill(h, d_powers_xy, s);
     if (rc == MZK_OK && hipStreamSynchronize(s) != hipSuccess) rc = MZK_E_HIP;
     if (rc != MZK_OK) { (void)hipFree(h->d_points_mont); delete h; return rc; }
   }

@@ -174,16 +174,23 @@ enum { MSM_PTS_PLAIN = 0, MSM_PTS_MONT = 1, MSM_PTS_TABLES = 2 };
 // Other widths stay selectable through mzk_srs_from_device_ex for tuning and tests (BASELINE configs[2] names 16 bits:
 // bench.py reports that width as its own leg).
 static inline int msm_table_windows(int c) { return 254 / c + 1; }
+// tables a handle with `sets` bucket sets holds: every sets-th window, ceil(windows / sets) = 254 / (c sets) + 1
+static inline int msm_table_rows(int c, int sets) { return 254 / (c * sets) + 1; }
 // Small SRS (the reference's actual sizes: a few thousand powers at most) take the short paths of mzk_msm.hip (two launches:
 // k_small_accumulate_scan + the tail); with tables there is no window Horner either (its ~120 serial doublings are the latency
 // floor of a small generic MSM), so they get narrow windows: 8 bits = 32 tables x 128 buckets up to 1024 points, 10 bits =
 // 26 tables x 512 buckets up to 2^14 (where the sortless path still beats the general pipeline: profiles/r03v_*), then 16 and,
-// from 2^19 points on, 17 bits through the general pipeline (tools/timing/window_sweep.py).
+// from 2^19 points on, 17 bits, from 2^22 on 20 bits through the general pipeline (tools/timing/window_sweep.py).
+// Round 4 (tools/gpu_jobs/r04_window_sweep.sh, profiles/r04c_window_sweep.txt; one box, c = 16 / 17 / 20 / 22):
+//   2^22   6.09 /  5.75 /  5.62 / 12.97      2^23  11.97 / 11.27 / 10.89 / 20.26      2^24  23.56 / 22.05 / 20.89 / 30.18
+// 20 bits (13 tables, 2^19 buckets) win from 2^22 points on: two accumulations fewer per pair outweigh the wider sort and the
+// longer reduction; 22 bits (12 tables) lose everything to the sort (2^21 buckets: 8192 per coarse bin, past the staged fine
+// scatter) and their accumulate is no faster (a longer bucket search per segment).
 static inline int msm_srs_window_bits(size_t n) {
-  return n <= 1024 ? 8 : (n <= ((size_t)1 << 14) ? 10 : (n < ((size_t)1 << 19) ? 16 : 17));
+  return n <= 1024 ? 8 : (n <= ((size_t)1 << 14) ? 10 : (n < ((size_t)1 << 19) ? 16 : (n < ((size_t)1 << 22) ? 17 : 20)));
 }
 static inline bool msm_srs_default_tables(size_t n) { return n > 0; }
-#define MSM_PTS_TABLES_C(c) (MSM_PTS_TABLES | ((c) << 8))
+#define MSM_PTS_TABLES_C(c) (MSM_PTS_TABLES | ((c) << 8))      // bits 16..23: bucket sets (0 or 1 = one)
 int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int point_kind, size_t table_stride, void* d_out,
                  bool out_partial_xyzz, hipStream_t s, const std::function<int()>* points_ready = nullptr);
 
@@ -220,12 +227,18 @@ struct mzk_srs {
   bool has_tables;
   int window_bits;
   int ctx_index;         // the context (device) that owns d_points_mont
+  // Bucket sets of the table layout (1 = every window shares one set: the default).  With k sets the handle holds only every
+  // k-th window table, T[q][i] = 2^(c k q) P_i: window w = k q + r adds T[q][i] into bucket set r, and the result is
+  // sum_r 2^(c r) B_r (k - 1 times c doublings at the very end).  1/k of the table memory for the same additions -- what a
+  // handle degrades to when the full tables do not fit the budget / the device (srs_alloc_layout).
+  int sets = 1;
   // optional (mzk_srs_build_direct): every multiple a window digit can ask for, D[(w n + i) 2^(direct_bits-1) + m] = (m + 1) 2^(direct_bits w) P_i,
   // affine Montgomery -- commitments of many short polynomials then need no buckets at all (msm_many_srs)
   void* d_direct = nullptr;
   int direct_bits = 0;
   size_t direct_bytes = 0;
-  int kind() const { return has_tables ? (mzk::MSM_PTS_TABLES | (window_bits << 8)) : (int)mzk::MSM_PTS_MONT; }
+  int kind() const { return has_tables ? (mzk::MSM_PTS_TABLES | (window_bits << 8) | (sets << 16)) : (int)mzk::MSM_PTS_MONT; }
+  size_t table_rows() const { return has_tables ? (size_t)mzk::msm_table_rows(window_bits, sets) : 2; }   // no tables: P_i, then phi(P_i) (GLV layout)
 };
 
 namespace mzk {

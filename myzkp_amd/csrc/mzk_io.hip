@@ -20,6 +20,7 @@
 using namespace mzk;
 
 namespace mzk {
+int srs_alloc_layout(mzk_srs* h, int with_tables);     // mzk_api.hip
 struct SrsFileHeader {
   char magic[8];          // "MZKSRS\0\0"
   uint32_t format;        // 2 (1 = older dumps without tables_fnv1a)
@@ -60,7 +61,7 @@ int mzk_srs_save(const mzk_srs* srs, const char* path, int with_tables) {
   WsGuard wsg(s);
   FileCloser fc{fopen(path, "wb")};
   if (!fc.f) { set_error("srs_save: cannot open %s for writing", path); return MZK_E_IO; }
-  const bool tables = with_tables && srs->has_tables;
+  const bool tables = with_tables && srs->has_tables && srs->sets == 1;      // a degraded layout (every k-th table) is rebuilt from the points on load
   SrsFileHeader h;
   memset(&h, 0, sizeof h);
   memcpy(h.magic, SRS_MAGIC, 8);
@@ -96,7 +97,7 @@ int mzk_srs_save(const mzk_srs* srs, const char* path, int with_tables) {
   return MZK_OK;
 }
 
-// with_tables as in mzk_srs_from_device_ex (0 = plain prepared points, 1 = default 16-bit windows, 8..22 = that width);
+// with_tables as in mzk_srs_from_device_ex (0 = plain prepared points, 1 = the default width for n (msm_srs_window_bits), 8..22 = that width);
 // tables stored in the file are used when their width matches, otherwise they are rebuilt from the points.
 int mzk_srs_load(const char* path, int with_tables, mzk_srs** out) {
   MZK_ENTER();
@@ -128,11 +129,16 @@ int mzk_srs_load(const char* path, int with_tables, mzk_srs** out) {
                           h.table_rows == (uint32_t)(msm_table_windows(want_bits) - 1) && n > 0;
   if (!use_stored) return mzk_srs_from_device_ex(d_plain, n, with_tables, out, s);
   WsGuard wsg(s);
-  mzk_srs* hd = new mzk_srs{nullptr, n, true, want_bits, ctx().index};
+  mzk_srs* hd = new mzk_srs{nullptr, n, false, 0, ctx().index};
   const size_t rows = (size_t)h.table_rows + 1;
-  int rc = MZK_OK;
+  int rc = srs_alloc_layout(hd, with_tables);
+  if (rc == MZK_OK && !(hd->has_tables && hd->sets == 1 && hd->window_bits == want_bits)) {
+    // the stored tables do not fit the budget / the device as they are: take whatever layout does fit, built from the points
+    mzk_srs_free(hd);
+    return mzk_srs_from_device_ex(d_plain, n, with_tables, out, s);
+  }
+  if (rc != MZK_OK) { delete hd; return rc; }
   uint64_t thash = hash;
-  if (hipMalloc(&hd->d_points_mont, n * 64 * rows) != hipSuccess) { set_error("srs_load: hipMalloc failed"); rc = MZK_E_HIP; }
   if (rc == MZK_OK) rc = msm_prepare_points(d_plain, n, hd->d_points_mont, nullptr, s);      // row 0 = the points, Montgomery form
   for (size_t row = 1; rc == MZK_OK && row < rows; row++) {
     for (size_t at = 0; rc == MZK_OK && at < n; at += IO_CHUNK_POINTS) {

@@ -225,6 +225,7 @@ __device__ __forceinline__ u32 raw_window(const u32* w, int win, int c) {
 // bucket = |digit| - 1, entry = w * table_stride + i.
 struct DigitLayout {
   int c, nwin, merged;
+  int sets;              // merged layout: bucket sets (mzk_srs::sets); window w goes to set w % sets and reads table row w / sets
   size_t table_stride;
   int glv;               // generic layout only: scalars are GLV-split, the phi images of the points start at phi_offset
   size_t phi_offset;
@@ -248,8 +249,8 @@ __device__ __forceinline__ void walk_digits(const u32* w, const DigitLayout& L, 
       carry = 0;
       if (raw > half) { mag = (1u << c) - raw; neg = 1; carry = 1; }
       if (mag != 0) {
-        const u32 key = (L.merged ? 0u : ((u32)win << (c - 1))) + (mag - 1);
-        const u32 payload = (L.merged ? (u32)((size_t)win * L.table_stride + i) : (u32)i) | (neg << 31);
+        const u32 key = (L.merged ? ((u32)(win % L.sets) << (c - 1)) : ((u32)win << (c - 1))) + (mag - 1);
+        const u32 payload = (L.merged ? (u32)((size_t)(win / L.sets) * L.table_stride + i) : (u32)i) | (neg << 31);
         emit(win, key, payload);
       }
     }
@@ -786,14 +787,32 @@ __global__ __launch_bounds__(256) void k_scan_finish(u32* __restrict__ offsets, 
   else if (i < n) offsets[i] = offsets[i] + pre;
 }
 
-// out[i] = sum_{j<i} in[j] for i <= n (out[n] = total); in == out allowed; scratch: (ceil(n / SCAN_BLOCK) + 2) words
-// Two launches: block-local scans, then every workgroup adds the totals in front of its block.
-// (A single-workgroup scan of the 65536 counters was measured: 40 us SLOWER per scan than the launches -- one CU
-// cannot stream and shuffle-scan 256 KiB as fast as 32 workgroups do, launch latency included.)
+// offsets[i] += prefix[block(i)] for a prefix array that is already scanned (prefix[nblocks] = total -> offsets[n])
+__global__ __launch_bounds__(256) void k_scan_add(u32* __restrict__ offsets, const u32* __restrict__ prefix, size_t nblocks, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) offsets[i] += prefix[i / SCAN_BLOCK];
+  else if (i == n) offsets[n] = prefix[nblocks];
+}
+// out[i] = sum_{j<i} in[j] for i <= n (out[n] = total); in == out allowed; scratch: scan_scratch_words(n) words.
+// Two launches: block-local scans, then every workgroup adds the totals in front of its block (k_scan_finish re-sums them
+// itself: a few dozen to a few hundred values).  (A single-workgroup scan of the 65536 counters was measured: 40 us SLOWER per
+// scan than the launches -- one CU cannot stream and shuffle-scan 256 KiB as fast as 32 workgroups do, launch latency included.)
+// Above SCAN_DIRECT_BLOCKS block totals that re-summing would be quadratic (the generic layout at 2^24 has 16384 of them, 22-bit
+// windows 65536: ~10^9 .. 10^10 redundant loads), so the totals are scanned by a recursive call and added (four or five launches).
+constexpr size_t SCAN_DIRECT_BLOCKS = 2048;
+static size_t scan_scratch_words(size_t n) {
+  const size_t sb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  return sb + 2 + (sb > SCAN_DIRECT_BLOCKS ? scan_scratch_words(sb) : 0);
+}
 static int launch_exclusive_scan(const u32* in, u32* out, size_t n, u32* scratch, hipStream_t s) {
   const size_t sb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
   hipLaunchKernelGGL(k_scan_local, dim3((unsigned)sb), dim3(256), 0, s, in, out, scratch, n);
-  hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((n + 255) / 256 + 1)), dim3(256), 0, s, out, (const u32*)scratch, sb, n);
+  if (sb <= SCAN_DIRECT_BLOCKS) {
+    hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)((n + 255) / 256 + 1)), dim3(256), 0, s, out, (const u32*)scratch, sb, n);
+  } else {
+    MZK_TRY(launch_exclusive_scan((const u32*)scratch, scratch, sb, scratch + sb + 2, s));      // scratch[b] = totals in front of block b, scratch[sb] = total
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)(n / 256 + 1)), dim3(256), 0, s, out, (const u32*)scratch, sb, n);
+  }
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }
@@ -1331,7 +1350,7 @@ struct SortArgs {
 template <class REC>
 static int sort_records(const SortArgs& a, hipStream_t s) {
   typedef typename REC::T R;
-  const int cw = (a.L.merged && !a.L.glv && (a.L.c == 16 || a.L.c == 17)) ? a.L.c : 0;
+  const int cw = (a.L.merged && !a.L.glv && a.L.sets == 1 && (a.L.c == 16 || a.L.c == 17 || a.L.c == 20)) ? a.L.c : 0;     // the default widths by SRS size
   static const int env_staged = tune_int("MZK_COARSE_STAGED", 1);      // 0: A/B against the direct stores
   if (cw != 0 && env_staged != 0) {
     const size_t lds = (size_t)STAGE_RECORDS * (sizeof(R) + 1) + (size_t)(4 * COARSE_BINS + 1) * 4;
@@ -1339,9 +1358,13 @@ static int sort_records(const SortArgs& a, hipStream_t s) {
     if (!attr) {
       MZK_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<REC, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       MZK_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<REC, 17>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      MZK_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<REC, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr = true;
     }
-    if (cw == 17)
+    if (cw == 20)
+      hipLaunchKernelGGL((k_coarse_scatter_staged<REC, 20>), dim3(a.nwg), dim3(SORT2_THREADS), lds, s, a.scalars, a.n, a.L.table_stride, a.key_shift, a.fine_mask,
+                         a.fb, (const u32*)a.binhist, a.nwg, (R*)a.tmp);
+    else if (cw == 17)
       hipLaunchKernelGGL((k_coarse_scatter_staged<REC, 17>), dim3(a.nwg), dim3(SORT2_THREADS), lds, s, a.scalars, a.n, a.L.table_stride, a.key_shift, a.fine_mask,
                          a.fb, (const u32*)a.binhist, a.nwg, (R*)a.tmp);
     else
@@ -1349,6 +1372,9 @@ static int sort_records(const SortArgs& a, hipStream_t s) {
                          a.fb, (const u32*)a.binhist, a.nwg, (R*)a.tmp);
   }
 #ifdef MZK_TUNING
+  else if (cw == 20)
+    hipLaunchKernelGGL((k_coarse_scatter<REC, 20>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb,
+                       (const u32*)a.binhist, a.nwg, (R*)a.tmp);
   else if (cw == 17)
     hipLaunchKernelGGL((k_coarse_scatter<REC, 17>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb,
                        (const u32*)a.binhist, a.nwg, (R*)a.tmp);
@@ -1394,21 +1420,24 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     return MZK_OK;
   }
   DigitLayout L;
-  const int table_c = (point_kind >> 8) ? (point_kind >> 8) : 16;
+  const int table_c = ((point_kind >> 8) & 0xff) ? ((point_kind >> 8) & 0xff) : 16;
+  const int table_sets = ((point_kind >> 16) & 0xff) ? ((point_kind >> 16) & 0xff) : 1;
   point_kind &= 0xff;
   L.merged = (point_kind == 2) ? 1 : 0;
+  L.sets = L.merged ? table_sets : 1;
   L.table_stride = table_stride;
   // generic layout: GLV split (mzk_glv.h) -- 2n points (P_i and phi(P_i) at phi_offset + i), half-length scalars
   L.glv = L.merged ? 0 : 1;
   L.phi_offset = (point_kind == 0) ? n : table_stride;   // prepared below / laid out by the SRS handle
   MsmShape sh = L.merged ? choose_shape(n) : choose_shape_glv(n);
   if (L.merged) {
-    sh.c = table_c; sh.nwin = msm_table_windows(table_c); sh.lgB = sh.c - 1; sh.nbuckets = (size_t)1 << sh.lgB;
+    sh.c = table_c; sh.nwin = msm_table_windows(table_c); sh.lgB = sh.c - 1; sh.nbuckets = (size_t)L.sets << sh.lgB;
   }
   L.c = sh.c; L.nwin = sh.nwin;
   const size_t NB = sh.nbuckets;
-  const int red_windows = L.merged ? 1 : sh.nwin;   // bucket sets to reduce
-  const int horner_c = L.merged ? 0 : sh.c;
+  const bool one_set = L.merged && L.sets == 1;     // the tail writes the result itself: no Horner over bucket sets
+  const int red_windows = L.merged ? L.sets : sh.nwin;   // bucket sets to reduce
+  const int horner_c = one_set ? 0 : sh.c;
   const u32* pts = (const u32*)d_points;
   void* pm = nullptr;
   if (point_kind == 0) {
@@ -1430,7 +1459,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   // (the generic layout has twice the entries per pair: measured at 4096 pairs it is 5 % slower on this path, the commit 14 % faster)
   static const int env_scan = tune_int("MZK_SMALL_SCAN", 1);     // 0: A/B against the sorted path
   static const int env_scan_log = tune_int("MZK_SCAN_MAX_LOG", 14);
-  const bool scan_ok = L.merged && env_scan != 0 && n <= ((size_t)1 << env_scan_log) && (L.c == 8 || (L.c >= 10 && L.c <= 13));
+  const bool scan_ok = one_set && env_scan != 0 && n <= ((size_t)1 << env_scan_log) && (L.c == 8 || (L.c >= 10 && L.c <= 13));
   if ((scan_ok || n < (L.merged ? SMALL_MAX_N : SMALL_MAX_N - 1)) && NB <= SMALL_MAX_BUCKETS) {
     u32 *offsets, *entries, *buckets, *wsum;
     MZK_TRY(ws_get(WS_MSM_OFFSETS, (NB + 1) * 4, (void**)&offsets));
@@ -1457,14 +1486,14 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     else
       hipLaunchKernelGGL(k_small_accumulate<64>, dim3((unsigned)NB), dim3(64), 0, s, pts, (const u32*)offsets, (const u32*)entries, buckets);
     prof_end(s, MZK_PH_MSM_ACCUMULATE);
-    MZK_TRY(reduce_bucket_sets(buckets, sh.lgB, red_windows, L.merged != 0, horner_c, wsum, (u32*)d_out, out_partial_xyzz, s));
+    MZK_TRY(reduce_bucket_sets(buckets, sh.lgB, red_windows, one_set, horner_c, wsum, (u32*)d_out, out_partial_xyzz, s));
     MZK_HIP(hipGetLastError());
     return MZK_OK;
   }
   // entries pack the point reference into 31 bits (+ sign) and entry positions into 32: reject shapes that overflow
   // (window widths below 16 on a > 2^26-point SRS) instead of gathering a wrong table row
   {
-    const size_t ref_limit = L.merged ? (size_t)sh.nwin * table_stride : L.phi_offset + n;
+    const size_t ref_limit = L.merged ? (size_t)msm_table_rows(sh.c, L.sets) * table_stride : L.phi_offset + n;
     if (ref_limit > ((size_t)1 << 31) || E_max >= ((size_t)1 << 32)) {
       set_error("msm: %zu pairs x %d windows (table stride %zu) exceed the 31-bit point references / 32-bit entry offsets", n, sh.nwin, table_stride);
       return MZK_E_ARG;
@@ -1488,7 +1517,6 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   const size_t nslots = T + NB + 1;
   const size_t heavy_words = 4 + (T + NB) / HEAVY_SLOTS;         // count + at most (T + NB) / 33 heavy buckets
   u32 *counts, *offsets, *ranks, *entries, *scan_tmp, *buckets, *slots;
-  const size_t scan_blocks = (NB + SCAN_BLOCK - 1) / SCAN_BLOCK;
   MZK_TRY(ws_get(WS_MSM_COUNTS, NB * 4, (void**)&counts));
   MZK_TRY(ws_get(WS_MSM_OFFSETS, (NB + 1) * 4, (void**)&offsets));
   // two-level sort when the bucket space is a power of two >= 2^12 (merged layout always; generic at c = 16)
@@ -1498,7 +1526,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
                          (n >= 4096 || ((point_kind & 0xff) == 2 && NBtot > ((size_t)1 << 15)));
   MZK_TRY(ws_get(WS_MSM_CURSOR, E_max * (two_level ? 8 : 4), (void**)&ranks));
   MZK_TRY(ws_get(WS_MSM_ENTRIES, E_max * 4, (void**)&entries));
-  MZK_TRY(ws_get(WS_MSM_SCAN, (scan_blocks + 1) * 4, (void**)&scan_tmp));
+  MZK_TRY(ws_get(WS_MSM_SCAN, scan_scratch_words(NB) * 4, (void**)&scan_tmp));
   MZK_TRY(ws_get(WS_MSM_BUCKETS, NB * 128, (void**)&buckets));
   MZK_TRY(ws_get(WS_MSM_SLOTS, nslots * SLOT_WORDS * 4 + heavy_words * 4, (void**)&slots));
   u32* heavy = slots + nslots * SLOT_WORDS;
@@ -1527,12 +1555,14 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     u32 *binhist, *finehist;
     MZK_TRY(ws_get(WS_MSM_WGHIST, (n_coarse + 1 + n_fine + 1) * 4, (void**)&binhist));
     finehist = binhist + n_coarse + 1;
-    const size_t sb_c = (n_coarse + SCAN_BLOCK - 1) / SCAN_BLOCK, sb_f = (n_fine + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    const size_t sb_f = (n_fine + SCAN_BLOCK - 1) / SCAN_BLOCK;
     u32* scan2;
-    MZK_TRY(ws_get(WS_MSM_SCAN, (sb_c + sb_f + 4) * 4, (void**)&scan2));
-    if (L.merged && !L.glv && L.c == 17)
+    MZK_TRY(ws_get(WS_MSM_SCAN, (scan_scratch_words(n_coarse) + scan_scratch_words(n_fine) + 4) * 4, (void**)&scan2));
+    if (L.merged && !L.glv && L.sets == 1 && L.c == 20)
+      hipLaunchKernelGGL(k_coarse_count<20>, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
+    else if (L.merged && !L.glv && L.sets == 1 && L.c == 17)
       hipLaunchKernelGGL(k_coarse_count<17>, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
-    else if (L.merged && !L.glv && L.c == 16)
+    else if (L.merged && !L.glv && L.sets == 1 && L.c == 16)
       hipLaunchKernelGGL(k_coarse_count<16>, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
     else
       hipLaunchKernelGGL(k_coarse_count<0>, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
@@ -1540,9 +1570,9 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     int fb = 0;
     while ((1 << fb) < F) fb++;
     // largest point reference: merged nwin * stride, generic phi_offset + n
-    const size_t ref_max = L.merged ? (size_t)sh.nwin * table_stride : L.phi_offset + n;
+    const size_t ref_max = L.merged ? (size_t)msm_table_rows(sh.c, L.sets) * table_stride : L.phi_offset + n;
     const bool compact = ref_max <= ((size_t)1 << (31 - fb));      // references are < ref_max
-    SortArgs sa{(const u32*)d_scalars, n, L, key_shift, fine_mask, fb, binhist, nwg, (void*)ranks, F, S, finehist, scan2 + sb_c + 2, sb_f, n_fine,
+    SortArgs sa{(const u32*)d_scalars, n, L, key_shift, fine_mask, fb, binhist, nwg, (void*)ranks, F, S, finehist, scan2 + scan_scratch_words(n_coarse) + 2, sb_f, n_fine,
                 offsets, entries, NBtot};
     MZK_TRY(compact ? sort_records<Rec4>(sa, s) : sort_records<Rec8>(sa, s));
   } else if (L.merged) {
@@ -1595,7 +1625,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
 
   u32* wsum;
   MZK_TRY(ws_get(WS_MSM_OUT, (size_t)MAX_WINDOWS * 128, (void**)&wsum));
-  MZK_TRY(reduce_bucket_sets(buckets, sh.lgB, red_windows, L.merged != 0, horner_c, wsum, (u32*)d_out, out_partial_xyzz, s));
+  MZK_TRY(reduce_bucket_sets(buckets, sh.lgB, red_windows, one_set, horner_c, wsum, (u32*)d_out, out_partial_xyzz, s));
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }
@@ -1710,11 +1740,10 @@ int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size
     const size_t T = (E_max + seg_sz - 1) / seg_sz;
     const size_t nslots = T + NBtot + 1;
     const size_t heavy_words = 4 + (T + NBtot) / HEAVY_SLOTS;
-    const size_t sb = (ncnt + SCAN_BLOCK - 1) / SCAN_BLOCK;
     u32 *offs, *compact, *entries, *scan_tmp, *buckets, *slots;
     MZK_TRY(ws_get(WS_MSM_COUNTS, (ncnt + 1) * 4, (void**)&offs));
     MZK_TRY(ws_get(WS_MSM_ENTRIES, E_max * 4, (void**)&entries));
-    MZK_TRY(ws_get(WS_MSM_SCAN, (sb + 2) * 4, (void**)&scan_tmp));
+    MZK_TRY(ws_get(WS_MSM_SCAN, scan_scratch_words(ncnt) * 4, (void**)&scan_tmp));
     MZK_TRY(ws_get(WS_MSM_BUCKETS, NBtot * 128, (void**)&buckets));
     MZK_TRY(ws_get(WS_MSM_SLOTS, nslots * SLOT_WORDS * 4 + heavy_words * 4, (void**)&slots));
     compact = offs;
@@ -1936,7 +1965,7 @@ int msm_direct_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elem
   }
   return MZK_OK;
 }
-bool srs_many_capable(const mzk_srs* srs) { return srs->d_direct != nullptr || (srs->has_tables && msm_many_supported(srs->window_bits)); }
+bool srs_many_capable(const mzk_srs* srs) { return srs->d_direct != nullptr || (srs->has_tables && srs->sets == 1 && msm_many_supported(srs->window_bits)); }
 int msm_many_srs(const mzk_srs* srs, const void* d_scalars, size_t n, size_t stride_elems, size_t count, void* d_out, hipStream_t s) {
   if (srs->d_direct) return msm_direct_many_dev_impl(d_scalars, n, stride_elems, count, srs->d_direct, srs->direct_bits, srs->n, d_out, s);
   return msm_many_dev_impl(d_scalars, n, stride_elems, count, srs->d_points_mont, srs->window_bits, srs->n, d_out, s);
