@@ -49,17 +49,53 @@ def recorded_traffic(kernel_prefix):
     return best
 
 
+def visible_gpus_without_hip(kfd_root="/sys/class/kfd/kfd/topology/nodes", environ=None):
+    """GPUs this process could use, counted WITHOUT touching the HIP runtime (the launcher parent must stay GPU-free by
+    construction): KFD topology nodes with simd_count > 0 (CPU nodes have 0), then the usual filters -- ROCR_VISIBLE_DEVICES
+    restricts the physical devices, HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES the ones of those HIP exposes (a comma list of
+    ordinals or UUIDs; an empty string or -1 hides all; entries after the first invalid ordinal are dropped, as the runtime does).
+    Returns None when the topology cannot be read (then the ranks' own check inside rank 0 decides)."""
+    environ = os.environ if environ is None else environ
+    try:
+        nodes = sorted(os.listdir(kfd_root), key=lambda x: int(x) if x.isdigit() else 1 << 30)
+    except OSError:
+        return None
+    count = 0
+    for nd in nodes:
+        try:
+            props = dict(l.split(None, 1) for l in open(os.path.join(kfd_root, nd, "properties")) if " " in l.strip())
+            if int(props.get("simd_count", "0").strip()) > 0:
+                count += 1
+        except (OSError, ValueError):
+            continue
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if var not in environ:
+            continue
+        kept = 0
+        for tok in environ[var].split(","):
+            tok = tok.strip()
+            if tok.isdigit() and int(tok) < count:
+                kept += 1
+            elif tok.upper().startswith("GPU-"):          # a UUID: cannot be resolved without the runtime -- count it
+                kept += 1
+            else:
+                break
+        count = min(count, kept)
+    return count
+
+
 def launch_ranks(n_gpus, argv):
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks (one process per GPU, RCCL) as a
-    child `python -m torch.distributed.run` and hand on rank 0's JSON line and the exit code.  This process never initialises
-    the GPU (torch.cuda.device_count() does not), so the children are ordinary child processes, not an exec from a GPU process."""
+    child `python -m torch.distributed.run` and hand on rank 0's JSON line and the exit code.  This process never touches the
+    HIP runtime -- the GPUs are counted from the KFD topology in sysfs (visible_gpus_without_hip); torch's own count is the
+    cross-check INSIDE the ranks -- so the children are ordinary child processes, not an exec from a GPU process."""
     import socket, subprocess
     shared = os.environ.get("MZK_BENCH_SHARED_GPU_TEST") == "1"
-    try:
-        import torch
-        visible = torch.cuda.device_count()
-    except Exception as ex:            # no torch / no driver: say so in the line
-        return fail_line(n_gpus, "cannot count GPUs: %s" % str(ex)[:200])
+    visible = visible_gpus_without_hip()
+    if visible is None:                # no KFD topology (no driver, or a container without /sys/class/kfd): nothing to launch on
+        if not shared:
+            return fail_line(n_gpus, "--gpus %d asked for but no GPU topology is readable (/sys/class/kfd/kfd/topology/nodes)" % n_gpus, visible_devices=0)
+        visible = 0
     if visible < n_gpus and not shared:
         return fail_line(n_gpus, "--gpus %d asked for but only %d GPU(s) visible; refusing to run fewer ranks than asked" % (n_gpus, visible),
                          visible_devices=visible)
