@@ -49,6 +49,34 @@ def recorded_traffic(kernel_prefix):
     return best
 
 
+def recorded_ntt_traffic(field_tag):
+    """Bytes per 2^20-point transform from the newest profiles/r*_hbm_traffic_pmc.txt that has a section for this field
+    (`== NTT <field_tag> 2^20`: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/timing/ntt_only.py): the sum over
+    the transform's kernels, raw and corrected.  Correction as calibrated on known byte counts (profiles/r02o_hbm_traffic_pmc.txt,
+    the microarchitecture guide's rule): FETCH_SIZE tallies a 128-byte request at 64, so streams read in runs of >= 128 bytes
+    count double -- every BN254 pass, and the contiguous rows of the M128 last pass; the M128 strided pass reads 64-byte runs
+    (4 columns x 16 bytes), counted 1:1.  WRITE_SIZE is exact.  None if no such record exists."""
+    import glob, re
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.txt"))):
+        inside, raw, corr, kernels = False, 0.0, 0.0, []
+        for line in open(path):
+            if line.startswith("== "):
+                inside = ("NTT %s 2^20" % field_tag) in line
+                continue
+            m = re.match(r"(.*?)\s+launches=.*FETCH_SIZE avg=\s*([0-9.]+) KiB\s+WRITE_SIZE avg=\s*([0-9.]+) KiB", line)
+            if inside and m and "k_ntt_" in m.group(1):
+                fe, wr = float(m.group(2)) * 1024, float(m.group(3)) * 1024
+                double = not (field_tag == "M128" and "k_ntt_strided" in m.group(1))
+                raw += fe + wr
+                corr += (2 * fe if double else fe) + wr
+                kernels.append(m.group(1).strip()[:40])
+        if kernels:
+            best = {"bytes": int(corr), "raw_bytes": int(raw), "kernels": kernels,
+                    "source": "profiles/%s (recorded rocprofv3 --pmc passes of tools/timing/ntt_only.py; FETCH_SIZE doubled for streams read in runs of >= 128 bytes, see recorded_ntt_traffic; not collected by this run)" % os.path.basename(path)}
+    return best
+
+
 def visible_gpus_without_hip(kfd_root="/sys/class/kfd/kfd/topology/nodes", environ=None):
     """GPUs this process could use, counted WITHOUT touching the HIP runtime (the launcher parent must stay GPU-free by
     construction): KFD topology nodes with simd_count > 0 (CPU nodes have 0), then the usual filters -- ROCR_VISIBLE_DEVICES
@@ -578,8 +606,8 @@ def main():
                 cf_h = cf.cpu().numpy().view(np.uint64).reshape(count, nn, 4)
                 got = mz.array_to_points(o_many.cpu().numpy().view(np.uint64).reshape(count, 8))
                 e["first_and_last_equal_oracle"] = bool(got[0] == orc.msm_fast(cf_h[0], pts_h) and got[-1] == orc.msm_fast(cf_h[-1], pts_h))
+                b0 = L.mzk_srs_table_bytes(hs)            # the window tables alone (a direct build replaces the previous direct tables)
                 for bits in (10, 12):
-                    b0 = L.mzk_srs_table_bytes(hs)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     check(L.mzk_srs_build_direct(hs, ctypes.c_int(bits), ctypes.c_size_t(16 << 30), stream))
@@ -729,7 +757,8 @@ def main():
 
     def hbm_roofline(alg_bytes, ms):
         ach = alg_bytes / (ms * 1e-3) / 1e9
-        return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None}
+        return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                "frac_of_measured_copy_rate": ach / copy_gbps, "measured_copy_GBps": copy_gbps, "traffic": None}
 
     acc_ms = msm_ph.get("msm_bucket_accumulate_in_timed_region", {}).get("avg_ms", float("nan"))
     roof = hbm_roofline(96.0 * n, acc_ms)
@@ -742,13 +771,28 @@ def main():
     ntt_roof["passes"] = npass
     ntt_roof["algorithmic_bytes_per_launch"] = 64 * n
     ntt_roof["frac_of_wall_clock"] = 64.0 * n / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+    if args.log2n == 20:
+        tr = recorded_ntt_traffic("Fr")
+        if tr is not None:
+            ntt_roof.update({"traffic": tr["bytes"], "traffic_raw_counters": tr["raw_bytes"], "traffic_source": tr["source"]})
+    nttm_total_ms = nttm_ph.get("ntt_whole_transform_in_timed_region", {}).get("avg_ms", float("nan"))
+    nttm_roof = dict(hbm_roofline(32.0 * n, nttm_total_ms), kernel="k_ntt_strided + k_ntt_last (whole transform)", algorithmic_bytes_per_launch=32 * n)
+    if args.log2n == 20:
+        tr = recorded_ntt_traffic("M128")
+        if tr is not None:
+            nttm_roof.update({"traffic": tr["bytes"], "traffic_raw_counters": tr["raw_bytes"], "traffic_source": tr["source"]})
     # integer-multiply roofline (the binding one): v_mad_u64_u32 per Montgomery product = 171
     msm_mads = n * 16 * (8 * 171 + 2 * 135)             # generic layout: 2 x 8 GLV windows; madd = 8M + 2S per (pair, window)
     srs_mads = n * srs_table_windows * (8 * 171 + 2 * 135)
     ntt_mads = (n // 2) * args.log2n * 171
+    # M128: 35 v_mad_u64_u32 + 5 v_mul_lo_u32 (same half rate) per product (5 x 5 limbs, sparse modulus 1 + 407 * 2^119)
+    nttm_mads = (n // 2) * args.log2n * 40
     alu = {"unit": "v_mad_u64_u32/s", "peak": MAD_PEAK_PER_S,
            "msm_accumulate_frac": msm_mads / (acc_ms * 1e-3) / MAD_PEAK_PER_S if acc_ms == acc_ms else None,
-           "ntt_frac": ntt_mads / (ntt_total_ms * 1e-3) / MAD_PEAK_PER_S if ntt_total_ms else None}
+           "ntt_frac": ntt_mads / (ntt_total_ms * 1e-3) / MAD_PEAK_PER_S if ntt_total_ms else None,
+           "ntt_m128_frac": nttm_mads / (nttm_total_ms * 1e-3) / MAD_PEAK_PER_S if nttm_total_ms == nttm_total_ms and nttm_total_ms else None,
+           "ntt_m128_note": "(n/2) log2(n) products x 40 half-rate multiplies each; the M128 transform is bound by neither roofline: what its "
+                            "two passes wait for is the global loads / stores of the one tile each CU holds (DESIGN.md section 4)"}
 
     srs_ms = srs_dt / K * 1e3
     srs_rate = world * n / (srs_dt / K)
@@ -807,7 +851,7 @@ def main():
                 "phases": ntt_ph},
         "ntt_m128": {"metric": "NTT elems/sec", "value": world * n / (nttm_dt / K), "unit": "elems/s", "ms_per_step": nttm_dt / K * 1e3,
                      "field": "M128 = 1 + 407*2^119 (fri.rs:408)", "log2n": args.log2n, "phases": nttm_ph,
-                     "roofline": dict(hbm_roofline(32.0 * n, nttm_ph.get("ntt_whole_transform_in_timed_region", {}).get("avg_ms", float("nan"))), kernel="k_ntt_strided + k_ntt_last (whole transform)", algorithmic_bytes_per_launch=32 * n)},
+                     "roofline": nttm_roof},
         "coset_lde_m128": {"metric": "LDE output elems/sec (fast_coset_evaluate, ntt.rs:254-269; blow-up 4)", "value": world * n / (lde_dt / K), "unit": "elems/s",
                            "ms_per_step": lde_dt / K * 1e3, "n_coef": n // 4, "order": n, "phases": lde_ph},
         "merkle_m128": {"metric": "Merkle::commit of a codeword, SHA3-256 hashes/sec (merkle.rs:15-25 over bincode leaves, fri.rs:160-166; "
