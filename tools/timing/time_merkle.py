@@ -1,4 +1,5 @@
-import ctypes, time, sys
+import ctypes, os, time, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import myzkp_amd as mz
 mz.init(0); L = mz.lib()
