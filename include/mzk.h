@@ -427,7 +427,7 @@ int mzk_kzg_open_quotient_dev(const void* d_coef, size_t n, const uint64_t u_hos
  * whether the window tables are built (worth it from ~30 commits per SRS on at 2^20 points; a one-shot pipeline keeps
  * the plain prepared points and pays the window Horner instead).  Default widths by size: 8 bits up to 1024 points,
  * 10 up to 2^14, 16 below 2^19, 17 below 2^22, 20 from there on (254 / c + 1 tables of n points each: 15 at 17 bits, 13 at 20;
- * measured per size, profiles/r03b_window_sweep.txt, profiles/r04c_window_sweep.txt). */
+ * measured per size, profiles/r03b_window_sweep.txt, profiles/round4_window_sweep.txt). */
 int mzk_srs_from_device(const void* d_powers_xy, size_t n, mzk_srs** out, void* stream);
 int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, mzk_srs** out, void* stream);
 /* with_tables: 0 = plain prepared points, 1 = tables with the default window width for n (above), 8..22 = that window width

@@ -181,7 +181,7 @@ static inline int msm_table_rows(int c, int sets) { return 254 / (c * sets) + 1;
 // floor of a small generic MSM), so they get narrow windows: 8 bits = 32 tables x 128 buckets up to 1024 points, 10 bits =
 // 26 tables x 512 buckets up to 2^14 (where the sortless path still beats the general pipeline: profiles/r03v_*), then 16 and,
 // from 2^19 points on, 17 bits, from 2^22 on 20 bits through the general pipeline (tools/timing/window_sweep.py).
-// Round 4 (tools/gpu_jobs/r04_window_sweep.sh, profiles/r04c_window_sweep.txt; one box, c = 16 / 17 / 20 / 22):
+// Round 4 (tools/gpu_jobs/r04_window_sweep.sh, profiles/round4_window_sweep.txt; one box, c = 16 / 17 / 20 / 22):
 //   2^22   6.09 /  5.75 /  5.62 / 12.97      2^23  11.97 / 11.27 / 10.89 / 20.26      2^24  23.56 / 22.05 / 20.89 / 30.18
 // 20 bits (13 tables, 2^19 buckets) win from 2^22 points on: two accumulations fewer per pair outweigh the wider sort and the
 // longer reduction; 22 bits (12 tables) lose everything to the sort (2^21 buckets: 8192 per coarse bin, past the staged fine

@@ -1932,7 +1932,8 @@ int msm_direct_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elem
     const size_t cnt = (count - first < per_pass) ? count - first : per_pass;
     // workgroups per polynomial: one round of resident workgroups over the batch (three 256-lane workgroups per CU at the
     // kernel's VGPR count), at least one, at most one per 256 items, and at most 64 (k_direct_fold / k_direct_finish add them)
-    const size_t resident = (size_t)ctx().num_cu * 3;
+    static const int parts_mul = tune_int("MZK_DIRECT_PARTS_MUL", 1);       // tuning build: rounds of workgroups per launch
+    const size_t resident = (size_t)ctx().num_cu * 3 * (size_t)(parts_mul > 0 ? parts_mul : 1);
     size_t parts = (resident + cnt / 2) / cnt;
     const size_t max_parts = (items + DIRECT_THREADS - 1) / DIRECT_THREADS;
     if (parts > max_parts) parts = max_parts;

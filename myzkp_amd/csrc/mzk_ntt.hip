@@ -981,7 +981,7 @@ static int run_plan_geo(const NttPlan* pl, const u32* d_in, u32* d_out, hipStrea
 template <class P>
 static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t s, const PreArgs* pre = nullptr, size_t batch = 1) {
   // M128 large tiles: two 512-lane workgroups per CU (GeoM) once there are at least two tiles per CU -- 2^25 and up: 1.69 instead of
-  // 1.83 - 1.85 ms at 2^25 (same box A/B, profiles/r04b_*).  A 2^20 transform is exactly 256 tiles, ONE per CU whatever the
+  // 1.83 - 1.85 ms at 2^25 (same box A/B, profiles/round4_ntt_m128_two_workgroups_ab.txt).  A 2^20 transform is exactly 256 tiles, ONE per CU whatever the
   // workgroup size, and the 512-lane form only halves the lanes working on it (0.057 against 0.047 ms): it keeps round 3's
   // single 1024-lane workgroup.  Tuning build: MZK_NTT_M128_TWO_WG = smallest log2 size on GeoM (99 = never).
   static const int two_wg_from = tune_int("MZK_NTT_M128_TWO_WG", 21);

@@ -14,6 +14,7 @@ timeout 1200 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err
 echo "bench rc=$?" >> $O/${T}_pytest.log
 python tools/timing/small_latency.py > $O/${T}_small_latency.txt 2>&1
 python tools/timing/many_commit.py 10:256,10:256:1:10,10:256:1:12,12:64,12:64:1:10,8:1024,8:1024:1:10,14:16 > $O/${T}_many_commit.txt 2>&1
+bash tools/gpu_jobs/r04_many_trace.sh > $O/${T}_many_commit_kernel_trace.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 BENCH="$R/bench.py --steps 10 --warmup 2 --skip-cpu --extra-sizes= --e2e-log2n 0 --strong-log2n 0 --strong-ntt-log2n 0 --no-two-in-flight"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_prof -- python3 $BENCH > $O/${T}_bench_under_rocprof.json 2> $O/${T}_prof.err
