@@ -818,6 +818,9 @@ def main():
         "process_group": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None,
                           "launched_by": os.environ.get("MZK_BENCH_LAUNCHED_BY", "external launcher" if world > 1 else "single process")},
         **({"REHEARSAL_NOT_A_MEASUREMENT": "ranks share one GPU, exchange over gloo via host (MZK_BENCH_SHARED_GPU_TEST=1)"} if shared_gpu_test else {}),
+        # `value` is measured at the library's default window width for this SRS size (17 bits at 2^20 since round 3; BASELINE
+        # configs[2] names 16 bits: the kzg_commit_16_bit_windows leg) -- stated at top level so that a change of the default shows
+        "value_window_bits": srs_window_bits,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 254-bit Montgomery)",
         "data": "synthetic",
         "config": {"workload": "KZG commit = BN254 G1 Pippenger MSM of 2^%d (scalar, point) pairs per GPU against a device-resident SRS "

@@ -119,6 +119,37 @@ def case_msm():
         h.close()
 
 
+def case_many():
+    """grid-batched commitments (bucket pass, then direct tables of a random width) and a table budget that degrades the layout"""
+    import ctypes
+    L = mz.lib()
+    n = rng.choice([1, 2, 31, 256, 257, 1000, 1024, 1025, 2049, 4096, rng.randrange(1, 6000)])
+    count = rng.choice([1, 2, 3, 4, 5, 9, 17, 40])
+    pts = orc.synth_points(rng.getrandbits(40), n).copy()
+    if n > 4 and rng.random() < 0.5:
+        pts[rng.randrange(n)] = 0
+    rows = np.stack([special_scalars(n) for _ in range(count)])
+    h = mz.Srs(pts)
+    m = rng.choice([n, n, rng.randrange(0, n + 1)])
+    want = [orc.msm_fast(np.ascontiguousarray(rows[k, :m]), pts[:m]) for k in range(count)]
+    check("commit_many_buckets", h.commit_many(np.ascontiguousarray(rows[:, :m])) == want, (n, m, count))
+    bits = rng.choice([8, 9, 10, 11, 12])
+    if n * (254 // bits + 1) * (1 << (bits - 1)) * 64 <= (3 << 29):
+        h.build_direct(bits)
+        check("commit_many_direct", h.commit_many(np.ascontiguousarray(rows[:, :m])) == want, (n, m, count, bits))
+    h.close()
+    big = rng.choice([1 << 15, (1 << 15) + rng.randrange(1, 5000)])
+    bp = orc.synth_points(rng.getrandbits(40), big)
+    bs = special_scalars(big)
+    L.mzk_set_table_budget(ctypes.c_size_t(rng.choice([1, 3, 5, 9]) * big * 64))
+    try:
+        hb = mz.Srs(bp)
+        check("commit_under_table_budget", hb.commit(bs) == orc.msm_fast(bs, bp), (big, L.mzk_srs_bucket_sets(hb._h)))
+        hb.close()
+    finally:
+        L.mzk_set_table_budget(ctypes.c_size_t(0))
+
+
 def case_merkle():
     fid = rng.choice((FR, M128))
     n = rng.choice([1, 2, 3, 5, 8, 31, 64, 100, 1000, 4096, 5000])
@@ -228,7 +259,7 @@ def case_coset_divide():
     check("fast_coset_divide", (rc == 0 and got[0] == 0 and np.array_equal(got[1], want)) or (rc != 0 and got[0] != 0), (fid, ll, lr, lg, rc, got[0]))
 
 
-CASES = [case_fri_fold, case_kzg_next, case_g2, case_coset_divide, case_ntt, case_ntt_batch, case_lde, case_scale_columns, case_msm, case_merkle, case_poly, case_kzg]
+CASES = [case_many, case_fri_fold, case_kzg_next, case_g2, case_coset_divide, case_ntt, case_ntt_batch, case_lde, case_scale_columns, case_msm, case_merkle, case_poly, case_kzg]
 
 
 def run(budget, seed, max_cases=None):
