@@ -619,6 +619,25 @@ def main():
                     e["direct_tables_%d_bit" % bits] = d
                 e["us_per_commit"] = e["one_call_ms"] / count * 1e3
                 e["speedup_over_one_at_a_time"] = e["one_at_a_time_ms"] / e["one_call_ms"]
+                # open_kzg per polynomial at its own point (das/avail.rs:132 opens per cell): one call (over the 12-bit direct tables
+                # built above) against one mzk_kzg_open_srs_dev per polynomial on the same handle
+                us_h = orc.synth_vector(orc.FR, SEED + 33, count)
+                ys_m = torch.zeros(count * 4, dtype=torch.int64, device=dev); ws_m = torch.zeros(count * 8, dtype=torch.int64, device=dev)
+                ys_1 = torch.zeros(count * 4, dtype=torch.int64, device=dev); ws_1 = torch.zeros(count * 8, dtype=torch.int64, device=dev)
+
+                def open_many():
+                    check(L.mzk_kzg_open_srs_many_dev(hs, dptr(cf), ctypes.c_size_t(nn), ctypes.c_size_t(count), us_h.ctypes.data_as(ctypes.c_void_p), dptr(ys_m), dptr(ws_m), stream))
+
+                def open_loop():
+                    for k in range(count):
+                        check(L.mzk_kzg_open_srs_dev(hs, ctypes.c_void_p(cf.data_ptr() + k * nn * 32), ctypes.c_size_t(nn), us_h[k].ctypes.data_as(ctypes.c_void_p),
+                                                     ctypes.c_void_p(ys_1.data_ptr() + k * 32), ctypes.c_void_p(ws_1.data_ptr() + k * 64), stream))
+                o = {"one_at_a_time_ms": clock(open_loop, 1), "one_call_ms": clock(open_many, max(K, 10))}
+                o["same_values_and_witnesses_as_single_calls"] = bool(torch.equal(ys_m, ys_1) and torch.equal(ws_m, ws_1))
+                y0 = orc.from_limbs(ys_m[:4].cpu().numpy().view(np.uint64).reshape(1, 4))[0]
+                o["first_value_equals_oracle_horner"] = bool(y0 == orc.poly_eval(orc.FR, cf_h[0], orc.from_limbs(us_h[:1])[0]))
+                o["us_per_opening"] = o["one_call_ms"] / count * 1e3
+                e["openings_over_direct_tables_12_bit"] = o
                 res[key] = e
             except Exception as ex:
                 res[key] = {"error": str(ex)[:300]}
