@@ -1076,6 +1076,8 @@ int mzk_srs_build_direct(mzk_srs* srs, int window_bits, size_t max_bytes, void* 
   return MZK_OK;
 }
 void mzk_srs_drop_direct(mzk_srs* srs) {
+  mzk::EntryGuard entry;
+  if (!entry.ok) return;          // another thread is inside a call that may be reading the tables
   if (!srs || !srs->d_direct) return;
   (void)hipDeviceSynchronize();
   (void)hipFree(srs->d_direct);
