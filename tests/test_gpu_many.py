@@ -257,3 +257,57 @@ def test_many_commits_256_by_1024_the_das_shape(mz):
     for k in range(count):
         assert got[k] == orc.msm_fast(coefs[k], p), k
     mz.lib().mzk_srs_free(h)
+
+
+def test_many_commits_more_polynomials_than_one_pass_holds(mz):
+    """the pass handles at most 2^21 buckets / 2^22 coefficients (bucket form) or 2^14 polynomials (direct form) at a time and
+    loops beyond that: 258 polynomials of 2^14 coefficients (two passes of the bucket form), 16500 polynomials of 8 coefficients
+    over direct tables (two passes), and openings across the same boundary"""
+    import torch
+    L = mz.lib()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # bucket form: 256 + 2 polynomials of 2^14 coefficients
+    n, count = 1 << 14, 258
+    p = orc.synth_points(31, n)
+    h = _srs_ex(mz, p, 1)
+    coefs = orc.synth_vector(FR, 32, n * count).reshape(count, n, 4)
+    got = _commit_many(mz, h, coefs)
+    for k in (0, 1, 127, 255, 256, 257):
+        assert got[k] == orc.msm_fast(coefs[k], p), k
+    # every point against the single call (device compare: the oracle would take minutes)
+    d_c = torch.from_numpy(coefs.view(np.int64).reshape(-1).copy()).cuda()
+    d_many = torch.zeros(count * 8, dtype=torch.int64, device="cuda")
+    d_one = torch.zeros(count * 8, dtype=torch.int64, device="cuda")
+    assert L.mzk_kzg_commit_srs_many_dev(h, ctypes.c_void_p(d_c.data_ptr()), ctypes.c_size_t(n), ctypes.c_size_t(count), ctypes.c_void_p(d_many.data_ptr()), st) == 0
+    for k in range(count):
+        assert L.mzk_kzg_commit_srs_dev(h, ctypes.c_void_p(d_c.data_ptr() + k * n * 32), ctypes.c_size_t(n), ctypes.c_void_p(d_one.data_ptr() + k * 64), 0, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(d_many, d_one)
+    # openings across the pass boundary (2^22 / 2^14 = 256 polynomials per pass)
+    us = orc.synth_vector(FR, 33, count)
+    d_y = torch.zeros(count * 4, dtype=torch.int64, device="cuda"); d_w = torch.zeros(count * 8, dtype=torch.int64, device="cuda")
+    assert L.mzk_kzg_open_srs_many_dev(h, ctypes.c_void_p(d_c.data_ptr()), ctypes.c_size_t(n), ctypes.c_size_t(count), us.ctypes.data_as(ctypes.c_void_p),
+                                       ctypes.c_void_p(d_y.data_ptr()), ctypes.c_void_p(d_w.data_ptr()), st) == 0, L.mzk_last_error()
+    torch.cuda.synchronize()
+    ys = orc.from_limbs(d_y.cpu().numpy().view(np.uint64).reshape(count, 4))
+    y1 = torch.zeros(4, dtype=torch.int64, device="cuda"); w1 = torch.zeros(8, dtype=torch.int64, device="cuda")
+    for k in (0, 255, 256, 257):
+        assert ys[k] == orc.poly_eval(FR, coefs[k], orc.from_limbs(us[k:k + 1])[0]), k
+        assert L.mzk_kzg_open_srs_dev(h, ctypes.c_void_p(d_c.data_ptr() + k * n * 32), ctypes.c_size_t(n), us[k].ctypes.data_as(ctypes.c_void_p),
+                                      ctypes.c_void_p(y1.data_ptr()), ctypes.c_void_p(w1.data_ptr()), st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(w1, d_w[8 * k:8 * k + 8]) and torch.equal(y1, d_y[4 * k:4 * k + 4]), k
+    L.mzk_srs_free(h)
+    del d_c, d_many, d_one
+    # direct form: 16384 + 116 polynomials of 8 coefficients
+    n, count = 8, 16500
+    p = orc.synth_points(41, n)
+    h = _srs_ex(mz, p, 1)
+    assert L.mzk_srs_build_direct(h, 10, ctypes.c_size_t(0), st) == 0, L.mzk_last_error()
+    coefs = orc.synth_vector(FR, 42, n * count).reshape(count, n, 4)
+    got = _commit_many(mz, h, coefs)
+    for k in list(range(0, count, 997)) + [16383, 16384, 16385, count - 1]:
+        assert got[k] == orc.msm_ref(coefs[k], p), k
+    L.mzk_srs_drop_direct(h)
+    assert _commit_many(mz, h, coefs) == got            # the bucket form agrees on all 16500
+    L.mzk_srs_free(h)
