@@ -112,3 +112,40 @@ def test_setup_on_device_then_dump_equals_oracle_setup(mz, tmp_path):
     assert L.mzk_srs_save(hh, os.fsencode(path), 0) == 0
     L.mzk_srs_free(hh)
     assert open(path, "rb").read()[64:] == orc.kzg_setup_ref(alpha, n - 1).tobytes()
+
+
+def test_dumps_and_loads_under_a_table_budget(mz, tmp_path):
+    """A handle degraded by mzk_set_table_budget dumps its points only (its every-2nd-table layout is rebuilt on load); a dump WITH
+    full tables loaded under a budget they do not fit degrades instead of failing -- commitments bit-identical all the way."""
+    import ctypes
+    L = mz.lib()
+    L.mzk_srs_table_bytes.restype = ctypes.c_size_t
+    n = (1 << 15) + 5
+    p = orc.synth_points(77, n)
+    s = orc.synth_vector(FR, 78, n)
+    want = orc.msm_fast(s, p)
+    full_path, deg_path = str(tmp_path / "full.bin"), str(tmp_path / "degraded.bin")
+    h = mz.Srs(p)
+    assert L.mzk_srs_bucket_sets(h._h) == 1
+    h.save(full_path, with_tables=True)
+    h.close()
+    try:
+        L.mzk_set_table_budget(ctypes.c_size_t(9 * n * 64))              # 16 tables do not fit, 8 do
+        h = mz.Srs(p)
+        assert L.mzk_srs_bucket_sets(h._h) == 2 and h.commit(s) == want
+        h.save(deg_path, with_tables=True)
+        assert os.path.getsize(deg_path) == 64 + 64 * n                  # points only
+        h.close()
+        g = mz.Srs.load(full_path, with_tables=1)                        # stored tables: 16 rows, over the budget
+        assert L.mzk_srs_bucket_sets(g._h) == 2 and L.mzk_srs_table_bytes(g._h) <= 9 * n * 64
+        assert g.commit(s) == want and np.array_equal(g.download(), p)
+        g.close()
+        L.mzk_set_table_budget(ctypes.c_size_t(0))
+        g = mz.Srs.load(deg_path, with_tables=1)                         # no budget any more: full tables, built from the points
+        assert L.mzk_srs_bucket_sets(g._h) == 1 and g.commit(s) == want
+        g.close()
+        g = mz.Srs.load(full_path, with_tables=1)                        # and the stored tables are used as they are
+        assert L.mzk_srs_bucket_sets(g._h) == 1 and g.commit(s) == want
+        g.close()
+    finally:
+        L.mzk_set_table_budget(ctypes.c_size_t(0))
