@@ -1927,7 +1927,7 @@ int msm_direct_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elem
     return MZK_OK;
   }
   const size_t items = n * (size_t)msm_table_windows(c);
-  const size_t per_pass = (size_t)1 << 14;                           // polynomials per pass (lane partials: <= 64 x 256 x 144 bytes each)
+  const size_t per_pass = (size_t)1 << 12;                           // polynomials per pass: cnt x parts <= ~4096 workgroups of lane partials (36 KiB each: <= 150 MiB)
   for (size_t first = 0; first < count; first += per_pass) {
     const size_t cnt = (count - first < per_pass) ? count - first : per_pass;
     // workgroups per polynomial: one round of resident workgroups over the batch (three 256-lane workgroups per CU at the

@@ -260,9 +260,9 @@ def test_many_commits_256_by_1024_the_das_shape(mz):
 
 
 def test_many_commits_more_polynomials_than_one_pass_holds(mz):
-    """the pass handles at most 2^21 buckets / 2^22 coefficients (bucket form) or 2^14 polynomials (direct form) at a time and
+    """the pass handles at most 2^21 buckets / 2^22 coefficients (bucket form) or 2^12 polynomials (direct form) at a time and
     loops beyond that: 258 polynomials of 2^14 coefficients (two passes of the bucket form), 16500 polynomials of 8 coefficients
-    over direct tables (two passes), and openings across the same boundary"""
+    over direct tables (five passes of 2^12) and over the bucket form (two), and openings across the same boundary"""
     import torch
     L = mz.lib()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -299,14 +299,14 @@ def test_many_commits_more_polynomials_than_one_pass_holds(mz):
         assert torch.equal(w1, d_w[8 * k:8 * k + 8]) and torch.equal(y1, d_y[4 * k:4 * k + 4]), k
     L.mzk_srs_free(h)
     del d_c, d_many, d_one
-    # direct form: 16384 + 116 polynomials of 8 coefficients
+    # direct form: 4 x 4096 + 116 polynomials of 8 coefficients
     n, count = 8, 16500
     p = orc.synth_points(41, n)
     h = _srs_ex(mz, p, 1)
     assert L.mzk_srs_build_direct(h, 10, ctypes.c_size_t(0), st) == 0, L.mzk_last_error()
     coefs = orc.synth_vector(FR, 42, n * count).reshape(count, n, 4)
     got = _commit_many(mz, h, coefs)
-    for k in list(range(0, count, 997)) + [16383, 16384, 16385, count - 1]:
+    for k in list(range(0, count, 997)) + [4095, 4096, 4097, 16383, 16384, 16385, count - 1]:
         assert got[k] == orc.msm_ref(coefs[k], p), k
     L.mzk_srs_drop_direct(h)
     assert _commit_many(mz, h, coefs) == got            # the bucket form agrees on all 16500
