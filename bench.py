@@ -120,11 +120,9 @@ def launch_ranks(n_gpus, argv):
     import socket, subprocess
     shared = os.environ.get("MZK_BENCH_SHARED_GPU_TEST") == "1"
     visible = visible_gpus_without_hip()
-    if visible is None:                # no KFD topology (no driver, or a container without /sys/class/kfd): nothing to launch on
-        if not shared:
-            return fail_line(n_gpus, "--gpus %d asked for but no GPU topology is readable (/sys/class/kfd/kfd/topology/nodes)" % n_gpus, visible_devices=0)
-        visible = 0
-    if visible < n_gpus and not shared:
+    # None = the KFD topology is not readable here (a container without /sys/class/kfd): do not guess -- start the ranks, whose own
+    # check (torch's device count inside the rank processes) refuses with a JSON line if there are fewer GPUs than ranks
+    if visible is not None and visible < n_gpus and not shared:
         return fail_line(n_gpus, "--gpus %d asked for but only %d GPU(s) visible; refusing to run fewer ranks than asked" % (n_gpus, visible),
                          visible_devices=visible)
     with socket.socket() as sk:
