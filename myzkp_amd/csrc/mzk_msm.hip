@@ -830,7 +830,10 @@ static int launch_exclusive_scan(const u32* in, u32* out, size_t n, u32* scratch
 //
 // PREFETCH = true keeps the next entry's point in 16 extra registers (139 VGPRs -> 3 waves per SIMD); false loads the
 // point where it is used (123 VGPRs -> 4 waves per SIMD) and leaves the latency to the other three waves.
-template <bool PREFETCH>
+// SENT (the one-kernel sort of the grid-batched commitments): a polynomial's entry region has a fixed capacity and its unused tail
+// is filled with MANY_SENTINEL entries, which are skipped without touching the table.
+constexpr u32 MANY_SENTINEL = 0xffffffffu;
+template <bool PREFETCH, bool SENT = false>
 __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ points_mont, const u32* __restrict__ offsets,
                                                          const u32* __restrict__ entries, u32* __restrict__ slots, size_t nbuckets,
                                                          u32 seg) {
@@ -865,7 +868,7 @@ __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ 
 #pragma unroll
       for (int k = 0; k < 16; k++) w[k] = wn[k];
     } else {
-      const size_t idx = ent & 0x7fffffffu;
+      const size_t idx = (SENT && ent == MANY_SENTINEL) ? 0 : (ent & 0x7fffffffu);
       load_words8(points_mont + idx * 16, w);
       load_words8(points_mont + idx * 16 + 8, w + 8);
     }
@@ -883,6 +886,7 @@ __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ 
       do { b++; bend = offsets[b + 1]; } while (e >= bend);
     }
     if (affine_words_is_inf(w)) continue;  // infinity contributes nothing (curve.rs:107-109)
+    if (SENT && ent == MANY_SENTINEL) continue;
     acc = xyzz_madd_signed_with<FeAsm>(acc, affine_load_mont(w), (ent >> 31) != 0);
   }
   xyzz_gstore_raw(slots, t + b, acc);
@@ -1640,6 +1644,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
 //   k_many_count     workgroup (j, chunk of 1024 coefficients): digits -> LDS histogram -> cnt[j][b][chunk]
 //   exclusive scan   over [j][b][chunk]: bucket (j, b) is the concatenation of its chunks' runs
 //   k_many_scatter   the same walk again, LDS cursors, entries to their final place
+//   (polynomials of <= 1024 coefficients: the three as ONE launch, k_many_sort1, with fixed-capacity entry regions)
 //   k_seg_accumulate / k_seg_combine[_heavy]   one lane per fixed-size segment of the sorted entries (mixed additions)
 //   k_halve_step*    the wide halving steps, grid.y = polynomial
 //   k_reduce_tail_row  one workgroup PER POLYNOMIAL: late steps, weighted sum, affine conversion (wave inversion)
@@ -1705,6 +1710,68 @@ __global__ __launch_bounds__(MANY_THREADS) void k_many_scatter(const u32* __rest
   }
 }
 
+// Polynomials of at most MANY_CHUNK coefficients: count, scan and scatter in ONE launch.  Workgroup j owns polynomial j and the entry
+// region [j CAP, (j + 1) CAP), CAP = n NWIN: LDS histogram (first walk), exclusive scan inside the workgroup, bucket offsets
+// j CAP + prefix (no global scan: the regions have a fixed size), placement through LDS cursors (second walk), and the unused tail
+// of the region -- zero digits emit nothing -- filled with sentinels, which belong to the polynomial's last bucket and are skipped
+// by k_seg_accumulate<.., SENT>.  One coefficient per lane (1024 lanes: at 256 polynomials the kernel is one workgroup per CU, i.e.
+// latency): 42 us at 256 x 2^10 against 17 + 10 + 35 us and three more launch gaps for the count / scan / scatter form (50 us with
+// 256 lanes of four coefficients each).  Longer polynomials keep the three-launch form: their buckets span several chunks.
+constexpr int SORT1_THREADS = 1024;
+constexpr int SORT1_PER_LANE = MANY_CHUNK / SORT1_THREADS;
+template <int C>
+__global__ __launch_bounds__(SORT1_THREADS) void k_many_sort1(const u32* __restrict__ scalars, size_t n, size_t stride_words, size_t table_stride, u32 cap,
+                                                              u32* __restrict__ offsets, size_t npoly, u32* __restrict__ entries) {
+  constexpr int NB = 1 << (C - 1);
+  constexpr int PER = (NB + SORT1_THREADS - 1) / SORT1_THREADS;      // counters per lane in the scan
+  __shared__ u32 hist[NB];
+  __shared__ u32 scan[SORT1_THREADS];
+  const size_t j = blockIdx.x;
+  const int tid = threadIdx.x;
+  for (int b = tid; b < NB; b += SORT1_THREADS) hist[b] = 0;
+  __syncthreads();
+  const u32* sc = scalars + j * stride_words;
+  u32 w[SORT1_PER_LANE][8];
+#pragma unroll
+  for (int k = 0; k < SORT1_PER_LANE; k++) {
+    const size_t i = tid + (size_t)k * SORT1_THREADS;
+    if (i < n) load_scalar_canonical(sc, i, w[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < SORT1_PER_LANE; k++) {
+    const size_t i = tid + (size_t)k * SORT1_THREADS;
+    if (i < n) walk_digits_merged<C>(w[k], 0, i, [&](int, u32 key, u32) { counter_inc_agg(hist, key); });
+  }
+  __syncthreads();
+  u32 local = 0;
+#pragma unroll
+  for (int q = 0; q < PER; q++) { const int b = tid * PER + q; if (b < NB) local += hist[b]; }
+  scan[tid] = local;
+  __syncthreads();
+  for (int off = 1; off < SORT1_THREADS; off <<= 1) {
+    const u32 t = (tid >= off) ? scan[tid - off] : 0u;
+    __syncthreads();
+    scan[tid] += t;
+    __syncthreads();
+  }
+  const u32 base = (u32)(j * cap);
+  const u32 total = scan[SORT1_THREADS - 1];
+  u32 run = scan[tid] - local;
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const int b = tid * PER + q;
+    if (b < NB) { const u32 c = hist[b]; hist[b] = run; offsets[j * NB + b] = base + run; run += c; }       // hist becomes the cursor
+  }
+  if (j + 1 == npoly && tid == 0) offsets[npoly * NB] = (u32)(npoly * cap);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < SORT1_PER_LANE; k++) {
+    const size_t i = tid + (size_t)k * SORT1_THREADS;
+    if (i < n) walk_digits_merged<C>(w[k], table_stride, i, [&](int, u32 key, u32 payload) { entries[base + counter_inc_agg(hist, key)] = payload; });
+  }
+  for (u32 e = total + tid; e < cap; e += SORT1_THREADS) entries[base + e] = MANY_SENTINEL;
+}
+
 bool msm_many_supported(int window_bits) { return window_bits == 8 || (window_bits >= 10 && window_bits <= 13); }
 
 // `count` MSMs of n scalars each (polynomial j at d_scalars + j * stride_elems * 32 bytes) against the window tables of one SRS
@@ -1752,7 +1819,12 @@ int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size
     prof_begin(s, MZK_PH_MSM_SORT);
     MZK_HIP(hipMemsetAsync(heavy, 0, 8, s));
     const unsigned nwg = (unsigned)(cnt * (size_t)nch);
+    const bool one_kernel_sort = nch == 1;      // polynomials of <= 1024 coefficients: fixed-capacity regions, k_many_sort1
 #define MZK_MANY_CASE(C) case C:                                                                                                                    \
+      if (one_kernel_sort) {                                                                                                                         \
+        hipLaunchKernelGGL((k_many_sort1<C>), dim3(nwg), dim3(SORT1_THREADS), 0, s, sc, n, stride_elems * 8, table_stride, (u32)(n * (size_t)nwin), offs, cnt, entries); \
+        break;                                                                                                                                       \
+      }                                                                                                                                              \
       hipLaunchKernelGGL((k_many_count<C>), dim3(nwg), dim3(MANY_THREADS), 0, s, sc, n, stride_elems * 8, nch, offs);                                \
       MZK_TRY(launch_exclusive_scan((const u32*)offs, offs, ncnt, scan_tmp, s));                                                                     \
       hipLaunchKernelGGL((k_many_scatter<C>), dim3(nwg), dim3(MANY_THREADS), 0, s, sc, n, stride_elems * 8, nch, table_stride, (const u32*)offs,     \
@@ -1763,8 +1835,12 @@ int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size
     MZK_HIP(hipGetLastError());
     prof_end(s, MZK_PH_MSM_SORT);
     prof_begin(s, MZK_PH_MSM_ACCUMULATE);
-    hipLaunchKernelGGL(k_seg_accumulate<false>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, (const u32*)d_tables, (const u32*)compact, (const u32*)entries,
-                       slots, NBtot, seg);
+    if (one_kernel_sort)
+      hipLaunchKernelGGL((k_seg_accumulate<false, true>), dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, (const u32*)d_tables, (const u32*)compact, (const u32*)entries,
+                         slots, NBtot, seg);
+    else
+      hipLaunchKernelGGL(k_seg_accumulate<false>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, (const u32*)d_tables, (const u32*)compact, (const u32*)entries,
+                         slots, NBtot, seg);
     prof_end(s, MZK_PH_MSM_ACCUMULATE);
     prof_begin(s, MZK_PH_MSM_SEG_COMBINE);
     hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NBtot + 127) / 128)), dim3(128), 0, s, slots, (const u32*)compact, buckets, NBtot, seg, heavy);
