@@ -50,7 +50,7 @@ struct WsBuf { void* p = nullptr; size_t cap = 0; };
 enum WsSlot { WS_NTT_TMP = 0, WS_NTT_IO_A, WS_NTT_IO_B, WS_MSM_POINTS, WS_MSM_SCALARS, WS_MSM_COUNTS, WS_MSM_OFFSETS,
               WS_MSM_CURSOR, WS_MSM_ENTRIES, WS_MSM_BUCKETS, WS_MSM_RED_A, WS_MSM_RED_B, WS_MSM_SCAN, WS_MSM_OUT, WS_MSM_SLOTS, WS_MSM_WGHIST, WS_BATCHINV, WS_XYZZ_TMP, WS_MERKLE_NODES, WS_FB_TABLE16, WS_FB_TABLE8, WS_NTT_PRE, WS_NTT_PRE_M128,
               WS_MISC_A, WS_MISC_B, WS_MISC_C, WS_MISC_D, WS_MISC_E, WS_MISC_F, WS_COUNT };
-enum AttrFlag { ATTR_FINE_SCATTER4 = 0, ATTR_FINE_SCATTER8, ATTR_DIGITS_LDS, ATTR_SMALL_MSM, ATTR_NTT_LARGE_FR, ATTR_NTT_LARGE_M128, ATTR_NTT_LARGE_M128_2WG, ATTR_TAIL_ROW, ATTR_COARSE_STAGED4, ATTR_COARSE_STAGED8, ATTR_COUNT };
+enum AttrFlag { ATTR_FINE_SCATTER4 = 0, ATTR_FINE_SCATTER8, ATTR_DIGITS_LDS, ATTR_SMALL_MSM, ATTR_NTT_LARGE_FR, ATTR_NTT_LARGE_M128, ATTR_NTT_LARGE_M128_2WG, ATTR_MANY_SORT1, ATTR_TAIL_ROW, ATTR_COARSE_STAGED4, ATTR_COARSE_STAGED8, ATTR_COUNT };
 struct Context {
   bool ready = false;
   int index = 0;                 // position in the context table (keys the per-context caches of the other translation units)

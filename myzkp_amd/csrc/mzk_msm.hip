@@ -1715,8 +1715,9 @@ __global__ __launch_bounds__(MANY_THREADS) void k_many_scatter(const u32* __rest
 // j CAP + prefix (no global scan: the regions have a fixed size), placement through LDS cursors (second walk), and the unused tail
 // of the region -- zero digits emit nothing -- filled with sentinels, which belong to the polynomial's last bucket and are skipped
 // by k_seg_accumulate<.., SENT>.  One coefficient per lane (1024 lanes: at 256 polynomials the kernel is one workgroup per CU, i.e.
-// latency): 42 us at 256 x 2^10 against 17 + 10 + 35 us and three more launch gaps for the count / scan / scatter form (50 us with
-// 256 lanes of four coefficients each).  Longer polynomials keep the three-launch form: their buckets span several chunks.
+// latency) and the sorted region staged in LDS (<= 128 KiB) and copied out as one stream: **19 us** at 256 x 2^10 against 17 + 10 +
+// 35 us and three more launch gaps for the count / scan / scatter form (placed directly into global memory it was 42 us: 32
+// isolated four-byte stores per lane).  Longer polynomials keep the three-launch form: their buckets span several chunks.
 constexpr int SORT1_THREADS = 1024;
 constexpr int SORT1_PER_LANE = MANY_CHUNK / SORT1_THREADS;
 template <int C>
@@ -1726,6 +1727,7 @@ __global__ __launch_bounds__(SORT1_THREADS) void k_many_sort1(const u32* __restr
   constexpr int PER = (NB + SORT1_THREADS - 1) / SORT1_THREADS;      // counters per lane in the scan
   __shared__ u32 hist[NB];
   __shared__ u32 scan[SORT1_THREADS];
+  extern __shared__ u32 stage[];                                   // [cap] the polynomial's entries, bucket-sorted
   const size_t j = blockIdx.x;
   const int tid = threadIdx.x;
   for (int b = tid; b < NB; b += SORT1_THREADS) hist[b] = 0;
@@ -1767,9 +1769,12 @@ __global__ __launch_bounds__(SORT1_THREADS) void k_many_sort1(const u32* __restr
 #pragma unroll
   for (int k = 0; k < SORT1_PER_LANE; k++) {
     const size_t i = tid + (size_t)k * SORT1_THREADS;
-    if (i < n) walk_digits_merged<C>(w[k], table_stride, i, [&](int, u32 key, u32 payload) { entries[base + counter_inc_agg(hist, key)] = payload; });
+    if (i < n) walk_digits_merged<C>(w[k], table_stride, i, [&](int, u32 key, u32 payload) { stage[counter_inc_agg(hist, key)] = payload; });
   }
-  for (u32 e = total + tid; e < cap; e += SORT1_THREADS) entries[base + e] = MANY_SENTINEL;
+  __syncthreads();
+  // the sorted region leaves LDS as one contiguous stream (placed directly, every lane's 32 four-byte stores went to 32 different
+  // lines: 42 us for the kernel; staged: the copy-out is 128 KiB of consecutive words), sentinels behind it
+  for (u32 e = tid; e < cap; e += SORT1_THREADS) entries[base + e] = (e < total) ? stage[e] : MANY_SENTINEL;
 }
 
 bool msm_many_supported(int window_bits) { return window_bits == 8 || (window_bits >= 10 && window_bits <= 13); }
@@ -1820,9 +1825,21 @@ int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size
     MZK_HIP(hipMemsetAsync(heavy, 0, 8, s));
     const unsigned nwg = (unsigned)(cnt * (size_t)nch);
     const bool one_kernel_sort = nch == 1;      // polynomials of <= 1024 coefficients: fixed-capacity regions, k_many_sort1
+    if (one_kernel_sort) {                      // its staged region is up to 128 KiB of LDS: the attribute, once per context
+      bool& done = ctx().attr_done[ATTR_MANY_SORT1];
+      if (!done) {
+        MZK_HIP(hipFuncSetAttribute((const void*)k_many_sort1<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+        MZK_HIP(hipFuncSetAttribute((const void*)k_many_sort1<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+        MZK_HIP(hipFuncSetAttribute((const void*)k_many_sort1<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+        MZK_HIP(hipFuncSetAttribute((const void*)k_many_sort1<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+        MZK_HIP(hipFuncSetAttribute((const void*)k_many_sort1<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+        done = true;
+      }
+    }
 #define MZK_MANY_CASE(C) case C:                                                                                                                    \
       if (one_kernel_sort) {                                                                                                                         \
-        hipLaunchKernelGGL((k_many_sort1<C>), dim3(nwg), dim3(SORT1_THREADS), 0, s, sc, n, stride_elems * 8, table_stride, (u32)(n * (size_t)nwin), offs, cnt, entries); \
+        hipLaunchKernelGGL((k_many_sort1<C>), dim3(nwg), dim3(SORT1_THREADS), n * (size_t)nwin * 4, s, sc, n, stride_elems * 8, table_stride,       \
+                           (u32)(n * (size_t)nwin), offs, cnt, entries);                                                                             \
         break;                                                                                                                                       \
       }                                                                                                                                              \
       hipLaunchKernelGGL((k_many_count<C>), dim3(nwg), dim3(MANY_THREADS), 0, s, sc, n, stride_elems * 8, nch, offs);                                \
