@@ -76,10 +76,160 @@ template <class P> MZK_HD Fe<P> fe_r2() {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Sparse modulus p = PT * 2^(29 (L-1)) + 1 (M128 = 1 + 407 * 2^119 = 3256 * 2^116 + 1, fri.rs:408): the Montgomery reduction
+// needs no multiplication by -p^-1 and one multiply-add per limb.  With beta = 2^29 and T = a b = T_lo + beta^(L-1) T_hi
+// (T_lo = the L-1 carried low limbs t_k), adding (beta^(L-1) - T_lo) p clears the low limbs:
+//     T beta^-(L-1)  ==  U = T_hi + PT * sum_k (MASK - t_k) beta^k + (PT + 1)           (mod p),
+// and one more limb the same way, U = u0 + beta U_hi, m = (1 + C) beta - u0:
+//     T beta^-L      ==  V = U_hi + (1 + C) + PT * m * beta^(L-2)  =  (T + (..) p) / R   [+ C p].
+// 25 + 5 multiply-adds for L = 5 and no v_mul_lo, against 25 + 10 + 5; the complements MASK - t_k are one v_bfi each.
+// Result: limbs 0 .. L-2 in [0, 2^29), top limb whatever is left; value in [T / R + C p, T / R + (1 + C) p + p / 2^29 + 3).
+// SIGNED: the limbs of `a` are two's-complement i32 (|a_i| < 2^31; the lazily accumulated butterflies of the NTT), columns are
+// signed 64-bit sums (v_mad_i64_i32, arithmetic shifts: floor semantics throughout), the top limb of the result is signed;
+// `b` always has non-negative limbs below 2^29.  A non-negative `a` gives a non-negative result.
+// ---------------------------------------------------------------------------------------------
+template <class P> struct SparseMod {
+  static constexpr bool value = (P::L == 5) && P::P[0] == 1 && P::P[1] == 0 && P::P[2] == 0 && P::P[3] == 0;
+};
+template <bool S> struct AccOf { typedef u64 acc; typedef u32 limb; };
+template <> struct AccOf<true> { typedef int64_t acc; typedef i32 limb; };
+template <class P, bool SIGNED, int C> MZK_HD Fe<P> fe_mul_sparse(const Fe<P>& a, const Fe<P>& b) {
+  constexpr int L = P::L;
+  static_assert(SparseMod<P>::value, "p = PT 2^(29 (L-1)) + 1");
+  typedef typename AccOf<SIGNED>::acc A;
+  typedef typename AccOf<SIGNED>::limb LL;
+  constexpr u32 PT = P::P[L - 1];
+  u32 n[L - 1];
+  Fe<P> r;
+  A acc = 0;
+#if defined(MZK_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+  {
+    __int128 ma = 0;
+    for (int i = 0; i < L; i++) {
+      const __int128 v = SIGNED ? (__int128)(i32)a.l[i] : (__int128)a.l[i];
+      if ((v < 0 ? -v : v) > ma) ma = v < 0 ? -v : v;
+      assert(b.l[i] <= MASK29 || i == L - 1);
+    }
+    const __int128 worst = ma * MASK29 * L + (__int128)PT * ((__int128)2 << 30) + ((__int128)1 << 36);
+    assert(worst < ((__int128)1 << (SIGNED ? 63 : 64)));
+  }
+#endif
+#pragma unroll
+  for (int k = 0; k < L - 1; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) acc += (A)(LL)a.l[i] * (A)(LL)b.l[k - i];
+    n[k] = ~(u32)acc & MASK29;
+    acc >>= W29;
+  }
+#pragma unroll
+  for (int k = L - 1; k < 2 * L - 1; k++) {
+#pragma unroll
+    for (int i = k - L + 1; i < L; i++) acc += (A)(LL)a.l[i] * (A)(LL)b.l[k - i];
+    if (k < 2 * L - 2) acc += (A)((u64)PT * n[k - L + 1]);
+    if (k == L - 1) {        // U's lowest limb: the constants of both steps enter here, then the second step's multiplier
+      acc += (A)(u64)(PT + 1 + ((u32)(1 + C) << W29));
+      n[0] = ((u32)(1 + C) << W29) - ((u32)acc & MASK29);
+    } else {
+      if (k == 2 * L - 2) acc += (A)((u64)PT * n[0]);
+      r.l[k - L] = (u32)acc & MASK29;
+    }
+    acc >>= W29;
+  }
+  MZK_ASSERT(SIGNED ? ((int64_t)acc >= -((int64_t)1 << 31) && (int64_t)acc < ((int64_t)1 << 31)) : ((u64)acc < ((u64)1 << 32)));
+  r.l[L - 1] = (u32)acc;
+  return r;
+}
+
+// ---- signed lazy limbs (the NTT butterflies of a sparse-modulus field, mzk_ntt.hip) -------------------------------------------
+// A value is sum l_i beta^i with l_i read as i32: sums and differences are ONE instruction per limb (no K p, no carry);
+// fe_scarry brings limbs 0 .. L-2 back into [0, 2^29) (the top limb stays signed), the signed product does the same as a side effect.
+template <class P> MZK_HD Fe<P> fe_sadd(const Fe<P>& a, const Fe<P>& b) {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) {
+    MZK_ASSERT((int64_t)(i32)a.l[i] + (i32)b.l[i] < ((int64_t)1 << 31) && (int64_t)(i32)a.l[i] + (i32)b.l[i] >= -((int64_t)1 << 31));
+    r.l[i] = a.l[i] + b.l[i];
+  }
+  return r;
+}
+template <class P> MZK_HD Fe<P> fe_ssub(const Fe<P>& a, const Fe<P>& b) {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) {
+    MZK_ASSERT((int64_t)(i32)a.l[i] - (i32)b.l[i] < ((int64_t)1 << 31) && (int64_t)(i32)a.l[i] - (i32)b.l[i] >= -((int64_t)1 << 31));
+    r.l[i] = a.l[i] - b.l[i];
+  }
+  return r;
+}
+template <class P> MZK_HD Fe<P> fe_scarry(const Fe<P>& a) {
+  Fe<P> r;
+  i32 c = 0;
+#pragma unroll
+  for (int i = 0; i < P::L - 1; i++) {
+    MZK_ASSERT((int64_t)(i32)a.l[i] + c < ((int64_t)1 << 31) && (int64_t)(i32)a.l[i] + c >= -((int64_t)1 << 31));
+    const i32 v = (i32)a.l[i] + c;
+    r.l[i] = (u32)v & MASK29;
+    c = v >> W29;        // arithmetic
+  }
+  MZK_ASSERT((int64_t)(i32)a.l[P::L - 1] + c < ((int64_t)1 << 31) && (int64_t)(i32)a.l[P::L - 1] + c >= -((int64_t)1 << 31));
+  r.l[P::L - 1] = a.l[P::L - 1] + (u32)c;
+  return r;
+}
+// Signed lazy -> the same residue as a NON-NEGATIVE lazy value: + SBIAS p limb-wise (three additions).  |value| < SBIAS p.
+template <class P> struct SLazy {
+  static constexpr u32 BIAS = 1u << 12;       // covers 2^10 levels of doubling on 128-bit inputs: |x| < 2^138 < 2^12 p
+};
+template <class P> MZK_HD Fe<P> fe_sbias(const Fe<P>& a) {
+  static_assert(SparseMod<P>::value, "p = PT 2^(29 (L-1)) + 1");
+  Fe<P> x = a;
+  // limb 0's share of the bias goes in as BIAS - 2^29 with the 2^29 carried into limb 1 by hand: limbs of 3 (2^29 - 1) stay inside
+  // i32 through the carry pass that follows in fe_sreduce
+  MZK_ASSERT((int64_t)(i32)a.l[0] + SLazy<P>::BIAS - ((int64_t)1 << W29) >= -((int64_t)1 << 31) && (int64_t)(i32)a.l[1] + 1 < ((int64_t)1 << 31));
+  x.l[0] += SLazy<P>::BIAS - (1u << W29);
+  x.l[1] += 1u;
+  x.l[P::L - 1] += P::P[P::L - 1] * SLazy<P>::BIAS;
+  return x;
+}
+// Canonical representative in [0, p) of a signed lazy value, |value| < SBIAS p, limbs within +-3 (2^29 - 1) (what the NTT's stage pairs leave).  After the bias and one carry
+// pass the top limb holds floor(x / 2^116) < 2^26; with x = x_lo + 2^116 (PT q + r) and 2^116 PT == -1 the residue is
+// x_lo + 2^116 r - q: canonical as it stands whenever limb 0 >= q (q < 2^14: all but ~2^-15 of the inputs); the rest borrows.
+template <class P> MZK_HD Fe<P> fe_sreduce(const Fe<P>& a) {
+  static_assert(SparseMod<P>::value, "p = PT 2^(29 (L-1)) + 1");
+  constexpr int L = P::L;
+  constexpr u32 PT = P::P[L - 1];
+  constexpr u64 QM = (((u64)1 << 43) + PT - 1) / PT;      // floor(t / PT) = (t QM) >> 43 exactly for t < 2^26 (t (QM PT - 2^43) < 2^43)
+  static_assert(QM < ((u64)1 << 32) && PT < (1u << 12), "quotient constant");
+  Fe<P> x = fe_scarry<P>(fe_sbias<P>(a));
+  MZK_ASSERT((i32)x.l[L - 1] >= 0 && x.l[L - 1] < (1u << 26));
+  const u32 q = (u32)(((u64)x.l[L - 1] * QM) >> 43);
+  const u32 r = x.l[L - 1] - q * PT;
+  MZK_ASSERT(r < PT);
+  if (x.l[0] >= q) {
+    x.l[0] -= q;
+    x.l[L - 1] = r;
+    return x;
+  }
+  x.l[0] -= q;
+  x.l[L - 1] = r;
+  x = fe_scarry<P>(x);
+  if ((i32)x.l[L - 1] < 0) {
+    x.l[0] += 1;
+    x.l[L - 1] += PT;
+    x = fe_scarry<P>(x);
+  }
+  return x;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Montgomery product  a*b/R mod p  (finely integrated product scanning, one 64-bit column
 // accumulator).  Reference semantics: Ring::mul_ref, field.rs:176-179 (value * value % modulus).
 // ---------------------------------------------------------------------------------------------
+template <class P> MZK_HD Fe<P> fe_mul_dense(const Fe<P>& a, const Fe<P>& b);
 template <class P> MZK_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+  if constexpr (SparseMod<P>::value) return fe_mul_sparse<P, false, 0>(a, b);
+  else return fe_mul_dense<P>(a, b);
+}
+template <class P> MZK_HD Fe<P> fe_mul_dense(const Fe<P>& a, const Fe<P>& b) {
   constexpr int L = P::L;
   u32 m[L];
   Fe<P> r;

@@ -136,6 +136,25 @@ template <class P> __device__ __forceinline__ Fe<P> fe_fit(const Fe<P>& v) {
   else return v;
 }
 
+// What a pass stores: x * (inter-pass twiddle) as something fe_pack can hold.  Signed lazy x: made non-negative first (three
+// additions), so that the signed product returns a value in [0, 1.05 p + 3) -- below 2^128 as it stands.
+template <class P> __device__ __forceinline__ Fe<P> inter_mul(const Fe<P>& x, const Fe<P>& tw) {
+  if constexpr (SparseMod<P>::value) return FeAsm<P>::smul(fe_sbias<P>(x), tw);
+  else return fe_fit<P>(FeAsm<P>::mul(x, tw));
+}
+// the last pass's output: optional scale, canonical representative
+template <class P> __device__ __forceinline__ Fe<P> final_reduce(const Fe<P>& x, const Fe<P>& sc, int has_scale) {
+  if constexpr (SparseMod<P>::value) {
+    Fe<P> v = x;
+    if (has_scale) v = FeAsm<P>::smul(v, sc);
+    return fe_sreduce<P>(v);
+  } else {
+    Fe<P> v = x;
+    if (has_scale) v = FeAsm<P>::mul(v, sc);
+    return fe_reduce<P>(v);
+  }
+}
+
 template <class P, class G> __device__ __forceinline__ Fe<P> lds_load(const u32* lds, int pos) {
   Fe<P> r;
   const int ph = G::phys(pos);
@@ -145,6 +164,19 @@ template <class P, class G> __device__ __forceinline__ Fe<P> lds_load(const u32*
 }
 template <class P, class G> __device__ __forceinline__ void lds_store(u32* lds, int pos, const Fe<P>& v) {
   const int ph = G::phys(pos);
+#pragma unroll
+  for (int i = 0; i < P::L; i++) lds[i * G::TILE + ph] = v.l[i];
+}
+// The same by PHYSICAL index.  Geo::phys is GF(2)-linear (shifts and XORs of the position's bits), so the four positions of a
+// radix-4 group, p0 + d with d in {0, d1, d2, d1 + d2} and p0 zero at the bits of d1 and d2, are phys(p0) ^ phys(d): one swizzle per
+// group and three XORs with wave-uniform constants instead of four swizzles (7 instructions each).
+template <class P, class G> __device__ __forceinline__ Fe<P> lds_load_ph(const u32* lds, int ph) {
+  Fe<P> r;
+#pragma unroll
+  for (int i = 0; i < P::L; i++) r.l[i] = lds[i * G::TILE + ph];
+  return r;
+}
+template <class P, class G> __device__ __forceinline__ void lds_store_ph(u32* lds, int ph, const Fe<P>& v) {
 #pragma unroll
   for (int i = 0; i < P::L; i++) lds[i * G::TILE + ph] = v.l[i];
 }
@@ -173,23 +205,44 @@ __device__ __forceinline__ void stage_twiddles(u32* twl, const u32* __restrict__
 // are only added, subtracted or multiplied again before the second stage normalises them (limbs < 2^29 + 2^30 there: the
 // product takes one operand with limbs up to 3 * 2^30, fe_mul's column bound, and the carrying add/sub any u32 that
 // does not overflow with 8p added).  Same values either way.
+// SIGNED LAZY butterflies (sparse-modulus fields: M128).  Values are sums of i32 limbs (mzk_field.h, fe_sadd / fe_ssub): a butterfly
+// is the product plus ONE instruction per limb and output -- no K p, no carry chain (10 instructions where the carrying pair took
+// 31 and the limb-wise one 15).  What keeps the limbs inside i32: the signed product returns limbs in [0, 2^29), and an operand that
+// is NOT multiplied on entry to a stage pair is carried once (fe_scarry: 12 instructions) -- x0 and x2 of a radix-4 group, all four
+// when the group's twiddles are 1.  With B = 2^29 - 1: inputs of a pair <= B  =>  after the first stage |.| <= 2 B, after the second
+// <= 3 B (4 B for the all-ones group of a raw first pair: x0 + x1 + x2 + x3), stored to LDS as they are; values only double per level (no reduction
+// mod p on the way), so after the <= 10 levels of a pass |x| < 2^138, which the products and the final reductions take
+// (fe_sbias / fe_sreduce: < 2^12 p).  tests/hostcheck restates the schedule with every bound as an assertion.
+template <class P> struct SignedLazy { static constexpr bool value = SparseMod<P>::value; };
+template <class P, class G>
+__device__ __forceinline__ Fe<P> tw_fetch(const u32* twl, int tws, int ti) {
+  Fe<P> w;
+  if constexpr (G::TWG) {
+    w = gload<P>(twl, (size_t)ti);         // twl = the plan's table in global memory (16 bytes per M128 twiddle; L1 / scalar cache)
+  } else if constexpr (G::template twpack<P>()) {
+    u32 ww[P::NW];
+#pragma unroll
+    for (int i = 0; i < P::NW; i++) ww[i] = twl[i * tws + ti];
+    w = fe_unpack<P>(ww);
+  } else {
+#pragma unroll
+    for (int i = 0; i < P::L; i++) w.l[i] = twl[i * tws + ti];
+  }
+  return w;
+}
+template <class P, class G>
+__device__ __forceinline__ void sbfly(Fe<P>& lo, Fe<P>& hi, const u32* twl, int tws, int ti, bool trivial) {
+  Fe<P> t = hi;
+  if (!trivial) t = FeAsm<P>::smul(t, tw_fetch<P, G>(twl, tws, ti));
+  hi = fe_ssub<P>(lo, t);
+  lo = fe_sadd<P>(lo, t);
+}
 template <class P, class G, bool LAZY = false>
 __device__ __forceinline__ void bfly(Fe<P>& lo, Fe<P>& hi, const u32* twl, int tws, int ti, bool trivial, bool raw) {
+  if constexpr (SignedLazy<P>::value) { sbfly<P, G>(lo, hi, twl, tws, ti, trivial); return; }
   Fe<P> t = hi;
   if (!trivial) {
-    Fe<P> w;
-    if constexpr (G::TWG) {
-      w = gload<P>(twl, (size_t)ti);         // twl = the plan's table in global memory (16 bytes per M128 twiddle; L1 / scalar cache)
-    } else if constexpr (G::template twpack<P>()) {
-      u32 ww[P::NW];
-#pragma unroll
-      for (int i = 0; i < P::NW; i++) ww[i] = twl[i * tws + ti];
-      w = fe_unpack<P>(ww);
-    } else {
-#pragma unroll
-      for (int i = 0; i < P::L; i++) w.l[i] = twl[i * tws + ti];
-    }
-    t = FeAsm<P>::mul(t, w);
+    t = FeAsm<P>::mul(t, tw_fetch<P, G>(twl, tws, ti));
   } else if (!raw) {
     t = fe_weak_reduce<P>(t);
   }
@@ -215,8 +268,20 @@ __device__ __forceinline__ void radix4_regs(Fe<P>& x0, Fe<P>& x1, Fe<P>& x2, Fe<
   const bool triv = (j1 == 0);
   const bool raw = (s == 1);
   const int t1 = j1 << (lgn - s);
+  if constexpr (SignedLazy<P>::value) {
+    if (!raw) {          // raw inputs (stage 1) are unpacked words: carried already
+      x0 = fe_scarry<P>(x0);
+      x2 = fe_scarry<P>(x2);
+      if (triv) { x1 = fe_scarry<P>(x1); x3 = fe_scarry<P>(x3); }
+    }
+  }
   bfly<P, G, NTT_LAZY_FIRST>(x0, x1, twl, tws, t1, triv, raw);
   bfly<P, G, NTT_LAZY_FIRST>(x2, x3, twl, tws, t1, triv, raw);
+  if constexpr (SignedLazy<P>::value) {
+    // the all-ones group would end at x0 + x1 + x2 + x3 = 4 B; only raw first pairs may (their readers carry or multiply first):
+    // everywhere else x2 + x3 is carried here, so that what reaches the final reductions stays at 3 B (1 group in 2^(s-1))
+    if (triv && (!raw || lgn == 2)) x2 = fe_scarry<P>(x2);
+  }
   bfly<P, G>(x0, x2, twl, tws, j1 << (lgn - s - 1), triv, false);
   bfly<P, G>(x1, x3, twl, tws, (j1 + (1 << lgh)) << (lgn - s - 1), false, false);
 }
@@ -280,9 +345,15 @@ __device__ __forceinline__ void first_pair_regs(Fe<P>& x0, Fe<P>& x1, Fe<P>& x2,
   bfly<P, G, NTT_LAZY_FIRST>(x0, x1, nullptr, 0, 0, true, true);
   bfly<P, G, NTT_LAZY_FIRST>(x2, x3, nullptr, 0, 0, true, true);
   bfly<P, G>(x0, x2, nullptr, 0, 0, true, false);
-  const Fe<P> t = FeAsm<P>::mul(x3, zeta);
-  x3 = fe_sub_carry<P, 8>(x1, t);
-  x1 = fe_add_carry<P>(x1, t);
+  if constexpr (SignedLazy<P>::value) {
+    const Fe<P> t = FeAsm<P>::smul(x3, zeta);
+    x3 = fe_ssub<P>(x1, t);
+    x1 = fe_sadd<P>(x1, t);
+  } else {
+    const Fe<P> t = FeAsm<P>::mul(x3, zeta);
+    x3 = fe_sub_carry<P, 8>(x1, t);
+    x1 = fe_add_carry<P>(x1, t);
+  }
 }
 // fused first / last stage pairs need one radix-4 group per lane (a full tile) and at least one stage pair after the first stage(s)
 template <class G> __device__ __forceinline__ bool fuse_edges(int lgn, int lgc, int enable) { return enable && lgn >= 4 && (lgn + lgc) == G::TL; }
@@ -325,8 +396,9 @@ __device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, i
       const int k0 = (grp << (s + 1)) | j1;
       const int p0 = (k0 << lgc) | c;
       const int d1 = 1 << (lgh + lgc), d2 = d1 << 1;
-      Fe<P> x0 = lds_load<P, G>(lds, p0), x1 = lds_load<P, G>(lds, p0 + d1);
-      Fe<P> x2 = lds_load<P, G>(lds, p0 + d2), x3 = lds_load<P, G>(lds, p0 + d2 + d1);
+      const int ph0 = G::phys(p0), ph1 = ph0 ^ G::phys(d1), ph2 = ph0 ^ G::phys(d2), ph3 = ph1 ^ G::phys(d2);
+      Fe<P> x0 = lds_load_ph<P, G>(lds, ph0), x1 = lds_load_ph<P, G>(lds, ph1);
+      Fe<P> x2 = lds_load_ph<P, G>(lds, ph2), x3 = lds_load_ph<P, G>(lds, ph3);
       bool done = false;
       if constexpr (HasShoup<P>::value) {
         if (tw_shoup && lgrest >= 6) {       // one j1 per wave: scalar twiddles
@@ -338,10 +410,10 @@ __device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, i
         if (G::TWG && lgrest >= 6) radix4_regs<P, G>(x0, x1, x2, x3, twl, tws, lgn, s, __builtin_amdgcn_readfirstlane(j1));   // scalar loads
         else radix4_regs<P, G>(x0, x1, x2, x3, twl, tws, lgn, s, j1);
       }
-      lds_store<P, G>(lds, p0, x0);
-      lds_store<P, G>(lds, p0 + d1, x1);
-      lds_store<P, G>(lds, p0 + d2, x2);
-      lds_store<P, G>(lds, p0 + d2 + d1, x3);
+      lds_store_ph<P, G>(lds, ph0, x0);
+      lds_store_ph<P, G>(lds, ph1, x1);
+      lds_store_ph<P, G>(lds, ph2, x2);
+      lds_store_ph<P, G>(lds, ph3, x3);
     }
     __syncthreads();
   }
@@ -388,10 +460,11 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_strided(const u32* __rest
         const int r = (tid >> lgc) + q * (G::NT >> lgc), c = tid & cmask;
         const int k0 = (int)(__brev((unsigned)r) >> (32 - (lgn - 2))) << 2;
         const int p0 = (k0 << lgc) | c, d1 = 1 << lgc;
-        lds_store<P, G>(lds, p0, x0);
-        lds_store<P, G>(lds, p0 + d1, x1);
-        lds_store<P, G>(lds, p0 + 2 * d1, x2);
-        lds_store<P, G>(lds, p0 + 3 * d1, x3);
+        const int ph0 = G::phys(p0), ph1 = ph0 ^ G::phys(d1), ph2 = ph0 ^ G::phys(2 * d1);
+        lds_store_ph<P, G>(lds, ph0, x0);
+        lds_store_ph<P, G>(lds, ph1, x1);
+        lds_store_ph<P, G>(lds, ph2, x2);
+        lds_store_ph<P, G>(lds, ph1 ^ G::phys(2 * d1), x3);
       }
     } else
 #pragma unroll
@@ -445,12 +518,12 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_strided(const u32* __rest
         const int p0 = (j1 << lgc) | c, d1 = 1 << (lgn - 2 + lgc);
         Fe<P> x[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) x[u] = lds_load<P, G>(lds, p0 + u * d1);
+        for (int u = 0; u < 4; u++) x[u] = lds_load_ph<P, G>(lds, G::phys(p0) ^ G::phys(u * d1));
         radix4_regs<P, G>(x[0], x[1], x[2], x[3], twl, 1 << (lgn - 1), lgn, lgn - 1, j1);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const size_t off = ((size_t)(j1 + (u << (lgn - 2))) << lgM) + (ct << lgc) + c;
-          gstore<P>(out, (o << (lgn + lgM)) + off, fe_fit<P>(FeAsm<P>::mul(x[u], fe_unpack<P>(tw[q + GQ * u]))));
+          gstore<P>(out, (o << (lgn + lgM)) + off, inter_mul<P>(x[u], fe_unpack<P>(tw[q + GQ * u])));
         }
       }
       return;
@@ -461,7 +534,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_strided(const u32* __rest
       const int k = e >> lgc, c = e & cmask;
       const size_t off = ((size_t)k << lgM) + (ct << lgc) + c;
       const Fe<P> v = lds_load<P, G>(lds, (k << lgc) | c);
-      gstore<P>(out, (o << (lgn + lgM)) + off, fe_fit<P>(FeAsm<P>::mul(v, fe_unpack<P>(tw[u]))));
+      gstore<P>(out, (o << (lgn + lgM)) + off, inter_mul<P>(v, fe_unpack<P>(tw[u])));
     }
   }
 }
@@ -517,10 +590,11 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_last(const u32* __restric
       first_pair_regs<P, G>(x0, x1, x2, x3, tw_tile, tw_shoup, lgn);
       const int k0 = (int)(__brev((unsigned)r4) >> (32 - (lgn - 2))) << 2;
       const int q0 = (k0 << lgr) | rr, d1 = 1 << lgr;
-      lds_store<P, G>(lds, q0, x0);
-      lds_store<P, G>(lds, q0 + d1, x1);
-      lds_store<P, G>(lds, q0 + 2 * d1, x2);
-      lds_store<P, G>(lds, q0 + 3 * d1, x3);
+      const int ph0 = G::phys(q0), ph1 = ph0 ^ G::phys(d1), ph2 = ph0 ^ G::phys(2 * d1);
+      lds_store_ph<P, G>(lds, ph0, x0);
+      lds_store_ph<P, G>(lds, ph1, x1);
+      lds_store_ph<P, G>(lds, ph2, x2);
+      lds_store_ph<P, G>(lds, ph1 ^ G::phys(2 * d1), x3);
     }
   } else
   for (int e0 = tid; e0 < tile_elems; e0 += UNR * G::NT) {       // one trip for a full tile: all loads first, then the LDS stores
@@ -545,7 +619,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_last(const u32* __restric
   }
   __syncthreads();
   tile_stages<P, G>(lds, twl, lgn, lgr, fused ? 3 - (lgn & 1) : 1, fused ? lgn - 2 : lgn, tw_shoup);
-  Fe<P> sc;
+  Fe<P> sc = fe_zero<P>();
   if (has_scale) sc = fe_unpack<P>(scale.w);
   if (fused) {         // last stage pair on registers: the group of lane (j1, rr) is rows j1 + u 2^(lgn-2), the elements it stores
     const int rr = tid & rmask;
@@ -556,14 +630,12 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_last(const u32* __restric
       const int q0 = (j1 << lgr) | rr, d1 = 1 << (lgn - 2 + lgr);
       Fe<P> x[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) x[u] = lds_load<P, G>(lds, q0 + u * d1);
+      for (int u = 0; u < 4; u++) x[u] = lds_load_ph<P, G>(lds, G::phys(q0) ^ G::phys(u * d1));
       radix4_regs<P, G>(x[0], x[1], x[2], x[3], twl, 1 << (lgn - 1), lgn, lgn - 1, j1);
       if (r >= total_rows) continue;
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        Fe<P> v = x[u];
-        if (has_scale) v = FeAsm<P>::mul(v, sc);
-        gstore<P>(out, ((r >> lg_rows) << logn) + (r & rowmask) + ((size_t)(j1 + (u << (lgn - 2))) << lg_rows), fe_reduce<P>(v));
+        gstore<P>(out, ((r >> lg_rows) << logn) + (r & rowmask) + ((size_t)(j1 + (u << (lgn - 2))) << lg_rows), final_reduce<P>(x[u], sc, has_scale));
       }
     }
     return;
@@ -572,9 +644,8 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_last(const u32* __restric
     const int rr = e & rmask, k = e >> lgr;
     const size_t r = p0 + rr;
     if (r >= total_rows) continue;
-    Fe<P> v = lds_load<P, G>(lds, (k << lgr) | rr);
-    if (has_scale) v = FeAsm<P>::mul(v, sc);
-    gstore<P>(out, ((r >> lg_rows) << logn) + (r & rowmask) + ((size_t)k << lg_rows), fe_reduce<P>(v));
+    const Fe<P> v = lds_load<P, G>(lds, (k << lgr) | rr);
+    gstore<P>(out, ((r >> lg_rows) << logn) + (r & rowmask) + ((size_t)k << lg_rows), final_reduce<P>(v, sc, has_scale));
   }
 }
 

@@ -59,6 +59,50 @@ template <class P> static void run_ntt_tile(const u32* words, int lgn, const u32
     x[k] = fe_unpack<P>(words + (size_t)j * P::NW);
   }
   bool use_shoup = false;
+  if constexpr (SparseMod<P>::value) {
+    // signed lazy schedule of the sparse-modulus fields (mzk_ntt.hip: sbfly / radix4_regs): limb-wise sums of i32 limbs, the
+    // unmultiplied inputs of a stage pair carried on entry, signed products, fe_sreduce at the end; every bound asserted
+    auto sb = [&](Fe<P>& lo, Fe<P>& hi, int ti, bool trivial) {
+      Fe<P> t = hi;
+      if (!trivial) t = fe_mul_sparse<P, true, 0>(t, tw[ti]);
+      hi = fe_ssub<P>(lo, t);
+      lo = fe_sadd<P>(lo, t);
+    };
+    int s = 1;
+    if (lgn & 1) {
+      for (int g = 0; g < n / 2; g++) sb(x[2 * g], x[2 * g + 1], 0, true);
+      s = 2;
+    }
+    for (; s + 1 <= lgn; s += 2) {
+      const int lgh = s - 1, half = 1 << lgh;
+      for (int grp = 0; grp < (n >> (s + 1)); grp++)
+        for (int j1 = 0; j1 < half; j1++) {
+          const int p0 = (grp << (s + 1)) | j1, d1 = half, d2 = half << 1;
+          const bool triv = j1 == 0, raw = s == 1;
+          if (!raw) {
+            x[p0] = fe_scarry<P>(x[p0]);
+            x[p0 + d2] = fe_scarry<P>(x[p0 + d2]);
+            if (triv) { x[p0 + d1] = fe_scarry<P>(x[p0 + d1]); x[p0 + d2 + d1] = fe_scarry<P>(x[p0 + d2 + d1]); }
+          }
+          const int t1 = j1 << (lgn - s);
+          sb(x[p0], x[p0 + d1], t1, triv);
+          sb(x[p0 + d2], x[p0 + d2 + d1], t1, triv);
+          if (triv && (!raw || lgn == 2)) x[p0 + d2] = fe_scarry<P>(x[p0 + d2]);
+          sb(x[p0], x[p0 + d2], j1 << (lgn - s - 1), triv);
+          sb(x[p0 + d1], x[p0 + d2 + d1], (j1 + half) << (lgn - s - 1), false);
+        }
+    }
+    for (int k = 0; k < n; k++) {
+      // what a strided pass stores (x * inter-pass twiddle, here the Montgomery one) must fit the packed words ...
+      const Fe<P> st = fe_mul_sparse<P, true, 0>(fe_sbias<P>(x[k]), fe_one<P>());
+      assert((i32)st.l[P::L - 1] >= 0 && st.l[P::L - 1] < (1u << (32 * P::NW - 29 * (P::L - 1))));
+      // ... and what the last pass stores is canonical
+      const Fe<P> c = fe_sreduce<P>(x[k]);
+      assert(fe_eq_canon<P>(c, fe_reduce<P>(st)));
+      fe_pack<P>(c, out + (size_t)k * P::NW);
+    }
+    return;
+  }
   auto bfly = [&](Fe<P>& lo, Fe<P>& hi, int ti, bool trivial, bool raw, bool lazy) {
     Fe<P> t = hi;
     if (!trivial && use_shoup) t = fe_shoup_mul<P>(t, shoup + (size_t)ti * 18, shoup + (size_t)ti * 18 + 9);
@@ -116,6 +160,22 @@ int hc_shoup_mul(const u32* x_limbs, const u32* w_limbs, const u32* wq_limbs, u3
   for (int i = 0; i < 9; i++) x.l[i] = x_limbs[i];
   const Fe<FrParams> r = fe_shoup_mul<FrParams>(x, w_limbs, wq_limbs);
   for (int i = 0; i < 9; i++) out_limbs[i] = r.l[i];
+  return 0;
+}
+// fe_mul_sparse<M128, signed, c> on raw limbs (a: 5 limbs, i32 when signed; b: 5 limbs below 2^29); out = 5 limbs
+int hc_m128_mul_sparse(int is_signed, int c, const u32* a_limbs, const u32* b_limbs, u32* out_limbs) {
+  Fe<M128Params> a, b, r;
+  for (int i = 0; i < 5; i++) { a.l[i] = a_limbs[i]; b.l[i] = b_limbs[i]; }
+  if (is_signed) r = c ? fe_mul_sparse<M128Params, true, 1>(a, b) : fe_mul_sparse<M128Params, true, 0>(a, b);
+  else r = c ? fe_mul_sparse<M128Params, false, 1>(a, b) : fe_mul_sparse<M128Params, false, 0>(a, b);
+  for (int i = 0; i < 5; i++) out_limbs[i] = r.l[i];
+  return 0;
+}
+// fe_sreduce<M128> of 5 signed lazy limbs; out = 4 canonical words
+int hc_m128_sreduce(const u32* a_limbs, u32* out_words) {
+  Fe<M128Params> a;
+  for (int i = 0; i < 5; i++) a.l[i] = a_limbs[i];
+  fe_pack<M128Params>(fe_sreduce<M128Params>(a), out_words);
   return 0;
 }
 // pack(unpack(w)) round trip

@@ -78,15 +78,22 @@ def test_large_sizes_vs_fast_oracle(mz, fid, lg):
 
 
 def test_noncanonical_edge_values(mz):
-    # all p-1 / zeros / ones inputs
+    # all p-1 / zeros / ones inputs; p - 2 and 2^116 - 1: every 29-bit limb of an M128 element at its maximum -- the worst case of the
+    # signed lazy butterflies (limb sums up to 4 (2^29 - 1)) and, through X[0] = n x, of the borrow path of the final reduction --
+    # in every tile geometry (one pass, two small-tile passes, the 2^10-level tiles of 2^20)
     for fid in (FR, M128):
         p = orc.MOD[fid]
-        for fill in (0, 1, p - 1):
-            n = 1 << 12
-            v = orc.to_limbs([fill] * n, orc.LIMBS[fid])
-            w = orc.root_of(fid, 12)
-            rc, want = orc.ntt_fast(fid, w, v)
-            assert np.array_equal(mz.ntt(fid, w, v), want)
+        for lg in (4, 9, 12, 15, 20):
+            for fill in (0, 1, p - 1, p - 2, (1 << 116) - 1, p - 64):
+                if lg != 12 and fill in (0, 1):
+                    continue
+                n = 1 << lg
+                v = orc.to_limbs([fill] * n, orc.LIMBS[fid])
+                w = orc.root_of(fid, lg)
+                rc, want = orc.ntt_fast(fid, w, v, threads=8)
+                got = mz.ntt(fid, w, v)
+                assert rc == 0 and np.array_equal(got, want), (fid, lg, fill)
+                assert np.array_equal(mz.intt(fid, w, got), v), (fid, lg, fill)
 
 
 def test_error_behaviour(mz):

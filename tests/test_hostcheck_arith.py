@@ -206,7 +206,8 @@ def test_ntt_stage_schedule_with_lazy_first_stages_holds_its_bounds(hc):
             n = 1 << lgn
             w = orc.root_of(fid, lgn)
             tw = orc.to_limbs([pow(w, j, p) for j in range(max(n // 2, 1))], nl).view(np.uint32).reshape(-1)
-            cases = [orc.synth_vector(fid, 40 + lgn, n, 1), orc.to_limbs([p - 1] * n, nl), orc.to_limbs([1] + [0] * (n - 1), nl)]
+            cases = [orc.synth_vector(fid, 40 + lgn, n, 1), orc.to_limbs([p - 1] * n, nl), orc.to_limbs([1] + [0] * (n - 1), nl),
+                     orc.to_limbs([p - 2] * n, nl)]          # p - 2: every 29-bit limb of M128 at its maximum (the signed lazy sums' worst case)
             for x in cases:
                 out = np.zeros(n * nw, dtype=np.uint32)
                 assert hc.hc_ntt_tile(fid, orc.ptr(np.ascontiguousarray(x).view(np.uint32).reshape(-1)), lgn, orc.ptr(tw), orc.ptr(out)) == 0
@@ -264,3 +265,81 @@ def test_ntt_stage_schedule_with_shoup_products_holds_its_bounds(hc):
         raw = np.full(n * 8, 0xFFFFFFFF, dtype=np.uint32)
         out = np.zeros(n * 8, dtype=np.uint32)
         assert hc.hc_ntt_tile_shoup(orc.ptr(raw), lgn, lgc, orc.ptr(tw), orc.ptr(sh), orc.ptr(out)) == 0
+
+
+def test_m128_sparse_product_signed_and_unsigned(hc):
+    """fe_mul_sparse (mzk_field.h; FeAsm<M128Params>::mul / smul compute the same columns): a b / 2^145 mod p for
+    p = 3256 * 2^116 + 1 without a multiplication by -p^-1 -- congruent, inside [T/R + c p, T/R + (1 + c) p + p / 2^29 + 3), low limbs
+    normalised, for unsigned lazy and for SIGNED lazy operands (i32 limbs up to +-(2^31 - 1)), a non-negative operand giving a
+    non-negative result; the column bound assertions of the host build are on."""
+    import random
+    rng = random.Random(33)
+    p, R = P_M128, 1 << 145
+    val = lambda l: sum(int(v) << (29 * i) for i, v in enumerate(l))
+    for case in range(6000):
+        signed = case % 2
+        kind = (case // 2) % 5
+        if kind == 0:
+            a = [rng.randrange(-(1 << 31) + 1, 1 << 31) if signed else rng.randrange(1 << 32) for _ in range(5)]
+        elif kind == 1:
+            a = _limbs29(rng.randrange(p), 5)
+        elif kind == 2:
+            a = [(1 << 31) - 1] * 5 if signed else [(1 << 32) - 1] * 5
+        elif kind == 3:
+            a = [-((1 << 31) - 1)] * 5 if signed else [0] * 5
+        else:
+            a = [0, 0, 0, 0, 0]
+            a[rng.randrange(5)] = rng.randrange(1 << 29)
+        if abs(val(a)) >= 1 << 144:
+            a[4] = rng.randrange(-(1 << 26), 1 << 26) if signed else rng.randrange(1 << 26)
+        b = _limbs29(rng.randrange(p), 5) if case % 7 else [0x1fffffff] * 4 + [3256]
+        for c in (0, 1):
+            out = np.zeros(5, dtype=np.uint32)
+            aa = np.array([v & 0xFFFFFFFF for v in a], dtype=np.uint32)
+            assert hc.hc_m128_mul_sparse(signed, c, orc.ptr(aa), orc.ptr(np.array(b, dtype=np.uint32)), orc.ptr(out)) == 0
+            r = [int(v) for v in out]
+            if signed and r[4] >= 1 << 31:
+                r[4] -= 1 << 32
+            A, B, V = val(a), val(b), val(r)
+            assert (V * R - A * B) % p == 0, case
+            assert all(0 <= v <= 0x1fffffff for v in r[:4])
+            assert A * B // R + c * p <= V <= A * B // R + (1 + c) * p + (p >> 29) + 3, case
+            if A >= 0:
+                assert V >= 0
+
+
+def test_m128_signed_lazy_reduction_is_canonical(hc):
+    """fe_sreduce: any signed lazy value below 2^12 p in magnitude -> [0, p); the borrow path (limb 0 below the folded quotient)
+    is forced as well: multiples of 2^116 * 3256, of p, values just around them."""
+    import random
+    rng = random.Random(34)
+    p = P_M128
+    lim = (1 << 12) * p
+
+    def lazy_limbs(x, spread):
+        # a signed-limb representation of x with limbs pushed away from the carried form (floor semantics: x may be negative)
+        l = [(x >> (29 * i)) & 0x1fffffff for i in range(4)] + [x >> 116]
+        for i in range(4):
+            k = rng.randrange(-spread, spread + 1)
+            l[i] -= k << 29
+            l[i + 1] += k
+        return l
+
+    xs = [rng.randrange(-lim + 1, lim) for _ in range(400)]
+    for q in list(range(0, 40)) + [4094, 4095]:
+        for d in (-3, -1, 0, 1, 2, 5):
+            xs += [q * p + d, -q * p + d, ((q * 3256) << 116) + d]          # the last: top limb a multiple of 3256, limb 0 < q
+    top = 3 * ((1 << 29) - 1)            # the widest limb a stage pair leaves
+    reps = {sum(v << (29 * i) for i, v in enumerate(l)): l for l in ([top] * 4 + [4 * 4095], [top, 0, 0, 0, 0], [-top] * 4 + [-40000],
+                                                                        [top, top, -top, top, 77])}
+    for x in xs + list(reps):
+        if abs(x) >= lim:
+            continue
+        for spread in (0, 1):
+            l = reps[x] if x in reps else lazy_limbs(x, spread)
+            assert sum(v << (29 * i) for i, v in enumerate(l)) == x
+            assert all(abs(v) <= 3 * ((1 << 29) - 1) for v in l)
+            out = np.zeros(4, dtype=np.uint32)
+            aa = np.array([v & 0xFFFFFFFF for v in l], dtype=np.uint32)
+            assert hc.hc_m128_sreduce(orc.ptr(aa), orc.ptr(out)) == 0
+            assert from_w32(out) == x % p, (x, spread)

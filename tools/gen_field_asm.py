@@ -118,6 +118,59 @@ def gen(kind, name, L, P):
     return "  static __device__ __forceinline__ %s %s {\n    %s r;\n%s%s\n    return r;\n  }\n" % (T, sig, T, pre, A.render())
 
 
+def gen_sparse(name, L, P, signed):
+    """fe_mul_sparse of mzk_field.h (p = PT 2^(29 (L-1)) + 1: M128) as one chain: 25 + 5 multiply-adds, the complements of the low
+    limbs by v_bfi, no v_mul_lo.  signed: the limbs of `a` are i32 (the NTT's lazily accumulated butterflies): v_mad_i64_i32 and
+    arithmetic shifts, signed top limb.  Same columns and sums as the C++ form (C = 0)."""
+    assert P[0] == 1 and not any(P[1:L - 1])
+    A = Asm()
+    r = [A.out("r.l[%d]" % i) for i in range(L)]
+    n = [A.out("n[%d]" % i) for i in range(L - 1)]
+    A.fix()
+    a = [A.inp("v", "a.l[%d]" % i) for i in range(L)]
+    b = [A.inp("v", "b.l[%d]" % i) for i in range(L)]
+    pt = A.inp("s", "%sParams::P[%d]" % (name, L - 1))
+    msk = A.inp("s", "0x1fffffffu")
+    c4 = A.inp("s", "(%sParams::P[%d] + 1u + (1u << 29))" % (name, L - 1))
+    mask = "0x1fffffff"
+    madop = "v_mad_i64_i32" if signed else "v_mad_u64_u32"
+    shr = "v_ashrrev_i64" if signed else "v_lshrrev_b64"
+    first = [True]
+
+    def mad(x, y):
+        A.emit("%s %s, vcc, %s, %s, %s" % (madop, COL, x, y, "0" if first[0] else COL))
+        first[0] = False
+
+    for k in range(L - 1):
+        for i in range(k + 1):
+            mad(a[i], b[k - i])
+        A.emit("v_bfi_b32 %s, %s, 0, %s" % (n[k], CLO, msk))          # (~lo) & MASK
+        A.emit("%s %s, 29, %s" % (shr, COL, COL))
+    for k in range(L - 1, 2 * L - 1):
+        for i in range(k - L + 1, L):
+            mad(a[i], b[k - i])
+        if k < 2 * L - 2:
+            mad(n[k - L + 1], pt)
+        if k == L - 1:
+            mad("1", c4)                                                # the constants of both reduction steps
+            A.emit("v_and_b32 %s, %s, %s" % (n[0], mask, CLO))
+            A.emit("v_sub_u32 %s, 0x20000000, %s" % (n[0], n[0]))      # m = 2^29 - u0
+            A.emit("%s %s, 29, %s" % (shr, COL, COL))
+        else:
+            if k == 2 * L - 2:
+                mad(n[0], pt)
+            A.emit("v_and_b32 %s, %s, %s" % (r[k - L], mask, CLO))
+            if k < 2 * L - 2:
+                A.emit("%s %s, 29, %s" % (shr, COL, COL))
+            else:
+                A.emit("v_alignbit_b32 %s, v1, v0, 29" % r[L - 1])
+    T = "Fe<%sParams>" % name
+    fn = "smul" if signed else "mul"
+    doc = ("  // a: signed lazy limbs (i32, |a_i| < 2^31); b: limbs below 2^29; result: limbs 0..%d in [0, 2^29), signed top limb\n" % (L - 2)) if signed else ""
+    return "%s  static __device__ __forceinline__ %s %s(const %s& a, const %s& b) {\n    %s r;\n    u32 n[%d];\n%s\n    return r;\n  }\n" % (
+        doc, T, fn, T, T, T, L - 1, A.render())
+
+
 def gen_shoup(name, L, p):
     """x * w mod p, w and wq = floor(w 2^(29 L) / p) as SCALAR operands (a wave-uniform twiddle): same columns as fe_shoup_mul."""
     A = Asm()
@@ -177,8 +230,13 @@ def main(out):
         check_slot_reuse(L)
         P = limbs(p, L)
         S.append("template <> struct FeAsm<%sParams> {" % name)
+        sparse = P[0] == 1 and not any(P[1:L - 1])
         for kind in ("mul", "sqr", "mul_add2"):
-            S.append(gen(kind, name, L, P))
+            if kind == "mul" and sparse:
+                S.append(gen_sparse(name, L, P, False))
+                S.append(gen_sparse(name, L, P, True))
+            else:
+                S.append(gen(kind, name, L, P))
         if name == "Fr":
             S.append(gen_shoup(name, L, p))
         S.append("};")
@@ -190,6 +248,7 @@ def main(out):
     S.append("  static MZK_HD Fe<P> sqr(const Fe<P>& a) { return fe_sqr<P>(a); }")
     S.append("  static MZK_HD Fe<P> mul_add2(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) { return fe_mul_add2<P>(a, b, c, d); }")
     S.append("  static MZK_HD Fe<P> shoup_mul(const Fe<P>& x, const u32* w, const u32* wq) { return fe_shoup_mul<P>(x, w, wq); }")
+    S.append("  static MZK_HD Fe<P> smul(const Fe<P>& a, const Fe<P>& b) { return fe_mul_sparse<P, true, 0>(a, b); }")
     S.append("};")
     S.append("}  // namespace mzk")
     S.append("#endif")
