@@ -40,6 +40,9 @@ constexpr int MAX_LEVEL_LOG = MZK_NTT_MAX_LEVEL_LOG;
 #define MZK_NTT_LAZY_FIRST 1       // 0: A/B builds of the carry-everywhere butterflies (tools/timing/time_ntt.py with MZK_HIP_LIB)
 #endif
 constexpr bool NTT_LAZY_FIRST = MZK_NTT_LAZY_FIRST != 0;
+#ifndef MZK_NTT_EARLY_TW
+#define MZK_NTT_EARLY_TW 0         // 1: A/B builds with the inter-pass twiddles requested at the top of the strided pass (measured slower, see k_ntt_strided)
+#endif
 // Tile geometry.  Small (1024 elements, 256 lanes, levels of <= 2^8): every size below 2^20.  Large (4096 elements,
 // 1024 lanes = one workgroup per CU, levels of <= 2^10): from 2^20 points on, where 256+ workgroups exist -- a 2^20
 // transform is TWO passes of 2^10 levels instead of three (one global round trip and one inter-pass twiddle product
@@ -445,12 +448,28 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_strided(const u32* __rest
   constexpr int GQ = G::GQ;                     // radix-4 groups per lane: element u = q + GQ v is member v of group q
   static_assert(UNR == 4 * GQ, "whole radix-4 groups per lane");
   const bool fused = fuse_edges<G>(lgn, lgc, fuse);   // first (plain loads only) and last stage pair on registers, next to the global accesses
+  // EARLY_TW (M128, one 1024-lane workgroup per CU: 44 of 128 VGPRs in use): the inter-pass twiddles of the lane's four elements are
+  // requested right behind its data, at the top of the kernel, and wait in 16 registers.  A 2^20 transform is one tile per CU with
+  // all CUs in lock-step, so the request after the stage loop met an idle HBM and every wave waited out the whole 16-MiB burst
+  // (~4 us of a 24-us pass); now that burst streams in under the butterflies.
+  constexpr bool EARLY_OK = SparseMod<P>::value && G::NT == 1024 && !G::TWG;
+  constexpr bool EARLY_TW = MZK_NTT_EARLY_TW == 1 && EARLY_OK;          // at the top, behind the data loads
+  constexpr bool MID_TW = MZK_NTT_EARLY_TW == 2 && EARLY_OK;            // behind the first barrier: the data has arrived, HBM is idle
+  u32 tw[UNR][P::NW];
+  auto tw_load_at = [&](int t, int u) {
+    const int e = t + u * G::NT;
+    gload_words<P>(tw_inter, ((size_t)(e >> lgc) << lgM) + (ct << lgc) + (e & cmask), tw[u]);
+  };
   if constexpr (!PRE) {
     u32 w[UNR][P::NW];
 #pragma unroll
     for (int u = 0; u < UNR; u++) {
       const int e = tid + u * G::NT;
       gload_words<P>(in, base + ((size_t)(e >> lgc) << lgM) + (e & cmask), w[u]);
+    }
+    if constexpr (EARLY_TW) {
+#pragma unroll
+      for (int u = 0; u < UNR; u++) tw_load_at(tid, u);
     }
     if (fused) {       // first stage pair next to the loads: the data of a wave starts computing when IT has arrived
 #pragma unroll
@@ -474,7 +493,11 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_strided(const u32* __rest
       const int k = (int)(__brev((unsigned)j1) >> (32 - lgn));
       lds_store<P, G>(lds, (k << lgc) | c, fe_unpack<P>(w[u]));
     }
-  } else
+  } else {
+  if constexpr (EARLY_TW) {      // the coefficient vector is a fraction of the tile (the rest is the zero padding): the twiddles may as well go first
+#pragma unroll
+    for (int u = 0; u < UNR; u++) tw_load_at(tid, u);
+  }
   for (int e = tid; e < tile_elems; e += G::NT) {
     const int j1 = e >> lgc, c = e & cmask;
     Fe<P> v;
@@ -495,7 +518,12 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_strided(const u32* __rest
     const int k = (int)(__brev((unsigned)j1) >> (32 - lgn));
     lds_store<P, G>(lds, (k << lgc) | c, v);
   }
+  }
   __syncthreads();
+  if constexpr (MID_TW) {
+#pragma unroll
+    for (int u = 0; u < UNR; u++) tw_load_at(tid, u);
+  }
   tile_stages<P, G>(lds, twl, lgn, lgc, (fused && !PRE) ? 3 - (lgn & 1) : 1, fused ? lgn - 2 : lgn, tw_shoup);
   {
     // The inter-pass twiddles of all the lane's elements, requested before the first product.  The epilogue's addresses are
@@ -504,13 +532,10 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_strided(const u32* __rest
     // keeps every hot kernel at zero).
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
-    u32 tw[UNR][P::NW];
-    auto tw_load = [&](int u) {
-      const int e = tid + u * G::NT;
-      gload_words<P>(tw_inter, ((size_t)(e >> lgc) << lgM) + (ct << lgc) + (e & cmask), tw[u]);
-    };
+    if constexpr (!EARLY_TW && !MID_TW) {
 #pragma unroll
-    for (int u = 0; u < UNR; u++) tw_load(u);
+      for (int u = 0; u < UNR; u++) tw_load_at(tid, u);
+    }
     if (fused) {       // last stage pair on registers: the lane's group q is rows j1 + v 2^(lgn-2), exactly the elements it stores
 #pragma unroll
       for (int q = 0; q < GQ; q++) {
