@@ -57,6 +57,9 @@ template <int TL_, int NT_, int MAXLV_, bool TWG_ = false, int WPE_ = 1> struct 
   static constexpr int TL = TL_, TILE = 1 << TL_, NT = NT_, MAXLV = MAXLV_, WPE = WPE_;
   static constexpr bool TWG = TWG_;
   static constexpr int GQ = TILE / NT_ / 4;            // radix-4 groups per lane and stage pair (fused first / last pairs)
+  // in-tile twiddles in LDS: entries per limb / word row.  A compile-time stride (the largest level's n/2, whatever this pass's level
+  // is) puts the rows at immediate offsets of ONE address: four vector additions per twiddle fetch less than a runtime stride.
+  static constexpr int TWS = 1 << (MAXLV_ - 1);
   // Logical tile position -> LDS word index inside a limb row.  The low five bits (the bank) are XORed with a GF(2)-linear
   // function of the upper bits, chosen by simulating every wave-level access of the kernels (bit-reversed scatter of
   // the load phase, the four loads and stores of every radix-4 stage pair, all level sizes the geometry runs;
@@ -72,10 +75,11 @@ template <int TL_, int NT_, int MAXLV_, bool TWG_ = false, int WPE_ = 1> struct 
   template <class P> static constexpr bool twpack() { return !TWG_ && (size_t)4 * P::L * (TILE + (1 << (MAXLV_ - 1))) > (size_t)160 * 1024; }
   template <class P> static constexpr size_t lds_bytes(int lgn) {
     if (TWG_) return sizeof(u32) * (size_t)P::L * TILE;
-    return sizeof(u32) * ((size_t)P::L * TILE + (size_t)(twpack<P>() ? P::NW : P::L) * (lgn >= 2 ? ((size_t)1 << (lgn - 1)) : 1));
+    return sizeof(u32) * ((size_t)P::L * TILE + (size_t)(twpack<P>() ? P::NW : P::L) * TWS);
   }
 };
 typedef Geo<TILE_LOG, NTHREADS, MAX_LEVEL_LOG> GeoS;
+typedef Geo<TILE_LOG, NTHREADS, TILE_LOG> GeoS1;   // the one-pass transforms of 2^9 and 2^10 points: their level is wider than GeoS's twiddle rows
 typedef Geo<12, 1024, 10> GeoL;
 typedef Geo<12, 512, 10, true, 4> GeoM;        // M128 large tiles: two workgroups per CU
 template <class P> struct LargeGeo { typedef GeoL type; };
@@ -193,11 +197,11 @@ __device__ __forceinline__ void stage_twiddles(u32* twl, const u32* __restrict__
   for (int j = threadIdx.x; j < cnt; j += G::NT) {
     if constexpr (G::template twpack<P>()) {      // packed words, word-major
 #pragma unroll
-      for (int i = 0; i < P::NW; i++) twl[i * cnt + j] = tw[(size_t)j * P::NW + i];
+      for (int i = 0; i < P::NW; i++) twl[i * G::TWS + j] = tw[(size_t)j * P::NW + i];
     } else {
       Fe<P> w = gload<P>(tw, j);
 #pragma unroll
-      for (int i = 0; i < P::L; i++) twl[i * cnt + j] = w.l[i];
+      for (int i = 0; i < P::L; i++) twl[i * G::TWS + j] = w.l[i];
     }
   }
 }
@@ -225,11 +229,11 @@ __device__ __forceinline__ Fe<P> tw_fetch(const u32* twl, int tws, int ti) {
   } else if constexpr (G::template twpack<P>()) {
     u32 ww[P::NW];
 #pragma unroll
-    for (int i = 0; i < P::NW; i++) ww[i] = twl[i * tws + ti];
+    for (int i = 0; i < P::NW; i++) ww[i] = twl[i * G::TWS + ti];
     w = fe_unpack<P>(ww);
   } else {
 #pragma unroll
-    for (int i = 0; i < P::L; i++) w.l[i] = twl[i * tws + ti];
+    for (int i = 0; i < P::L; i++) w.l[i] = twl[i * G::TWS + ti];
   }
   return w;
 }
@@ -265,10 +269,13 @@ __device__ __forceinline__ void bfly(Fe<P>& lo, Fe<P>& hi, const u32* twl, int t
 // w^0 = 1: about one stage's worth of products per level.
 // One radix-4 group in registers: the two butterfly stages s, s + 1 on the four elements at k-distance 2^(s-1), 2^s
 // (x0, x1 = first stage pair; x2, x3 the second); j1 = the group's index inside the first stage's half.
-template <class P, class G>
+// MODE: 0 = a lane decides for itself whether its twiddles are 1 (execution-masked branches around every product and register
+// copies where they join); 1 = no lane of the wave has j1 = 0, 2 = all have: straight-line code.  radix4_wave picks the mode from a
+// ballot -- all but one or two waves of a stage pair are uniform (the groups are enumerated twiddle-major).
+template <class P, class G, int MODE = 0>
 __device__ __forceinline__ void radix4_regs(Fe<P>& x0, Fe<P>& x1, Fe<P>& x2, Fe<P>& x3, const u32* twl, int tws, int lgn, int s, int j1) {
   const int lgh = s - 1;
-  const bool triv = (j1 == 0);
+  const bool triv = MODE == 0 ? (j1 == 0) : (MODE == 2);
   const bool raw = (s == 1);
   const int t1 = j1 << (lgn - s);
   if constexpr (SignedLazy<P>::value) {
@@ -287,6 +294,15 @@ __device__ __forceinline__ void radix4_regs(Fe<P>& x0, Fe<P>& x1, Fe<P>& x2, Fe<
   }
   bfly<P, G>(x0, x2, twl, tws, j1 << (lgn - s - 1), triv, false);
   bfly<P, G>(x1, x3, twl, tws, (j1 + (1 << lgh)) << (lgn - s - 1), false, false);
+}
+template <class P, class G>
+__device__ __forceinline__ void radix4_wave(Fe<P>& x0, Fe<P>& x1, Fe<P>& x2, Fe<P>& x3, const u32* twl, int tws, int lgn, int s, int j1) {
+  // (M128 single-workgroup tiles only: three copies of the group are ~30 more VGPRs, which the BN254 kernels and the 512-lane M128 form -- both at their 128-register cap -- would spill)
+  if constexpr (!SignedLazy<P>::value || G::TWG) { radix4_regs<P, G, 0>(x0, x1, x2, x3, twl, tws, lgn, s, j1); return; }
+  const unsigned long long trivial = __ballot(j1 == 0);
+  if (trivial == 0) radix4_regs<P, G, 1>(x0, x1, x2, x3, twl, tws, lgn, s, j1);
+  else if (trivial == __ballot(1)) radix4_regs<P, G, 2>(x0, x1, x2, x3, twl, tws, lgn, s, j1);
+  else radix4_regs<P, G, 0>(x0, x1, x2, x3, twl, tws, lgn, s, j1);
 }
 // Stage pairs whose twiddles are the same for a whole wave (groups are enumerated twiddle-major: 2^lgrest consecutive groups
 // share j1, so from lgrest >= 6 on a wave has ONE j1) take them from the plan's Shoup table by scalar loads -- entry ti =
@@ -410,8 +426,8 @@ __device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, i
         }
       }
       if (!done) {
-        if (G::TWG && lgrest >= 6) radix4_regs<P, G>(x0, x1, x2, x3, twl, tws, lgn, s, __builtin_amdgcn_readfirstlane(j1));   // scalar loads
-        else radix4_regs<P, G>(x0, x1, x2, x3, twl, tws, lgn, s, j1);
+        if (G::TWG && lgrest >= 6) radix4_wave<P, G>(x0, x1, x2, x3, twl, tws, lgn, s, __builtin_amdgcn_readfirstlane(j1));   // scalar loads
+        else radix4_wave<P, G>(x0, x1, x2, x3, twl, tws, lgn, s, j1);
       }
       lds_store_ph<P, G>(lds, ph0, x0);
       lds_store_ph<P, G>(lds, ph1, x1);
@@ -544,7 +560,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_strided(const u32* __rest
         Fe<P> x[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) x[u] = lds_load_ph<P, G>(lds, G::phys(p0) ^ G::phys(u * d1));
-        radix4_regs<P, G>(x[0], x[1], x[2], x[3], twl, 1 << (lgn - 1), lgn, lgn - 1, j1);
+        radix4_wave<P, G>(x[0], x[1], x[2], x[3], twl, 1 << (lgn - 1), lgn, lgn - 1, j1);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const size_t off = ((size_t)(j1 + (u << (lgn - 2))) << lgM) + (ct << lgc) + c;
@@ -656,7 +672,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_last(const u32* __restric
       Fe<P> x[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) x[u] = lds_load_ph<P, G>(lds, G::phys(q0) ^ G::phys(u * d1));
-      radix4_regs<P, G>(x[0], x[1], x[2], x[3], twl, 1 << (lgn - 1), lgn, lgn - 1, j1);
+      radix4_wave<P, G>(x[0], x[1], x[2], x[3], twl, 1 << (lgn - 1), lgn, lgn - 1, j1);
       if (r >= total_rows) continue;
 #pragma unroll
       for (int u = 0; u < 4; u++) {
@@ -1030,7 +1046,7 @@ static int run_plan_geo(const NttPlan* pl, const u32* d_in, u32* d_out, hipStrea
   ProfScope whole(s, MZK_PH_NTT_TOTAL);
   static const int fuse = tune_int("MZK_NTT_FUSE_EDGES", 1);     // 0: A/B (tools/timing/time_ntt.py)
   static const int shoup = tune_int("MZK_NTT_SHOUP", 1);
-  if (G::TL != TILE_LOG) {        // tiles above 64 KiB of LDS need the attribute, once per context and instantiation
+  if constexpr (G::TL != TILE_LOG) {        // tiles above 64 KiB of LDS need the attribute, once per context and instantiation
     bool& done = ctx().attr_done[P::NW == 4 ? (G::TWG ? ATTR_NTT_LARGE_M128_2WG : ATTR_NTT_LARGE_M128) : ATTR_NTT_LARGE_FR];
     if (!done) {
       MZK_HIP(hipFuncSetAttribute((const void*)k_ntt_strided<P, true, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1043,6 +1059,7 @@ static int run_plan_geo(const NttPlan* pl, const u32* d_in, u32* d_out, hipStrea
   u32* tmp = nullptr;
   if (li.nlev > 1) MZK_TRY(ws_get(WS_NTT_TMP, (batch << logn) * sizeof(u32) * P::NW, (void**)&tmp));
   int lg_after = (int)logn;
+  if constexpr (G::MAXLV < G::TL || G::TL != TILE_LOG)      // (GeoS1 serves single-pass plans only: no strided kernels of its own)
   for (int t = 0; t < li.nlev - 1; t++) {
     const int lgn = li.lg[t], lgM = lg_after - lgn;
     const int lgc = G::TL - lgn;
@@ -1083,6 +1100,7 @@ static int run_plan(const NttPlan* pl, const u32* d_in, u32* d_out, hipStream_t 
   static const int two_wg_from = tune_int("MZK_NTT_M128_TWO_WG", 21);
   if (pl->large && P::NW == 4 && (int)pl->logn >= two_wg_from) return run_plan_geo<P, typename LargeGeo<P>::type>(pl, d_in, d_out, s, pre, batch);
   if (pl->large) return run_plan_geo<P, GeoL>(pl, d_in, d_out, s, pre, batch);
+  if (pl->li.nlev == 1 && pl->li.lg[0] > GeoS::MAXLV) return run_plan_geo<P, GeoS1>(pl, d_in, d_out, s, pre, batch);
   return run_plan_geo<P, GeoS>(pl, d_in, d_out, s, pre, batch);
 }
 
