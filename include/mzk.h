@@ -44,8 +44,10 @@ enum { MZK_OK = 0,
        MZK_E_NOGPU = -8,      /* no gfx950 device visible: there is NO CPU fallback */
        MZK_E_CALLBACK = -9,   /* a caller-supplied callback reported failure (mzk_fri_commit's challenge) */
        MZK_E_IO = -10,        /* file could not be opened / read / written, or is not a valid dump (mzk_srs_save/load) */
-       MZK_E_BUSY = -11       /* another host thread is inside a call: the library serves one call at a time (see above);
-                                 nothing was enqueued, the call may simply be repeated */ };
+       MZK_E_BUSY = -11,      /* another host thread is inside a call: the library serves one call at a time (see above);
+                                 nothing was enqueued, the call may simply be repeated */
+       MZK_E_NOMEM = -12      /* the device has no memory left for this call even after every idle workspace buffer of the context
+                                 was released (see mzk_set_workspace_budget / mzk_trim_workspace); nothing was enqueued */ };
 
 /* Select the device for this process, create streams/workspace.  Idempotent: when context 0 already drives
  * `device_ordinal` nothing is torn down (contexts made by mzk_init_devices, their streams and every handle stay valid);
@@ -441,6 +443,23 @@ int mzk_srs_from_device_ex(const void* d_powers_xy, size_t n, int with_tables, m
  * 2 / 4 = degraded, 0 = no tables).  Applies to mzk_srs_upload, mzk_srs_from_device[_ex], mzk_srs_load and the sharded forms. */
 int mzk_set_table_budget(size_t bytes);
 int mzk_srs_bucket_sets(const mzk_srs* srs);
+/* Scratch memory that gives itself back (the reference's Vec buffers are freed when commit_kzg / ntt return, kzg.rs:57-59,
+ * ntt.rs:7-48; the library instead keeps per-context workspace buffers so that steady-state calls never allocate).
+ *   mzk_set_workspace_budget(bytes): the workspace a context may KEEP (0 = no limit, the default).  A call takes what it needs;
+ *     whenever a buffer has to grow while the context holds more than the budget, every buffer the running call has not asked for
+ *     is released first (the device is waited for).  Setting a budget below what is held releases the idle buffers at once.
+ *   Whatever the budget: an allocation the device refuses -- workspace, SRS tables, prepared points -- is tried again after the idle
+ *     workspace has been released, and a new SRS handle does that BEFORE it degrades its table layout; what is still refused is
+ *     MZK_E_NOMEM (never a bare MZK_E_HIP), with nothing enqueued.
+ *   mzk_trim_workspace(&released): releases every workspace buffer of every context and the tables of the cached transform plans
+ *     (rebuilt on demand); waits for the devices.  released may be NULL.
+ *   mzk_workspace_bytes(&bytes): workspace bytes currently held over all contexts. */
+int mzk_set_workspace_budget(size_t bytes);
+int mzk_trim_workspace(size_t* bytes_released);
+int mzk_workspace_bytes(size_t* bytes);
+/* Device copy at 16 bytes per lane, grid-stride, on `stream` (d_dst and d_src 16-byte aligned, bytes a multiple of 16): the
+ * memory-bound yardstick the benchmark quotes beside the nominal HBM peak (bench.py hbm_copy_GBps_measured). */
+int mzk_selftest_copy_dev(const void* d_src, void* d_dst, size_t bytes, void* stream);
 
 /* Host-side parameter arithmetic of the library (roots, inverses, offsets: O(log n) scalar work per call, never on the
  * data path), exposed for checking without a GPU: op 0 = a * b, 1 = a^-1 (0 -> 0), 2 = a^(b[0]), 3 = a * b by the

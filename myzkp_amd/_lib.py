@@ -14,7 +14,8 @@ MODULUS = {
     FIELD_FQ: 21888242871839275222246405745257275088696311157297823662689037894645226208583,
 }
 ERRORS = {0: "MZK_OK", -1: "MZK_E_ARG", -2: "MZK_E_NOT_POW2", -3: "MZK_E_ROOT_ORDER", -4: "MZK_E_ROOT_PRIM",
-          -5: "MZK_E_LENGTH", -6: "MZK_E_RANGE", -7: "MZK_E_HIP", -8: "MZK_E_NOGPU", -9: "MZK_E_CALLBACK", -10: "MZK_E_IO"}
+          -5: "MZK_E_LENGTH", -6: "MZK_E_RANGE", -7: "MZK_E_HIP", -8: "MZK_E_NOGPU", -9: "MZK_E_CALLBACK", -10: "MZK_E_IO",
+          -11: "MZK_E_BUSY", -12: "MZK_E_NOMEM"}
 
 
 class MzkError(RuntimeError):
@@ -68,6 +69,24 @@ def _check(rc):
 
 def init(device=0):
     _check(lib().mzk_init(int(device)))
+
+
+def set_workspace_budget(nbytes):
+    """bytes of scratch a context may keep between calls (0 = no limit); idle buffers above it are released at once"""
+    _check(lib().mzk_set_workspace_budget(ctypes.c_size_t(int(nbytes))))
+
+
+def trim_workspace():
+    """release every workspace buffer and cached transform plan of every context; returns the workspace bytes given back"""
+    out = ctypes.c_size_t(0)
+    _check(lib().mzk_trim_workspace(ctypes.byref(out)))
+    return out.value
+
+
+def workspace_bytes():
+    out = ctypes.c_size_t(0)
+    _check(lib().mzk_workspace_bytes(ctypes.byref(out)))
+    return out.value
 
 
 def shutdown():

@@ -24,6 +24,8 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 static std::atomic<uint64_t> g_owner{0};
 static thread_local int t_depth = 0;
 static thread_local char t_marker;            // its address is this thread's id
+static uint64_t g_call_epoch = 1;              // one per outermost API call: which workspace slots the running call has asked for
+static size_t g_ws_budget = 0;                 // mzk_set_workspace_budget: bytes of workspace a context may keep (0 = no limit)
 EntryGuard::EntryGuard() : ok(true), nested(false) {
   if (t_depth > 0) { t_depth++; nested = true; return; }
   uint64_t expected = 0;
@@ -33,6 +35,7 @@ EntryGuard::EntryGuard() : ok(true), nested(false) {
     return;
   }
   t_depth = 1;
+  g_call_epoch++;
 }
 EntryGuard::~EntryGuard() {
   if (!ok) return;
@@ -62,8 +65,51 @@ CtxScope::~CtxScope() {
   if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
 }
 
+// Workspace memory gives itself back (round 5).  The slots only ever grew, so a 2^27-pair MSM left gigabytes in them for good, a
+// later call could fail in here with a bare HIP error, and a new SRS handle degraded its tables although idle scratch was in the
+// way -- where commit_kzg(&poly, &pk) cannot fail for memory at all (kzg.rs:57-59).  Now: a slot remembers the outermost call
+// that last asked for it; when an allocation would exceed the caller's budget (mzk_set_workspace_budget) or the device refuses
+// it, every slot the RUNNING call has not asked for is freed and the allocation tried again; what is still refused is
+// MZK_E_NOMEM, not MZK_E_HIP.  mzk_trim_workspace() does the same on request, for every context, cached transform plans included.
+size_t ws_bytes_held() {
+  size_t t = 0;
+  for (const auto& b : ctx().ws) t += b.cap;
+  return t;
+}
+size_t ws_trim_idle() {
+  Context& c = ctx();
+  size_t idle = 0;
+  for (const auto& b : c.ws) if (b.p && b.epoch != g_call_epoch) idle += b.cap;
+  if (!idle) return 0;
+  (void)hipDeviceSynchronize();
+  for (auto& b : c.ws) {
+    if (b.p && b.epoch != g_call_epoch) {
+      (void)hipFree(b.p);
+      b.p = nullptr; b.cap = 0;
+    }
+  }
+  c.ws_gen = ++g_gen_counter;          // device tables cached inside slots (fixed-base tables of g, offset powers) are gone with them
+  return idle;
+}
+int dev_alloc(void** out, size_t bytes, const char* what) {
+  *out = nullptr;
+  hipError_t e = hipMalloc(out, bytes);
+  if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
+    (void)hipGetLastError();
+    if (ws_trim_idle()) e = hipMalloc(out, bytes);
+  }
+  if (e == hipSuccess) return MZK_OK;
+  (void)hipGetLastError();
+  *out = nullptr;
+  if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
+    set_error("%s: the device has no %zu bytes left (idle workspace already released)", what, bytes);
+    return MZK_E_NOMEM;
+  }
+  return hip_fail(e, what, __FILE__, __LINE__);
+}
 int ws_get(WsSlot slot, size_t bytes, void** out) {
   WsBuf& b = ctx().ws[slot];
+  b.epoch = g_call_epoch;
   if (bytes > b.cap) {
     if (b.p) {
       MZK_HIP(hipDeviceSynchronize());
@@ -71,7 +117,8 @@ int ws_get(WsSlot slot, size_t bytes, void** out) {
       b.p = nullptr; b.cap = 0;
     }
     size_t cap = bytes < 4096 ? 4096 : bytes;
-    MZK_HIP(hipMalloc(&b.p, cap));
+    if (g_ws_budget && ws_bytes_held() + cap > g_ws_budget) (void)ws_trim_idle();
+    MZK_TRY(dev_alloc(&b.p, cap, "workspace"));
     b.cap = cap;
   }
   *out = b.p;
@@ -882,7 +929,7 @@ int mzk_g1_fold_partials_dev(const void* d_partials16, int count, void* d_out_xy
 //      sets multiply the bucket count, and beyond 2^19 buckets the sort leaves its staged path)
 //   -> the prepared points and their endomorphism images only (the generic GLV layout: 128 bytes per point).
 // The last step ignores the budget (it is what the library needs to work at all); only when even that allocation fails is
-// the error MZK_E_HIP.  mzk_srs_window_bits / mzk_srs_bucket_sets / mzk_srs_table_bytes report what a handle got.
+// the error MZK_E_NOMEM.  mzk_srs_window_bits / mzk_srs_bucket_sets / mzk_srs_table_bytes report what a handle got.
 static size_t g_table_budget = 0;
 namespace mzk {
 int srs_alloc_layout(mzk_srs* h, int with_tables) {
@@ -907,14 +954,14 @@ int srs_alloc_layout(mzk_srs* h, int with_tables) {
     const bool last = k == nc - 1;
     if (!last && g_table_budget && bytes > g_table_budget) continue;
     void* p = nullptr;
-    if (n == 0 || hipMalloc(&p, bytes) == hipSuccess) {
+    // (dev_alloc: a refused allocation is tried again after the idle workspace has been released -- BEFORE the layout degrades)
+    if (n == 0 || dev_alloc(&p, bytes, "SRS handle") == MZK_OK) {
       h->d_points_mont = p; h->has_tables = cand[k].tables; h->window_bits = cand[k].bits; h->sets = cand[k].sets;
       return MZK_OK;
     }
-    (void)hipGetLastError();
   }
-  set_error("SRS handle: hipMalloc of %zu bytes (the prepared points alone) failed", n * 128);
-  return MZK_E_HIP;
+  set_error("SRS handle: the device has no %zu bytes left for the prepared points alone (idle workspace already released)", n * 128);
+  return MZK_E_NOMEM;
 }
 // fills a freshly laid-out handle from n affine canonical points in device memory
 int srs_fill(mzk_srs* h, const void* d_plain, hipStream_t s) {
@@ -931,6 +978,42 @@ int srs_fill(mzk_srs* h, const void* d_plain, hipStream_t s) {
 extern "C" {
 
 int mzk_set_table_budget(size_t bytes) { g_table_budget = bytes; return MZK_OK; }
+int mzk_set_workspace_budget(size_t bytes) {
+  MZK_ENTER();
+  g_ws_budget = bytes;
+  if (bytes) {
+    for (int i = 0; i < ctx_count(); i++) {
+      CtxScope sc(i);
+      if (sc.ok && ws_bytes_held() > bytes) (void)ws_trim_idle();
+    }
+  }
+  return MZK_OK;
+}
+int mzk_trim_workspace(size_t* bytes_released) {
+  MZK_ENTER();
+  size_t total = 0;
+  for (int i = 0; i < ctx_count(); i++) {
+    CtxScope sc(i);
+    if (!sc.ok) continue;
+    total += ws_trim_idle();
+    (void)hipDeviceSynchronize();
+    ntt_release_plans();           // tables of the cached transform plans: rebuilt on the next call that needs them
+    poly_release_pool();
+  }
+  if (bytes_released) *bytes_released = total;
+  return MZK_OK;
+}
+int mzk_workspace_bytes(size_t* bytes) {
+  MZK_ENTER();
+  if (!bytes) { set_error("workspace_bytes: null pointer"); return MZK_E_ARG; }
+  size_t total = 0;
+  for (int i = 0; i < ctx_count(); i++) {
+    CtxScope sc(i);
+    if (sc.ok) total += ws_bytes_held();
+  }
+  *bytes = total;
+  return MZK_OK;
+}
 int mzk_srs_bucket_sets(const mzk_srs* srs) { return (srs && srs->has_tables) ? srs->sets : 0; }
 
 int mzk_srs_upload(const uint64_t* powers_xy, size_t n, mzk_srs** out) {
@@ -1320,6 +1403,11 @@ int mzk_synth_field_dev(int field_id, uint64_t seed, size_t n, void* d_out, void
   WsGuard wsg((hipStream_t)stream);
   if (!d_out && n) { set_error("synth: null pointer"); return MZK_E_ARG; }
   return synth_field_impl(field_id, seed, n, d_out, (hipStream_t)stream);
+}
+int mzk_selftest_copy_dev(const void* d_src, void* d_dst, size_t bytes, void* stream) {
+  MZK_ENTER();
+  if ((bytes && (!d_src || !d_dst)) || (bytes & 15) || ((uintptr_t)d_src & 15) || ((uintptr_t)d_dst & 15)) { set_error("selftest_copy: pointers and size must be 16-byte multiples"); return MZK_E_ARG; }
+  return selftest_copy_impl(d_src, d_dst, bytes, (hipStream_t)stream);
 }
 int mzk_selftest_field_asm(int field_id, uint64_t seed, size_t n, uint64_t* mismatches) {
   MZK_ENTER();

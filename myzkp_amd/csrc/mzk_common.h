@@ -46,7 +46,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 // how the multi-GPU path is exercised on a one-GPU box).  Every entry point works on the CURRENT context
 // (mzk_ctx_select; context 0 after init); the *_multi entry points walk all of them.
 constexpr int MZK_MAX_CTX = 16;
-struct WsBuf { void* p = nullptr; size_t cap = 0; };
+struct WsBuf { void* p = nullptr; size_t cap = 0; uint64_t epoch = 0; };      // epoch: the outermost API call that last asked for the slot
 enum WsSlot { WS_NTT_TMP = 0, WS_NTT_IO_A, WS_NTT_IO_B, WS_MSM_POINTS, WS_MSM_SCALARS, WS_MSM_COUNTS, WS_MSM_OFFSETS,
               WS_MSM_CURSOR, WS_MSM_ENTRIES, WS_MSM_BUCKETS, WS_MSM_RED_A, WS_MSM_RED_B, WS_MSM_SCAN, WS_MSM_OUT, WS_MSM_SLOTS, WS_MSM_WGHIST, WS_BATCHINV, WS_XYZZ_TMP, WS_MERKLE_NODES, WS_FB_TABLE16, WS_FB_TABLE8, WS_NTT_PRE, WS_NTT_PRE_M128,
               WS_MISC_A, WS_MISC_B, WS_MISC_C, WS_MISC_D, WS_MISC_E, WS_MISC_F, WS_COUNT };
@@ -104,6 +104,12 @@ struct CtxScope {
 // Grow-only device scratch buffers of the current context, keyed by slot, so steady-state calls never hipMalloc.
 int ws_get(WsSlot slot, size_t bytes, void** out);
 void ws_release_all();
+// Frees the slots of the current context that the running outermost call has not asked for (all of them between calls); waits for
+// the device first (earlier *_dev calls may still be reading them).  Returns the bytes given back.
+size_t ws_trim_idle();
+size_t ws_bytes_held();
+// hipMalloc that tries again after ws_trim_idle() when the device is out of memory; MZK_E_NOMEM if it still is.
+int dev_alloc(void** out, size_t bytes, const char* what);
 uint64_t ws_generation();
 // Put one at the top of every entry point that enqueues work using workspace slots on stream s.
 struct WsGuard {
@@ -214,6 +220,7 @@ int synth_g1_impl(uint64_t seed, size_t n, void* d_out, hipStream_t s);
 int selftest_inv_wave_impl(uint64_t seed, size_t n, uint64_t* mismatches_host, hipStream_t s);
 int selftest_row_ec_impl(uint64_t seed, size_t n, int dbl_reps, uint64_t* mismatches_host, hipStream_t s);
 int selftest_field_asm_impl(int fid, uint64_t seed, size_t n, uint64_t* mismatches_host, hipStream_t s);
+int selftest_copy_impl(const void* d_src, void* d_dst, size_t bytes, hipStream_t s);
 int kzg_setup_g1_dev(const uint64_t* alpha_host, const uint64_t* g1_host, size_t first, size_t count, void* d_powers_xy, hipStream_t s);
 int kzg_open_dev(const void* d_coef, size_t n, const uint64_t* u_host, const void* d_points, int point_kind, size_t table_stride,
                  void* d_y, void* d_w_xy, void* d_q_out, hipStream_t s);

@@ -68,6 +68,27 @@ __global__ void k_selftest_field_asm(u64 seed, size_t n, unsigned long long* __r
   if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
 
+// 16 bytes per lane, four independent loads in flight per lane and trip, grid-stride over a grid of 8 workgroups per CU
+__global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+int selftest_copy_impl(const void* d_src, void* d_dst, size_t bytes, hipStream_t s) {
+  if (!bytes) return MZK_OK;
+  const size_t n16 = bytes / 16;
+  size_t blocks = (n16 + 255) / 256;
+  const size_t cap = (size_t)ctx().num_cu * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_copy16, dim3((unsigned)blocks), dim3(256), 0, s, (const uint4*)d_src, (uint4*)d_dst, n16);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+
 int selftest_field_asm_impl(int fid, uint64_t seed, size_t n, uint64_t* mismatches_host, hipStream_t s) {
   unsigned long long* d;
   MZK_TRY(ws_get(WS_MISC_A, 8, (void**)&d));

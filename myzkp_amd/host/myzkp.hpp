@@ -42,6 +42,10 @@ struct Panic : std::runtime_error {
 inline void expect(int rc) {
   if (rc != MZK_OK) throw Panic(rc, mzk_last_error());
 }
+// scratch memory of the library (no reference counterpart: the reference's Vec buffers die with each call): what a context may keep
+// between calls, and an explicit release; MZK_E_NOMEM surfaces through expect() like every other status
+inline void set_workspace_budget(size_t bytes) { expect(mzk_set_workspace_budget(bytes)); }
+inline size_t trim_workspace() { size_t r = 0; expect(mzk_trim_workspace(&r)); return r; }
 
 // ---- ModulusValue phantom types (field.rs:94-96, :408-431; bn128.rs:19-30; fri.rs:408) -------------
 struct ModEIP197 { static constexpr int FIELD_ID = MZK_FIELD_FR; static constexpr int LIMBS = 4; };

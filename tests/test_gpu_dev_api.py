@@ -242,6 +242,56 @@ def test_table_budget_degrades_the_layout_not_the_result(env):
     assert seen == [1, 1, 2, 4, 0, 0]
 
 
+def test_workspace_gives_itself_back(env):
+    """VERDICT r04 #5: the workspace only ever grew.  A 2^24-pair generic MSM leaves gigabytes in its slots; a workspace budget below
+    that releases them at once, a full-table 2^20 handle built afterwards gets its undegraded layout and commits bit-exactly
+    (oracle Pippenger on the same pairs); with the budget in force a later call of another kind trims what the MSM left instead of
+    stacking on top of it; mzk_trim_workspace gives everything back and the next calls rebuild what they need."""
+    torch, mz, L, dev, st = env
+    L.mzk_srs_table_bytes.restype = ctypes.c_size_t
+    big, n = 1 << 24, 1 << 20
+    try:
+        pts = torch.empty(big * 8, dtype=torch.int64, device=dev)
+        sc = torch.empty(big * 4, dtype=torch.int64, device=dev)
+        _ok(L, L.mzk_synth_g1_points_dev(ctypes.c_uint64(811), ctypes.c_size_t(big), _dp(pts), st))
+        _ok(L, L.mzk_synth_field_dev(FR, ctypes.c_uint64(812), ctypes.c_size_t(big), _dp(sc), st))
+        out = torch.zeros(8, dtype=torch.int64, device=dev)
+        _ok(L, L.mzk_msm_g1_bn254_dev(_dp(sc), _dp(pts), ctypes.c_size_t(big), _dp(out), st))
+        torch.cuda.synchronize()
+        held = mz.workspace_bytes()
+        assert held > (1 << 30), held                              # prepared points + endomorphism images alone are 4 GiB
+        budget = 256 << 20
+        mz.set_workspace_budget(budget)
+        assert mz.workspace_bytes() <= budget
+        h = ctypes.c_void_p()
+        _ok(L, L.mzk_srs_from_device(_dp(pts), ctypes.c_size_t(n), ctypes.byref(h), st))
+        assert L.mzk_srs_bucket_sets(h) == 1 and L.mzk_srs_window_bits(h) == 17 and L.mzk_srs_table_bytes(h) == 15 * n * 64
+        _ok(L, L.mzk_kzg_commit_srs_dev(h, _dp(sc), ctypes.c_size_t(n), _dp(out), 0, st))
+        torch.cuda.synchronize()
+        got = mz.array_to_points(out.cpu().numpy().view(np.uint64))[0]
+        hp = pts[: n * 8].cpu().numpy().view(np.uint64).reshape(n, 8)
+        hs = sc[: n * 4].cpu().numpy().view(np.uint64).reshape(n, 4)
+        assert got == orc.msm_fast(hs, hp)
+        L.mzk_srs_free(h)
+        # under the budget a call of another kind releases what the commit left before it grows its own slots
+        after_commit = mz.workspace_bytes()
+        v = torch.empty((1 << 22) * 4, dtype=torch.int64, device=dev)
+        w = torch.empty_like(v)
+        _ok(L, L.mzk_synth_field_dev(FR, ctypes.c_uint64(813), ctypes.c_size_t(1 << 22), _dp(v), st))
+        root = mz.to_limbs([mz.root_of_unity(FR, 22)], 4)
+        _ok(L, L.mzk_ntt_dev(FR, root.ctypes.data_as(ctypes.c_void_p), _dp(v), _dp(w), ctypes.c_size_t(1 << 22), 0, st))
+        torch.cuda.synchronize()
+        assert mz.workspace_bytes() <= max(budget, (1 << 22) * 32 + 4096), (after_commit, mz.workspace_bytes())
+        back = torch.empty_like(v)
+        released = mz.trim_workspace()
+        assert released > 0 and mz.workspace_bytes() == 0
+        _ok(L, L.mzk_ntt_dev(FR, root.ctypes.data_as(ctypes.c_void_p), _dp(w), _dp(back), ctypes.c_size_t(1 << 22), 1, st))      # plans rebuilt
+        torch.cuda.synchronize()
+        assert torch.equal(back, v)
+    finally:
+        mz.set_workspace_budget(0)
+
+
 def test_second_host_thread_gets_busy_not_corruption():
     """include/mzk.h: one host thread at a time.  A call arriving while another thread is inside the library returns MZK_E_BUSY
     (-11) before touching any state; the call in progress is unaffected (VERDICT r02 weak #8)."""

@@ -49,20 +49,31 @@ def kernel_resources(so):
             name = g("name")
             if not name:
                 continue
-            try:
-                name = subprocess.run([os.path.join(LLVM, "llvm-cxxfilt"), name], capture_output=True, text=True).stdout.strip() or name
-            except Exception:
-                pass
+            for filt in (os.path.join(LLVM, "llvm-cxxfilt"), "c++filt"):      # (this image ships binutils' c++filt, not LLVM's)
+                try:
+                    name = subprocess.run([filt, name], capture_output=True, text=True).stdout.strip() or name
+                    break
+                except Exception:
+                    pass
             res[name] = {"vgpr": int(g("vgpr_count") or 0), "sgpr": int(g("sgpr_count") or 0), "vgpr_spill": int(g("vgpr_spill_count") or 0),
                          "sgpr_spill": int(g("sgpr_spill_count") or 0), "scratch": int(g("private_segment_fixed_size") or 0),
                          "lds": int(g("group_segment_fixed_size") or 0), "max_flat_wg": int(g("max_flat_workgroup_size") or 0)}
     return res
 
 
+# the kernels bench.py prices (substrings of the demangled names): tests/test_abi_load.py guards their spills and scratch, and
+# `python tools/kernel_resources.py --priced` prints their table (profiles/r05final_kernel_resources.txt)
+PRICED = ("k_seg_accumulate", "k_seg_combine", "k_ntt_strided", "k_ntt_last", "k_direct_accumulate", "k_direct_finish", "k_many_sort1", "k_many_count",
+          "k_many_scatter", "k_open_many", "k_fine_scatter", "k_fine_count", "k_coarse_scatter", "k_coarse_count", "k_merkle", "k_fri_fold", "k_reduce_tail_row",
+          "k_prepare_points", "k_window_combine_row")
+
+
 if __name__ == "__main__":
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     args = sys.argv[1:]
     so = args.pop(0) if args and args[0].endswith(".so") else os.path.join(here, "myzkp_amd", "libmzk_hip.so")
+    if "--priced" in args:
+        args = [a for a in args if a != "--priced"] + list(PRICED)
     r = kernel_resources(so)
     print("%-110s %5s %5s %7s %7s %8s %7s" % ("kernel", "vgpr", "sgpr", "v-spill", "s-spill", "scratch", "lds"))
     for k in sorted(r):
