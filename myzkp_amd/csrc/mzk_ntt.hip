@@ -110,6 +110,40 @@ struct LevelInfo {
 };
 
 // ---- global memory <-> limbs ----------------------------------------------------------------------
+// The streaming accesses of the transform passes -- the data (read once, written once per pass) and the inter-pass twiddles -- can
+// carry the non-temporal hint (MZK_NTT_NT = 1).  A plain copy gains 25 % from it on MI355X (profiles/round5_copy_kernel_variants.txt);
+// the transforms LOSE: M128 2^20 0.0407 -> 0.0433 ms, 2^22 0.151 -> 0.180 (same box, profiles/round5_ntt_nontemporal_ab.txt) -- what
+// one pass writes, the next one reads back out of L2 / the 256-MiB Infinity Cache, and so it does the twiddle tables of the
+// previous transform; the hint takes that away.  Off.
+#ifndef MZK_NTT_NT
+#define MZK_NTT_NT 0
+#endif
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t stream_load16(const u32* p) {
+  if (MZK_NTT_NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  return *reinterpret_cast<const u32x4_t*>(p);
+}
+__device__ __forceinline__ void stream_store16(u32* p, u32x4_t v) {
+  if (MZK_NTT_NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(p));
+  else *reinterpret_cast<u32x4_t*>(p) = v;
+}
+template <class P> __device__ __forceinline__ void gload_words_stream(const u32* __restrict__ g, size_t idx, u32 (&w)[P::NW]) {
+#pragma unroll
+  for (int q = 0; q < P::NW / 4; q++) {
+    const u32x4_t v = stream_load16(g + idx * P::NW + 4 * q);
+    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+  }
+}
+template <class P> __device__ __forceinline__ void gstore_stream(u32* __restrict__ g, size_t idx, const Fe<P>& v) {
+  u32 w[P::NW];
+  fe_pack<P>(v, w);
+#pragma unroll
+  for (int q = 0; q < P::NW / 4; q++) {
+    u32x4_t t;
+    t.x = w[4 * q]; t.y = w[4 * q + 1]; t.z = w[4 * q + 2]; t.w = w[4 * q + 3];
+    stream_store16(g + idx * P::NW + 4 * q, t);
+  }
+}
 template <class P> __device__ __forceinline__ Fe<P> gload(const u32* __restrict__ g, size_t idx) {
   u32 w[P::NW];
   const uint4* p4 = reinterpret_cast<const uint4*>(g + idx * P::NW);
@@ -474,14 +508,14 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_strided(const u32* __rest
   u32 tw[UNR][P::NW];
   auto tw_load_at = [&](int t, int u) {
     const int e = t + u * G::NT;
-    gload_words<P>(tw_inter, ((size_t)(e >> lgc) << lgM) + (ct << lgc) + (e & cmask), tw[u]);
+    gload_words_stream<P>(tw_inter, ((size_t)(e >> lgc) << lgM) + (ct << lgc) + (e & cmask), tw[u]);
   };
   if constexpr (!PRE) {
     u32 w[UNR][P::NW];
 #pragma unroll
     for (int u = 0; u < UNR; u++) {
       const int e = tid + u * G::NT;
-      gload_words<P>(in, base + ((size_t)(e >> lgc) << lgM) + (e & cmask), w[u]);
+      gload_words_stream<P>(in, base + ((size_t)(e >> lgc) << lgM) + (e & cmask), w[u]);
     }
     if constexpr (EARLY_TW) {
 #pragma unroll
@@ -564,7 +598,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_strided(const u32* __rest
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const size_t off = ((size_t)(j1 + (u << (lgn - 2))) << lgM) + (ct << lgc) + c;
-          gstore<P>(out, (o << (lgn + lgM)) + off, inter_mul<P>(x[u], fe_unpack<P>(tw[q + GQ * u])));
+          gstore_stream<P>(out, (o << (lgn + lgM)) + off, inter_mul<P>(x[u], fe_unpack<P>(tw[q + GQ * u])));
         }
       }
       return;
@@ -575,7 +609,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_strided(const u32* __rest
       const int k = e >> lgc, c = e & cmask;
       const size_t off = ((size_t)k << lgM) + (ct << lgc) + c;
       const Fe<P> v = lds_load<P, G>(lds, (k << lgc) | c);
-      gstore<P>(out, (o << (lgn + lgM)) + off, inter_mul<P>(v, fe_unpack<P>(tw[u])));
+      gstore_stream<P>(out, (o << (lgn + lgM)) + off, inter_mul<P>(v, fe_unpack<P>(tw[u])));
     }
   }
 }
@@ -621,7 +655,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_last(const u32* __restric
       for (int u = 0; u < 4; u++) {
 #pragma unroll
         for (int q = 0; q < P::NW; q++) w[g][u][q] = 0;
-        if (r < total_rows) gload_words<P>(in, row_base(r) + r4 + ((size_t)u << (lgn - 2)), w[g][u]);
+        if (r < total_rows) gload_words_stream<P>(in, row_base(r) + r4 + ((size_t)u << (lgn - 2)), w[g][u]);
       }
     }
 #pragma unroll
@@ -647,7 +681,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_last(const u32* __restric
       const size_t r = p0 + rr;
 #pragma unroll
       for (int q = 0; q < P::NW; q++) w[u][q] = 0;
-      if (e < tile_elems && r < total_rows) gload_words<P>(in, row_base(r) + j, w[u]);
+      if (e < tile_elems && r < total_rows) gload_words_stream<P>(in, row_base(r) + j, w[u]);
     }
 #pragma unroll
     for (int u = 0; u < UNR; u++) {
@@ -676,7 +710,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_last(const u32* __restric
       if (r >= total_rows) continue;
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        gstore<P>(out, ((r >> lg_rows) << logn) + (r & rowmask) + ((size_t)(j1 + (u << (lgn - 2))) << lg_rows), final_reduce<P>(x[u], sc, has_scale));
+        gstore_stream<P>(out, ((r >> lg_rows) << logn) + (r & rowmask) + ((size_t)(j1 + (u << (lgn - 2))) << lg_rows), final_reduce<P>(x[u], sc, has_scale));
       }
     }
     return;
@@ -686,7 +720,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_last(const u32* __restric
     const size_t r = p0 + rr;
     if (r >= total_rows) continue;
     const Fe<P> v = lds_load<P, G>(lds, (k << lgr) | rr);
-    gstore<P>(out, ((r >> lg_rows) << logn) + (r & rowmask) + ((size_t)k << lg_rows), final_reduce<P>(v, sc, has_scale));
+    gstore_stream<P>(out, ((r >> lg_rows) << logn) + (r & rowmask) + ((size_t)k << lg_rows), final_reduce<P>(v, sc, has_scale));
   }
 }
 

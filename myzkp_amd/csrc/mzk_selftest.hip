@@ -68,22 +68,33 @@ __global__ void k_selftest_field_asm(u64 seed, size_t n, unsigned long long* __r
   if (bad) atomicAdd(mismatches, (unsigned long long)bad);
 }
 
-// 16 bytes per lane, four independent loads in flight per lane and trip, grid-stride over a grid of 8 workgroups per CU
+// The memory-bound yardstick: one chunk of 4 x 256 x 16 bytes per workgroup (no grid-stride loop: short-lived workgroups keep more
+// requests in flight across the chip than 8 persistent ones per CU), four independent 16-byte loads per lane, non-temporal loads and
+// stores (the data is touched once).  tools/microbench/copy_bw.hip measured the shapes on MI355X (profiles/round5_copy_kernel_variants.txt):
+// 6.26 TB/s read + write for this one against 4.3-4.7 for grid-stride forms, 5.5 for hipMemcpyAsync, 4.7-5.1 for torch's copy_.
+__device__ __forceinline__ uint4 nt_load16(const uint4* p) {
+  uint4 v;
+  v.x = __builtin_nontemporal_load(&p->x); v.y = __builtin_nontemporal_load(&p->y);
+  v.z = __builtin_nontemporal_load(&p->z); v.w = __builtin_nontemporal_load(&p->w);
+  return v;
+}
+__device__ __forceinline__ void nt_store16(uint4* p, const uint4& v) {
+  __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
+  __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
+}
 __global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n16; i += 4 * stride) {
-    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-  }
-  for (; i < n16; i += stride) dst[i] = src[i];
+  const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+  uint4 v[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) if (base + (size_t)u * 256 < n16) v[u] = nt_load16(src + base + (size_t)u * 256);
+#pragma unroll
+  for (int u = 0; u < 4; u++) if (base + (size_t)u * 256 < n16) nt_store16(dst + base + (size_t)u * 256, v[u]);
 }
 int selftest_copy_impl(const void* d_src, void* d_dst, size_t bytes, hipStream_t s) {
   if (!bytes) return MZK_OK;
   const size_t n16 = bytes / 16;
-  size_t blocks = (n16 + 255) / 256;
-  const size_t cap = (size_t)ctx().num_cu * 8;
-  if (blocks > cap) blocks = cap;
+  const size_t blocks = (n16 + 1023) / 1024;
+  if (blocks > 0x7fffffffu) { set_error("selftest_copy: at most 2^45 bytes per call"); return MZK_E_ARG; }
   hipLaunchKernelGGL(k_copy16, dim3((unsigned)blocks), dim3(256), 0, s, (const uint4*)d_src, (uint4*)d_dst, n16);
   MZK_HIP(hipGetLastError());
   return MZK_OK;
