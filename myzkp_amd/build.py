@@ -35,6 +35,10 @@ def build(force=False, verbose=False, tuning=False):
     asm_h = os.path.join(CSRC, "mzk_field_asm.h")
     if os.path.exists(gen_asm) and (_newer(gen_asm, asm_h) or _newer(gen, asm_h)):
         subprocess.check_call([sys.executable, gen_asm, asm_h])
+    gen_k = os.path.join(ROOT, "tools", "gen_keccak_asm.py")
+    kec_h = os.path.join(CSRC, "mzk_keccak_asm.h")
+    if os.path.exists(gen_k) and _newer(gen_k, kec_h):
+        subprocess.check_call([sys.executable, gen_k, kec_h])
     objdir = os.path.join(HERE, "build_tuning" if tuning else "build")
     os.makedirs(objdir, exist_ok=True)
     out = OUT_TUNING if tuning else OUT

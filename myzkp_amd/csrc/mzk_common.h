@@ -162,6 +162,10 @@ void kzg_release_cache();       // mzk_kzg.hip: fixed-base tables of the current
 void poly_release_pool();       // mzk_poly.hip: parked scratch blocks of the current context
 int fri_fold_dev_impl(int fid, const void* d_cw, size_t n, const uint64_t* alpha, const uint64_t* offset, const uint64_t* omega,
                       void* d_out, hipStream_t s);
+struct FriFoldConsts { uint64_t half[4], oinv[4], winv[4], rmod[4]; };
+int fri_fold_consts(int fid, const uint64_t* offset, const uint64_t* omega, FriFoldConsts* fc);
+void fri_fold_consts_square(int fid, FriFoldConsts* fc);
+int fri_fold_dev_consts(int fid, const void* d_cw, size_t n, const uint64_t* alpha, const FriFoldConsts& fc, void* d_out, hipStream_t s);
 int kzg_batch_open_dev(const void* d_coef, size_t n, const uint64_t* us_host, size_t k, const void* d_points, int point_kind,
                        size_t table_stride, void* d_ys, void* d_w_xy, hipStream_t s);
 

@@ -10,6 +10,7 @@
 // 64-bit logic ops -- ALU-bound, ~5k VALU ops per hash; algorithmic HBM traffic is S*n bytes in, 32*(n-1) out.
 #include <algorithm>
 #include "mzk_common.h"
+#include "mzk_keccak_asm.h"
 
 namespace mzk {
 
@@ -104,7 +105,21 @@ template <int R> __device__ __forceinline__ u32 pair_rot(u32 mine) {
 }
 __device__ __forceinline__ u32 x3(u32 a, u32 b, u32 c) { return (u32)__builtin_amdgcn_bitop3_b32((int)a, (int)b, (int)c, 0x96); }
 __device__ __forceinline__ u32 chi32(u32 a, u32 b, u32 c) { return a ^ (~b & c); }
+#ifndef MZK_KECCAK_PAIR_ASM
+#define MZK_KECCAK_PAIR_ASM 1       // 0: the compiler-scheduled round below (A/B builds)
+#endif
 __device__ __forceinline__ void keccak_f_pair(u32 (&a)[25], int parity) {
+#if MZK_KECCAK_PAIR_ASM
+  // One scheduled asm block per round (mzk_keccak_asm.h, generated): hipcc emitted the round word by word -- xor, s_nop 1,
+  // v_mov_b32_dpp, s_nop 0, v_alignbit: 49 wait-state instructions per round, 7.6 cycles per instruction on the lone wave of a
+  // tree's upper levels; batched (all xors, all lane exchanges, all funnel shifts) every hazard distance is covered by independent work.
+#pragma unroll 1
+  for (int rnd = 0; rnd < 24; rnd++) {
+    const u64 rc = KECCAK_RC[rnd];
+    keccak_round_pair_asm(a, parity ? (u32)(rc >> 32) : (u32)rc);
+  }
+  return;
+#endif
 #pragma unroll 1
   for (int rnd = 0; rnd < 24; rnd++) {
     const u32 c0 = x3(x3(a[0], a[5], a[10]), a[15], a[20]);
@@ -329,16 +344,42 @@ __global__ __launch_bounds__(128) void k_merkle_level_pair(const u64* __restrict
 constexpr int TAIL_NODES = 512;
 __global__ __launch_bounds__(TAIL_NODES) void k_merkle_tail(u64* __restrict__ level, size_t count, size_t stop) {
   // `level` holds `count` nodes; the levels above follow contiguously (count/2, count/4, ... stop); stop = 1 for one tree,
-  // the number of trees for a batch (their roots are the last level)
+  // the number of trees for a batch (their roots are the last level).
+  // The digests travel from level to level through LDS (ping-pong): every level is one dependent hash on an almost empty CU, and
+  // reading the children back from global memory behind a fence was a ~1.5-us round trip per level on top of the ~7 us of the hash.
+  // Global memory still receives every digest (the authentication paths are gathered from there) but nobody waits for it.
+  __shared__ u32 sh[2][TAIL_NODES * 8];
+  const int tid = threadIdx.x;
+  {
+    const u32* g = reinterpret_cast<const u32*>(level);
+    for (size_t i = tid; i < count * 8; i += TAIL_NODES) sh[0][i] = g[i];
+  }
+  __syncthreads();
   u64* below = level;
+  int cur = 0;
   while (count > stop) {
     const size_t up = count / 2;
     u64* above = below + 4 * count;
-    if ((threadIdx.x >> 1) < up) sha3_of_two_digests_pair(below + 8 * (threadIdx.x >> 1), above + 4 * (threadIdx.x >> 1), threadIdx.x & 1);
-    __threadfence_block();
+    const int h = tid >> 1, parity = tid & 1;
+    if ((size_t)h < up) {
+      u32 a[25];
+      const u32* c32 = sh[cur] + 16 * h;
+#pragma unroll
+      for (int i = 0; i < 8; i++) a[i] = c32[2 * i + parity];
+      a[8] = parity ? 0u : 0x06u;
+#pragma unroll
+      for (int i = 9; i < 25; i++) a[i] = 0;
+      a[16] = parity ? 0x80000000u : 0u;
+      keccak_f_pair(a, parity);
+      u32* o32 = reinterpret_cast<u32*>(above + 4 * h);
+      u32* l32 = sh[cur ^ 1] + 8 * h;
+#pragma unroll
+      for (int i = 0; i < 4; i++) { o32[2 * i + parity] = a[i]; l32[2 * i + parity] = a[i]; }
+    }
     __syncthreads();
     below = above;
     count = up;
+    cur ^= 1;
   }
 }
 // authentication path: node (index >> l) ^ 1 of level l, l = 1 .. depth-1; level l starts at node n - n / 2^(l-1)
@@ -397,6 +438,12 @@ struct mzk_merkle {
   hipEvent_t built = nullptr;    // recorded behind the last kernel of the build
   // ragged leaf counts: the tree is built over m = 2^floor(log2 n) items (see k_merkle_ragged_items); d_nodes, depth
   // and the gather kernel then refer to the item tree
+  // FRI::commit with the trees kept: the codewords and digests of ALL rounds live in one device allocation shared by the rounds'
+  // handles (one hipMalloc per commit instead of two per round, and no copies: a round hashes and folds in place there);
+  // d_leaves / d_nodes then point into it and the last handle freed releases it.
+  struct SharedBlock { void* p; int refs; };
+  SharedBlock* shared = nullptr;
+  bool owns_leaves = false;        // with `shared`: d_leaves is nevertheless an allocation of its own (signed round-0 leaves)
   bool ragged = false;
   size_t m = 0;
   void* d_items = nullptr;
@@ -904,6 +951,11 @@ int mzk_merkle_open_multi(const mzk_merkle* const* trees, size_t n_trees, const 
 
 void mzk_merkle_free(mzk_merkle* t) {
   if (!t) return;
+  if (t->shared) {
+    if (--t->shared->refs == 0) { (void)hipFree(t->shared->p); delete t->shared; }
+    if (!t->owns_leaves) t->d_leaves = nullptr;
+    t->d_nodes = nullptr;
+  }
   if (t->d_leaves) (void)hipFree(t->d_leaves);
   if (t->d_nodes) (void)hipFree(t->d_nodes);
   if (t->d_items) (void)hipFree(t->d_items);
@@ -1040,8 +1092,27 @@ static int fri_commit_rounds(int field_id, const uint64_t* codeword, const uint8
   for (int r = 0; r < num_rounds; r++) total += n >> r;
   uint8_t* d_all;
   u64* d_nodes;
-  MZK_TRY(ws_get(WS_NTT_IO_A, total * esz, (void**)&d_all));
-  MZK_TRY(ws_get(WS_MERKLE_NODES, n * 32, (void**)&d_nodes));
+  mzk_merkle::SharedBlock* shared = nullptr;
+  if (trees_out) {
+    // trees kept: codewords and digests of every round in ONE allocation that the rounds' handles share (2 hipMalloc and two
+    // device copies per round before: ~25 us of a ~155-us round at 2^14); layout: [codewords of all rounds | digests of round 0 | 1 | ...]
+    for (int r = 0; r < num_rounds; r++) trees_out[r] = nullptr;
+    size_t node_bytes = 0;
+    for (int r = 0; r < num_rounds; r++) if ((n >> r) >= 2) node_bytes += ((n >> r) - 1) * 32;
+    const size_t cw_bytes = (total * esz + 255) & ~(size_t)255;
+    void* blk = nullptr;
+    MZK_TRY(dev_alloc(&blk, cw_bytes + node_bytes + 256, "fri_commit: kept trees"));
+    shared = new mzk_merkle::SharedBlock{blk, 1};        // this function's own reference, dropped at the end
+    d_all = (uint8_t*)blk;
+    d_nodes = (u64*)((uint8_t*)blk + cw_bytes);
+  } else {
+    MZK_TRY(ws_get(WS_NTT_IO_A, total * esz, (void**)&d_all));
+    MZK_TRY(ws_get(WS_MERKLE_NODES, n * 32, (void**)&d_nodes));
+  }
+  struct DropRef {        // every exit path: the handles already handed out keep the block alive, otherwise it goes
+    mzk_merkle::SharedBlock* b;
+    ~DropRef() { if (b && --b->refs == 0) { (void)hipFree(b->p); delete b; } }
+  } drop{shared};
   MZK_HIP(hipMemcpyAsync(d_all, codeword, n * esz, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
   u8* d_neg = nullptr;
   if (negative) {     // round 0 hashes bincode of the UNSANITIZED elements (fri.rs:160-166); the fold sanitizes (fri.rs:190)
@@ -1051,6 +1122,10 @@ static int fri_commit_rounds(int field_id, const uint64_t* codeword, const uint8
   uint64_t om[4], of[4], alpha[4];
   memcpy(om, omega, 8 * nl);
   memcpy(of, offset, 8 * nl);
+  // the fold's constants 2^-1, offset^-1, omega^-1: inverted ONCE here and squared along with omega and offset (three host
+  // inversions per round before)
+  FriFoldConsts fc;
+  MZK_TRY(fri_fold_consts(field_id, of, om, &fc));
   uint8_t* cur = d_all;
   size_t len = n;
   for (int r = 0; r < num_rounds; r++) {
@@ -1063,16 +1138,23 @@ static int fri_commit_rounds(int field_id, const uint64_t* codeword, const uint8
     } else {
       MZK_TRY(merkle_hash_levels(0, field_id, cur, nullptr, len, d_nodes, s, r == 0 ? d_neg : nullptr));
       MZK_HIP(hipMemcpyAsync(root, d_nodes + 4 * (len - 2), 32, hipMemcpyDeviceToHost, s));
-      if (trees_out) {      // keep this round's tree: its own copy of the leaves (round 0: still unsanitized) and of the digests
+      if (trees_out) {      // keep this round's tree: its leaves and digests stay where they were computed, in the shared block
         mzk_merkle* t = new mzk_merkle();
-        t->kind = 0; t->field = field_id; t->n = len; t->stream = s; t->d_nodes = nullptr; t->d_leaves = nullptr;
+        t->kind = 0; t->field = field_id; t->n = len; t->stream = s;
+        t->d_nodes = d_nodes; t->d_leaves = cur;
+        t->shared = shared; shared->refs++;
         t->depth = 0;
         while (((size_t)1 << t->depth) < len) t->depth++;
         trees_out[r] = t;
-        if (hipMalloc(&t->d_leaves, len * esz) != hipSuccess || hipMalloc((void**)&t->d_nodes, (len - 1) * 32) != hipSuccess) { set_error("fri_commit: hipMalloc failed"); return MZK_E_HIP; }
-        MZK_HIP(hipMemcpyAsync(t->d_leaves, cur, len * esz, hipMemcpyDeviceToDevice, s));
-        MZK_HIP(hipMemcpyAsync(t->d_nodes, d_nodes, (len - 1) * 32, hipMemcpyDeviceToDevice, s));
-        if (r == 0 && negative) t->neg.assign(negative, negative + n);
+        if (r == 0 && negative) {
+          // round 0 commits to the UNSANITIZED elements and the fold below canonicalises the codeword in place: the tree keeps
+          // the magnitudes as they were given, in a copy of its own
+          void* own = nullptr;
+          MZK_TRY(dev_alloc(&own, len * esz, "fri_commit: round-0 leaves"));
+          MZK_HIP(hipMemcpyAsync(own, cur, len * esz, hipMemcpyDeviceToDevice, s));
+          t->d_leaves = own; t->owns_leaves = true;
+          t->neg.assign(negative, negative + n);
+        }
         MZK_TRY(merkle_stamp(t, s));
       }
       MZK_HIP(hipStreamSynchronize(s));
@@ -1090,9 +1172,11 @@ static int fri_commit_rounds(int field_id, const uint64_t* codeword, const uint8
     if (last) break;
     if (!h_is_canonical(hf, alpha)) { set_error("fri_commit: challenge of round %d not canonical", r); return MZK_E_RANGE; }
     uint8_t* next = cur + len * esz;
-    MZK_TRY(fri_fold_dev_impl(field_id, cur, len, alpha, of, om, next, s));
+    MZK_TRY(fri_fold_dev_consts(field_id, cur, len, alpha, fc, next, s));
     h_mulmod(hf, om, om, om);
     h_mulmod(hf, of, of, of);
+    fri_fold_consts_square(field_id, &fc);
+    if (trees_out && len >= 2) d_nodes += 4 * (len - 1);        // the next round's digests follow this round's
     cur = next;
     len /= 2;
   }

@@ -1333,6 +1333,42 @@ __global__ void k_fri_fold(const u32* __restrict__ cw, size_t h, Words8 r0_mont,
     r = FeAsm<P>::mul(r, winv);
   }
 }
+// The fold's host-side constants for (offset, omega): 2^-1, offset^-1, omega^-1 (plain) and R mod p.  FRI::commit squares offset and
+// omega from round to round (fri.rs:186-187), and so it may their inverses: one set of inversions per commit instead of per round.
+int fri_fold_consts(int fid, const uint64_t* offset, const uint64_t* omega, FriFoldConsts* fc) {
+  const HostField* hf = host_field(fid);
+  uint64_t two[4] = {2, 0, 0, 0};
+  h_invmod(hf, fc->half, two);
+  h_invmod(hf, fc->oinv, offset);
+  h_invmod(hf, fc->winv, omega);
+  h_powmod_u64(hf, fc->rmod, two, (uint64_t)(29 * (fid == MZK_FIELD_M128 ? 5 : 9)));
+  return MZK_OK;
+}
+void fri_fold_consts_square(int fid, FriFoldConsts* fc) {
+  const HostField* hf = host_field(fid);
+  h_mulmod(hf, fc->oinv, fc->oinv, fc->oinv);
+  h_mulmod(hf, fc->winv, fc->winv, fc->winv);
+}
+int fri_fold_dev_consts(int fid, const void* d_cw, size_t n, const uint64_t* alpha, const FriFoldConsts& fc, void* d_out, hipStream_t s) {
+  const size_t h = n / 2;
+  if (h == 0) return MZK_OK;
+  const HostField* hf = host_field(fid);
+  uint64_t r0[4], winv[4], halfv[4];
+  h_mulmod(hf, r0, fc.half, alpha);
+  h_mulmod(hf, r0, r0, fc.oinv);
+  h_mulmod(hf, r0, r0, fc.rmod); h_mulmod(hf, winv, fc.winv, fc.rmod); h_mulmod(hf, halfv, fc.half, fc.rmod);
+  Words8 r0w, winvw, halfw;
+  to_words(r0, hf->nl, &r0w); to_words(winv, hf->nl, &winvw); to_words(halfv, hf->nl, &halfw);
+  const int per_lane = h >= ((size_t)1 << 20) ? GEN_CHUNK : (h >= ((size_t)1 << 16) ? 4 : 1);
+  const size_t chunks = (h + (size_t)per_lane - 1) / (size_t)per_lane;
+  const unsigned blocks = (unsigned)((chunks + 127) / 128);
+  if (fid == MZK_FIELD_M128)
+    hipLaunchKernelGGL((k_fri_fold<M128Params>), dim3(blocks), dim3(128), 0, s, (const u32*)d_cw, h, r0w, winvw, halfw, (u32*)d_out, per_lane);
+  else
+    hipLaunchKernelGGL((k_fri_fold<FrParams>), dim3(blocks), dim3(128), 0, s, (const u32*)d_cw, h, r0w, winvw, halfw, (u32*)d_out, per_lane);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
 int fri_fold_dev_impl(int fid, const void* d_cw, size_t n, const uint64_t* alpha, const uint64_t* offset, const uint64_t* omega,
                       void* d_out, hipStream_t s) {
   if (fid != MZK_FIELD_FR && fid != MZK_FIELD_M128) { set_error("fri_fold: bad field id %d", fid); return MZK_E_ARG; }
