@@ -1405,8 +1405,12 @@ int fri_fold_dev_impl(int fid, const void* d_cw, size_t n, const uint64_t* alpha
 // domain in and out.  One lane owns DIV_BATCH consecutive elements and inverts them together (Montgomery's
 // trick: running products, ONE Fermat inversion, unwind): ~5 products per element + 1/DIV_BATCH of an inversion.
 constexpr int DIV_BATCH = 16;
+// regs > 1: `regs` numerator vectors (a_stride elements apart) over ONE denominator vector -- the interpolation of several trace
+// registers over one domain divides every register's values by the same Z'(x_i) (ntt.rs:233-242 per register): the lane's inversion
+// serves all of them, out[r * out_stride + i] = a[r * a_stride + i] / b[i].
 template <class P>
-__global__ __launch_bounds__(128) void k_pointwise_div(const u32* __restrict__ a, const u32* __restrict__ b, u32* __restrict__ out, size_t n) {
+__global__ __launch_bounds__(128) void k_pointwise_div(const u32* __restrict__ a, const u32* __restrict__ b, u32* __restrict__ out, size_t n,
+                                                        size_t regs = 1, size_t a_stride = 0, size_t out_stride = 0) {
   const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * DIV_BATCH;
   if (i0 >= n) return;
   const int len = (int)((n - i0 < (size_t)DIV_BATCH) ? (n - i0) : (size_t)DIV_BATCH);
@@ -1430,9 +1434,11 @@ __global__ __launch_bounds__(128) void k_pointwise_div(const u32* __restrict__ a
       Fe<P> ym = fe_to_mont<P>(y);
       if (zero) ym = fe_one<P>();
       inv = FeAsm<P>::mul(inv, ym);
-      const Fe<P> x = gload<P>(a, i0 + j);
-      const Fe<P> q = fe_reduce<P>(FeAsm<P>::mul(x, yinv));       // plain * Montgomery = plain
-      gstore<P>(out, i0 + j, zero ? fe_zero<P>() : q);
+      for (size_t r = 0; r < regs; r++) {
+        const Fe<P> x = gload<P>(a, r * a_stride + i0 + j);
+        const Fe<P> q = fe_reduce<P>(FeAsm<P>::mul(x, yinv));       // plain * Montgomery = plain
+        gstore<P>(out, r * out_stride + i0 + j, zero ? fe_zero<P>() : q);
+      }
     }
   }
 }
@@ -1478,6 +1484,15 @@ int pointwise_div_dev(int fid, const void* d_a, const void* d_b, void* d_out, si
   const unsigned blocks = (unsigned)(((n + DIV_BATCH - 1) / DIV_BATCH + 127) / 128);
   if (fid == MZK_FIELD_M128) hipLaunchKernelGGL((k_pointwise_div<M128Params>), dim3(blocks), dim3(128), 0, s, (const u32*)d_a, (const u32*)d_b, (u32*)d_out, n);
   else hipLaunchKernelGGL((k_pointwise_div<FrParams>), dim3(blocks), dim3(128), 0, s, (const u32*)d_a, (const u32*)d_b, (u32*)d_out, n);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+// `regs` numerator vectors (a_stride elements apart) over one denominator vector; results out_stride elements apart
+int pointwise_div_shared_dev(int fid, const void* d_a, size_t a_stride, const void* d_b, void* d_out, size_t out_stride, size_t n, size_t regs, hipStream_t s) {
+  if (n == 0 || regs == 0) return MZK_OK;
+  const unsigned blocks = (unsigned)(((n + DIV_BATCH - 1) / DIV_BATCH + 127) / 128);
+  if (fid == MZK_FIELD_M128) hipLaunchKernelGGL((k_pointwise_div<M128Params>), dim3(blocks), dim3(128), 0, s, (const u32*)d_a, (const u32*)d_b, (u32*)d_out, n, regs, a_stride, out_stride);
+  else hipLaunchKernelGGL((k_pointwise_div<FrParams>), dim3(blocks), dim3(128), 0, s, (const u32*)d_a, (const u32*)d_b, (u32*)d_out, n, regs, a_stride, out_stride);
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }

@@ -618,8 +618,9 @@ static int interpolate_impl(int fid, const uint64_t* domain, const uint64_t* val
     const size_t g = std::min(group, batch - r0);
     MZK_HIP(hipMemcpyAsync(d_vals.p, values + r0 * n * nl, g * n * esz, hipMemcpyHostToDevice, s));
     MZK_HIP(hipMemsetAsync(d_ws.p, 0, g * T.N * esz, s));
-    for (size_t r = 0; r < g; r++)
-      MZK_TRY(pointwise_div_dev(fid, (const char*)d_vals.p + r * n * esz, d_zp.p, (char*)d_ws.p + r * T.N * esz, n, s));
+    // all registers of the group in one launch: they divide by the same Z'(d_i), inverted once per lane (one launch and one
+    // inversion chain per REGISTER before: 16 x 60 us of a 3.5-ms batch of 16 registers of 2^14 points)
+    MZK_TRY(pointwise_div_shared_dev(fid, d_vals.p, n, d_zp.p, d_ws.p, T.N, n, g, s));
     MZK_TRY(T.combine(d_dom.p, d_ws.p, d_ress.p, g));
     MZK_HIP(hipMemcpyAsync(res.data(), d_ress.p, g * T.N * esz, hipMemcpyDeviceToHost, s));
     MZK_HIP(hipStreamSynchronize(s));
