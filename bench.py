@@ -599,8 +599,9 @@ def main():
             return None
         res = {}
         L.mzk_srs_table_bytes.restype = ctypes.c_size_t
-        for lg, count in ((10, 256), (12, 64)):
+        for lg, count in ((10, 256), (12, 64), (14, 16)):
             nn = 1 << lg
+            with_direct = lg <= 12          # direct tables of 2^14 powers would be 14 GiB at 10 bits: the bucket pass only
             key = "%d_x_2^%d" % (count, lg)
             hs = ctypes.c_void_p()
             try:
@@ -637,6 +638,12 @@ def main():
                 cf_h = cf.cpu().numpy().view(np.uint64).reshape(count, nn, 4)
                 got = mz.array_to_points(o_many.cpu().numpy().view(np.uint64).reshape(count, 8))
                 e["first_and_last_equal_oracle"] = bool(got[0] == orc.msm_fast(cf_h[0], pts_h) and got[-1] == orc.msm_fast(cf_h[-1], pts_h))
+                e["table_bytes_after_the_pass"] = int(L.mzk_srs_table_bytes(hs))     # from 2^13 coefficients on: + the 12-bit tables the pass builds once
+                e["us_per_commit"] = e["one_call_ms"] / count * 1e3
+                e["speedup_over_one_at_a_time"] = e["one_at_a_time_ms"] / e["one_call_ms"]
+                if not with_direct:
+                    res[key] = e
+                    continue
                 b0 = L.mzk_srs_table_bytes(hs)            # the window tables alone (a direct build replaces the previous direct tables)
                 for bits in (10, 12):
                     torch.cuda.synchronize()

@@ -1038,6 +1038,7 @@ void mzk_srs_free(mzk_srs* srs) {
   if (!srs) return;
   if (srs->d_points_mont) (void)hipFree(srs->d_points_mont);
   if (srs->d_direct) (void)hipFree(srs->d_direct);
+  if (srs->d_tables_wide) (void)hipFree(srs->d_tables_wide);
   delete srs;
 }
 int mzk_kzg_commit_srs(const mzk_srs* srs, const uint64_t* coef, size_t n, uint64_t out_xy[8]) {
@@ -1170,7 +1171,7 @@ int mzk_srs_window_bits(const mzk_srs* srs) { return (srs && srs->has_tables) ? 
 int mzk_srs_direct_bits(const mzk_srs* srs) { return (srs && srs->d_direct) ? srs->direct_bits : 0; }
 size_t mzk_srs_table_bytes(const mzk_srs* srs) {
   if (!srs) return 0;
-  return srs->n * 64 * srs->table_rows() + srs->direct_bytes;
+  return srs->n * 64 * srs->table_rows() + srs->direct_bytes + srs->wide_bytes;
 }
 
 // The _many forms take the grid pass whenever the handle can (any count >= 1); the _batch forms from MANY_MIN_COUNT polynomials

@@ -249,6 +249,13 @@ struct mzk_srs {
   void* d_direct = nullptr;
   int direct_bits = 0;
   size_t direct_bytes = 0;
+  // optional, built by the first grid-batched pass that wants them (msm_many_srs): a SECOND set of window tables, wider than the
+  // handle's own.  A handle of <= 2^14 points keeps 8- / 10-bit tables for the sortless single commit; a batch of LONG polynomials
+  // (>= 2^13 coefficients) is 20 % faster over 12-bit ones (shorter accumulate, and a bucket's partials are a chain a quarter as
+  // long in the segment combine: profiles/round5_many_commit_widths.txt).  22 x n points: 22 MiB at 2^14.
+  mutable void* d_tables_wide = nullptr;
+  mutable int wide_bits = 0;
+  mutable size_t wide_bytes = 0;
   int kind() const { return has_tables ? (mzk::MSM_PTS_TABLES | (window_bits << 8) | (sets << 16)) : (int)mzk::MSM_PTS_MONT; }
   size_t table_rows() const { return has_tables ? (size_t)mzk::msm_table_rows(window_bits, sets) : 2; }   // no tables: P_i, then phi(P_i) (GLV layout)
 };

@@ -2060,8 +2060,24 @@ int msm_direct_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elem
   return MZK_OK;
 }
 bool srs_many_capable(const mzk_srs* srs) { return srs->d_direct != nullptr || (srs->has_tables && srs->sets == 1 && msm_many_supported(srs->window_bits)); }
+// Window width of the bucket pass by polynomial length (same-box sweep, profiles/round5_many_commit_widths.txt: 16 x 2^14 0.884 ms at
+// 10 bits, 0.707 at 12; 32 x 2^13 0.842 / 0.713; 64 x 2^12 0.730 / 0.752; 128 x 2^11 0.755 / 1.236): 12 bits from 2^13 coefficients on.
+constexpr size_t MANY_WIDE_FROM = (size_t)1 << 13;
+constexpr int MANY_WIDE_BITS = 12;
 int msm_many_srs(const mzk_srs* srs, const void* d_scalars, size_t n, size_t stride_elems, size_t count, void* d_out, hipStream_t s) {
   if (srs->d_direct) return msm_direct_many_dev_impl(d_scalars, n, stride_elems, count, srs->d_direct, srs->direct_bits, srs->n, d_out, s);
+  if (n >= MANY_WIDE_FROM && srs->has_tables && srs->sets == 1 && srs->window_bits < MANY_WIDE_BITS) {
+    if (!srs->d_tables_wide) {       // once per handle: row 0 of its own tables are the prepared points
+      const size_t bytes = (size_t)msm_table_windows(MANY_WIDE_BITS) * srs->n * 64;
+      void* t = nullptr;
+      if (dev_alloc(&t, bytes, "wide window tables of the grid-batched pass") == MZK_OK) {
+        const int rc = msm_build_tables(srs->d_points_mont, srs->n, t, MANY_WIDE_BITS, s);
+        if (rc != MZK_OK) { (void)hipFree(t); return rc; }
+        srs->d_tables_wide = t; srs->wide_bits = MANY_WIDE_BITS; srs->wide_bytes = bytes;
+      }      // no memory for them: the handle's own tables serve (slower, same points)
+    }
+    if (srs->d_tables_wide) return msm_many_dev_impl(d_scalars, n, stride_elems, count, srs->d_tables_wide, srs->wide_bits, srs->n, d_out, s);
+  }
   return msm_many_dev_impl(d_scalars, n, stride_elems, count, srs->d_points_mont, srs->window_bits, srs->n, d_out, s);
 }
 

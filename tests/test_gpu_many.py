@@ -78,7 +78,9 @@ def _skew(coefs, n):
 
 
 @pytest.mark.parametrize("n,count,width", [(1, 3, 1), (7, 1, 1), (100, 9, 1), (256, 33, 1), (1024, 6, 1), (1025, 5, 1), (3000, 7, 1), (4096, 3, 1),
-                                           (5000, 2, 1), (700, 5, 10), (700, 4, 11), (2100, 3, 12), (1500, 3, 13)])
+                                           (5000, 2, 1), (700, 5, 10), (700, 4, 11), (2100, 3, 12), (1500, 3, 13),
+                                           # round 5: from 2^13 coefficients on the pass runs over 12-bit tables the handle builds on first use
+                                           (2049, 6, 1), (8191, 5, 1), (8192, 5, 1), (8193, 6, 1), (16384, 6, 1)])
 def test_many_commits_equal_oracle_and_single_calls(mz, n, count, width):
     """ragged lengths (not a multiple of the 1024-coefficient chunks, of the lanes, of anything), count = 1, skewed scalar
     rows, infinity among the points, every table width the grid-batched pass supports"""
@@ -94,6 +96,16 @@ def test_many_commits_equal_oracle_and_single_calls(mz, n, count, width):
         want = orc.msm_ref(coefs[k], p) if n <= 300 else orc.msm_fast(coefs[k], p)
         assert got[k] == want, (n, count, width, k)
         assert got[k] == _commit_one(mz, h, coefs[k]), (n, k)
+    if n >= 8192 and width == 1:
+        # the wide tables are the handle's (built once, counted by mzk_srs_table_bytes, used again by the next call; a SHORTER batch
+        # against the same handle keeps to its own tables and a longer prefix than 2^13 takes the wide ones): same points either way
+        L = mz.lib()
+        L.mzk_srs_table_bytes.restype = ctypes.c_size_t
+        assert L.mzk_srs_table_bytes(h) == (26 + 22) * n * 64
+        assert _commit_many(mz, h, coefs) == got
+        flat = coefs.reshape(-1, 4)                  # a batch of SHORTER polynomials out of the same buffer: polynomial k = the k-th run of m coefficients
+        for m in (3000, min(n, 8200)):
+            assert _commit_many(mz, h, coefs[:2], n=m) == [orc.msm_fast(np.ascontiguousarray(flat[k * m:(k + 1) * m]), p[:m]) for k in range(2)], m
     mz.lib().mzk_srs_free(h)
 
 
