@@ -19,6 +19,7 @@
 //   5. k_halve_step / k_reduce_tail   sum_b (b+1) B_b per bucket set by in-place halving
 //   6. k_window_combine (mzk_msm_tail.hip)  Horner over the bucket sets, XYZZ -> affine (one inversion)
 #include <stdlib.h>
+#include <type_traits>
 #include "mzk_common.h"
 #include "mzk_ec.h"
 #include "mzk_coop.h"
@@ -457,11 +458,16 @@ constexpr int COARSE_BINS = 1 << COARSE_LOG;
 constexpr int COARSE_PER_WG = 4096;
 constexpr int SORT2_THREADS = 1024;
 // C: compile-time window width of the merged layout (walk_digits_merged), 0 = any layout by walk_digits
-template <int C>
+// CL: log2 of the coarse bins.  256 everywhere but at 20-bit windows (2^19 buckets, the default from 2^22 points on): there 1024, so
+// that a bin covers 512 buckets instead of 2048 and a fine workgroup's round of 8192 records leaves in runs of ~16 entries (64 bytes)
+// instead of ~4 -- k_fine_scatter cost 7 ps per entry at 2048 buckets per bin against 3.2 at 17-bit windows (profiles/round5_sort_1024_bins.txt).
+template <int C, int CL = COARSE_LOG>
 __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_count(const u32* __restrict__ scalars, size_t n, DigitLayout L, int key_shift,
                                                                  u32* __restrict__ binhist, int nwg) {
-  __shared__ u32 hist[COARSE_BINS];
-  if (threadIdx.x < COARSE_BINS) hist[threadIdx.x] = 0;
+  constexpr int BINS = 1 << CL;
+  static_assert(BINS <= SORT2_THREADS, "one lane per bin");
+  __shared__ u32 hist[BINS];
+  if (threadIdx.x < BINS) hist[threadIdx.x] = 0;
   __syncthreads();
   const size_t lo = (size_t)blockIdx.x * COARSE_PER_WG;
   const size_t hi = (lo + COARSE_PER_WG < n) ? lo + COARSE_PER_WG : n;
@@ -481,7 +487,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_count(const u32* __res
     }
   }
   __syncthreads();
-  if (threadIdx.x < COARSE_BINS) binhist[(size_t)threadIdx.x * nwg + blockIdx.x] = hist[threadIdx.x];
+  if (threadIdx.x < BINS) binhist[(size_t)threadIdx.x * nwg + blockIdx.x] = hist[threadIdx.x];
 }
 // Intermediate records of the two-level sort: (payload, fine key).  The 8-byte form always works; when the point
 // reference, the fine key and the sign fit 32 bits together (up to 2^20 pairs in both layouts) the 4-byte form halves the
@@ -531,20 +537,30 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter(const u32* __r
 // against the 72 us of the isolated 8-byte stores above (profiles/r04g_*) -- the scatter, not the digits, is what that kernel
 // waits for.  Per chunk: histogram by LDS atomics, one-wave exclusive scan, placement through LDS cursors, copy-out.
 // Merged layout with a compile-time window width only (the digits are walked twice).
-constexpr int STAGE_RECORDS = 16 * SORT2_THREADS;       // per chunk: NWIN <= 16 records per scalar
-template <class REC, int C>
+// records staged per chunk of 1024 scalars: NWIN <= 16 per scalar; with 1024 bins (two-byte bin tags) the 13 windows of the 20-bit layout
+constexpr int stage_records(int C, int CL) { return (CL > 8 ? (254 / C + 1) : 16) * SORT2_THREADS; }
+constexpr size_t stage_lds_bytes(int C, int CL, size_t rec_bytes) {
+  return (size_t)stage_records(C, CL) * (rec_bytes + (CL > 8 ? 2 : 1)) + (size_t)(4 * (1 << CL) + 1) * 4;
+}
+constexpr int STAGE_RECORDS = 16 * SORT2_THREADS;
+template <class REC, int C, int CL = COARSE_LOG>
 __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter_staged(const u32* __restrict__ scalars, size_t n, size_t table_stride, int key_shift,
                                                                           u32 fine_mask, int fb, const u32* __restrict__ binbase, int nwg,
                                                                           typename REC::T* __restrict__ tmp) {
   typedef typename REC::T R;
+  constexpr int COARSE_BINS = 1 << CL;           // (shadows the 256 of the other kernels)
+  constexpr int STAGE_RECORDS = stage_records(C, CL);
+  constexpr int PER_LANE = COARSE_BINS / 64;     // bins per lane in the one-wave scan
+  typedef typename std::conditional<(CL > 8), unsigned short, unsigned char>::type BinTag;
+  static_assert(stage_lds_bytes(C, CL, sizeof(R)) <= (size_t)160 * 1024, "staging must fit the LDS");
   extern __shared__ __attribute__((aligned(16))) u32 lds_stage[];
   R* stage = reinterpret_cast<R*>(lds_stage);                                   // [STAGE_RECORDS]
-  unsigned char* stage_bin = reinterpret_cast<unsigned char*>(stage + STAGE_RECORDS);   // [STAGE_RECORDS]
+  BinTag* stage_bin = reinterpret_cast<BinTag*>(stage + STAGE_RECORDS);         // [STAGE_RECORDS]
   u32* cursor = reinterpret_cast<u32*>(stage_bin + STAGE_RECORDS);              // [COARSE_BINS] running position of (bin, this workgroup) in tmp
   u32* hist = cursor + COARSE_BINS;                                             // [COARSE_BINS] records of the chunk per bin, then placement cursors
   u32* loff = hist + COARSE_BINS;                                               // [COARSE_BINS + 1] chunk-local exclusive offsets
   u32* gpos = loff + COARSE_BINS + 1;                                           // [COARSE_BINS] destination of the chunk's run of each bin
-  static_assert(COARSE_BINS == 256, "one wave scans four bins per lane");
+  static_assert(COARSE_BINS % 64 == 0 && COARSE_BINS <= SORT2_THREADS, "one wave scans PER_LANE bins per lane; one lane per bin elsewhere");
   const int tid = threadIdx.x;
   if (tid < COARSE_BINS) cursor[tid] = binbase[(size_t)tid * nwg + blockIdx.x];
   const size_t lo = (size_t)blockIdx.x * COARSE_PER_WG;
@@ -562,16 +578,19 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter_staged(const u
     __syncthreads();
     if (i < hi) walk_digits_merged<C>(w[k], table_stride, i, [&](int, u32 key, u32) { counter_inc_agg(hist, key >> key_shift); });
     __syncthreads();
-    if (tid < 64) {                      // exclusive scan of the 256 counts by one wave: four bins per lane
-      const u32 c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
-      u32 incl = c0 + c1 + c2 + c3;
+    if (tid < 64) {                      // exclusive scan of the bin counts by one wave: PER_LANE consecutive bins per lane
+      u32 c[PER_LANE], sum = 0;
+#pragma unroll
+      for (int q = 0; q < PER_LANE; q++) { c[q] = hist[PER_LANE * tid + q]; sum += c[q]; }
+      u32 incl = sum;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
         const u32 up = (u32)__shfl_up((int)incl, d, 64);
         if (tid >= d) incl += up;
       }
-      const u32 base = incl - (c0 + c1 + c2 + c3);
-      loff[4 * tid] = base; loff[4 * tid + 1] = base + c0; loff[4 * tid + 2] = base + c0 + c1; loff[4 * tid + 3] = base + c0 + c1 + c2;
+      u32 run = incl - sum;
+#pragma unroll
+      for (int q = 0; q < PER_LANE; q++) { loff[PER_LANE * tid + q] = run; run += c[q]; }
       if (tid == 63) loff[COARSE_BINS] = incl;
     }
     __syncthreads();
@@ -586,7 +605,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter_staged(const u
       const u32 bin = key >> key_shift;
       const u32 pos = counter_inc_agg(hist, bin);
       stage[pos] = REC::make(payload, key & fine_mask, fb);
-      stage_bin[pos] = (unsigned char)bin;
+      stage_bin[pos] = (BinTag)bin;
     });
     __syncthreads();
     const u32 total = loff[COARSE_BINS];
@@ -1350,22 +1369,28 @@ int msm_build_tables(const void* d_points_mont, size_t n, void* d_tables, int wi
 struct SortArgs {
   const u32* scalars; size_t n; DigitLayout L; int key_shift; u32 fine_mask; int fb; u32* binhist; int nwg; void* tmp; int F; int S;
   u32* finehist; u32* scan3; size_t sb_f; size_t n_fine; u32* offsets; u32* entries; size_t NBtot;
+  int cl;           // log2 of the coarse bins: COARSE_LOG, or 10 for the 20-bit merged layout
 };
 template <class REC>
 static int sort_records(const SortArgs& a, hipStream_t s) {
   typedef typename REC::T R;
   const int cw = (a.L.merged && !a.L.glv && a.L.sets == 1 && (a.L.c == 16 || a.L.c == 17 || a.L.c == 20)) ? a.L.c : 0;     // the default widths by SRS size
   static const int env_staged = tune_int("MZK_COARSE_STAGED", 1);      // 0: A/B against the direct stores
-  if (cw != 0 && env_staged != 0) {
-    const size_t lds = (size_t)STAGE_RECORDS * (sizeof(R) + 1) + (size_t)(4 * COARSE_BINS + 1) * 4;
+  const unsigned bins = 1u << a.cl;
+  if (cw != 0 && (env_staged != 0 || a.cl != COARSE_LOG)) {
+    const size_t lds = stage_lds_bytes(cw, a.cl, sizeof(R));
     bool& attr = ctx().attr_done[sizeof(R) == 4 ? ATTR_COARSE_STAGED4 : ATTR_COARSE_STAGED8];
     if (!attr) {
       MZK_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<REC, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       MZK_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<REC, 17>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       MZK_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<REC, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      MZK_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<REC, 20, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr = true;
     }
-    if (cw == 20)
+    if (cw == 20 && a.cl == 10)
+      hipLaunchKernelGGL((k_coarse_scatter_staged<REC, 20, 10>), dim3(a.nwg), dim3(SORT2_THREADS), lds, s, a.scalars, a.n, a.L.table_stride, a.key_shift, a.fine_mask,
+                         a.fb, (const u32*)a.binhist, a.nwg, (R*)a.tmp);
+    else if (cw == 20)
       hipLaunchKernelGGL((k_coarse_scatter_staged<REC, 20>), dim3(a.nwg), dim3(SORT2_THREADS), lds, s, a.scalars, a.n, a.L.table_stride, a.key_shift, a.fine_mask,
                          a.fb, (const u32*)a.binhist, a.nwg, (R*)a.tmp);
     else if (cw == 17)
@@ -1389,7 +1414,7 @@ static int sort_records(const SortArgs& a, hipStream_t s) {
   else
     hipLaunchKernelGGL((k_coarse_scatter<REC, 0>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb,
                        (const u32*)a.binhist, a.nwg, (R*)a.tmp);
-  hipLaunchKernelGGL((k_fine_count<REC>), dim3(COARSE_BINS, a.S), dim3(SORT2_THREADS), 0, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg, a.F, a.S,
+  hipLaunchKernelGGL((k_fine_count<REC>), dim3(bins, a.S), dim3(SORT2_THREADS), 0, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg, a.F, a.S,
                      a.fb, a.finehist);
   MZK_TRY(launch_exclusive_scan((const u32*)a.finehist, a.finehist, a.n_fine, a.scan3, s));
   if (a.F <= STAGE_F_MAX) {
@@ -1399,10 +1424,10 @@ static int sort_records(const SortArgs& a, hipStream_t s) {
       MZK_HIP(hipFuncSetAttribute((const void*)k_fine_scatter<REC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       staged_attr = true;
     }
-    hipLaunchKernelGGL((k_fine_scatter<REC>), dim3(COARSE_BINS, a.S), dim3(SORT2_THREADS), lds, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg, a.F,
+    hipLaunchKernelGGL((k_fine_scatter<REC>), dim3(bins, a.S), dim3(SORT2_THREADS), lds, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg, a.F,
                        a.S, a.fb, (const u32*)a.finehist, a.offsets, a.entries, a.NBtot);
   } else {
-    hipLaunchKernelGGL((k_fine_scatter_direct<REC>), dim3(COARSE_BINS, a.S), dim3(SORT2_THREADS), 0, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg,
+    hipLaunchKernelGGL((k_fine_scatter_direct<REC>), dim3(bins, a.S), dim3(SORT2_THREADS), 0, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg,
                        a.F, a.S, a.fb, (const u32*)a.finehist, a.offsets, a.entries, a.NBtot);
   }
   MZK_HIP(hipGetLastError());
@@ -1526,7 +1551,11 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   // two-level sort when the bucket space is a power of two >= 2^12 (merged layout always; generic at c = 16)
   const size_t NBtot = NB;
   // (small inputs keep the one-pass kernels, except that the merged one-pass histogram must fit the LDS: 2^15 buckets)
-  const bool two_level = (NBtot & (NBtot - 1)) == 0 && NBtot >= 4096 && (NBtot / COARSE_BINS) <= (size_t)FINE_MAX &&
+  // coarse bins: 256, or 1024 for the 20-bit merged layout (2^19 buckets: 512 per bin instead of 2048; k_coarse_count)
+  static const int env_cl20 = tune_int("MZK_COARSE_LOG_20", 10);      // tuning build: 8 = the 256-bin form at 20 bits too
+  const int cl = (L.merged && !L.glv && L.sets == 1 && L.c == 20 && env_cl20 == 10) ? 10 : COARSE_LOG;
+  const size_t cbins = (size_t)1 << cl;
+  const bool two_level = (NBtot & (NBtot - 1)) == 0 && NBtot >= 4096 && (NBtot / cbins) <= (size_t)FINE_MAX &&
                          (n >= 4096 || ((point_kind & 0xff) == 2 && NBtot > ((size_t)1 << 15)));
   MZK_TRY(ws_get(WS_MSM_CURSOR, E_max * (two_level ? 8 : 4), (void**)&ranks));
   MZK_TRY(ws_get(WS_MSM_ENTRIES, E_max * 4, (void**)&entries));
@@ -1543,26 +1572,28 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   if (two_level) {
     int kb = 0;
     while (((size_t)1 << kb) < NBtot) kb++;
-    const int key_shift = kb - COARSE_LOG;
-    const int F = (int)(NBtot / COARSE_BINS);
+    const int key_shift = kb - cl;
+    const int F = (int)(NBtot / cbins);
     const u32 fine_mask = (u32)F - 1u;
     const int nwg = (int)((n + COARSE_PER_WG - 1) / COARSE_PER_WG);
     // records per fine workgroup: 32 Ki for the merged layout, 16 Ki for the generic one (measured: generic sort 0.250 -> 0.230 ms
     // at 2^20, merged equal within noise from 16 Ki to 64 Ki: profiles/r04m_*), 128 Ki when a bin has thousands of buckets
     // (the [bucket][sub] histogram that is scanned afterwards has NB * S entries)
     static const int env_per_fine = tune_int("MZK_PER_FINE", 0);      // tuning: tools/timing/window_sweep.py
-    const size_t per_fine = env_per_fine > 0 ? (size_t)env_per_fine : ((NBtot / COARSE_BINS >= 4096) ? 131072 : (L.glv ? 16384 : 32768));
-    int S = (int)((E_max / COARSE_BINS + per_fine - 1) / per_fine);
+    const size_t per_fine = env_per_fine > 0 ? (size_t)env_per_fine : ((NBtot / cbins >= 4096) ? 131072 : (L.glv ? 16384 : 32768));
+    int S = (int)((E_max / cbins + per_fine - 1) / per_fine);
     if (S < 2) S = 2;
     if (S > 64) S = 64;
-    const size_t n_coarse = (size_t)COARSE_BINS * nwg, n_fine = NBtot * (size_t)S;
+    const size_t n_coarse = cbins * nwg, n_fine = NBtot * (size_t)S;
     u32 *binhist, *finehist;
     MZK_TRY(ws_get(WS_MSM_WGHIST, (n_coarse + 1 + n_fine + 1) * 4, (void**)&binhist));
     finehist = binhist + n_coarse + 1;
     const size_t sb_f = (n_fine + SCAN_BLOCK - 1) / SCAN_BLOCK;
     u32* scan2;
     MZK_TRY(ws_get(WS_MSM_SCAN, (scan_scratch_words(n_coarse) + scan_scratch_words(n_fine) + 4) * 4, (void**)&scan2));
-    if (L.merged && !L.glv && L.sets == 1 && L.c == 20)
+    if (cl == 10)
+      hipLaunchKernelGGL((k_coarse_count<20, 10>), dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
+    else if (L.merged && !L.glv && L.sets == 1 && L.c == 20)
       hipLaunchKernelGGL(k_coarse_count<20>, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
     else if (L.merged && !L.glv && L.sets == 1 && L.c == 17)
       hipLaunchKernelGGL(k_coarse_count<17>, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
@@ -1577,7 +1608,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     const size_t ref_max = L.merged ? (size_t)msm_table_rows(sh.c, L.sets) * table_stride : L.phi_offset + n;
     const bool compact = ref_max <= ((size_t)1 << (31 - fb));      // references are < ref_max
     SortArgs sa{(const u32*)d_scalars, n, L, key_shift, fine_mask, fb, binhist, nwg, (void*)ranks, F, S, finehist, scan2 + scan_scratch_words(n_coarse) + 2, sb_f, n_fine,
-                offsets, entries, NBtot};
+                offsets, entries, NBtot, cl};
     MZK_TRY(compact ? sort_records<Rec4>(sa, s) : sort_records<Rec8>(sa, s));
   } else if (L.merged) {
     // LDS histogram path (no global atomics)
