@@ -504,10 +504,12 @@ struct Rec4 {   // ref << (fb + 1) | fine << 1 | sign;  needs ref < 2^(31 - fb)
   static __device__ __forceinline__ u32 fine(const T& r, u32 fmask, int) { return (r >> 1) & fmask; }
   static __device__ __forceinline__ u32 payload(const T& r, int fb) { return (r >> (fb + 1)) | ((r & 1u) << 31); }
 };
-template <class REC, int C>
+template <class REC, int C, int CL = COARSE_LOG>
 __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter(const u32* __restrict__ scalars, size_t n, DigitLayout L, int key_shift,
                                                                    u32 fine_mask, int fb, const u32* __restrict__ binbase, int nwg,
                                                                    typename REC::T* __restrict__ tmp) {
+  constexpr int COARSE_BINS = 1 << CL;
+  static_assert(COARSE_BINS <= SORT2_THREADS, "one lane per bin");
   __shared__ u32 cursor[COARSE_BINS];
   if (threadIdx.x < COARSE_BINS) cursor[threadIdx.x] = binbase[(size_t)threadIdx.x * nwg + blockIdx.x];
   __syncthreads();
@@ -1553,6 +1555,8 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   // (small inputs keep the one-pass kernels, except that the merged one-pass histogram must fit the LDS: 2^15 buckets)
   // coarse bins: 256, or 1024 for the 20-bit merged layout (2^19 buckets: 512 per bin instead of 2048; k_coarse_count)
   static const int env_cl20 = tune_int("MZK_COARSE_LOG_20", 10);      // tuning build: 8 = the 256-bin form at 20 bits too
+  // (the generic GLV layout stays at 256 bins: its coarse scatter stores records one by one -- the walk is the GLV split, no staging --
+  // and 512 bins measured slower at 2^22 and 2^24: sort 3.77 -> 3.91 ms, profiles/round5_sort_1024_bins.txt)
   const int cl = (L.merged && !L.glv && L.sets == 1 && L.c == 20 && env_cl20 == 10) ? 10 : COARSE_LOG;
   const size_t cbins = (size_t)1 << cl;
   const bool two_level = (NBtot & (NBtot - 1)) == 0 && NBtot >= 4096 && (NBtot / cbins) <= (size_t)FINE_MAX &&
