@@ -425,6 +425,15 @@ int mzk_init_devices(const int* device_ordinals, int n_devices) {
 // CtxScope switches.  Called from inside a call on the owning thread (a callback), the fast path leaves the current context
 // and the device alone -- the enclosing call owns them.
 int mzk_init(int device_ordinal) {
+  // Idempotent fast path WITHOUT the entry guard: a second host thread's first call during a long call of another
+  // thread used to get MZK_E_BUSY here, where mzk_init had been a harmless no-op.  Reading g_nctx / context 0 is safe against the
+  // only writers (mzk_init_devices, mzk_shutdown: hosts do not run those concurrently with their first calls), nothing is written,
+  // and the caller's HIP device is set for ITS thread only.
+  if (g_nctx > 0 && g_ctxs[0].ready && g_ctxs[0].device == device_ordinal && g_cur == 0) {
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess && (dev == device_ordinal || hipSetDevice(device_ordinal) == hipSuccess)) return MZK_OK;
+    (void)hipGetLastError();
+  }
   mzk::EntryGuard entry;
   if (!entry.ok) return MZK_E_BUSY;
   if (g_nctx > 0 && g_ctxs[0].ready && g_ctxs[0].device == device_ordinal) return entry.nested ? MZK_OK : ctx_select(0);
@@ -1155,7 +1164,12 @@ int mzk_srs_build_direct(mzk_srs* srs, int window_bits, size_t max_bytes, void* 
   int rc = msm_build_direct(srs->d_points_mont, srs->n, c, d, (hipStream_t)stream);
   if (rc == MZK_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = MZK_E_HIP;
   if (rc != MZK_OK) { (void)hipFree(d); return rc; }
-  if (srs->d_direct) (void)hipFree(srs->d_direct);       // (the stream is idle: nothing reads the old tables any more)
+  if (srs->d_direct) {
+    // the old tables may still be read by work enqueued on OTHER streams of the handle's device (the in-flight lanes of the batch
+    // entry points, a caller's second stream): wait for the whole device -- srs_check_ctx above made it the current one -- before freeing
+    (void)hipDeviceSynchronize();
+    (void)hipFree(srs->d_direct);
+  }
   srs->d_direct = d; srs->direct_bits = c; srs->direct_bytes = bytes;
   return MZK_OK;
 }
@@ -1163,6 +1177,8 @@ void mzk_srs_drop_direct(mzk_srs* srs) {
   mzk::EntryGuard entry;
   if (!entry.ok) return;          // another thread is inside a call that may be reading the tables
   if (!srs || !srs->d_direct) return;
+  CtxScope sc(srs->ctx_index);    // the handle's own context and device, whatever is current: synchronise THAT device
+  if (!sc.ok) return;
   (void)hipDeviceSynchronize();
   (void)hipFree(srs->d_direct);
   srs->d_direct = nullptr; srs->direct_bits = 0; srs->direct_bytes = 0;
