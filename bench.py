@@ -33,14 +33,20 @@ def fail_line(n_gpus, msg, **more):
     return 2
 
 
-def recorded_traffic(kernel_prefix):
+def recorded_traffic(kernel_prefix, section="KZG commit 2^20"):
     """FETCH_SIZE + WRITE_SIZE per launch (bytes) of a kernel from the newest profiles/r*_hbm_traffic_pmc.txt that names it in
-    its 2^20 KZG-commit section (written by tools/timing/pmc_summary.py under rocprofv3 --pmc; the bench itself never runs
-    under the profiler).  None if no such record exists."""
+    the given section (`== KZG commit 2^20 ...`, `== generic MSM 2^20 ...`; written by tools/timing/pmc_summary.py under
+    rocprofv3 --pmc; the bench itself never runs under the profiler).  None if no such record exists."""
     import glob, re
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.txt"))):
+        inside = False
         for line in open(path):
+            if line.startswith("== "):
+                inside = section in line
+                continue
+            if not inside:
+                continue
             m = re.match(r"(.*?)\s+launches=.*FETCH_SIZE avg=\s*([0-9.]+) KiB\s+WRITE_SIZE avg=\s*([0-9.]+) KiB", line)
             if m and kernel_prefix in m.group(1):
                 best = {"bytes": int((float(m.group(2)) + float(m.group(3))) * 1024),
@@ -926,6 +932,13 @@ def main():
     roof = hbm_roofline(96.0 * n, acc_ms)
     roof["kernel"] = "k_seg_accumulate"
     roof["algorithmic_bytes_per_launch"] = 96 * n
+    if args.log2n == 20:
+        # the generic layout gathers 2 x 8 window entries per pair from the prepared points and their endomorphism images
+        # (64-byte rows, random: raw counters, see recorded_traffic)
+        tr = recorded_traffic("k_seg_accumulate", section="generic MSM 2^20")
+        if tr is not None:
+            roof["traffic"] = tr["bytes"]
+            roof["traffic_source"] = tr["source"]
     ntt_total_ms = ntt_ph.get("ntt_whole_transform_in_priced_pass", {}).get("avg_ms", float("nan"))
     npass = sum(1 for k in ntt_ph if k.startswith("ntt_pass") and not k.endswith("_in_priced_pass"))
     ntt_roof = hbm_roofline(64.0 * n, ntt_total_ms)
