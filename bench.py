@@ -1197,7 +1197,7 @@ def main():
             err = str(ex)[:300]
         # every rank reaches this point; only fold if all local stages succeeded everywhere
         all_ok = max_over_ranks(0.0 if err is None else 1.0) == 0.0
-        e2e = {"log2_degree": lg, "n_gpus": world,
+        e2e = {"log2_degree": lg, "n_gpus": world, "srs_points_this_rank": hi - lo, "srs_points_total": nn,
                "what": "evaluations -> iNTT -> setup(alpha) -> commit -> open(u), device-resident, MSMs and SRS sharded over the ranks (BASELINE configs[4])"}
         if all_ok:
             barrier_sync()

@@ -60,8 +60,10 @@ def test_multi_rank_line_describes_its_process_group_and_exchanges():
     world_size == N, the nccl backend named for a real run, exchanges > 0, and the sharded transform's bytes per rank and
     exchange = (N - 1) / N * n / N * 32."""
     import glob
-    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r04final_rehearsal_world*_shared_gpu.json")))
+    rounds = sorted({os.path.basename(f)[:8] for f in glob.glob(os.path.join(ROOT, "profiles", "r0*final_rehearsal_world*_shared_gpu.json"))})
+    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", rounds[-1] + "_rehearsal_world*_shared_gpu.json")))       # the newest round's set
     assert len(recs) >= 3, "world-2/4/8 rehearsals missing from profiles/"
+
     for path in recs:
         rec = json.loads([l for l in open(path) if l.startswith("{")][-1])
         N = rec["n_gpus"]
@@ -76,3 +78,11 @@ def test_multi_rank_line_describes_its_process_group_and_exchanges():
         sm = rec["strong_scaling_msm"]
         assert sm["n_gpus"] == N and sm["pairs_per_gpu"] * N == sm["total_pairs"] and sm["trapdoor_identity_holds"] is True
         assert sn["every_part_equals_single_gpu_transform"] is True
+        # the end-to-end leg as well -- the SRS is sharded (each rank builds and commits against ITS powers only), the
+        # partials of commit and open are gathered and folded, and the trapdoor identities hold on the folded points
+        e2e = rec["e2e_kzg"]
+        assert e2e["n_gpus"] == N and "error" not in e2e
+        assert {"intt", "setup_srs_powers", "srs_prepare", "commit_local", "open_local", "gather_and_fold"} <= set(e2e["stages_ms"])
+        assert e2e["trapdoor_identities_hold"] is True and e2e["overlapped_results_identical"] is True
+        if "srs_points_this_rank" in e2e:              # (records from round 5 on)
+            assert e2e["srs_points_total"] == 1 << e2e["log2_degree"] and e2e["srs_points_this_rank"] * N == e2e["srs_points_total"]
