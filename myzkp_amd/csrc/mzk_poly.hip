@@ -304,11 +304,16 @@ struct PolyPool {
 };
 static PolyPool g_poly_pool[MZK_MAX_CTX];
 constexpr size_t POLY_POOL_MAX_BYTES = (size_t)2 << 30;
-void poly_release_pool() {
+void poly_release_plans();
+static void poly_release_free_blocks() {
   PolyPool& pool = g_poly_pool[ctx().index];
   for (auto& b : pool.free_blocks) (void)hipFree(b.p);
   pool.free_blocks.clear();
   pool.bytes = 0;
+}
+void poly_release_pool() {         // shutdown / mzk_trim_workspace: nothing of this file is in use
+  poly_release_plans();            // the cached interpolation plans: their buffers go back into the pool first
+  poly_release_free_blocks();
 }
 struct DevBuf {
   void* p = nullptr;
@@ -334,7 +339,7 @@ struct DevBuf {
     }
     if (hipMalloc(&p, want) != hipSuccess) {
       (void)hipGetLastError();
-      poly_release_pool();                             // out of memory with blocks parked in the pool: give them back and retry
+      poly_release_free_blocks();                      // out of memory with blocks parked in the pool: give them back and retry (cached plans may be in use: they stay)
       if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; set_error("poly: hipMalloc(%zu) failed", want); return MZK_E_HIP; }
     }
     cap = want;
@@ -584,6 +589,76 @@ static int evaluate_impl(int fid, const uint64_t* coef, size_t m, const uint64_t
 // `batch` value vectors over ONE domain (the registers of a trace, fast_stark.rs:203-215): the subproduct tree and the
 // Z'(d_i) are built once, each register costs a pointwise division and one up-sweep.  out: batch rows of n elements
 // (row r holds out_lens[r] coefficients, zero-padded).
+// ---- interpolation plans: what fast_interpolate derives from the domain alone ------------------------------------------------------
+struct InterpPlanBase {
+  int fid = -1;
+  size_t n = 0;
+  std::vector<uint64_t> domain;      // exact host copy: the key
+  uint64_t stamp = 0;
+  size_t bytes = 0;
+  virtual ~InterpPlanBase() {}
+};
+template <class P> struct InterpPlan : InterpPlanBase {
+  PolyTree<P> T;
+  DevBuf d_dom, d_zp;
+};
+static std::vector<InterpPlanBase*> g_interp_plans[MZK_MAX_CTX];
+static uint64_t g_interp_stamp = 0;
+constexpr size_t INTERP_MAX_PLANS = 4;
+constexpr size_t INTERP_MAX_BYTES = (size_t)1 << 30;
+void poly_release_plans() {
+  auto& v = g_interp_plans[ctx().index];
+  for (auto* p : v) delete p;
+  v.clear();
+}
+template <class P>
+static int interp_plan_get(int fid, const uint64_t* domain, size_t n, const uint64_t* root, size_t root_order, hipStream_t s, InterpPlan<P>** out, bool* transient) {
+  *transient = false;
+  auto& v = g_interp_plans[ctx().index];
+  const size_t nl = (size_t)host_field(fid)->nl;
+  for (auto* b : v) {
+    if (b->fid == fid && b->n == n && !memcmp(b->domain.data(), domain, n * nl * 8)) {
+      b->stamp = ++g_interp_stamp;
+      *out = static_cast<InterpPlan<P>*>(b);
+      return MZK_OK;
+    }
+  }
+  const size_t esz = field_bytes(fid);
+  InterpPlan<P>* pl = new InterpPlan<P>();
+  pl->fid = fid; pl->n = n;
+  int rc = tree_init(&pl->T, fid, n, root, root_order, s);
+  DevBuf d_dz;
+  if (rc == MZK_OK) rc = pl->d_dom.alloc(n * esz);
+  if (rc == MZK_OK) rc = d_dz.alloc(n * esz);
+  if (rc == MZK_OK) rc = pl->d_zp.alloc(pl->T.N * esz);
+  if (rc == MZK_OK && hipMemcpyAsync(pl->d_dom.p, domain, n * esz, hipMemcpyHostToDevice, s) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipMemcpyAsync", __FILE__, __LINE__);
+  if (rc == MZK_OK) rc = pl->T.build(pl->d_dom.p, true);
+  if (rc == MZK_OK) {
+    // w_i = v_i / Z'(d_i); a repeated point has Z' = 0 and the reference's division by inverse(0) = 0 (field.rs:209-232)
+    // zeroes its target at the level that separates the two copies (ntt.rs:233-242): w_i = 0 as well
+    hipLaunchKernelGGL((k_derivative<P>), dim3(grid256(n)), dim3(256), 0, s, (const u32*)pl->T.low[pl->T.levels].w(), pl->T.N, pl->T.pad, n, d_dz.w());
+    rc = pl->T.evaluate(d_dz.p, n, pl->d_dom.p, pl->d_zp.p, n);
+  }
+  if (rc != MZK_OK) { (void)hipStreamSynchronize(s); delete pl; return rc; }
+  pl->domain.assign(domain, domain + n * nl);
+  pl->stamp = ++g_interp_stamp;
+  pl->bytes = (size_t)(3 * pl->T.levels + 4) * pl->T.N * esz;
+  size_t total = pl->bytes;
+  for (auto* b : v) total += b->bytes;
+  while (pl->bytes <= INTERP_MAX_BYTES && !v.empty() && (v.size() >= INTERP_MAX_PLANS || total > INTERP_MAX_BYTES)) {      // least recently used first; their buffers return to the pool
+    size_t victim = 0;
+    for (size_t i = 1; i < v.size(); i++) if (v[i]->stamp < v[victim]->stamp) victim = i;
+    (void)hipStreamSynchronize(s);
+    total -= v[victim]->bytes;
+    delete v[victim];
+    v.erase(v.begin() + (long)victim);
+  }
+  if (pl->bytes <= INTERP_MAX_BYTES) v.push_back(pl);
+  else *transient = true;           // too large to keep (2^22 points and up): the caller deletes it after use, as before round 5
+  *out = pl;
+  return MZK_OK;
+}
+
 template <class P>
 static int interpolate_impl(int fid, const uint64_t* domain, const uint64_t* values, size_t n, size_t batch, const uint64_t* root, size_t root_order,
                             uint64_t* out, size_t* out_lens) {
@@ -598,17 +673,21 @@ static int interpolate_impl(int fid, const uint64_t* domain, const uint64_t* val
   }
   hipStream_t s = ctx().stream;
   WsGuard wsg(s);
-  PolyTree<P> T;
   MZK_TRY(check_order_for(n - n / 2, root_order, "fast_interpolate"));        // ntt.rs:219-220
-  MZK_TRY(tree_init(&T, fid, n, root, root_order, s));
-  DevBuf d_dom, d_dz, d_zp;
-  MZK_TRY(d_dom.alloc(n * esz)); MZK_TRY(d_dz.alloc(n * esz)); MZK_TRY(d_zp.alloc(T.N * esz));
-  MZK_HIP(hipMemcpyAsync(d_dom.p, domain, n * esz, hipMemcpyHostToDevice, s));
-  MZK_TRY(T.build(d_dom.p, true));
-  // w_i = v_i / Z'(d_i); a repeated point has Z' = 0 and the reference's division by inverse(0) = 0 (field.rs:209-232)
-  // zeroes its target at the level that separates the two copies (ntt.rs:233-242): w_i = 0 as well
-  hipLaunchKernelGGL((k_derivative<P>), dim3(grid256(n)), dim3(256), 0, s, (const u32*)T.low[T.levels].w(), T.N, T.pad, n, d_dz.w());
-  MZK_TRY(T.evaluate(d_dz.p, n, d_dom.p, d_zp.p, n));
+  // Everything that depends on the DOMAIN alone -- the subproduct tree with its transformed levels, Z'(d_i) -- is a plan, kept per
+  // context like the twiddle tables of a transform: a STARK prover interpolates every trace over the same omicron domain
+  // (fast_stark.rs:209-229), and that half of the work (zerofier tree, Newton inverse, the whole down-sweep) is the same each time.
+  // Keyed by the exact domain (a host copy is compared), not by a hash.
+  InterpPlan<P>* plan = nullptr;
+  bool transient = false;
+  MZK_TRY(interp_plan_get<P>(fid, domain, n, root, root_order, s, &plan, &transient));
+  struct Drop {         // a plan too large for the cache lives for this call only (every exit path; the stream is idle by then or is waited for)
+    InterpPlanBase* p; hipStream_t s;
+    ~Drop() { if (p) { (void)hipStreamSynchronize(s); delete p; } }
+  } drop{transient ? plan : nullptr, s};
+  PolyTree<P>& T = plan->T;
+  DevBuf& d_dom = plan->d_dom;
+  DevBuf& d_zp = plan->d_zp;
   // registers go through the up-sweep in groups (at most 2^24 elements per buffer)
   const size_t group = std::max<size_t>(1, std::min<size_t>(batch, ((size_t)1 << 24) / T.N));
   DevBuf d_vals, d_ws, d_ress;

@@ -152,3 +152,33 @@ def test_batched_interpolation_shares_the_tree_and_equals_single_calls(mz, fid):
     empty = mz.fast_interpolate_batch(fid, np.zeros((0, nl), dtype=np.uint64), np.zeros((3, 0, nl), dtype=np.uint64), orc.root_of(fid, 3), 8)
     assert len(empty) == 3 and all(len(e) == 0 for e in empty)                     # ntt.rs:207-209 per register
     assert mz.fast_interpolate_batch(fid, orc.synth_vector(fid, 1, 4), np.zeros((0, 4, nl), dtype=np.uint64), orc.root_of(fid, 3), 8) == []
+
+
+@pytest.mark.parametrize("fid", [FR, M128])
+def test_interpolation_plans_are_keyed_by_the_exact_domain(mz, fid):
+    """Round 5: what fast_interpolate derives from the domain alone (subproduct tree, Z'(d_i)) is kept per context like a transform's
+    twiddle tables.  The key is the exact domain: the same domain again (other values) reuses the plan and still equals the oracle;
+    a domain that differs in ONE element, the same points in another order, another length and more domains than the cache holds
+    (least recently used out, then back in) each get their own -- every result against the oracle's interpolation (ntt.rs:203-252)."""
+    lg = 9
+    om = orc.root_of(fid, lg)
+    n = 300
+    doms = [orc.synth_vector(fid, 7000 + k, n) for k in range(6)]
+    d1 = doms[0].copy(); d1[n - 1] = doms[1][5]                      # one element changed
+    d2 = np.ascontiguousarray(doms[0][::-1])                          # same set, reversed order
+    d3 = np.ascontiguousarray(doms[0][:257])                          # a prefix: another length
+    order = [doms[0], doms[0], d1, doms[0], d2, d3, doms[1], doms[2], doms[3], doms[4], doms[5], doms[0], d1, doms[5]]
+    for step, dom in enumerate(order):
+        vals = orc.synth_vector(fid, 7100 + step, dom.shape[0])
+        rc, want = orc.fast_interpolate_ref(fid, dom, vals, om, 1 << lg)
+        assert rc == 0
+        got = mz.fast_interpolate(fid, dom, vals, om, 1 << lg)
+        assert got.shape == want.shape and np.array_equal(got, want), step
+    # a batch over a cached domain, and after the caches were dropped
+    vals = np.stack([orc.synth_vector(fid, 7200 + k, n) for k in range(3)])
+    first = mz.fast_interpolate_batch(fid, doms[0], vals, om, 1 << lg)
+    assert mz.trim_workspace() >= 0
+    again = mz.fast_interpolate_batch(fid, doms[0], vals, om, 1 << lg)
+    for a, b, v in zip(first, again, vals):
+        rc, want = orc.fast_interpolate_ref(fid, doms[0], v, om, 1 << lg)
+        assert np.array_equal(a, want) and np.array_equal(b, want)
