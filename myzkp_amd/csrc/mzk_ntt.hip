@@ -123,8 +123,13 @@ __device__ __forceinline__ u32x4_t stream_load16(const u32* p) {
   if (MZK_NTT_NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
   return *reinterpret_cast<const u32x4_t*>(p);
 }
-__device__ __forceinline__ void stream_store16(u32* p, u32x4_t v) {
+// wt: the store goes out write-through at agent scope (`sc1`), so what a pass writes reaches the fabric while the other waves
+// still compute instead of sitting dirty in the XCDs' L2s until the end-of-kernel release flushes it.  A template flag of the pass
+// kernels (a run-time branch around the store cost the 128-VGPR instantiations two to four spilled registers), chosen per transform
+// size by run_plan_geo.
+__device__ __forceinline__ void stream_store16(u32* p, u32x4_t v, bool wt) {
   if (MZK_NTT_NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(p));
+  else if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
   else *reinterpret_cast<u32x4_t*>(p) = v;
 }
 template <class P> __device__ __forceinline__ void gload_words_stream(const u32* __restrict__ g, size_t idx, u32 (&w)[P::NW]) {
@@ -134,14 +139,14 @@ template <class P> __device__ __forceinline__ void gload_words_stream(const u32*
     w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
   }
 }
-template <class P> __device__ __forceinline__ void gstore_stream(u32* __restrict__ g, size_t idx, const Fe<P>& v) {
+template <class P> __device__ __forceinline__ void gstore_stream(u32* __restrict__ g, size_t idx, const Fe<P>& v, bool wt) {
   u32 w[P::NW];
   fe_pack<P>(v, w);
 #pragma unroll
   for (int q = 0; q < P::NW / 4; q++) {
     u32x4_t t;
     t.x = w[4 * q]; t.y = w[4 * q + 1]; t.z = w[4 * q + 2]; t.w = w[4 * q + 3];
-    stream_store16(g + idx * P::NW + 4 * q, t);
+    stream_store16(g + idx * P::NW + 4 * q, t, wt);
   }
 }
 template <class P> __device__ __forceinline__ Fe<P> gload(const u32* __restrict__ g, size_t idx) {
@@ -480,7 +485,7 @@ __device__ __forceinline__ void tile_stages(u32* lds, const u32* twl, int lgn, i
 // of their own.  offset^idx = offset^(j1 M) * offset^col comes from two small per-call tables (pre_row: 2^lgn
 // entries, pre_col: M entries, Montgomery form).
 struct PreArgs { const u32* coef; size_t n_coef; const u32* pre_row; const u32* pre_col; };
-template <class P, bool PRE, class G>
+template <class P, bool PRE, class G, bool WT>
 __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_strided(const u32* __restrict__ in, u32* __restrict__ out,
                                                            const u32* __restrict__ tw_tile,
                                                            const u32* __restrict__ tw_inter, int lgn, int lgM, int lgc, PreArgs pre, int fuse, const u32* __restrict__ tw_shoup) {
@@ -497,6 +502,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_strided(const u32* __rest
   constexpr int UNR = G::TILE / G::NT;          // elements per lane and tile (tile_elems == G::TILE here)
   constexpr int GQ = G::GQ;                     // radix-4 groups per lane: element u = q + GQ v is member v of group q
   static_assert(UNR == 4 * GQ, "whole radix-4 groups per lane");
+  constexpr bool wt = WT;
   const bool fused = fuse_edges<G>(lgn, lgc, fuse);   // first (plain loads only) and last stage pair on registers, next to the global accesses
   // EARLY_TW (M128, one 1024-lane workgroup per CU: 44 of 128 VGPRs in use): the inter-pass twiddles of the lane's four elements are
   // requested right behind its data, at the top of the kernel, and wait in 16 registers.  A 2^20 transform is one tile per CU with
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_strided(const u32* __rest
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const size_t off = ((size_t)(j1 + (u << (lgn - 2))) << lgM) + (ct << lgc) + c;
-          gstore_stream<P>(out, (o << (lgn + lgM)) + off, inter_mul<P>(x[u], fe_unpack<P>(tw[q + GQ * u])));
+          gstore_stream<P>(out, (o << (lgn + lgM)) + off, inter_mul<P>(x[u], fe_unpack<P>(tw[q + GQ * u])), wt);
         }
       }
       return;
@@ -609,7 +615,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_strided(const u32* __rest
       const int k = e >> lgc, c = e & cmask;
       const size_t off = ((size_t)k << lgM) + (ct << lgc) + c;
       const Fe<P> v = lds_load<P, G>(lds, (k << lgc) | c);
-      gstore_stream<P>(out, (o << (lgn + lgM)) + off, inter_mul<P>(v, fe_unpack<P>(tw[u])));
+      gstore_stream<P>(out, (o << (lgn + lgM)) + off, inter_mul<P>(v, fe_unpack<P>(tw[u])), wt);
     }
   }
 }
@@ -618,7 +624,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_strided(const u32* __rest
 // single-pass inverse), canonical output.  The grid may cover a BATCH of transforms stored back to back (row
 // r = blockIdx * 2^lgr + rr belongs to transform r >> lg_rows): the product trees of mzk_poly.hip transform hundreds
 // of small polynomials per launch.
-template <class P, class G>
+template <class P, class G, bool WT>
 __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_last(const u32* __restrict__ in, u32* __restrict__ out,
                                                         const u32* __restrict__ tw_tile, LevelInfo li, int lgn, int lgr,
                                                         int lg_rows, Words8 scale, int has_scale, size_t total_rows, int fuse, const u32* __restrict__ tw_shoup) {
@@ -634,6 +640,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_last(const u32* __restric
   constexpr int UNR = G::TILE / G::NT;
   constexpr int GQ = G::GQ;
   static_assert(UNR == 4 * GQ, "whole radix-4 groups per lane");
+  constexpr bool wt = WT;
   const bool fused = fuse_edges<G>(lgn, lgr, fuse);      // full tile, even number of levels: first and last stage pair on registers
   auto row_base = [&](size_t r) -> size_t {        // first element of logical row r in the previous pass's layout
     size_t rem = r & rowmask, row = 0;
@@ -710,7 +717,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_last(const u32* __restric
       if (r >= total_rows) continue;
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        gstore_stream<P>(out, ((r >> lg_rows) << logn) + (r & rowmask) + ((size_t)(j1 + (u << (lgn - 2))) << lg_rows), final_reduce<P>(x[u], sc, has_scale));
+        gstore_stream<P>(out, ((r >> lg_rows) << logn) + (r & rowmask) + ((size_t)(j1 + (u << (lgn - 2))) << lg_rows), final_reduce<P>(x[u], sc, has_scale), wt);
       }
     }
     return;
@@ -720,7 +727,7 @@ __global__ __launch_bounds__(G::NT, G::WPE) void k_ntt_last(const u32* __restric
     const size_t r = p0 + rr;
     if (r >= total_rows) continue;
     const Fe<P> v = lds_load<P, G>(lds, (k << lgr) | rr);
-    gstore_stream<P>(out, ((r >> lg_rows) << logn) + (r & rowmask) + ((size_t)k << lg_rows), final_reduce<P>(v, sc, has_scale));
+    gstore_stream<P>(out, ((r >> lg_rows) << logn) + (r & rowmask) + ((size_t)k << lg_rows), final_reduce<P>(v, sc, has_scale), wt);
   }
 }
 
@@ -1080,12 +1087,20 @@ static int run_plan_geo(const NttPlan* pl, const u32* d_in, u32* d_out, hipStrea
   ProfScope whole(s, MZK_PH_NTT_TOTAL);
   static const int fuse = tune_int("MZK_NTT_FUSE_EDGES", 1);     // 0: A/B (tools/timing/time_ntt.py)
   static const int shoup = tune_int("MZK_NTT_SHOUP", 1);
+  // write-through stores (stream_store16) for multi-pass transforms whose data is between 2^WT_LO and 2^WT_HI bytes; mask bit 0:
+  // the strided passes, bit 1: the last pass
+  // (same-box map, profiles/round5_ntt_write_through_ab.txt: Fr 2^17..2^19 -1..-13 %, M128 2^17..2^22 -2..-16 %; below 2 MiB and
+  // from 32 MiB (Fr) / 128 MiB (M128) up it gains nothing or costs 3-9 %: the working set no longer sits in the Infinity Cache)
+  static const int wt_lo = tune_int("MZK_NTT_WT_LO", 21), wt_hi = tune_int("MZK_NTT_WT_HI", P::NW == 4 ? 26 : 24), wt_mask = tune_int("MZK_NTT_WT_MASK", 3);
+  const size_t bytes = (batch << logn) * sizeof(u32) * P::NW;
+  const bool wt_on = li.nlev > 1 && bytes >= ((size_t)1 << wt_lo) && bytes <= ((size_t)1 << wt_hi);
+  const bool wt_s = wt_on && (wt_mask & 1), wt_l = wt_on && (wt_mask & 2);
   if constexpr (G::TL != TILE_LOG) {        // tiles above 64 KiB of LDS need the attribute, once per context and instantiation
     bool& done = ctx().attr_done[P::NW == 4 ? (G::TWG ? ATTR_NTT_LARGE_M128_2WG : ATTR_NTT_LARGE_M128) : ATTR_NTT_LARGE_FR];
     if (!done) {
-      MZK_HIP(hipFuncSetAttribute((const void*)k_ntt_strided<P, true, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      MZK_HIP(hipFuncSetAttribute((const void*)k_ntt_strided<P, false, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      MZK_HIP(hipFuncSetAttribute((const void*)k_ntt_last<P, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      const void* fns[] = {(const void*)k_ntt_strided<P, true, G, false>, (const void*)k_ntt_strided<P, false, G, false>, (const void*)k_ntt_last<P, G, false>,
+                           (const void*)k_ntt_strided<P, true, G, true>,  (const void*)k_ntt_strided<P, false, G, true>,  (const void*)k_ntt_last<P, G, true>};
+      for (const void* f : fns) MZK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       done = true;
     }
   }
@@ -1100,12 +1115,11 @@ static int run_plan_geo(const NttPlan* pl, const u32* d_in, u32* d_out, hipStrea
     const unsigned blocks = (unsigned)(batch << (logn - G::TL));      // `o` in the kernel runs over the batch too
     {
       ProfScope ps(s, MZK_PH_NTT_PASS0 + t);
-      if (t == 0 && pre)
-        hipLaunchKernelGGL((k_ntt_strided<P, true, G>), dim3(blocks), dim3(G::NT), G::template lds_bytes<P>(lgn), s, src, tmp, pl->tw_tile[t],
-                           pl->tw_inter[t], lgn, lgM, lgc, *pre, fuse, shoup ? pl->tw_shoup[t] : nullptr);
-      else
-        hipLaunchKernelGGL((k_ntt_strided<P, false, G>), dim3(blocks), dim3(G::NT), G::template lds_bytes<P>(lgn), s, src, tmp, pl->tw_tile[t],
-                           pl->tw_inter[t], lgn, lgM, lgc, PreArgs{nullptr, 0, nullptr, nullptr}, fuse, shoup ? pl->tw_shoup[t] : nullptr);
+      const bool with_pre = t == 0 && pre;
+      auto* k = with_pre ? (wt_s ? k_ntt_strided<P, true, G, true> : k_ntt_strided<P, true, G, false>)
+                         : (wt_s ? k_ntt_strided<P, false, G, true> : k_ntt_strided<P, false, G, false>);
+      hipLaunchKernelGGL(k, dim3(blocks), dim3(G::NT), G::template lds_bytes<P>(lgn), s, src, tmp, pl->tw_tile[t], pl->tw_inter[t], lgn, lgM, lgc,
+                         with_pre ? *pre : PreArgs{nullptr, 0, nullptr, nullptr}, fuse, shoup ? pl->tw_shoup[t] : nullptr);
     }
     src = tmp;
     lg_after = lgM;
@@ -1118,7 +1132,7 @@ static int run_plan_geo(const NttPlan* pl, const u32* d_in, u32* d_out, hipStrea
     while (lgr > 0 && ((size_t)1 << lgr) > total_rows) lgr--;
     const unsigned blocks = (unsigned)((total_rows + ((size_t)1 << lgr) - 1) >> lgr);
     ProfScope ps(s, MZK_PH_NTT_PASS0 + li.nlev - 1);
-    hipLaunchKernelGGL((k_ntt_last<P, G>), dim3(blocks), dim3(G::NT), G::template lds_bytes<P>(lgn), s, src, d_out,
+    hipLaunchKernelGGL((wt_l ? k_ntt_last<P, G, true> : k_ntt_last<P, G, false>), dim3(blocks), dim3(G::NT), G::template lds_bytes<P>(lgn), s, src, d_out,
                        pl->tw_tile[li.nlev - 1], li, lgn, lgr, lg_rows, pl->last_scale, pl->has_last_scale, total_rows, fuse,
                        shoup ? pl->tw_shoup[li.nlev - 1] : nullptr);
   }
