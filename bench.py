@@ -647,6 +647,23 @@ def main():
                 e["table_bytes_after_the_pass"] = int(L.mzk_srs_table_bytes(hs))     # from 2^13 coefficients on: + the 12-bit tables the pass builds once
                 e["us_per_commit"] = e["one_call_ms"] / count * 1e3
                 e["speedup_over_one_at_a_time"] = e["one_at_a_time_ms"] / e["one_call_ms"]
+                if lg == 10:
+                    # the same batch on 31-byte coefficients (the DAS callers chunk their data into 31-byte field elements,
+                    # das/avail.rs:88-98): the top window of every scalar is empty but for the carry of the signed digits, which
+                    # all lands in one bucket per polynomial (mzk_msm.hip bucket_end / HEAVY_SLOTS)
+                    cf31 = cf.clone()
+                    cf31.view(-1, 4)[:, 3] &= (1 << 56) - 1
+                    o31 = torch.zeros(count * 8, dtype=torch.int64, device=dev)
+
+                    def many31():
+                        check(L.mzk_kzg_commit_srs_many_dev(hs, dptr(cf31), ctypes.c_size_t(nn), ctypes.c_size_t(count), dptr(o31), stream))
+                    d31 = {"one_call_ms": clock(many31, max(K, 30))}
+                    c31_h = cf31.cpu().numpy().view(np.uint64).reshape(count, nn, 4)
+                    g31 = mz.array_to_points(o31.cpu().numpy().view(np.uint64).reshape(count, 8))
+                    d31["first_and_last_equal_oracle"] = bool(g31[0] == orc.msm_fast(c31_h[0], pts_h) and g31[-1] == orc.msm_fast(c31_h[-1], pts_h))
+                    d31["us_per_commit"] = d31["one_call_ms"] / count * 1e3
+                    e["coefficients_of_31_bytes"] = d31
+                    del cf31, o31
                 if not with_direct:
                     res[key] = e
                     continue

@@ -917,7 +917,19 @@ __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ 
 // Buckets with more than HEAVY_SLOTS partials (skewed scalars: bit vectors, repeated values) would be one long
 // serial chain; they are queued in `heavy` (count at heavy[0], bucket ids from heavy[1]) and summed by a whole
 // workgroup each (k_seg_combine_heavy).
-constexpr u32 HEAVY_SLOTS = 32;
+// 16, not 32 (round 5): uniform scalars give a bucket 2 - 9 partials on every path, and the signed digits of SHORT scalars put the carry
+// out of their last non-zero window into bucket 0 of the window above (248-bit coefficients at 8-bit windows: bucket 0 of every
+// polynomial holds three times the entries of the others, a chain of 24 in a kernel that is as long as its longest chain)
+constexpr u32 HEAVY_SLOTS = 16;
+// end of bucket b's entries.  The one-kernel sort of the grid-batched commitments (k_many_sort1) leaves a tail of sentinels behind the
+// LAST bucket of every polynomial's fixed-capacity region; `tails` (one word per polynomial, or null) is where the real entries end,
+// so that the sentinel-only segments are not summed as a chain of identity partials (short coefficients -- the 31-byte chunks of the
+// reference's DAS callers -- leave ~1100 sentinels per 1024-coefficient polynomial: nine extra dependent additions in a kernel
+// that is as long as its longest chain, 73 -> 148 us at 256 x 2^10)
+__device__ __forceinline__ u32 bucket_end(const u32* __restrict__ offsets, const u32* __restrict__ tails, int lg_nb, size_t b) {
+  if (tails && (b & (((size_t)1 << lg_nb) - 1)) == (((size_t)1 << lg_nb) - 1)) return tails[b >> lg_nb];
+  return offsets[b + 1];
+}
 __device__ __forceinline__ bool defer_heavy(size_t b, size_t s0, size_t s1, u32* __restrict__ heavy, bool leader) {
   if (s1 - s0 + 1 <= HEAVY_SLOTS) return false;
   if (leader) heavy[1 + atomicAdd(&heavy[0], 1u)] = (u32)b;
@@ -939,14 +951,14 @@ __global__ __launch_bounds__(128) void k_seg_combine_wide(const u32* __restrict_
   xyzz_gstore(buckets, b, acc);
 }
 __global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slots, const u32* __restrict__ offsets, u32* __restrict__ buckets,
-                                                      size_t nbuckets, u32 seg, u32* __restrict__ heavy) {
+                                                      size_t nbuckets, u32 seg, u32* __restrict__ heavy, const u32* __restrict__ tails, int lg_nb) {
   // one DPP quad per bucket: a bucket's partials form a serial chain of additions (about nine at 2^20 merged),
   // so the quad-cooperative addition cuts the kernel's latency; the quad also splits the 128-byte records.
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t b = tid >> 2;
   const int lane = (int)(tid & 3);
   if (b >= nbuckets) return;
-  const u32 o0 = offsets[b], o1 = offsets[b + 1];
+  const u32 o0 = offsets[b], o1 = bucket_end(offsets, tails, lg_nb, b);
   Xyzz acc = xyzz_inf();
   if (o1 > o0) {
     const size_t s0 = (size_t)(o0 / seg) + b, s1 = (size_t)((o1 - 1) / seg) + b;
@@ -959,13 +971,14 @@ __global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slo
 constexpr int HEAVY_THREADS = 256;
 constexpr int HEAVY_QUADS = HEAVY_THREADS / 4;
 __global__ __launch_bounds__(HEAVY_THREADS) void k_seg_combine_heavy(const u32* __restrict__ slots, const u32* __restrict__ offsets,
-                                                                      u32* __restrict__ buckets, u32 seg, const u32* __restrict__ heavy) {
+                                                                      u32* __restrict__ buckets, u32 seg, const u32* __restrict__ heavy,
+                                                                      const u32* __restrict__ tails, int lg_nb) {
   __shared__ __attribute__((aligned(16))) u32 sh[HEAVY_QUADS * 32];
   const u32 count = heavy[0];
   const int lane = threadIdx.x & 3, quad = threadIdx.x >> 2;
   for (u32 h = blockIdx.x; h < count; h += gridDim.x) {
     const size_t b = heavy[1 + h];
-    const u32 o0 = offsets[b], o1 = offsets[b + 1];
+    const u32 o0 = offsets[b], o1 = bucket_end(offsets, tails, lg_nb, b);
     const size_t s0 = (size_t)(o0 / seg) + b, s1 = (size_t)((o1 - 1) / seg) + b;
     Xyzz acc = xyzz_inf();
     for (size_t sl = s0 + quad; sl <= s1; sl += HEAVY_QUADS) acc = xyzz_add_quad(acc, xyzz_gload_raw_quad(slots, sl, lane), lane);
@@ -1657,8 +1670,8 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   if (NB >= ((size_t)1 << wide_min_log))
     hipLaunchKernelGGL(k_seg_combine_wide, dim3((unsigned)((NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy);
   else
-    hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy);
-  hipLaunchKernelGGL(k_seg_combine_heavy, dim3(512), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)offsets, buckets, seg, (const u32*)heavy);
+    hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy, (const u32*)nullptr, 0);
+  hipLaunchKernelGGL(k_seg_combine_heavy, dim3(512), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)offsets, buckets, seg, (const u32*)heavy, (const u32*)nullptr, 0);
   MZK_HIP(hipGetLastError());
   prof_end(s, MZK_PH_MSM_SEG_COMBINE);
 
@@ -1748,8 +1761,8 @@ __global__ __launch_bounds__(MANY_THREADS) void k_many_scatter(const u32* __rest
 // Polynomials of at most MANY_CHUNK coefficients: count, scan and scatter in ONE launch.  Workgroup j owns polynomial j and the entry
 // region [j CAP, (j + 1) CAP), CAP = n NWIN: LDS histogram (first walk), exclusive scan inside the workgroup, bucket offsets
 // j CAP + prefix (no global scan: the regions have a fixed size), placement through LDS cursors (second walk), and the unused tail
-// of the region -- zero digits emit nothing -- filled with sentinels, which belong to the polynomial's last bucket and are skipped
-// by k_seg_accumulate<.., SENT>.  One coefficient per lane (1024 lanes: at 256 polynomials the kernel is one workgroup per CU, i.e.
+// of the region -- zero digits emit nothing -- filled with sentinels, which k_seg_accumulate<.., SENT> skips and bucket_end (tails[j]) keeps
+// out of the last bucket's sum.  One coefficient per lane (1024 lanes: at 256 polynomials the kernel is one workgroup per CU, i.e.
 // latency) and the sorted region staged in LDS (<= 128 KiB) and copied out as one stream: **19 us** at 256 x 2^10 against 17 + 10 +
 // 35 us and three more launch gaps for the count / scan / scatter form (placed directly into global memory it was 42 us: 32
 // isolated four-byte stores per lane).  Longer polynomials keep the three-launch form: their buckets span several chunks.
@@ -1757,7 +1770,7 @@ constexpr int SORT1_THREADS = 1024;
 constexpr int SORT1_PER_LANE = MANY_CHUNK / SORT1_THREADS;
 template <int C>
 __global__ __launch_bounds__(SORT1_THREADS) void k_many_sort1(const u32* __restrict__ scalars, size_t n, size_t stride_words, size_t table_stride, u32 cap,
-                                                              u32* __restrict__ offsets, size_t npoly, u32* __restrict__ entries) {
+                                                              u32* __restrict__ offsets, size_t npoly, u32* __restrict__ entries, u32* __restrict__ tails) {
   constexpr int NB = 1 << (C - 1);
   constexpr int PER = (NB + SORT1_THREADS - 1) / SORT1_THREADS;      // counters per lane in the scan
   __shared__ u32 hist[NB];
@@ -1800,6 +1813,7 @@ __global__ __launch_bounds__(SORT1_THREADS) void k_many_sort1(const u32* __restr
     if (b < NB) { const u32 c = hist[b]; hist[b] = run; offsets[j * NB + b] = base + run; run += c; }       // hist becomes the cursor
   }
   if (j + 1 == npoly && tid == 0) offsets[npoly * NB] = (u32)(npoly * cap);
+  if (tid == 0) tails[j] = base + total;          // where the sentinels begin: bucket_end
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < SORT1_PER_LANE; k++) {
@@ -1854,7 +1868,9 @@ int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size
     MZK_TRY(ws_get(WS_MSM_BUCKETS, NBtot * 128, (void**)&buckets));
     MZK_TRY(ws_get(WS_MSM_SLOTS, nslots * SLOT_WORDS * 4 + heavy_words * 4, (void**)&slots));
     compact = offs;
+    u32* tails = nullptr;                   // one-kernel sort only: end of every polynomial's real entries (bucket_end)
     if (nch > 1) MZK_TRY(ws_get(WS_MSM_OFFSETS, (NBtot + 1) * 4, (void**)&compact));
+    else MZK_TRY(ws_get(WS_MSM_OFFSETS, cnt * 4, (void**)&tails));
     u32* heavy = slots + nslots * SLOT_WORDS;
     prof_begin(s, MZK_PH_MSM_SORT);
     MZK_HIP(hipMemsetAsync(heavy, 0, 8, s));
@@ -1874,7 +1890,7 @@ int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size
 #define MZK_MANY_CASE(C) case C:                                                                                                                    \
       if (one_kernel_sort) {                                                                                                                         \
         hipLaunchKernelGGL((k_many_sort1<C>), dim3(nwg), dim3(SORT1_THREADS), n * (size_t)nwin * 4, s, sc, n, stride_elems * 8, table_stride,       \
-                           (u32)(n * (size_t)nwin), offs, cnt, entries);                                                                             \
+                           (u32)(n * (size_t)nwin), offs, cnt, entries, tails);                                                                           \
         break;                                                                                                                                       \
       }                                                                                                                                              \
       hipLaunchKernelGGL((k_many_count<C>), dim3(nwg), dim3(MANY_THREADS), 0, s, sc, n, stride_elems * 8, nch, offs);                                \
@@ -1895,8 +1911,8 @@ int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size
                          slots, NBtot, seg);
     prof_end(s, MZK_PH_MSM_ACCUMULATE);
     prof_begin(s, MZK_PH_MSM_SEG_COMBINE);
-    hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NBtot + 127) / 128)), dim3(128), 0, s, slots, (const u32*)compact, buckets, NBtot, seg, heavy);
-    hipLaunchKernelGGL(k_seg_combine_heavy, dim3(512), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)compact, buckets, seg, (const u32*)heavy);
+    hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NBtot + 127) / 128)), dim3(128), 0, s, slots, (const u32*)compact, buckets, NBtot, seg, heavy, (const u32*)tails, lgB);
+    hipLaunchKernelGGL(k_seg_combine_heavy, dim3(512), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)compact, buckets, seg, (const u32*)heavy, (const u32*)tails, lgB);
     MZK_HIP(hipGetLastError());
     prof_end(s, MZK_PH_MSM_SEG_COMBINE);
     prof_begin(s, MZK_PH_MSM_REDUCE);

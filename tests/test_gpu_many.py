@@ -109,6 +109,28 @@ def test_many_commits_equal_oracle_and_single_calls(mz, n, count, width):
     mz.lib().mzk_srs_free(h)
 
 
+@pytest.mark.parametrize("n,count,width,bits", [(1024, 7, 1, 248), (1024, 5, 1, 64), (1000, 6, 1, 9), (300, 9, 1, 248), (1024, 5, 10, 248), (700, 5, 12, 130),
+                                                (1024, 4, 13, 248), (4096, 3, 1, 248)])
+def test_many_commits_of_short_coefficients(mz, n, count, width, bits):
+    """the reference's DAS callers commit to 31-byte chunks (das/avail.rs:88-98), so the top windows of every scalar are
+    zero and the fixed-capacity entry regions of the one-kernel sort end in a long run of sentinels.  Those are kept out of the last
+    bucket's sum (bucket_end, mzk_msm.hip); same points as the oracle and as the single call, whatever the coefficient width."""
+    p = orc.synth_points(77 + n + bits, n)
+    h = _srs_ex(mz, p, width)
+    coefs = np.stack([orc.synth_vector(FR, 4100 + 17 * k + bits, n) for k in range(count)])
+    top, rem = bits // 64, bits % 64
+    coefs[:, :, top + 1:] = 0
+    coefs[:, :, top] &= np.uint64((1 << rem) - 1)
+    if count > 2:
+        coefs[2][:] = 0                              # a polynomial with no entry at all: its region is sentinels only
+        coefs[1][1:] = 0                             # and one with a single coefficient
+    got = _commit_many(mz, h, coefs)
+    for k in range(count):
+        assert got[k] == (orc.msm_ref(coefs[k], p) if n <= 300 else orc.msm_fast(coefs[k], p)), (n, width, bits, k)
+        assert got[k] == _commit_one(mz, h, coefs[k]), (n, k)
+    mz.lib().mzk_srs_free(h)
+
+
 @pytest.mark.parametrize("n,count,bits", [(1, 2, 8), (255, 3, 9), (256, 5, 10), (257, 4, 11), (1000, 6, 12), (1024, 5, 10), (2500, 3, 8), (5000, 2, 0)])
 def test_many_commits_over_direct_tables(mz, n, count, bits):
     """mzk_srs_build_direct: the same batches with no buckets at all -- every multiple of every window-table row gathered

@@ -1,7 +1,8 @@
 """Grid-batched commitments of many short polynomials (mzk_kzg_commit_srs_many_dev) against the same batch one commit at a
 time: ms per batch, us per commit, the per-phase split of the pass.
-    python tools/timing/many_commit.py [lg_n:count[:width[:direct]],...]      width: 1 = default window tables, 8..22 that width;
-direct: 0 = none, 8..12 = direct tables of that width (mzk_srs_build_direct)"""
+    python tools/timing/many_commit.py [lg_n:count[:width[:direct[:bits]]],...]      width: 1 = default window tables, 8..22 that width;
+direct: 0 = none, 8..12 = direct tables of that width (mzk_srs_build_direct); bits: coefficients below 2^bits (the reference's DAS
+callers commit to 31-byte chunks: 248), default full-width"""
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -17,10 +18,13 @@ for i in range(32):
 shapes = sys.argv[1] if len(sys.argv) > 1 else "10:256,12:64,8:1024,14:16,10:256:8,10:256:11"
 for spec in shapes.split(','):
     f = [int(x) for x in spec.split(':')]
-    lg, count, width, direct = f[0], f[1], (f[2] if len(f) > 2 else 1), (f[3] if len(f) > 3 else 0)
+    lg, count, width, direct, bits = f[0], f[1], (f[2] if len(f) > 2 else 1), (f[3] if len(f) > 3 else 0), (f[4] if len(f) > 4 else 256)
     n = 1 << lg
     sc = torch.empty(n * count * 4, dtype=torch.int64, device=dev); pt = torch.empty(n * 8, dtype=torch.int64, device=dev)
     L.mzk_synth_field_dev(0, ctypes.c_uint64(1), ctypes.c_size_t(n * count), ctypes.c_void_p(sc.data_ptr()), st)
+    if bits < 256:
+        assert bits > 192
+        sc.view(-1, 4)[:, 3] &= (1 << (bits - 192)) - 1
     L.mzk_synth_g1_points_dev(ctypes.c_uint64(2), ctypes.c_size_t(n), ctypes.c_void_p(pt.data_ptr()), st)
     h = ctypes.c_void_p()
     assert L.mzk_srs_from_device_ex(ctypes.c_void_p(pt.data_ptr()), ctypes.c_size_t(n), width, ctypes.byref(h), st) == 0, L.mzk_last_error()
@@ -58,6 +62,6 @@ for spec in shapes.split(','):
         L.mzk_prof_read(i, ctypes.byref(ms), ctypes.byref(cnt))
         if cnt.value: split.append("%s %.3f" % (nm, ms.value / 10))
     L.mzk_prof_enable(0)
-    print("%4d x 2^%-2d (tables: %s): many %.3f ms = %.2f us per commit | one at a time %.3f ms = %.1f us per commit | %.1fx | same points: %s | %s"
-          % (count, lg, ("default" if width == 1 else "%d-bit" % width) + note, res[0], res[0] / count * 1e3, res[1], res[1] / count * 1e3, res[1] / res[0], same, "  ".join(split)), flush=True)
+    print("%4d x 2^%-2d%s (tables: %s): many %.3f ms = %.2f us per commit | one at a time %.3f ms = %.1f us per commit | %.1fx | same points: %s | %s"
+          % (count, lg, "" if bits == 256 else " %d-bit coefficients" % bits, ("default" if width == 1 else "%d-bit" % width) + note, res[0], res[0] / count * 1e3, res[1], res[1] / count * 1e3, res[1] / res[0], same, "  ".join(split)), flush=True)
     L.mzk_srs_free(h)
