@@ -915,7 +915,7 @@ __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ 
 // pass 2: buckets[b] = sum of slots [offsets[b] / seg + b, (offsets[b+1] - 1) / seg + b]   (inclusive end:
 // the last entry of bucket b is offsets[b+1]-1)
 // Buckets with more than HEAVY_SLOTS partials (skewed scalars: bit vectors, repeated values) would be one long
-// serial chain; they are queued in `heavy` (count at heavy[0], bucket ids from heavy[1]) and summed by a whole
+// serial chain; they are queued in `heavy` (count at heavy[0], then (bucket id, end of entries) pairs) and summed by a whole
 // workgroup each (k_seg_combine_heavy).
 // 16, not 32 (round 5): uniform scalars give a bucket 2 - 9 partials on every path, and the signed digits of SHORT scalars put the carry
 // out of their last non-zero window into bucket 0 of the window above (248-bit coefficients at 8-bit windows: bucket 0 of every
@@ -930,9 +930,10 @@ __device__ __forceinline__ u32 bucket_end(const u32* __restrict__ offsets, const
   if (tails && (b & (((size_t)1 << lg_nb) - 1)) == (((size_t)1 << lg_nb) - 1)) return tails[b >> lg_nb];
   return offsets[b + 1];
 }
-__device__ __forceinline__ bool defer_heavy(size_t b, size_t s0, size_t s1, u32* __restrict__ heavy, bool leader) {
+// (the list holds pairs: bucket id and the end of its entries as the deferring kernel saw it, bucket_end)
+__device__ __forceinline__ bool defer_heavy(size_t b, size_t s0, size_t s1, u32 o1, u32* __restrict__ heavy, bool leader) {
   if (s1 - s0 + 1 <= HEAVY_SLOTS) return false;
-  if (leader) heavy[1 + atomicAdd(&heavy[0], 1u)] = (u32)b;
+  if (leader) { const u32 i = atomicAdd(&heavy[0], 1u); heavy[1 + 2 * i] = (u32)b; heavy[2 + 2 * i] = o1; }
   return true;
 }
 // one lane per bucket: with 2^19 buckets of one or two partials each (generic layout) the kernel is bound by
@@ -945,7 +946,7 @@ __global__ __launch_bounds__(128) void k_seg_combine_wide(const u32* __restrict_
   Xyzz acc = xyzz_inf();
   if (o1 > o0) {
     const size_t s0 = (size_t)(o0 / seg) + b, s1 = (size_t)((o1 - 1) / seg) + b;
-    if (defer_heavy(b, s0, s1, heavy, true)) return;
+    if (defer_heavy(b, s0, s1, o1, heavy, true)) return;
     for (size_t sl = s0; sl <= s1; sl++) acc = xyzz_add_with<FeAsm>(acc, xyzz_gload_raw(slots, sl));
   }
   xyzz_gstore(buckets, b, acc);
@@ -962,7 +963,7 @@ __global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slo
   Xyzz acc = xyzz_inf();
   if (o1 > o0) {
     const size_t s0 = (size_t)(o0 / seg) + b, s1 = (size_t)((o1 - 1) / seg) + b;
-    if (defer_heavy(b, s0, s1, heavy, lane == 0)) return;       // quad-uniform
+    if (defer_heavy(b, s0, s1, o1, heavy, lane == 0)) return;       // quad-uniform
     acc = xyzz_gload_raw_quad(slots, s0, lane);
     for (size_t sl = s0 + 1; sl <= s1; sl++) acc = xyzz_add_quad(acc, xyzz_gload_raw_quad(slots, sl, lane), lane);
   }
@@ -971,14 +972,13 @@ __global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slo
 constexpr int HEAVY_THREADS = 256;
 constexpr int HEAVY_QUADS = HEAVY_THREADS / 4;
 __global__ __launch_bounds__(HEAVY_THREADS) void k_seg_combine_heavy(const u32* __restrict__ slots, const u32* __restrict__ offsets,
-                                                                      u32* __restrict__ buckets, u32 seg, const u32* __restrict__ heavy,
-                                                                      const u32* __restrict__ tails, int lg_nb) {
+                                                                      u32* __restrict__ buckets, u32 seg, const u32* __restrict__ heavy) {
   __shared__ __attribute__((aligned(16))) u32 sh[HEAVY_QUADS * 32];
   const u32 count = heavy[0];
   const int lane = threadIdx.x & 3, quad = threadIdx.x >> 2;
   for (u32 h = blockIdx.x; h < count; h += gridDim.x) {
-    const size_t b = heavy[1 + h];
-    const u32 o0 = offsets[b], o1 = bucket_end(offsets, tails, lg_nb, b);
+    const size_t b = heavy[1 + 2 * h];
+    const u32 o0 = offsets[b], o1 = heavy[2 + 2 * h];
     const size_t s0 = (size_t)(o0 / seg) + b, s1 = (size_t)((o1 - 1) / seg) + b;
     Xyzz acc = xyzz_inf();
     for (size_t sl = s0 + quad; sl <= s1; sl += HEAVY_QUADS) acc = xyzz_add_quad(acc, xyzz_gload_raw_quad(slots, sl, lane), lane);
@@ -1559,7 +1559,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   const u32 seg = (u32)seg_sz;
   const size_t T = (E_max + seg_sz - 1) / seg_sz;
   const size_t nslots = T + NB + 1;
-  const size_t heavy_words = 4 + (T + NB) / HEAVY_SLOTS;         // count + at most (T + NB) / 33 heavy buckets
+  const size_t heavy_words = 4 + 2 * ((T + NB) / HEAVY_SLOTS);   // count + at most (T + NB) / 17 heavy buckets, two words each
   u32 *counts, *offsets, *ranks, *entries, *scan_tmp, *buckets, *slots;
   MZK_TRY(ws_get(WS_MSM_COUNTS, NB * 4, (void**)&counts));
   MZK_TRY(ws_get(WS_MSM_OFFSETS, (NB + 1) * 4, (void**)&offsets));
@@ -1671,7 +1671,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     hipLaunchKernelGGL(k_seg_combine_wide, dim3((unsigned)((NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy);
   else
     hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy, (const u32*)nullptr, 0);
-  hipLaunchKernelGGL(k_seg_combine_heavy, dim3(512), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)offsets, buckets, seg, (const u32*)heavy, (const u32*)nullptr, 0);
+  hipLaunchKernelGGL(k_seg_combine_heavy, dim3(512), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)offsets, buckets, seg, (const u32*)heavy);
   MZK_HIP(hipGetLastError());
   prof_end(s, MZK_PH_MSM_SEG_COMBINE);
 
@@ -1860,7 +1860,7 @@ int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size
     const u32 seg = (u32)seg_sz;
     const size_t T = (E_max + seg_sz - 1) / seg_sz;
     const size_t nslots = T + NBtot + 1;
-    const size_t heavy_words = 4 + (T + NBtot) / HEAVY_SLOTS;
+    const size_t heavy_words = 4 + 2 * ((T + NBtot) / HEAVY_SLOTS);
     u32 *offs, *compact, *entries, *scan_tmp, *buckets, *slots;
     MZK_TRY(ws_get(WS_MSM_COUNTS, (ncnt + 1) * 4, (void**)&offs));
     MZK_TRY(ws_get(WS_MSM_ENTRIES, E_max * 4, (void**)&entries));
@@ -1912,7 +1912,7 @@ int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size
     prof_end(s, MZK_PH_MSM_ACCUMULATE);
     prof_begin(s, MZK_PH_MSM_SEG_COMBINE);
     hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NBtot + 127) / 128)), dim3(128), 0, s, slots, (const u32*)compact, buckets, NBtot, seg, heavy, (const u32*)tails, lgB);
-    hipLaunchKernelGGL(k_seg_combine_heavy, dim3(512), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)compact, buckets, seg, (const u32*)heavy, (const u32*)tails, lgB);
+    hipLaunchKernelGGL(k_seg_combine_heavy, dim3(512), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)compact, buckets, seg, (const u32*)heavy);
     MZK_HIP(hipGetLastError());
     prof_end(s, MZK_PH_MSM_SEG_COMBINE);
     prof_begin(s, MZK_PH_MSM_REDUCE);
