@@ -930,10 +930,17 @@ __device__ __forceinline__ u32 bucket_end(const u32* __restrict__ offsets, const
   if (tails && (b & (((size_t)1 << lg_nb) - 1)) == (((size_t)1 << lg_nb) - 1)) return tails[b >> lg_nb];
   return offsets[b + 1];
 }
-// (the list holds pairs: bucket id and the end of its entries as the deferring kernel saw it, bucket_end)
+// Layout of `heavy`: [0] count, [1] unused, [2, 2 + HEAVY_GRID) arrival counters of k_seg_combine_heavy's shared buckets (zeroed with
+// the count, one memset), then (bucket id, end of its entries as the deferring kernel saw it -- bucket_end) pairs, then HEAVY_GRID
+// XYZZ records of scratch for the workgroups that share a bucket.
+constexpr int HEAVY_GRID = 512;
+constexpr int HEAVY_HDR = 2 + HEAVY_GRID;
+constexpr size_t HEAVY_CLEAR_BYTES = (size_t)HEAVY_HDR * 4;
+__host__ __device__ constexpr size_t heavy_list_words(size_t max_heavy) { return HEAVY_HDR + 2 * max_heavy + 2; }
+__host__ __device__ constexpr size_t heavy_total_words(size_t max_heavy) { return heavy_list_words(max_heavy) + (size_t)HEAVY_GRID * 32 + 8; }
 __device__ __forceinline__ bool defer_heavy(size_t b, size_t s0, size_t s1, u32 o1, u32* __restrict__ heavy, bool leader) {
   if (s1 - s0 + 1 <= HEAVY_SLOTS) return false;
-  if (leader) { const u32 i = atomicAdd(&heavy[0], 1u); heavy[1 + 2 * i] = (u32)b; heavy[2 + 2 * i] = o1; }
+  if (leader) { const u32 i = atomicAdd(&heavy[0], 1u); heavy[HEAVY_HDR + 2 * i] = (u32)b; heavy[HEAVY_HDR + 2 * i + 1] = o1; }
   return true;
 }
 // one lane per bucket: with 2^19 buckets of one or two partials each (generic layout) the kernel is bound by
@@ -971,29 +978,76 @@ __global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slo
 }
 constexpr int HEAVY_THREADS = 256;
 constexpr int HEAVY_QUADS = HEAVY_THREADS / 4;
-__global__ __launch_bounds__(HEAVY_THREADS) void k_seg_combine_heavy(const u32* __restrict__ slots, const u32* __restrict__ offsets,
-                                                                      u32* __restrict__ buckets, u32 seg, const u32* __restrict__ heavy) {
-  __shared__ __attribute__((aligned(16))) u32 sh[HEAVY_QUADS * 32];
-  const u32 count = heavy[0];
-  const int lane = threadIdx.x & 3, quad = threadIdx.x >> 2;
-  for (u32 h = blockIdx.x; h < count; h += gridDim.x) {
-    const size_t b = heavy[1 + 2 * h];
-    const u32 o0 = offsets[b], o1 = heavy[2 + 2 * h];
-    const size_t s0 = (size_t)(o0 / seg) + b, s1 = (size_t)((o1 - 1) / seg) + b;
-    Xyzz acc = xyzz_inf();
-    for (size_t sl = s0 + quad; sl <= s1; sl += HEAVY_QUADS) acc = xyzz_add_quad(acc, xyzz_gload_raw_quad(slots, sl, lane), lane);
-    xyzz_gstore_quad(sh, quad, acc, lane);
-    __syncthreads();
-    for (int off = HEAVY_QUADS / 2; off >= 1; off >>= 1) {
-      if (quad < off) {
-        const Xyzz x = xyzz_gload_quad(sh, quad, lane), y = xyzz_gload_quad(sh, quad + off, lane);
-        xyzz_gstore_quad(sh, quad, xyzz_add_quad(x, y, lane), lane);
-      }
-      __syncthreads();
+// the workgroup's HEAVY_QUADS partial sums (one per quad, in sh) -> sh[0]
+__device__ __forceinline__ void heavy_tree(u32* sh, const Xyzz& acc, int quad, int lane) {
+  xyzz_gstore_quad(sh, quad, acc, lane);
+  __syncthreads();
+  for (int off = HEAVY_QUADS / 2; off >= 1; off >>= 1) {
+    if (quad < off) {
+      const Xyzz x = xyzz_gload_quad(sh, quad, lane), y = xyzz_gload_quad(sh, quad + off, lane);
+      xyzz_gstore_quad(sh, quad, xyzz_add_quad(x, y, lane), lane);
     }
-    if (quad == 0) xyzz_gstore_quad(buckets, b, xyzz_gload_quad(sh, 0, lane), lane);
     __syncthreads();
   }
+}
+// Many heavy buckets: one workgroup each, in turn.  FEW of them (at most half the grid: bit vectors, constant polynomials, all-equal
+// scalars -- one to fifteen buckets holding up to 2^20 entries, i.e. ~17000 partials each): G = grid / count workgroups share a bucket,
+// each sums a contiguous G-th of its partials into a scratch record, and the last one to arrive (a counter per bucket) sums the G
+// records.  One workgroup per bucket made a commit to 2^20 ones 2.0 ms and to 2^20 equal scalars 5.1 ms against 1.5 ms on uniform ones.
+__global__ __launch_bounds__(HEAVY_THREADS) void k_seg_combine_heavy(const u32* __restrict__ slots, const u32* __restrict__ offsets,
+                                                                      u32* __restrict__ buckets, u32 seg, u32* __restrict__ heavy, size_t max_heavy) {
+  __shared__ __attribute__((aligned(16))) u32 sh[HEAVY_QUADS * 32];
+  __shared__ u32 last_arrival;
+  const u32 count = heavy[0];
+  if (count == 0) return;
+  const int lane = threadIdx.x & 3, quad = threadIdx.x >> 2;
+  const u32* list = heavy + HEAVY_HDR;
+  if (2 * count > gridDim.x) {
+    for (u32 h = blockIdx.x; h < count; h += gridDim.x) {
+      const size_t b = list[2 * h];
+      const u32 o0 = offsets[b], o1 = list[2 * h + 1];
+      const size_t s0 = (size_t)(o0 / seg) + b, s1 = (size_t)((o1 - 1) / seg) + b;
+      Xyzz acc = xyzz_inf();
+      for (size_t sl = s0 + quad; sl <= s1; sl += HEAVY_QUADS) acc = xyzz_add_quad(acc, xyzz_gload_raw_quad(slots, sl, lane), lane);
+      heavy_tree(sh, acc, quad, lane);
+      if (quad == 0) xyzz_gstore_quad(buckets, b, xyzz_gload_quad(sh, 0, lane), lane);
+      __syncthreads();
+    }
+    return;
+  }
+  const u32 G = gridDim.x / count;
+  const u32 h = blockIdx.x / G, part = blockIdx.x % G;
+  if (h >= count) return;
+  u32* scratch = heavy + heavy_list_words(max_heavy);          // record h G + part
+  const size_t b = list[2 * h];
+  const u32 o0 = offsets[b], o1 = list[2 * h + 1];
+  const size_t s0 = (size_t)(o0 / seg) + b, s1 = (size_t)((o1 - 1) / seg) + b;
+  if (s1 - s0 + 1 <= 4 * HEAVY_QUADS) {                         // a bucket of a few partials per quad: sharing it costs a second tree and
+    if (part != 0) return;                                      // two fences (256 buckets of 24 partials: 40 -> 90 us) -- part 0 alone
+    Xyzz acc = xyzz_inf();
+    for (size_t sl = s0 + quad; sl <= s1; sl += HEAVY_QUADS) acc = xyzz_add_quad(acc, xyzz_gload_raw_quad(slots, sl, lane), lane);
+    heavy_tree(sh, acc, quad, lane);
+    if (quad == 0) xyzz_gstore_quad(buckets, b, xyzz_gload_quad(sh, 0, lane), lane);
+    return;
+  }
+  const size_t per = (s1 - s0 + G) / G;                         // ceil(partials / G)
+  const size_t lo = s0 + (size_t)part * per;
+  size_t hi = lo + per - 1;
+  if (hi > s1) hi = s1;
+  Xyzz acc = xyzz_inf();
+  for (size_t sl = lo + quad; sl <= hi; sl += HEAVY_QUADS) acc = xyzz_add_quad(acc, xyzz_gload_raw_quad(slots, sl, lane), lane);
+  heavy_tree(sh, acc, quad, lane);
+  if (quad == 0) xyzz_gstore_quad(scratch, (size_t)h * G + part, xyzz_gload_quad(sh, 0, lane), lane);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last_arrival = (atomicAdd(&heavy[2 + h], 1u) == G - 1) ? 1u : 0u;
+  __syncthreads();
+  if (!last_arrival) return;
+  __threadfence();
+  acc = xyzz_inf();
+  for (u32 q = quad; q < G; q += HEAVY_QUADS) acc = xyzz_add_quad(acc, xyzz_gload_quad(scratch, (size_t)h * G + q, lane), lane);
+  heavy_tree(sh, acc, quad, lane);
+  if (quad == 0) xyzz_gstore_quad(buckets, b, xyzz_gload_quad(sh, 0, lane), lane);
 }
 
 // ---- 5. bucket reduction: sum_b (b+1) B_b per bucket set, by in-place halving ---------------------------
@@ -1559,7 +1613,8 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   const u32 seg = (u32)seg_sz;
   const size_t T = (E_max + seg_sz - 1) / seg_sz;
   const size_t nslots = T + NB + 1;
-  const size_t heavy_words = 4 + 2 * ((T + NB) / HEAVY_SLOTS);   // count + at most (T + NB) / 17 heavy buckets, two words each
+  const size_t max_heavy = (T + NB) / HEAVY_SLOTS + 1;             // at most (T + NB) / 17 buckets hold more than 16 partials
+  const size_t heavy_words = heavy_total_words(max_heavy);
   u32 *counts, *offsets, *ranks, *entries, *scan_tmp, *buckets, *slots;
   MZK_TRY(ws_get(WS_MSM_COUNTS, NB * 4, (void**)&counts));
   MZK_TRY(ws_get(WS_MSM_OFFSETS, (NB + 1) * 4, (void**)&offsets));
@@ -1584,7 +1639,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   // every slot k_seg_combine reads is written by k_seg_accumulate first (slot t + b exists exactly when segment t
   // overlaps bucket b; checked by poisoning the array under the whole GPU suite), so only the heavy-bucket counter
   // needs clearing
-  MZK_HIP(hipMemsetAsync(heavy, 0, 8, s));
+  MZK_HIP(hipMemsetAsync(heavy, 0, HEAVY_CLEAR_BYTES, s));
   const unsigned nblk = (unsigned)((n + 255) / 256);
   if (two_level) {
     int kb = 0;
@@ -1671,7 +1726,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     hipLaunchKernelGGL(k_seg_combine_wide, dim3((unsigned)((NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy);
   else
     hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy, (const u32*)nullptr, 0);
-  hipLaunchKernelGGL(k_seg_combine_heavy, dim3(512), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)offsets, buckets, seg, (const u32*)heavy);
+  hipLaunchKernelGGL(k_seg_combine_heavy, dim3(HEAVY_GRID), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)offsets, buckets, seg, heavy, max_heavy);
   MZK_HIP(hipGetLastError());
   prof_end(s, MZK_PH_MSM_SEG_COMBINE);
 
@@ -1860,7 +1915,8 @@ int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size
     const u32 seg = (u32)seg_sz;
     const size_t T = (E_max + seg_sz - 1) / seg_sz;
     const size_t nslots = T + NBtot + 1;
-    const size_t heavy_words = 4 + 2 * ((T + NBtot) / HEAVY_SLOTS);
+    const size_t max_heavy = (T + NBtot) / HEAVY_SLOTS + 1;
+    const size_t heavy_words = heavy_total_words(max_heavy);
     u32 *offs, *compact, *entries, *scan_tmp, *buckets, *slots;
     MZK_TRY(ws_get(WS_MSM_COUNTS, (ncnt + 1) * 4, (void**)&offs));
     MZK_TRY(ws_get(WS_MSM_ENTRIES, E_max * 4, (void**)&entries));
@@ -1873,7 +1929,7 @@ int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size
     else MZK_TRY(ws_get(WS_MSM_OFFSETS, cnt * 4, (void**)&tails));
     u32* heavy = slots + nslots * SLOT_WORDS;
     prof_begin(s, MZK_PH_MSM_SORT);
-    MZK_HIP(hipMemsetAsync(heavy, 0, 8, s));
+    MZK_HIP(hipMemsetAsync(heavy, 0, HEAVY_CLEAR_BYTES, s));
     const unsigned nwg = (unsigned)(cnt * (size_t)nch);
     const bool one_kernel_sort = nch == 1;      // polynomials of <= 1024 coefficients: fixed-capacity regions, k_many_sort1
     if (one_kernel_sort) {                      // its staged region is up to 128 KiB of LDS: the attribute, once per context
@@ -1912,7 +1968,7 @@ int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size
     prof_end(s, MZK_PH_MSM_ACCUMULATE);
     prof_begin(s, MZK_PH_MSM_SEG_COMBINE);
     hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NBtot + 127) / 128)), dim3(128), 0, s, slots, (const u32*)compact, buckets, NBtot, seg, heavy, (const u32*)tails, lgB);
-    hipLaunchKernelGGL(k_seg_combine_heavy, dim3(512), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)compact, buckets, seg, (const u32*)heavy);
+    hipLaunchKernelGGL(k_seg_combine_heavy, dim3(HEAVY_GRID), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)compact, buckets, seg, heavy, max_heavy);
     MZK_HIP(hipGetLastError());
     prof_end(s, MZK_PH_MSM_SEG_COMBINE);
     prof_begin(s, MZK_PH_MSM_REDUCE);

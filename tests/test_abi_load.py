@@ -124,6 +124,7 @@ def test_no_hot_kernel_spills_registers():
         "k_ntt_last<mzk::FrParams": (24, "same"),
         "k_many_sort1": (64, "per-window histogram bases kept in scalar registers across the walk"),
         "k_open_many": (16, "chunk bookkeeping of the suffix scan"),
+        "k_seg_combine_heavy": (8, "skewed inputs only (returns at once when no bucket was deferred, i.e. on every uniform input); two forms in one kernel -- a workgroup per bucket / several per bucket -- rather than a launch more on the path of every MSM"),
         "k_reduce_tail_row": (128, "single-workgroup latency tail: non-inlined one-shot operations, constants of four Horner chains"),
         "k_direct_finish": (96, "one workgroup per polynomial, latency tail: the non-inlined row operations of the tail"),
         "k_window_combine_row": (64, "one wave, latency tail (112 doublings): same non-inlined row operations"),

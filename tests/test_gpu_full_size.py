@@ -229,3 +229,40 @@ def test_msm_2_22_skewed_scalars_long_segments_and_heavy_buckets(env):
     L.mzk_srs_free(h)
     del pts
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("pattern", ["ones", "equal", "200_values", "600_values", "ones_then_uniform"])
+def test_msm_2_20_every_form_of_the_heavy_bucket_combine(env, pattern):
+    """k_seg_combine_heavy has two forms: few deferred buckets (at most half its grid: bit vectors, constant polynomials) are shared
+    by several workgroups each, with a last-arrival sum over their scratch records; many of them get one workgroup each, in turn.
+    1 bucket (all ones: every workgroup on it), 15 (all scalars equal), 200 values (two or three workgroups per bucket), 600
+    (one per bucket), and ones followed by uniform scalars; both layouts, trapdoor identity."""
+    torch, mz, L, dev, st = env
+    n = 1 << 20
+    alpha = orc.from_limbs(orc.synth_vector(FR, 5511, 1))[0]
+    s = np.zeros((n, 4), dtype=np.uint64)
+    if pattern == "ones":
+        s[:, 0] = 1
+    elif pattern == "equal":
+        s[:] = orc.to_limbs([0x2abcdef01234567890abcdef1234567890abcdef0fedcba9876543210fedcba9 % P_FR], 4)[0]
+    elif pattern.endswith("_values"):
+        k = int(pattern.split("_")[0])
+        s[:, 0] = (orc.synth_vector(M128, 5512, n)[:, 0] % np.uint64(k)) * np.uint64(97) + np.uint64(1)     # k distinct values below 2^16
+    else:
+        s[: n // 2, 0] = 1
+        s[n // 2:] = orc.synth_vector(FR, 5513, n // 2)
+    pts = _srs_points_dev(env, alpha, n)
+    ds = _to_dev(torch, dev, s)
+    out = torch.zeros(16, dtype=torch.int64, device=dev)
+    _ok(L, L.mzk_msm_g1_bn254_dev(_dp(ds), _dp(pts), ctypes.c_size_t(n), _dp(out), st))
+    h = ctypes.c_void_p()
+    _ok(L, L.mzk_srs_from_device(_dp(pts), ctypes.c_size_t(n), ctypes.byref(h), st))
+    _ok(L, L.mzk_kzg_commit_srs_dev(h, _dp(ds), ctypes.c_size_t(n), _dp(out, 64), ctypes.c_int(0), st))
+    _ok(L, L.mzk_kzg_commit_srs_dev(h, _dp(ds), ctypes.c_size_t(n), _dp(out, 64), ctypes.c_int(0), st))      # twice: the arrival counters start from zero again
+    torch.cuda.synchronize()
+    want = orc.ec_mul(0, G, orc.poly_eval(FR, s, alpha))
+    assert _point(mz, out[:8]) == want
+    assert _point(mz, out[8:]) == want
+    L.mzk_srs_free(h)
+    del pts
+    torch.cuda.empty_cache()
