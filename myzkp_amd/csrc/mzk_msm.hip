@@ -854,12 +854,25 @@ static int launch_exclusive_scan(const u32* in, u32* out, size_t n, u32* scratch
 // SENT (the one-kernel sort of the grid-batched commitments): a polynomial's entry region has a fixed capacity and its unused tail
 // is filled with MANY_SENTINEL entries, which are skipped without touching the table.
 constexpr u32 MANY_SENTINEL = 0xffffffffu;
+// Segment length as the kernels see it.  The host sizes `seg` for the MOST entries the scalars can have (every digit non-zero); short
+// or sparse scalars -- bits, bytes, 64-bit values, half of them zero -- emit a fraction of that, and with the host's length the
+// entries would fill the first few workgroups' lanes with full-length chains while the other CUs idle (2^20 16-bit scalars: 1/15 of
+// the entries, accumulate 0.32 ms against 1.1 on full-width ones).  With t_max != 0 every kernel of the segment stage derives the
+// length from the entry count the sort left at offsets[nbuckets]: the entries spread over all t_max lanes again (never more: slot
+// t + b stays inside the t_max + nbuckets slots), down to SEG_MIN entries per lane.  Full-width uniform scalars get the host's value.
+constexpr u32 SEG_MIN = 8;
+__device__ __forceinline__ u32 segment_length(u32 seg_host, u32 t_max, u32 total_entries) {
+  if (t_max == 0) return seg_host;
+  const u32 v = (total_entries + t_max - 1) / t_max;
+  return v < SEG_MIN ? SEG_MIN : v;
+}
 template <bool PREFETCH, bool SENT = false>
 __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ points_mont, const u32* __restrict__ offsets,
                                                          const u32* __restrict__ entries, u32* __restrict__ slots, size_t nbuckets,
-                                                         u32 seg) {
+                                                         u32 seg_host, u32 t_max) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const u32 total_entries = offsets[nbuckets];
+  const u32 seg = segment_length(seg_host, t_max, total_entries);
   const u64 e0w = (u64)t * seg;
   if (e0w >= total_entries) return;
   const u32 e0 = (u32)e0w;
@@ -917,10 +930,13 @@ __global__ __launch_bounds__(256) void k_seg_accumulate(const u32* __restrict__ 
 // Buckets with more than HEAVY_SLOTS partials (skewed scalars: bit vectors, repeated values) would be one long
 // serial chain; they are queued in `heavy` (count at heavy[0], then (bucket id, end of entries) pairs) and summed by a whole
 // workgroup each (k_seg_combine_heavy).
-// 16, not 32 (round 5): uniform scalars give a bucket 2 - 9 partials on every path, and the signed digits of SHORT scalars put the carry
-// out of their last non-zero window into bucket 0 of the window above (248-bit coefficients at 8-bit windows: bucket 0 of every
-// polynomial holds three times the entries of the others, a chain of 24 in a kernel that is as long as its longest chain)
-constexpr u32 HEAVY_SLOTS = 16;
+// The threshold is 32 partials; 16 for the one-kernel sort of the grid-batched pass (HEAVY_SLOTS_SORT1): there a bucket has 8 - 9
+// partials and the signed digits of SHORT coefficients (31-byte chunks) put the carry out of their last non-zero window into bucket 0
+// of the window above -- ONE bucket per polynomial with three times the entries of the others, a chain of ~30 in a kernel that is as
+// long as its longest chain (256 x 2^10: segment combine 0.149 -> 0.105 ms).  Elsewhere 16 loses: 64 x 2^12 full-width coefficients have
+// ~12 such buckets per polynomial (the 4-bit top window), 768 deferred buckets are two rounds of the workgroup kernel: 0.114 -> 0.168.
+constexpr u32 HEAVY_SLOTS = 32;
+constexpr u32 HEAVY_SLOTS_SORT1 = 16;
 // end of bucket b's entries.  The one-kernel sort of the grid-batched commitments (k_many_sort1) leaves a tail of sentinels behind the
 // LAST bucket of every polynomial's fixed-capacity region; `tails` (one word per polynomial, or null) is where the real entries end,
 // so that the sentinel-only segments are not summed as a chain of identity partials (short coefficients -- the 31-byte chunks of the
@@ -930,7 +946,7 @@ __device__ __forceinline__ u32 bucket_end(const u32* __restrict__ offsets, const
   if (tails && (b & (((size_t)1 << lg_nb) - 1)) == (((size_t)1 << lg_nb) - 1)) return tails[b >> lg_nb];
   return offsets[b + 1];
 }
-// Layout of `heavy`: [0] count, [1] unused, [2, 2 + HEAVY_GRID) arrival counters of k_seg_combine_heavy's shared buckets (zeroed with
+// Layout of `heavy`: [0] count, [1] the segment length in force (written by the combine kernel), [2, 2 + HEAVY_GRID) arrival counters of k_seg_combine_heavy's shared buckets (zeroed with
 // the count, one memset), then (bucket id, end of its entries as the deferring kernel saw it -- bucket_end) pairs, then HEAVY_GRID
 // XYZZ records of scratch for the workgroups that share a bucket.
 constexpr int HEAVY_GRID = 512;
@@ -938,17 +954,19 @@ constexpr int HEAVY_HDR = 2 + HEAVY_GRID;
 constexpr size_t HEAVY_CLEAR_BYTES = (size_t)HEAVY_HDR * 4;
 __host__ __device__ constexpr size_t heavy_list_words(size_t max_heavy) { return HEAVY_HDR + 2 * max_heavy + 2; }
 __host__ __device__ constexpr size_t heavy_total_words(size_t max_heavy) { return heavy_list_words(max_heavy) + (size_t)HEAVY_GRID * 32 + 8; }
-__device__ __forceinline__ bool defer_heavy(size_t b, size_t s0, size_t s1, u32 o1, u32* __restrict__ heavy, bool leader) {
-  if (s1 - s0 + 1 <= HEAVY_SLOTS) return false;
+__device__ __forceinline__ bool defer_heavy(size_t b, size_t s0, size_t s1, u32 o1, u32* __restrict__ heavy, bool leader, u32 threshold = HEAVY_SLOTS) {
+  if (s1 - s0 + 1 <= threshold) return false;
   if (leader) { const u32 i = atomicAdd(&heavy[0], 1u); heavy[HEAVY_HDR + 2 * i] = (u32)b; heavy[HEAVY_HDR + 2 * i + 1] = o1; }
   return true;
 }
 // one lane per bucket: with 2^19 buckets of one or two partials each (generic layout) the kernel is bound by
 // the record traffic, not by a dependent chain
 __global__ __launch_bounds__(128) void k_seg_combine_wide(const u32* __restrict__ slots, const u32* __restrict__ offsets,
-                                                           u32* __restrict__ buckets, size_t nbuckets, u32 seg, u32* __restrict__ heavy) {
+                                                           u32* __restrict__ buckets, size_t nbuckets, u32 seg_host, u32* __restrict__ heavy, u32 t_max) {
   const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbuckets) return;
+  const u32 seg = segment_length(seg_host, t_max, offsets[nbuckets]);
+  if (b == 0) heavy[1] = seg;                        // k_seg_combine_heavy reads it there
   const u32 o0 = offsets[b], o1 = offsets[b + 1];
   Xyzz acc = xyzz_inf();
   if (o1 > o0) {
@@ -959,18 +977,20 @@ __global__ __launch_bounds__(128) void k_seg_combine_wide(const u32* __restrict_
   xyzz_gstore(buckets, b, acc);
 }
 __global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slots, const u32* __restrict__ offsets, u32* __restrict__ buckets,
-                                                      size_t nbuckets, u32 seg, u32* __restrict__ heavy, const u32* __restrict__ tails, int lg_nb) {
+                                                      size_t nbuckets, u32 seg_host, u32* __restrict__ heavy, const u32* __restrict__ tails, int lg_nb, u32 t_max) {
   // one DPP quad per bucket: a bucket's partials form a serial chain of additions (about nine at 2^20 merged),
   // so the quad-cooperative addition cuts the kernel's latency; the quad also splits the 128-byte records.
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t b = tid >> 2;
   const int lane = (int)(tid & 3);
   if (b >= nbuckets) return;
+  const u32 seg = segment_length(seg_host, t_max, offsets[nbuckets]);
+  if (tid == 0) heavy[1] = seg;                      // k_seg_combine_heavy reads it there
   const u32 o0 = offsets[b], o1 = bucket_end(offsets, tails, lg_nb, b);
   Xyzz acc = xyzz_inf();
   if (o1 > o0) {
     const size_t s0 = (size_t)(o0 / seg) + b, s1 = (size_t)((o1 - 1) / seg) + b;
-    if (defer_heavy(b, s0, s1, o1, heavy, lane == 0)) return;       // quad-uniform
+    if (defer_heavy(b, s0, s1, o1, heavy, lane == 0, tails ? HEAVY_SLOTS_SORT1 : HEAVY_SLOTS)) return;       // quad-uniform
     acc = xyzz_gload_raw_quad(slots, s0, lane);
     for (size_t sl = s0 + 1; sl <= s1; sl++) acc = xyzz_add_quad(acc, xyzz_gload_raw_quad(slots, sl, lane), lane);
   }
@@ -995,11 +1015,12 @@ __device__ __forceinline__ void heavy_tree(u32* sh, const Xyzz& acc, int quad, i
 // each sums a contiguous G-th of its partials into a scratch record, and the last one to arrive (a counter per bucket) sums the G
 // records.  One workgroup per bucket made a commit to 2^20 ones 2.0 ms and to 2^20 equal scalars 5.1 ms against 1.5 ms on uniform ones.
 __global__ __launch_bounds__(HEAVY_THREADS) void k_seg_combine_heavy(const u32* __restrict__ slots, const u32* __restrict__ offsets,
-                                                                      u32* __restrict__ buckets, u32 seg, u32* __restrict__ heavy, size_t max_heavy) {
+                                                                      u32* __restrict__ buckets, u32* __restrict__ heavy, size_t max_heavy) {
   __shared__ __attribute__((aligned(16))) u32 sh[HEAVY_QUADS * 32];
   __shared__ u32 last_arrival;
   const u32 count = heavy[0];
   if (count == 0) return;
+  const u32 seg = heavy[1];                          // the segment length the deferring kernel used (segment_length)
   const int lane = threadIdx.x & 3, quad = threadIdx.x >> 2;
   const u32* list = heavy + HEAVY_HDR;
   if (2 * count > gridDim.x) {
@@ -1022,8 +1043,9 @@ __global__ __launch_bounds__(HEAVY_THREADS) void k_seg_combine_heavy(const u32* 
   const size_t b = list[2 * h];
   const u32 o0 = offsets[b], o1 = list[2 * h + 1];
   const size_t s0 = (size_t)(o0 / seg) + b, s1 = (size_t)((o1 - 1) / seg) + b;
-  if (s1 - s0 + 1 <= 4 * HEAVY_QUADS) {                         // a bucket of a few partials per quad: sharing it costs a second tree and
-    if (part != 0) return;                                      // two fences (256 buckets of 24 partials: 40 -> 90 us) -- part 0 alone
+  if (s1 - s0 + 1 <= 16 * HEAVY_QUADS) {                        // up to 16 partials per quad: sharing costs a second tree (six dependent
+    if (part != 0) return;                                      // additions) and two fences -- 256 buckets of 24 partials 40 -> 90 us, 48
+                                                                // buckets of 260 partials 40 -> 75 us -- so part 0 takes these alone
     Xyzz acc = xyzz_inf();
     for (size_t sl = s0 + quad; sl <= s1; sl += HEAVY_QUADS) acc = xyzz_add_quad(acc, xyzz_gload_raw_quad(slots, sl, lane), lane);
     heavy_tree(sh, acc, quad, lane);
@@ -1612,8 +1634,9 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   if (env_seg > 0) seg_sz = (size_t)env_seg;
   const u32 seg = (u32)seg_sz;
   const size_t T = (E_max + seg_sz - 1) / seg_sz;
+  const u32 t_max = env_seg > 0 ? 0u : (u32)T;            // the kernels shorten the segments when the scalars emit fewer entries (segment_length)
   const size_t nslots = T + NB + 1;
-  const size_t max_heavy = (T + NB) / HEAVY_SLOTS + 1;             // at most (T + NB) / 17 buckets hold more than 16 partials
+  const size_t max_heavy = (T + NB) / HEAVY_SLOTS + 1;             // at most (T + NB) / 33 buckets hold more than 32 partials
   const size_t heavy_words = heavy_total_words(max_heavy);
   u32 *counts, *offsets, *ranks, *entries, *scan_tmp, *buckets, *slots;
   MZK_TRY(ws_get(WS_MSM_COUNTS, NB * 4, (void**)&counts));
@@ -1715,18 +1738,18 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   // the true entry count lives in offsets[NB] on the device; lanes past it exit (E_max bounds it)
 #ifdef MZK_TUNING
   if (acc_prefetch)
-    hipLaunchKernelGGL(k_seg_accumulate<true>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, pts, offsets, entries, slots, NB, seg);
+    hipLaunchKernelGGL(k_seg_accumulate<true>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, pts, offsets, entries, slots, NB, seg, t_max);
   else
 #endif
-    hipLaunchKernelGGL(k_seg_accumulate<false>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, pts, offsets, entries, slots, NB, seg);
+    hipLaunchKernelGGL(k_seg_accumulate<false>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, pts, offsets, entries, slots, NB, seg, t_max);
   prof_end(s, MZK_PH_MSM_ACCUMULATE);
   prof_begin(s, MZK_PH_MSM_SEG_COMBINE);
   static const int wide_min_log = tune_int("MZK_COMBINE_WIDE_MIN_LOG", 17);
   if (NB >= ((size_t)1 << wide_min_log))
-    hipLaunchKernelGGL(k_seg_combine_wide, dim3((unsigned)((NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy);
+    hipLaunchKernelGGL(k_seg_combine_wide, dim3((unsigned)((NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy, t_max);
   else
-    hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy, (const u32*)nullptr, 0);
-  hipLaunchKernelGGL(k_seg_combine_heavy, dim3(HEAVY_GRID), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)offsets, buckets, seg, heavy, max_heavy);
+    hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy, (const u32*)nullptr, 0, t_max);
+  hipLaunchKernelGGL(k_seg_combine_heavy, dim3(HEAVY_GRID), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)offsets, buckets, heavy, max_heavy);
   MZK_HIP(hipGetLastError());
   prof_end(s, MZK_PH_MSM_SEG_COMBINE);
 
@@ -1915,7 +1938,7 @@ int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size
     const u32 seg = (u32)seg_sz;
     const size_t T = (E_max + seg_sz - 1) / seg_sz;
     const size_t nslots = T + NBtot + 1;
-    const size_t max_heavy = (T + NBtot) / HEAVY_SLOTS + 1;
+    const size_t max_heavy = (T + NBtot) / HEAVY_SLOTS_SORT1 + 1;
     const size_t heavy_words = heavy_total_words(max_heavy);
     u32 *offs, *compact, *entries, *scan_tmp, *buckets, *slots;
     MZK_TRY(ws_get(WS_MSM_COUNTS, (ncnt + 1) * 4, (void**)&offs));
@@ -1959,16 +1982,18 @@ int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size
     MZK_HIP(hipGetLastError());
     prof_end(s, MZK_PH_MSM_SORT);
     prof_begin(s, MZK_PH_MSM_ACCUMULATE);
+    // (the one-kernel sort's regions have a fixed capacity, sentinels included: the host's segment length stands there)
+    const u32 t_max = one_kernel_sort ? 0u : (u32)T;
     if (one_kernel_sort)
       hipLaunchKernelGGL((k_seg_accumulate<false, true>), dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, (const u32*)d_tables, (const u32*)compact, (const u32*)entries,
-                         slots, NBtot, seg);
+                         slots, NBtot, seg, t_max);
     else
       hipLaunchKernelGGL(k_seg_accumulate<false>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, (const u32*)d_tables, (const u32*)compact, (const u32*)entries,
-                         slots, NBtot, seg);
+                         slots, NBtot, seg, t_max);
     prof_end(s, MZK_PH_MSM_ACCUMULATE);
     prof_begin(s, MZK_PH_MSM_SEG_COMBINE);
-    hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NBtot + 127) / 128)), dim3(128), 0, s, slots, (const u32*)compact, buckets, NBtot, seg, heavy, (const u32*)tails, lgB);
-    hipLaunchKernelGGL(k_seg_combine_heavy, dim3(HEAVY_GRID), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)compact, buckets, seg, heavy, max_heavy);
+    hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NBtot + 127) / 128)), dim3(128), 0, s, slots, (const u32*)compact, buckets, NBtot, seg, heavy, (const u32*)tails, lgB, t_max);
+    hipLaunchKernelGGL(k_seg_combine_heavy, dim3(HEAVY_GRID), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)compact, buckets, heavy, max_heavy);
     MZK_HIP(hipGetLastError());
     prof_end(s, MZK_PH_MSM_SEG_COMBINE);
     prof_begin(s, MZK_PH_MSM_REDUCE);
