@@ -13,7 +13,8 @@ echo "pytest rc=$?" >> $O/${T}_pytest.log
 timeout 1200 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err
 echo "bench rc=$?" >> $O/${T}_pytest.log
 python tools/timing/small_latency.py > $O/${T}_small_latency.txt 2>&1
-python tools/timing/many_commit.py 10:256,10:256:1:10,10:256:1:12,12:64,12:64:1:10,8:1024,8:1024:1:10,13:32,14:16 > $O/${T}_many_commit.txt 2>&1
+python tools/timing/many_commit.py 10:256,10:256:1:10,10:256:1:12,12:64,12:64:1:10,8:1024,8:1024:1:10,13:32,14:16,10:256:1:0:248,12:64:1:0:248,8:1024:1:0:248 > $O/${T}_many_commit.txt 2>&1
+python tools/timing/skew_msm.py "uniform,bits,bytes,16-bit scalars,32-bit,64-bit,128-bit,248-bit,half zero,all ones,all-equal" > $O/${T}_short_scalars.txt 2>&1
 python tools/timing/stark_commit_pipeline.py 12 16 > $O/${T}_stark_commit_pipeline.txt 2>&1
 python tools/timing/stark_commit_pipeline.py 14 16 >> $O/${T}_stark_commit_pipeline.txt 2>&1
 python tools/timing/fri_round_cost.py > $O/${T}_fri_round_cost.txt 2>&1
@@ -51,4 +52,4 @@ run_pmc generic $R/tools/timing/generic_phases.py 20
 cd $R
 python3 tools/kernel_resources.py --priced > $O/${T}_kernel_resources.txt 2>&1
 find $O -name "*.csv" -size +4M -delete
-tail -16 $O/${T}_pytest.log; head -c 600 $O/${T}_bench.json; echo; head -30 $O/${T}_per_msm_kernel_budget.txt; cat $O/${T}_hbm_traffic_pmc.txt | cut -c1-160 | head -50; cat $O/${T}_sq_counters.txt | head -90; grep -v amdgpu $O/${T}_small_latency.txt; grep -v amdgpu $O/${T}_many_commit.txt | cut -c1-200; grep -v amdgpu $O/${T}_stark_commit_pipeline.txt; grep -v amdgpu $O/${T}_fri_round_cost.txt; grep -v amdgpu $O/${T}_time_ntt.txt; grep -v amdgpu $O/${T}_generic_phases.txt | cut -c1-220
+tail -16 $O/${T}_pytest.log; head -c 600 $O/${T}_bench.json; echo; head -30 $O/${T}_per_msm_kernel_budget.txt; cat $O/${T}_hbm_traffic_pmc.txt | cut -c1-160 | head -50; cat $O/${T}_sq_counters.txt | head -90; grep -v amdgpu $O/${T}_small_latency.txt; grep -v amdgpu $O/${T}_many_commit.txt | cut -c1-200; grep -v amdgpu $O/${T}_stark_commit_pipeline.txt; grep -v amdgpu $O/${T}_fri_round_cost.txt; grep -v amdgpu $O/${T}_time_ntt.txt; grep -v amdgpu $O/${T}_generic_phases.txt | cut -c1-220; grep -v amdgpu $O/${T}_short_scalars.txt
