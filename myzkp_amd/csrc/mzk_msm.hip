@@ -618,23 +618,68 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter_staged(const u
     __syncthreads();
   }
 }
-// slice of bin b handled by sub-workgroup s of S: bins are the runs [binbase[b * nwg], binbase[(b+1) * nwg])
-__device__ __forceinline__ void fine_slice(const u32* __restrict__ binbase, int nwg, int b, int s, int S, u32* lo, u32* hi) {
-  const u32 start = binbase[(size_t)b * nwg], end = binbase[(size_t)(b + 1) * nwg];   // binbase has 256 * nwg + 1 entries
-  const u64 len = end - start;
-  *lo = start + (u32)(len * (u64)s / (u64)S);
-  *hi = start + (u32)(len * (u64)(s + 1) / (u64)S);
+// Which slice of which bin a fine workgroup handles.  A bin is the run [binbase[b nwg], binbase[(b + 1) nwg]) of the coarse-sorted
+// records.  On uniform scalars every bin holds E / bins records and S workgroups each take an S-th of it; SHORT scalars do not fill
+// the bins evenly -- bytes put every entry of a 17-bit window into bin 0, 248-bit coefficients put a fifteenth of all entries into the
+// four bins of the 10-bit top window -- and with S slices for every bin two workgroups then counted and scattered a whole window alone
+// (k_fine_scatter 50 -> 547 us at 2^20 bytes, 186 us at 248 bits).  So a bin gets max(S, ceil(len / cap)) slices, cap = 1.5 nominal
+// slices: the uniform case keeps its S, an over-full bin is cut into as many workgroups as it needs.  Every workgroup derives the same
+// plan from the bin boundaries (one load per lane and a block scan of two barriers): workgroup w -> (bin, slice); the histogram of bin b sits at
+// finehist[F P_b + f S_b + s] (P_b = slices before bin b), one flat exclusive scan as before; workgroups past the last slice zero
+// their block of the histogram, so the scan runs over the host's bound F * gridDim.
+struct FineSlice { int bin, s, Sb; u32 lo, hi; bool active; };
+// (sc, res: LDS scratch of the caller, SORT2_THREADS and 6 words -- no static LDS here: k_fine_scatter asks for all 160 KiB as dynamic)
+__device__ __forceinline__ FineSlice fine_plan(const u32* __restrict__ binbase, int nwg, int bins, int S, u32 cap, u32* sc, u32* res) {
+  const int tid = threadIdx.x;
+  u32 start = 0, len = 0, Sb = 0;
+  if (tid < bins) {
+    start = binbase[(size_t)tid * nwg];
+    len = binbase[(size_t)(tid + 1) * nwg] - start;
+    Sb = (len + cap - 1) / cap;
+    if (Sb < (u32)S) Sb = (u32)S;
+  }
+  if (tid == 0) res[0] = 0xffffffffu;
+  // inclusive scan of Sb over the workgroup: inside each wave by shuffles, the 16 wave totals by the first wave -- two barriers
+  const int lane = tid & 63, wave = tid >> 6;
+  u32 v = Sb;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const u32 t = __shfl_up(v, off, 64); if (lane >= off) v += t; }
+  if (lane == 63) sc[wave] = v;
+  __syncthreads();
+  if (wave == 0) {
+    u32 t = (lane < SORT2_THREADS / 64) ? sc[lane] : 0u;
+#pragma unroll
+    for (int off = 1; off < SORT2_THREADS / 64; off <<= 1) { const u32 u = __shfl_up(t, off, 64); if (lane >= off) t += u; }
+    if (lane < SORT2_THREADS / 64) sc[lane] = t;
+  }
+  __syncthreads();
+  const u32 w = blockIdx.x, incl = v + (wave ? sc[wave - 1] : 0u), excl = incl - Sb;
+  if (tid < bins && excl <= w && w < incl) { res[0] = (u32)tid; res[1] = w - excl; res[2] = Sb; res[3] = start; res[4] = len; res[5] = excl; }
+  __syncthreads();
+  FineSlice r;
+  r.active = res[0] != 0xffffffffu;
+  r.bin = (int)res[0]; r.s = (int)res[1]; r.Sb = (int)res[2];
+  const u64 L = res[4];
+  r.lo = res[3] + (u32)(L * (u64)r.s / (u64)r.Sb);
+  r.hi = res[3] + (u32)(L * (u64)(r.s + 1) / (u64)r.Sb);
+  return r;
 }
 constexpr int FINE_UNROLL = 8;
 constexpr int FINE_MAX = 8192;     // buckets per bin: NB / 256 (128 merged c = 16, 2048 generic c = 16, 8192 merged c = 22)
 template <class REC>
 __global__ __launch_bounds__(SORT2_THREADS) void k_fine_count(const typename REC::T* __restrict__ tmp, const u32* __restrict__ binbase, int nwg, int F,
-                                                               int S, int fb, u32* __restrict__ finehist) {
+                                                               int S, int fb, u32* __restrict__ finehist, int bins, u32 cap) {
   __shared__ u32 hist[FINE_MAX];
+  __shared__ u32 sc[SORT2_THREADS];
+  const FineSlice p = fine_plan(binbase, nwg, bins, S, cap, sc, hist);
+  __syncthreads();                      // (hist is the plan's scratch until here)
+  if (!p.active) {                      // past the last slice: this block of the histogram scans as zeros
+    for (int f = threadIdx.x; f < F; f += SORT2_THREADS) finehist[(size_t)blockIdx.x * F + f] = 0;
+    return;
+  }
   for (int f = threadIdx.x; f < F; f += SORT2_THREADS) hist[f] = 0;
   __syncthreads();
-  u32 lo, hi;
-  fine_slice(binbase, nwg, blockIdx.x, blockIdx.y, S, &lo, &hi);
+  const u32 lo = p.lo, hi = p.hi;
   // FINE_UNROLL independent loads in flight per lane: the loop is otherwise one global-load latency per entry
   for (u32 base = lo + threadIdx.x; base < hi; base += FINE_UNROLL * SORT2_THREADS) {
     u32 f[FINE_UNROLL];
@@ -647,24 +692,29 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_fine_count(const typename REC
     for (int k = 0; k < FINE_UNROLL; k++) if (f[k] != 0xffffffffu) counter_inc_agg(hist, f[k]);
   }
   __syncthreads();
-  for (int f = threadIdx.x; f < F; f += SORT2_THREADS) finehist[((size_t)blockIdx.x * F + f) * S + blockIdx.y] = hist[f];
+  const size_t hbase = (size_t)F * (blockIdx.x - (u32)p.s);        // F P_b: the slices of a bin are consecutive workgroups
+  for (int f = threadIdx.x; f < F; f += SORT2_THREADS) finehist[hbase + (size_t)f * p.Sb + p.s] = hist[f];
 }
 // Direct form: every record is stored straight to its final position (isolated 4-byte stores).  Only used when a
 // bin has more buckets than the staged kernel below has LDS for.
 template <class REC>
 __global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter_direct(const typename REC::T* __restrict__ tmp, const u32* __restrict__ binbase, int nwg, int F,
                                                                  int S, int fb, const u32* __restrict__ finebase, u32* __restrict__ offsets,
-                                                                 u32* __restrict__ entries, size_t nbuckets) {
+                                                                 u32* __restrict__ entries, size_t nbuckets, int bins, u32 cap) {
   __shared__ u32 cursor[FINE_MAX];
-  for (int f = threadIdx.x; f < F; f += SORT2_THREADS) {
-    const u32 base = finebase[((size_t)blockIdx.x * F + f) * S + blockIdx.y];
-    cursor[f] = base;
-    if (blockIdx.y == 0) offsets[(size_t)blockIdx.x * F + f] = base;      // start of bucket (bin, f)
-  }
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) offsets[nbuckets] = finebase[nbuckets * (size_t)S];   // total entries
+  __shared__ u32 sc[SORT2_THREADS];
+  const FineSlice p = fine_plan(binbase, nwg, bins, S, cap, sc, cursor);
   __syncthreads();
-  u32 lo, hi;
-  fine_slice(binbase, nwg, blockIdx.x, blockIdx.y, S, &lo, &hi);
+  if (blockIdx.x == 0 && threadIdx.x == 0) offsets[nbuckets] = finebase[(size_t)F * gridDim.x];   // total entries
+  if (!p.active) return;
+  const size_t hbase = (size_t)F * (blockIdx.x - (u32)p.s);
+  for (int f = threadIdx.x; f < F; f += SORT2_THREADS) {
+    const u32 base = finebase[hbase + (size_t)f * p.Sb + p.s];
+    cursor[f] = base;
+    if (p.s == 0) offsets[(size_t)p.bin * F + f] = base;      // start of bucket (bin, f)
+  }
+  __syncthreads();
+  const u32 lo = p.lo, hi = p.hi;
   for (u32 base = lo + threadIdx.x; base < hi; base += FINE_UNROLL * SORT2_THREADS) {
     typename REC::T r[FINE_UNROLL];
 #pragma unroll
@@ -692,7 +742,7 @@ constexpr int STAGE_F_MAX = 2048;
 template <class REC>
 __global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter(const typename REC::T* __restrict__ tmp, const u32* __restrict__ binbase, int nwg, int F,
                                                                  int S, int fb, const u32* __restrict__ finebase, u32* __restrict__ offsets,
-                                                                 u32* __restrict__ entries, size_t nbuckets) {
+                                                                 u32* __restrict__ entries, size_t nbuckets, int bins, u32 cap) {
   extern __shared__ u32 lds_fs[];
   u32* gbase = lds_fs;                 // [F]   global position of the next entry of bucket f written by this workgroup
   u32* cnt = gbase + F;                // [F]   records of bucket f in the current round
@@ -701,14 +751,17 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter(const typename R
   u32* spay = scan + SORT2_THREADS;    // [STAGE_CAP] staged payloads, bucket-sorted
   unsigned short* skey = reinterpret_cast<unsigned short*>(spay + STAGE_CAP);   // [STAGE_CAP] their buckets
   const int tid = threadIdx.x;
+  const FineSlice p = fine_plan(binbase, nwg, bins, S, cap, scan, gbase);
+  __syncthreads();                     // (gbase is the plan's scratch until here)
+  if (blockIdx.x == 0 && tid == 0) offsets[nbuckets] = finebase[(size_t)F * gridDim.x];   // total entries
+  if (!p.active) return;
+  const size_t hbase = (size_t)F * (blockIdx.x - (u32)p.s);
   for (int f = tid; f < F; f += SORT2_THREADS) {
-    const u32 base = finebase[((size_t)blockIdx.x * F + f) * S + blockIdx.y];
+    const u32 base = finebase[hbase + (size_t)f * p.Sb + p.s];
     gbase[f] = base;
-    if (blockIdx.y == 0) offsets[(size_t)blockIdx.x * F + f] = base;      // start of bucket (bin, f)
+    if (p.s == 0) offsets[(size_t)p.bin * F + f] = base;      // start of bucket (bin, f)
   }
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) offsets[nbuckets] = finebase[nbuckets * (size_t)S];   // total entries
-  u32 lo, hi;
-  fine_slice(binbase, nwg, blockIdx.x, blockIdx.y, S, &lo, &hi);
+  const u32 lo = p.lo, hi = p.hi;
   const int per = (F + SORT2_THREADS - 1) / SORT2_THREADS;     // counters per lane in the prefix (<= 2)
   for (u32 chunk = lo; chunk < hi; chunk += STAGE_CAP) {
     const u32 cend = (hi - chunk > (u32)STAGE_CAP) ? chunk + STAGE_CAP : hi;
@@ -1460,6 +1513,7 @@ int msm_build_tables(const void* d_points_mont, size_t n, void* d_tables, int wi
 struct SortArgs {
   const u32* scalars; size_t n; DigitLayout L; int key_shift; u32 fine_mask; int fb; u32* binhist; int nwg; void* tmp; int F; int S;
   u32* finehist; u32* scan3; size_t sb_f; size_t n_fine; u32* offsets; u32* entries; size_t NBtot;
+  unsigned fine_wgs; u32 fine_cap;       // grid of the fine kernels (slices of all bins + the extra slices of over-full ones) and the slice capacity (fine_plan)
   int cl;           // log2 of the coarse bins: COARSE_LOG, or 10 for the 20-bit merged layout
 };
 template <class REC>
@@ -1505,8 +1559,8 @@ static int sort_records(const SortArgs& a, hipStream_t s) {
   else
     hipLaunchKernelGGL((k_coarse_scatter<REC, 0>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb,
                        (const u32*)a.binhist, a.nwg, (R*)a.tmp);
-  hipLaunchKernelGGL((k_fine_count<REC>), dim3(bins, a.S), dim3(SORT2_THREADS), 0, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg, a.F, a.S,
-                     a.fb, a.finehist);
+  hipLaunchKernelGGL((k_fine_count<REC>), dim3(a.fine_wgs), dim3(SORT2_THREADS), 0, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg, a.F, a.S,
+                     a.fb, a.finehist, (int)bins, a.fine_cap);
   MZK_TRY(launch_exclusive_scan((const u32*)a.finehist, a.finehist, a.n_fine, a.scan3, s));
   if (a.F <= STAGE_F_MAX) {
     const size_t lds = ((size_t)3 * a.F + SORT2_THREADS + STAGE_CAP) * 4 + (size_t)STAGE_CAP * 2;
@@ -1515,11 +1569,11 @@ static int sort_records(const SortArgs& a, hipStream_t s) {
       MZK_HIP(hipFuncSetAttribute((const void*)k_fine_scatter<REC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       staged_attr = true;
     }
-    hipLaunchKernelGGL((k_fine_scatter<REC>), dim3(bins, a.S), dim3(SORT2_THREADS), lds, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg, a.F,
-                       a.S, a.fb, (const u32*)a.finehist, a.offsets, a.entries, a.NBtot);
+    hipLaunchKernelGGL((k_fine_scatter<REC>), dim3(a.fine_wgs), dim3(SORT2_THREADS), lds, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg, a.F,
+                       a.S, a.fb, (const u32*)a.finehist, a.offsets, a.entries, a.NBtot, (int)bins, a.fine_cap);
   } else {
-    hipLaunchKernelGGL((k_fine_scatter_direct<REC>), dim3(bins, a.S), dim3(SORT2_THREADS), 0, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg,
-                       a.F, a.S, a.fb, (const u32*)a.finehist, a.offsets, a.entries, a.NBtot);
+    hipLaunchKernelGGL((k_fine_scatter_direct<REC>), dim3(a.fine_wgs), dim3(SORT2_THREADS), 0, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg,
+                       a.F, a.S, a.fb, (const u32*)a.finehist, a.offsets, a.entries, a.NBtot, (int)bins, a.fine_cap);
   }
   MZK_HIP(hipGetLastError());
   return MZK_OK;
@@ -1679,7 +1733,11 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     int S = (int)((E_max / cbins + per_fine - 1) / per_fine);
     if (S < 2) S = 2;
     if (S > 64) S = 64;
-    const size_t n_coarse = cbins * nwg, n_fine = NBtot * (size_t)S;
+    // fine workgroups: S slices for every bin + the extra slices of over-full bins (fine_plan: a slice holds at most 1.5 nominal ones)
+    const size_t slice_nom = (E_max + cbins * (size_t)S - 1) / (cbins * (size_t)S);
+    const size_t slice_cap = slice_nom + slice_nom / 2 + 1;
+    const size_t fine_wgs = cbins * (size_t)S + (E_max + slice_cap - 1) / slice_cap + 1;
+    const size_t n_coarse = cbins * nwg, n_fine = (size_t)F * fine_wgs;
     u32 *binhist, *finehist;
     MZK_TRY(ws_get(WS_MSM_WGHIST, (n_coarse + 1 + n_fine + 1) * 4, (void**)&binhist));
     finehist = binhist + n_coarse + 1;
@@ -1703,7 +1761,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     const size_t ref_max = L.merged ? (size_t)msm_table_rows(sh.c, L.sets) * table_stride : L.phi_offset + n;
     const bool compact = ref_max <= ((size_t)1 << (31 - fb));      // references are < ref_max
     SortArgs sa{(const u32*)d_scalars, n, L, key_shift, fine_mask, fb, binhist, nwg, (void*)ranks, F, S, finehist, scan2 + scan_scratch_words(n_coarse) + 2, sb_f, n_fine,
-                offsets, entries, NBtot, cl};
+                offsets, entries, NBtot, (unsigned)fine_wgs, (u32)slice_cap, cl};
     MZK_TRY(compact ? sort_records<Rec4>(sa, s) : sort_records<Rec8>(sa, s));
   } else if (L.merged) {
     // LDS histogram path (no global atomics)
