@@ -144,7 +144,11 @@ def _skewed_scalar_sets(n, seed):
     small = np.zeros((n, 4), dtype=np.uint64); small[:, 0] = uni[:, 0] & np.uint64(0xffff)
     mixed = uni.copy(); mixed[: (3 * n) // 4] = ones[: (3 * n) // 4]        # 75 % ones, 25 % uniform
     minus1 = np.tile(orc.to_limbs([P_FR - 1], 4), (n, 1))                     # every digit negative-carrying
-    return {"ones": ones, "bits": bits, "equal": equal, "small16": small, "mixed": mixed, "minus_one": minus1}
+    # short scalars (witness values): every entry of a window lands in one or a few coarse bins of the two-level sort (fine_plan)
+    byte = np.zeros((n, 4), dtype=np.uint64); byte[:, 0] = uni[:, 0] & np.uint64(0xff)
+    b128 = uni.copy(); b128[:, 2:] = 0
+    b248 = uni.copy(); b248[:, 3] &= np.uint64((1 << 56) - 1)
+    return {"ones": ones, "bits": bits, "equal": equal, "small16": small, "mixed": mixed, "minus_one": minus1, "bytes": byte, "128_bit": b128, "248_bit": b248}
 
 
 def test_skewed_scalars_merged_two_level_sort(mz):
@@ -178,11 +182,11 @@ def test_small_commit_without_sort_launch_skewed_scalars(mz, n):
 
 def test_skewed_scalars_generic_two_level_sort(mz):
     """generic layout takes the two-level sort from n = 2^19 (c = 16); heavy buckets there go through
-    k_seg_combine_wide's deferral"""
+    k_seg_combine_wide's deferral; short scalars leave its coarse bins (window-major keys) very unevenly filled (fine_plan)"""
     n = 1 << 19
     p = orc.synth_points(778, n)
     sets = _skewed_scalar_sets(n, 32)
-    for name in ("ones", "bits", "mixed", "equal"):
+    for name in ("ones", "bits", "mixed", "equal", "bytes", "small16", "128_bit", "248_bit"):
         assert mz.msm_g1(sets[name], p) == orc.msm_fast(sets[name], p), name
 
 
