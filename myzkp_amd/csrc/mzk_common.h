@@ -157,6 +157,7 @@ int coset_divide_dev_impl(int fid, const void* d_lhs, size_t tl, const void* d_r
                           const uint64_t* root_host, size_t order, void* d_out, hipStream_t s);
 int pointwise_div_dev(int fid, const void* d_a, const void* d_b, void* d_out, size_t n, hipStream_t s);
 int pointwise_div_shared_dev(int fid, const void* d_a, size_t a_stride, const void* d_b, void* d_out, size_t out_stride, size_t n, size_t regs, hipStream_t s);
+int pointwise_mul_shared_dev(int fid, const void* d_a, size_t a_stride, const void* d_b, void* d_out, size_t out_stride, size_t n, size_t regs, hipStream_t s);
 int pointwise_mul_dev(int fid, const void* d_a, const void* d_b, void* d_out, size_t n, hipStream_t s);
 void ntt_release_plans();
 void kzg_release_cache();       // mzk_kzg.hip: fixed-base tables of the current context

@@ -255,13 +255,21 @@ __global__ __launch_bounds__(256) void k_derivative(const u32* __restrict__ low_
   pl_store<P>(dz, j, pl_mul<P>(z, m));
 }
 // P_chunk = sum_i w_i Zc / (X - x_i): lane i divides synthetically (q_63 = 1, q_{k-1} = zc_k + x_i q_k), the scaled
-// coefficients are summed over the wave; out0[chunk * 64 + k] = coefficient k
+// coefficients are summed over the wave; out0[chunk * 64 + k] = coefficient k.
+// The 64 sums over the wave go through LDS eight coefficients at a time (round 5): every lane writes its eight scaled terms, lane
+// (col, sub) adds rows sub, sub + 8, ... of column col, three shuffle steps finish the column -- 8 LDS reads and 3 shuffles per eight
+// coefficients and lane where the butterfly reduction of each coefficient took 6 shuffle steps of NW words each (k_chunk_combine was
+// 0.35 ms of a 1.63-ms interpolation of 16 registers at 2^14 points).
+constexpr int COMBINE_BLOCK = 8;
 template <class P>
 __global__ __launch_bounds__(64) void k_chunk_combine(const u32* __restrict__ domain, const u32* __restrict__ w, size_t n, const u32* __restrict__ low0,
                                                       u32* __restrict__ out0, size_t chunks) {
   // blockIdx.x = register * chunks + chunk: the weights and the output of register r are N = chunks * 64 elements apart,
   // the domain and the level-0 zerofiers are shared
+  static_assert(CHUNK == 64 && COMBINE_BLOCK * COMBINE_BLOCK == CHUNK, "one wave, eight columns of eight row groups");
   __shared__ u32 sh_z[CHUNK * P::NW];
+  __shared__ u32 sh_t[COMBINE_BLOCK * CHUNK * P::NW];      // [column][lane]: the terms of eight coefficients
+  __shared__ u32 sh_o[CHUNK * P::NW];                      // the chunk's coefficients, for the coalesced store
   const int lane = threadIdx.x;
   const size_t reg = blockIdx.x / chunks;
   const size_t idx = ((size_t)blockIdx.x - reg * chunks) * CHUNK + lane;
@@ -272,14 +280,23 @@ __global__ __launch_bounds__(64) void k_chunk_combine(const u32* __restrict__ do
   Fe<P> x = fe_zero<P>(), wi = fe_zero<P>();
   if (idx < n) { x = fe_reduce<P>(fe_to_mont<P>(pl_load<P>(domain, idx))); wi = fe_reduce<P>(fe_to_mont<P>(pl_load<P>(w, idx))); }
   Fe<P> q = pl_one<P>();
-  Fe<P> mine = fe_zero<P>();
-  for (int k = CHUNK - 1; k >= 0; k--) {
-    Fe<P> term = fe_reduce<P>(FeAsm<P>::mul(q, wi));
-    for (int m = 1; m < 64; m <<= 1) term = pl_add<P>(term, shfl_xor_fe<P>(term, m));
-    if (lane == k) mine = term;
-    if (k > 0) q = pl_add<P>(pl_load<P>(sh_z, k), fe_reduce<P>(FeAsm<P>::mul(q, x)));
+  const int col = lane >> 3, sub = lane & 7;
+  for (int kb = CHUNK - COMBINE_BLOCK; kb >= 0; kb -= COMBINE_BLOCK) {
+#pragma unroll 1
+    for (int kk = COMBINE_BLOCK - 1; kk >= 0; kk--) {
+      const int k = kb + kk;
+      pl_store<P>(sh_t, kk * CHUNK + lane, fe_reduce<P>(FeAsm<P>::mul(q, wi)));
+      if (k > 0) q = pl_add<P>(pl_load<P>(sh_z, k), fe_reduce<P>(FeAsm<P>::mul(q, x)));
+    }
+    __syncthreads();
+    Fe<P> sum = pl_load<P>(sh_t, col * CHUNK + sub);
+#pragma unroll 1
+    for (int j = 1; j < COMBINE_BLOCK; j++) sum = pl_add<P>(sum, pl_load<P>(sh_t, col * CHUNK + j * COMBINE_BLOCK + sub));
+    for (int m = 1; m < COMBINE_BLOCK; m <<= 1) sum = pl_add<P>(sum, shfl_xor_fe<P>(sum, m));
+    if (sub == 0) pl_store<P>(sh_o, kb + col, sum);
+    __syncthreads();
   }
-  pl_store<P>(out0, idx, mine);
+  pl_store<P>(out0, idx, pl_load<P>(sh_o, lane));
 }
 // W[q * 2D + k] = Pl[k] Zr[k] + Pr[k] Zl[k]   (all transformed, children q*2, q*2+1 of degree D)
 template <class P>
@@ -600,7 +617,7 @@ struct InterpPlanBase {
 };
 template <class P> struct InterpPlan : InterpPlanBase {
   PolyTree<P> T;
-  DevBuf d_dom, d_zp;
+  DevBuf d_dom, d_zp;        // the domain; 1 / Z'(d_i)
 };
 static std::vector<InterpPlanBase*> g_interp_plans[MZK_MAX_CTX];
 static uint64_t g_interp_stamp = 0;
@@ -627,7 +644,7 @@ static int interp_plan_get(int fid, const uint64_t* domain, size_t n, const uint
   InterpPlan<P>* pl = new InterpPlan<P>();
   pl->fid = fid; pl->n = n;
   int rc = tree_init(&pl->T, fid, n, root, root_order, s);
-  DevBuf d_dz;
+  DevBuf d_dz, d_zpv;
   if (rc == MZK_OK) rc = pl->d_dom.alloc(n * esz);
   if (rc == MZK_OK) rc = d_dz.alloc(n * esz);
   if (rc == MZK_OK) rc = pl->d_zp.alloc(pl->T.N * esz);
@@ -637,7 +654,16 @@ static int interp_plan_get(int fid, const uint64_t* domain, size_t n, const uint
     // w_i = v_i / Z'(d_i); a repeated point has Z' = 0 and the reference's division by inverse(0) = 0 (field.rs:209-232)
     // zeroes its target at the level that separates the two copies (ntt.rs:233-242): w_i = 0 as well
     hipLaunchKernelGGL((k_derivative<P>), dim3(grid256(n)), dim3(256), 0, s, (const u32*)pl->T.low[pl->T.levels].w(), pl->T.N, pl->T.pad, n, d_dz.w());
-    rc = pl->T.evaluate(d_dz.p, n, pl->d_dom.p, pl->d_zp.p, n);
+    rc = d_zpv.alloc(pl->T.N * esz);
+    if (rc == MZK_OK) rc = pl->T.evaluate(d_dz.p, n, pl->d_dom.p, d_zpv.p, n);
+  }
+  if (rc == MZK_OK) {
+    // the plan keeps 1 / Z'(d_i) (0 where Z' = 0, as the division gives): d_dz is free again and takes the numerators, all ones
+    std::vector<uint64_t> ones(n * nl, 0);
+    for (size_t i = 0; i < n; i++) ones[i * nl] = 1;
+    if (hipMemcpyAsync(d_dz.p, ones.data(), n * esz, hipMemcpyHostToDevice, s) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipMemcpyAsync", __FILE__, __LINE__);
+    if (rc == MZK_OK) rc = pointwise_div_shared_dev(fid, d_dz.p, n, d_zpv.p, pl->d_zp.p, n, n, 1, s);
+    if (hipStreamSynchronize(s) != hipSuccess && rc == MZK_OK) rc = hip_fail(hipGetLastError(), "hipStreamSynchronize", __FILE__, __LINE__);      // `ones` is read until here
   }
   if (rc != MZK_OK) { (void)hipStreamSynchronize(s); delete pl; return rc; }
   pl->domain.assign(domain, domain + n * nl);
@@ -697,9 +723,9 @@ static int interpolate_impl(int fid, const uint64_t* domain, const uint64_t* val
     const size_t g = std::min(group, batch - r0);
     MZK_HIP(hipMemcpyAsync(d_vals.p, values + r0 * n * nl, g * n * esz, hipMemcpyHostToDevice, s));
     MZK_HIP(hipMemsetAsync(d_ws.p, 0, g * T.N * esz, s));
-    // all registers of the group in one launch: they divide by the same Z'(d_i), inverted once per lane (one launch and one
-    // inversion chain per REGISTER before: 16 x 60 us of a 3.5-ms batch of 16 registers of 2^14 points)
-    MZK_TRY(pointwise_div_shared_dev(fid, d_vals.p, n, d_zp.p, d_ws.p, T.N, n, g, s));
+    // all registers of the group in one launch: they divide by the same Z'(d_i), whose inverses the plan holds (round 4: one launch and
+    // one inversion chain per REGISTER, 16 x 60 us of a 3.5-ms batch of 16 registers of 2^14 points; then one shared chain, 0.18 ms)
+    MZK_TRY(pointwise_mul_shared_dev(fid, d_vals.p, n, d_zp.p, d_ws.p, T.N, n, g, s));
     MZK_TRY(T.combine(d_dom.p, d_ws.p, d_ress.p, g));
     MZK_HIP(hipMemcpyAsync(res.data(), d_ress.p, g * T.N * esz, hipMemcpyDeviceToHost, s));
     MZK_HIP(hipStreamSynchronize(s));
