@@ -168,6 +168,13 @@ int mzk_fast_interpolate(int field_id, const uint64_t* domain, const uint64_t* v
  * coefficients, zero-padded).  Each row bit-identical to the single call. */
 int mzk_fast_interpolate_batch(int field_id, const uint64_t* domain, const uint64_t* values, size_t n, size_t batch, const uint64_t* root,
                                size_t root_order, uint64_t* out, size_t* out_lens);
+/* The same with the values and the coefficients in HBM -- a prover uploads its trace once and the coefficients feed mzk_coset_lde_batch_dev
+ * without visiting the host (fast_stark.rs:209-231: interpolate, then fast_coset_evaluate, per register).  d_values: batch rows of n
+ * elements, canonical (not checked), complete on `stream` (a hipStream_t) before the call; d_out: batch rows of n elements, row r holds
+ * out_lens[r] coefficients and zeros behind them.  domain and out_lens are host memory (the domain keys the cached plan, the lengths are
+ * what the caller builds its Polynomial values from).  Returns when d_out is complete.  Rows bit-identical to mzk_fast_interpolate_batch. */
+int mzk_fast_interpolate_batch_dev(int field_id, const uint64_t* domain, const void* d_values, size_t n, size_t batch, const uint64_t* root,
+                                   size_t root_order, void* d_out, size_t* out_lens, void* stream);
 
 /* FRI commit-loop split-and-fold (zkstark/fri.rs:182-193):
  * out[i] = 2^-1 ((1 + alpha/(offset omega^i)) c[i] + (1 - alpha/(offset omega^i)) c[n/2 + i]), i < n/2,

@@ -737,6 +737,18 @@ def fast_interpolate_batch(fid, domain, values, root, root_order):
     return [out[k, :lens[k]] for k in range(batch)]
 
 
+def fast_interpolate_batch_dev(fid, domain, d_values_ptr, batch, root, root_order, d_out_ptr, stream=0):
+    """mzk_fast_interpolate_batch_dev: values and coefficients in HBM (raw device pointers, batch rows of len(domain) elements each);
+    returns the trimmed lengths."""
+    d = _arr(fid, domain)
+    n = d.shape[0]
+    lens = (ctypes.c_size_t * max(batch, 1))()
+    r = _one(fid, root)
+    _check(lib().mzk_fast_interpolate_batch_dev(fid, _p(d), ctypes.c_void_p(d_values_ptr), ctypes.c_size_t(n), ctypes.c_size_t(batch), _p(r),
+                                                ctypes.c_size_t(root_order), ctypes.c_void_p(d_out_ptr), lens, ctypes.c_void_p(stream)))
+    return [int(lens[k]) for k in range(batch)]
+
+
 def g2_points_to_array(pts):
     """[((x0, x1), (y0, y1)), ...] -> (n, 16) limbs; infinity = ((0, 0), (0, 0))."""
     a = np.zeros((len(pts), 16), dtype=np.uint64)

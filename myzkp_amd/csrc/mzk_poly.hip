@@ -606,6 +606,28 @@ static int evaluate_impl(int fid, const uint64_t* coef, size_t m, const uint64_t
 // `batch` value vectors over ONE domain (the registers of a trace, fast_stark.rs:203-215): the subproduct tree and the
 // Z'(d_i) are built once, each register costs a pointwise division and one up-sweep.  out: batch rows of n elements
 // (row r holds out_lens[r] coefficients, zero-padded).
+// trimmed length of every row (the reference's final `+` trims trailing zeros, polynomial.rs:214-228): lens[r] = 1 + the highest
+// i < n with rows[r * stride + pad + i] != 0, or 0.  One workgroup per row.
+template <class P>
+__global__ __launch_bounds__(256) void k_row_len(const u32* __restrict__ rows, size_t stride, size_t pad, size_t n, u32* __restrict__ lens) {
+  __shared__ u32 sh[256];
+  const u32* row = rows + ((size_t)blockIdx.x * stride + pad) * P::NW;
+  u32 best = 0;
+  for (size_t i = threadIdx.x; i < n; i += 256) {
+    u32 a = 0;
+#pragma unroll
+    for (int k = 0; k < P::NW; k++) a |= row[i * P::NW + k];
+    if (a) best = (u32)i + 1;
+  }
+  sh[threadIdx.x] = best;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off && sh[threadIdx.x + off] > sh[threadIdx.x]) sh[threadIdx.x] = sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) lens[blockIdx.x] = sh[0];
+}
+
 // ---- interpolation plans: what fast_interpolate derives from the domain alone ------------------------------------------------------
 struct InterpPlanBase {
   int fid = -1;
@@ -686,19 +708,32 @@ static int interp_plan_get(int fid, const uint64_t* domain, size_t n, const uint
 }
 
 template <class P>
+// values / out on the host, or -- d_values / d_out non-null -- in HBM (mzk_fast_interpolate_batch_dev: `user` is the stream the caller's
+// buffers are ordered on; the work runs on the context's stream behind an event and is complete when the call returns)
 static int interpolate_impl(int fid, const uint64_t* domain, const uint64_t* values, size_t n, size_t batch, const uint64_t* root, size_t root_order,
-                            uint64_t* out, size_t* out_lens) {
+                            uint64_t* out, size_t* out_lens, const void* d_values = nullptr, void* d_out = nullptr, hipStream_t user = nullptr) {
   const HostField* hf = host_field(fid);
   const int nl = hf->nl;
   const size_t esz = field_bytes(fid);
   if (n == 0) { for (size_t r = 0; r < batch; r++) out_lens[r] = 0; return MZK_OK; }                 // ntt.rs:207-209
+  const bool on_device = d_values != nullptr;
   if (n == 1) {                                                                                      // ntt.rs:211-215: coef = [values[0]], untrimmed
-    memcpy(out, values, batch * esz);
+    if (on_device) {
+      MZK_HIP(hipMemcpyAsync(d_out, d_values, batch * esz, hipMemcpyDeviceToDevice, user));
+      MZK_HIP(hipStreamSynchronize(user));
+    } else memcpy(out, values, batch * esz);
     for (size_t r = 0; r < batch; r++) out_lens[r] = 1;
     return MZK_OK;
   }
   hipStream_t s = ctx().stream;
   WsGuard wsg(s);
+  if (on_device && user != s) {          // the caller's buffers are complete on `user`: the context's stream waits for that point
+    hipEvent_t ev;
+    MZK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e1 = hipEventRecord(ev, user), e2 = e1 == hipSuccess ? hipStreamWaitEvent(s, ev, 0) : e1;
+    (void)hipEventDestroy(ev);
+    MZK_HIP(e2);
+  }
   MZK_TRY(check_order_for(n - n / 2, root_order, "fast_interpolate"));        // ntt.rs:219-220
   // Everything that depends on the DOMAIN alone -- the subproduct tree with its transformed levels, Z'(d_i) -- is a plan, kept per
   // context like the twiddle tables of a transform: a STARK prover interpolates every trace over the same omicron domain
@@ -716,34 +751,29 @@ static int interpolate_impl(int fid, const uint64_t* domain, const uint64_t* val
   DevBuf& d_zp = plan->d_zp;
   // registers go through the up-sweep in groups (at most 2^24 elements per buffer)
   const size_t group = std::max<size_t>(1, std::min<size_t>(batch, ((size_t)1 << 24) / T.N));
-  DevBuf d_vals, d_ws, d_ress;
-  MZK_TRY(d_vals.alloc(group * n * esz)); MZK_TRY(d_ws.alloc(group * T.N * esz)); MZK_TRY(d_ress.alloc(group * T.N * esz));
-  std::vector<uint64_t> res(group * T.N * nl);
+  DevBuf d_vals, d_ws, d_ress, d_lens;
+  if (!on_device) MZK_TRY(d_vals.alloc(group * n * esz));
+  MZK_TRY(d_ws.alloc(group * T.N * esz)); MZK_TRY(d_ress.alloc(group * T.N * esz)); MZK_TRY(d_lens.alloc(group * 4 + 64));
+  std::vector<u32> lens(group);
   for (size_t r0 = 0; r0 < batch; r0 += group) {
     const size_t g = std::min(group, batch - r0);
-    MZK_HIP(hipMemcpyAsync(d_vals.p, values + r0 * n * nl, g * n * esz, hipMemcpyHostToDevice, s));
+    const void* vals = on_device ? (const void*)((const uint8_t*)d_values + r0 * n * esz) : d_vals.p;
+    if (!on_device) MZK_HIP(hipMemcpyAsync(d_vals.p, values + r0 * n * nl, g * n * esz, hipMemcpyHostToDevice, s));
     MZK_HIP(hipMemsetAsync(d_ws.p, 0, g * T.N * esz, s));
     // all registers of the group in one launch: they divide by the same Z'(d_i), whose inverses the plan holds (round 4: one launch and
     // one inversion chain per REGISTER, 16 x 60 us of a 3.5-ms batch of 16 registers of 2^14 points; then one shared chain, 0.18 ms)
-    MZK_TRY(pointwise_mul_shared_dev(fid, d_vals.p, n, d_zp.p, d_ws.p, T.N, n, g, s));
+    MZK_TRY(pointwise_mul_shared_dev(fid, vals, n, d_zp.p, d_ws.p, T.N, n, g, s));
     MZK_TRY(T.combine(d_dom.p, d_ws.p, d_ress.p, g));
-    MZK_HIP(hipMemcpyAsync(res.data(), d_ress.p, g * T.N * esz, hipMemcpyDeviceToHost, s));
+    // sum_i w_i Z_pad / (X - d_i) = X^pad * interpolant: row r of the result is elements [pad, pad + n) of its T.N-element row, copied out as
+    // n elements (zeros beyond the trimmed length: polynomial.rs:214-228 trims like the final `+`; the length comes from the device)
+    hipLaunchKernelGGL((k_row_len<P>), dim3((unsigned)g), dim3(256), 0, s, (const u32*)d_ress.p, T.N, T.pad, n, (u32*)d_lens.p);
+    MZK_HIP(hipGetLastError());
+    const uint8_t* src = (const uint8_t*)d_ress.p + T.pad * esz;
+    if (on_device) MZK_HIP(hipMemcpy2DAsync((uint8_t*)d_out + r0 * n * esz, n * esz, src, T.N * esz, n * esz, g, hipMemcpyDeviceToDevice, s));
+    else MZK_HIP(hipMemcpy2DAsync(out + r0 * n * nl, n * esz, src, T.N * esz, n * esz, g, hipMemcpyDeviceToHost, s));
+    MZK_HIP(hipMemcpyAsync(lens.data(), d_lens.p, g * 4, hipMemcpyDeviceToHost, s));
     MZK_HIP(hipStreamSynchronize(s));
-    for (size_t r = 0; r < g; r++) {
-      const uint64_t* rr = res.data() + r * T.N * nl;
-      // sum_i w_i Z_pad / (X - d_i) = X^pad * interpolant; trimmed like the final `+` (polynomial.rs:214-228)
-      size_t len = n;
-      while (len > 0) {
-        uint64_t a = 0;
-        for (int k = 0; k < nl; k++) a |= rr[(len - 1 + T.pad) * nl + k];
-        if (a) break;
-        len--;
-      }
-      uint64_t* dst = out + (r0 + r) * n * nl;
-      memcpy(dst, rr + T.pad * nl, len * esz);
-      if (batch > 1 && len < n) memset(dst + len * nl, 0, (n - len) * esz);
-      out_lens[r0 + r] = len;
-    }
+    for (size_t r = 0; r < g; r++) out_lens[r0 + r] = lens[r];
   }
   return MZK_OK;
 }
@@ -799,6 +829,19 @@ int mzk_fast_interpolate_batch(int field_id, const uint64_t* domain, const uint6
   MZK_TRY(check_canonical(hf, values, n * batch, "values"));
   return field_id == MZK_FIELD_M128 ? interpolate_impl<M128Params>(field_id, domain, values, n, batch, root, root_order, out, out_lens)
                                     : interpolate_impl<FrParams>(field_id, domain, values, n, batch, root, root_order, out, out_lens);
+}
+
+int mzk_fast_interpolate_batch_dev(int field_id, const uint64_t* domain, const void* d_values, size_t n, size_t batch, const uint64_t* root,
+                                   size_t root_order, void* d_out, size_t* out_lens, void* stream) {
+  MZK_ENTER();
+  if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("fast_interpolate: bad field id %d", field_id); return MZK_E_ARG; }
+  if (batch == 0) return MZK_OK;
+  if (!root || !out_lens || (n && (!domain || !d_values || !d_out))) { set_error("fast_interpolate: null pointer"); return MZK_E_ARG; }
+  const HostField* hf = host_field(field_id);
+  MZK_TRY(check_root(hf, root, root_order));
+  MZK_TRY(check_canonical(hf, domain, n, "domain"));
+  return field_id == MZK_FIELD_M128 ? interpolate_impl<M128Params>(field_id, domain, nullptr, n, batch, root, root_order, nullptr, out_lens, d_values, d_out, (hipStream_t)stream)
+                                    : interpolate_impl<FrParams>(field_id, domain, nullptr, n, batch, root, root_order, nullptr, out_lens, d_values, d_out, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -155,6 +155,38 @@ def test_batched_interpolation_shares_the_tree_and_equals_single_calls(mz, fid):
 
 
 @pytest.mark.parametrize("fid", [FR, M128])
+def test_interpolation_with_values_and_coefficients_in_hbm(mz, fid):
+    """mzk_fast_interpolate_batch_dev: the trace uploaded once, the coefficients left in HBM for the extension.  Rows (zeros behind the
+    trimmed length) and lengths equal the host-buffer call and the oracle; a zero register, a constant one, n = 1, a repeated point, a
+    ragged size; the buffers ordered on a stream of the caller's, not the library's."""
+    import torch
+    nl = orc.LIMBS[fid]
+    side = torch.cuda.Stream()
+    for n, lg in ((1, 3), (2, 3), (65, 8), (300, 10), (1025, 12), (4093, 13)):
+        om = orc.root_of(fid, lg)
+        dom = orc.synth_vector(fid, 41 + n, n)
+        if n >= 65:
+            dom[9] = dom[2]
+        vals = np.stack([orc.synth_vector(fid, 950 + k + n, n) for k in range(5)])
+        vals[1] = 0
+        vals[2] = vals[2][0]
+        want = mz.fast_interpolate_batch(fid, dom, vals, om, 1 << lg)
+        with torch.cuda.stream(side):
+            d_v = torch.from_numpy(vals.view(np.int64).reshape(-1).copy()).cuda()
+            d_o = torch.full((5 * n * nl,), -1, dtype=torch.int64, device="cuda")
+            lens = mz.fast_interpolate_batch_dev(fid, dom, d_v.data_ptr(), 5, om, 1 << lg, d_o.data_ptr(), side.cuda_stream)
+        rows = d_o.cpu().numpy().view(np.uint64).reshape(5, n, nl)
+        for k in range(5):
+            assert lens[k] == want[k].shape[0], (n, k)
+            assert np.array_equal(rows[k, :lens[k]], want[k]), (n, k)
+            assert not rows[k, lens[k]:].any(), (n, k)
+        if n == 300:
+            rc, ref = orc.fast_interpolate_ref(fid, dom, vals[3], om, 1 << lg)
+            assert rc == 0 and np.array_equal(rows[3, :lens[3]], ref)
+    assert mz.fast_interpolate_batch_dev(fid, orc.synth_vector(fid, 1, 4), 0, 0, orc.root_of(fid, 3), 8, 0) == []
+
+
+@pytest.mark.parametrize("fid", [FR, M128])
 def test_interpolation_plans_are_keyed_by_the_exact_domain(mz, fid):
     """Round 5: what fast_interpolate derives from the domain alone (subproduct tree, Z'(d_i)) is kept per context like a transform's
     twiddle tables.  The key is the exact domain: the same domain again (other values) reuses the plan and still equals the oracle;

@@ -44,6 +44,16 @@ for rep in range(3):            # first pass warms plans and workspaces; the fas
     # for ~35 ms once in a few hundred calls, whatever is running)
     polys_loop, t_i1 = timed(lambda: [mz.fast_interpolate(fid, dom, trace[r], omicron, 1 << lg_om) for r in range(R)])
     polys_batch, t_i2 = timed(lambda: mz.fast_interpolate_batch(fid, dom, trace, omicron, 1 << lg_om))
+    import torch
+    d_out = torch.zeros(R * cycles * 2, dtype=torch.int64, device="cuda")
+    def interp_hbm():
+        d_tr = torch.from_numpy(np.ascontiguousarray(trace).view(np.int64).reshape(-1)).cuda()
+        lens = mz.fast_interpolate_batch_dev(fid, dom, d_tr.data_ptr(), R, omicron, 1 << lg_om, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return lens
+    lens_hbm, t_i3 = timed(interp_hbm)
+    rows_hbm = d_out.cpu().numpy().view(np.uint64).reshape(R, cycles, 2)
+    assert all(lens_hbm[r] == len(polys_batch[r]) and np.array_equal(rows_hbm[r, :lens_hbm[r]], polys_batch[r]) for r in range(R))
     coefs = pad(polys_batch, 1 << lg_om)
     cw_loop, t_l1 = timed(lambda: [mz.coset_lde(fid, coefs[r], orc.M128_GEN, omega, 1 << lg_fri) for r in range(R)])
     cw_batch, t_l2 = timed(lambda: mz.coset_lde_batch(fid, coefs, orc.M128_GEN, omega, 1 << lg_fri))
@@ -64,13 +74,14 @@ for rep in range(3):            # first pass warms plans and workspaces; the fas
     assert same
     if rep == 0:
         continue
-    for k, v in (("i1", t_i1), ("i2", t_i2), ("l1", t_l1), ("l2", t_l2), ("m1", t_m1), ("m2", t_m2), ("o1", t_o1), ("o2", t_o2), ("o3", t_o3), ("f", t_f)):
+    for k, v in (("i1", t_i1), ("i2", t_i2), ("i3", t_i3), ("l1", t_l1), ("l2", t_l2), ("m1", t_m1), ("m2", t_m2), ("o1", t_o1), ("o2", t_o2), ("o3", t_o3), ("f", t_f)):
         best[k] = min(best.get(k, v), v)
 print("M128, %d registers x %d cycles, FRI domain 2^%d, %d FRI rounds, %d openings per round" % (R, cycles, lg_fri, rounds, 3 * T))
 print("  step                         item by item     one call")
 for name, a, b in (("fast_interpolate", "i1", "i2"), ("fast_coset_evaluate", "l1", "l2"), ("Merkle::commit", "m1", "m2"), ("Merkle::open (query phase)", "o1", "o2")):
     print("  %-28s %9.2f ms  %9.2f ms" % (name, best[a], best[b]))
 print("  %-28s %9s     %9.2f ms   (one call per round: mzk_merkle_open_batch)" % ("  same, round by round", "", best["o3"]))
+print("  %-28s %9s     %9.2f ms   (mzk_fast_interpolate_batch_dev: trace uploaded inside, coefficients left in HBM)" % ("fast_interpolate, HBM form", "", best["i3"]))
 print("  %-28s %9s     %9.2f ms   (one call in both)" % ("FRI::commit, trees kept", "", best["f"]))
 print("  total                        %9.2f ms  %9.2f ms   identical results: True" % (best["i1"] + best["l1"] + best["m1"] + best["o1"] + best["f"],
                                                                                   best["i2"] + best["l2"] + best["m2"] + best["o2"] + best["f"]))
