@@ -26,7 +26,16 @@ def special_scalars(n):
     s = orc.synth_vector(FR, rng.getrandbits(40), max(n, 1))[:n].copy()
     p = orc.P_FR
     pool = [0, 1, 2, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 1 << 253, (1 << 128) - 1, 1 << 127, 0xFFFF, 0x8000, 0x10000]
-    mode = rng.randrange(4)
+    mode = rng.randrange(6)
+    if mode >= 4 and n:          # short scalars (witness values): bits, bytes, 16 / 64 / 128 / 248-bit -- uneven sort bins, short segments
+        bits = rng.choice([1, 8, 16, 64, 128, 248])
+        full, rem = bits // 64, bits % 64
+        s[:, full + (1 if rem else 0):] = 0
+        if rem:
+            s[:, full] &= np.uint64((1 << rem) - 1)
+        if mode == 5:
+            s[rng.randrange(n):] = 0      # and a zero tail
+        return s
     for i in range(n):
         if mode == 1 and rng.random() < 0.3 or mode == 2:
             s[i] = orc.to_limbs([rng.choice(pool)], 4)[0]
@@ -96,7 +105,7 @@ def case_scale_columns():
 
 
 def case_msm():
-    n = rng.choice([0, 1, 2, 3, 17, 100, 1000, 4095, 4096, 4097, 9000, 20000, rng.randrange(1, 30000)])
+    n = rng.choice([0, 1, 2, 3, 17, 100, 1000, 4095, 4096, 4097, 9000, 20000, rng.randrange(1, 30000), rng.randrange(1 << 15, 1 << 17)])
     s = special_scalars(n)
     pts = orc.synth_points(rng.getrandbits(40), max(n, 1))[:n].copy()
     if n > 4:
@@ -184,6 +193,18 @@ def case_poly():
     vals = vec(fid, n)
     rc, want = orc.fast_interpolate_ref(fid, dom, vals, root, order)
     check("fast_interpolate", rc == 0 and np.array_equal(mz.fast_interpolate(fid, dom, vals, root, order), want), (fid, n))
+    import torch
+    batch = rng.choice([1, 2, 5])
+    rows = np.stack([vals] + [vec(fid, n) if rng.random() < 0.7 else np.zeros_like(vals) for _ in range(batch - 1)])
+    d_v = torch.from_numpy(rows.view(np.int64).reshape(-1).copy()).cuda()
+    d_o = torch.full((batch * n * NL[fid],), -1, dtype=torch.int64, device="cuda")
+    lens = mz.fast_interpolate_batch_dev(fid, dom, d_v.data_ptr(), batch, root, order, d_o.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    got = d_o.cpu().numpy().view(np.uint64).reshape(batch, n, NL[fid])
+    ok = rc == 0 and lens[0] == want.shape[0] and np.array_equal(got[0, :lens[0]], want)
+    for k in range(batch):
+        rk, wk = orc.fast_interpolate_ref(fid, dom, np.ascontiguousarray(rows[k]), root, order)
+        ok = ok and rk == 0 and lens[k] == wk.shape[0] and np.array_equal(got[k, :lens[k]], wk) and not got[k, lens[k]:].any()
+    check("fast_interpolate_batch_dev", ok, (fid, n, batch))
     cf = vec(fid, rng.choice([1, n, 2 * n + 1]))
     rc, want = orc.fast_evaluate_ref(fid, cf, dom, root, order)
     check("fast_evaluate", rc == 0 and np.array_equal(mz.fast_evaluate(fid, cf, dom, root, order), want), (fid, n))
