@@ -55,6 +55,29 @@ def recorded_traffic(kernel_prefix, section="KZG commit 2^20"):
     return best
 
 
+def recorded_valu_instructions(kernel_prefix, section="KZG commit 2^20"):
+    """Wave-level VALU instructions per launch (SQ_INSTS_VALU, mean) of a kernel from the newest profiles/r*_sq_counters.txt that names it in
+    the given section (written by tools/timing/pmc_sq_summary.py under rocprofv3 --pmc, a run of its own).  None if no such record exists."""
+    import glob, re
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.txt"))):
+        inside, in_kernel = False, False
+        for line in open(path):
+            if line.startswith("== "):
+                inside, in_kernel = section in line, False
+                continue
+            if not inside:
+                continue
+            if not line.startswith(" "):
+                in_kernel = kernel_prefix in line
+                continue
+            m = re.match(r"\s+SQ_INSTS_VALU\s+mean\s+([0-9.]+)", line)
+            if m and in_kernel:
+                best = {"instructions": float(m.group(1)), "source": "profiles/%s" % os.path.basename(path)}
+                in_kernel = False
+    return best
+
+
 def recorded_ntt_traffic(field_tag):
     """Bytes per 2^20-point transform from the newest profiles/r*_hbm_traffic_pmc.txt that has a section for this field
     (`== NTT <field_tag> 2^20`: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/timing/ntt_only.py): the sum over
@@ -1023,6 +1046,14 @@ def main():
             srs_roof["traffic_source"] = tr["source"]
     srs_roof["algorithmic_bytes_per_launch"] = 96 * n
     alu["kzg_commit_accumulate_frac"] = srs_mads / (srs_acc_ms * 1e-3) / MAD_PEAK_PER_S if srs_acc_ms == srs_acc_ms else None
+    # Among multiply-adds EVERY VALU instruction costs a multiply-add's issue slot (tools/microbench/op_rates.hip, profiles/round5_op_issue_rates.txt:
+    # 1.75 ns per wave-instruction and SIMD, whatever the mix), so the kernel's issue-side roofline is its executed VALU instructions (recorded
+    # SQ_INSTS_VALU of the same kernel at the same size) x that slot / its SIMDs
+    vi = recorded_valu_instructions("k_seg_accumulate") if args.log2n == 20 else None
+    if vi is not None and srs_acc_ms == srs_acc_ms:
+        simds = torch.cuda.get_device_properties(dev).multi_processor_count * 4
+        alu["kzg_commit_accumulate_valu_issue"] = {"frac": vi["instructions"] / simds * 1.75e-9 / (srs_acc_ms * 1e-3), "valu_instructions_per_launch": vi["instructions"],
+                                                   "slot_ns": 1.75, "source": vi["source"] + " (recorded counters) and profiles/round5_op_issue_rates.txt (the slot)"}
     out = {
         "metric": METRIC,
         "value": srs_rate, "unit": "pairs/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": srs_ms,
