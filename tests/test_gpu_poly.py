@@ -186,6 +186,25 @@ def test_interpolation_with_values_and_coefficients_in_hbm(mz, fid):
     assert mz.fast_interpolate_batch_dev(fid, orc.synth_vector(fid, 1, 4), 0, 0, orc.root_of(fid, 3), 8, 0) == []
 
 
+def test_interpolation_in_hbm_more_registers_than_one_group(mz):
+    """the registers go through the up-sweep in groups of at most 2^24 elements: 4100 registers of 4093 points are two groups (4096 + 4);
+    rows on both sides of the boundary against the single call"""
+    import torch
+    fid, n, lg, batch = M128, 4093, 13, 4100
+    om = orc.root_of(fid, lg)
+    dom = orc.synth_vector(fid, 77, n)
+    vals = orc.synth_vector(fid, 78, batch * n).reshape(batch, n, 2)
+    d_v = torch.from_numpy(vals.view(np.int64).reshape(-1)).cuda()
+    d_o = torch.full((batch * n * 2,), -1, dtype=torch.int64, device="cuda")
+    lens = mz.fast_interpolate_batch_dev(fid, dom, d_v.data_ptr(), batch, om, 1 << lg, d_o.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    for k in (0, 1, 4095, 4096, 4097, 4099):
+        want = mz.fast_interpolate(fid, dom, vals[k], om, 1 << lg)
+        row = d_o[k * n * 2:(k + 1) * n * 2].cpu().numpy().view(np.uint64).reshape(n, 2)
+        assert lens[k] == want.shape[0] and np.array_equal(row[:lens[k]], want) and not row[lens[k]:].any(), k
+    del d_v, d_o
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("fid", [FR, M128])
 def test_interpolation_plans_are_keyed_by_the_exact_domain(mz, fid):
     """Round 5: what fast_interpolate derives from the domain alone (subproduct tree, Z'(d_i)) is kept per context like a transform's
