@@ -340,6 +340,39 @@ __global__ __launch_bounds__(128) void k_merkle_level_pair(const u64* __restrict
   if (i >= count) return;                    // pair-uniform
   sha3_of_two_digests_pair(below + 8 * i, above + 4 * i, (int)(t & 1));
 }
+// LV consecutive small levels in one launch (round 5): a workgroup hashes 32 << LV parents from global children, then their parents from
+// the digests it just left in LDS, and so on -- each level after the first costs one hash (~5 us) instead of a launch of its own (8.7 us:
+// the same hash plus the dependent kernel boundary).  Every digest still goes to global memory for the authentication paths.
+template <int LV>
+__global__ __launch_bounds__(64 << LV) void k_merkle_level_pair_multi(const u64* __restrict__ below, size_t parents, u64* __restrict__ above) {
+  constexpr int H0 = 32 << LV;
+  __shared__ u32 sh[2][H0 * 8];
+  const int h = threadIdx.x >> 1, parity = threadIdx.x & 1;
+  size_t cnt = parents, base = (size_t)blockIdx.x * H0;
+  u64* dst = above;
+  int width = H0;
+#pragma unroll 1
+  for (int lv = 0; lv < LV; lv++) {
+    if (h < width && base + h < cnt) {                 // pair-uniform
+      u32 a[25];
+      const u32* c32 = lv == 0 ? reinterpret_cast<const u32*>(below + 8 * (base + h)) : sh[(lv - 1) & 1] + 16 * h;
+#pragma unroll
+      for (int i = 0; i < 8; i++) a[i] = c32[2 * i + parity];
+      a[8] = parity ? 0u : 0x06u;
+#pragma unroll
+      for (int i = 9; i < 25; i++) a[i] = 0;
+      a[16] = parity ? 0x80000000u : 0u;
+      keccak_f_pair(a, parity);
+      u32* o32 = reinterpret_cast<u32*>(dst + 4 * (base + h));
+      u32* l32 = sh[lv & 1] + 8 * h;
+#pragma unroll
+      for (int i = 0; i < 4; i++) { o32[2 * i + parity] = a[i]; l32[2 * i + parity] = a[i]; }
+    }
+    __syncthreads();
+    dst += 4 * cnt;
+    cnt >>= 1; base >>= 1; width >>= 1;
+  }
+}
 // the last levels (<= TAIL_NODES nodes each) in one workgroup: no launch per level; one lane pair per hash
 constexpr int TAIL_NODES = 512;
 __global__ __launch_bounds__(TAIL_NODES) void k_merkle_tail(u64* __restrict__ level, size_t count, size_t stop) {
@@ -500,6 +533,18 @@ static int merkle_hash_levels(int kind, int fid, const void* d_leaves, const u64
   size_t count = pairs;
   while (count > (size_t)TAIL_NODES && count > trees) {
     u64* above = below + 4 * count;
+    if (count / 2 <= LEVEL_PAIR_MAX && (count >> 3) >= (size_t)TAIL_NODES && (count >> 3) >= trees) {          // three levels in one launch
+      hipLaunchKernelGGL((k_merkle_level_pair_multi<3>), dim3((unsigned)((count / 2 + 255) / 256)), dim3(512), 0, s, (const u64*)below, count / 2, above);
+      below = above + 4 * (count / 2) + 4 * (count / 4);
+      count >>= 3;
+      continue;
+    }
+    if (count / 2 <= LEVEL_PAIR_MAX && (count >> 2) >= (size_t)TAIL_NODES && (count >> 2) >= trees) {          // two
+      hipLaunchKernelGGL((k_merkle_level_pair_multi<2>), dim3((unsigned)((count / 2 + 127) / 128)), dim3(256), 0, s, (const u64*)below, count / 2, above);
+      below = above + 4 * (count / 2);
+      count >>= 2;
+      continue;
+    }
     if (count / 2 <= LEVEL_PAIR_MAX)
       hipLaunchKernelGGL(k_merkle_level_pair, dim3((unsigned)((count + 127) / 128)), dim3(128), 0, s, (const u64*)below, count / 2, above);
     else
