@@ -125,6 +125,19 @@ int ws_get(WsSlot slot, size_t bytes, void** out) {
   return MZK_OK;
 }
 uint64_t ws_generation() { return ctx().ws_gen; }
+int d2h_sync(void* host, const void* dev, size_t bytes, hipStream_t s) {
+  if (bytes == 0 || bytes > SMALL_D2H_MAX) {
+    if (bytes) MZK_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
+    MZK_HIP(hipStreamSynchronize(s));
+    return MZK_OK;
+  }
+  Context& c = ctx();
+  if (!c.bounce) MZK_HIP(hipHostMalloc(&c.bounce, SMALL_D2H_MAX, hipHostMallocPortable));
+  MZK_HIP(hipMemcpyAsync(c.bounce, dev, bytes, hipMemcpyDeviceToHost, s));
+  MZK_HIP(hipStreamSynchronize(s));
+  memcpy(host, c.bounce, bytes);
+  return MZK_OK;
+}
 void ws_release_all() {
   Context& c = ctx();
   c.ws_gen = ++g_gen_counter;
@@ -478,6 +491,7 @@ void mzk_shutdown(void) {
       if (c.xstream[k]) (void)hipStreamDestroy(c.xstream[k]);
     }
     if (c.stream) (void)hipStreamDestroy(c.stream);
+    if (c.bounce) (void)hipHostFree(c.bounce);
     c = Context();
   }
   g_nctx = 0;
@@ -554,11 +568,7 @@ static int stage_in(WsSlot slot, const void* host, size_t bytes, void** dev, hip
   return MZK_OK;
 }
 // device result -> host buffer; returns with the host buffer complete
-static int stage_out(void* host, const void* dev, size_t bytes, hipStream_t s) {
-  if (bytes) MZK_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
-  return MZK_OK;
-}
+static int stage_out(void* host, const void* dev, size_t bytes, hipStream_t s) { return d2h_sync(host, dev, bytes, s); }
 // a second stream of the current context for transfers that should run beside its kernels, with the two events that fork it
 // from / join it to the context's stream (created on first use; shared with mzk_ntt_multi's exchange, which never overlaps a call)
 static int side_stream(hipStream_t* side, hipEvent_t* fork, hipEvent_t* join) {
@@ -737,14 +747,12 @@ int mzk_fft_multiply(int field_id, const uint64_t* a, size_t la, const uint64_t*
     MZK_TRY(ws_get(WS_MISC_C, esz, &dc));
     if (la == 0 || lb == 0) { *out_len = 0; return MZK_OK; }
     MZK_TRY(pointwise_mul_dev(field_id, da, db, dc, 1, s));
-    MZK_HIP(hipMemcpyAsync(res.data(), dc, esz, hipMemcpyDeviceToHost, s));
-    MZK_HIP(hipStreamSynchronize(s));
+    MZK_TRY(d2h_sync(res.data(), dc, esz, s));
   } else {
     if (!omega) { set_error("fft_multiply: null omega"); return MZK_E_ARG; }
     void* dc;
     MZK_TRY(conv_on_device(field_id, a, la, b, lb, omega, n, &dc, s));
-    MZK_HIP(hipMemcpyAsync(res.data(), dc, n * esz, hipMemcpyDeviceToHost, s));
-    MZK_HIP(hipStreamSynchronize(s));
+    MZK_TRY(d2h_sync(res.data(), dc, n * esz, s));
   }
   size_t lo = trimmed_len(res.data(), m, nl);  // truncate(m) then trim_trailing_zeros, polynomial.rs:271-275
   memcpy(out, res.data(), lo * esz);
@@ -792,8 +800,7 @@ int mzk_fast_multiply(int field_id, const uint64_t* a, size_t la, const uint64_t
   void* dc;
   MZK_TRY(conv_on_device(field_id, a, la, b, lb, r, order, &dc, s));
   std::vector<uint64_t> res(order * nl);
-  MZK_HIP(hipMemcpyAsync(res.data(), dc, order * esz, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(d2h_sync(res.data(), dc, order * esz, s));
   size_t lo = trim ? trimmed_len(res.data(), da + db - 1, nl) : order;
   memcpy(out, res.data(), lo * esz);
   *out_len = lo;
@@ -908,8 +915,7 @@ int mzk_msm_g1_bn254(const uint64_t* scalars, const uint64_t* points_xy, size_t 
     return MZK_OK;
   };
   MZK_TRY(msm_dev_impl(d_s, d_p, n, MSM_PTS_PLAIN, 0, d_o, false, s, &points_ready));
-  MZK_HIP(hipMemcpyAsync(out_xy, d_o, 64, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(d2h_sync(out_xy, d_o, 64, s));
   return MZK_OK;
 }
 int mzk_msm_g1_bn254_dev(const void* d_scalars, const void* d_points_xy, size_t n, void* d_out_xy, void* stream) {
@@ -1061,8 +1067,7 @@ int mzk_kzg_commit_srs(const mzk_srs* srs, const uint64_t* coef, size_t n, uint6
   MZK_TRY(stage_in(WS_MSM_SCALARS, coef, n * 32, &d_s, s));
   MZK_TRY(ws_get(WS_MISC_B, 256, &d_o));
   MZK_TRY(msm_dev_impl(d_s, srs->d_points_mont, n, srs->kind(), srs->n, d_o, false, s));
-  MZK_HIP(hipMemcpyAsync(out_xy, d_o, 64, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(d2h_sync(out_xy, d_o, 64, s));
   return MZK_OK;
 }
 
@@ -1261,8 +1266,7 @@ int mzk_kzg_open_srs_batch(const mzk_srs* srs, const uint64_t* coefs, size_t n, 
   char* d_w = d_y + count * 32;
   MZK_TRY(open_batch_route(srs, d_c, n, count, us, d_y, d_w, 0, MANY_MIN_COUNT, s));
   MZK_HIP(hipMemcpyAsync(ys, d_y, count * 32, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipMemcpyAsync(ws_xy, d_w, count * 64, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(d2h_sync(ws_xy, d_w, count * 64, s));
   return MZK_OK;
 }
 int mzk_kzg_commit_srs_batch(const mzk_srs* srs, const uint64_t* coefs, size_t n, size_t count, uint64_t* out_xy) {
@@ -1277,8 +1281,7 @@ int mzk_kzg_commit_srs_batch(const mzk_srs* srs, const uint64_t* coefs, size_t n
     MZK_TRY(ws_get(WS_MISC_F, count * 64, &d_o));
   }
   MZK_TRY(mzk_kzg_commit_srs_batch_dev(srs, d_c, n, count, d_o, 0, s));
-  MZK_HIP(hipMemcpyAsync(out_xy, d_o, count * 64, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(d2h_sync(out_xy, d_o, count * 64, s));
   return MZK_OK;
 }
 
@@ -1365,8 +1368,7 @@ int mzk_kzg_batch_open(const uint64_t* coef, size_t n, const uint64_t* us, size_
   MZK_TRY(ws_get(WS_NTT_IO_B, 64 + k * 32 + 64, &d_o));
   MZK_TRY(kzg_batch_open_dev(d_c, n, us, k, d_p, MSM_PTS_PLAIN, 0, (char*)d_o + 64, d_o, s));
   std::vector<uint64_t> tmp(8 + 4 * k + 8);
-  MZK_HIP(hipMemcpyAsync(tmp.data(), d_o, 64 + k * 32, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(d2h_sync(tmp.data(), d_o, 64 + k * 32, s));
   memcpy(w_xy, tmp.data(), 64);
   if (k) memcpy(ys, tmp.data() + 8, k * 32);
   return MZK_OK;
@@ -1408,8 +1410,7 @@ int mzk_kzg_open(const uint64_t* coef, size_t n, const uint64_t u[4], const uint
   MZK_TRY(ws_get(WS_NTT_IO_B, 256, &d_o));
   MZK_TRY(kzg_open_dev(d_c, n, u, d_p, MSM_PTS_PLAIN, 0, d_o, (char*)d_o + 64, nullptr, s));
   uint64_t tmp[16];
-  MZK_HIP(hipMemcpyAsync(tmp, d_o, 128, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(d2h_sync(tmp, d_o, 128, s));
   memcpy(y, tmp, 32);
   memcpy(w_xy, tmp + 8, 64);
   return MZK_OK;

@@ -72,7 +72,15 @@ struct Context {
   hipStream_t xstream[MZK_MAX_CTX] = {};
   hipEvent_t xdone[MZK_MAX_CTX] = {};
   hipEvent_t xready = nullptr;
+  void* bounce = nullptr;        // SMALL_D2H_MAX bytes of pinned host memory: the landing zone of d2h_sync's small results
 };
+// Result of a call -> host memory, and wait: the stream is idle on return.  A commitment, a Merkle root, a handful of lengths are 32-128
+// bytes, and hipMemcpyAsync into PAGEABLE memory costs ~12 us more than the same copy into pinned memory before the synchronize returns
+// (tools/microbench/root_mailbox.hip: 73.8 against 63.6 us around a 50-us kernel; a host-mapped mailbox the host polls saves 4 more and was
+// not worth its moving parts) -- per FRI round, per small commitment.  Up to SMALL_D2H_MAX bytes land in the context's pinned buffer and
+// are copied on from there; larger results go straight to the caller's buffer as before (56 GB/s either way).
+constexpr size_t SMALL_D2H_MAX = 4096;
+int d2h_sync(void* host, const void* dev, size_t bytes, hipStream_t s);
 // peer access between the devices of two contexts: 1 = enabled (or same device), 0 = the runtime refused (copies then stage
 // through the host inside hipMemcpyPeerAsync; still correct)
 int ctx_peer_enabled(int a, int b);

@@ -111,8 +111,7 @@ int mzk_msm_g2_bn254(const uint64_t* scalars, const uint64_t* points_xy, size_t 
     MZK_HIP(hipMemcpyAsync(d_p, points_xy, n * 128, hipMemcpyHostToDevice, s));
   }
   MZK_TRY(g2_msm_dev_impl(d_s, d_p, n, d_o, s));
-  MZK_HIP(hipMemcpyAsync(out_xy, d_o, 128, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(d2h_sync(out_xy, d_o, 128, s));
   return MZK_OK;
 }
 int mzk_kzg_setup_g2(const uint64_t alpha[4], const uint64_t g2_xy[16], size_t max_d, uint64_t* powers2_xy) {
@@ -132,8 +131,7 @@ int mzk_kzg_setup_g2(const uint64_t alpha[4], const uint64_t g2_xy[16], size_t m
   for (int i = 0; i < 4; i++) { aw.w[2 * i] = (u32)alpha[i]; aw.w[2 * i + 1] = (u32)(alpha[i] >> 32); }
   hipLaunchKernelGGL(k_g2_powers, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, s, aw, (const u32*)d_g, (size_t)0, count, (u32*)d_o);
   MZK_HIP(hipGetLastError());
-  MZK_HIP(hipMemcpyAsync(powers2_xy, d_o, count * 128, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(d2h_sync(powers2_xy, d_o, count * 128, s));
   return MZK_OK;
 }
 

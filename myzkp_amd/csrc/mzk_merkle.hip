@@ -639,8 +639,7 @@ static int merkle_build(int kind, int fid, const void* src, bool src_on_device, 
     const int nl = field_limbs64(fid);
     std::vector<uint64_t> host(n * (size_t)nl);
     if (src_on_device) {
-      MZK_HIP(hipMemcpyAsync(host.data(), src, leaf_bytes, hipMemcpyDeviceToHost, s));
-      MZK_HIP(hipStreamSynchronize(s));
+      MZK_TRY(d2h_sync(host.data(), src, leaf_bytes, s));
     } else {
       memcpy(host.data(), src, leaf_bytes);
     }
@@ -742,23 +741,20 @@ int mzk_merkle_root(const mzk_merkle* t, uint8_t* root, size_t cap, size_t* root
     size_t len;
     if (t->kind == 0) {
       uint64_t limbs[4];
-      MZK_HIP(hipMemcpyAsync(limbs, t->d_leaves, field_bytes(t->field), hipMemcpyDeviceToHost, ms.s));
-      MZK_HIP(hipStreamSynchronize(ms.s));
+      MZK_TRY(d2h_sync(limbs, t->d_leaves, field_bytes(t->field), ms.s));
       len = host_bincode_field(limbs, field_limbs64(t->field), buf, !t->neg.empty() && t->neg[0]);
       if (cap < len) { set_error("merkle_root: buffer too small (%zu < %zu)", cap, len); return MZK_E_LENGTH; }
       memcpy(root, buf, len);
     } else {
       len = (size_t)(t->offsets[1] - t->offsets[0]);
       if (cap < len) { set_error("merkle_root: buffer too small (%zu < %zu)", cap, len); return MZK_E_LENGTH; }
-      if (len) MZK_HIP(hipMemcpyAsync(root, t->d_leaves, len, hipMemcpyDeviceToHost, ms.s));
-      MZK_HIP(hipStreamSynchronize(ms.s));
+      MZK_TRY(d2h_sync(root, t->d_leaves, len, ms.s));
     }
     *root_len = len;
     return MZK_OK;
   }
   if (cap < 32) { set_error("merkle_root: buffer too small"); return MZK_E_LENGTH; }
-  MZK_HIP(hipMemcpyAsync(root, t->d_nodes + 4 * ((t->ragged ? t->m : t->n) - 2), 32, hipMemcpyDeviceToHost, ms.s));
-  MZK_HIP(hipStreamSynchronize(ms.s));
+  MZK_TRY(d2h_sync(root, t->d_nodes + 4 * ((t->ragged ? t->m : t->n) - 2), 32, ms.s));
   *root_len = 32;
   return MZK_OK;
 }
@@ -811,8 +807,7 @@ int mzk_merkle_open(const mzk_merkle* t, size_t index, uint8_t* path, size_t str
       hipLaunchKernelGGL(k_merkle_gather, dim3(1), dim3(64), 0, s, (const u64*)t->d_nodes, t->m, p, t->depth, d_out);
       MZK_HIP(hipGetLastError());
       uint8_t tmp[64 * 32];
-      MZK_HIP(hipMemcpyAsync(tmp, d_out, (size_t)(t->depth - 1) * 32, hipMemcpyDeviceToHost, s));
-      MZK_HIP(hipStreamSynchronize(s));
+      MZK_TRY(d2h_sync(tmp, d_out, (size_t)(t->depth - 1) * 32, s));
       for (int l = 1; l < t->depth; l++) { memcpy(path + (size_t)(l + k) * stride, tmp + 32 * (l - 1), 32); path_len[l + k] = 32; }
     } else {
       MZK_HIP(hipStreamSynchronize(s));
@@ -834,8 +829,7 @@ int mzk_merkle_open(const mzk_merkle* t, size_t index, uint8_t* path, size_t str
     hipLaunchKernelGGL(k_merkle_gather, dim3(1), dim3(64), 0, s, (const u64*)t->d_nodes, t->n, index, t->depth, d_out);
     MZK_HIP(hipGetLastError());
     uint8_t tmp[64 * 32];
-    MZK_HIP(hipMemcpyAsync(tmp, d_out, (size_t)(t->depth - 1) * 32, hipMemcpyDeviceToHost, s));
-    MZK_HIP(hipStreamSynchronize(s));
+    MZK_TRY(d2h_sync(tmp, d_out, (size_t)(t->depth - 1) * 32, s));
     for (int l = 1; l < t->depth; l++) { memcpy(path + (size_t)l * stride, tmp + 32 * (l - 1), 32); path_len[l] = 32; }
   } else {
     MZK_HIP(hipStreamSynchronize(s));
@@ -880,8 +874,7 @@ int mzk_merkle_open_batch(const mzk_merkle* t, const uint64_t* indices, size_t c
   std::vector<uint64_t> hn(node_words64 + 1);
   std::vector<uint32_t> hl(count * (size_t)lw);
   if (node_words64) MZK_HIP(hipMemcpyAsync(hn.data(), d_on, node_words64 * 8, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipMemcpyAsync(hl.data(), d_ol, count * (size_t)lw * 4, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(d2h_sync(hl.data(), d_ol, count * (size_t)lw * 4, s));
   for (size_t q = 0; q < count; q++) {
     uint64_t limbs[4] = {0, 0, 0, 0};
     memcpy(limbs, hl.data() + q * lw, (size_t)lw * 4);
@@ -964,8 +957,7 @@ int mzk_merkle_open_multi(const mzk_merkle* const* trees, size_t n_trees, const 
   std::vector<uint64_t> hn(total_nodes + 1);
   std::vector<uint32_t> hl(total_leaf_words + 1);
   if (total_nodes) MZK_HIP(hipMemcpyAsync(hn.data(), d_on, total_nodes * 8, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipMemcpyAsync(hl.data(), d_ol, total_leaf_words * 4, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(d2h_sync(hl.data(), d_ol, total_leaf_words * 4, s));
   size_t at = 0, at_nodes = 0, at_leaf = 0, at_entry = 0;
   for (size_t t = 0; t < n_trees; t++) {
     if (counts[t] == 0) continue;
@@ -1027,8 +1019,7 @@ int mzk_merkle_commit_field_dev(int field_id, const void* d_elems, size_t n, uin
   if (n == 1) {
     uint64_t limbs[4];
     uint8_t buf[48];
-    MZK_HIP(hipMemcpyAsync(limbs, d_elems, field_bytes(field_id), hipMemcpyDeviceToHost, s));
-    MZK_HIP(hipStreamSynchronize(s));
+    MZK_TRY(d2h_sync(limbs, d_elems, field_bytes(field_id), s));
     const size_t len = host_bincode_field(limbs, field_limbs64(field_id), buf);
     if (cap < len) { set_error("merkle: root buffer too small"); return MZK_E_LENGTH; }
     memcpy(root, buf, len);
@@ -1039,8 +1030,7 @@ int mzk_merkle_commit_field_dev(int field_id, const void* d_elems, size_t n, uin
   u64* d_nodes;
   MZK_TRY(ws_get(WS_MERKLE_NODES, (n - 1) * 32, (void**)&d_nodes));
   MZK_TRY(merkle_hash_levels(0, field_id, d_elems, nullptr, n, d_nodes, s));
-  MZK_HIP(hipMemcpyAsync(root, d_nodes + 4 * (n - 2), 32, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(d2h_sync(root, d_nodes + 4 * (n - 2), 32, s));
   *root_len = 32;
   return MZK_OK;
 }
@@ -1060,8 +1050,7 @@ int mzk_merkle_commit_field_batch_dev(int field_id, const void* d_elems, size_t 
   u64* d_nodes;
   MZK_TRY(ws_get(WS_MERKLE_NODES, (total - batch) * 32, (void**)&d_nodes));
   MZK_TRY(merkle_hash_levels(0, field_id, d_elems, nullptr, total, d_nodes, s, nullptr, batch));
-  MZK_HIP(hipMemcpyAsync(roots, d_nodes + 4 * (total - 2 * batch), batch * 32, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(d2h_sync(roots, d_nodes + 4 * (total - 2 * batch), batch * 32, s));
   return MZK_OK;
 }
 int mzk_merkle_commit_field_batch(int field_id, const uint64_t* elems, size_t n, size_t batch, uint8_t* roots) {
@@ -1177,12 +1166,10 @@ static int fri_commit_rounds(int field_id, const uint64_t* codeword, const uint8
     uint8_t* root = roots + 48 * (size_t)r;
     if (len == 1) {
       uint64_t limbs[4];
-      MZK_HIP(hipMemcpyAsync(limbs, cur, esz, hipMemcpyDeviceToHost, s));
-      MZK_HIP(hipStreamSynchronize(s));
+      MZK_TRY(d2h_sync(limbs, cur, esz, s));
       root_len[r] = host_bincode_field(limbs, nl, root, r == 0 && negative && negative[0]);
     } else {
       MZK_TRY(merkle_hash_levels(0, field_id, cur, nullptr, len, d_nodes, s, r == 0 ? d_neg : nullptr));
-      MZK_HIP(hipMemcpyAsync(root, d_nodes + 4 * (len - 2), 32, hipMemcpyDeviceToHost, s));
       if (trees_out) {      // keep this round's tree: its leaves and digests stay where they were computed, in the shared block
         mzk_merkle* t = new mzk_merkle();
         t->kind = 0; t->field = field_id; t->n = len; t->stream = s;
@@ -1202,7 +1189,7 @@ static int fri_commit_rounds(int field_id, const uint64_t* codeword, const uint8
         }
         MZK_TRY(merkle_stamp(t, s));
       }
-      MZK_HIP(hipStreamSynchronize(s));
+      MZK_TRY(d2h_sync(root, d_nodes + 4 * (len - 2), 32, s));      // the transcript needs the root now (through the pinned landing zone: d2h_sync)
       root_len[r] = 32;
     }
     if (r == 0 && d_neg) {      // from here on the codeword is its canonical representative: v -> p - |v| where Sign::Minus
@@ -1225,8 +1212,7 @@ static int fri_commit_rounds(int field_id, const uint64_t* codeword, const uint8
     cur = next;
     len /= 2;
   }
-  if (codewords_out) MZK_HIP(hipMemcpyAsync(codewords_out, d_all, total * esz, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(d2h_sync(codewords_out, d_all, codewords_out ? total * esz : 0, s));
   return MZK_OK;
 }
 int mzk_fri_commit(int field_id, const uint64_t* codeword, size_t n, const uint64_t* omega, const uint64_t* offset, int num_rounds,

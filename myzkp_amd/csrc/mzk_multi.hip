@@ -54,8 +54,7 @@ static int gather_and_fold(int world, const uint64_t* h_records, uint64_t out_xy
   MZK_HIP(hipMemcpyAsync(d_rec, h_records, (size_t)world * 128, hipMemcpyHostToDevice, s));
   void* d_out = (char*)d_rec + (size_t)world * 128;
   MZK_TRY(msm_fold_partials_impl(d_rec, world, d_out, s));
-  MZK_HIP(hipMemcpyAsync(out_xy, d_out, 64, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(d2h_sync(out_xy, d_out, 64, s));
   return MZK_OK;
 }
 

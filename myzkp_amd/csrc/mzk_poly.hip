@@ -545,8 +545,7 @@ static int zerofier_impl(int fid, const uint64_t* domain, size_t n, const uint64
   MZK_HIP(hipMemcpyAsync(d_dom.p, domain, n * esz, hipMemcpyHostToDevice, s));
   MZK_TRY(T.build(d_dom.p, false));
   std::vector<uint64_t> top(T.N * nl);
-  MZK_HIP(hipMemcpyAsync(top.data(), T.low[T.levels].p, T.N * esz, hipMemcpyDeviceToHost, s));
-  MZK_HIP(hipStreamSynchronize(s));
+  MZK_TRY(d2h_sync(top.data(), T.low[T.levels].p, T.N * esz, s));
   memset(out, 0, len * esz);
   for (size_t j = 0; j < n; j++) memcpy(out + j * nl, top.data() + (j + T.pad) * nl, esz);     // Z[j] = Zpad[j + pad]
   out[n * nl] = 1;                                                                             // monic
@@ -572,8 +571,7 @@ static int evaluate_impl(int fid, const uint64_t* coef, size_t m, const uint64_t
   MZK_TRY(T.build(d_dom.p, true));
   if (m <= T.N) {
     MZK_TRY(T.evaluate(d_f.p, m, d_dom.p, d_vals.p, n));
-    MZK_HIP(hipMemcpyAsync(out, d_vals.p, n * esz, hipMemcpyDeviceToHost, s));
-    MZK_HIP(hipStreamSynchronize(s));
+    MZK_TRY(d2h_sync(out, d_vals.p, n * esz, s));
     return MZK_OK;
   }
   // deg f >= N (more coefficients than padded points; no reference caller does this): f = sum_b X^(b N) f_b, so
@@ -584,8 +582,7 @@ static int evaluate_impl(int fid, const uint64_t* coef, size_t m, const uint64_t
   for (size_t b = nb; b-- > 0;) {
     const size_t lo = b * T.N, cnt = (m - lo < T.N) ? m - lo : T.N;
     MZK_TRY(T.evaluate((const uint8_t*)d_f.p + lo * esz, cnt, d_dom.p, d_vals.p, n));
-    MZK_HIP(hipMemcpyAsync(blk.data(), d_vals.p, n * esz, hipMemcpyDeviceToHost, s));
-    MZK_HIP(hipStreamSynchronize(s));
+    MZK_TRY(d2h_sync(blk.data(), d_vals.p, n * esz, s));
     for (size_t i = 0; i < n; i++) {       // acc = acc * x^N + f_b(x)   (n host products per block: parameter-sized next to the tree work)
       uint64_t t[4];
       h_mulmod(hf, t, acc.data() + i * nl, xn.data() + i * nl);
@@ -771,8 +768,7 @@ static int interpolate_impl(int fid, const uint64_t* domain, const uint64_t* val
     const uint8_t* src = (const uint8_t*)d_ress.p + T.pad * esz;
     if (on_device) MZK_HIP(hipMemcpy2DAsync((uint8_t*)d_out + r0 * n * esz, n * esz, src, T.N * esz, n * esz, g, hipMemcpyDeviceToDevice, s));
     else MZK_HIP(hipMemcpy2DAsync(out + r0 * n * nl, n * esz, src, T.N * esz, n * esz, g, hipMemcpyDeviceToHost, s));
-    MZK_HIP(hipMemcpyAsync(lens.data(), d_lens.p, g * 4, hipMemcpyDeviceToHost, s));
-    MZK_HIP(hipStreamSynchronize(s));
+    MZK_TRY(d2h_sync(lens.data(), d_lens.p, g * 4, s));
     for (size_t r = 0; r < g; r++) out_lens[r0 + r] = lens[r];
   }
   return MZK_OK;
