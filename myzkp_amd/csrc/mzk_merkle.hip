@@ -488,9 +488,12 @@ namespace mzk {
 static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 
 // end of a successful build on stream s of the current context
-static int merkle_stamp(mzk_merkle* t, hipStream_t s) {
+// complete_on_return: the caller synchronizes the stream before it hands the tree out (every round of mzk_fri_commit does, for the
+// transcript), so there is nothing to order later calls behind: no event (one marker packet per round less between the kernels)
+static int merkle_stamp(mzk_merkle* t, hipStream_t s, bool complete_on_return = false) {
   t->ctx_index = ctx().index;
   t->device = ctx().device;
+  if (complete_on_return) return MZK_OK;
   if (!t->built) MZK_HIP(hipEventCreateWithFlags(&t->built, hipEventDisableTiming));
   MZK_HIP(hipEventRecord(t->built, s));
   return MZK_OK;
@@ -1187,7 +1190,7 @@ static int fri_commit_rounds(int field_id, const uint64_t* codeword, const uint8
           t->d_leaves = own; t->owns_leaves = true;
           t->neg.assign(negative, negative + n);
         }
-        MZK_TRY(merkle_stamp(t, s));
+        MZK_TRY(merkle_stamp(t, s, true));
       }
       MZK_TRY(d2h_sync(root, d_nodes + 4 * (len - 2), 32, s));      // the transcript needs the root now (through the pinned landing zone: d2h_sync)
       root_len[r] = 32;
