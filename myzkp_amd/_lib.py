@@ -609,7 +609,7 @@ def fri_commit(fid, codeword, omega, offset, num_rounds, challenge, negative=Non
         # An exception must not escape into C (ctypes would print it and carry on with whatever alpha_out holds):
         # keep it, make the C loop stop (non-zero status -> MZK_E_CALLBACK), re-raise below.
         try:
-            a = challenge(rnd, bool(last), bytes(root[:root_len]))
+            a = challenge(rnd, bool(last), ctypes.string_at(root, root_len))      # (slicing the pointer builds a list first: ~4 us per round)
             if last:
                 return 0
             if a is None:
