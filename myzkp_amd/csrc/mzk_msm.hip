@@ -1161,6 +1161,45 @@ __global__ __launch_bounds__(128) void k_halve_step(u32* __restrict__ buckets, i
   if (id >= total) return;                        // quad-uniform
   halve_op(buckets + ((size_t)blockIdx.y << lgB) * 32, lgB, t, id, (int)(tid & 3));
 }
+// SEVERAL halving steps per launch.  Steps t0 .. t0 + s - 1 never pair two indices that differ by less than 2^(lgB - t0 - s), so
+// every live region (region 0 = [0, W) and the regions a = 1 .. t0 at 2^(lgB - a), W = 2^(lgB - t0)) falls apart into
+// 2^(lgB - t0 - s) independent problems of 2^s elements with that stride: the same recursion on a local array (region 0: every
+// step leaves its upper half behind as a new block; the others only fold).  One workgroup loads its 2^s records (<= 32 KiB)
+// into LDS, runs the s steps between barriers (DPP-quad additions, 128 quads) and stores back the s + 1 (or one) records
+// that are still live -- instead of s dependent launches at ~6-10 us each whatever they hold (the 2^16 buckets of the
+// 17-bit commit: thirteen launches, 91 us; now two launches of eight steps each).
+constexpr int HMULTI_THREADS = 512;
+constexpr int HMULTI_QUADS = HMULTI_THREADS / 4;
+constexpr int HMULTI_MAX_S = 8;
+__global__ __launch_bounds__(HMULTI_THREADS) void k_halve_multi(u32* __restrict__ buckets, int lgB, int t0, int s) {
+  extern __shared__ __attribute__((aligned(16))) u32 lds_hm[];
+  const int lgs = lgB - t0 - s;                    // log2 of the stride
+  const int a = (int)(blockIdx.x >> lgs);          // region
+  const size_t j0 = blockIdx.x & (((size_t)1 << lgs) - 1);
+  u32* buf = buckets + ((size_t)blockIdx.y << lgB) * 32;
+  const size_t base = ((a == 0) ? 0 : ((size_t)1 << (lgB - a))) + j0;
+  const int ql = threadIdx.x & 3, quad = threadIdx.x >> 2;
+  uint4* l4 = reinterpret_cast<uint4*>(lds_hm);
+  uint4* g4 = reinterpret_cast<uint4*>(buf);
+  for (int i = threadIdx.x; i < (8 << s); i += HMULTI_THREADS) l4[i] = g4[(base + ((size_t)(i >> 3) << lgs)) * 8 + (i & 7)];
+  __syncthreads();
+  for (int tl = 0; tl < s; tl++) {
+    const int lgh = s - tl - 1;
+    const int total = ((a == 0) ? (tl + 1) : 1) << lgh;
+    for (int id = quad; id < total; id += HMULTI_QUADS) {        // quad-uniform
+      const int aa = id >> lgh, j = id & ((1 << lgh) - 1);
+      const int lo = ((aa == 0) ? 0 : (1 << (s - aa))) + j;
+      const Xyzz x = xyzz_gload_quad(lds_hm, (size_t)lo, ql), y = xyzz_gload_quad(lds_hm, (size_t)(lo + (1 << lgh)), ql);
+      xyzz_gstore_quad(lds_hm, (size_t)lo, xyzz_add_quad(x, y, ql), ql);
+    }
+    __syncthreads();
+  }
+  const int nlive = (a == 0) ? s + 1 : 1;          // local 0 and, in region 0, the heads 2^q of the blocks the steps left behind
+  for (int i = threadIdx.x; i < 8 * nlive; i += HMULTI_THREADS) {
+    const int e = i >> 3, k = (e == 0) ? 0 : (1 << (e - 1));
+    g4[(base + ((size_t)k << lgs)) * 8 + (i & 7)] = l4[k * 8 + (i & 7)];
+  }
+}
 #ifdef MZK_TUNING      // the DPP-quad tail of round 2: reachable only through MZK_ROW_TAILS=0 (A/B timing), not in the shipped library
 constexpr int TAIL_THREADS = 512;
 constexpr int TAIL_QUADS = TAIL_THREADS / 4;
@@ -1404,6 +1443,32 @@ static size_t row_tail_max_ops() {
   return v < 1 ? 1 : v;
 }
 
+// The halving steps that run as launches of their own, in front of the single-workgroup tail: one lane per addition while a step is
+// throughput-bound (>= 2^16 additions over all sets), then k_halve_multi, up to eight steps per launch, until a step is at most
+// `tail_max` additions wide.  *t_next = the first step left to the tail (lgB: all done, the tail only forms the weighted sum).
+// MZK_HALVE_MULTI=0 (tuning build): one launch per step, the form of rounds 2-5.
+static int launch_halving_steps(u32* buckets, int lgB, int sets, size_t tail_max, int* t_next, hipStream_t s) {
+  static const int env_multi = tune_int("MZK_HALVE_MULTI", 1);
+  int t = 0;
+  while (t < lgB && ((size_t)(t + 1) << (lgB - t - 1)) > tail_max) {
+    const size_t total = (size_t)(t + 1) << (lgB - t - 1);
+    if (total * (size_t)sets >= ((size_t)1 << 16)) {
+      hipLaunchKernelGGL(k_halve_step_wide, dim3((unsigned)((total + 127) / 128), (unsigned)sets), dim3(128), 0, s, buckets, lgB, t);
+      t++;
+    } else if (env_multi == 0) {
+      hipLaunchKernelGGL(k_halve_step, dim3((unsigned)((4 * total + 127) / 128), (unsigned)sets), dim3(128), 0, s, buckets, lgB, t);
+      t++;
+    } else {
+      const int st = (lgB - t < HMULTI_MAX_S) ? lgB - t : HMULTI_MAX_S;
+      hipLaunchKernelGGL(k_halve_multi, dim3((unsigned)((size_t)(t + 1) << (lgB - t - st)), (unsigned)sets), dim3(HMULTI_THREADS), ((size_t)128 << st), s, buckets, lgB, t, st);
+      t += st;
+    }
+  }
+  MZK_HIP(hipGetLastError());
+  *t_next = t;
+  return MZK_OK;
+}
+
 // Bucket reduction of `sets` bucket sets of 2^lgB buckets each: sum_b (b+1) B_b by in-place halving -- wide steps as launches,
 // the late ones inside one workgroup per set -- then, for the generic layout, the Horner over the windows.  merged: one set, the
 // tail writes the result itself (affine point, or the XYZZ partial record).
@@ -1417,14 +1482,7 @@ static int reduce_bucket_sets(u32* buckets, int lgB, int sets, bool merged, int 
 #else
   const size_t tail_max = row_tail_max_ops();
 #endif
-  while (t_start < lgB && ((size_t)(t_start + 1) << (lgB - t_start - 1)) > tail_max) t_start++;
-  for (int t = 0; t < t_start; t++) {
-    const size_t total = (size_t)(t + 1) << (lgB - t - 1);
-    if (total * (size_t)sets >= ((size_t)1 << 16))
-      hipLaunchKernelGGL(k_halve_step_wide, dim3((unsigned)((total + 127) / 128), (unsigned)sets), dim3(128), 0, s, buckets, lgB, t);
-    else
-      hipLaunchKernelGGL(k_halve_step, dim3((unsigned)((4 * total + 127) / 128), (unsigned)sets), dim3(128), 0, s, buckets, lgB, t);
-  }
+  MZK_TRY(launch_halving_steps(buckets, lgB, sets, tail_max, &t_start, s));
   if (merged) {
 #ifdef MZK_TUNING
     if (!rows) hipLaunchKernelGGL(k_reduce_tail, dim3(1), dim3(TAIL_THREADS), 0, s, buckets, lgB, t_start, d_out, out_partial_xyzz ? 0 : 1);
@@ -1530,9 +1588,13 @@ static int sort_records(const SortArgs& a, hipStream_t s) {
       MZK_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<REC, 17>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       MZK_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<REC, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       MZK_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<REC, 20, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      MZK_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<REC, 17, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr = true;
     }
-    if (cw == 20 && a.cl == 10)
+    if (cw == 17 && a.cl == 9)
+      hipLaunchKernelGGL((k_coarse_scatter_staged<REC, 17, 9>), dim3(a.nwg), dim3(SORT2_THREADS), lds, s, a.scalars, a.n, a.L.table_stride, a.key_shift, a.fine_mask,
+                         a.fb, (const u32*)a.binhist, a.nwg, (R*)a.tmp);
+    else if (cw == 20 && a.cl == 10)
       hipLaunchKernelGGL((k_coarse_scatter_staged<REC, 20, 10>), dim3(a.nwg), dim3(SORT2_THREADS), lds, s, a.scalars, a.n, a.L.table_stride, a.key_shift, a.fine_mask,
                          a.fb, (const u32*)a.binhist, a.nwg, (R*)a.tmp);
     else if (cw == 20)
@@ -1702,7 +1764,15 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   static const int env_cl20 = tune_int("MZK_COARSE_LOG_20", 10);      // tuning build: 8 = the 256-bin form at 20 bits too
   // (the generic GLV layout stays at 256 bins: its coarse scatter stores records one by one -- the walk is the GLV split, no staging --
   // and 512 bins measured slower at 2^22 and 2^24: sort 3.77 -> 3.91 ms, profiles/round5_sort_1024_bins.txt)
-  const int cl = (L.merged && !L.glv && L.sets == 1 && L.c == 20 && env_cl20 == 10) ? 10 : COARSE_LOG;
+  int cl = (L.merged && !L.glv && L.sets == 1 && L.c == 20 && env_cl20 == 10) ? 10 : COARSE_LOG;
+  // 17-bit merged layout: 512 bins when that one bit is what lets the sort's intermediate records shrink from 8 to 4 bytes (reference
+  // 15 n < 2^24, 7-bit fine key, sign: 2^20 pairs exactly) -- the coarse scatter writes and both fine passes read half the bytes
+  // (profiles/round6_sort_rec4_512_bins_ab.txt; without that gain 512 bins lost to 256 in round 3: HISTORY)
+  static const int env_cl17 = tune_int("MZK_COARSE_LOG_17", 9);       // tuning build: 8 = the 256-bin form with 8-byte records
+  if (L.merged && !L.glv && L.sets == 1 && L.c == 17 && env_cl17 == 9 && cl == COARSE_LOG && COARSE_LOG == 8) {
+    const size_t ref_max17 = (size_t)msm_table_rows(sh.c, L.sets) * table_stride;
+    if (ref_max17 > ((size_t)1 << (31 - 8)) && ref_max17 <= ((size_t)1 << (31 - 7))) cl = 9;
+  }
   const size_t cbins = (size_t)1 << cl;
   const bool two_level = (NBtot & (NBtot - 1)) == 0 && NBtot >= 4096 && (NBtot / cbins) <= (size_t)FINE_MAX &&
                          (n >= 4096 || ((point_kind & 0xff) == 2 && NBtot > ((size_t)1 << 15)));
@@ -1746,6 +1816,8 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     MZK_TRY(ws_get(WS_MSM_SCAN, (scan_scratch_words(n_coarse) + scan_scratch_words(n_fine) + 4) * 4, (void**)&scan2));
     if (cl == 10)
       hipLaunchKernelGGL((k_coarse_count<20, 10>), dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
+    else if (cl == 9)
+      hipLaunchKernelGGL((k_coarse_count<17, 9>), dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
     else if (L.merged && !L.glv && L.sets == 1 && L.c == 20)
       hipLaunchKernelGGL(k_coarse_count<20>, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
     else if (L.merged && !L.glv && L.sets == 1 && L.c == 17)
@@ -2056,15 +2128,7 @@ int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size
     prof_end(s, MZK_PH_MSM_SEG_COMBINE);
     prof_begin(s, MZK_PH_MSM_REDUCE);
     int t_start = 0;
-    const size_t tail_max = row_tail_max_ops();
-    while (t_start < lgB && ((size_t)(t_start + 1) << (lgB - t_start - 1)) > tail_max) t_start++;
-    for (int t = 0; t < t_start; t++) {
-      const size_t total = (size_t)(t + 1) << (lgB - t - 1);
-      if (total * cnt >= ((size_t)1 << 16))
-        hipLaunchKernelGGL(k_halve_step_wide, dim3((unsigned)((total + 127) / 128), (unsigned)cnt), dim3(128), 0, s, buckets, lgB, t);
-      else
-        hipLaunchKernelGGL(k_halve_step, dim3((unsigned)((4 * total + 127) / 128), (unsigned)cnt), dim3(128), 0, s, buckets, lgB, t);
-    }
+    MZK_TRY(launch_halving_steps(buckets, lgB, (int)cnt, row_tail_max_ops(), &t_start, s));
     MZK_TRY(launch_reduce_tail_row(buckets, lgB, t_start, (int)cnt, out, 1, s));
     MZK_HIP(hipGetLastError());
     prof_end(s, MZK_PH_MSM_REDUCE);

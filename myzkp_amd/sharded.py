@@ -17,9 +17,16 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+# A world of ONE rank needs no exchange and normally takes none.  With FORCE_COLLECTIVES set the collectives are issued all the
+# same (a gather of one record, an all-to-all of one chunk): that is how a one-GPU box runs the RCCL branch -- process group,
+# stream ordering against the C ABI's kernels, int64 device tensors -- before the first multi-GPU job does
+# (tests/test_gpu_rccl_world1.py, `bench.py --force-process-group`).
+FORCE_COLLECTIVES = False
+
+
 def all_gather_partials(partial):
     """partial: 1-D tensor (one fixed-size record per rank) -> (world, record) tensor on every rank."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size() == 1 and not FORCE_COLLECTIVES):
         return partial.reshape(1, -1)
     world = dist.get_world_size()
     flat = partial.contiguous().reshape(-1)
@@ -74,7 +81,8 @@ def ntt_sharded_steps(modulus, log2n, world, root, inverse, layout_in, layout_ou
     w = pow(root, p - 2, p) if inverse else root           # the root the sums run over
     root_W, root_m = pow(root, m, p), pow(root, W, p)      # forward roots of the W- and m-point transforms (as the callers pass them)
     if W == 1:
-        return [lambda ops, r, b: ops.ntt(b, m, root_m, inverse)]
+        local = lambda ops, r, b: ops.ntt(b, m, root_m, inverse)
+        return [None, local] if FORCE_COLLECTIVES else [local]        # (forced: the exchange of one chunk with oneself, then the transform)
 
     def across(ops, r, b):            # [a][t'] -> m/W transforms over a -> [k1][t']
         fused = getattr(ops, "ntt_columns", None)
@@ -176,13 +184,14 @@ class DeviceOps:
 
 def ntt_sharded(x_local, modulus, log2n, root, ops, inverse=False, layout_in="contiguous", layout_out="contiguous", group=None):
     """This rank's part of ONE n-point transform (ntt.rs:7-64) whose vector is spread over the ranks of `group`."""
-    if not dist.is_available() or not dist.is_initialized():
-        rank, world = 0, 1
-    else:
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    live = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if live else (0, 1)
     buf = x_local
     for step in ntt_sharded_steps(modulus, log2n, world, root, inverse, layout_in, layout_out):
-        buf = ops.all_to_all(buf, group) if step is None else step(ops, rank, buf)
+        if step is None:
+            buf = ops.all_to_all(buf, group) if live else buf
+        else:
+            buf = step(ops, rank, buf)
     return buf
 
 
