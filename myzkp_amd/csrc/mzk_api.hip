@@ -1190,6 +1190,7 @@ void mzk_srs_drop_direct(mzk_srs* srs) {
 }
 int mzk_srs_window_bits(const mzk_srs* srs) { return (srs && srs->has_tables) ? srs->window_bits : 0; }
 int mzk_srs_direct_bits(const mzk_srs* srs) { return (srs && srs->d_direct) ? srs->direct_bits : 0; }
+int mzk_msm_generic_window_bits(size_t n) { return mzk::msm_generic_window_bits(n); }
 size_t mzk_srs_table_bytes(const mzk_srs* srs) {
   if (!srs) return 0;
   return srs->n * 64 * srs->table_rows() + srs->direct_bytes + srs->wide_bytes;

@@ -216,6 +216,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
 
 // Grid-batched form for many short polynomials against one set of narrow window tables (mzk_msm.hip, mzk_kzg.hip)
 bool msm_many_supported(int window_bits);
+int msm_generic_window_bits(size_t n);        // window width of the generic (GLV) layout for n pairs
 int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size_t count, const void* d_tables, int c, size_t table_stride, void* d_out,
                       hipStream_t s);
 constexpr size_t MSM_DIRECT_MAX_N = (size_t)1 << 14;

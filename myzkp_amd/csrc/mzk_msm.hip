@@ -63,6 +63,13 @@ static MsmShape choose_shape_glv(size_t n) {
   if (c < 8) c = 8;
   if (c > 16) c = 16;
   if (c == 15) c = 16;     // 2^17 pairs: 8 full windows + the two-level sort beat 9 windows with a 6-bit top window
+  // From 2^23 pairs on: 19 bits -- SEVEN windows per half instead of eight (14 mixed additions per pair, not 16: the accumulate is 80 % of
+  // the call), 7 x 2^18 buckets.  17 and 18 bits still need eight windows (7 x 18 = 126 leaves the top window nothing but carries),
+  // 20 bits also seven but twice the buckets, 22 bits six windows over 6 x 2^21 buckets whose reduction costs what the windows save.
+  // Below 2^23 the 3.7 M additions of the larger bucket reduction outweigh the saved 2 n (profiles/round6_generic_window_sweep.txt).
+  static const int env_glv_c = tune_int("MZK_GLV_C", 0);         // tuning build: force a width (the sweep)
+  if (lg >= 24) c = 19;
+  if (env_glv_c > 0) c = env_glv_c;
   // nwin windows must cover the 126 magnitude bits plus the signed-digit carry.  The top window only holds
   // 126 - c (nwin - 1) real bits; if that is (almost) nothing, every scalar whose carry runs into it lands in the
   // same few buckets (c = 14: ONE bucket receives a third of all entries) -- step c down until the top window is
@@ -78,6 +85,8 @@ static MsmShape choose_shape_glv(size_t n) {
   s.nbuckets = (size_t)s.nwin << s.lgB;
   return s;
 }
+
+int msm_generic_window_bits(size_t n) { return choose_shape_glv(n ? n : 1).c; }
 
 // ---- global loads of packed 256-bit values -----------------------------------------------------------
 __device__ __forceinline__ void load_words8(const u32* __restrict__ g, u32* w) {
@@ -318,6 +327,30 @@ __device__ __forceinline__ void walk_digits_merged(const u32* w, size_t table_st
   }
 }
 
+// Exclusive prefix of one value per lane over a workgroup of NT lanes, and the workgroup's total: shuffles inside the waves, the
+// NT / 64 wave totals by the first wave -- two barriers (the Hillis-Steele form over LDS this replaces took 2 log2(NT) = 20 at 1024
+// lanes, ~5 us of a kernel that runs for 20-50).  sc: NT / 64 + 1 words of LDS; a barrier must separate two calls on the same sc.
+template <int NT>
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32* sc, u32* total) {
+  constexpr int NW = NT / 64;
+  static_assert(NT % 64 == 0 && NW <= 64, "whole waves, at most 64 of them");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32 incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const u32 t = (u32)__shfl_up((int)incl, off, 64); if (lane >= off) incl += t; }
+  if (lane == 63) sc[wave] = incl;
+  __syncthreads();
+  if (wave == 0) {
+    u32 t = (lane < NW) ? sc[lane] : 0u;
+#pragma unroll
+    for (int off = 1; off < NW; off <<= 1) { const u32 u = (u32)__shfl_up((int)t, off, 64); if (lane >= off) t += u; }
+    if (lane < NW) sc[lane] = t;
+  }
+  __syncthreads();
+  if (total) *total = sc[NW - 1];
+  return (wave ? sc[wave - 1] : 0u) + incl - v;
+}
+
 // Counter increment (LDS or global) that stays fast when most of a wave hits ONE counter (bit-vector or repeated
 // scalars, the sparsely populated top window of a GLV half):
 // the lanes sharing the first active lane's key take a single atomic together.  Returns the lane's rank.
@@ -461,13 +494,24 @@ constexpr int SORT2_THREADS = 1024;
 // CL: log2 of the coarse bins.  256 everywhere but at 20-bit windows (2^19 buckets, the default from 2^22 points on): there 1024, so
 // that a bin covers 512 buckets instead of 2048 and a fine workgroup's round of 8192 records leaves in runs of ~16 entries (64 bytes)
 // instead of ~4 -- k_fine_scatter cost 7 ps per entry at 2048 buckets per bin against 3.2 at 17-bit windows (profiles/round5_sort_1024_bins.txt).
+// Scan-free form (bin_tot != null; profiles/round6_sort_without_global_scans_ab.txt): a bin's total is summed with one atomic per
+// (workgroup, bin) into bin_tot (zeroed by the call's one memset), k_coarse_scatter* turns the totals into bin starts itself and
+// CLAIMS its runs from per-bin cursors, and the workgroups also zero the fine level's per-bucket counters here (zero_words words at
+// zero_ptr) -- the two launches of the global scan between this kernel and the scatter (~20 us whatever they scan) are gone.  Which
+// workgroup's records come first inside a bin is then arbitrary, as the order of entries inside a bucket always was.
 template <int C, int CL = COARSE_LOG>
 __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_count(const u32* __restrict__ scalars, size_t n, DigitLayout L, int key_shift,
-                                                                 u32* __restrict__ binhist, int nwg) {
+                                                                 u32* __restrict__ binhist, int nwg, u32* __restrict__ bin_tot, u32* __restrict__ zero_ptr,
+                                                                 size_t zero_words) {
   constexpr int BINS = 1 << CL;
   static_assert(BINS <= SORT2_THREADS, "one lane per bin");
   __shared__ u32 hist[BINS];
   if (threadIdx.x < BINS) hist[threadIdx.x] = 0;
+  if (zero_ptr) {
+    const size_t per = (zero_words + gridDim.x - 1) / gridDim.x;
+    const size_t z0 = (size_t)blockIdx.x * per, z1 = (z0 + per < zero_words) ? z0 + per : zero_words;
+    for (size_t z = z0 + threadIdx.x; z < z1; z += SORT2_THREADS) zero_ptr[z] = 0;
+  }
   __syncthreads();
   const size_t lo = (size_t)blockIdx.x * COARSE_PER_WG;
   const size_t hi = (lo + COARSE_PER_WG < n) ? lo + COARSE_PER_WG : n;
@@ -487,7 +531,36 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_count(const u32* __res
     }
   }
   __syncthreads();
-  if (threadIdx.x < BINS) binhist[(size_t)threadIdx.x * nwg + blockIdx.x] = hist[threadIdx.x];
+  if (threadIdx.x < BINS) {
+    const u32 v = hist[threadIdx.x];
+    binhist[(size_t)threadIdx.x * nwg + blockIdx.x] = v;
+    if (bin_tot && v) atomicAdd(&bin_tot[threadIdx.x], v);
+  }
+}
+// Exclusive prefix of the BINS bin totals into LDS (start[BINS] = all records), by the first wave: BINS / 64 consecutive bins per lane.
+// Workgroup 0 also publishes it (start_out, BINS + 1 words): the fine kernels read the bin boundaries there.  Ends with a barrier.
+template <int BINS>
+__device__ __forceinline__ void bin_starts(const u32* __restrict__ bin_tot, u32* start, u32* __restrict__ start_out) {
+  constexpr int PER = BINS / 64;
+  static_assert(BINS % 64 == 0, "whole lanes");
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    u32 c[PER], sum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; q++) { c[q] = bin_tot[PER * tid + q]; sum += c[q]; }
+    u32 incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const u32 up = (u32)__shfl_up((int)incl, d, 64);
+      if (tid >= d) incl += up;
+    }
+    u32 run = incl - sum;
+#pragma unroll
+    for (int q = 0; q < PER; q++) { start[PER * tid + q] = run; run += c[q]; }
+    if (tid == 63) start[BINS] = incl;
+  }
+  __syncthreads();
+  if (start_out && blockIdx.x == 0) for (int b = tid; b <= BINS; b += blockDim.x) start_out[b] = start[b];
 }
 // Intermediate records of the two-level sort: (payload, fine key).  The 8-byte form always works; when the point
 // reference, the fine key and the sign fit 32 bits together (up to 2^20 pairs in both layouts) the 4-byte form halves the
@@ -507,11 +580,21 @@ struct Rec4 {   // ref << (fb + 1) | fine << 1 | sign;  needs ref < 2^(31 - fb)
 template <class REC, int C, int CL = COARSE_LOG>
 __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter(const u32* __restrict__ scalars, size_t n, DigitLayout L, int key_shift,
                                                                    u32 fine_mask, int fb, const u32* __restrict__ binbase, int nwg,
-                                                                   typename REC::T* __restrict__ tmp) {
+                                                                   typename REC::T* __restrict__ tmp, const u32* __restrict__ bin_tot,
+                                                                   u32* __restrict__ bin_cur, u32* __restrict__ bin_start_out) {
   constexpr int COARSE_BINS = 1 << CL;
   static_assert(COARSE_BINS <= SORT2_THREADS, "one lane per bin");
   __shared__ u32 cursor[COARSE_BINS];
-  if (threadIdx.x < COARSE_BINS) cursor[threadIdx.x] = binbase[(size_t)threadIdx.x * nwg + blockIdx.x];
+  __shared__ u32 bscan[COARSE_BINS + 1];
+  if (bin_tot) {      // scan-free form: binbase holds this kernel's RAW counts (k_coarse_count), the run of (bin, workgroup) is claimed
+    bin_starts<COARSE_BINS>(bin_tot, bscan, bin_start_out);
+    if (threadIdx.x < COARSE_BINS) {
+      const u32 mine = binbase[(size_t)threadIdx.x * nwg + blockIdx.x];
+      cursor[threadIdx.x] = bscan[threadIdx.x] + (mine ? atomicAdd(&bin_cur[threadIdx.x], mine) : 0u);
+    }
+  } else if (threadIdx.x < COARSE_BINS) {
+    cursor[threadIdx.x] = binbase[(size_t)threadIdx.x * nwg + blockIdx.x];
+  }
   __syncthreads();
   const size_t lo = (size_t)blockIdx.x * COARSE_PER_WG;
   const size_t hi = (lo + COARSE_PER_WG < n) ? lo + COARSE_PER_WG : n;
@@ -548,7 +631,8 @@ constexpr int STAGE_RECORDS = 16 * SORT2_THREADS;
 template <class REC, int C, int CL = COARSE_LOG>
 __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter_staged(const u32* __restrict__ scalars, size_t n, size_t table_stride, int key_shift,
                                                                           u32 fine_mask, int fb, const u32* __restrict__ binbase, int nwg,
-                                                                          typename REC::T* __restrict__ tmp) {
+                                                                          typename REC::T* __restrict__ tmp, const u32* __restrict__ bin_tot,
+                                                                          u32* __restrict__ bin_cur, u32* __restrict__ bin_start_out) {
   typedef typename REC::T R;
   constexpr int COARSE_BINS = 1 << CL;           // (shadows the 256 of the other kernels)
   constexpr int STAGE_RECORDS = stage_records(C, CL);
@@ -564,7 +648,9 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter_staged(const u
   u32* gpos = loff + COARSE_BINS + 1;                                           // [COARSE_BINS] destination of the chunk's run of each bin
   static_assert(COARSE_BINS % 64 == 0 && COARSE_BINS <= SORT2_THREADS, "one wave scans PER_LANE bins per lane; one lane per bin elsewhere");
   const int tid = threadIdx.x;
-  if (tid < COARSE_BINS) cursor[tid] = binbase[(size_t)tid * nwg + blockIdx.x];
+  // scan-free form (bin_tot != null): cursor[] holds the bin STARTS and every chunk claims its run of a bin from the bin's global cursor
+  if (bin_tot) bin_starts<COARSE_BINS>(bin_tot, loff, bin_start_out);      // (loff: COARSE_BINS + 1 words, free until the first chunk's scan)
+  if (tid < COARSE_BINS) cursor[tid] = bin_tot ? loff[tid] : binbase[(size_t)tid * nwg + blockIdx.x];
   const size_t lo = (size_t)blockIdx.x * COARSE_PER_WG;
   const size_t hi = (lo + COARSE_PER_WG < n) ? lo + COARSE_PER_WG : n;
   u32 w[COARSE_PER_WG / SORT2_THREADS][8];
@@ -598,8 +684,12 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter_staged(const u
     __syncthreads();
     if (tid < COARSE_BINS) {
       const u32 cnt = hist[tid];
-      gpos[tid] = cursor[tid];
-      cursor[tid] += cnt;
+      if (bin_tot) {
+        gpos[tid] = cursor[tid] + (cnt ? atomicAdd(&bin_cur[tid], cnt) : 0u);
+      } else {
+        gpos[tid] = cursor[tid];
+        cursor[tid] += cnt;
+      }
       hist[tid] = loff[tid];             // placement cursor
     }
     __syncthreads();
@@ -627,7 +717,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_coarse_scatter_staged(const u
 // plan from the bin boundaries (one load per lane and a block scan of two barriers): workgroup w -> (bin, slice); the histogram of bin b sits at
 // finehist[F P_b + f S_b + s] (P_b = slices before bin b), one flat exclusive scan as before; workgroups past the last slice zero
 // their block of the histogram, so the scan runs over the host's bound F * gridDim.
-struct FineSlice { int bin, s, Sb; u32 lo, hi; bool active; };
+struct FineSlice { int bin, s, Sb; u32 lo, hi, start; bool active; };
 // (sc, res: LDS scratch of the caller, SORT2_THREADS and 6 words -- no static LDS here: k_fine_scatter asks for all 160 KiB as dynamic)
 __device__ __forceinline__ FineSlice fine_plan(const u32* __restrict__ binbase, int nwg, int bins, int S, u32 cap, u32* sc, u32* res) {
   const int tid = threadIdx.x;
@@ -660,6 +750,7 @@ __device__ __forceinline__ FineSlice fine_plan(const u32* __restrict__ binbase, 
   r.active = res[0] != 0xffffffffu;
   r.bin = (int)res[0]; r.s = (int)res[1]; r.Sb = (int)res[2];
   const u64 L = res[4];
+  r.start = res[3];
   r.lo = res[3] + (u32)(L * (u64)r.s / (u64)r.Sb);
   r.hi = res[3] + (u32)(L * (u64)(r.s + 1) / (u64)r.Sb);
   return r;
@@ -668,7 +759,7 @@ constexpr int FINE_UNROLL = 8;
 constexpr int FINE_MAX = 8192;     // buckets per bin: NB / 256 (128 merged c = 16, 2048 generic c = 16, 8192 merged c = 22)
 template <class REC>
 __global__ __launch_bounds__(SORT2_THREADS) void k_fine_count(const typename REC::T* __restrict__ tmp, const u32* __restrict__ binbase, int nwg, int F,
-                                                               int S, int fb, u32* __restrict__ finehist, int bins, u32 cap) {
+                                                               int S, int fb, u32* __restrict__ finehist, int bins, u32 cap, u32* __restrict__ bucket_tot) {
   __shared__ u32 hist[FINE_MAX];
   __shared__ u32 sc[SORT2_THREADS];
   const FineSlice p = fine_plan(binbase, nwg, bins, S, cap, sc, hist);
@@ -693,7 +784,11 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_fine_count(const typename REC
   }
   __syncthreads();
   const size_t hbase = (size_t)F * (blockIdx.x - (u32)p.s);        // F P_b: the slices of a bin are consecutive workgroups
-  for (int f = threadIdx.x; f < F; f += SORT2_THREADS) finehist[hbase + (size_t)f * p.Sb + p.s] = hist[f];
+  for (int f = threadIdx.x; f < F; f += SORT2_THREADS) {
+    const u32 v = hist[f];
+    finehist[hbase + (size_t)f * p.Sb + p.s] = v;
+    if (bucket_tot && v) atomicAdd(&bucket_tot[(size_t)p.bin * F + f], v);      // the bucket's size over all slices (k_fine_scatter: no global scan)
+  }
 }
 // Direct form: every record is stored straight to its final position (isolated 4-byte stores).  Only used when a
 // bin has more buckets than the staged kernel below has LDS for.
@@ -742,7 +837,8 @@ constexpr int STAGE_F_MAX = 2048;
 template <class REC>
 __global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter(const typename REC::T* __restrict__ tmp, const u32* __restrict__ binbase, int nwg, int F,
                                                                  int S, int fb, const u32* __restrict__ finebase, u32* __restrict__ offsets,
-                                                                 u32* __restrict__ entries, size_t nbuckets, int bins, u32 cap) {
+                                                                 u32* __restrict__ entries, size_t nbuckets, int bins, u32 cap, const u32* __restrict__ bucket_tot,
+                                                                 u32* __restrict__ bucket_cur) {
   extern __shared__ u32 lds_fs[];
   u32* gbase = lds_fs;                 // [F]   global position of the next entry of bucket f written by this workgroup
   u32* cnt = gbase + F;                // [F]   records of bucket f in the current round
@@ -753,13 +849,35 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter(const typename R
   const int tid = threadIdx.x;
   const FineSlice p = fine_plan(binbase, nwg, bins, S, cap, scan, gbase);
   __syncthreads();                     // (gbase is the plan's scratch until here)
-  if (blockIdx.x == 0 && tid == 0) offsets[nbuckets] = finebase[(size_t)F * gridDim.x];   // total entries
+  if (blockIdx.x == 0 && tid == 0) offsets[nbuckets] = bucket_tot ? binbase[(size_t)bins * nwg] : finebase[(size_t)F * gridDim.x];   // total entries
   if (!p.active) return;
   const size_t hbase = (size_t)F * (blockIdx.x - (u32)p.s);
-  for (int f = tid; f < F; f += SORT2_THREADS) {
-    const u32 base = finebase[hbase + (size_t)f * p.Sb + p.s];
-    gbase[f] = base;
-    if (p.s == 0) offsets[(size_t)p.bin * F + f] = base;      // start of bucket (bin, f)
+  if (bucket_tot) {
+    // No global scan ran.  The bin's records start at a known place (the coarse sort's boundary) and hold its F buckets one after the
+    // other: bucket offsets = bin start + exclusive prefix of the bin's F bucket totals (k_fine_count summed them with atomics), and this
+    // slice's run inside a bucket is claimed from the bucket's cursor (the order of the slices inside a bucket is arbitrary, as the order
+    // of entries inside a bucket always was).  Whatever the number of slices a skewed bin was cut into, a workgroup reads F totals.
+    const int per2 = (F + SORT2_THREADS - 1) / SORT2_THREADS;
+    u32 local = 0;
+    for (int q = 0; q < per2; q++) { const int f = tid * per2 + q; if (f < F) { const u32 v = bucket_tot[(size_t)p.bin * F + f]; cnt[f] = v; local += v; } }
+    u32 run = p.start + block_excl_scan<SORT2_THREADS>(local, scan, nullptr);
+    for (int q = 0; q < per2; q++) {
+      const int f = tid * per2 + q;
+      if (f < F) {
+        const u32 v = cnt[f];
+        const u32 mine = finebase[hbase + (size_t)f * p.Sb + p.s];
+        gbase[f] = run + (mine ? atomicAdd(&bucket_cur[(size_t)p.bin * F + f], mine) : 0u);
+        if (p.s == 0) offsets[(size_t)p.bin * F + f] = run;
+        run += v;
+      }
+    }
+    __syncthreads();                                            // (cnt is the rounds' counter array from here on)
+  } else {
+    for (int f = tid; f < F; f += SORT2_THREADS) {
+      const u32 base = finebase[hbase + (size_t)f * p.Sb + p.s];
+      gbase[f] = base;
+      if (p.s == 0) offsets[(size_t)p.bin * F + f] = base;      // start of bucket (bin, f)
+    }
   }
   const u32 lo = p.lo, hi = p.hi;
   const int per = (F + SORT2_THREADS - 1) / SORT2_THREADS;     // counters per lane in the prefix (<= 2)
@@ -778,18 +896,10 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_fine_scatter(const typename R
 #pragma unroll
     for (int k = 0; k < STAGE_PER_LANE; k++) rk[k] = (chunk + tid + k * SORT2_THREADS < cend) ? counter_inc_agg(cnt, REC::fine(r[k], fmask, fb)) : 0u;
     __syncthreads();
-    // exclusive prefix of cnt[0..F): lane-local run of `per` counters, Hillis-Steele over the lane sums
+    // exclusive prefix of cnt[0..F): lane-local run of `per` counters, block scan over the lane sums
     u32 local = 0;
     for (int q = 0; q < per; q++) { const int f = tid * per + q; if (f < F) local += cnt[f]; }
-    scan[tid] = local;
-    __syncthreads();
-    for (int off = 1; off < SORT2_THREADS; off <<= 1) {
-      const u32 t = (tid >= off) ? scan[tid - off] : 0u;
-      __syncthreads();
-      scan[tid] += t;
-      __syncthreads();
-    }
-    u32 run = scan[tid] - local;
+    u32 run = block_excl_scan<SORT2_THREADS>(local, scan, nullptr);
     for (int q = 0; q < per; q++) { const int f = tid * per + q; if (f < F) { lpre[f] = run; run += cnt[f]; } }
     __syncthreads();
 #pragma unroll
@@ -825,16 +935,9 @@ __global__ __launch_bounds__(256) void k_scan_local(const u32* __restrict__ in, 
     v[k] = (base + k < n) ? in[base + k] : 0u;
     sum += v[k];
   }
-  sh[threadIdx.x] = sum;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    u32 t = (threadIdx.x >= (unsigned)off) ? sh[threadIdx.x - off] : 0u;
-    __syncthreads();
-    sh[threadIdx.x] += t;
-    __syncthreads();
-  }
-  u32 excl = sh[threadIdx.x] - sum;
-  if (threadIdx.x == 255) block_sums[blockIdx.x] = sh[255];
+  u32 block_total;
+  u32 excl = block_excl_scan<256>(sum, sh, &block_total);
+  if (threadIdx.x == 255) block_sums[blockIdx.x] = block_total;
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; k++) {
     if (base + k < n) out[base + k] = excl;
@@ -1002,10 +1105,15 @@ __device__ __forceinline__ u32 bucket_end(const u32* __restrict__ offsets, const
 // Layout of `heavy`: [0] count, [1] the segment length in force (written by the combine kernel), [2, 2 + HEAVY_GRID) arrival counters of k_seg_combine_heavy's shared buckets (zeroed with
 // the count, one memset), then (bucket id, end of its entries as the deferring kernel saw it -- bucket_end) pairs, then HEAVY_GRID
 // XYZZ records of scratch for the workgroups that share a bucket.
+// Behind the arrival counters, inside the same cleared header: the scan-free sort's per-bin totals and cursors (k_coarse_count /
+// k_coarse_scatter*: SORT_CTR_BINS words each) -- one memset per call clears everything that has to start at zero.
 constexpr int HEAVY_GRID = 512;
-constexpr int HEAVY_HDR = 2 + HEAVY_GRID;
+constexpr int SORT_CTR_BINS = 1024;               // the most coarse bins any layout uses (20-bit merged windows)
+constexpr int SORT_CTR_AT = 2 + HEAVY_GRID;       // bin totals at heavy[SORT_CTR_AT ..), bin cursors SORT_CTR_BINS words further
+constexpr int HEAVY_HDR = SORT_CTR_AT + 2 * SORT_CTR_BINS;
 constexpr size_t HEAVY_CLEAR_BYTES = (size_t)HEAVY_HDR * 4;
-__host__ __device__ constexpr size_t heavy_list_words(size_t max_heavy) { return HEAVY_HDR + 2 * max_heavy + 2; }
+// (a multiple of four words: the scratch records behind the list are read and written as uint4)
+__host__ __device__ constexpr size_t heavy_list_words(size_t max_heavy) { return (HEAVY_HDR + 2 * max_heavy + 2 + 3) & ~(size_t)3; }
 __host__ __device__ constexpr size_t heavy_total_words(size_t max_heavy) { return heavy_list_words(max_heavy) + (size_t)HEAVY_GRID * 32 + 8; }
 __device__ __forceinline__ bool defer_heavy(size_t b, size_t s0, size_t s1, u32 o1, u32* __restrict__ heavy, bool leader, u32 threshold = HEAVY_SLOTS) {
   if (s1 - s0 + 1 <= threshold) return false;
@@ -1276,20 +1384,13 @@ __global__ __launch_bounds__(SMALL_SORT_THREADS) void k_small_sort(const u32* __
   const int per = (NB + SMALL_SORT_THREADS - 1) / SMALL_SORT_THREADS;
   u32 local = 0;
   for (int q = 0; q < per; q++) { const int b = tid * per + q; if (b < NB) local += hist[b]; }
-  scan[tid] = local;
-  __syncthreads();
-  for (int off = 1; off < SMALL_SORT_THREADS; off <<= 1) {
-    const u32 t = (tid >= off) ? scan[tid - off] : 0u;
-    __syncthreads();
-    scan[tid] += t;
-    __syncthreads();
-  }
-  u32 run = scan[tid] - local;
+  u32 all_entries;
+  u32 run = block_excl_scan<SMALL_SORT_THREADS>(local, scan, &all_entries);
   for (int q = 0; q < per; q++) {
     const int b = tid * per + q;
     if (b < NB) { const u32 c = hist[b]; hist[b] = run; offsets[b] = run; run += c; }
   }
-  if (tid == SMALL_SORT_THREADS - 1) offsets[NB] = scan[tid];
+  if (tid == SMALL_SORT_THREADS - 1) offsets[NB] = all_entries;
   __syncthreads();
   for (size_t i = tid; i < n; i += SMALL_SORT_THREADS) {
     u32 w[8];
@@ -1455,11 +1556,18 @@ static int launch_halving_steps(u32* buckets, int lgB, int sets, size_t tail_max
     if (total * (size_t)sets >= ((size_t)1 << 16)) {
       hipLaunchKernelGGL(k_halve_step_wide, dim3((unsigned)((total + 127) / 128), (unsigned)sets), dim3(128), 0, s, buckets, lgB, t);
       t++;
-    } else if (env_multi == 0) {
+      continue;
+    }
+    // several steps per launch only in the latency regime -- at most one workgroup per CU.  Its workgroups are unequal (region 0 carries
+    // t + 1 times the additions of the others) and stay where they were placed, so with more of them than CUs the launches of ONE step,
+    // which spread every step's additions over the whole chip, are faster (generic 2^20, 384 workgroups: bucket reduction 0.204 -> 0.222 ms;
+    // 256 x 2^10 at 11 bits 0.196 -> 0.270; profiles/round6_halving_multi_and_rec4_ab.txt)
+    const int st = (lgB - t < HMULTI_MAX_S) ? lgB - t : HMULTI_MAX_S;
+    const size_t multi_wgs = ((size_t)(t + 1) << (lgB - t - st)) * (size_t)sets;
+    if (env_multi == 0 || multi_wgs > (size_t)ctx().num_cu) {
       hipLaunchKernelGGL(k_halve_step, dim3((unsigned)((4 * total + 127) / 128), (unsigned)sets), dim3(128), 0, s, buckets, lgB, t);
       t++;
     } else {
-      const int st = (lgB - t < HMULTI_MAX_S) ? lgB - t : HMULTI_MAX_S;
       hipLaunchKernelGGL(k_halve_multi, dim3((unsigned)((size_t)(t + 1) << (lgB - t - st)), (unsigned)sets), dim3(HMULTI_THREADS), ((size_t)128 << st), s, buckets, lgB, t, st);
       t += st;
     }
@@ -1573,6 +1681,9 @@ struct SortArgs {
   u32* finehist; u32* scan3; size_t sb_f; size_t n_fine; u32* offsets; u32* entries; size_t NBtot;
   unsigned fine_wgs; u32 fine_cap;       // grid of the fine kernels (slices of all bins + the extra slices of over-full ones) and the slice capacity (fine_plan)
   int cl;           // log2 of the coarse bins: COARSE_LOG, or 10 for the 20-bit merged layout
+  // scan-free forms (null: the global scans of rounds 3-5): per-bin totals / cursors (in the call's cleared header), the bins + 1 bin starts the
+  // coarse scatter publishes, per-bucket totals / cursors (zeroed by k_coarse_count)
+  u32 *bin_tot, *bin_cur, *bin_start, *bucket_tot, *bucket_cur;
 };
 template <class REC>
 static int sort_records(const SortArgs& a, hipStream_t s) {
@@ -1580,6 +1691,11 @@ static int sort_records(const SortArgs& a, hipStream_t s) {
   const int cw = (a.L.merged && !a.L.glv && a.L.sets == 1 && (a.L.c == 16 || a.L.c == 17 || a.L.c == 20)) ? a.L.c : 0;     // the default widths by SRS size
   static const int env_staged = tune_int("MZK_COARSE_STAGED", 1);      // 0: A/B against the direct stores
   const unsigned bins = 1u << a.cl;
+  // scan-free forms: a.bin_tot / a.bucket_tot non-null (see k_coarse_count, k_fine_scatter)
+#define MZK_STAGED(C, CLOG) hipLaunchKernelGGL((k_coarse_scatter_staged<REC, C, CLOG>), dim3(a.nwg), dim3(SORT2_THREADS), lds, s, a.scalars, a.n, a.L.table_stride, \
+                                               a.key_shift, a.fine_mask, a.fb, (const u32*)a.binhist, a.nwg, (R*)a.tmp, (const u32*)a.bin_tot, a.bin_cur, a.bin_start)
+#define MZK_DIRECT(C) hipLaunchKernelGGL((k_coarse_scatter<REC, C>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb, \
+                                         (const u32*)a.binhist, a.nwg, (R*)a.tmp, (const u32*)a.bin_tot, a.bin_cur, a.bin_start)
   if (cw != 0 && (env_staged != 0 || a.cl != COARSE_LOG)) {
     const size_t lds = stage_lds_bytes(cw, a.cl, sizeof(R));
     bool& attr = ctx().attr_done[sizeof(R) == 4 ? ATTR_COARSE_STAGED4 : ATTR_COARSE_STAGED8];
@@ -1591,39 +1707,29 @@ static int sort_records(const SortArgs& a, hipStream_t s) {
       MZK_HIP(hipFuncSetAttribute((const void*)k_coarse_scatter_staged<REC, 17, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr = true;
     }
-    if (cw == 17 && a.cl == 9)
-      hipLaunchKernelGGL((k_coarse_scatter_staged<REC, 17, 9>), dim3(a.nwg), dim3(SORT2_THREADS), lds, s, a.scalars, a.n, a.L.table_stride, a.key_shift, a.fine_mask,
-                         a.fb, (const u32*)a.binhist, a.nwg, (R*)a.tmp);
-    else if (cw == 20 && a.cl == 10)
-      hipLaunchKernelGGL((k_coarse_scatter_staged<REC, 20, 10>), dim3(a.nwg), dim3(SORT2_THREADS), lds, s, a.scalars, a.n, a.L.table_stride, a.key_shift, a.fine_mask,
-                         a.fb, (const u32*)a.binhist, a.nwg, (R*)a.tmp);
-    else if (cw == 20)
-      hipLaunchKernelGGL((k_coarse_scatter_staged<REC, 20>), dim3(a.nwg), dim3(SORT2_THREADS), lds, s, a.scalars, a.n, a.L.table_stride, a.key_shift, a.fine_mask,
-                         a.fb, (const u32*)a.binhist, a.nwg, (R*)a.tmp);
-    else if (cw == 17)
-      hipLaunchKernelGGL((k_coarse_scatter_staged<REC, 17>), dim3(a.nwg), dim3(SORT2_THREADS), lds, s, a.scalars, a.n, a.L.table_stride, a.key_shift, a.fine_mask,
-                         a.fb, (const u32*)a.binhist, a.nwg, (R*)a.tmp);
-    else
-      hipLaunchKernelGGL((k_coarse_scatter_staged<REC, 16>), dim3(a.nwg), dim3(SORT2_THREADS), lds, s, a.scalars, a.n, a.L.table_stride, a.key_shift, a.fine_mask,
-                         a.fb, (const u32*)a.binhist, a.nwg, (R*)a.tmp);
+    if (cw == 17 && a.cl == 9) MZK_STAGED(17, 9);
+    else if (cw == 20 && a.cl == 10) MZK_STAGED(20, 10);
+    else if (cw == 20) MZK_STAGED(20, COARSE_LOG);
+    else if (cw == 17) MZK_STAGED(17, COARSE_LOG);
+    else MZK_STAGED(16, COARSE_LOG);
   }
 #ifdef MZK_TUNING
-  else if (cw == 20)
-    hipLaunchKernelGGL((k_coarse_scatter<REC, 20>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb,
-                       (const u32*)a.binhist, a.nwg, (R*)a.tmp);
-  else if (cw == 17)
-    hipLaunchKernelGGL((k_coarse_scatter<REC, 17>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb,
-                       (const u32*)a.binhist, a.nwg, (R*)a.tmp);
-  else if (cw == 16)
-    hipLaunchKernelGGL((k_coarse_scatter<REC, 16>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb,
-                       (const u32*)a.binhist, a.nwg, (R*)a.tmp);
+  else if (cw == 20) MZK_DIRECT(20);
+  else if (cw == 17) MZK_DIRECT(17);
+  else if (cw == 16) MZK_DIRECT(16);
 #endif
-  else
-    hipLaunchKernelGGL((k_coarse_scatter<REC, 0>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb,
-                       (const u32*)a.binhist, a.nwg, (R*)a.tmp);
-  hipLaunchKernelGGL((k_fine_count<REC>), dim3(a.fine_wgs), dim3(SORT2_THREADS), 0, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg, a.F, a.S,
-                     a.fb, a.finehist, (int)bins, a.fine_cap);
-  MZK_TRY(launch_exclusive_scan((const u32*)a.finehist, a.finehist, a.n_fine, a.scan3, s));
+  else if (a.cl == 10) hipLaunchKernelGGL((k_coarse_scatter<REC, 0, 10>), dim3(a.nwg), dim3(SORT2_THREADS), 0, s, a.scalars, a.n, a.L, a.key_shift, a.fine_mask, a.fb,
+                                          (const u32*)a.binhist, a.nwg, (R*)a.tmp, (const u32*)a.bin_tot, a.bin_cur, a.bin_start);
+  else MZK_DIRECT(0);
+#undef MZK_STAGED
+#undef MZK_DIRECT
+  // bin boundaries as the fine kernels index them: the coarse scan's [bin][workgroup] prefix, or the scan-free form's bins + 1 starts
+  const u32* bounds = a.bin_tot ? (const u32*)a.bin_start : (const u32*)a.binhist;
+  const int bstride = a.bin_tot ? 1 : a.nwg;
+  const bool fine_free = a.bucket_tot != nullptr && a.F <= STAGE_F_MAX;
+  hipLaunchKernelGGL((k_fine_count<REC>), dim3(a.fine_wgs), dim3(SORT2_THREADS), 0, s, (const R*)a.tmp, bounds, bstride, a.F, a.S,
+                     a.fb, a.finehist, (int)bins, a.fine_cap, fine_free ? a.bucket_tot : (u32*)nullptr);
+  if (!fine_free) MZK_TRY(launch_exclusive_scan((const u32*)a.finehist, a.finehist, a.n_fine, a.scan3, s));
   if (a.F <= STAGE_F_MAX) {
     const size_t lds = ((size_t)3 * a.F + SORT2_THREADS + STAGE_CAP) * 4 + (size_t)STAGE_CAP * 2;
     bool& staged_attr = ctx().attr_done[sizeof(R) == 4 ? ATTR_FINE_SCATTER4 : ATTR_FINE_SCATTER8];     // per instantiation and context
@@ -1631,10 +1737,11 @@ static int sort_records(const SortArgs& a, hipStream_t s) {
       MZK_HIP(hipFuncSetAttribute((const void*)k_fine_scatter<REC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       staged_attr = true;
     }
-    hipLaunchKernelGGL((k_fine_scatter<REC>), dim3(a.fine_wgs), dim3(SORT2_THREADS), lds, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg, a.F,
-                       a.S, a.fb, (const u32*)a.finehist, a.offsets, a.entries, a.NBtot, (int)bins, a.fine_cap);
+    hipLaunchKernelGGL((k_fine_scatter<REC>), dim3(a.fine_wgs), dim3(SORT2_THREADS), lds, s, (const R*)a.tmp, bounds, bstride, a.F,
+                       a.S, a.fb, (const u32*)a.finehist, a.offsets, a.entries, a.NBtot, (int)bins, a.fine_cap,
+                       fine_free ? (const u32*)a.bucket_tot : (const u32*)nullptr, fine_free ? a.bucket_cur : (u32*)nullptr);
   } else {
-    hipLaunchKernelGGL((k_fine_scatter_direct<REC>), dim3(a.fine_wgs), dim3(SORT2_THREADS), 0, s, (const R*)a.tmp, (const u32*)a.binhist, a.nwg,
+    hipLaunchKernelGGL((k_fine_scatter_direct<REC>), dim3(a.fine_wgs), dim3(SORT2_THREADS), 0, s, (const R*)a.tmp, bounds, bstride,
                        a.F, a.S, a.fb, (const u32*)a.finehist, a.offsets, a.entries, a.NBtot, (int)bins, a.fine_cap);
   }
   MZK_HIP(hipGetLastError());
@@ -1755,10 +1862,14 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   const size_t max_heavy = (T + NB) / HEAVY_SLOTS + 1;             // at most (T + NB) / 33 buckets hold more than 32 partials
   const size_t heavy_words = heavy_total_words(max_heavy);
   u32 *counts, *offsets, *ranks, *entries, *scan_tmp, *buckets, *slots;
-  MZK_TRY(ws_get(WS_MSM_COUNTS, NB * 4, (void**)&counts));
-  MZK_TRY(ws_get(WS_MSM_OFFSETS, (NB + 1) * 4, (void**)&offsets));
   // two-level sort when the bucket space is a power of two >= 2^12 (merged layout always; generic at c = 16)
-  const size_t NBtot = NB;
+  // The two-level sort wants a power of two: the generic layout's 7 x 2^18 buckets (19-bit windows) sort as if there were an eighth,
+  // empty window -- the sort's arrays are sized by NBtot, its offsets beyond NB all equal the entry count, everything after the sort
+  // works on the NB real buckets.
+  size_t NBtot = NB;
+  if (L.glv && (NB & (NB - 1)) != 0 && sh.c >= 17) { NBtot = 1; while (NBtot < NB) NBtot <<= 1; }
+  MZK_TRY(ws_get(WS_MSM_COUNTS, 2 * NBtot * 4, (void**)&counts));      // (two-level sort, scan-free form: per-bucket totals + cursors)
+  MZK_TRY(ws_get(WS_MSM_OFFSETS, (NBtot + 1) * 4, (void**)&offsets));
   // (small inputs keep the one-pass kernels, except that the merged one-pass histogram must fit the LDS: 2^15 buckets)
   // coarse bins: 256, or 1024 for the 20-bit merged layout (2^19 buckets: 512 per bin instead of 2048; k_coarse_count)
   static const int env_cl20 = tune_int("MZK_COARSE_LOG_20", 10);      // tuning build: 8 = the 256-bin form at 20 bits too
@@ -1767,12 +1878,13 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   int cl = (L.merged && !L.glv && L.sets == 1 && L.c == 20 && env_cl20 == 10) ? 10 : COARSE_LOG;
   // 17-bit merged layout: 512 bins when that one bit is what lets the sort's intermediate records shrink from 8 to 4 bytes (reference
   // 15 n < 2^24, 7-bit fine key, sign: 2^20 pairs exactly) -- the coarse scatter writes and both fine passes read half the bytes
-  // (profiles/round6_sort_rec4_512_bins_ab.txt; without that gain 512 bins lost to 256 in round 3: HISTORY)
+  // (profiles/round6_halving_multi_and_rec4_ab.txt; without that gain 512 bins lost to 256 in round 3: HISTORY)
   static const int env_cl17 = tune_int("MZK_COARSE_LOG_17", 9);       // tuning build: 8 = the 256-bin form with 8-byte records
   if (L.merged && !L.glv && L.sets == 1 && L.c == 17 && env_cl17 == 9 && cl == COARSE_LOG && COARSE_LOG == 8) {
     const size_t ref_max17 = (size_t)msm_table_rows(sh.c, L.sets) * table_stride;
     if (ref_max17 > ((size_t)1 << (31 - 8)) && ref_max17 <= ((size_t)1 << (31 - 7))) cl = 9;
   }
+  if (L.glv && NBtot > ((size_t)STAGE_F_MAX << COARSE_LOG)) cl = 10;      // generic layout at 19 bits: 2^21 sorted buckets, 2048 per bin
   const size_t cbins = (size_t)1 << cl;
   const bool two_level = (NBtot & (NBtot - 1)) == 0 && NBtot >= 4096 && (NBtot / cbins) <= (size_t)FINE_MAX &&
                          (n >= 4096 || ((point_kind & 0xff) == 2 && NBtot > ((size_t)1 << 15)));
@@ -1799,7 +1911,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     // at 2^20, merged equal within noise from 16 Ki to 64 Ki: profiles/r04m_*), 128 Ki when a bin has thousands of buckets
     // (the [bucket][sub] histogram that is scanned afterwards has NB * S entries)
     static const int env_per_fine = tune_int("MZK_PER_FINE", 0);      // tuning: tools/timing/window_sweep.py
-    const size_t per_fine = env_per_fine > 0 ? (size_t)env_per_fine : ((NBtot / cbins >= 4096) ? 131072 : (L.glv ? 16384 : 32768));
+    const size_t per_fine = env_per_fine > 0 ? (size_t)env_per_fine : ((NBtot / cbins >= 4096) ? 131072 : (NBtot / cbins >= 2048) ? 65536 : (L.glv ? 16384 : 32768));
     int S = (int)((E_max / cbins + per_fine - 1) / per_fine);
     if (S < 2) S = 2;
     if (S > 64) S = 64;
@@ -1809,31 +1921,41 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     const size_t fine_wgs = cbins * (size_t)S + (E_max + slice_cap - 1) / slice_cap + 1;
     const size_t n_coarse = cbins * nwg, n_fine = (size_t)F * fine_wgs;
     u32 *binhist, *finehist;
-    MZK_TRY(ws_get(WS_MSM_WGHIST, (n_coarse + 1 + n_fine + 1) * 4, (void**)&binhist));
+    MZK_TRY(ws_get(WS_MSM_WGHIST, (n_coarse + 1 + n_fine + 1 + cbins + 1) * 4, (void**)&binhist));
     finehist = binhist + n_coarse + 1;
     const size_t sb_f = (n_fine + SCAN_BLOCK - 1) / SCAN_BLOCK;
     u32* scan2;
     MZK_TRY(ws_get(WS_MSM_SCAN, (scan_scratch_words(n_coarse) + scan_scratch_words(n_fine) + 4) * 4, (void**)&scan2));
-    if (cl == 10)
-      hipLaunchKernelGGL((k_coarse_count<20, 10>), dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
-    else if (cl == 9)
-      hipLaunchKernelGGL((k_coarse_count<17, 9>), dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
-    else if (L.merged && !L.glv && L.sets == 1 && L.c == 20)
-      hipLaunchKernelGGL(k_coarse_count<20>, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
-    else if (L.merged && !L.glv && L.sets == 1 && L.c == 17)
-      hipLaunchKernelGGL(k_coarse_count<17>, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
-    else if (L.merged && !L.glv && L.sets == 1 && L.c == 16)
-      hipLaunchKernelGGL(k_coarse_count<16>, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
-    else
-      hipLaunchKernelGGL(k_coarse_count<0>, dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg);
-    MZK_TRY(launch_exclusive_scan((const u32*)binhist, binhist, n_coarse, scan2, s));
+    // scan-free sort (k_coarse_count, k_fine_scatter): no global scan at either level, nine launches -> five
+    static const int env_scan_free = tune_int("MZK_SORT_SCAN_FREE", 3);       // tuning build: bit 0 = coarse level, bit 1 = fine level
+    const bool coarse_free = (env_scan_free & 1) != 0 && cbins <= (size_t)SORT_CTR_BINS;
+    const bool fine_free = (env_scan_free & 2) != 0 && F <= STAGE_F_MAX;
+    u32* bin_tot = coarse_free ? heavy + SORT_CTR_AT : nullptr;
+    u32* bin_cur = coarse_free ? heavy + SORT_CTR_AT + SORT_CTR_BINS : nullptr;
+    u32* bin_start = coarse_free ? finehist + n_fine + 1 : nullptr;
+    u32* bucket_tot = fine_free ? counts : nullptr;                          // (counts: 2 NB words, see above)
+    u32* bucket_cur = fine_free ? counts + NBtot : nullptr;
+    u32* zero_ptr = fine_free ? counts : nullptr;
+    const size_t zero_words = fine_free ? 2 * NBtot : 0;
+#define MZK_CCOUNT(C, CLOG) hipLaunchKernelGGL((k_coarse_count<C, CLOG>), dim3(nwg), dim3(SORT2_THREADS), 0, s, (const u32*)d_scalars, n, L, key_shift, binhist, nwg, \
+                                               bin_tot, zero_ptr, zero_words)
+    const bool plain_merged = L.merged && !L.glv && L.sets == 1;
+    if (cl == 10 && L.glv) MZK_CCOUNT(0, 10);
+    else if (cl == 10) MZK_CCOUNT(20, 10);
+    else if (cl == 9) MZK_CCOUNT(17, 9);
+    else if (plain_merged && L.c == 20) MZK_CCOUNT(20, COARSE_LOG);
+    else if (plain_merged && L.c == 17) MZK_CCOUNT(17, COARSE_LOG);
+    else if (plain_merged && L.c == 16) MZK_CCOUNT(16, COARSE_LOG);
+    else MZK_CCOUNT(0, COARSE_LOG);
+#undef MZK_CCOUNT
+    if (!coarse_free) MZK_TRY(launch_exclusive_scan((const u32*)binhist, binhist, n_coarse, scan2, s));
     int fb = 0;
     while ((1 << fb) < F) fb++;
     // largest point reference: merged nwin * stride, generic phi_offset + n
     const size_t ref_max = L.merged ? (size_t)msm_table_rows(sh.c, L.sets) * table_stride : L.phi_offset + n;
     const bool compact = ref_max <= ((size_t)1 << (31 - fb));      // references are < ref_max
     SortArgs sa{(const u32*)d_scalars, n, L, key_shift, fine_mask, fb, binhist, nwg, (void*)ranks, F, S, finehist, scan2 + scan_scratch_words(n_coarse) + 2, sb_f, n_fine,
-                offsets, entries, NBtot, (unsigned)fine_wgs, (u32)slice_cap, cl};
+                offsets, entries, NBtot, (unsigned)fine_wgs, (u32)slice_cap, cl, bin_tot, bin_cur, bin_start, bucket_tot, bucket_cur};
     MZK_TRY(compact ? sort_records<Rec4>(sa, s) : sort_records<Rec8>(sa, s));
   } else if (L.merged) {
     // LDS histogram path (no global atomics)
@@ -2004,17 +2126,9 @@ __global__ __launch_bounds__(SORT1_THREADS) void k_many_sort1(const u32* __restr
   u32 local = 0;
 #pragma unroll
   for (int q = 0; q < PER; q++) { const int b = tid * PER + q; if (b < NB) local += hist[b]; }
-  scan[tid] = local;
-  __syncthreads();
-  for (int off = 1; off < SORT1_THREADS; off <<= 1) {
-    const u32 t = (tid >= off) ? scan[tid - off] : 0u;
-    __syncthreads();
-    scan[tid] += t;
-    __syncthreads();
-  }
+  u32 total;
+  u32 run = block_excl_scan<SORT1_THREADS>(local, scan, &total);
   const u32 base = (u32)(j * cap);
-  const u32 total = scan[SORT1_THREADS - 1];
-  u32 run = scan[tid] - local;
 #pragma unroll
   for (int q = 0; q < PER; q++) {
     const int b = tid * PER + q;
