@@ -418,7 +418,7 @@ int mzk_srs_window_bits(const mzk_srs* srs);
 int mzk_srs_direct_bits(const mzk_srs* srs);
 /* Window width (bits of a signed digit) mzk_msm_g1_bn254* uses for n arbitrary points: every scalar is split in two halves of
  * 127 bits (mzk_glv.h), each cut into 126 / bits + 1 windows -- 2 x that many mixed additions per pair (16 bits and 16 additions
- * up to 2^22 pairs, 19 bits and 14 additions from 2^23 on).  Sizing information for the callers of Polynomial::
+ * below 3 x 2^21 pairs, 19 bits and 14 additions from there on).  Sizing information for the callers of Polynomial::
  * eval_with_powers_on_curve (polynomial.rs:156-165), which has no such notion; bench.py prices the accumulate kernel with it. */
 int mzk_msm_generic_window_bits(size_t n);
 size_t mzk_srs_table_bytes(const mzk_srs* srs);

@@ -15,6 +15,7 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof g_err, fmt, ap);
   va_end(ap);
 }
+void clear_error() { g_err[0] = 0; }
 int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
   return MZK_E_HIP;
@@ -50,10 +51,19 @@ int ctx_peer_enabled(int a, int b) { return (a >= 0 && b >= 0 && a < g_nctx && b
 static uint64_t g_gen_counter = 1;
 Context& ctx() { return g_ctxs[g_cur]; }
 int ctx_count() { return g_nctx; }
+// What mzk_init's unguarded fast path may look at, and nothing else: the ordinal context 0 drives WHILE it is ready and current, -1
+// otherwise.  Every writer of g_cur / of context 0 (ctx_select, CtxScope, mzk_init_devices, mzk_shutdown) publishes it with release
+// order, the fast path reads it with acquire order -- it never touches g_nctx, g_ctxs or g_cur, which those writers change under the
+// entry guard the fast path does not take.
+static std::atomic<int> g_ctx0_current_on{-1};
+static void publish_ctx0() {
+  g_ctx0_current_on.store((g_nctx > 0 && g_cur == 0 && g_ctxs[0].ready) ? g_ctxs[0].device : -1, std::memory_order_release);
+}
 int ctx_select(int index) {
   if (index < 0 || index >= g_nctx || !g_ctxs[index].ready) { set_error("context %d does not exist (%d initialised)", index, g_nctx); return MZK_E_ARG; }
   MZK_HIP(hipSetDevice(g_ctxs[index].device));
   g_cur = index;
+  publish_ctx0();
   return MZK_OK;
 }
 CtxScope::CtxScope(int index) : prev_ctx(g_cur), prev_dev(-1), ok(false) {
@@ -62,6 +72,7 @@ CtxScope::CtxScope(int index) : prev_ctx(g_cur), prev_dev(-1), ok(false) {
 }
 CtxScope::~CtxScope() {
   g_cur = prev_ctx;
+  publish_ctx0();
   if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
 }
 
@@ -72,24 +83,30 @@ CtxScope::~CtxScope() {
 // it, every slot the RUNNING call has not asked for is freed and the allocation tried again; what is still refused is
 // MZK_E_NOMEM, not MZK_E_HIP.  mzk_trim_workspace() does the same on request, for every context, cached transform plans included.
 size_t ws_bytes_held() {
-  size_t t = 0;
+  size_t t = poly_bytes_held();        // the polynomial routines' pool and cached plans count as workspace
   for (const auto& b : ctx().ws) t += b.cap;
   return t;
 }
 size_t ws_trim_idle() {
   Context& c = ctx();
+  const size_t poly_idle = poly_trim_idle();
   size_t idle = 0;
   for (const auto& b : c.ws) if (b.p && b.epoch != g_call_epoch) idle += b.cap;
-  if (!idle) return 0;
+  if (!idle) return poly_idle;
   (void)hipDeviceSynchronize();
-  for (auto& b : c.ws) {
+  bool table_slot_freed = false;
+  for (int k = 0; k < WS_COUNT; k++) {
+    WsBuf& b = c.ws[k];
     if (b.p && b.epoch != g_call_epoch) {
       (void)hipFree(b.p);
       b.p = nullptr; b.cap = 0;
+      table_slot_freed = table_slot_freed || k == WS_FB_TABLE16 || k == WS_FB_TABLE8 || k == WS_NTT_PRE || k == WS_NTT_PRE_M128;
     }
   }
-  c.ws_gen = ++g_gen_counter;          // device tables cached inside slots (fixed-base tables of g, offset powers) are gone with them
-  return idle;
+  // device tables cached inside slots (fixed-base tables of g, offset powers) are gone with THEIR slots only: a trim in the middle of a
+  // call that holds them leaves the caches valid (a budgeted loop that alternates call kinds rebuilt them on every call otherwise)
+  if (table_slot_freed) c.ws_gen = ++g_gen_counter;
+  return idle + poly_idle;
 }
 int dev_alloc(void** out, size_t bytes, const char* what) {
   *out = nullptr;
@@ -439,10 +456,11 @@ int mzk_init_devices(const int* device_ordinals, int n_devices) {
 // and the device alone -- the enclosing call owns them.
 int mzk_init(int device_ordinal) {
   // Idempotent fast path WITHOUT the entry guard: a second host thread's first call during a long call of another
-  // thread used to get MZK_E_BUSY here, where mzk_init had been a harmless no-op.  Reading g_nctx / context 0 is safe against the
-  // only writers (mzk_init_devices, mzk_shutdown: hosts do not run those concurrently with their first calls), nothing is written,
-  // and the caller's HIP device is set for ITS thread only.
-  if (g_nctx > 0 && g_ctxs[0].ready && g_ctxs[0].device == device_ordinal && g_cur == 0) {
+  // thread used to get MZK_E_BUSY here, where mzk_init had been a harmless no-op.  It reads ONE atomic (g_ctx0_current_on: context 0
+  // ready on this ordinal and current), nothing is written, and the caller's HIP device is set for ITS thread only.  While another
+  // thread's *_multi call has switched contexts, or a shutdown / re-initialisation is under way, the flag is -1 and the guarded
+  // path below answers (MZK_E_BUSY in those windows, as for every other entry point).
+  if (g_ctx0_current_on.load(std::memory_order_acquire) == device_ordinal) {
     int dev = -1;
     if (hipGetDevice(&dev) == hipSuccess && (dev == device_ordinal || hipSetDevice(device_ordinal) == hipSuccess)) return MZK_OK;
     (void)hipGetLastError();
@@ -472,6 +490,7 @@ void mzk_shutdown(void) {
     g_prof_pool.clear();
     for (auto& e : g_prof_open) { if (e) (void)hipEventDestroy(e); e = nullptr; }
   }
+  g_ctx0_current_on.store(-1, std::memory_order_release);     // mzk_init's fast path must not answer for a context that is going away
   for (int i = 0; i < g_nctx; i++) {
     Context& c = g_ctxs[i];
     if (!c.ready) continue;
@@ -947,6 +966,7 @@ int mzk_g1_fold_partials_dev(const void* d_partials16, int count, void* d_out_xy
 // the error MZK_E_NOMEM.  mzk_srs_window_bits / mzk_srs_bucket_sets / mzk_srs_table_bytes report what a handle got.
 static size_t g_table_budget = 0;
 namespace mzk {
+size_t table_budget_bytes() { return g_table_budget; }
 int srs_alloc_layout(mzk_srs* h, int with_tables) {
   const size_t n = h->n;
   struct Cand { bool tables; int bits, sets; };

@@ -28,6 +28,8 @@ static inline constexpr int tune_int(const char*, int dflt) { return dflt; }
 
 // ---- error plumbing ------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
+void clear_error();                            // a refused allocation that the call then does without leaves no message behind
+size_t table_budget_bytes();                   // mzk_set_table_budget (0 = no limit)
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
 #define MZK_HIP(x)                                                        \
   do {                                                                    \
@@ -118,6 +120,8 @@ size_t ws_trim_idle();
 size_t ws_bytes_held();
 // hipMalloc that tries again after ws_trim_idle() when the device is out of memory; MZK_E_NOMEM if it still is.
 int dev_alloc(void** out, size_t bytes, const char* what);
+size_t poly_bytes_held();                      // mzk_poly.hip: pool blocks + cached interpolation plans of the current context
+size_t poly_trim_idle();                       // ... released but for what the running call uses; bytes given back
 uint64_t ws_generation();
 // Put one at the top of every entry point that enqueues work using workspace slots on stream s.
 struct WsGuard {

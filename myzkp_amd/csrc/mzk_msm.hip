@@ -63,12 +63,13 @@ static MsmShape choose_shape_glv(size_t n) {
   if (c < 8) c = 8;
   if (c > 16) c = 16;
   if (c == 15) c = 16;     // 2^17 pairs: 8 full windows + the two-level sort beat 9 windows with a 6-bit top window
-  // From 2^23 pairs on: 19 bits -- SEVEN windows per half instead of eight (14 mixed additions per pair, not 16: the accumulate is 80 % of
-  // the call), 7 x 2^18 buckets.  17 and 18 bits still need eight windows (7 x 18 = 126 leaves the top window nothing but carries),
-  // 20 bits also seven but twice the buckets, 22 bits six windows over 6 x 2^21 buckets whose reduction costs what the windows save.
-  // Below 2^23 the 3.7 M additions of the larger bucket reduction outweigh the saved 2 n (profiles/round6_generic_window_sweep.txt).
+  // From 3 x 2^21 pairs on: 19 bits -- SEVEN windows per half instead of eight (14 mixed additions per pair, not 16: the accumulate is
+  // 80 % of the call), 7 x 2^18 buckets.  17 and 18 bits still need eight windows (7 x 18 = 126 leaves the top window nothing but
+  // carries), 20 bits also seven but twice the buckets, 22 bits six windows over 6 x 2^21 buckets whose reduction and one-pass sort cost
+  // more than the windows save.  The larger bucket set costs ~0.7 ms more to sort, combine and reduce whatever n is, the saved additions
+  // 0.145 ms per 2^20 pairs: 2^22 +3.6 %, 2^23 -2 %, 2^24 -6.5 %, 2^26 -7.5 % (profiles/round6_generic_window_sweep.txt).
   static const int env_glv_c = tune_int("MZK_GLV_C", 0);         // tuning build: force a width (the sweep)
-  if (lg >= 24) c = 19;
+  if (n >= ((size_t)3 << 21)) c = 19;
   if (env_glv_c > 0) c = env_glv_c;
   // nwin windows must cover the 126 magnitude bits plus the signed-digit carry.  The top window only holds
   // 126 - c (nwin - 1) real bits; if that is (almost) nothing, every scalar whose carry runs into it lands in the
@@ -2435,14 +2436,22 @@ constexpr int MANY_WIDE_BITS = 12;
 int msm_many_srs(const mzk_srs* srs, const void* d_scalars, size_t n, size_t stride_elems, size_t count, void* d_out, hipStream_t s) {
   if (srs->d_direct) return msm_direct_many_dev_impl(d_scalars, n, stride_elems, count, srs->d_direct, srs->direct_bits, srs->n, d_out, s);
   if (n >= MANY_WIDE_FROM && srs->has_tables && srs->sets == 1 && srs->window_bits < MANY_WIDE_BITS) {
-    if (!srs->d_tables_wide) {       // once per handle: row 0 of its own tables are the prepared points
+    if (!srs->d_tables_wide && srs->wide_bits == 0) {       // once per handle: row 0 of its own tables are the prepared points
       const size_t bytes = (size_t)msm_table_windows(MANY_WIDE_BITS) * srs->n * 64;
+      const size_t own = (size_t)srs->n * 64 * srs->table_rows() + srs->direct_bytes;
       void* t = nullptr;
-      if (dev_alloc(&t, bytes, "wide window tables of the grid-batched pass") == MZK_OK) {
+      // the caller's table budget (mzk_set_table_budget) covers these tables too; a refusal -- budget or device -- is remembered on the
+      // handle (wide_bits = -1), so that later batches do not repeat a failing hipMalloc and the idle-workspace release it triggers,
+      // and the message of the refused allocation does not stay behind on a call that returns MZK_OK
+      const bool within_budget = table_budget_bytes() == 0 || own + bytes <= table_budget_bytes();
+      if (within_budget && dev_alloc(&t, bytes, "wide window tables of the grid-batched pass") == MZK_OK) {
         const int rc = msm_build_tables(srs->d_points_mont, srs->n, t, MANY_WIDE_BITS, s);
         if (rc != MZK_OK) { (void)hipFree(t); return rc; }
         srs->d_tables_wide = t; srs->wide_bits = MANY_WIDE_BITS; srs->wide_bytes = bytes;
-      }      // no memory for them: the handle's own tables serve (slower, same points)
+      } else {
+        srs->wide_bits = -1;         // no memory (or no budget) for them: the handle's own tables serve (slower, same points)
+        if (within_budget) clear_error();
+      }
     }
     if (srs->d_tables_wide) return msm_many_dev_impl(d_scalars, n, stride_elems, count, srs->d_tables_wide, srs->wide_bits, srs->n, d_out, s);
   }

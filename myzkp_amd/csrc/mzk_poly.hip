@@ -322,6 +322,7 @@ struct PolyPool {
 static PolyPool g_poly_pool[MZK_MAX_CTX];
 constexpr size_t POLY_POOL_MAX_BYTES = (size_t)2 << 30;
 void poly_release_plans();
+size_t poly_trim_idle();
 static void poly_release_free_blocks() {
   PolyPool& pool = g_poly_pool[ctx().index];
   for (auto& b : pool.free_blocks) (void)hipFree(b.p);
@@ -355,9 +356,13 @@ struct DevBuf {
       }
     }
     if (hipMalloc(&p, want) != hipSuccess) {
+      // the ABI's out-of-memory contract (mzk.h): give back what the running call does not use -- the blocks parked in this pool, the
+      // cached interpolation plans but the one in use, then (dev_alloc) the idle workspace slots -- retry, and what is still refused is
+      // MZK_E_NOMEM, never a bare HIP error
       (void)hipGetLastError();
-      poly_release_free_blocks();                      // out of memory with blocks parked in the pool: give them back and retry (cached plans may be in use: they stay)
-      if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; set_error("poly: hipMalloc(%zu) failed", want); return MZK_E_HIP; }
+      p = nullptr;
+      (void)poly_trim_idle();
+      MZK_TRY(dev_alloc(&p, want, "polynomial scratch"));
     }
     cap = want;
     return MZK_OK;
@@ -639,6 +644,7 @@ template <class P> struct InterpPlan : InterpPlanBase {
   DevBuf d_dom, d_zp;        // the domain; 1 / Z'(d_i)
 };
 static std::vector<InterpPlanBase*> g_interp_plans[MZK_MAX_CTX];
+static InterpPlanBase* g_interp_busy[MZK_MAX_CTX];     // the cached plan the running call works with: never evicted under it
 static uint64_t g_interp_stamp = 0;
 constexpr size_t INTERP_MAX_PLANS = 4;
 constexpr size_t INTERP_MAX_BYTES = (size_t)1 << 30;
@@ -646,6 +652,32 @@ void poly_release_plans() {
   auto& v = g_interp_plans[ctx().index];
   for (auto* p : v) delete p;
   v.clear();
+  g_interp_busy[ctx().index] = nullptr;
+}
+// Device bytes this file holds on the current context outside any call: blocks parked in the pool + the cached plans (their own
+// estimate).  Part of mzk_workspace_bytes and of the workspace budget.
+size_t poly_bytes_held() {
+  size_t t = g_poly_pool[ctx().index].bytes;
+  for (auto* b : g_interp_plans[ctx().index]) t += b->bytes;
+  return t;
+}
+// Everything here the RUNNING call does not use goes back to the device: the cached plans but the busy one (their buffers pass
+// through the pool), then the parked blocks.  Returns the bytes released.  Called when an allocation was refused or would exceed
+// the budget (ws_trim_idle) and by mzk_trim_workspace.
+size_t poly_trim_idle() {
+  const size_t before = poly_bytes_held();
+  auto& v = g_interp_plans[ctx().index];
+  InterpPlanBase* busy = g_interp_busy[ctx().index];
+  bool any = false;
+  for (size_t i = v.size(); i-- > 0;) {
+    if (v[i] == busy) continue;
+    if (!any) { (void)hipDeviceSynchronize(); any = true; }      // a plan's buffers may still be read by enqueued work of an earlier call
+    delete v[i];
+    v.erase(v.begin() + (long)i);
+  }
+  poly_release_free_blocks();
+  const size_t after = poly_bytes_held();
+  return before > after ? before - after : 0;
 }
 // the domain of an interpolation is canonical if a cached plan was built from exactly these limbs (it was checked then); otherwise check it now
 static int interp_check_domain(int fid, const HostField* hf, const uint64_t* domain, size_t n) {
@@ -746,9 +778,10 @@ static int interpolate_impl(int fid, const uint64_t* domain, const uint64_t* val
   bool transient = false;
   MZK_TRY(interp_plan_get<P>(fid, domain, n, root, root_order, s, &plan, &transient));
   struct Drop {         // a plan too large for the cache lives for this call only (every exit path; the stream is idle by then or is waited for)
-    InterpPlanBase* p; hipStream_t s;
-    ~Drop() { if (p) { (void)hipStreamSynchronize(s); delete p; } }
-  } drop{transient ? plan : nullptr, s};
+    InterpPlanBase* p; hipStream_t s; int idx;
+    ~Drop() { g_interp_busy[idx] = nullptr; if (p) { (void)hipStreamSynchronize(s); delete p; } }
+  } drop{transient ? plan : nullptr, s, ctx().index};
+  g_interp_busy[ctx().index] = transient ? nullptr : plan;      // an allocation of this call that runs out of memory evicts the OTHER cached plans only
   PolyTree<P>& T = plan->T;
   DevBuf& d_dom = plan->d_dom;
   DevBuf& d_zp = plan->d_zp;

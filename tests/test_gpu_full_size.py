@@ -92,19 +92,19 @@ def test_msm_2_24_generic_and_srs_tables_trapdoor_identity(env):
 
 
 def test_msm_generic_first_size_of_the_19_bit_windows_trapdoor_identity(env):
-    """2^23 pairs is where the generic (GLV) layout goes from 16-bit to 19-bit windows (seven windows per half-scalar over 7 x 2^18
-    buckets, sorted as 2^21 with an empty eighth window: mzk_msm.hip choose_shape_glv): a ragged size just above the switch and one
-    just below it, against the closed form sum_i s_i [alpha^i]G = [f(alpha)]G (polynomial.rs:156-165)."""
+    """3 x 2^21 pairs is where the generic (GLV) layout goes from 16-bit to 19-bit windows (seven windows per half-scalar over 7 x 2^18
+    buckets, sorted as 2^21 with an empty eighth window: mzk_msm.hip choose_shape_glv): a ragged size just above the switch and the
+    last one below it, against the closed form sum_i s_i [alpha^i]G = [f(alpha)]G (polynomial.rs:156-165)."""
     torch, mz, L, dev, st = env
-    n = (1 << 23) + 4321
-    assert L.mzk_msm_generic_window_bits(ctypes.c_size_t(n)) == 19 and L.mzk_msm_generic_window_bits(ctypes.c_size_t((1 << 23) - 1)) == 16
+    n = (3 << 21) + 4321
+    assert L.mzk_msm_generic_window_bits(ctypes.c_size_t(n)) == 19 and L.mzk_msm_generic_window_bits(ctypes.c_size_t((3 << 21) - 1)) == 16
     alpha = orc.from_limbs(orc.synth_vector(FR, 2301, 1))[0]
     sc = torch.empty(n * 4, dtype=torch.int64, device=dev)
     _ok(L, L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(2302), ctypes.c_size_t(n), _dp(sc), st))
     pts = _srs_points_dev(env, alpha, n)
     out = torch.zeros(16, dtype=torch.int64, device=dev)
     s_cpu = orc.synth_vector(FR, 2302, n)
-    for k, m in enumerate((n, (1 << 23) - 1)):
+    for k, m in enumerate((n, (3 << 21) - 1)):
         _ok(L, L.mzk_msm_g1_bn254_dev(_dp(sc), _dp(pts), ctypes.c_size_t(m), _dp(out, 64 * k), st))
         torch.cuda.synchronize()
         assert _point(mz, out[8 * k:8 * k + 8]) == orc.ec_mul(0, G, orc.poly_eval(FR, s_cpu[:m], alpha)), "generic MSM of %d pairs != [f(alpha)]G" % m
