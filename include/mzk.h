@@ -437,6 +437,18 @@ int mzk_kzg_setup_g1_dev(const uint64_t alpha_host[4], const uint64_t g1_xy_host
 int mzk_kzg_setup_g1_range_dev(const uint64_t alpha_host[4], const uint64_t g1_xy_host[8], size_t first, size_t count,
                                void* d_powers_xy, void* stream);
 int mzk_kzg_open_quotient_dev(const void* d_coef, size_t n, const uint64_t u_host[4], void* d_y, void* d_q, void* stream);
+/* The quotient of open_kzg (kzg.rs:61-72: (f - y) / (X - u)) SHARDED over the ranks: q_{i-1} = b_i with b_i = c_i + u b_{i+1} is a suffix
+ * recurrence over the whole coefficient vector, so the rank that holds the slice c[lo, hi) needs one value from the ranks above it,
+ * b_hi.  Two local passes around one exchange of 32 bytes per rank:
+ *   mzk_kzg_open_slice_value_dev     d_value (4 limbs) = sum_t c[lo + t] u^t, the slice's value at u (its b_lo with carry 0);
+ *   (the ranks gather the values; top rank down: b_lo(g) = value(g) + u^(hi - lo) b_hi(g), b_hi(g - 1) = b_lo(g); y = b_lo(0))
+ *   mzk_kzg_open_slice_quotient_dev  d_q_slice (len elements) = b[lo + 1 .. hi], given carry_in = b_hi (4 limbs, canonical; 0 for the
+ *                                    top rank) -- exactly the quotient coefficients q[lo .. hi) the rank commits against ITS powers
+ *                                    (the top rank's last one, q[n - 1] = b_n = 0, contributes nothing).
+ * Same field elements as the one-piece recurrence, hence the same witness.  myzkp_amd/sharded.py: sharded_open_quotient. */
+int mzk_kzg_open_slice_value_dev(const void* d_coef_slice, size_t len, const uint64_t u_host[4], void* d_value, void* stream);
+int mzk_kzg_open_slice_quotient_dev(const void* d_coef_slice, size_t len, const uint64_t u_host[4], const uint64_t carry_in[4], void* d_q_slice,
+                                    void* stream);
 /* Build an SRS handle from points already in HBM (affine canonical, n * 8 limbs).  The _ex form chooses
  * whether the window tables are built (worth it from ~30 commits per SRS on at 2^20 points; a one-shot pipeline keeps
  * the plain prepared points and pays the window Horner instead).  Default widths by size: 8 bits up to 1024 points,

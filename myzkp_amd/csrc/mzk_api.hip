@@ -599,6 +599,73 @@ static int side_stream(hipStream_t* side, hipEvent_t* fork, hipEvent_t* join) {
   return MZK_OK;
 }
 
+// Host buffers in PIECES (the callers own host Vecs: kzg.rs:57-72): piece k + 1 crosses PCIe on the side stream -- a pageable
+// hipMemcpyAsync keeps the host in the call until the piece is staged -- while the GPU sorts and accumulates piece k
+// (msm_chunked_impl).  Split points in 1/256ths of n: MZK_HOST_CHUNKS_COMMIT / _MSM in the tuning build, e.g. "64,256" = 25 % + 75 %.
+// The first piece is small (nothing runs under its transfer), the later ones must keep the accumulate's lanes busy; every piece is
+// rounded to whole sort workgroups (4096 pairs).
+static int host_chunk_plan(size_t n, const char* env_name, const int* dflt, int dflt_count, mzk::MsmChunk* ch) {
+  int cuts[8], K = 0;
+#ifdef MZK_TUNING
+  if (const char* v = getenv(env_name)) {
+    for (const char* p = v; *p && K < 8;) { cuts[K++] = atoi(p); while (*p && *p != ',') p++; if (*p == ',') p++; }
+  }
+#else
+  (void)env_name;
+#endif
+  if (K == 0) for (; K < dflt_count; K++) cuts[K] = dflt[K];
+  size_t prev = 0;
+  int out = 0;
+  for (int k = 0; k < K; k++) {
+    size_t end = (k + 1 == K) ? n : ((n * (size_t)cuts[k] / 256) & ~(size_t)4095);
+    if (end > n) end = n;
+    if (end <= prev) continue;
+    ch[out++] = mzk::MsmChunk{nullptr, prev, end - prev, nullptr};
+    prev = end;
+  }
+  if (prev < n) { if (out) ch[out - 1].n += n - prev; else ch[out++] = mzk::MsmChunk{nullptr, 0, n, nullptr}; }
+  return out;
+}
+static bool host_chunks_enabled() {
+  static const int v = mzk::tune_int("MZK_HOST_CHUNKS", 1);        // tuning build: 0 = one piece, the form of rounds 2-5
+  return v != 0;
+}
+// scalars (32 bytes per pair) and, for the generic MSM, points (64 bytes per pair) of every piece: host -> their workspace slots on
+// the side stream; `ev[k]` fires when piece k has landed
+struct HostChunkUpload {
+  const uint64_t *scalars, *points;
+  void *d_s, *d_p;
+  mzk::MsmChunk* ch;
+  hipEvent_t* ev;
+  hipStream_t side;
+  int operator()(int k) const {
+    const size_t i0 = ch[k].i0, m = ch[k].n;
+    MZK_HIP(hipMemcpyAsync((uint8_t*)d_s + i0 * 32, scalars + i0 * 4, m * 32, hipMemcpyHostToDevice, side));
+    if (points) MZK_HIP(hipMemcpyAsync((uint8_t*)d_p + i0 * 64, points + i0 * 8, m * 64, hipMemcpyHostToDevice, side));
+    MZK_HIP(hipEventRecord(ev[k], side));
+    return MZK_OK;
+  }
+};
+struct EventSet {          // a few events for the length of one call
+  hipEvent_t ev[8] = {};
+  int make(int count) { for (int k = 0; k < count; k++) MZK_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming)); return MZK_OK; }
+  ~EventSet() { for (auto e : ev) if (e) (void)hipEventDestroy(e); }
+};
+static int msm_host_chunked(const uint64_t* scalars, const uint64_t* points, void* d_s, void* d_p, const void* d_points_for_msm, size_t n, int point_kind,
+                            size_t table_stride, void* d_o, hipStream_t s, mzk::MsmChunk* ch, int K) {
+  hipStream_t side;
+  hipEvent_t fork, join;
+  MZK_TRY(side_stream(&side, &fork, &join));
+  MZK_HIP(hipEventRecord(fork, s));              // the side stream starts behind everything enqueued so far (the slots' previous readers)
+  MZK_HIP(hipStreamWaitEvent(side, fork, 0));
+  EventSet es;
+  MZK_TRY(es.make(K));
+  for (int k = 0; k < K; k++) { ch[k].d_scalars = (const uint8_t*)d_s + ch[k].i0 * 32; ch[k].ready = es.ev[k]; }
+  const HostChunkUpload up{scalars, points, d_s, d_p, ch, es.ev, side};
+  const std::function<int(int)> before = [&](int k) -> int { return up(k); };
+  return msm_chunked_impl(ch, K, d_points_for_msm, n, point_kind, table_stride, d_o, false, s, nullptr, &before);
+}
+
 int mzk_ntt(int field_id, const uint64_t* root, const uint64_t* in, uint64_t* out, size_t n, int inverse) {
   MZK_ENTER();
   if (field_id != MZK_FIELD_FR && field_id != MZK_FIELD_M128) { set_error("ntt: bad field id %d", field_id); return MZK_E_ARG; }
@@ -923,10 +990,21 @@ int mzk_msm_g1_bn254(const uint64_t* scalars, const uint64_t* points_xy, size_t 
   hipEvent_t fork, join;
   MZK_TRY(side_stream(&side, &fork, &join));
   MZK_TRY(ws_get(WS_MISC_A, n ? n * 64 : 16, &d_p));
+  MZK_TRY(ws_get(WS_MISC_B, 256, &d_o));
+  if (msm_chunkable(n, MSM_PTS_PLAIN) && host_chunks_enabled()) {
+    // four equal pieces of scalars + points: the transfers (96 bytes per pair: 1.7 ms at 2^20) run under the pieces' kernels but for
+    // the first piece's (profiles/round6_host_buffer_chunks.txt)
+    static const int quarters[4] = {64, 128, 192, 256};
+    MsmChunk ch[8];
+    MZK_TRY(ws_get(WS_MSM_SCALARS, n * 32, &d_s));
+    const int K = host_chunk_plan(n, "MZK_HOST_CHUNKS_MSM", quarters, 4, ch);
+    MZK_TRY(msm_host_chunked(scalars, points_xy, d_s, d_p, d_p, n, MSM_PTS_PLAIN, 0, d_o, s, ch, K));
+    MZK_TRY(d2h_sync(out_xy, d_o, 64, s));
+    return MZK_OK;
+  }
   MZK_HIP(hipEventRecord(fork, s));
   MZK_HIP(hipStreamWaitEvent(side, fork, 0));
   MZK_TRY(stage_in(WS_MSM_SCALARS, scalars, n * 32, &d_s, s));
-  MZK_TRY(ws_get(WS_MISC_B, 256, &d_o));
   const std::function<int()> points_ready = [&]() -> int {
     if (n) MZK_HIP(hipMemcpyAsync(d_p, points_xy, n * 64, hipMemcpyHostToDevice, side));
     MZK_HIP(hipEventRecord(join, side));
@@ -1084,8 +1162,18 @@ int mzk_kzg_commit_srs(const mzk_srs* srs, const uint64_t* coef, size_t n, uint6
   hipStream_t s = ctx().stream;
   WsGuard wsg(s);
   void *d_s, *d_o;
-  MZK_TRY(stage_in(WS_MSM_SCALARS, coef, n * 32, &d_s, s));
   MZK_TRY(ws_get(WS_MISC_B, 256, &d_o));
+  if (msm_chunkable(n, srs->kind()) && host_chunks_enabled()) {
+    // a quarter of the coefficients first, the rest under its kernels (two pieces: every piece costs a segment combine of its own)
+    static const int quarter_then_rest[2] = {64, 256};
+    MsmChunk ch[8];
+    MZK_TRY(ws_get(WS_MSM_SCALARS, n * 32, &d_s));
+    const int K = host_chunk_plan(n, "MZK_HOST_CHUNKS_COMMIT", quarter_then_rest, 2, ch);
+    MZK_TRY(msm_host_chunked(coef, nullptr, d_s, nullptr, srs->d_points_mont, n, srs->kind(), srs->n, d_o, s, ch, K));
+    MZK_TRY(d2h_sync(out_xy, d_o, 64, s));
+    return MZK_OK;
+  }
+  MZK_TRY(stage_in(WS_MSM_SCALARS, coef, n * 32, &d_s, s));
   MZK_TRY(msm_dev_impl(d_s, srs->d_points_mont, n, srs->kind(), srs->n, d_o, false, s));
   MZK_TRY(d2h_sync(out_xy, d_o, 64, s));
   return MZK_OK;
@@ -1097,6 +1185,24 @@ int mzk_kzg_commit_srs_dev(const mzk_srs* srs, const void* d_coef, size_t n, voi
   if (!srs || !d_out || (!d_coef && n)) { set_error("commit_srs_dev: null pointer"); return MZK_E_ARG; }
   MZK_TRY(srs_check_ctx(srs));
   if (n > srs->n) { set_error("index out of bounds: the len is %zu but the index is %zu", srs->n, srs->n); return MZK_E_LENGTH; }
+#ifdef MZK_TUNING
+  // what-if of the verdict's two-half pipeline (VERDICT r05 #1a): MZK_DEV_CHUNKS pieces of resident coefficients, piece k + 1's sort on a
+  // side stream (MZK_DEV_SORT_STREAM=1) under piece k's accumulate -- measured and not adopted (profiles/round6_two_half_pipeline.txt)
+  static const int dev_chunks = mzk::tune_int("MZK_DEV_CHUNKS", 0), dev_sort_stream = mzk::tune_int("MZK_DEV_SORT_STREAM", 0);
+  if (dev_chunks >= 2 && dev_chunks <= 8 && msm_chunkable(n, srs->kind())) {
+    MsmChunk ch[8];
+    size_t prev = 0;
+    for (int k = 0; k < dev_chunks; k++) {
+      const size_t end = (k + 1 == dev_chunks) ? n : ((n * (size_t)(k + 1) / (size_t)dev_chunks) & ~(size_t)4095);
+      ch[k] = MsmChunk{(const uint8_t*)d_coef + prev * 32, prev, end - prev, nullptr};
+      prev = end;
+    }
+    hipStream_t side = nullptr;
+    hipEvent_t fork, join;
+    if (dev_sort_stream) MZK_TRY(side_stream(&side, &fork, &join));
+    return msm_chunked_impl(ch, dev_chunks, srs->d_points_mont, n, srs->kind(), srs->n, d_out, out_partial != 0, (hipStream_t)stream, side);
+  }
+#endif
   return msm_dev_impl(d_coef, srs->d_points_mont, n, srs->kind(), srs->n, d_out, out_partial != 0,
                       (hipStream_t)stream);
 }
@@ -1331,6 +1437,33 @@ int mzk_kzg_open_quotient_dev(const void* d_coef, size_t n, const uint64_t u_hos
   if (!d_q && n > 1) { set_error("open_quotient: null pointer"); return MZK_E_ARG; }
   int dummy;
   return kzg_open_dev(d_coef, n, u_host, nullptr, MSM_PTS_PLAIN, 0, d_y, nullptr, d_q ? d_q : (void*)&dummy, (hipStream_t)stream);
+}
+int mzk_kzg_open_slice_value_dev(const void* d_coef_slice, size_t len, const uint64_t u_host[4], void* d_value, void* stream) {
+  MZK_ENTER();
+  WsGuard wsg((hipStream_t)stream);
+  if (!d_value || !u_host || (!d_coef_slice && len)) { set_error("open_slice_value: null pointer"); return MZK_E_ARG; }
+  // the slice's own recurrence with nothing behind it: b_lo = the slice as a polynomial, evaluated at u (kzg_open_dev's y)
+  return kzg_open_dev(d_coef_slice, len, u_host, nullptr, MSM_PTS_PLAIN, 0, d_value, nullptr, nullptr, (hipStream_t)stream, true);
+}
+int mzk_kzg_open_slice_quotient_dev(const void* d_coef_slice, size_t len, const uint64_t u_host[4], const uint64_t carry_in[4], void* d_q_slice,
+                                    void* stream) {
+  MZK_ENTER();
+  hipStream_t s = (hipStream_t)stream;
+  WsGuard wsg(s);
+  if (!u_host || !carry_in || ((!d_coef_slice || !d_q_slice) && len)) { set_error("open_slice_quotient: null pointer"); return MZK_E_ARG; }
+  if (!h_is_canonical(host_field(MZK_FIELD_FR), carry_in)) { set_error("open_slice_quotient: carry not canonical"); return MZK_E_RANGE; }
+  if (len == 0) return MZK_OK;
+  // b over the slice with b_hi = carry is the plain recurrence over the len + 1 coefficients (slice, carry): the copy's last element
+  // b_len = carry, b_{len-1} = c_{len-1} + u carry, ...; its quotient output b_1 .. b_len is the slice of q
+  void* ext;
+  MZK_TRY(ws_get(WS_MISC_E, (len + 1) * 32, &ext));
+  MZK_HIP(hipMemcpyAsync(ext, d_coef_slice, len * 32, hipMemcpyDeviceToDevice, s));
+  MZK_HIP(hipMemcpyAsync((uint8_t*)ext + len * 32, carry_in, 32, hipMemcpyHostToDevice, s));
+  void* d_y;
+  MZK_TRY(ws_get(WS_MISC_F, 64, &d_y));
+  MZK_TRY(kzg_open_dev(ext, len + 1, u_host, nullptr, MSM_PTS_PLAIN, 0, d_y, nullptr, d_q_slice, s));
+  MZK_HIP(hipStreamSynchronize(s));           // carry_in is the caller's host memory: read until here
+  return MZK_OK;
 }
 int mzk_srs_from_device(const void* d_powers_xy, size_t n, mzk_srs** out, void* stream) {
   return mzk_srs_from_device_ex(d_powers_xy, n, 1, out, stream);

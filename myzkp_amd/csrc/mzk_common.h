@@ -215,8 +215,22 @@ static inline int msm_srs_window_bits(size_t n) {
 }
 static inline bool msm_srs_default_tables(size_t n) { return n > 0; }
 #define MSM_PTS_TABLES_C(c) (MSM_PTS_TABLES | ((c) << 8))      // bits 16..23: bucket sets (0 or 1 = one)
+// One MSM computed in CHUNKS of consecutive pairs (msm_chunked_impl): every chunk is sorted and accumulated on its own -- as soon as
+// ITS scalars (and points) are on the device -- into its own bucket array, the chunks' bucket arrays are summed and reduced once.
+// msm_dev_impl in chunk mode (cc != null) takes the chunk's scalars, the WHOLE point array, and stops after the segment combine.
+struct MsmChunkCtx {
+  int k, K;              // this chunk, number of chunks
+  size_t i0;             // index of the chunk's first pair in the whole problem
+  size_t n_total;        // pairs of the whole problem: decides the window width / bucket layout of every chunk
+  size_t n_alloc;        // the largest chunk: size of the per-chunk buffers (the same in every call, so that no workspace slot is regrown)
+  hipStream_t sort_stream;   // where the digit sort runs (null: the main stream): a chunk's sort may run under the previous chunk's accumulate
+};
+struct MsmChunk { const void* d_scalars; size_t i0, n; hipEvent_t ready; };    // ready (or null): recorded when the chunk's inputs are on the device
+int msm_chunked_impl(const MsmChunk* chunks, int K, const void* d_points, size_t n_total, int point_kind, size_t table_stride, void* d_out,
+                     bool out_partial_xyzz, hipStream_t s, hipStream_t sort_stream, const std::function<int(int)>* before_chunk = nullptr);
+bool msm_chunkable(size_t n_total, int point_kind);      // large enough, and a layout the chunk mode covers
 int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int point_kind, size_t table_stride, void* d_out,
-                 bool out_partial_xyzz, hipStream_t s, const std::function<int()>* points_ready = nullptr);
+                 bool out_partial_xyzz, hipStream_t s, const std::function<int()>* points_ready = nullptr, const MsmChunkCtx* cc = nullptr);
 
 // Grid-batched form for many short polynomials against one set of narrow window tables (mzk_msm.hip, mzk_kzg.hip)
 bool msm_many_supported(int window_bits);
@@ -242,7 +256,7 @@ int selftest_field_asm_impl(int fid, uint64_t seed, size_t n, uint64_t* mismatch
 int selftest_copy_impl(const void* d_src, void* d_dst, size_t bytes, hipStream_t s);
 int kzg_setup_g1_dev(const uint64_t* alpha_host, const uint64_t* g1_host, size_t first, size_t count, void* d_powers_xy, hipStream_t s);
 int kzg_open_dev(const void* d_coef, size_t n, const uint64_t* u_host, const void* d_points, int point_kind, size_t table_stride,
-                 void* d_y, void* d_w_xy, void* d_q_out, hipStream_t s);
+                 void* d_y, void* d_w_xy, void* d_q_out, hipStream_t s, bool value_only = false);
 
 }  // namespace mzk
 

@@ -390,8 +390,8 @@ int kzg_batch_open_dev(const void* d_coef, size_t n, const uint64_t* us_host, si
 
 // d_y: 8 words; d_w_xy: 16 words.
 int kzg_open_dev(const void* d_coef, size_t n, const uint64_t* u_host, const void* d_points, int point_kind, size_t table_stride,
-                 void* d_y, void* d_w_xy, void* d_q_out, hipStream_t s) {
-  if (!u_host || !d_y || (!d_w_xy && !d_q_out) || (!d_coef && n) || (!d_points && n > 1 && !d_q_out)) { set_error("kzg_open: null pointer"); return MZK_E_ARG; }
+                 void* d_y, void* d_w_xy, void* d_q_out, hipStream_t s, bool value_only) {
+  if (!u_host || !d_y || (!d_w_xy && !d_q_out && !value_only) || (!d_coef && n) || (!d_points && n > 1 && !d_q_out && !value_only)) { set_error("kzg_open: null pointer"); return MZK_E_ARG; }
   const HostField* fr = host_field(MZK_FIELD_FR);
   if (!h_is_canonical(fr, u_host)) { set_error("kzg_open: u not canonical"); return MZK_E_RANGE; }
   if (n == 0) {  // empty polynomial: y = 0, quotient empty -> infinity
@@ -445,6 +445,7 @@ int kzg_open_dev(const void* d_coef, size_t n, const uint64_t* u_host, const voi
   }
   MZK_HIP(hipGetLastError());
   MZK_HIP(hipMemcpyAsync(d_y, bbuf, 32, hipMemcpyDeviceToDevice, s));   // y = b_0
+  if (value_only) return MZK_OK;          // f(u) alone (the sharded opening's first pass: the slice's value)
   if (d_q_out) {   // quotient only (sharded opening: every rank MSMs its own slice of q)
     if (n > 1) MZK_HIP(hipMemcpyAsync(d_q_out, bbuf + 8, (n - 1) * 32, hipMemcpyDeviceToDevice, s));
     return MZK_OK;

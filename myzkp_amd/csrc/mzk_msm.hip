@@ -1755,9 +1755,15 @@ static int sort_records(const SortArgs& a, hipStream_t s) {
 // that reads the points -- the host-buffer entry point stages the points onto the device there, so that the transfer of the
 // 64 n bytes of points runs under the sort of the scalars instead of in front of it.
 int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int point_kind, size_t table_stride, void* d_out,
-                 bool out_partial_xyzz, hipStream_t s, const std::function<int()>* points_ready) {
+                 bool out_partial_xyzz, hipStream_t s, const std::function<int()>* points_ready, const MsmChunkCtx* cc) {
   if (!d_out || ((!d_scalars || !d_points) && n)) { set_error("msm: null pointer"); return MZK_E_ARG; }
   if (n > ((size_t)1 << 27)) { set_error("msm: n > 2^27 not supported"); return MZK_E_ARG; }
+  // chunk mode (msm_chunked_impl): the pairs [i0, i0 + n) of a problem of n_shape pairs; layout by the whole problem, per-chunk buffers
+  // sized for the largest chunk, returns with the chunk's buckets summed (no reduction)
+  const size_t n_shape = cc ? cc->n_total : n, n_alloc = cc ? cc->n_alloc : n, i0 = cc ? cc->i0 : 0;
+  const int ck = cc ? cc->k : 0, cK = cc ? cc->K : 1;
+  hipStream_t ss = (cc && cc->sort_stream) ? cc->sort_stream : s;      // the stream of the digit sort
+  if (cc && (n < SMALL_MAX_N || n > n_alloc)) { set_error("msm: chunk of %zu pairs (chunks hold 4097 .. %zu)", n, n_alloc); return MZK_E_ARG; }
   if (n == 0) {  // empty polynomial -> point at infinity (polynomial.rs:160)
     if (points_ready) MZK_TRY((*points_ready)());
     MZK_HIP(hipMemsetAsync(d_out, 0, out_partial_xyzz ? 128 : 64, s));
@@ -1772,8 +1778,8 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   L.table_stride = table_stride;
   // generic layout: GLV split (mzk_glv.h) -- 2n points (P_i and phi(P_i) at phi_offset + i), half-length scalars
   L.glv = L.merged ? 0 : 1;
-  L.phi_offset = (point_kind == 0) ? n : table_stride;   // prepared below / laid out by the SRS handle
-  MsmShape sh = L.merged ? choose_shape(n) : choose_shape_glv(n);
+  L.phi_offset = (point_kind == 0) ? n_shape : table_stride;   // prepared below / laid out by the SRS handle
+  MsmShape sh = L.merged ? choose_shape(n_shape) : choose_shape_glv(n_shape);
   if (L.merged) {
     sh.c = table_c; sh.nwin = msm_table_windows(table_c); sh.lgB = sh.c - 1; sh.nbuckets = (size_t)L.sets << sh.lgB;
   }
@@ -1782,11 +1788,12 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   const bool one_set = L.merged && L.sets == 1;     // the tail writes the result itself: no Horner over bucket sets
   const int red_windows = L.merged ? L.sets : sh.nwin;   // bucket sets to reduce
   const int horner_c = one_set ? 0 : sh.c;
-  const u32* pts = (const u32*)d_points;
+  // (a chunk's entries count from its first pair: every table row / the endomorphism images sit at the same distance behind it)
+  const u32* pts = (const u32*)d_points + i0 * 16;
   void* pm = nullptr;
   if (point_kind == 0) {
-    MZK_TRY(ws_get(WS_MSM_POINTS, 2 * n * 64, &pm));
-    pts = (const u32*)pm;
+    MZK_TRY(ws_get(WS_MSM_POINTS, 2 * n_shape * 64, &pm));
+    pts = (const u32*)pm + i0 * 16;
   }
   bool prepared = false;
   auto prepare = [&]() -> int {          // Montgomery form + endomorphism images of plain points; once, before their first reader
@@ -1795,16 +1802,17 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     if (points_ready) MZK_TRY((*points_ready)());
     if (point_kind != 0) return MZK_OK;
     prof_begin(s, MZK_PH_MSM_PREPARE);
-    MZK_TRY(msm_prepare_points(d_points, n, pm, (u32*)pm + n * 16, s));
+    MZK_TRY(msm_prepare_points((const u32*)d_points + i0 * 16, n, (u32*)pm + i0 * 16, (u32*)pm + (n_shape + i0) * 16, s));
     prof_end(s, MZK_PH_MSM_PREPARE);
     return MZK_OK;
   };
-  const size_t E_max = n * (size_t)(L.glv ? 2 * sh.nwin : sh.nwin);
+  const size_t windows_per_pair = (size_t)(L.glv ? 2 * sh.nwin : sh.nwin);
+  const size_t E_max = n * windows_per_pair, E_alloc = n_alloc * windows_per_pair;
   // (the generic layout has twice the entries per pair: measured at 4096 pairs it is 5 % slower on this path, the commit 14 % faster)
   static const int env_scan = tune_int("MZK_SMALL_SCAN", 1);     // 0: A/B against the sorted path
   static const int env_scan_log = tune_int("MZK_SCAN_MAX_LOG", 14);
   const bool scan_ok = one_set && env_scan != 0 && n <= ((size_t)1 << env_scan_log) && (L.c == 8 || (L.c >= 10 && L.c <= 13));
-  if ((scan_ok || n < (L.merged ? SMALL_MAX_N : SMALL_MAX_N - 1)) && NB <= SMALL_MAX_BUCKETS) {
+  if (!cc && (scan_ok || n < (L.merged ? SMALL_MAX_N : SMALL_MAX_N - 1)) && NB <= SMALL_MAX_BUCKETS) {
     u32 *offsets, *entries, *buckets, *wsum;
     MZK_TRY(ws_get(WS_MSM_OFFSETS, (NB + 1) * 4, (void**)&offsets));
     MZK_TRY(ws_get(WS_MSM_ENTRIES, E_max * 4, (void**)&entries));
@@ -1870,7 +1878,10 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   size_t NBtot = NB;
   if (L.glv && (NB & (NB - 1)) != 0 && sh.c >= 17) { NBtot = 1; while (NBtot < NB) NBtot <<= 1; }
   MZK_TRY(ws_get(WS_MSM_COUNTS, 2 * NBtot * 4, (void**)&counts));      // (two-level sort, scan-free form: per-bucket totals + cursors)
-  MZK_TRY(ws_get(WS_MSM_OFFSETS, (NBtot + 1) * 4, (void**)&offsets));
+  // per-chunk buffers (chunk mode: cK of each, one behind the other; the sort's scratch is shared -- the chunks' sorts run one after
+  // the other on one stream, and nothing after a chunk's sort reads it)
+  MZK_TRY(ws_get(WS_MSM_OFFSETS, (size_t)cK * (NBtot + 1) * 4, (void**)&offsets));
+  offsets += (size_t)ck * (NBtot + 1);
   // (small inputs keep the one-pass kernels, except that the merged one-pass histogram must fit the LDS: 2^15 buckets)
   // coarse bins: 256, or 1024 for the 20-bit merged layout (2^19 buckets: 512 per bin instead of 2048; k_coarse_count)
   static const int env_cl20 = tune_int("MZK_COARSE_LOG_20", 10);      // tuning build: 8 = the 256-bin form at 20 bits too
@@ -1889,12 +1900,31 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   const size_t cbins = (size_t)1 << cl;
   const bool two_level = (NBtot & (NBtot - 1)) == 0 && NBtot >= 4096 && (NBtot / cbins) <= (size_t)FINE_MAX &&
                          (n >= 4096 || ((point_kind & 0xff) == 2 && NBtot > ((size_t)1 << 15)));
-  MZK_TRY(ws_get(WS_MSM_CURSOR, E_max * (two_level ? 8 : 4), (void**)&ranks));
-  MZK_TRY(ws_get(WS_MSM_ENTRIES, E_max * 4, (void**)&entries));
+  if (cc && !two_level) { set_error("msm: chunk mode needs the two-level sort (layout %d bits, %zu buckets)", sh.c, NB); return MZK_E_ARG; }
+  MZK_TRY(ws_get(WS_MSM_CURSOR, E_alloc * (two_level ? 8 : 4), (void**)&ranks));
+  MZK_TRY(ws_get(WS_MSM_ENTRIES, (size_t)cK * E_alloc * 4, (void**)&entries));
+  entries += (size_t)ck * E_alloc;
   MZK_TRY(ws_get(WS_MSM_SCAN, scan_scratch_words(NB) * 4, (void**)&scan_tmp));
-  MZK_TRY(ws_get(WS_MSM_BUCKETS, NB * 128, (void**)&buckets));
-  MZK_TRY(ws_get(WS_MSM_SLOTS, nslots * SLOT_WORDS * 4 + heavy_words * 4, (void**)&slots));
+  MZK_TRY(ws_get(WS_MSM_BUCKETS, (size_t)cK * NB * 128, (void**)&buckets));
+  buckets += (size_t)ck * NB * 32;
+  // (a chunk never has more segments than resident lanes, nor than entries / 16: the slot region of every chunk is sized for that)
+  const size_t T_cap = cc ? ((resident_lanes + 1 < E_alloc / 16 + 1) ? resident_lanes + 1 : E_alloc / 16 + 1) : T;
+  const size_t nslots_cap = T_cap + NB + 1, heavy_words_cap = heavy_total_words((T_cap + NB) / HEAVY_SLOTS + 1);
+  const size_t slot_region_words = (nslots_cap * SLOT_WORDS + heavy_words_cap + 3) & ~(size_t)3;
+  MZK_TRY(ws_get(WS_MSM_SLOTS, (size_t)cK * slot_region_words * 4, (void**)&slots));
+  slots += (size_t)ck * slot_region_words;
   u32* heavy = slots + nslots * SLOT_WORDS;
+  // the digit sort runs on `ss`: behind everything the main stream has enqueued so far (the workspace's previous users), and the
+  // accumulate on the main stream behind it
+  if (ss != s) {
+    hipEvent_t ev;
+    MZK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    const hipError_t e1 = hipEventRecord(ev, s), e2 = (e1 == hipSuccess) ? hipStreamWaitEvent(ss, ev, 0) : e1;
+    (void)hipEventDestroy(ev);
+    MZK_HIP(e2);
+  }
+  hipStream_t s_main = s;
+  s = ss;              // (the sort phase below is written against `s`)
   prof_begin(s, MZK_PH_MSM_SORT);
   // every slot k_seg_combine reads is written by k_seg_accumulate first (slot t + b exists exactly when segment t
   // overlaps bucket b; checked by poisoning the array under the whole GPU suite), so only the heavy-bucket counter
@@ -1922,18 +1952,23 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     const size_t fine_wgs = cbins * (size_t)S + (E_max + slice_cap - 1) / slice_cap + 1;
     const size_t n_coarse = cbins * nwg, n_fine = (size_t)F * fine_wgs;
     u32 *binhist, *finehist;
-    MZK_TRY(ws_get(WS_MSM_WGHIST, (n_coarse + 1 + n_fine + 1 + cbins + 1) * 4, (void**)&binhist));
-    finehist = binhist + n_coarse + 1;
+    // (chunk mode: sized for the largest chunk, the same request in every chunk's call)
+    const size_t nwg_a = (n_alloc + COARSE_PER_WG - 1) / COARSE_PER_WG, n_coarse_a = cbins * nwg_a;
+    const size_t slice_nom_a = (E_alloc + cbins * (size_t)64 - 1) / (cbins * (size_t)64);      // (S <= 64: the smallest nominal slice)
+    const size_t fine_wgs_a = cc ? cbins * 64 + (E_alloc + slice_nom_a) / (slice_nom_a + slice_nom_a / 2 + 1) + 2 : fine_wgs;
+    const size_t n_fine_a = cc ? (size_t)F * fine_wgs_a : n_fine;
+    MZK_TRY(ws_get(WS_MSM_WGHIST, ((cc ? n_coarse_a : n_coarse) + 1 + n_fine_a + 1 + cbins + 1) * 4, (void**)&binhist));
+    finehist = binhist + (cc ? n_coarse_a : n_coarse) + 1;
     const size_t sb_f = (n_fine + SCAN_BLOCK - 1) / SCAN_BLOCK;
     u32* scan2;
-    MZK_TRY(ws_get(WS_MSM_SCAN, (scan_scratch_words(n_coarse) + scan_scratch_words(n_fine) + 4) * 4, (void**)&scan2));
+    MZK_TRY(ws_get(WS_MSM_SCAN, (scan_scratch_words(cc ? n_coarse_a : n_coarse) + scan_scratch_words(n_fine_a) + 4) * 4, (void**)&scan2));
     // scan-free sort (k_coarse_count, k_fine_scatter): no global scan at either level, nine launches -> five
     static const int env_scan_free = tune_int("MZK_SORT_SCAN_FREE", 3);       // tuning build: bit 0 = coarse level, bit 1 = fine level
     const bool coarse_free = (env_scan_free & 1) != 0 && cbins <= (size_t)SORT_CTR_BINS;
     const bool fine_free = (env_scan_free & 2) != 0 && F <= STAGE_F_MAX;
     u32* bin_tot = coarse_free ? heavy + SORT_CTR_AT : nullptr;
     u32* bin_cur = coarse_free ? heavy + SORT_CTR_AT + SORT_CTR_BINS : nullptr;
-    u32* bin_start = coarse_free ? finehist + n_fine + 1 : nullptr;
+    u32* bin_start = coarse_free ? finehist + n_fine_a + 1 : nullptr;
     u32* bucket_tot = fine_free ? counts : nullptr;                          // (counts: 2 NB words, see above)
     u32* bucket_cur = fine_free ? counts + NBtot : nullptr;
     u32* zero_ptr = fine_free ? counts : nullptr;
@@ -1955,7 +1990,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
     // largest point reference: merged nwin * stride, generic phi_offset + n
     const size_t ref_max = L.merged ? (size_t)msm_table_rows(sh.c, L.sets) * table_stride : L.phi_offset + n;
     const bool compact = ref_max <= ((size_t)1 << (31 - fb));      // references are < ref_max
-    SortArgs sa{(const u32*)d_scalars, n, L, key_shift, fine_mask, fb, binhist, nwg, (void*)ranks, F, S, finehist, scan2 + scan_scratch_words(n_coarse) + 2, sb_f, n_fine,
+    SortArgs sa{(const u32*)d_scalars, n, L, key_shift, fine_mask, fb, binhist, nwg, (void*)ranks, F, S, finehist, scan2 + scan_scratch_words(cc ? n_coarse_a : n_coarse) + 2, sb_f, n_fine,
                 offsets, entries, NBtot, (unsigned)fine_wgs, (u32)slice_cap, cl, bin_tot, bin_cur, bin_start, bucket_tot, bucket_cur};
     MZK_TRY(compact ? sort_records<Rec4>(sa, s) : sort_records<Rec8>(sa, s));
   } else if (L.merged) {
@@ -1986,6 +2021,14 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   }
   MZK_HIP(hipGetLastError());
   prof_end(s, MZK_PH_MSM_SORT);
+  if (s != s_main) {       // the accumulate (main stream) behind this chunk's sort
+    hipEvent_t ev;
+    MZK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    const hipError_t e1 = hipEventRecord(ev, s), e2 = (e1 == hipSuccess) ? hipStreamWaitEvent(s_main, ev, 0) : e1;
+    (void)hipEventDestroy(ev);
+    MZK_HIP(e2);
+  }
+  s = s_main;
   MZK_TRY(prepare());
   prof_begin(s, MZK_PH_MSM_ACCUMULATE);
   // the true entry count lives in offsets[NB] on the device; lanes past it exit (E_max bounds it)
@@ -2005,10 +2048,70 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   hipLaunchKernelGGL(k_seg_combine_heavy, dim3(HEAVY_GRID), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)offsets, buckets, heavy, max_heavy);
   MZK_HIP(hipGetLastError());
   prof_end(s, MZK_PH_MSM_SEG_COMBINE);
+  if (cc) return MZK_OK;        // chunk mode: msm_chunked_impl sums the chunks' bucket arrays and reduces once
 
   u32* wsum;
   MZK_TRY(ws_get(WS_MSM_OUT, (size_t)MAX_WINDOWS * 128, (void**)&wsum));
   MZK_TRY(reduce_bucket_sets(buckets, sh.lgB, red_windows, one_set, horner_c, wsum, (u32*)d_out, out_partial_xyzz, s));
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
+}
+
+// ---- one MSM in chunks -------------------------------------------------------------------------------------------------------------
+// buckets[b] += buckets[k NB + b], k = 1 .. K-1 (one lane per bucket)
+__global__ __launch_bounds__(128) void k_fold_bucket_sets(u32* __restrict__ buckets, size_t NB, int K) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= NB) return;
+  Xyzz acc = xyzz_gload(buckets, b);
+  for (int k = 1; k < K; k++) acc = xyzz_add_with<FeAsm>(acc, xyzz_gload(buckets, (size_t)k * NB + b));
+  xyzz_gstore(buckets, b, acc);
+}
+// Chunk mode covers the layouts of the large calls: window tables with one bucket set, and the generic GLV layout -- from 2^18 pairs on
+// (every chunk must take the two-level sort and keep the accumulate's lanes busy).
+bool msm_chunkable(size_t n_total, int point_kind) {
+  const int kind = point_kind & 0xff, sets = ((point_kind >> 16) & 0xff) ? ((point_kind >> 16) & 0xff) : 1;
+  return n_total >= ((size_t)1 << 18) && (kind != MSM_PTS_TABLES || sets == 1);
+}
+// Sum over the chunks' pairs = the MSM of all n_total pairs (polynomial.rs:156-165 is a sum over independent pairs; the bucket sums
+// are too).  chunks[k].d_scalars: that chunk's scalars on the device; d_points: the WHOLE point array / table set.  A chunk is sorted
+// (on sort_stream if given -- then chunk k + 1's sort may run under chunk k's accumulate) and accumulated as soon as its `ready`
+// event has fired: the host-buffer entry points upload chunk k + 1 meanwhile.  Same canonical affine point as the one-piece call.
+int msm_chunked_impl(const MsmChunk* chunks, int K, const void* d_points, size_t n_total, int point_kind, size_t table_stride, void* d_out,
+                     bool out_partial_xyzz, hipStream_t s, hipStream_t sort_stream, const std::function<int(int)>* before_chunk) {
+  if (!chunks || K < 1 || K > 8 || !d_out || !d_points) { set_error("msm_chunked: bad argument"); return MZK_E_ARG; }
+  size_t n_alloc = 0, covered = 0;
+  for (int k = 0; k < K; k++) {
+    if (chunks[k].i0 != covered) { set_error("msm_chunked: chunks must be consecutive"); return MZK_E_ARG; }
+    covered += chunks[k].n;
+    n_alloc = chunks[k].n > n_alloc ? chunks[k].n : n_alloc;
+  }
+  if (covered != n_total || !msm_chunkable(n_total, point_kind)) { set_error("msm_chunked: chunks do not cover a chunkable problem"); return MZK_E_ARG; }
+  for (int k = 0; k < K; k++) {
+    // before_chunk(k): the caller brings chunk k's inputs onto the device (a host-buffer entry point copies them here, blocking the
+    // host while the GPU works on chunk k - 1) and records chunks[k].ready
+    if (before_chunk) MZK_TRY((*before_chunk)(k));
+    if (chunks[k].ready) MZK_HIP(hipStreamWaitEvent(sort_stream ? sort_stream : s, chunks[k].ready, 0));
+    if (chunks[k].ready && sort_stream && (point_kind & 0xff) == MSM_PTS_PLAIN) MZK_HIP(hipStreamWaitEvent(s, chunks[k].ready, 0));     // the points are read on the main stream
+    const MsmChunkCtx cc{k, K, chunks[k].i0, n_total, n_alloc, sort_stream};
+    MZK_TRY(msm_dev_impl(chunks[k].d_scalars, d_points, chunks[k].n, point_kind, table_stride, d_out, out_partial_xyzz, s, nullptr, &cc));
+  }
+  // the layout every chunk used (msm_dev_impl derives the same from n_total)
+  const int kind = point_kind & 0xff;
+  const int table_c = ((point_kind >> 8) & 0xff) ? ((point_kind >> 8) & 0xff) : 16;
+  const bool merged = kind == MSM_PTS_TABLES;
+  MsmShape sh = merged ? choose_shape(n_total) : choose_shape_glv(n_total);
+  if (merged) { sh.c = table_c; sh.nwin = msm_table_windows(table_c); sh.lgB = sh.c - 1; sh.nbuckets = (size_t)1 << sh.lgB; }
+  const size_t NB = sh.nbuckets;
+  u32 *buckets, *wsum;
+  MZK_TRY(ws_get(WS_MSM_BUCKETS, (size_t)K * NB * 128, (void**)&buckets));       // (the chunks' request: same size, same buffer)
+  MZK_TRY(ws_get(WS_MSM_OUT, (size_t)MAX_WINDOWS * 128, (void**)&wsum));
+  if (K > 1) {
+    prof_begin(s, MZK_PH_MSM_SEG_COMBINE);
+    hipLaunchKernelGGL(k_fold_bucket_sets, dim3((unsigned)((NB + 127) / 128)), dim3(128), 0, s, buckets, NB, K);
+    MZK_HIP(hipGetLastError());
+    prof_end(s, MZK_PH_MSM_SEG_COMBINE);
+  }
+  MZK_TRY(reduce_bucket_sets(buckets, sh.lgB, merged ? 1 : sh.nwin, merged, merged ? 0 : sh.c, wsum, (u32*)d_out, out_partial_xyzz, s));
   MZK_HIP(hipGetLastError());
   return MZK_OK;
 }

@@ -250,3 +250,41 @@ def test_wide_sort_records_above_2pow20(mz):
     h = mz.Srs(srs)
     assert h.commit(s) == want
     h.close()
+
+
+@pytest.mark.parametrize("n", [5, (1 << 18), (1 << 20) - 12345])
+def test_host_buffer_calls_in_pieces_equal_the_resident_calls(mz, n):
+    """commit_kzg(&poly, &pk) hands over host Vecs (kzg.rs:57-59), so the host-buffer entry points upload their
+    inputs in pieces and sort / accumulate a piece while the next one crosses PCIe (msm_chunked_impl: per-piece bucket arrays, summed
+    and reduced once).  From 2^18 pairs on; below that one piece as before.  A ragged size, the smallest chunked size and a tiny one
+    through both entry points against the device-resident calls on the same pairs (bit-identical) and the oracle's Pippenger."""
+    import ctypes
+    import torch
+    L, dev = mz.lib(), torch.device("cuda", 0)
+    L.mzk_last_error.restype = ctypes.c_char_p
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    sc = torch.empty(n * 4, dtype=torch.int64, device=dev)
+    pt = torch.empty(n * 8, dtype=torch.int64, device=dev)
+    assert L.mzk_synth_field_dev(0, ctypes.c_uint64(7100 + n % 97), ctypes.c_size_t(n), ctypes.c_void_p(sc.data_ptr()), st) == 0
+    assert L.mzk_synth_g1_points_dev(ctypes.c_uint64(7200 + n % 97), ctypes.c_size_t(n), ctypes.c_void_p(pt.data_ptr()), st) == 0
+    out = torch.zeros(16, dtype=torch.int64, device=dev)
+    assert L.mzk_msm_g1_bn254_dev(ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(pt.data_ptr()), ctypes.c_size_t(n), ctypes.c_void_p(out.data_ptr()), st) == 0
+    h = ctypes.c_void_p()
+    assert L.mzk_srs_from_device(ctypes.c_void_p(pt.data_ptr()), ctypes.c_size_t(n), ctypes.byref(h), st) == 0
+    assert L.mzk_kzg_commit_srs_dev(h, ctypes.c_void_p(sc.data_ptr()), ctypes.c_size_t(n), ctypes.c_void_p(out.data_ptr() + 64), 0, st) == 0
+    torch.cuda.synchronize()
+    hs = sc.cpu().numpy().view(np.uint64).reshape(n, 4).copy()
+    hp = pt.cpu().numpy().view(np.uint64).reshape(n, 8).copy()
+    want = orc.msm_fast(hs, hp)
+    res = mz.array_to_points(out.cpu().numpy().view(np.uint64).reshape(2, 8))
+    assert res[0] == want and res[1] == want
+    assert mz.msm_g1(hs, hp) == want, "host-buffer MSM"
+    got = np.zeros((1, 8), dtype=np.uint64)
+    for _ in range(2):          # twice: the second call reuses every workspace slot of the first
+        assert L.mzk_kzg_commit_srs(h, hs.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n), got.ctypes.data_as(ctypes.c_void_p)) == 0, L.mzk_last_error()
+        assert mz.array_to_points(got)[0] == want, "host-scalar commit"
+    # a prefix of the coefficients against the same handle (n smaller than the SRS: the pieces follow n, the table rows the handle)
+    m = n - n // 3
+    assert L.mzk_kzg_commit_srs(h, hs.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(m), got.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert mz.array_to_points(got)[0] == orc.msm_fast(hs[:m], hp[:m])
+    L.mzk_srs_free(h)
