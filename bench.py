@@ -645,16 +645,13 @@ def timed(B, step, K, W, price_mask=0, priced_in_timed_region=True):
 
 
 def leg_clock_under_load(B, step, card):
-    """The shader clock while the headline step runs: a further, UNTIMED pass of the same step, sysfs sampled from the host
-    between enqueues (reading sysfs is no HIP call).  None when the card's sysfs node is not visible from here."""
-    if card is None:
-        return None
+    """The shader clock while the headline step runs: a further, UNTIMED pass of the same step (160 steps on every rank), sysfs sampled
+    from the host between enqueues (reading sysfs is no HIP call).  None when the card's sysfs node is not visible from here."""
     samples = []
-    t_end = time.perf_counter() + 0.25
-    while time.perf_counter() < t_end:
+    for _ in range(40):                  # a FIXED number of steps: the step may hold a collective, every rank must run as many as the others
         for _ in range(4):
             step()
-        v = sclk_now_mhz(card)
+        v = sclk_now_mhz(card) if card is not None else None
         if v:
             samples.append(v)
         B.torch.cuda.synchronize()
@@ -1158,7 +1155,8 @@ def leg_extra_sizes(B):
 def leg_e2e_kzg(B):
     """BASELINE configs[4]: end-to-end KZG at degree 2^e2e, 1 vs N GPUs.  evaluations -> iNTT -> setup(alpha) -> commit ->
     open(u).  Strong scaling over the N ranks of this job: the (cheap) iNTT is replicated, rank g builds SRS powers [lo, hi),
-    runs the MSMs of its slice of the coefficient / quotient vectors, partials are all-gathered (2 x N x 128 B) and folded."""
+    commits its slice of the coefficients, computes ITS slice of the quotient (one 32-byte value per rank exchanged:
+    sharded.sharded_open_quotient) and commits that; the partials are all-gathered (2 x N x 128 B) and folded."""
     torch, L, mz, orc, np, args, dev, stream, rank, world, sharded = B.torch, B.L, B.mz, B.orc, B.np, B.args, B.dev, B.stream, B.rank, B.world, B.sharded
     lg = args.e2e_log2n
     nn = 1 << lg
@@ -1174,14 +1172,13 @@ def leg_e2e_kzg(B):
     try:
         ev = torch.empty(nn * 4, dtype=torch.int64, device=dev)
         cf = torch.empty(nn * 4, dtype=torch.int64, device=dev)
-        qq = torch.zeros(nn * 4, dtype=torch.int64, device=dev)
         sp = torch.empty((hi - lo) * 8, dtype=torch.int64, device=dev)
-        yv = torch.zeros(4, dtype=torch.int64, device=dev)
         check(B, L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(SEED + 555), ctypes.c_size_t(nn), dptr(ev), stream))
         rt = mz.to_limbs([mz.root_of_unity(mz.FIELD_FR, lg)], 4)
         alpha = orc.from_limbs(orc.synth_vector(orc.FR, SEED + 556, 1))[0]
         uu = orc.from_limbs(orc.synth_vector(orc.FR, SEED + 557, 1))[0]
-        a_l, u_l, g_l = mz.to_limbs([alpha], 4), mz.to_limbs([uu], 4), mz.points_to_array([(1, 2)])
+        a_l, g_l = mz.to_limbs([alpha], 4), mz.points_to_array([(1, 2)])
+        open_ops, y_host, keep_q = sharded.DeviceOpenOps(), [None], [None]
 
         def stage(name, fn, record):
             # every rank runs the same barriers and the same collective failure check per stage: a rank that
@@ -1223,9 +1220,10 @@ def leg_e2e_kzg(B):
             stage("commit_local", lambda: check(B, L.mzk_kzg_commit_srs_dev(hh, off(cf, lo, 4), ctypes.c_size_t(hi - lo), dptr(rec_c), ctypes.c_int(1), stream)), record)
 
             def open_local():
-                check(B, L.mzk_kzg_open_quotient_dev(dptr(cf), ctypes.c_size_t(nn), u_l.ctypes.data_as(ctypes.c_void_p), dptr(yv), dptr(qq), stream))
-                qhi = min(hi, nn - 1)
-                check(B, L.mzk_kzg_commit_srs_dev(hh, off(qq, lo, 4), ctypes.c_size_t(max(qhi - lo, 0)), dptr(rec_w), ctypes.c_int(1), stream))
+                # the quotient sharded like everything else (sharded.sharded_open_quotient): this rank's slice from ITS coefficients, one
+                # 32-byte value per rank gathered; y = f(u) comes out of the same exchange
+                y_host[0], qs = sharded.sharded_open_quotient(open_ops, cf[lo * 4:hi * 4], nn, uu, orc.P_FR, rank, world)
+                check(B, L.mzk_kzg_commit_srs_dev(hh, dptr(qs), ctypes.c_size_t(hi - lo), dptr(rec_w), ctypes.c_int(1), stream))
             stage("open_local", open_local, record)
         # the two MSMs of a proof are independent: commit on context 0, open (quotient + its MSM) on context 1 of the same
         # GPU at the same time -- the sort and the latency-bound tails of one run under the accumulation of the other
@@ -1234,12 +1232,14 @@ def leg_e2e_kzg(B):
         L.mzk_ctx_stream.restype = ctypes.c_void_p
         s1 = ctypes.c_void_p(L.mzk_ctx_stream(1))
 
+        open_ops1 = sharded.DeviceOpenOps(stream=s1.value)
+
         def commit_and_open():
             mz.ctx_select(1)
             try:
-                check(B, L.mzk_kzg_open_quotient_dev(dptr(cf), ctypes.c_size_t(nn), u_l.ctypes.data_as(ctypes.c_void_p), dptr(yv), dptr(qq), s1))
-                qhi = min(hi, nn - 1)
-                check(B, L.mzk_kzg_commit_srs_dev(hh, off(qq, lo, 4), ctypes.c_size_t(max(qhi - lo, 0)), dptr(rec_w2), ctypes.c_int(1), s1))
+                _, qs1 = sharded.sharded_open_quotient(open_ops1, cf[lo * 4:hi * 4], nn, uu, orc.P_FR, rank, world)
+                keep_q[0] = qs1          # (alive until the stage's synchronize: the MSM reads it on s1)
+                check(B, L.mzk_kzg_commit_srs_dev(hh, dptr(qs1), ctypes.c_size_t(hi - lo), dptr(rec_w2), ctypes.c_int(1), s1))
             finally:
                 mz.ctx_select(0)
             check(B, L.mzk_kzg_commit_srs_dev(hh, off(cf, lo, 4), ctypes.c_size_t(hi - lo), dptr(rec_c2), ctypes.c_int(1), stream))
@@ -1275,7 +1275,7 @@ def leg_e2e_kzg(B):
             oc = fin.cpu().numpy().view(np.uint64)
             cf_cpu = cf.cpu().numpy().view(np.uint64).reshape(-1, 4)
             fa = orc.poly_eval(orc.FR, cf_cpu, alpha)
-            yy = mz.from_limbs(yv.cpu().numpy().view(np.uint64).reshape(1, 4))[0]
+            yy = y_host[0]
             qa = (fa - yy) * pow(alpha - uu, -1, orc.P_FR) % orc.P_FR
             okc = mz.array_to_points(oc[:8])[0] == orc.ec_mul(0, (1, 2), fa)
             oky = yy == orc.poly_eval(orc.FR, cf_cpu, uu)
@@ -1628,7 +1628,7 @@ def main():
     T = {}
     T["msm"] = timed(B, lambda: msm_step(B), K, W, 1 << PH_ACC)
     T["srs"] = timed(B, lambda: srs_step(B), K, W, 1 << PH_ACC)
-    clock_under_load = leg_clock_under_load(B, lambda: srs_step(B), card) if rank == 0 else None
+    clock_under_load = leg_clock_under_load(B, lambda: srs_step(B), card)       # (every rank: the step holds the gather)
     if B.all_legs:
         T["ntt"] = timed(B, lambda: ntt_step(B), K, W, 1 << PH_NTT_TOTAL, priced_in_timed_region=False)
         T["nttm"] = timed(B, lambda: ntt_m128_step(B), K, W, 1 << PH_NTT_TOTAL, priced_in_timed_region=False)

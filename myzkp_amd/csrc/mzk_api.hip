@@ -606,13 +606,9 @@ static int side_stream(hipStream_t* side, hipEvent_t* fork, hipEvent_t* join) {
 // rounded to whole sort workgroups (4096 pairs).
 static int host_chunk_plan(size_t n, const char* env_name, const int* dflt, int dflt_count, mzk::MsmChunk* ch) {
   int cuts[8], K = 0;
-#ifdef MZK_TUNING
-  if (const char* v = getenv(env_name)) {
+  if (const char* v = mzk::tune_str(env_name)) {           // (tuning build only: null in the shipped library)
     for (const char* p = v; *p && K < 8;) { cuts[K++] = atoi(p); while (*p && *p != ',') p++; if (*p == ',') p++; }
   }
-#else
-  (void)env_name;
-#endif
   if (K == 0) for (; K < dflt_count; K++) cuts[K] = dflt[K];
   size_t prev = 0;
   int out = 0;

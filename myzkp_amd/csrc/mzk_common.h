@@ -21,9 +21,10 @@ namespace mzk {
 // is the constant default, and the kernels only a non-default switch can reach are not compiled at all.
 #ifdef MZK_TUNING
 #include <stdlib.h>
-static inline int tune_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static inline int tune_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; } static inline const char* tune_str(const char* name) { return getenv(name); }
 #else
 static inline constexpr int tune_int(const char*, int dflt) { return dflt; }
+static inline constexpr const char* tune_str(const char*) { return nullptr; }
 #endif
 
 // ---- error plumbing ------------------------------------------------------------------------------

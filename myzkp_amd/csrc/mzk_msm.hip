@@ -1138,23 +1138,47 @@ __global__ __launch_bounds__(128) void k_seg_combine_wide(const u32* __restrict_
   }
   xyzz_gstore(buckets, b, acc);
 }
+// the same point held by the lane `dist` lanes away (every lane of a quad holds its quad's whole point)
+__device__ __forceinline__ Xyzz xyzz_from_lane_xor(const Xyzz& p, int dist) {
+  Xyzz r;
+#pragma unroll
+  for (int i = 0; i < FqParams::L; i++) {
+    r.X.l[i] = (u32)__shfl_xor((int)p.X.l[i], dist, 64); r.Y.l[i] = (u32)__shfl_xor((int)p.Y.l[i], dist, 64);
+    r.ZZ.l[i] = (u32)__shfl_xor((int)p.ZZ.l[i], dist, 64); r.ZZZ.l[i] = (u32)__shfl_xor((int)p.ZZZ.l[i], dist, 64);
+  }
+  return r;
+}
+// QPB DPP quads per bucket (1, 2 or 4).  A bucket's partials form a serial chain of additions, so the quad-cooperative addition
+// cuts the kernel's latency (the quad also splits the 128-byte records).  With one quad per bucket the chain is as long as the
+// bucket has partials -- five at 2^20 merged, but nine in a grid-batched pass of 64 x 2^12 coefficients, whose 32768 buckets
+// fill only two waves per SIMD: there QPB adjacent quads take every QPB-th partial each and fold their sums through shuffles
+// (chain of 9 -> 5 + 1 at QPB = 2, 3 + 2 at QPB = 4; the host picks QPB so that the grid stays within four waves per SIMD).
+template <int QPB>
 __global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slots, const u32* __restrict__ offsets, u32* __restrict__ buckets,
                                                       size_t nbuckets, u32 seg_host, u32* __restrict__ heavy, const u32* __restrict__ tails, int lg_nb, u32 t_max) {
-  // one DPP quad per bucket: a bucket's partials form a serial chain of additions (about nine at 2^20 merged),
-  // so the quad-cooperative addition cuts the kernel's latency; the quad also splits the 128-byte records.
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t b = tid >> 2;
-  const int lane = (int)(tid & 3);
-  if (b >= nbuckets) return;
+  const size_t b = tid / (4 * QPB);
+  const int lane = (int)(tid & 3), q = (int)((tid >> 2) % QPB);
+  if (b >= nbuckets) return;                         // (a bucket's QPB quads are adjacent lanes of one wave: uniform for the shuffles below)
   const u32 seg = segment_length(seg_host, t_max, offsets[nbuckets]);
   if (tid == 0) heavy[1] = seg;                      // k_seg_combine_heavy reads it there
   const u32 o0 = offsets[b], o1 = bucket_end(offsets, tails, lg_nb, b);
   Xyzz acc = xyzz_inf();
   if (o1 > o0) {
     const size_t s0 = (size_t)(o0 / seg) + b, s1 = (size_t)((o1 - 1) / seg) + b;
-    if (defer_heavy(b, s0, s1, o1, heavy, lane == 0, tails ? HEAVY_SLOTS_SORT1 : HEAVY_SLOTS)) return;       // quad-uniform
-    acc = xyzz_gload_raw_quad(slots, s0, lane);
-    for (size_t sl = s0 + 1; sl <= s1; sl++) acc = xyzz_add_quad(acc, xyzz_gload_raw_quad(slots, sl, lane), lane);
+    if (defer_heavy(b, s0, s1, o1, heavy, lane == 0 && q == 0, tails ? HEAVY_SLOTS_SORT1 : HEAVY_SLOTS)) return;       // uniform over the bucket's quads
+    if (QPB == 1) {
+      acc = xyzz_gload_raw_quad(slots, s0, lane);
+      for (size_t sl = s0 + 1; sl <= s1; sl++) acc = xyzz_add_quad(acc, xyzz_gload_raw_quad(slots, sl, lane), lane);
+    } else {
+      for (size_t sl = s0 + q; sl <= s1; sl += QPB) acc = xyzz_add_quad(acc, xyzz_gload_raw_quad(slots, sl, lane), lane);
+    }
+  }
+  if (QPB > 1) {
+    // (all lanes of the bucket's quads are here, empty buckets included: the shuffles see active partners)
+    acc = xyzz_add_quad(acc, xyzz_from_lane_xor(acc, 4), lane);
+    if (QPB > 2) acc = xyzz_add_quad(acc, xyzz_from_lane_xor(acc, 8), lane);
+    if (q != 0) return;
   }
   xyzz_gstore_quad(buckets, b, acc, lane);
 }
@@ -2044,7 +2068,7 @@ int msm_dev_impl(const void* d_scalars, const void* d_points, size_t n, int poin
   if (NB >= ((size_t)1 << wide_min_log))
     hipLaunchKernelGGL(k_seg_combine_wide, dim3((unsigned)((NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy, t_max);
   else
-    hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy, (const u32*)nullptr, 0, t_max);
+    hipLaunchKernelGGL(k_seg_combine<1>, dim3((unsigned)((4 * NB + 127) / 128)), dim3(128), 0, s, slots, offsets, buckets, NB, seg, heavy, (const u32*)nullptr, 0, t_max);
   hipLaunchKernelGGL(k_seg_combine_heavy, dim3(HEAVY_GRID), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)offsets, buckets, heavy, max_heavy);
   MZK_HIP(hipGetLastError());
   prof_end(s, MZK_PH_MSM_SEG_COMBINE);
@@ -2340,7 +2364,19 @@ int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size
                          slots, NBtot, seg, t_max);
     prof_end(s, MZK_PH_MSM_ACCUMULATE);
     prof_begin(s, MZK_PH_MSM_SEG_COMBINE);
-    hipLaunchKernelGGL(k_seg_combine, dim3((unsigned)((4 * NBtot + 127) / 128)), dim3(128), 0, s, slots, (const u32*)compact, buckets, NBtot, seg, heavy, (const u32*)tails, lgB, t_max);
+    // quads per bucket: as many as keep the grid within four waves per SIMD (2^16 quads), when a bucket has a chain worth splitting
+    // (profiles/round6_seg_combine_quads_per_bucket_ab.txt)
+    static const int env_qpb = tune_int("MZK_COMBINE_QPB", 0);          // tuning build: force 1 / 2 / 4
+    const size_t partials_per_bucket = (E_max / seg_sz + NBtot - 1) / NBtot + 1;
+    int qpb = (partials_per_bucket >= 6 && NBtot * 4 <= ((size_t)1 << 16)) ? 4 : (partials_per_bucket >= 6 && NBtot * 2 <= ((size_t)1 << 16)) ? 2 : 1;
+    if (env_qpb == 1 || env_qpb == 2 || env_qpb == 4) qpb = env_qpb;
+    const unsigned cgrid = (unsigned)((4 * (size_t)qpb * NBtot + 127) / 128);
+    if (qpb == 4)
+      hipLaunchKernelGGL(k_seg_combine<4>, dim3(cgrid), dim3(128), 0, s, slots, (const u32*)compact, buckets, NBtot, seg, heavy, (const u32*)tails, lgB, t_max);
+    else if (qpb == 2)
+      hipLaunchKernelGGL(k_seg_combine<2>, dim3(cgrid), dim3(128), 0, s, slots, (const u32*)compact, buckets, NBtot, seg, heavy, (const u32*)tails, lgB, t_max);
+    else
+      hipLaunchKernelGGL(k_seg_combine<1>, dim3(cgrid), dim3(128), 0, s, slots, (const u32*)compact, buckets, NBtot, seg, heavy, (const u32*)tails, lgB, t_max);
     hipLaunchKernelGGL(k_seg_combine_heavy, dim3(HEAVY_GRID), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)compact, buckets, heavy, max_heavy);
     MZK_HIP(hipGetLastError());
     prof_end(s, MZK_PH_MSM_SEG_COMBINE);

@@ -40,6 +40,83 @@ def sharded_msm(local_partial_fn, fold_fn):
     return fold_fn(all_gather_partials(local_partial_fn()))
 
 
+# ---- open_kzg sharded over the ranks: the quotient's suffix recurrence with ONE 32-byte value per rank exchanged ----------------------
+# kzg.rs:61-72: y = f(u), q = (f - y) / (X - u), w = MSM(q, powers).  q_{i-1} = b_i with b_i = c_i + u b_{i+1} (b_n = 0) runs over the
+# WHOLE coefficient vector; the rank that holds c[lo, hi) only needs b_hi from the ranks above it:
+#   1. value(g) = sum_t c[lo_g + t] u^t        -- local (ops.slice_value); what b_lo(g) would be if nothing followed the slice
+#   2. all-gather of the W values (32 bytes each)
+#   3. every rank, top slice down: b_lo(g) = value(g) + u^(hi_g - lo_g) * b_hi(g),  b_hi(g - 1) = b_lo(g);  y = b_lo(0) = f(u)
+#   4. q[lo_g .. hi_g) = b[lo_g + 1 .. hi_g]   -- local (ops.slice_quotient with carry b_hi(g)); the rank commits it against ITS powers
+# and the W witness partials are gathered and folded like every other sharded MSM.  Rounds 2-5 computed the whole quotient on every
+# rank (0.55 ms of the 2^22 end-to-end run that did not shrink with the number of GPUs).
+def all_gather_values(value_limbs):
+    """value_limbs: 1-D int64 tensor (4 limbs) -> (world, 4) on every rank; FORCE_COLLECTIVES as for all_gather_partials."""
+    return all_gather_partials(value_limbs)
+
+
+def open_carries(values, lens, u, modulus):
+    """values[g]: slice g as a polynomial at u; lens[g]: its length.  Returns (y, carries): carries[g] = b at the first index behind
+    slice g (0 for the top slice), y = f(u)."""
+    W = len(values)
+    carries, b = [0] * W, 0
+    for g in range(W - 1, -1, -1):
+        carries[g] = b
+        b = (values[g] + pow(u, lens[g], modulus) * b) % modulus
+    return b, carries
+
+
+def sharded_open_quotient(ops, coef_slice, n, u, modulus, rank, world):
+    """This rank's slice q[lo, hi) of open_kzg's quotient and y = f(u), from its slice c[lo, hi) of the n coefficients.
+    ops.slice_value(coef_slice, u) -> int;  ops.gather_values(int) -> list of the W ranks' ints;
+    ops.slice_quotient(coef_slice, u, carry) -> the slice of q (same length as the slice; the top rank's last element is b_n = 0)."""
+    lens = [shard_range(n, g, world)[1] - shard_range(n, g, world)[0] for g in range(world)]
+    values = ops.gather_values(ops.slice_value(coef_slice, u))
+    y, carries = open_carries(values, lens, u, modulus)
+    return y, ops.slice_quotient(coef_slice, u, carries[rank])
+
+
+class DeviceOpenOps:
+    """The local passes of sharded_open_quotient on the GPU (C ABI on torch's current stream) and the gather over the process group."""
+
+    def __init__(self, stream=None):
+        """stream: a raw HIP stream the local passes run on (default: torch's current stream).  The gather is torch's, on torch's
+        stream, so a pass on another stream is waited for before its value is handed on."""
+        import ctypes
+        import myzkp_amd as mz
+        self.ct, self.mz, self.L, self.stream = ctypes, mz, mz.lib(), stream
+
+    def _st(self):
+        return self.ct.c_void_p(self.stream if self.stream is not None else torch.cuda.current_stream().cuda_stream)
+
+    def _join(self):
+        if self.stream is not None:
+            torch.cuda.ExternalStream(self.stream).synchronize()
+
+    def _ok(self, rc):
+        if rc != 0:
+            raise self.mz.MzkError(rc, self.L.mzk_last_error().decode())
+
+    def slice_value(self, coef, u):
+        ul = self.mz.to_limbs([u], 4)
+        out = torch.zeros(4, dtype=torch.int64, device=coef.device)
+        self._ok(self.L.mzk_kzg_open_slice_value_dev(self.ct.c_void_p(coef.data_ptr()), self.ct.c_size_t(coef.numel() // 4), ul.ctypes.data_as(self.ct.c_void_p),
+                                                     self.ct.c_void_p(out.data_ptr()), self._st()))
+        self._join()
+        return out                       # stays on the device: the gather takes it from there
+
+    def gather_values(self, value):
+        import numpy as np
+        recs = all_gather_values(value)
+        return self.mz.from_limbs(recs.cpu().numpy().view(np.uint64).reshape(-1, 4))
+
+    def slice_quotient(self, coef, u, carry):
+        ul, cl = self.mz.to_limbs([u], 4), self.mz.to_limbs([carry], 4)
+        q = torch.empty_like(coef)
+        self._ok(self.L.mzk_kzg_open_slice_quotient_dev(self.ct.c_void_p(coef.data_ptr()), self.ct.c_size_t(coef.numel() // 4), ul.ctypes.data_as(self.ct.c_void_p),
+                                                        cl.ctypes.data_as(self.ct.c_void_p), self.ct.c_void_p(q.data_ptr()), self._st()))
+        return q
+
+
 # ---- one transform sharded over the ranks (SURVEY 8e: the four-step layout with an all-to-all) ---------------------------
 # n = W m points over W ranks (W a power of two, W^2 <= n), natural order in and out as in ntt.rs:7-64.  Two layouts of a
 # distributed vector:   "contiguous": rank r holds x[r m .. (r+1) m)          "cyclic": rank r holds x[r], x[r + W], ...

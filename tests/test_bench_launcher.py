@@ -176,3 +176,36 @@ def test_recorded_traffic_is_flagged_stale_when_the_kernel_sources_changed(tmp_p
     assert bench.traffic_is_stale(str(fresh), "msm") is False and bench.traffic_is_stale(str(fresh), "ntt") is False
     assert bench.traffic_is_stale(str(old), "msm") is True
     assert bench.traffic_is_stale(str(other), "msm") is True and bench.traffic_is_stale(str(other), "ntt") is False
+
+
+def test_no_collective_step_runs_on_one_rank_only():
+    """Round 6's first rehearsals hung for their whole timeout: the clock-under-load leg ran the headline step -- which holds an
+    all-gather when N > 1 -- under `if rank == 0`.  Static guard: inside bench.py no call of a function that may issue a collective
+    sits under a condition on `rank` (an `if` statement or a conditional expression)."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    collective = {"srs_step", "msm_step", "timed", "leg_e2e_kzg", "leg_strong_msm", "leg_strong_ntt", "leg_clock_under_load", "barrier_sync", "max_over_ranks",
+                  "all_gather_partials", "all_gather_values", "sharded_open_quotient", "ntt_sharded", "sharded_msm"}
+
+    def mentions_rank(node):
+        return any(isinstance(n, ast.Name) and n.id == "rank" or isinstance(n, ast.Attribute) and n.attr == "rank" for n in ast.walk(node))
+
+    def calls(node):
+        out = []
+        for n in ast.walk(node):
+            if isinstance(n, ast.Call):
+                f = n.func
+                name = f.id if isinstance(f, ast.Name) else (f.attr if isinstance(f, ast.Attribute) else None)
+                if name in collective:
+                    out.append((name, n.lineno))
+        return out
+
+    bad = []
+    for node in ast.walk(tree):
+        if isinstance(node, ast.If) and mentions_rank(node.test):
+            for part in node.body + node.orelse:
+                bad += calls(part)
+        if isinstance(node, ast.IfExp) and mentions_rank(node.test):
+            bad += calls(node.body) + calls(node.orelse)
+    assert not bad, "collective calls under a condition on the rank: %s" % bad

@@ -121,3 +121,43 @@ def test_sharded_end_to_end_on_one_gpu(world):
     assert commit == orc.ec_mul(0, (1, 2), fa)
     assert y == orc.poly_eval(FR, coef_cpu, u)
     assert w == orc.ec_mul(0, (1, 2), (fa - y) * pow(alpha - u, -1, P_FR) % P_FR)
+
+
+@pytest.mark.parametrize("n,world", [(1000, 3), (1 << 16, 8), (33, 2), (5, 4)])
+def test_sharded_open_quotient_equals_the_whole_quotient(n, world):
+    """the quotient of open_kzg (kzg.rs:61-72) computed slice by slice -- mzk_kzg_open_slice_value_dev, the top-down
+    carries (sharded.open_carries), mzk_kzg_open_slice_quotient_dev -- with all `world` ranks inside one process: the concatenated
+    slices are the quotient mzk_kzg_open_quotient_dev computes in one piece (followed by q[n-1] = b_n = 0), y is the same f(u), and
+    both equal the recurrence b_i = c_i + u b_{i+1} on Python integers."""
+    import torch
+    import myzkp_amd as mz
+    from myzkp_amd import sharded
+    mz.init(0)
+    L = mz.lib()
+    dev = torch.device("cuda", 0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    coef = torch.empty(n * 4, dtype=torch.int64, device=dev)
+    assert L.mzk_synth_field_dev(mz.FIELD_FR, ctypes.c_uint64(4100 + n % 89), ctypes.c_size_t(n), ctypes.c_void_p(coef.data_ptr()), st) == 0
+    u = orc.from_limbs(orc.synth_vector(FR, 4200 + n % 89, 1))[0]
+    u_l = mz.to_limbs([u], 4)
+    whole_y = torch.zeros(4, dtype=torch.int64, device=dev)
+    whole_q = torch.zeros(n * 4, dtype=torch.int64, device=dev)             # n - 1 elements written, the last stays 0 = b_n
+    assert L.mzk_kzg_open_quotient_dev(ctypes.c_void_p(coef.data_ptr()), ctypes.c_size_t(n), u_l.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(whole_y.data_ptr()),
+                                       ctypes.c_void_p(whole_q.data_ptr()), st) == 0, L.mzk_last_error().decode()
+    ops = sharded.DeviceOpenOps()
+    spans = [sharded.shard_range(n, g, world) for g in range(world)]
+    values = []
+    for lo, hi in spans:
+        v = ops.slice_value(coef[lo * 4:hi * 4], u)
+        values.append(mz.from_limbs(v.cpu().numpy().view(np.uint64).reshape(1, 4))[0])
+    y, carries = sharded.open_carries(values, [hi - lo for lo, hi in spans], u, P_FR)
+    parts = [ops.slice_quotient(coef[lo * 4:hi * 4], u, carries[g]) for g, (lo, hi) in enumerate(spans)]
+    torch.cuda.synchronize()
+    got_q = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=dev)
+    assert torch.equal(got_q, whole_q)
+    assert y == mz.from_limbs(whole_y.cpu().numpy().view(np.uint64).reshape(1, 4))[0]
+    c = orc.from_limbs(coef.cpu().numpy().view(np.uint64).reshape(n, 4))
+    b = [0] * (n + 1)
+    for i in range(n - 1, -1, -1):
+        b[i] = (c[i] + u * b[i + 1]) % P_FR
+    assert y == b[0] and orc.from_limbs(got_q.cpu().numpy().view(np.uint64).reshape(n, 4)) == b[1:]

@@ -106,6 +106,8 @@ def case_scale_columns():
 
 def case_msm():
     n = rng.choice([0, 1, 2, 3, 17, 100, 1000, 4095, 4096, 4097, 9000, 20000, rng.randrange(1, 30000), rng.randrange(1 << 15, 1 << 17)])
+    if rng.random() < 0.04:
+        n = rng.randrange(1 << 18, (1 << 18) + (1 << 16))                 # from 2^18 pairs on the host-buffer calls upload and compute in pieces (msm_chunked_impl)
     s = special_scalars(n)
     pts = orc.synth_points(rng.getrandbits(40), max(n, 1))[:n].copy()
     if n > 4:

@@ -12,7 +12,7 @@ echo "forced nccl rc=$?"; tail -c 400 $O/${T}_bench_forced_nccl_world1.json
 export MZK_BENCH_SHARED_GPU_TEST=1 MZK_BENCH_WATCHDOG_S=700
 for w in 2 4 8; do
   s=20; [ $w = 8 ] && s=24
-  timeout 1200 python bench.py --gpus $w --steps 3 --warmup 1 --log2n 18 --extra-sizes= --e2e-log2n 18 --strong-log2n $s --strong-ntt-log2n 20 --skip-cpu \
+  timeout 600 python bench.py --gpus $w --steps 3 --warmup 1 --log2n 18 --extra-sizes= --e2e-log2n 18 --strong-log2n $s --strong-ntt-log2n 20 --skip-cpu \
     --detail-file $O/${T}_rehearsal_world${w}_shared_gpu_detail.json > $O/${T}_rehearsal_world${w}_shared_gpu.json 2> $O/${T}_rehearsal_world${w}.err
   echo "rehearsal world $w rc=$?"
   tail -c 300 $O/${T}_rehearsal_world${w}_shared_gpu.json; echo
