@@ -1148,11 +1148,10 @@ __device__ __forceinline__ Xyzz xyzz_from_lane_xor(const Xyzz& p, int dist) {
   }
   return r;
 }
-// QPB DPP quads per bucket (1, 2 or 4).  A bucket's partials form a serial chain of additions, so the quad-cooperative addition
-// cuts the kernel's latency (the quad also splits the 128-byte records).  With one quad per bucket the chain is as long as the
-// bucket has partials -- five at 2^20 merged, but nine in a grid-batched pass of 64 x 2^12 coefficients, whose 32768 buckets
-// fill only two waves per SIMD: there QPB adjacent quads take every QPB-th partial each and fold their sums through shuffles
-// (chain of 9 -> 5 + 1 at QPB = 2, 3 + 2 at QPB = 4; the host picks QPB so that the grid stays within four waves per SIMD).
+// One DPP quad per bucket (QPB = 1: the shipped form).  A bucket's partials form a serial chain of additions, so the quad-cooperative
+// addition cuts the kernel's latency (the quad also splits the 128-byte records).  QPB = 2 / 4 -- adjacent quads take every QPB-th
+// partial each and fold their sums through shuffles, chain of 9 -> 5 + 1 / 3 + 2 in a grid-batched pass of 64 x 2^12 coefficients --
+// exist in the tuning build only: measured slower everywhere (see msm_many_dev_impl), the kernel is bound by its instruction count.
 template <int QPB>
 __global__ __launch_bounds__(128) void k_seg_combine(const u32* __restrict__ slots, const u32* __restrict__ offsets, u32* __restrict__ buckets,
                                                       size_t nbuckets, u32 seg_host, u32* __restrict__ heavy, const u32* __restrict__ tails, int lg_nb, u32 t_max) {
@@ -2364,18 +2363,19 @@ int msm_many_dev_impl(const void* d_scalars, size_t n, size_t stride_elems, size
                          slots, NBtot, seg, t_max);
     prof_end(s, MZK_PH_MSM_ACCUMULATE);
     prof_begin(s, MZK_PH_MSM_SEG_COMBINE);
-    // quads per bucket: as many as keep the grid within four waves per SIMD (2^16 quads), when a bucket has a chain worth splitting
-    // (profiles/round6_seg_combine_quads_per_bucket_ab.txt)
-    static const int env_qpb = tune_int("MZK_COMBINE_QPB", 0);          // tuning build: force 1 / 2 / 4
-    const size_t partials_per_bucket = (E_max / seg_sz + NBtot - 1) / NBtot + 1;
-    int qpb = (partials_per_bucket >= 6 && NBtot * 4 <= ((size_t)1 << 16)) ? 4 : (partials_per_bucket >= 6 && NBtot * 2 <= ((size_t)1 << 16)) ? 2 : 1;
-    if (env_qpb == 1 || env_qpb == 2 || env_qpb == 4) qpb = env_qpb;
-    const unsigned cgrid = (unsigned)((4 * (size_t)qpb * NBtot + 127) / 128);
-    if (qpb == 4)
-      hipLaunchKernelGGL(k_seg_combine<4>, dim3(cgrid), dim3(128), 0, s, slots, (const u32*)compact, buckets, NBtot, seg, heavy, (const u32*)tails, lgB, t_max);
-    else if (qpb == 2)
-      hipLaunchKernelGGL(k_seg_combine<2>, dim3(cgrid), dim3(128), 0, s, slots, (const u32*)compact, buckets, NBtot, seg, heavy, (const u32*)tails, lgB, t_max);
+    // ONE quad per bucket.  Two or four quads per bucket, each taking every 2nd / 4th partial and folding through shuffles (the "tree" of
+    // VERDICT r05 #5 and of round 5's DESIGN 9a iii), were built and measured: slower at every shape -- 64 x 2^12 segment combine 0.111 ->
+    // 0.149 / 0.167 ms, 16 x 2^14 0.112 -> 0.130 / 0.168, 256 x 2^10 0.073 -> 0.092 / 0.135 (profiles/round6_seg_combine_quads_per_bucket_ab.txt):
+    // the kernel is bound by the instructions of its additions, not by the length of a bucket's chain, and the fold adds some.
+    const unsigned cgrid = (unsigned)((4 * NBtot + 127) / 128);
+#ifdef MZK_TUNING
+    static const int env_qpb = tune_int("MZK_COMBINE_QPB", 1);          // tuning build: 2 / 4 = the measured-and-dropped forms
+    if (env_qpb == 4)
+      hipLaunchKernelGGL(k_seg_combine<4>, dim3(4 * cgrid), dim3(128), 0, s, slots, (const u32*)compact, buckets, NBtot, seg, heavy, (const u32*)tails, lgB, t_max);
+    else if (env_qpb == 2)
+      hipLaunchKernelGGL(k_seg_combine<2>, dim3(2 * cgrid), dim3(128), 0, s, slots, (const u32*)compact, buckets, NBtot, seg, heavy, (const u32*)tails, lgB, t_max);
     else
+#endif
       hipLaunchKernelGGL(k_seg_combine<1>, dim3(cgrid), dim3(128), 0, s, slots, (const u32*)compact, buckets, NBtot, seg, heavy, (const u32*)tails, lgB, t_max);
     hipLaunchKernelGGL(k_seg_combine_heavy, dim3(HEAVY_GRID), dim3(HEAVY_THREADS), 0, s, (const u32*)slots, (const u32*)compact, buckets, heavy, max_heavy);
     MZK_HIP(hipGetLastError());
