@@ -1178,7 +1178,8 @@ def leg_e2e_kzg(B):
         alpha = orc.from_limbs(orc.synth_vector(orc.FR, SEED + 556, 1))[0]
         uu = orc.from_limbs(orc.synth_vector(orc.FR, SEED + 557, 1))[0]
         a_l, g_l = mz.to_limbs([alpha], 4), mz.points_to_array([(1, 2)])
-        open_ops, y_host, keep_q = sharded.DeviceOpenOps(), [None], [None]
+        q_buf, q_buf1 = torch.zeros((hi - lo) * 4, dtype=torch.int64, device=dev), torch.zeros((hi - lo) * 4, dtype=torch.int64, device=dev)
+        open_ops, y_host, keep_q = sharded.DeviceOpenOps(out=q_buf), [None], [None]
 
         def stage(name, fn, record):
             # every rank runs the same barriers and the same collective failure check per stage: a rank that
@@ -1232,7 +1233,7 @@ def leg_e2e_kzg(B):
         L.mzk_ctx_stream.restype = ctypes.c_void_p
         s1 = ctypes.c_void_p(L.mzk_ctx_stream(1))
 
-        open_ops1 = sharded.DeviceOpenOps(stream=s1.value)
+        open_ops1 = sharded.DeviceOpenOps(stream=s1.value, out=q_buf1)
 
         def commit_and_open():
             mz.ctx_select(1)

@@ -69,6 +69,8 @@ def sharded_open_quotient(ops, coef_slice, n, u, modulus, rank, world):
     """This rank's slice q[lo, hi) of open_kzg's quotient and y = f(u), from its slice c[lo, hi) of the n coefficients.
     ops.slice_value(coef_slice, u) -> int;  ops.gather_values(int) -> list of the W ranks' ints;
     ops.slice_quotient(coef_slice, u, carry) -> the slice of q (same length as the slice; the top rank's last element is b_n = 0)."""
+    if world == 1 and not FORCE_COLLECTIVES and hasattr(ops, "whole"):
+        return ops.whole(coef_slice, u)            # one rank holds everything: the one-piece recurrence (one pass, no exchange)
     lens = [shard_range(n, g, world)[1] - shard_range(n, g, world)[0] for g in range(world)]
     values = ops.gather_values(ops.slice_value(coef_slice, u))
     y, carries = open_carries(values, lens, u, modulus)
@@ -78,12 +80,29 @@ def sharded_open_quotient(ops, coef_slice, n, u, modulus, rank, world):
 class DeviceOpenOps:
     """The local passes of sharded_open_quotient on the GPU (C ABI on torch's current stream) and the gather over the process group."""
 
-    def __init__(self, stream=None):
+    def __init__(self, stream=None, out=None):
         """stream: a raw HIP stream the local passes run on (default: torch's current stream).  The gather is torch's, on torch's
-        stream, so a pass on another stream is waited for before its value is handed on."""
+        stream, so a pass on another stream is waited for before its value is handed on.  out: the caller's buffer for the slice of q
+        (int64, as long as the coefficient slice; a fresh tensor per call otherwise)."""
         import ctypes
         import myzkp_amd as mz
-        self.ct, self.mz, self.L, self.stream = ctypes, mz, mz.lib(), stream
+        self.ct, self.mz, self.L, self.stream, self.out = ctypes, mz, mz.lib(), stream, out
+
+    def _q(self, coef):
+        return self.out if self.out is not None and self.out.numel() == coef.numel() else torch.empty_like(coef)
+
+    def whole(self, coef, u):
+        """world 1: y and q in one pass (mzk_kzg_open_quotient_dev); q has the slice's length, its last element b_n = 0"""
+        import numpy as np
+        ul = self.mz.to_limbs([u], 4)
+        q = self._q(coef)
+        y = torch.zeros(4, dtype=torch.int64, device=coef.device)
+        n = coef.numel() // 4
+        q[-4:] = 0
+        self._ok(self.L.mzk_kzg_open_quotient_dev(self.ct.c_void_p(coef.data_ptr()), self.ct.c_size_t(n), ul.ctypes.data_as(self.ct.c_void_p),
+                                                  self.ct.c_void_p(y.data_ptr()), self.ct.c_void_p(q.data_ptr()), self._st()))
+        self._join()
+        return self.mz.from_limbs(y.cpu().numpy().view(np.uint64).reshape(1, 4))[0], q
 
     def _st(self):
         return self.ct.c_void_p(self.stream if self.stream is not None else torch.cuda.current_stream().cuda_stream)
@@ -111,7 +130,7 @@ class DeviceOpenOps:
 
     def slice_quotient(self, coef, u, carry):
         ul, cl = self.mz.to_limbs([u], 4), self.mz.to_limbs([carry], 4)
-        q = torch.empty_like(coef)
+        q = self._q(coef)
         self._ok(self.L.mzk_kzg_open_slice_quotient_dev(self.ct.c_void_p(coef.data_ptr()), self.ct.c_size_t(coef.numel() // 4), ul.ctypes.data_as(self.ct.c_void_p),
                                                         cl.ctypes.data_as(self.ct.c_void_p), self.ct.c_void_p(q.data_ptr()), self._st()))
         return q

@@ -161,3 +161,8 @@ def test_sharded_open_quotient_equals_the_whole_quotient(n, world):
     for i in range(n - 1, -1, -1):
         b[i] = (c[i] + u * b[i + 1]) % P_FR
     assert y == b[0] and orc.from_limbs(got_q.cpu().numpy().view(np.uint64).reshape(n, 4)) == b[1:]
+    # the driver function at world 1 takes the one-piece recurrence (no exchange) into the caller's buffer: same y, same q
+    buf = torch.full((n * 4,), -1, dtype=torch.int64, device=dev)
+    y1, q1 = sharded.sharded_open_quotient(sharded.DeviceOpenOps(out=buf), coef, n, u, P_FR, 0, 1)
+    torch.cuda.synchronize()
+    assert y1 == y and q1.data_ptr() == buf.data_ptr() and torch.equal(q1, got_q)
