@@ -1097,8 +1097,10 @@ def leg_copy_rate(B):
 
 
 # ---------------------------------------------------------------------------------------------------- other sizes, sharded legs
-def leg_extra_sizes(B):
-    """Extra sizes (single GPU view, rank 0 only, a few repetitions each): the 2^24 half of BASELINE.json's metric."""
+def leg_extra_sizes(B, card=None):
+    """Extra sizes (single GPU view, rank 0 only, a few repetitions each): the 2^24 half of BASELINE.json's metric.  The shader clock is
+    sampled while each leg's kernels run: under the same power cap the 2^24 accumulate -- 13 GiB of tables gathered from HBM -- runs
+    ~12 % below the clock of the 2^20 one (profiles/round6_accumulate_2p20_vs_2p24_counters.txt), which is most of its per-addition gap."""
     torch, L, mz, args, dev, stream = B.torch, B.L, B.mz, B.args, B.dev, B.stream
     extras = {}
     if B.rank != 0 or not B.all_legs:
@@ -1139,6 +1141,11 @@ def leg_extra_sizes(B):
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / reps
                 e[name] = {"ms": dt * 1e3, "rate": nn / dt, "hbm_frac": (64.0 if name == "ntt" else 96.0) * nn / dt / 1e9 / HBM_PEAK_GBPS}
+                if card is not None and dt > 2e-3:          # an untimed further call, the clock read while its kernels run
+                    fn()
+                    time.sleep(dt * 0.6)
+                    e[name]["sclk_mhz_mid_call"] = sclk_now_mhz(card)
+                    torch.cuda.synchronize()
             # round trip property at this size: intt(ntt(x)) == x
             check(B, L.mzk_ntt_dev(mz.FIELD_FR, rt.ctypes.data_as(ctypes.c_void_p), dptr(vout), dptr(vout), ctypes.c_size_t(nn), 1, stream))
             torch.cuda.synchronize()
@@ -1724,7 +1731,7 @@ def main():
     out["hbm_copy_GBps_measured"] = copy_gbps
 
     progress(B, "line assembled; extra sizes")
-    extras = leg_extra_sizes(B)
+    extras = leg_extra_sizes(B, card)
     detail["extra_sizes_1gpu"] = extras
     for tag, e in extras.items():
         if "error" in e:
@@ -1734,6 +1741,8 @@ def main():
         out["msm_2p%s_arbitrary_points_pairs_per_s" % lgx], out["msm_2p%s_arbitrary_points_ms" % lgx] = e["msm_generic"]["rate"], e["msm_generic"]["ms"]
         out["ntt_2p%s_elems_per_s" % lgx], out["ntt_2p%s_ms" % lgx] = e["ntt"]["rate"], e["ntt"]["ms"]
         out["hbm_frac_2p%s" % lgx] = {"msm": e["kzg_commit_srs"]["hbm_frac"], "msm_arbitrary_points": e["msm_generic"]["hbm_frac"], "ntt": e["ntt"]["hbm_frac"]}
+        if "sclk_mhz_mid_call" in e["kzg_commit_srs"]:
+            out["gpu_clock_mhz_under_load_2p%s_msm" % lgx] = e["kzg_commit_srs"]["sclk_mhz_mid_call"]
 
     if args.e2e_log2n > 0:
         e2e = leg_e2e_kzg(B)
