@@ -1043,9 +1043,19 @@ def leg_stark_commit_pipeline(B, lgt=14, regs=16):
                 t.close()
         if not (ok_interp and ok_hbm and ok_lde and ok_root and ok_fold):
             return {"error": "parity: interpolate %s (HBM form %s), lde %s, merkle root %s, first fold %s" % (ok_interp, ok_hbm, ok_lde, ok_root, ok_fold)}
+        # the same 16 registers over a domain that is NOT a subgroup prefix (arbitrary points): the subproduct-tree path of the same call,
+        # timed beside the trace domain's inverse-transform path
+        dom_arb = orc.synth_vector(orc.M128, 4242, cycles)
+
+        def stage_interpolate_arbitrary():
+            d_trace = torch.from_numpy(trace_flat).to(dev)
+            mz.fast_interpolate_batch_dev(fid, dom_arb, d_trace.data_ptr(), regs, omicron, 1 << lgt, d_coefs_arb.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        d_coefs_arb = torch.zeros(regs * cycles * 2, dtype=torch.int64, device=dev)
+        stage_interpolate_arbitrary()
         best = {}
         for rep in range(4):
-            for name, fn in (("interpolate_host", stage_interpolate), ("interpolate", stage_interpolate_hbm), ("coset_lde", stage_lde), ("merkle_commit", stage_merkle), ("fri_commit", stage_fri)):
+            for name, fn in (("interpolate_host", stage_interpolate), ("interpolate", stage_interpolate_hbm), ("interpolate_arbitrary", stage_interpolate_arbitrary),
+                             ("coset_lde", stage_lde), ("merkle_commit", stage_merkle), ("fri_commit", stage_fri)):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 r = fn()
@@ -1063,12 +1073,15 @@ def leg_stark_commit_pipeline(B, lgt=14, regs=16):
                               "merkle_commit_batch_dev": best["merkle_commit"], "fri_commit_keep_trees_dev": best["fri_commit"]},
                 "total_ms": best["interpolate"] + best["coset_lde"] + best["merkle_commit"] + best["fri_commit"],
                 "interpolate_%d_registers_host_buffers_ms" % regs: best["interpolate_host"],
+                "interpolate_%d_registers_arbitrary_domain_ms" % regs: best["interpolate_arbitrary"],
                 "fri_us_per_round": best["fri_commit"] / rounds * 1e3,
                 "parity": {"interpolate_vs_oracle": ok_interp, "interpolate_hbm_form_equals_host_form": ok_hbm, "coset_lde_vs_oracle": ok_lde, "merkle_root_vs_oracle": ok_root,
                            "first_fri_fold_vs_oracle": ok_fold},
                 "note": "best of three repetitions per stage, each bracketed by a device synchronize; the trace is uploaded inside the interpolation stage "
                         "(mzk_fast_interpolate_batch_dev; the host-buffer form, coefficients back over PCIe, is timed beside it), everything after "
-                        "it stays in HBM; the challenge callback hashes on the host as the reference's transcript does"}
+                        "it stays in HBM; the challenge callback hashes on the host as the reference's transcript does.  The trace domain omicron^i is a "
+                        "prefix of a power-of-two subgroup: its interpolation is one inverse transform plus three dot products per register; the same "
+                        "call on arbitrary points (subproduct tree) is the _arbitrary_domain_ figure"}
     except Exception as ex:
         return {"error": str(ex)[:300]}
 
@@ -1782,6 +1795,7 @@ def main():
         "pcie_ntt_host_buffers": pick(s, "pcie_inclusive", "ntt_host_buffers", "ms_per_call"),
         "stark_commit_pipeline_total": pick(s, "stark_commit_pipeline", "total_ms"),
         "stark_interpolate_16_registers": pick(s, "stark_commit_pipeline", "stages_ms", "interpolate_16_registers_trace_uploaded_coefficients_in_hbm"),
+        "stark_interpolate_16_registers_arbitrary_domain": pick(s, "stark_commit_pipeline", "interpolate_16_registers_arbitrary_domain_ms"),
         "stark_fri_us_per_round": pick(s, "stark_commit_pipeline", "fri_us_per_round"),
     })
     out["legs_ms"] = {k: (round(v, 5) if isinstance(v, float) else v) for k, v in legs_ms.items() if v is not None}

@@ -155,6 +155,10 @@ int mzk_fast_coset_divide(int field_id, const uint64_t* lhs, size_t ll, const ui
  *   interpolate: the polynomial of degree < n through (domain[i], values[i]), trimmed like the reference's final sum;
  *                n = 1 -> [values[0]] untrimmed.  A repeated domain point gets weight inverse(0) = 0, as in the
  *                reference (field.rs:209-232 via ntt.rs:233-242).  out must hold n elements.
+ *                When the domain is the first n points 1, g, g^2 ... of a subgroup of order next_pow2(n) with at most 64 of its
+ *                points missing -- FastStark's trace_domain = omicron^i (fast_stark.rs:197-215) -- the same coefficients come from
+ *                ONE inverse transform of the values extended by the interpolant's values at the missing points (a dot product
+ *                each, weights kept with the cached plan); every other domain goes through the tree.
  * root / root_order: the two reference assertions (MZK_E_ROOT_ORDER / MZK_E_ROOT_PRIM); where the reference's
  * internal zerofier products would exceed root_order (it then wraps around or panics inside ntt) -> MZK_E_LENGTH. */
 int mzk_fast_zerofier(int field_id, const uint64_t* domain, size_t n, const uint64_t* root, size_t root_order, uint64_t* out, size_t* out_len);

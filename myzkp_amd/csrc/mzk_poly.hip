@@ -630,6 +630,134 @@ __global__ __launch_bounds__(256) void k_row_len(const u32* __restrict__ rows, s
   if (threadIdx.x == 0) lens[blockIdx.x] = sh[0];
 }
 
+// ---- interpolation over a prefix of a power-of-two subgroup ---------------------------------------------------------------------
+// FastStark::prove interpolates every trace register over trace_domain = [omicron^i, i < cycles] (fast_stark.rs:197-215): the first n
+// points of the subgroup generated by g = omicron, whose order N = 2^k is the next power of two above the cycle count (N - n = m points
+// are missing: 3 for the reference's padded traces).  On the WHOLE subgroup interpolation is the inverse transform with root g; on a
+// prefix the interpolant f (degree < n = N - m, unique: the points are distinct) is the inverse transform of the values extended by the
+// m numbers u_j = f(g^(n+j)), and those are fixed by the m top coefficients of the transform being zero:
+//     sum_j u_j x_(n+j)^(1+t) = - sum_(i<n) v_i x_i^(1+t),  t < m,   x_i = g^i      (coefficient N-1-t of the inverse transform, times N)
+// an m x m system whose matrix A[t][j] = x_(n+j)^(1+t) depends on the domain alone.  With its inverse, u_j = sum_i v_i C[j][i] where
+// C[j][i] = - sum_t Ainv[j][t] x_i^(1+t) is part of the plan: a call costs m dot products of length n per register and ONE batched
+// inverse transform of N points -- O(n log n + m n) where the subproduct tree is O(n log^2 n) with ~50 launches.  The coefficients are
+// those of the same polynomial the reference's recursion returns (ntt.rs:203-252), trimmed the same way; any other domain (and a prefix
+// with more than PREFIX_MAX_MISSING points missing) goes through the tree below.
+constexpr size_t PREFIX_MAX_MISSING = 64;
+// C[j * n + i] = Montgomery form of  - x_i sum_t ainv[j * m + t] x_i^t  (Horner in x_i); blockIdx.y = j
+template <class P>
+__global__ __launch_bounds__(256) void k_prefix_weights(const u32* __restrict__ domain, size_t n, const u32* __restrict__ ainv, int m, u32* __restrict__ C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t j = blockIdx.y;
+  if (i >= n) return;
+  const Fe<P> x = fe_reduce<P>(fe_to_mont<P>(pl_load<P>(domain, i)));       // Montgomery form: mul(acc, x) is the plain product
+  Fe<P> acc = fe_zero<P>();
+  for (int t = m - 1; t >= 0; t--) acc = pl_add<P>(fe_reduce<P>(FeAsm<P>::mul(acc, x)), pl_load<P>(ainv, j * (size_t)m + t));
+  acc = fe_reduce<P>(fe_neg_canon<P>(fe_reduce<P>(FeAsm<P>::mul(acc, x))));
+  pl_store<P>(C, j * n + i, fe_reduce<P>(fe_to_mont<P>(acc)));
+}
+// ext[r * N + i] = i < n ? v[r * n + i] : 0, N = 2^lgN  (the m missing values are written by k_prefix_missing afterwards)
+template <class P>
+__global__ __launch_bounds__(256) void k_prefix_pad(const u32* __restrict__ v, size_t n, int lgN, size_t total, u32* __restrict__ ext) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const size_t r = e >> lgN, i = e & (((size_t)1 << lgN) - 1);
+  pl_store<P>(ext, e, i < n ? pl_load<P>(v, r * n + i) : fe_zero<P>());
+}
+// ext[r * N + n + j] = sum_i v[r * n + i] C[j * n + i]: one workgroup per (missing point j = blockIdx.x, register r = blockIdx.y)
+constexpr int PREFIX_NT = 1024;
+template <class P>
+__global__ __launch_bounds__(PREFIX_NT) void k_prefix_missing(const u32* __restrict__ v, size_t n, size_t N, const u32* __restrict__ C, u32* __restrict__ ext) {
+  __shared__ u32 sh[(PREFIX_NT / 64) * P::NW];
+  const size_t j = blockIdx.x, r = blockIdx.y;
+  const u32* row = v + r * n * P::NW;
+  const u32* cj = C + j * n * P::NW;
+  Fe<P> acc = fe_zero<P>();
+  for (size_t i = threadIdx.x; i < n; i += PREFIX_NT) acc = pl_add<P>(acc, fe_reduce<P>(FeAsm<P>::mul(pl_load<P>(row, i), pl_load<P>(cj, i))));
+  for (int k = 1; k < 64; k <<= 1) acc = pl_add<P>(acc, shfl_xor_fe<P>(acc, k));
+  if ((threadIdx.x & 63) == 0) pl_store<P>(sh, threadIdx.x >> 6, acc);
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    Fe<P> t = threadIdx.x < PREFIX_NT / 64 ? pl_load<P>(sh, threadIdx.x) : fe_zero<P>();
+    for (int k = 1; k < PREFIX_NT / 64; k <<= 1) t = pl_add<P>(t, shfl_xor_fe<P>(t, k));
+    if (threadIdx.x == 0) pl_store<P>(ext, r * N + n + j, t);
+  }
+}
+
+// host side (parameters only): a + b, a - b mod p for canonical a, b
+static void hp_add(const HostField* f, uint64_t* r, const uint64_t* a, const uint64_t* b) {
+  uint64_t t[4] = {0, 0, 0, 0};
+  unsigned __int128 c = 0;
+  for (int i = 0; i < f->nl; i++) { c += (unsigned __int128)a[i] + b[i]; t[i] = (uint64_t)c; c >>= 64; }
+  bool ge = c != 0;
+  if (!ge) { ge = true; for (int k = f->nl - 1; k >= 0; k--) if (t[k] != f->p[k]) { ge = t[k] > f->p[k]; break; } }
+  if (ge) { unsigned __int128 br = 0; for (int k = 0; k < f->nl; k++) { unsigned __int128 d = (unsigned __int128)t[k] - f->p[k] - (uint64_t)br; t[k] = (uint64_t)d; br = (d >> 64) & 1; } }
+  for (int i = 0; i < f->nl; i++) r[i] = t[i];
+}
+static void hp_sub(const HostField* f, uint64_t* r, const uint64_t* a, const uint64_t* b) {
+  uint64_t nb[4] = {0, 0, 0, 0};
+  bool zero = true;
+  for (int i = 0; i < f->nl; i++) zero = zero && b[i] == 0;
+  if (!zero) { unsigned __int128 br = 0; for (int k = 0; k < f->nl; k++) { unsigned __int128 d = (unsigned __int128)f->p[k] - b[k] - (uint64_t)br; nb[k] = (uint64_t)d; br = (d >> 64) & 1; } }
+  hp_add(f, r, a, nb);
+}
+// domain[i] == g^i for i < n with g = domain[1] of order exactly N = next_pow2(n), at most PREFIX_MAX_MISSING points of the subgroup
+// missing.  An arbitrary domain leaves at i = 2 after two short exponentiations; a true prefix costs n host products, once per plan.
+static bool prefix_of_subgroup(const HostField* hf, const uint64_t* domain, size_t n, size_t* N_out) {
+  static const int enabled = tune_int("MZK_INTERP_PREFIX", 1);      // tuning build: 0 = every domain through the tree (A/B, tests of the tree)
+  if (!enabled || n < 2) return false;
+  const int nl = hf->nl;
+  const size_t N = next_pow2(n);
+  if (N - n > PREFIX_MAX_MISSING || (N - n) * n * (size_t)nl * 8 > ((size_t)1 << 30)) return false;
+  if (!h_is_one(hf, domain)) return false;
+  const uint64_t* g = domain + nl;
+  uint64_t t[4] = {0, 0, 0, 0};
+  h_powmod_u64(hf, t, g, N);
+  if (!h_is_one(hf, t)) return false;
+  h_powmod_u64(hf, t, g, N / 2);
+  if (h_is_one(hf, t)) return false;
+  uint64_t cur[4] = {0, 0, 0, 0};
+  memcpy(cur, g, 8 * (size_t)nl);
+  for (size_t i = 2; i < n; i++) {
+    h_mulmod(hf, cur, cur, g);
+    if (memcmp(cur, domain + i * nl, 8 * (size_t)nl)) return false;
+  }
+  *N_out = N;
+  return true;
+}
+// Ainv (m x m, row-major, canonical) of A[t][j] = x_(n+j)^(1+t) by Gauss-Jordan on the host; false if a pivot is missing (cannot
+// happen for distinct non-zero x: every leading minor is a Vandermonde determinant times a product of x's)
+static bool prefix_system_inverse(const HostField* hf, const uint64_t* g, size_t n, size_t m, std::vector<uint64_t>* out) {
+  const size_t nl = (size_t)hf->nl;
+  std::vector<uint64_t> a(m * 2 * m * 4, 0);                  // [A | I], four limbs per entry
+  auto at = [&](size_t row, size_t col) { return a.data() + (row * 2 * m + col) * 4; };
+  for (size_t j = 0; j < m; j++) {
+    uint64_t x[4] = {0, 0, 0, 0}, pw[4] = {0, 0, 0, 0};
+    h_powmod_u64(hf, x, g, (uint64_t)(n + j));
+    memcpy(pw, x, 8 * nl);
+    for (size_t t = 0; t < m; t++) { memcpy(at(t, j), pw, 8 * nl); h_mulmod(hf, pw, pw, x); }
+    at(j, m + j)[0] = 1;
+  }
+  auto is_zero = [&](const uint64_t* v) { for (size_t k = 0; k < nl; k++) if (v[k]) return false; return true; };
+  for (size_t col = 0; col < m; col++) {
+    size_t piv = col;
+    while (piv < m && is_zero(at(piv, col))) piv++;
+    if (piv == m) return false;
+    if (piv != col) for (size_t k = 0; k < 2 * m * 4; k++) std::swap(a[col * 2 * m * 4 + k], a[piv * 2 * m * 4 + k]);
+    uint64_t inv[4] = {0, 0, 0, 0};
+    h_invmod(hf, inv, at(col, col));
+    for (size_t k = 0; k < 2 * m; k++) h_mulmod(hf, at(col, k), at(col, k), inv);
+    for (size_t row = 0; row < m; row++) {
+      if (row == col || is_zero(at(row, col))) continue;
+      uint64_t f[4] = {0, 0, 0, 0}, prod[4] = {0, 0, 0, 0};
+      memcpy(f, at(row, col), 8 * nl);
+      for (size_t k = 0; k < 2 * m; k++) { h_mulmod(hf, prod, at(col, k), f); hp_sub(hf, at(row, k), at(row, k), prod); }
+    }
+  }
+  out->assign(m * m * nl, 0);
+  for (size_t j = 0; j < m; j++) for (size_t t = 0; t < m; t++) memcpy(out->data() + (j * m + t) * nl, at(j, m + t), 8 * nl);
+  return true;
+}
+
 // ---- interpolation plans: what fast_interpolate derives from the domain alone ------------------------------------------------------
 struct InterpPlanBase {
   int fid = -1;
@@ -642,6 +770,12 @@ struct InterpPlanBase {
 template <class P> struct InterpPlan : InterpPlanBase {
   PolyTree<P> T;
   DevBuf d_dom, d_zp;        // the domain; 1 / Z'(d_i)
+  // a prefix of a power-of-two subgroup (see k_prefix_weights): no tree; the generator, the subgroup's order, the number of its points
+  // that are missing and the weights that give the interpolant's values there
+  bool prefix = false;
+  uint64_t g[4] = {0, 0, 0, 0};
+  size_t pN = 0, pm = 0;
+  DevBuf d_C;
 };
 static std::vector<InterpPlanBase*> g_interp_plans[MZK_MAX_CTX];
 static InterpPlanBase* g_interp_busy[MZK_MAX_CTX];     // the cached plan the running call works with: never evicted under it
@@ -698,23 +832,41 @@ static int interp_plan_get(int fid, const uint64_t* domain, size_t n, const uint
     }
   }
   const size_t esz = field_bytes(fid);
+  const HostField* hf = host_field(fid);
   InterpPlan<P>* pl = new InterpPlan<P>();
   pl->fid = fid; pl->n = n;
   int rc = tree_init(&pl->T, fid, n, root, root_order, s);
   DevBuf d_dz, d_zpv;
   if (rc == MZK_OK) rc = pl->d_dom.alloc(n * esz);
-  if (rc == MZK_OK) rc = d_dz.alloc(n * esz);
-  if (rc == MZK_OK) rc = pl->d_zp.alloc(pl->T.N * esz);
   if (rc == MZK_OK && hipMemcpyAsync(pl->d_dom.p, domain, n * esz, hipMemcpyHostToDevice, s) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipMemcpyAsync", __FILE__, __LINE__);
-  if (rc == MZK_OK) rc = pl->T.build(pl->d_dom.p, true);
-  if (rc == MZK_OK) {
+  std::vector<uint64_t> ainv;
+  if (rc == MZK_OK && prefix_of_subgroup(hf, domain, n, &pl->pN)) {
+    pl->pm = pl->pN - n;
+    memcpy(pl->g, domain + nl, 8 * nl);
+    pl->prefix = pl->pm == 0 || prefix_system_inverse(hf, pl->g, n, pl->pm, &ainv);
+  }
+  if (rc == MZK_OK && pl->prefix && pl->pm) {
+    const size_t m = pl->pm;
+    DevBuf d_ainv;
+    rc = d_ainv.alloc(m * m * esz);
+    if (rc == MZK_OK) rc = pl->d_C.alloc(m * n * esz);
+    if (rc == MZK_OK && hipMemcpyAsync(d_ainv.p, ainv.data(), m * m * esz, hipMemcpyHostToDevice, s) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipMemcpyAsync", __FILE__, __LINE__);
+    if (rc == MZK_OK) {
+      hipLaunchKernelGGL((k_prefix_weights<P>), dim3(grid256(n), (unsigned)m), dim3(256), 0, s, (const u32*)pl->d_dom.p, n, (const u32*)d_ainv.p, (int)m, pl->d_C.w());
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = hip_fail(hipGetLastError(), "k_prefix_weights", __FILE__, __LINE__);      // `ainv`, d_ainv are read until here
+    }
+  }
+  if (rc == MZK_OK && !pl->prefix) rc = d_dz.alloc(n * esz);
+  if (rc == MZK_OK && !pl->prefix) rc = pl->d_zp.alloc(pl->T.N * esz);
+  if (rc == MZK_OK && !pl->prefix) rc = pl->T.build(pl->d_dom.p, true);
+  if (rc == MZK_OK && !pl->prefix) {
     // w_i = v_i / Z'(d_i); a repeated point has Z' = 0 and the reference's division by inverse(0) = 0 (field.rs:209-232)
     // zeroes its target at the level that separates the two copies (ntt.rs:233-242): w_i = 0 as well
     hipLaunchKernelGGL((k_derivative<P>), dim3(grid256(n)), dim3(256), 0, s, (const u32*)pl->T.low[pl->T.levels].w(), pl->T.N, pl->T.pad, n, d_dz.w());
     rc = d_zpv.alloc(pl->T.N * esz);
     if (rc == MZK_OK) rc = pl->T.evaluate(d_dz.p, n, pl->d_dom.p, d_zpv.p, n);
   }
-  if (rc == MZK_OK) {
+  if (rc == MZK_OK && !pl->prefix) {
     // the plan keeps 1 / Z'(d_i) (0 where Z' = 0, as the division gives): d_dz is free again and takes the numerators, all ones
     std::vector<uint64_t> ones(n * nl, 0);
     for (size_t i = 0; i < n; i++) ones[i * nl] = 1;
@@ -725,7 +877,7 @@ static int interp_plan_get(int fid, const uint64_t* domain, size_t n, const uint
   if (rc != MZK_OK) { (void)hipStreamSynchronize(s); delete pl; return rc; }
   pl->domain.assign(domain, domain + n * nl);
   pl->stamp = ++g_interp_stamp;
-  pl->bytes = (size_t)(3 * pl->T.levels + 4) * pl->T.N * esz;
+  pl->bytes = pl->prefix ? (pl->pm + 1) * n * esz : (size_t)(3 * pl->T.levels + 4) * pl->T.N * esz;
   size_t total = pl->bytes;
   for (auto* b : v) total += b->bytes;
   while (pl->bytes <= INTERP_MAX_BYTES && !v.empty() && (v.size() >= INTERP_MAX_PLANS || total > INTERP_MAX_BYTES)) {      // least recently used first; their buffers return to the pool
@@ -782,6 +934,33 @@ static int interpolate_impl(int fid, const uint64_t* domain, const uint64_t* val
     ~Drop() { g_interp_busy[idx] = nullptr; if (p) { (void)hipStreamSynchronize(s); delete p; } }
   } drop{transient ? plan : nullptr, s, ctx().index};
   g_interp_busy[ctx().index] = transient ? nullptr : plan;      // an allocation of this call that runs out of memory evicts the OTHER cached plans only
+  if (plan->prefix) {
+    // values -> [values | the interpolant at the missing points] -> inverse transform with the domain's generator: coefficients
+    const size_t N = plan->pN, m = plan->pm;
+    int lgN = 0;
+    while (((size_t)1 << lgN) < N) lgN++;
+    const size_t group = std::max<size_t>(1, std::min<size_t>(batch, ((size_t)1 << 24) / N));
+    DevBuf d_vals, d_ext, d_lens;
+    if (!on_device) MZK_TRY(d_vals.alloc(group * n * esz));
+    MZK_TRY(d_ext.alloc(group * N * esz)); MZK_TRY(d_lens.alloc(group * 4 + 64));
+    std::vector<u32> lens(group);
+    for (size_t r0 = 0; r0 < batch; r0 += group) {
+      const size_t g = std::min(group, batch - r0);
+      const void* vals = on_device ? (const void*)((const uint8_t*)d_values + r0 * n * esz) : d_vals.p;
+      if (!on_device) MZK_HIP(hipMemcpyAsync(d_vals.p, values + r0 * n * nl, g * n * esz, hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL((k_prefix_pad<P>), dim3(grid256(g * N)), dim3(256), 0, s, (const u32*)vals, n, lgN, g * N, d_ext.w());
+      if (m) hipLaunchKernelGGL((k_prefix_missing<P>), dim3((unsigned)m, (unsigned)g), dim3(PREFIX_NT), 0, s, (const u32*)vals, n, N, (const u32*)plan->d_C.p, d_ext.w());
+      MZK_HIP(hipGetLastError());
+      MZK_TRY(ntt_batch_dev_impl(fid, plan->g, d_ext.p, d_ext.p, N, g, 1, s));
+      hipLaunchKernelGGL((k_row_len<P>), dim3((unsigned)g), dim3(256), 0, s, (const u32*)d_ext.p, N, (size_t)0, n, (u32*)d_lens.p);
+      MZK_HIP(hipGetLastError());
+      if (on_device) MZK_HIP(hipMemcpy2DAsync((uint8_t*)d_out + r0 * n * esz, n * esz, d_ext.p, N * esz, n * esz, g, hipMemcpyDeviceToDevice, s));
+      else MZK_HIP(hipMemcpy2DAsync(out + r0 * n * nl, n * esz, d_ext.p, N * esz, n * esz, g, hipMemcpyDeviceToHost, s));
+      MZK_TRY(d2h_sync(lens.data(), d_lens.p, g * 4, s));
+      for (size_t r = 0; r < g; r++) out_lens[r0 + r] = lens[r];
+    }
+    return MZK_OK;
+  }
   PolyTree<P>& T = plan->T;
   DevBuf& d_dom = plan->d_dom;
   DevBuf& d_zp = plan->d_zp;

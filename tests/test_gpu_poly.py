@@ -233,3 +233,86 @@ def test_interpolation_plans_are_keyed_by_the_exact_domain(mz, fid):
     for a, b, v in zip(first, again, vals):
         rc, want = orc.fast_interpolate_ref(fid, doms[0], v, om, 1 << lg)
         assert np.array_equal(a, want) and np.array_equal(b, want)
+
+
+def _subgroup_prefix(fid, lg, n):
+    om, p = orc.root_of(fid, lg), orc.MOD[fid]
+    dom, acc = [], 1
+    for _ in range(n):
+        dom.append(acc); acc = acc * om % p
+    return om, orc.to_limbs(dom, orc.LIMBS[fid])
+
+
+@pytest.mark.parametrize("fid", [M128, FR])
+@pytest.mark.parametrize("lg,missing", [(1, 0), (2, 0), (2, 1), (3, 3), (6, 0), (6, 1), (7, 3), (8, 17), (10, 3), (9, 64), (9, 65)])
+def test_interpolation_over_a_prefix_of_a_subgroup_equals_the_oracle(mz, fid, lg, missing):
+    """Round 6: trace_domain = [omicron^i, i < cycles] (fast_stark.rs:197-215) is the first n points of a subgroup of order 2^lg; the
+    library interpolates it with ONE inverse transform after filling in the interpolant's values at the missing points
+    (mzk_poly.hip, k_prefix_weights) -- same coefficients and same trimmed length as the reference's recursion (ntt.rs:203-252) for a random
+    register, a zero one, a constant one and one whose interpolant has low degree; single call, batch, and the HBM form.  65 missing
+    points is one more than the path takes: that domain goes through the subproduct tree."""
+    import torch
+    n = (1 << lg) - missing
+    nl = orc.LIMBS[fid]
+    om, dom = _subgroup_prefix(fid, lg, n)
+    low = orc.synth_vector(fid, 8100 + lg, max(1, n // 3))
+    dl = orc.from_limbs(dom)
+    vals = np.stack([orc.synth_vector(fid, 8000 + lg + missing, n), np.zeros((n, nl), dtype=np.uint64), orc.synth_vector(fid, 8001 + lg, n),
+                     orc.to_limbs([orc.poly_eval(fid, low, d) for d in dl], nl)])
+    vals[2] = vals[2][0]
+    want = []
+    for k in range(4):
+        rc, w = orc.fast_interpolate_ref(fid, dom, vals[k], om, 1 << lg)
+        assert rc == 0
+        want.append(w)
+    assert np.array_equal(want[3], low[:want[3].shape[0]]) and not low[want[3].shape[0]:].any()
+    for k in range(4):
+        got = mz.fast_interpolate(fid, dom, vals[k], om, 1 << lg)
+        assert got.shape == want[k].shape and np.array_equal(got, want[k]), k
+    got = mz.fast_interpolate_batch(fid, dom, vals, om, 1 << lg)
+    assert all(g.shape == w.shape and np.array_equal(g, w) for g, w in zip(got, want))
+    d_v = torch.from_numpy(vals.view(np.int64).reshape(-1).copy()).cuda()
+    d_o = torch.full((4 * n * nl,), -1, dtype=torch.int64, device="cuda")
+    lens = mz.fast_interpolate_batch_dev(fid, dom, d_v.data_ptr(), 4, om, 1 << lg, d_o.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    rows = d_o.cpu().numpy().view(np.uint64).reshape(4, n, nl)
+    for k in range(4):
+        assert lens[k] == want[k].shape[0] and np.array_equal(rows[k, :lens[k]], want[k]) and not rows[k, lens[k]:].any(), k
+
+
+@pytest.mark.parametrize("fid", [M128, FR])
+def test_domains_that_only_look_like_a_subgroup_prefix_take_the_tree(mz, fid):
+    """what the prefix test must refuse: the last point changed, the first point not 1, a generator whose order is larger than the next
+    power of two above n, the points of a prefix in another order -- each against the oracle's recursion"""
+    lg, n = 8, 253
+    om, dom = _subgroup_prefix(fid, lg, n)
+    nl = orc.LIMBS[fid]
+    d_last = dom.copy(); d_last[n - 1] = orc.synth_vector(fid, 8200, 1)[0]
+    d_first = dom.copy(); d_first[0] = orc.synth_vector(fid, 8201, 1)[0]
+    _, d_big = _subgroup_prefix(fid, lg + 1, n)                        # order 512, 253 points: 256 is not its order
+    d_swap = dom.copy(); d_swap[[5, 9]] = d_swap[[9, 5]]
+    for step, d in enumerate((d_last, d_first, d_big, d_swap, dom)):
+        vals = orc.synth_vector(fid, 8300 + step, n)
+        root = orc.root_of(fid, lg + 1)
+        rc, want = orc.fast_interpolate_ref(fid, d, vals, root, 1 << (lg + 1))
+        assert rc == 0
+        got = mz.fast_interpolate(fid, d, vals, root, 1 << (lg + 1))
+        assert got.shape == want.shape and np.array_equal(got, want), step
+
+
+@pytest.mark.parametrize("fid,lg,regs", [(M128, 14, 16), (FR, 14, 3), (M128, 20, 2), (FR, 18, 1)])
+def test_trace_sized_prefix_interpolation_by_its_defining_property(mz, fid, lg, regs):
+    """16 registers of 2^14 - 3 cycles (the STARK shape of the bench) and up to 2^20 - 3: the coefficients, zero-extended to the subgroup's
+    order and transformed forward with omicron, reproduce every register on the first `cycles` points; no coefficient beyond cycles"""
+    n = (1 << lg) - 3
+    nl = orc.LIMBS[fid]
+    om = orc.root_of(fid, lg)
+    e1 = np.zeros((1 << lg, nl), dtype=np.uint64); e1[1, 0] = 1          # the transform of the unit vector e_1 is [omicron^i]
+    dom = np.ascontiguousarray(mz.ntt(fid, om, e1)[:n])
+    assert orc.from_limbs(dom[:3]) == [1, om, om * om % orc.MOD[fid]]
+    vals = np.stack([orc.synth_vector(fid, 8400 + r, n) for r in range(regs)])
+    got = mz.fast_interpolate_batch(fid, dom, vals, om, 1 << lg)
+    for r in range(regs):
+        assert got[r].shape[0] <= n
+        full = np.zeros((1 << lg, nl), dtype=np.uint64)
+        full[:got[r].shape[0]] = got[r]
+        assert np.array_equal(mz.ntt(fid, om, full)[:n], vals[r]), r

@@ -190,6 +190,15 @@ def case_poly():
     check("fft_multiply", rc == 0 and np.array_equal(mz.fft_multiply(fid, a, b, w), want), (fid, la, lb))
     n = rng.choice([1, 2, 7, 8, 9, 33, 200])
     dom = orc.to_limbs(rng.sample(range(1, 1 << 60), n), NL[fid])
+    if rng.random() < 0.4:        # the first n points of a power-of-two subgroup (a STARK's trace domain): the library's inverse-transform path
+        lgs = rng.choice([1, 2, 3, 5, 6, 8])
+        n = max(1, (1 << lgs) - rng.choice([0, 0, 1, 2, 3, 5, 30, 64, 65]))
+        g, pts, acc = orc.root_of(fid, lgs), [], 1
+        for _ in range(n):
+            pts.append(acc); acc = acc * g % orc.MOD[fid]
+        if rng.random() < 0.15 and n > 2:
+            pts[rng.randrange(n)] = rng.randrange(1, 1 << 60)          # ... and one that only looks like it
+        dom = orc.to_limbs(pts, NL[fid])
     lgr = max(4, (2 * n).bit_length() + 1)
     root, order = orc.root_of(fid, lgr), 1 << lgr
     vals = vec(fid, n)
