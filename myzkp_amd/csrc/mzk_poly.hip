@@ -19,7 +19,9 @@
 //     1 / rev(Z_pad) mod X^N (Newton), then down the tree  t_left = (t_node * Z_right)[D .. 2D)  (one cyclic product
 //     of size 2D per node, re-using the transformed low parts kept from the way up), and a 64-point finish per wave;
 //   * interpolation: weights w_i = v_i / Z'(d_i) (Z' evaluated as above), then the same tree upwards:
-//     P_parent = X^D (P_l + P_r) + P_l Z_r' + P_r Z_l'.
+//     P_parent = X^D (P_l + P_r) + P_l Z_r' + P_r Z_l';
+//   * interpolation over the first n points of a power-of-two subgroup (the trace domain of fast_stark.rs:197-215) needs no tree: one
+//     inverse transform after the m = next_pow2(n) - n missing values are filled in (k_prefix_weights and below).
 #include <algorithm>
 #include <vector>
 #include "mzk_common.h"
