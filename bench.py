@@ -1213,7 +1213,7 @@ def leg_e2e_kzg(B):
             except Exception as ex:
                 local_err = str(ex)[:300]
             if record and local_err is None:
-                stages[name] = (time.perf_counter() - t0) * 1e3
+                stages[name] = min(stages.get(name, float("inf")), (time.perf_counter() - t0) * 1e3)     # best of the recorded passes
             if max_over_ranks(B, 0.0 if local_err is None else 1.0) > 0.0:
                 raise StageFailed(local_err or "a peer rank failed in stage " + name)
 
@@ -1229,7 +1229,8 @@ def leg_e2e_kzg(B):
     try:
         if err is not None:
             raise StageFailed(err)
-        for record in (False, True):     # first pass builds plans / workspaces
+        for record in (False, True, True):     # first pass builds plans / workspaces; two recorded passes, the better time of each stage
+            # (one pass alone showed a 2.4-ms hiccup in one stage on one box of round 6: profiles/round6_bench_default_after_prefix_interpolation.json)
             if hh:
                 L.mzk_srs_free(hh); hh = ctypes.c_void_p()
             stage("intt", lambda: check(B, L.mzk_ntt_dev(mz.FIELD_FR, rt.ctypes.data_as(ctypes.c_void_p), dptr(ev), dptr(cf), ctypes.c_size_t(nn), 1, stream)), record)
@@ -1264,7 +1265,7 @@ def leg_e2e_kzg(B):
             finally:
                 mz.ctx_select(0)
             check(B, L.mzk_kzg_commit_srs_dev(hh, off(cf, lo, 4), ctypes.c_size_t(hi - lo), dptr(rec_c2), ctypes.c_int(1), stream))
-        for record in (False, True):
+        for record in (False, True, True):
             stage("commit_and_open_overlapped", commit_and_open, record)
         overlapped_ms = stages.pop("commit_and_open_overlapped")
         # partial records are XYZZ (projective: the entry order inside a bucket comes from atomics, so the representation of
@@ -1279,7 +1280,8 @@ def leg_e2e_kzg(B):
     # every rank reaches this point; only fold if all local stages succeeded everywhere
     all_ok = max_over_ranks(B, 0.0 if err is None else 1.0) == 0.0
     e2e = {"log2_degree": lg, "n_gpus": world, "srs_points_this_rank": hi - lo, "srs_points_total": nn,
-           "what": "evaluations -> iNTT -> setup(alpha) -> commit -> open(u), device-resident, MSMs and SRS sharded over the ranks (BASELINE configs[4])"}
+           "what": "evaluations -> iNTT -> setup(alpha) -> commit -> open(u), device-resident, MSMs and SRS sharded over the ranks (BASELINE configs[4]); "
+                   "every stage bracketed by a barrier and a device synchronize, one warm-up pass, the better of two recorded passes per stage"}
     if all_ok:
         barrier_sync(B)
         t0 = time.perf_counter()
