@@ -941,7 +941,7 @@ static int interpolate_impl(int fid, const uint64_t* domain, const uint64_t* val
     const size_t N = plan->pN, m = plan->pm;
     int lgN = 0;
     while (((size_t)1 << lgN) < N) lgN++;
-    const size_t group = std::max<size_t>(1, std::min<size_t>(batch, ((size_t)1 << 24) / N));
+    const size_t group = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(batch, ((size_t)1 << 24) / N), 65535));      // (65535: the register index is a grid's y)
     DevBuf d_vals, d_ext, d_lens;
     if (!on_device) MZK_TRY(d_vals.alloc(group * n * esz));
     MZK_TRY(d_ext.alloc(group * N * esz)); MZK_TRY(d_lens.alloc(group * 4 + 64));

@@ -316,3 +316,20 @@ def test_trace_sized_prefix_interpolation_by_its_defining_property(mz, fid, lg, 
         full = np.zeros((1 << lg, nl), dtype=np.uint64)
         full[:got[r].shape[0]] = got[r]
         assert np.array_equal(mz.ntt(fid, om, full)[:n], vals[r]), r
+
+
+def test_prefix_interpolation_of_more_registers_than_one_launch_takes(mz):
+    """70000 registers over the three-point prefix 1, i, -1 of the order-4 subgroup: the registers go through in groups of at most 65535
+    (the register index is the y of a grid); rows on both sides of the boundary against the closed form of the degree-2 interpolant"""
+    import torch
+    fid, n, batch = M128, 3, 70000
+    p = orc.MOD[fid]
+    om, dom = _subgroup_prefix(fid, 2, n)
+    vals = orc.synth_vector(fid, 8500, batch * n).reshape(batch, n, 2)
+    d_v = torch.from_numpy(vals.view(np.int64).reshape(-1)).cuda()
+    d_o = torch.full((batch * n * 2,), -1, dtype=torch.int64, device="cuda")
+    lens = mz.fast_interpolate_batch_dev(fid, dom, d_v.data_ptr(), batch, om, 4, d_o.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    rows = d_o.cpu().numpy().view(np.uint64).reshape(batch, n, 2)
+    for k in (0, 1, 65534, 65535, 65536, 69999):
+        rc, want = orc.fast_interpolate_ref(fid, dom, np.ascontiguousarray(vals[k]), om, 4)
+        assert rc == 0 and lens[k] == want.shape[0] and np.array_equal(rows[k, :lens[k]], want) and not rows[k, lens[k]:].any(), k
