@@ -150,7 +150,9 @@ int mzk_fast_coset_divide(int field_id, const uint64_t* lhs, size_t ll, const ui
  * fast_zerofier, :53).  Subproduct trees on the device (O(n log^2 n); the reference's remainders are O(n^2)).
  *   zerofier:    prod (X - domain[i]).  n = 0 -> empty; n < 8 -> n + 1 coefficients (the schoolbook branch trims);
  *                n >= 8 -> next_pow2(n + 1) coefficients, zero padded (fast_multiply does not trim its NTT branch).
- *                out must hold max(n + 1, next_pow2(n + 1)) elements.
+ *                out must hold max(n + 1, next_pow2(n + 1)) elements.  Over the first n points of a power-of-two subgroup with
+ *                at most 64 of its points missing (FastStark's transition zerofier, fast_stark.rs:53-57) the coefficients
+ *                come from one launch: Z = (X^N - 1) / prod over the missing points, expanded by partial fractions.
  *   evaluate:    out[i] = f(domain[i]), i < n (m coefficients, any m).
  *   interpolate: the polynomial of degree < n through (domain[i], values[i]), trimmed like the reference's final sum;
  *                n = 1 -> [values[0]] untrimmed.  A repeated domain point gets weight inverse(0) = 0, as in the

@@ -534,6 +534,9 @@ static int check_order_for(size_t points, size_t root_order, const char* who) {
   return MZK_OK;
 }
 
+// the zerofier of a subgroup prefix without the tree (defined with the other prefix routines below); *done = false: not such a domain
+template <class P> static int zerofier_of_prefix(int fid, const uint64_t* domain, size_t n, size_t len, uint64_t* out, hipStream_t s, bool* done);
+
 template <class P>
 static int zerofier_impl(int fid, const uint64_t* domain, size_t n, const uint64_t* root, size_t root_order, uint64_t* out, size_t* out_len) {
   const HostField* hf = host_field(fid);
@@ -545,6 +548,11 @@ static int zerofier_impl(int fid, const uint64_t* domain, size_t n, const uint64
   MZK_TRY(check_order_for(n, root_order, "fast_zerofier"));
   hipStream_t s = ctx().stream;
   WsGuard wsg(s);
+  {
+    bool done = false;
+    MZK_TRY(zerofier_of_prefix<P>(fid, domain, n, len, out, s, &done));
+    if (done) { *out_len = len; return MZK_OK; }
+  }
   PolyTree<P> T;
   MZK_TRY(tree_init(&T, fid, n, root, root_order, s));
   DevBuf d_dom;
@@ -703,8 +711,10 @@ static void hp_sub(const HostField* f, uint64_t* r, const uint64_t* a, const uin
   hp_add(f, r, a, nb);
 }
 // domain[i] == g^i for i < n with g = domain[1] of order exactly N = next_pow2(n), at most PREFIX_MAX_MISSING points of the subgroup
-// missing.  An arbitrary domain leaves at i = 2 after two short exponentiations; a true prefix costs n host products, once per plan.
-static bool prefix_of_subgroup(const HostField* hf, const uint64_t* domain, size_t n, size_t* N_out) {
+// missing.  Two steps: the host looks at the order of g and at three points (an arbitrary domain leaves here after a few short
+// exponentiations), then a kernel compares EVERY point with its power of g (n host products were 0.3 ms at 2^14 points -- more than the
+// zerofier below takes) and raises a flag on the first difference.
+static bool prefix_candidate(const HostField* hf, const uint64_t* domain, size_t n, size_t* N_out) {
   static const int enabled = tune_int("MZK_INTERP_PREFIX", 1);      // tuning build: 0 = every domain through the tree (A/B, tests of the tree)
   if (!enabled || n < 2) return false;
   const int nl = hf->nl;
@@ -717,14 +727,35 @@ static bool prefix_of_subgroup(const HostField* hf, const uint64_t* domain, size
   if (!h_is_one(hf, t)) return false;
   h_powmod_u64(hf, t, g, N / 2);
   if (h_is_one(hf, t)) return false;
-  uint64_t cur[4] = {0, 0, 0, 0};
-  memcpy(cur, g, 8 * (size_t)nl);
-  for (size_t i = 2; i < n; i++) {
-    h_mulmod(hf, cur, cur, g);
-    if (memcmp(cur, domain + i * nl, 8 * (size_t)nl)) return false;
+  if (n > 2) {
+    h_mulmod(hf, t, g, g);
+    if (memcmp(t, domain + 2 * nl, 8 * (size_t)nl)) return false;
+    h_powmod_u64(hf, t, g, (uint64_t)(n - 1));
+    if (memcmp(t, domain + (n - 1) * nl, 8 * (size_t)nl)) return false;
   }
   *N_out = N;
   return true;
+}
+template <class P>
+__global__ __launch_bounds__(256) void k_prefix_check(const u32* __restrict__ domain, size_t n, u32* __restrict__ flag) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fe<P> g = fe_reduce<P>(fe_to_mont<P>(pl_load<P>(domain, 1)));
+  Fe<P> one = fe_zero<P>();
+  one.l[0] = 1;
+  const Fe<P> want = fe_reduce<P>(FeAsm<P>::mul(fe_reduce<P>(fe_pow_u64<P>(g, (u64)i)), one));      // g^i, plain and canonical
+  const Fe<P> have = pl_load<P>(domain, i);
+  u32 diff = 0;
+#pragma unroll
+  for (int k = 0; k < P::L; k++) diff |= want.l[k] ^ have.l[k];
+  if (diff) atomicOr(flag, 1u);
+}
+// launches the comparison of the n device-resident points; *d_flag (one word, zeroed here) is non-zero afterwards if the domain is no prefix
+template <class P> static int prefix_check_launch(const void* d_domain, size_t n, u32* d_flag, hipStream_t s) {
+  MZK_HIP(hipMemsetAsync(d_flag, 0, 4, s));
+  hipLaunchKernelGGL((k_prefix_check<P>), dim3(grid256(n)), dim3(256), 0, s, (const u32*)d_domain, n, d_flag);
+  MZK_HIP(hipGetLastError());
+  return MZK_OK;
 }
 // Ainv (m x m, row-major, canonical) of A[t][j] = x_(n+j)^(1+t) by Gauss-Jordan on the host; false if a pivot is missing (cannot
 // happen for distinct non-zero x: every leading minor is a Vandermonde determinant times a product of x's)
@@ -758,6 +789,99 @@ static bool prefix_system_inverse(const HostField* hf, const uint64_t* g, size_t
   out->assign(m * m * nl, 0);
   for (size_t j = 0; j < m; j++) for (size_t t = 0; t < m; t++) memcpy(out->data() + (j * m + t) * nl, at(j, m + t), 8 * nl);
   return true;
+}
+
+// The zerofier of such a prefix (FastStark's transition zerofier, fast_stark.rs:53-57: omicron^i for i < cycles - 1): Z D = X^N - 1 with
+// D = prod_j (X - x_(n+j)) over the m missing points, so the coefficients of Z are minus those of the power series 1 / D, and by partial
+// fractions  z_k = sum_j rho_j w_j^(k+1),  k <= n,  w_j = 1 / x_(n+j),  rho_j = 1 / prod_(l != j) (x_(n+j) - x_(n+l))  (host, m^2 products).
+// One launch: a lane owns ZERO_CHUNK consecutive coefficients, one exponentiation per missing point and lane.  params: m pairs (rho_j, w_j).
+constexpr int ZERO_CHUNK = 8;
+template <class P>
+__global__ __launch_bounds__(256) void k_prefix_zerofier(const u32* __restrict__ params, int m, size_t count, u32* __restrict__ out) {
+  const size_t k0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * ZERO_CHUNK;
+  if (k0 >= count) return;
+  Fe<P> acc[ZERO_CHUNK];
+#pragma unroll
+  for (int c = 0; c < ZERO_CHUNK; c++) acc[c] = fe_zero<P>();
+  for (int j = 0; j < m; j++) {
+    const Fe<P> w = fe_reduce<P>(fe_to_mont<P>(pl_load<P>(params, 2 * (size_t)j + 1)));         // Montgomery form: mul(t, w) is the plain product
+    Fe<P> t = fe_reduce<P>(FeAsm<P>::mul(pl_load<P>(params, 2 * (size_t)j), fe_reduce<P>(fe_pow_u64<P>(w, (u64)k0 + 1))));      // rho_j w_j^(k0+1), plain
+#pragma unroll
+    for (int c = 0; c < ZERO_CHUNK; c++) {
+      acc[c] = pl_add<P>(acc[c], t);
+      t = fe_reduce<P>(FeAsm<P>::mul(t, w));
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < ZERO_CHUNK; c++) if (k0 + c < count) pl_store<P>(out, k0 + c, acc[c]);
+}
+// (rho_j, w_j) for j < m, canonical, interleaved; false if two missing points coincide (cannot happen in a subgroup)
+static bool prefix_zerofier_params(const HostField* hf, const uint64_t* g, size_t n, size_t N, std::vector<uint64_t>* out) {
+  const size_t nl = (size_t)hf->nl, m = N - n;
+  std::vector<uint64_t> x(m * 4, 0);
+  for (size_t j = 0; j < m; j++) h_powmod_u64(hf, x.data() + 4 * j, g, (uint64_t)(n + j));
+  out->assign(2 * m * nl, 0);
+  for (size_t j = 0; j < m; j++) {
+    uint64_t prod[4] = {1, 0, 0, 0}, d[4] = {0, 0, 0, 0}, inv[4] = {0, 0, 0, 0}, w[4] = {0, 0, 0, 0};
+    for (size_t l = 0; l < m; l++) {
+      if (l == j) continue;
+      hp_sub(hf, d, x.data() + 4 * j, x.data() + 4 * l);
+      bool zero = true;
+      for (size_t k = 0; k < nl; k++) zero = zero && d[k] == 0;
+      if (zero) return false;
+      h_mulmod(hf, prod, prod, d);
+    }
+    h_invmod(hf, inv, prod);
+    h_powmod_u64(hf, w, g, (uint64_t)(N - (n + j)));           // 1 / x_(n+j) = g^(N - n - j)
+    memcpy(out->data() + (2 * j) * nl, inv, 8 * nl);
+    memcpy(out->data() + (2 * j + 1) * nl, w, 8 * nl);
+  }
+  return true;
+}
+
+template <class P>
+static int zerofier_of_prefix(int fid, const uint64_t* domain, size_t n, size_t len, uint64_t* out, hipStream_t s, bool* done) {
+  const HostField* hf = host_field(fid);
+  const size_t nl = (size_t)hf->nl, esz = field_bytes(fid);
+  size_t N = 0;
+  *done = false;
+  if (!prefix_candidate(hf, domain, n, &N)) return MZK_OK;
+  const size_t m = N - n;
+  std::vector<uint64_t> params;
+  if (m && !prefix_zerofier_params(hf, domain + nl, n, N, &params)) return MZK_OK;
+  // every point is compared on the device; the coefficients are computed behind the comparison without waiting for its answer and
+  // thrown away if it says no (one synchronize for both)
+  DevBuf d_dom, d_flag, d_params, d_z;
+  u32 flag = 1;
+  MZK_TRY(d_dom.alloc(n * esz)); MZK_TRY(d_flag.alloc(4));
+  std::vector<uint64_t> z;
+  struct Settle {            // an error return below must not leave copies in flight that read or write this frame's vectors
+    hipStream_t s; bool armed;
+    ~Settle() { if (armed) (void)hipStreamSynchronize(s); }
+  } settle{s, true};
+  MZK_HIP(hipMemcpyAsync(d_dom.p, domain, n * esz, hipMemcpyHostToDevice, s));
+  MZK_TRY(prefix_check_launch<P>(d_dom.p, n, (u32*)d_flag.p, s));
+  if (m) {
+    MZK_TRY(d_params.alloc(2 * m * esz)); MZK_TRY(d_z.alloc((n + 1) * esz));
+    MZK_HIP(hipMemcpyAsync(d_params.p, params.data(), 2 * m * esz, hipMemcpyHostToDevice, s));
+    const size_t lanes = (n + 1 + ZERO_CHUNK - 1) / ZERO_CHUNK;
+    hipLaunchKernelGGL((k_prefix_zerofier<P>), dim3(grid256(lanes)), dim3(256), 0, s, (const u32*)d_params.p, (int)m, n + 1, d_z.w());
+    MZK_HIP(hipGetLastError());
+    z.resize((n + 1) * nl);
+    MZK_HIP(hipMemcpyAsync(z.data(), d_z.p, (n + 1) * esz, hipMemcpyDeviceToHost, s));
+  }
+  MZK_TRY(d2h_sync(&flag, d_flag.p, 4, s));                   // (`params`, `z` and the caller's domain are in flight until here)
+  settle.armed = false;
+  if (flag) return MZK_OK;                                    // not a prefix after all: the caller runs the tree
+  memset(out, 0, len * esz);
+  if (m == 0) {                                               // the whole subgroup: X^N - 1
+    uint64_t one[4] = {1, 0, 0, 0}, zero[4] = {0, 0, 0, 0}, neg[4] = {0, 0, 0, 0};
+    hp_sub(hf, neg, zero, one);
+    memcpy(out, neg, 8 * nl);
+    out[N * nl] = 1;
+  } else memcpy(out, z.data(), (n + 1) * esz);
+  *done = true;
+  return MZK_OK;
 }
 
 // ---- interpolation plans: what fast_interpolate derives from the domain alone ------------------------------------------------------
@@ -842,10 +966,17 @@ static int interp_plan_get(int fid, const uint64_t* domain, size_t n, const uint
   if (rc == MZK_OK) rc = pl->d_dom.alloc(n * esz);
   if (rc == MZK_OK && hipMemcpyAsync(pl->d_dom.p, domain, n * esz, hipMemcpyHostToDevice, s) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipMemcpyAsync", __FILE__, __LINE__);
   std::vector<uint64_t> ainv;
-  if (rc == MZK_OK && prefix_of_subgroup(hf, domain, n, &pl->pN)) {
-    pl->pm = pl->pN - n;
-    memcpy(pl->g, domain + nl, 8 * nl);
-    pl->prefix = pl->pm == 0 || prefix_system_inverse(hf, pl->g, n, pl->pm, &ainv);
+  if (rc == MZK_OK && prefix_candidate(hf, domain, n, &pl->pN)) {
+    DevBuf d_flag;
+    u32 flag = 1;
+    rc = d_flag.alloc(4);
+    if (rc == MZK_OK) rc = prefix_check_launch<P>(pl->d_dom.p, n, (u32*)d_flag.p, s);
+    if (rc == MZK_OK) rc = d2h_sync(&flag, d_flag.p, 4, s);
+    if (rc == MZK_OK && flag == 0) {
+      pl->pm = pl->pN - n;
+      memcpy(pl->g, domain + nl, 8 * nl);
+      pl->prefix = pl->pm == 0 || prefix_system_inverse(hf, pl->g, n, pl->pm, &ainv);
+    }
   }
   if (rc == MZK_OK && pl->prefix && pl->pm) {
     const size_t m = pl->pm;

@@ -269,6 +269,12 @@ def test_interpolation_over_a_prefix_of_a_subgroup_equals_the_oracle(mz, fid, lg
     for k in range(4):
         got = mz.fast_interpolate(fid, dom, vals[k], om, 1 << lg)
         assert got.shape == want[k].shape and np.array_equal(got, want[k]), k
+    # the zerofier of the same prefix (fast_stark.rs:53-57 builds its transition zerofier over omicron^i, i < cycles - 1): minus the power
+    # series of 1 / prod (X - missing point), one launch; the root only feeds the reference's assertions (order 2^(lg+1): n + 1 coefficients fit)
+    big = orc.root_of(fid, lg + 1)
+    rc, zw = orc.fast_zerofier_ref(fid, dom, big, 2 << lg)
+    zg = mz.fast_zerofier(fid, dom, big, 2 << lg)
+    assert rc == 0 and zg.shape == zw.shape and np.array_equal(zg, zw)
     got = mz.fast_interpolate_batch(fid, dom, vals, om, 1 << lg)
     assert all(g.shape == w.shape and np.array_equal(g, w) for g, w in zip(got, want))
     d_v = torch.from_numpy(vals.view(np.int64).reshape(-1).copy()).cuda()
@@ -293,6 +299,8 @@ def test_domains_that_only_look_like_a_subgroup_prefix_take_the_tree(mz, fid):
     for step, d in enumerate((d_last, d_first, d_big, d_swap, dom)):
         vals = orc.synth_vector(fid, 8300 + step, n)
         root = orc.root_of(fid, lg + 1)
+        rc, zw = orc.fast_zerofier_ref(fid, d, root, 1 << (lg + 1))
+        assert rc == 0 and np.array_equal(mz.fast_zerofier(fid, d, root, 1 << (lg + 1)), zw), step
         rc, want = orc.fast_interpolate_ref(fid, d, vals, root, 1 << (lg + 1))
         assert rc == 0
         got = mz.fast_interpolate(fid, d, vals, root, 1 << (lg + 1))
@@ -316,6 +324,12 @@ def test_trace_sized_prefix_interpolation_by_its_defining_property(mz, fid, lg, 
         full = np.zeros((1 << lg, nl), dtype=np.uint64)
         full[:got[r].shape[0]] = got[r]
         assert np.array_equal(mz.ntt(fid, om, full)[:n], vals[r]), r
+    # the transition zerofier over the first cycles - 1 points: monic of that degree, zero on exactly those points of the subgroup
+    big = orc.root_of(fid, lg + 1)
+    z = mz.fast_zerofier(fid, dom[:n - 1], big, 2 << lg)
+    assert z.shape[0] == 1 << lg and orc.from_limbs(z[n - 1:n])[0] == 1 and not z[n:].any()
+    zv = mz.ntt(fid, om, np.ascontiguousarray(z))
+    assert not zv[:n - 1].any() and all(zv[i].any() for i in range(n - 1, 1 << lg))
 
 
 def test_prefix_interpolation_of_more_registers_than_one_launch_takes(mz):

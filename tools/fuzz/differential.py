@@ -202,6 +202,8 @@ def case_poly():
     lgr = max(4, (2 * n).bit_length() + 1)
     root, order = orc.root_of(fid, lgr), 1 << lgr
     vals = vec(fid, n)
+    rc, want = orc.fast_zerofier_ref(fid, dom, root, order)
+    check("fast_zerofier", rc == 0 and np.array_equal(mz.fast_zerofier(fid, dom, root, order), want), (fid, n))
     rc, want = orc.fast_interpolate_ref(fid, dom, vals, root, order)
     check("fast_interpolate", rc == 0 and np.array_equal(mz.fast_interpolate(fid, dom, vals, root, order), want), (fid, n))
     import torch
