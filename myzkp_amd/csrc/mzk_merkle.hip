@@ -21,7 +21,7 @@ template <int R> __device__ __forceinline__ u64 rotl64(u64 x) {
   if constexpr (R == 0) return x;
   else return (x << R) | (x >> (64 - R));
 }
-__constant__ u64 KECCAK_RC[24] = {
+__constant__ u64 KECCAK_RC[32] = {      // 24 round constants (+ 8 pad words: keccak_f_pair fetches one round ahead)
     0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
     0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
     0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
@@ -113,10 +113,14 @@ __device__ __forceinline__ void keccak_f_pair(u32 (&a)[25], int parity) {
   // One scheduled asm block per round (mzk_keccak_asm.h, generated): hipcc emitted the round word by word -- xor, s_nop 1,
   // v_mov_b32_dpp, s_nop 0, v_alignbit: 49 wait-state instructions per round, 7.6 cycles per instruction on the lone wave of a
   // tree's upper levels; batched (all xors, all lane exchanges, all funnel shifts) every hazard distance is covered by independent work.
+  // the round constant of round r + 1 is fetched while round r runs: loaded at the top of the round it belongs to, the scalar load and
+  // its wait (~100 cycles on the lone wave of a tree's upper levels, a fifth of the round) sat in front of every round
+  u64 rc = KECCAK_RC[0];
 #pragma unroll 1
   for (int rnd = 0; rnd < 24; rnd++) {
-    const u64 rc = KECCAK_RC[rnd];
+    const u64 nxt = KECCAK_RC[(rnd + 1) & 31];          // (the table has 32 entries: the last fetch reads a pad word)
     keccak_round_pair_asm(a, parity ? (u32)(rc >> 32) : (u32)rc);
+    rc = nxt;
   }
   return;
 #endif
