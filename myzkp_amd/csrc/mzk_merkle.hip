@@ -115,6 +115,24 @@ __device__ __forceinline__ void keccak_f_pair(u32 (&a)[25], int parity) {
   // tree's upper levels; batched (all xors, all lane exchanges, all funnel shifts) every hazard distance is covered by independent work.
   // the round constant of round r + 1 is fetched while round r runs: loaded at the top of the round it belongs to, the scalar load and
   // its wait (~100 cycles on the lone wave of a tree's upper levels, a fifth of the round) sat in front of every round
+  // Where the round constant comes from (same-box A/B, profiles/round6_keccak_round_constant_ab.txt; FRI round at 2^14 / Merkle commit of 2^16 leaves):
+  //   0  `KECCAK_RC[rnd]` inside its round: s_getpc + address arithmetic + s_load_dwordx2 + s_waitcnt in front of EVERY round of the lone wave
+  //      of a tree's upper levels -- a fifth of the round                                                             114 - 116 us / 0.153 ms
+  //   1  the constant of round r + 1 fetched while round r runs (the wait finds it there)                           106 - 108 us / 0.147 ms
+  //   2  all 24 rounds unrolled, the constants literals of the instruction stream (49 KB of code in k_merkle_tail)  104 - 105 us / 0.139 ms
+#ifndef MZK_KECCAK_RC_AHEAD
+#define MZK_KECCAK_RC_AHEAD 2
+#endif
+#if MZK_KECCAK_RC_AHEAD == 2
+  // all 24 rounds unrolled, the constants literals of the instruction stream: no scalar load, no address arithmetic per round
+  constexpr u64 K[24] = {
+      0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL, 0x0000000080000001ULL,
+      0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+      0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL,
+      0x000000000000800aULL, 0x800000008000000aULL, 0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+#pragma unroll
+  for (int rnd = 0; rnd < 24; rnd++) keccak_round_pair_asm(a, parity ? (u32)(K[rnd] >> 32) : (u32)K[rnd]);
+#elif MZK_KECCAK_RC_AHEAD
   u64 rc = KECCAK_RC[0];
 #pragma unroll 1
   for (int rnd = 0; rnd < 24; rnd++) {
@@ -122,6 +140,13 @@ __device__ __forceinline__ void keccak_f_pair(u32 (&a)[25], int parity) {
     keccak_round_pair_asm(a, parity ? (u32)(rc >> 32) : (u32)rc);
     rc = nxt;
   }
+#else
+#pragma unroll 1
+  for (int rnd = 0; rnd < 24; rnd++) {
+    const u64 rc = KECCAK_RC[rnd];
+    keccak_round_pair_asm(a, parity ? (u32)(rc >> 32) : (u32)rc);
+  }
+#endif
   return;
 #endif
 #pragma unroll 1
