@@ -9,6 +9,7 @@
 // Work shape: n/2 + n/4 + ... one-block Keccak-f[1600] permutations (each message fits the 136-byte rate), pure
 // 64-bit logic ops -- ALU-bound, ~5k VALU ops per hash; algorithmic HBM traffic is S*n bytes in, 32*(n-1) out.
 #include <algorithm>
+#include <atomic>
 #include "mzk_common.h"
 #include "mzk_keccak_asm.h"
 
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(64 << LV) void k_merkle_level_pair_multi(const u64*
 }
 // the last levels (<= TAIL_NODES nodes each) in one workgroup: no launch per level; one lane pair per hash
 constexpr int TAIL_NODES = 512;
-__global__ __launch_bounds__(TAIL_NODES) void k_merkle_tail(u64* __restrict__ level, size_t count, size_t stop) {
+__global__ __launch_bounds__(TAIL_NODES) void k_merkle_tail(u64* __restrict__ level, size_t count, size_t stop, u32* __restrict__ mailbox, u32 seq) {
   // `level` holds `count` nodes; the levels above follow contiguously (count/2, count/4, ... stop); stop = 1 for one tree,
   // the number of trees for a batch (their roots are the last level).
   // The digests travel from level to level through LDS (ping-pong): every level is one dependent hash on an almost empty CU, and
@@ -442,6 +443,14 @@ __global__ __launch_bounds__(TAIL_NODES) void k_merkle_tail(u64* __restrict__ le
     below = above;
     count = up;
     cur ^= 1;
+  }
+  // one tree whose root the host is waiting for (a FRI round's transcript, Merkle::commit): the root goes straight into the caller's mapped
+  // host buffer, then a fence, then the sequence number the host spins on -- no copy engine, no stream synchronize (merkle_root_to_host)
+  if (mailbox != nullptr && tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) __builtin_nontemporal_store(sh[cur][i], mailbox + i);
+    __threadfence_system();
+    __hip_atomic_store(mailbox + 8, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 // authentication path: node (index >> l) ^ 1 of level l, l = 1 .. depth-1; level l starts at node n - n / 2^(l-1)
@@ -549,8 +558,10 @@ struct MerkleScope {
 // `trees` > 1: n = trees * (leaves per tree), all trees of one power-of-two size, leaves back to back.  Level l of the whole
 // array is then level l of every tree side by side (pairs never straddle trees), so a batch is the bottom of one big tree,
 // hashed down to `trees` nodes: the roots, at d_nodes + 4 * (n - 2 * trees).
+// mailbox / seq: see merkle_root_to_host; *mailed = the tail ran and will post the root there
 static int merkle_hash_levels(int kind, int fid, const void* d_leaves, const u64* d_off, size_t n, u64* d_nodes, hipStream_t s,
-                              const u8* d_neg = nullptr, size_t trees = 1) {
+                              const u8* d_neg = nullptr, size_t trees = 1, u32* mailbox = nullptr, u32 seq = 0, bool* mailed = nullptr) {
+  if (mailed) *mailed = false;
   if (n < 2) return MZK_OK;
   ProfScope ps(s, MZK_PH_MERKLE);
   const size_t pairs = n / 2;
@@ -584,9 +595,43 @@ static int merkle_hash_levels(int kind, int fid, const void* d_leaves, const u64
     below = above;
     count /= 2;
   }
-  if (count > trees) hipLaunchKernelGGL(k_merkle_tail, dim3(1), dim3(TAIL_NODES), 0, s, below, count, trees);
+  if (count > trees) {
+    const bool mail = mailbox != nullptr && trees == 1;
+    hipLaunchKernelGGL(k_merkle_tail, dim3(1), dim3(TAIL_NODES), 0, s, below, count, trees, mail ? mailbox : (u32*)nullptr, seq);
+    if (mail && mailed) *mailed = true;
+  }
   MZK_HIP(hipGetLastError());
   return MZK_OK;
+}
+// The root of ONE tree to the host.  The copy engine and the stream synchronize behind it cost ~15 us per FRI round; the tail kernel instead
+// writes the 32 bytes and a sequence number into the context's pinned landing zone (mapped into the device's address space) and the host spins on
+// the number.  Stream errors still surface: every 1024 spins the stream is queried, and when it has drained without the number showing up
+// (or the tail was not part of this tree: two leaves) the root is fetched the ordinary way.  The stream is NOT synchronized on return.
+struct RootMailbox { u32* p; u32 seq; };
+static u32 g_mailbox_seq[MZK_MAX_CTX];        // per context: the number of the last root a tail kernel was asked to post
+static int merkle_mailbox(RootMailbox* mb) {
+  Context& c = ctx();
+  if (!c.bounce) MZK_HIP(hipHostMalloc(&c.bounce, SMALL_D2H_MAX, hipHostMallocPortable));
+  static const int enabled = tune_int("MZK_ROOT_MAILBOX", 1);     // tuning build: 0 = copy + synchronize (A/B)
+  mb->p = enabled ? (u32*)c.bounce + 512 : nullptr;                 // the second half of the landing zone: d2h_sync uses the first bytes
+  mb->seq = ++g_mailbox_seq[c.index];
+  if (mb->seq == 0) mb->seq = ++g_mailbox_seq[c.index];
+  if (mb->p) ((volatile u32*)mb->p)[8] = 0;                         // (a larger d2h_sync may have run over this half since the last root)
+  return MZK_OK;
+}
+static int merkle_root_to_host(uint8_t* root, const u64* d_root, const RootMailbox& mb, bool mailed, hipStream_t s) {
+  if (mailed && mb.p) {
+    volatile u32* flag = mb.p + 8;
+    for (unsigned spins = 1;; spins++) {
+      if (*flag == mb.seq) { std::atomic_thread_fence(std::memory_order_acquire); memcpy(root, (const void*)mb.p, 32); return MZK_OK; }
+      if ((spins & 1023) == 0) {
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess) { if (*flag == mb.seq) continue; break; }       // drained: the number is there or never comes
+        if (q != hipErrorNotReady) return hip_fail(q, "hipStreamQuery", __FILE__, __LINE__);
+      }
+    }
+  }
+  return d2h_sync(root, d_root, 32, s);
 }
 
 // bincode(FiniteFieldElement) of ONE canonical element on the host: used for the n == 1 root and for the
@@ -1061,8 +1106,11 @@ int mzk_merkle_commit_field_dev(int field_id, const void* d_elems, size_t n, uin
   if (cap < 32) { set_error("merkle: root buffer too small"); return MZK_E_LENGTH; }
   u64* d_nodes;
   MZK_TRY(ws_get(WS_MERKLE_NODES, (n - 1) * 32, (void**)&d_nodes));
-  MZK_TRY(merkle_hash_levels(0, field_id, d_elems, nullptr, n, d_nodes, s));
-  MZK_TRY(d2h_sync(root, d_nodes + 4 * (n - 2), 32, s));
+  RootMailbox mb;
+  bool mailed = false;
+  MZK_TRY(merkle_mailbox(&mb));
+  MZK_TRY(merkle_hash_levels(0, field_id, d_elems, nullptr, n, d_nodes, s, nullptr, 1, mb.p, mb.seq, &mailed));
+  MZK_TRY(merkle_root_to_host(root, d_nodes + 4 * (n - 2), mb, mailed, s));
   *root_len = 32;
   return MZK_OK;
 }
@@ -1201,7 +1249,10 @@ static int fri_commit_rounds(int field_id, const uint64_t* codeword, const uint8
       MZK_TRY(d2h_sync(limbs, cur, esz, s));
       root_len[r] = host_bincode_field(limbs, nl, root, r == 0 && negative && negative[0]);
     } else {
-      MZK_TRY(merkle_hash_levels(0, field_id, cur, nullptr, len, d_nodes, s, r == 0 ? d_neg : nullptr));
+      RootMailbox mb;
+      bool mailed = false;
+      MZK_TRY(merkle_mailbox(&mb));
+      MZK_TRY(merkle_hash_levels(0, field_id, cur, nullptr, len, d_nodes, s, r == 0 ? d_neg : nullptr, 1, mb.p, mb.seq, &mailed));
       if (trees_out) {      // keep this round's tree: its leaves and digests stay where they were computed, in the shared block
         mzk_merkle* t = new mzk_merkle();
         t->kind = 0; t->field = field_id; t->n = len; t->stream = s;
@@ -1221,7 +1272,7 @@ static int fri_commit_rounds(int field_id, const uint64_t* codeword, const uint8
         }
         MZK_TRY(merkle_stamp(t, s, true));
       }
-      MZK_TRY(d2h_sync(root, d_nodes + 4 * (len - 2), 32, s));      // the transcript needs the root now (through the pinned landing zone: d2h_sync)
+      MZK_TRY(merkle_root_to_host(root, d_nodes + 4 * (len - 2), mb, mailed, s));      // the transcript needs the root now
       root_len[r] = 32;
     }
     if (r == 0 && d_neg) {      // from here on the codeword is its canonical representative: v -> p - |v| where Sign::Minus
