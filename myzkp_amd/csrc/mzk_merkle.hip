@@ -256,6 +256,72 @@ __global__ __launch_bounds__(LEAF_THREADS) void k_merkle_leaf_pairs(const u32* _
   o2[1] = make_ulonglong2(a[2], a[3]);
 }
 
+// The same level by lane PAIRS, for trees whose leaf level is itself latency-bound (a FRI round's codeword: at most 2^15 pairs are one
+// wave per SIMD at two lanes each): lane e of a pair serialises element e of its message -- the odd lane starts behind the even lane's
+// element, whose digit count it recounts --, the halves of the 17 rate words come back from LDS and the permutation is the lane-pair one
+// (~127 instructions per round and lane instead of 190).  Same bytes, same digests as k_merkle_leaf_pairs.
+constexpr size_t LEAF_PAIR_MAX = (size_t)1 << 15;      // pairs
+template <int NW>
+__global__ __launch_bounds__(LEAF_THREADS) void k_merkle_leaf_pairs_lp(const u32* __restrict__ elems, size_t pairs, u64* __restrict__ nodes,
+                                                                        const u8* __restrict__ neg) {
+  __shared__ u32 blk[SHA3_RATE / 4][LEAF_THREADS / 2];
+  const int tid = threadIdx.x, col = tid >> 1, parity = tid & 1;
+  const size_t i = (size_t)blockIdx.x * (LEAF_THREADS / 2) + col;
+  const bool live = i < pairs;                    // pair-uniform; every lane reaches the barriers
+#pragma unroll
+  for (int w = parity; w < SHA3_RATE / 4; w += 2) blk[w][col] = 0;
+  __syncthreads();
+  if (live) {
+    auto put = [&](int pos, u32 byte) { atomicOr(&blk[pos >> 2][col], (byte & 255u) << (8 * (pos & 3))); };     // the two lanes may meet in one word
+    u32 w0[NW], w[NW];
+    {
+      const uint4* p4 = reinterpret_cast<const uint4*>(elems + (2 * i) * NW);
+#pragma unroll
+      for (int q = 0; q < NW / 4; q++) { uint4 v = p4[q]; w0[4 * q] = v.x; w0[4 * q + 1] = v.y; w0[4 * q + 2] = v.z; w0[4 * q + 3] = v.w; }
+    }
+    int k0 = 0;
+#pragma unroll
+    for (int j = 0; j < NW; j++) if (w0[j]) k0 = j + 1;
+    if (parity) {
+      const uint4* p4 = reinterpret_cast<const uint4*>(elems + (2 * i + 1) * NW);
+#pragma unroll
+      for (int q = 0; q < NW / 4; q++) { uint4 v = p4[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NW; j++) w[j] = w0[j];
+    }
+    int k = 0;
+#pragma unroll
+    for (int j = 0; j < NW; j++) if (w[j]) k = j + 1;
+    int pos = parity ? 9 + 4 * k0 : 0;
+    put(pos, k ? ((neg && neg[2 * i + parity]) ? 0xffu : 1u) : 0u);
+    put(pos + 1, (u32)k);
+    pos += 9;
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+      if (j < k) {
+        put(pos, w[j] & 255u); put(pos + 1, (w[j] >> 8) & 255u); put(pos + 2, (w[j] >> 16) & 255u); put(pos + 3, w[j] >> 24);
+        pos += 4;
+      }
+    }
+    if (parity) {
+      put(pos, 0x06u);
+      put(SHA3_RATE - 1, 0x80u);
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  u32 a[25];
+#pragma unroll
+  for (int l = 0; l < SHA3_RATE / 8; l++) a[l] = blk[2 * l + parity][col];
+#pragma unroll
+  for (int l = SHA3_RATE / 8; l < 25; l++) a[l] = 0;
+  keccak_f_pair(a, parity);
+  u32* o32 = reinterpret_cast<u32*>(nodes + 4 * i);
+#pragma unroll
+  for (int l = 0; l < 4; l++) o32[2 * l + parity] = a[l];
+}
+
 // ---- level 1 from arbitrary byte leaves: leaf 2i || leaf 2i+1 is the contiguous range off[2i] .. off[2i+2) ---
 __global__ __launch_bounds__(128) void k_merkle_leaf_pairs_bytes(const u8* __restrict__ leaves, const u64* __restrict__ off, size_t pairs,
                                                                  u64* __restrict__ nodes) {
@@ -568,10 +634,18 @@ static int merkle_hash_levels(int kind, int fid, const void* d_leaves, const u64
   const unsigned blocks = (unsigned)((pairs + 127) / 128);
   if (kind == 1)
     hipLaunchKernelGGL(k_merkle_leaf_pairs_bytes, dim3(blocks), dim3(128), 0, s, (const u8*)d_leaves, d_off, pairs, d_nodes);
-  else if (fid == MZK_FIELD_M128)
-    hipLaunchKernelGGL((k_merkle_leaf_pairs<4>), dim3(blocks), dim3(LEAF_THREADS), 0, s, (const u32*)d_leaves, pairs, d_nodes, d_neg);
-  else
-    hipLaunchKernelGGL((k_merkle_leaf_pairs<8>), dim3(blocks), dim3(LEAF_THREADS), 0, s, (const u32*)d_leaves, pairs, d_nodes, d_neg);
+  else {
+    static const int lp_on = tune_int("MZK_LEAF_LANE_PAIRS", 1);      // tuning build: 0 = one lane per leaf pair at every size (A/B)
+    const bool lp = lp_on && pairs <= LEAF_PAIR_MAX;
+    const unsigned lpb = (unsigned)((pairs + LEAF_THREADS / 2 - 1) / (LEAF_THREADS / 2));
+    if (fid == MZK_FIELD_M128) {
+      if (lp) hipLaunchKernelGGL((k_merkle_leaf_pairs_lp<4>), dim3(lpb), dim3(LEAF_THREADS), 0, s, (const u32*)d_leaves, pairs, d_nodes, d_neg);
+      else hipLaunchKernelGGL((k_merkle_leaf_pairs<4>), dim3(blocks), dim3(LEAF_THREADS), 0, s, (const u32*)d_leaves, pairs, d_nodes, d_neg);
+    } else {
+      if (lp) hipLaunchKernelGGL((k_merkle_leaf_pairs_lp<8>), dim3(lpb), dim3(LEAF_THREADS), 0, s, (const u32*)d_leaves, pairs, d_nodes, d_neg);
+      else hipLaunchKernelGGL((k_merkle_leaf_pairs<8>), dim3(blocks), dim3(LEAF_THREADS), 0, s, (const u32*)d_leaves, pairs, d_nodes, d_neg);
+    }
+  }
   u64* below = d_nodes;
   size_t count = pairs;
   while (count > (size_t)TAIL_NODES && count > trees) {
