@@ -592,8 +592,9 @@ namespace mzk {
 static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 
 // end of a successful build on stream s of the current context
-// complete_on_return: the caller synchronizes the stream before it hands the tree out (every round of mzk_fri_commit does, for the
-// transcript), so there is nothing to order later calls behind: no event (one marker packet per round less between the kernels)
+// complete_on_return: the caller synchronizes the stream before it hands the tree out (mzk_fri_commit does once, after its last round --
+// since round 6 a round's root reaches the transcript through the mailbox without a synchronize; an error return frees the trees, and
+// hipFree waits for the device), so there is nothing to order later calls behind: no event (one marker packet per round less)
 static int merkle_stamp(mzk_merkle* t, hipStream_t s, bool complete_on_return = false) {
   t->ctx_index = ctx().index;
   t->device = ctx().device;
